@@ -1,0 +1,154 @@
+/*
+ * gpso_hip.h -- C-ABI of libgpso_hip.so: the MI355X (gfx950) GP-surrogate + leaf-UCB engine.
+ *
+ * The reference (jajcayn/pygpso v0.6.1) is pure Python and has NO native interface: its numerics
+ * are GPflow/TensorFlow calls.  Every entry point below therefore cites the reference call site
+ * it replaces (paths relative to the reference repo) instead of an existing FFI symbol.  The
+ * Python binding a maintainer adds is the ctypes stub in INTEGRATION.md (shipped as
+ * pygpso_amd/_lib.py).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all host matrices are C-contiguous row-major float64;
+ *   - every call returns GPSO_OK (0) or a negative GPSO_E_* code; the message is available from
+ *     gpso_last_error(ctx) (ctx == NULL: the message of the last failed gpso_create on this thread);
+ *   - the library owns its device memory; the caller owns every buffer it passes in;
+ *   - calls are synchronous at the boundary: host outputs are valid on return;
+ *   - a context is bound to one device and one HIP stream, is NOT thread-safe and NOT fork-safe
+ *     (the reference drives this path from a single Python thread, gpso/optimisation.py:594-622);
+ *   - "mem" arguments say where a caller buffer lives: GPSO_MEM_HOST or GPSO_MEM_DEVICE
+ *     (a device pointer valid on the context's device, e.g. torch.Tensor.data_ptr()).
+ */
+#ifndef GPSO_HIP_H
+#define GPSO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gpso_ctx gpso_ctx;
+
+/* status codes */
+#define GPSO_OK 0
+#define GPSO_E_ARG (-1)   /* bad argument / shape                                             */
+#define GPSO_E_HIP (-2)   /* a HIP runtime call failed                                        */
+#define GPSO_E_NOTPD (-3) /* K + noise*I not positive definite (message names the pivot);     */
+                          /* the reference lets TF's InvalidArgumentError escape here         */
+#define GPSO_E_OOM (-4)   /* device allocation failed                                         */
+#define GPSO_E_STATE (-5) /* call order: no training data / no posterior resident yet         */
+#define GPSO_E_RCCL (-6)  /* reserved for the multi-GPU group calls                           */
+
+/* arithmetic type of a context (what the kernels compute in) */
+#define GPSO_F64 0
+#define GPSO_F32 1
+
+/* stationary kernels, [gpflow.kernels]: the objects passed as gp_kernel at gpso/gp_surrogate.py:393-434 */
+#define GPSO_MATERN52 0 /* default, gpso/gp_surrogate.py:424 */
+#define GPSO_MATERN32 1
+#define GPSO_MATERN12 2
+#define GPSO_SQEXP 3 /* SquaredExponential / RBF */
+
+#define GPSO_MEM_HOST 0
+#define GPSO_MEM_DEVICE 1
+
+/* which device-resident matrix / vector the debug getters copy out (as float64) */
+#define GPSO_MAT_CHOL 0  /* L, lower Cholesky factor of K + noise*I (upper triangle returned as 0) */
+#define GPSO_MAT_LINV 1  /* L^-1 (lower)                                                        */
+#define GPSO_MAT_KINV 2  /* (K + noise*I)^-1, valid after a gpso_fit_eval with grad != NULL      */
+#define GPSO_MAT_GRAM 3  /* K + noise*I as assembled (only valid before factorisation: debug)    */
+#define GPSO_VEC_ALPHA 0 /* alpha = (K + noise*I)^-1 (y - c)                                     */
+#define GPSO_VEC_WHITE 1 /* a = L^-1 (y - c)                                                     */
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+
+/* Replaces: constructing gpflow.models.GPR (gpso/gp_surrogate.py:488-495) -- the model object
+ * that owns data, hyper-parameters and cached factorisation.  dtype: GPSO_F64 | GPSO_F32. */
+int gpso_create(gpso_ctx** out, int device, int dtype);
+void gpso_destroy(gpso_ctx* ctx);
+const char* gpso_last_error(const gpso_ctx* ctx);
+
+/* Run all work on an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) instead
+ * of the context's own stream; NULL restores the private stream. */
+int gpso_set_stream(gpso_ctx* ctx, void* hip_stream);
+int gpso_synchronize(gpso_ctx* ctx);
+
+/* ---- fit (GPSurrogate.gp_update -> GPRSurrogate._gp_train) --------------------------------- */
+
+/* Replaces: GPSurrogate.current_training_data hand-off + `model.data = (x, y)`
+ * (gpso/gp_surrogate.py:232-244, :498).  X[N*D], y[N] float64 host. */
+int gpso_set_data(gpso_ctx* ctx, const double* X, const double* y, int64_t n, int d);
+
+/* Replaces: ONE evaluation of gpflow GPR.training_loss (+ its reverse-mode gradient) inside
+ * optimiser.minimize (gpso/gp_surrogate.py:500-503).  Hyper-parameters are the CONSTRAINED values:
+ * lengthscales[n_ls] (n_ls = 1 isotropic, or = D for ARD), kernel variance, noise variance,
+ * constant mean.  Outputs: *nlml = 1/2 |L^-1(y-c)|^2 + sum log L_ii + N/2 log 2pi;
+ * grad (nullable) = d nlml / d (lengthscales..., variance, noise, mean_c), n_ls + 3 values.
+ * Leaves L, L^-1, alpha resident (the posterior is predict-ready afterwards). */
+int gpso_fit_eval(gpso_ctx* ctx, int kernel, const double* lengthscales, int n_ls, double variance,
+                  double noise, double mean_c, double* nlml, double* grad);
+
+/* Interop / debug: install a posterior computed elsewhere (host float64: X[N*D], L[N*N] row-major
+ * lower, alpha[N]) -- the device still derives L^-1 and its tile packing itself.  Mirrors loading
+ * saved GPflow parameters into a placeholder model (gpso/gp_surrogate.py:463-473). */
+int gpso_set_posterior(gpso_ctx* ctx, const double* X, const double* L, const double* alpha,
+                       int64_t n, int d, int kernel, const double* lengthscales, int n_ls,
+                       double variance, double noise, double mean_c);
+
+/* ---- predict (gpflow_model.predict_y users) ----------------------------------------------- */
+
+/* Replaces: gpflow_model.predict_y(coords) at gpso/gp_surrogate.py:298 (gp_predict) and
+ * gpso/plotting.py:351-353.  Xs[M*D] in xs_dtype (GPSO_F64|GPSO_F32) living in xs_mem;
+ * mean[M], var[M] float64 living in out_mem; var INCLUDES the noise variance. */
+int gpso_predict(gpso_ctx* ctx, const void* xs, int xs_dtype, int xs_mem, int64_t m, double* mean,
+                 double* var, int out_mem);
+
+/* Replaces: GPSurrogate.gp_eval_best_ucb (gpso/gp_surrogate.py:313-328): predict_y, then
+ * ucb = mean + varsigma * VAR, then first arg-max -- per segment.  seg_off[nseg+1] (host) delimits
+ * independent leaf batches (NULL with nseg = 1 means one segment [0, M)); outputs (host, nseg each):
+ * idx = winner's row index relative to its segment start, and its mean / var / ucb. */
+int gpso_best_ucb(gpso_ctx* ctx, const void* xs, int xs_dtype, int xs_mem, int64_t m,
+                  const int64_t* seg_off, int nseg, double varsigma, int64_t* idx, double* mean,
+                  double* var, double* ucb);
+
+/* ---- ternary geometry on device (LeafNode.grow, gpso/param_space.py:175-200,257-307) -------- */
+
+/* Centres of levels 0..depth-1 of the ternary subtree under each of nseg boxes, generated on the
+ * device with the reference's float64 recurrence (bit-for-bit), level-major; rows per box =
+ * (3^depth - 1) / 2.  bounds[nseg*D*2] = (lo, hi) per dimension, host float64.
+ * gpso_grow copies the centres out (host float64 [nseg*rows*D]);
+ * gpso_best_ucb_grow scores them without leaving the device: one call = one exploration level
+ * of GPSOptimiser._tree_explore (gpso/optimisation.py:366-403). */
+int64_t gpso_grow_rows(int depth);
+int gpso_grow(gpso_ctx* ctx, const double* bounds, int nseg, int d, int depth, double* out_coords);
+int gpso_best_ucb_grow(gpso_ctx* ctx, const double* bounds, int nseg, int depth, double varsigma,
+                       int64_t* idx, double* mean, double* var, double* ucb);
+
+/* ---- introspection ------------------------------------------------------------------------- */
+
+/* padded problem size the device works with (multiple of 128), 0 before gpso_set_data */
+int64_t gpso_padded_n(const gpso_ctx* ctx);
+int gpso_get_matrix(gpso_ctx* ctx, int which, double* out /* [N*N] host */);
+int gpso_get_vector(gpso_ctx* ctx, int which, double* out /* [N] host */);
+
+/* Device pointers + byte sizes of everything a peer GPU needs to predict (packed L^-1, scaled X,
+ * norms, alpha, hyper-parameter block), for an RCCL broadcast driven from Python
+ * (torch.distributed): fills up to cap entries, returns the count (or a negative status). */
+int gpso_posterior_buffers(gpso_ctx* ctx, void** ptrs, int64_t* nbytes, int cap);
+/* Allocate the same buffers for n, d on a receiving rank so they can be broadcast into. */
+int gpso_alloc_posterior(gpso_ctx* ctx, int64_t n, int d);
+/* After the buffers were filled by a broadcast: mark the posterior resident (reads the
+ * hyper-parameter block back from the device). */
+int gpso_adopt_posterior(gpso_ctx* ctx);
+
+/* last-call device timings in milliseconds measured with HIP events on the context's stream:
+ * what = 0: dominant predict kernel (leaf tiles) of the last predict/best_ucb call,
+ *        1: whole last predict/best_ucb call, 2: whole last gpso_fit_eval call. */
+double gpso_last_ms(gpso_ctx* ctx, int what);
+
+const char* gpso_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPSO_HIP_H */

@@ -1,0 +1,111 @@
+"""
+ctypes binding of ``libgpso_hip.so`` (C-ABI: ``include/gpso_hip.h``).
+
+This is the whole Python<->HIP boundary: plain pointers and sizes, no torch types.  The library
+is built in-tree by ``__graft_entry__.build()`` / ``make -C pygpso_amd/csrc``.  There is NO CPU
+fallback: if the shared library is missing or no HIP device is present, the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgpso_hip.so")
+
+# status codes / enums (mirror include/gpso_hip.h)
+OK, E_ARG, E_HIP, E_NOTPD, E_OOM, E_STATE, E_RCCL = 0, -1, -2, -3, -4, -5, -6
+F64, F32 = 0, 1
+MATERN52, MATERN32, MATERN12, SQEXP = 0, 1, 2, 3
+MEM_HOST, MEM_DEVICE = 0, 1
+MAT_CHOL, MAT_LINV, MAT_KINV, MAT_GRAM = 0, 1, 2, 3
+VEC_ALPHA, VEC_WHITE = 0, 1
+
+KERNEL_IDS = {
+    "Matern52": MATERN52,
+    "Matern32": MATERN32,
+    "Matern12": MATERN12,
+    "Exponential": MATERN12,
+    "SquaredExponential": SQEXP,
+    "RBF": SQEXP,
+}
+
+_c_double_p = C.POINTER(C.c_double)
+_c_int64_p = C.POINTER(C.c_int64)
+
+# every symbol include/gpso_hip.h declares: (restype, argtypes)
+SIGNATURES = {
+    "gpso_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
+    "gpso_destroy": (None, [C.c_void_p]),
+    "gpso_last_error": (C.c_char_p, [C.c_void_p]),
+    "gpso_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gpso_synchronize": (C.c_int, [C.c_void_p]),
+    "gpso_set_data": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, C.c_int64, C.c_int]),
+    "gpso_fit_eval": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, C.c_int, C.c_double, C.c_double,
+                                C.c_double, _c_double_p, _c_double_p]),
+    "gpso_set_posterior": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, _c_double_p, C.c_int64,
+                                     C.c_int, C.c_int, _c_double_p, C.c_int, C.c_double, C.c_double,
+                                     C.c_double]),
+    "gpso_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p,
+                               C.c_void_p, C.c_int]),
+    "gpso_best_ucb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, _c_int64_p,
+                                C.c_int, C.c_double, _c_int64_p, _c_double_p, _c_double_p,
+                                _c_double_p]),
+    "gpso_grow_rows": (C.c_int64, [C.c_int]),
+    "gpso_grow": (C.c_int, [C.c_void_p, _c_double_p, C.c_int, C.c_int, C.c_int, _c_double_p]),
+    "gpso_best_ucb_grow": (C.c_int, [C.c_void_p, _c_double_p, C.c_int, C.c_int, C.c_double,
+                                     _c_int64_p, _c_double_p, _c_double_p, _c_double_p]),
+    "gpso_padded_n": (C.c_int64, [C.c_void_p]),
+    "gpso_get_matrix": (C.c_int, [C.c_void_p, C.c_int, _c_double_p]),
+    "gpso_get_vector": (C.c_int, [C.c_void_p, C.c_int, _c_double_p]),
+    "gpso_posterior_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), _c_int64_p, C.c_int]),
+    "gpso_alloc_posterior": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
+    "gpso_adopt_posterior": (C.c_int, [C.c_void_p]),
+    "gpso_last_ms": (C.c_double, [C.c_void_p, C.c_int]),
+    "gpso_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+class GpsoHipError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libgpso_hip error {code}: {message}")
+        self.code = code
+
+
+def load():
+    """Load libgpso_hip.so (once) and attach prototypes.  Raises if the extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C pygpso_amd/csrc`). "
+            "pygpso_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def as_f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != shape:
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return a
+
+
+def dptr(a):
+    return a.ctypes.data_as(_c_double_p)
+
+
+def i64ptr(a):
+    return a.ctypes.data_as(_c_int64_p)

@@ -1,0 +1,110 @@
+// Shared device-side definitions for libgpso_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gpso {
+
+constexpr int kWave = 64;      // CDNA wavefront
+constexpr int kPadN = 128;     // training size is padded to a multiple of this
+constexpr int kFitBlock = 64;  // panel / tile edge of the factorisation kernels
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// ---- MFMA traits ----------------------------------------------------------------------------
+// Both instructions compute a 16x16 tile D = A[16x4] * B[4x16] + C per wave with
+//   A operand: lane l holds A[i = l & 15][k = l >> 4]
+//   B operand: lane l holds B[k = l >> 4][j = l & 15]
+//   C/D:       4 values per lane, column j = l & 15, row:
+//       f32 (v_mfma_f32_16x16x4_f32):  row = 4 * (l >> 4) + r
+//       f64 (v_mfma_f64_16x16x4_f64):  row = (l >> 4) + 4 * r
+template <typename T>
+struct Mfma;
+
+template <>
+struct Mfma<float> {
+  using vec4 = f32x4;
+  static __device__ __forceinline__ vec4 mma(float a, float b, vec4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  // row of accumulator register r on lane l
+  static __device__ __forceinline__ int crow(int lane, int r) { return 4 * (lane >> 4) + r; }
+  // which A-operand row must carry "logical row m" so that register r of lane l ends up holding
+  // logical row 4 * (l >> 4) + r  (identity for the f32 layout)
+  static __device__ __forceinline__ int arow_for_k4(int m) { return m; }
+};
+
+template <>
+struct Mfma<double> {
+  using vec4 = f64x4;
+  static __device__ __forceinline__ vec4 mma(double a, double b, vec4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) + 4 * r; }
+  // f64 C/D puts A-row m into register (m >> 2) of lane group (m & 3); feeding logical row
+  // 4 * (m & 3) + (m >> 2) there makes register r of lane l hold logical row 4 * (l >> 4) + r
+  static __device__ __forceinline__ int arow_for_k4(int m) { return 4 * (m & 3) + (m >> 2); }
+};
+
+// ---- hyper-parameters as the kernels see them ---------------------------------------------------
+struct KernParams {
+  int kernel;       // GPSO_MATERN52 ...
+  double variance;  // sigma^2
+  double noise;     // sigma_n^2
+  double mean_c;    // constant mean
+};
+
+// k(r^2) for the four stationary kernels, GPflow semantics:
+// Matern family clamps r^2 at 1e-36 before the square root; SE uses r^2 directly.
+__device__ __forceinline__ double kern_from_r2(int kernel, double r2, double variance) {
+  if (kernel == 3) return variance * exp(-0.5 * r2);
+  const double r = sqrt(fmax(r2, 1e-36));
+  if (kernel == 0) {
+    const double s5 = 2.23606797749978969641;
+    return variance * (1.0 + s5 * r + (5.0 / 3.0) * (r * r)) * exp(-s5 * r);
+  }
+  if (kernel == 1) {
+    const double s3 = 1.73205080756887729353;
+    return variance * (1.0 + s3 * r) * exp(-s3 * r);
+  }
+  return variance * exp(-r);
+}
+
+__device__ __forceinline__ float kern_from_r2(int kernel, float r2, float variance) {
+  if (kernel == 3) return variance * __expf(-0.5f * r2);
+  const float r = __builtin_sqrtf(fmaxf(r2, 1e-36f));
+  if (kernel == 0) {
+    const float s5 = 2.2360679775f;
+    return variance * (1.0f + s5 * r + (5.0f / 3.0f) * (r * r)) * __expf(-s5 * r);
+  }
+  if (kernel == 1) {
+    const float s3 = 1.7320508076f;
+    return variance * (1.0f + s3 * r) * __expf(-s3 * r);
+  }
+  return variance * __expf(-r);
+}
+
+// d k / d(r^2) * variance-scaled, used by the gradient reductions
+__device__ __forceinline__ double dkern_dr2(int kernel, double r2, double variance) {
+  if (kernel == 3) return -0.5 * variance * exp(-0.5 * r2);
+  const double r = sqrt(fmax(r2, 1e-36));
+  if (kernel == 0) {
+    const double s5 = 2.23606797749978969641;
+    return -variance * (5.0 / 6.0) * (1.0 + s5 * r) * exp(-s5 * r);
+  }
+  if (kernel == 1) {
+    const double s3 = 1.73205080756887729353;
+    return -variance * 1.5 * exp(-s3 * r);
+  }
+  return -variance * 0.5 * exp(-r) / r;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+}  // namespace gpso

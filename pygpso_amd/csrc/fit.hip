@@ -1,0 +1,675 @@
+// GP posterior fit on gfx950 (K1-K6 of SURVEY.md 2.4), all matrices resident in HBM, row-major,
+// leading dimension npad (multiple of 128):
+//
+//   scale_x      X/lengthscale (+ squared norms, + MFMA-fragment packing for the predict kernel)
+//   gram         K = k(X,X) + noise I      x.x^T on MFMA 16x16x4, Matern/SE map fused as epilogue
+//   potrf        blocked right-looking Cholesky, 64-wide panels:
+//                  potrf_diag (one wave, LDS) -> also inverts the diagonal block
+//                  panel  L21 = A21 inv(L11)^T,  trailing A22 -= L21 L21^T   (MFMA tile GEMM)
+//   trtri        L^-1 by level doubling: off-diagonal block = -inv(B) * C * inv(A), batched per level
+//   pack_linv    re-tile L^-1 into the fragment-major layout leaf_tiles_kernel streams
+//   solve_alpha  a = L^-1 (y-c), alpha = L^-T a, NLML (wavefront reductions, double accumulators)
+//   gradient     Kinv = L^-T L^-1, then sum W o dK/dtheta reductions (analytic d NLML / d theta)
+//
+// Replaces what gpflow GPR.training_loss + its autodiff do per L-BFGS-B evaluation
+// (gpso/gp_surrogate.py:500-503).
+#include <climits>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace gpso {
+
+// =============================================================================================
+// scale + pack inputs
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void scale_x_kernel(const double* __restrict__ x64, int64_t n,
+                                                      int64_t npad, int d, int dp,
+                                                      const double* __restrict__ ls,
+                                                      T* __restrict__ xs, T* __restrict__ xnorm) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npad) return;
+  T acc = 0;
+  for (int k = 0; k < dp; ++k) {
+    T v = 0;
+    if (i < n && k < d) v = (T)(x64[i * d + k] / ls[k]);
+    xs[i * dp + k] = v;
+    acc += v * v;
+  }
+  xnorm[i] = acc;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_xs_kernel(const T* __restrict__ xs, int64_t npad, int dp,
+                                                      T* __restrict__ xs_p) {
+  // one thread per packed element: ((kt * dp4 + c) * 64 + lane)
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int dp4 = dp / 4;
+  if (idx >= npad * dp) return;
+  const int lane = (int)(idx & 63);
+  const int64_t q = idx >> 6;
+  const int c = (int)(q % dp4);
+  const int64_t kt = q / dp4;
+  const int row = Mfma<T>::arow_for_k4(lane & 15);
+  xs_p[idx] = xs[(kt * 16 + row) * dp + 4 * c + (lane >> 4)];
+}
+
+template <typename T>
+void launch_scale_x(hipStream_t st, const double* x64, int64_t n, int64_t npad, int d, int dp,
+                    const double* ls, T* xs, T* xnorm, T* xs_p) {
+  hipLaunchKernelGGL((scale_x_kernel<T>), dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, st,
+                     x64, n, npad, d, dp, ls, xs, xnorm);
+  hipLaunchKernelGGL((pack_xs_kernel<T>), dim3((unsigned)((npad * dp + 255) / 256)), dim3(256), 0,
+                     st, xs, npad, dp, xs_p);
+}
+template void launch_scale_x<float>(hipStream_t, const double*, int64_t, int64_t, int, int, const double*, float*, float*, float*);
+template void launch_scale_x<double>(hipStream_t, const double*, int64_t, int64_t, int, int, const double*, double*, double*, double*);
+
+// =============================================================================================
+// Gram matrix: one wave per 16x16 tile, x.x^T on MFMA, kernel map as epilogue
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void gram_kernel(const T* __restrict__ xs,
+                                                   const T* __restrict__ xnorm, int64_t n,
+                                                   int64_t npad, int dp, int kernel, T variance,
+                                                   T noise, T* __restrict__ K) {
+  using M = Mfma<T>;
+  using vec4 = typename M::vec4;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t i0 = (int64_t)blockIdx.y * 16;
+  const int64_t j0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
+  vec4 s{0, 0, 0, 0};
+  for (int c = 0; c < dp / 4; ++c) {
+    const T a = xs[(i0 + (lane & 15)) * dp + 4 * c + (lane >> 4)];
+    const T b = xs[(j0 + (lane & 15)) * dp + 4 * c + (lane >> 4)];
+    s = M::mma(a, b, s);
+  }
+  const int64_t j = j0 + (lane & 15);
+  const T nbj = xnorm[j];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = i0 + M::crow(lane, r);
+    T v;
+    if (i < n && j < n) {
+      const T r2 = T(-2) * s[r] + (xnorm[i] + nbj);
+      v = kern_from_r2(kernel, r2, variance);
+      if (i == j) v += noise;
+    } else {
+      v = (i == j) ? T(1) : T(0);
+    }
+    K[i * npad + j] = v;
+  }
+}
+
+template <typename T>
+void launch_gram(hipStream_t st, const T* xs, const T* xnorm, int64_t n, int64_t npad, int dp,
+                 const KernParams& kp, T* K) {
+  const dim3 grid((unsigned)(npad / 64), (unsigned)(npad / 16));
+  hipLaunchKernelGGL((gram_kernel<T>), grid, dim3(256), 0, st, xs, xnorm, n, npad, dp, kp.kernel,
+                     (T)kp.variance, (T)kp.noise, K);
+}
+template void launch_gram<float>(hipStream_t, const float*, const float*, int64_t, int64_t, int, const KernParams&, float*);
+template void launch_gram<double>(hipStream_t, const double*, const double*, int64_t, int64_t, int, const KernParams&, double*);
+
+// =============================================================================================
+// 64x64 diagonal block: Cholesky + triangular inverse, one wave, operands in LDS
+// =============================================================================================
+constexpr int kDS = kFitBlock + 1;  // LDS row stride (conflict-free row-per-lane access)
+
+// in-LDS inverse of the lower-triangular block Ls -> Xs (lane c owns column c)
+__device__ __forceinline__ void trinv64_lds(const double* Ls, double* Xs, int lane) {
+  // forward substitution on the identity; loops are wave-uniform (Ls reads broadcast, Xs reads
+  // are one column per lane): X[i][c] = (delta_ic - sum_{k<i} L[i][k] X[k][c]) / L[i][i]
+  const int c = lane;
+  for (int i = 0; i < kFitBlock; ++i) {
+    double acc = (i == c) ? 1.0 : 0.0;
+    for (int k = 0; k < i; ++k) acc -= Ls[i * kDS + k] * Xs[k * kDS + c];
+    Xs[i * kDS + c] = (i < c) ? 0.0 : acc / Ls[i * kDS + i];
+  }
+}
+
+// One wave. A: 64x64 block at K + k0*ld + k0. Writes L11 (upper part zeroed) back, inv(L11) into
+// linv's diagonal block, the block's log-det partial (rows < n only) and the failing pivot.
+template <typename T>
+__global__ __launch_bounds__(64) void potrf_diag_kernel(T* __restrict__ K, T* __restrict__ linv,
+                                                        int64_t ld, int64_t k0, int64_t n,
+                                                        double* __restrict__ logdet_part,
+                                                        int* __restrict__ info) {
+  __shared__ double Ls[kFitBlock * kDS];
+  __shared__ double Xs[kFitBlock * kDS];
+  const int lane = threadIdx.x;
+  T* A = K + k0 * ld + k0;
+  for (int r = 0; r < kFitBlock; ++r) Ls[r * kDS + lane] = (double)A[(int64_t)r * ld + lane];
+  __syncthreads();
+  // left-looking column Cholesky: lane i owns row i; accumulate in double whatever T is
+  double logdet = 0.0;
+  for (int j = 0; j < kFitBlock; ++j) {
+    double v = Ls[lane * kDS + j];
+    for (int k = 0; k < j; ++k) v -= Ls[lane * kDS + k] * Ls[j * kDS + k];
+    double piv = __shfl(v, j);
+    if (!(piv > 0.0)) {  // also catches NaN
+      if (lane == 0 && k0 + j < n) atomicMin(info, (int)(k0 + j));
+      piv = 1.0;
+    }
+    const double ljj = sqrt(piv);
+    if (k0 + j < n) logdet += log(ljj);
+    __syncthreads();
+    if (lane == j) Ls[lane * kDS + j] = ljj;
+    if (lane > j) Ls[lane * kDS + j] = v / ljj;
+    if (lane < j) Ls[lane * kDS + j] = 0.0;  // (reads of column j above the diagonal are done)
+    __syncthreads();
+  }
+  // zero the strict upper triangle so the block is a clean lower-triangular matrix
+  for (int k = lane + 1; k < kFitBlock; ++k) Ls[lane * kDS + k] = 0.0;
+  __syncthreads();
+  trinv64_lds(Ls, Xs, lane);
+  __syncthreads();
+  T* Xo = linv + k0 * ld + k0;
+  for (int r = 0; r < kFitBlock; ++r) {
+    A[(int64_t)r * ld + lane] = (T)Ls[r * kDS + lane];
+    Xo[(int64_t)r * ld + lane] = (T)Xs[r * kDS + lane];
+  }
+  if (lane == 0) logdet_part[k0 / kFitBlock] = logdet;
+}
+
+// inverse of every 64x64 diagonal block of an already-factorised L (gpso_set_posterior path)
+template <typename T>
+__global__ __launch_bounds__(64) void trinv_diag_kernel(const T* __restrict__ L,
+                                                        T* __restrict__ linv, int64_t ld) {
+  __shared__ double Ls[kFitBlock * kDS];
+  __shared__ double Xs[kFitBlock * kDS];
+  const int lane = threadIdx.x;
+  const int64_t k0 = (int64_t)blockIdx.x * kFitBlock;
+  const T* A = L + k0 * ld + k0;
+  for (int r = 0; r < kFitBlock; ++r)
+    Ls[r * kDS + lane] = (lane <= r) ? (double)A[(int64_t)r * ld + lane] : 0.0;
+  __syncthreads();
+  trinv64_lds(Ls, Xs, lane);
+  __syncthreads();
+  T* Xo = linv + k0 * ld + k0;
+  for (int r = 0; r < kFitBlock; ++r) Xo[(int64_t)r * ld + lane] = (T)Xs[r * kDS + lane];
+}
+
+// =============================================================================================
+// generic batched 64x64-tile GEMM on MFMA 16x16x4:  C = alpha * opA * opB + beta * C
+// =============================================================================================
+struct GemmDesc {
+  const void* A;
+  int64_t sai, sak;  // opA(i,k) = A[i*sai + k*sak]
+  const void* B;
+  int64_t sbk, sbj;  // opB(k,j) = B[k*sbk + j*sbj]
+  void* C;
+  int64_t ldc;
+  int64_t batchA, batchB, batchC;  // element strides between batch entries (blockIdx.z)
+  int m, n, k;                     // sizes of a full batch entry, multiples of 64
+  int m_last;                      // rows of the LAST batch entry (multiple of 64, <= m)
+  int nbatch;
+  double alpha, beta;
+  int lower_only;  // skip tiles strictly above the diagonal (tj > ti)
+  int kmode;       // 0: all k | 1: k >= 64 tj | 2: k >= 64 ti | 3: k < 64 (ti + 1)
+};
+
+constexpr int kGK = 32;       // k-step staged in LDS
+constexpr int kGS = kGK + 4;  // LDS row stride (keeps vec4 alignment)
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tile_kernel(GemmDesc g) {
+  using M = Mfma<T>;
+  using vec4 = typename M::vec4;
+  __shared__ __align__(32) T As[64 * kGS];
+  __shared__ __align__(32) T Bs[64 * kGS];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int ti = blockIdx.y, tj = blockIdx.x, bz = blockIdx.z;
+  if (g.lower_only && tj > ti) return;
+  const int m_here = (bz == g.nbatch - 1) ? g.m_last : g.m;
+  if (ti * 64 >= m_here) return;
+  const T* A = static_cast<const T*>(g.A) + (int64_t)bz * g.batchA;
+  const T* B = static_cast<const T*>(g.B) + (int64_t)bz * g.batchB;
+  T* C = static_cast<T*>(g.C) + (int64_t)bz * g.batchC;
+
+  int k_lo = 0, k_hi = g.k;
+  if (g.kmode == 1) k_lo = 64 * tj;
+  if (g.kmode == 2) k_lo = 64 * ti;
+  if (g.kmode == 3) k_hi = min(g.k, 64 * (ti + 1));
+
+  const int wr = wave >> 1, wc = wave & 1;
+  vec4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = vec4{0, 0, 0, 0};
+
+  const bool a_kcontig = (g.sak == 1);
+  const bool b_kcontig = (g.sbk == 1);
+  for (int k0 = k_lo; k0 < k_hi; k0 += kGK) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int idx = tid + 256 * p;
+      int i, k;
+      if (a_kcontig) { k = idx & 31; i = idx >> 5; } else { i = idx & 63; k = idx >> 6; }
+      As[i * kGS + k] = A[(int64_t)(ti * 64 + i) * g.sai + (int64_t)(k0 + k) * g.sak];
+      int j, kb;
+      if (b_kcontig) { kb = idx & 31; j = idx >> 5; } else { j = idx & 63; kb = idx >> 6; }
+      Bs[j * kGS + kb] = B[(int64_t)(k0 + kb) * g.sbk + (int64_t)(tj * 64 + j) * g.sbj];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < kGK / 16; ++kk) {
+      vec4 a4[2], b4[2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        a4[x] = *reinterpret_cast<const vec4*>(&As[(wr * 32 + x * 16 + (lane & 15)) * kGS + kk * 16 + 4 * (lane >> 4)]);
+        b4[x] = *reinterpret_cast<const vec4*>(&Bs[(wc * 32 + x * 16 + (lane & 15)) * kGS + kk * 16 + 4 * (lane >> 4)]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[a][b] = M::mma(a4[a][r], b4[b][r], acc[a][b]);
+    }
+    __syncthreads();
+  }
+  const T alpha = (T)g.alpha, beta = (T)g.beta;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t i = ti * 64 + wr * 32 + a * 16 + M::crow(lane, r);
+        const int64_t j = tj * 64 + wc * 32 + b * 16 + (lane & 15);
+        T* c = C + i * g.ldc + j;
+        T v = alpha * acc[a][b][r];
+        if (g.beta != 0.0) v += beta * (*c);
+        *c = v;
+      }
+}
+
+template <typename T>
+static void launch_gemm(hipStream_t st, const GemmDesc& g) {
+  if (g.m <= 0 || g.n <= 0 || g.nbatch <= 0) return;
+  const dim3 grid((unsigned)(g.n / 64), (unsigned)(g.m / 64), (unsigned)g.nbatch);
+  hipLaunchKernelGGL((gemm_tile_kernel<T>), grid, dim3(256), 0, st, g);
+}
+
+// =============================================================================================
+// blocked Cholesky
+// =============================================================================================
+template <typename T>
+void launch_potrf(hipStream_t st, T* K, T* linv, int64_t n, int64_t npad, double* logdet_part,
+                  int* info) {
+  const int nb = (int)(npad / kFitBlock);
+  for (int p = 0; p < nb; ++p) {
+    const int64_t k0 = (int64_t)p * kFitBlock;
+    hipLaunchKernelGGL((potrf_diag_kernel<T>), dim3(1), dim3(64), 0, st, K, linv, npad, k0, n,
+                       logdet_part, info);
+    const int m = (int)(npad - k0 - kFitBlock);
+    if (m <= 0) break;
+    T* A21 = K + (k0 + kFitBlock) * npad + k0;
+    // L21 = A21 * inv(L11)^T    (in place: every workgroup reads only the rows it overwrites)
+    GemmDesc t{};
+    t.A = A21; t.sai = npad; t.sak = 1;
+    t.B = linv + k0 * npad + k0; t.sbk = 1; t.sbj = npad;  // opB(k,j) = inv11[j][k]
+    t.C = A21; t.ldc = npad;
+    t.m = m; t.n = kFitBlock; t.k = kFitBlock; t.m_last = m; t.nbatch = 1;
+    t.alpha = 1.0; t.beta = 0.0;
+    launch_gemm<T>(st, t);
+    // A22 -= L21 L21^T   (lower tiles)
+    GemmDesc s{};
+    s.A = A21; s.sai = npad; s.sak = 1;
+    s.B = A21; s.sbk = 1; s.sbj = npad;
+    s.C = K + (k0 + kFitBlock) * npad + (k0 + kFitBlock); s.ldc = npad;
+    s.m = m; s.n = m; s.k = kFitBlock; s.m_last = m; s.nbatch = 1;
+    s.alpha = -1.0; s.beta = 1.0; s.lower_only = 1;
+    launch_gemm<T>(st, s);
+  }
+}
+template void launch_potrf<float>(hipStream_t, float*, float*, int64_t, int64_t, double*, int*);
+template void launch_potrf<double>(hipStream_t, double*, double*, int64_t, int64_t, double*, int*);
+
+// =============================================================================================
+// triangular inverse by level doubling
+// =============================================================================================
+// level with half-size s: pairs p = 0.. ; A = [2ps, 2ps+s), B = [2ps+s, min(2ps+2s, npad));
+//   W[B,A]    = L[B,A] * Linv[A,A]         (Linv[A,A] lower  -> k >= 64 tj)
+//   Linv[B,A] = -Linv[B,B] * W[B,A]        (Linv[B,B] lower  -> k <  64 (ti+1))
+template <typename T>
+void launch_trtri(hipStream_t st, const T* L, T* linv, T* work, int64_t npad) {
+  for (int64_t s = kFitBlock; s < npad; s *= 2) {
+    const int64_t span = 2 * s;
+    const int nfull = (int)(npad / span);          // pairs with a full-size B
+    const int64_t rem = npad - (int64_t)nfull * span;  // leftover columns
+    int nbatch = nfull;
+    int m_last = (int)s;
+    if (rem > s) {  // one more pair with a partial B of rem - s rows
+      nbatch = nfull + 1;
+      m_last = (int)(rem - s);
+    }
+    if (nbatch == 0) continue;
+    const int64_t bstride = span * npad + span;
+    GemmDesc a{};
+    a.A = L + s * npad; a.sai = npad; a.sak = 1;  // L[B rows, A cols]
+    a.B = linv; a.sbk = npad; a.sbj = 1;          // Linv[A, A]
+    a.C = work + s * npad; a.ldc = npad;
+    a.batchA = a.batchB = a.batchC = bstride;
+    a.m = (int)s; a.n = (int)s; a.k = (int)s; a.m_last = m_last; a.nbatch = nbatch;
+    a.alpha = 1.0; a.beta = 0.0; a.kmode = 1;
+    launch_gemm<T>(st, a);
+    GemmDesc b{};
+    b.A = linv + s * npad + s; b.sai = npad; b.sak = 1;  // Linv[B, B]
+    b.B = work + s * npad; b.sbk = npad; b.sbj = 1;      // W[B, A]
+    b.C = linv + s * npad; b.ldc = npad;
+    b.batchA = b.batchB = b.batchC = bstride;
+    b.m = (int)s; b.n = (int)s; b.k = (int)s; b.m_last = m_last; b.nbatch = nbatch;
+    b.alpha = -1.0; b.beta = 0.0; b.kmode = 3;
+    launch_gemm<T>(st, b);
+  }
+}
+template void launch_trtri<float>(hipStream_t, const float*, float*, float*, int64_t);
+template void launch_trtri<double>(hipStream_t, const double*, double*, double*, int64_t);
+
+// =============================================================================================
+// pack L^-1 into MFMA fragment-major tiles (layout documented in predict.hip)
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void pack_linv_kernel(const T* __restrict__ linv, int64_t n,
+                                                        int64_t npad, T* __restrict__ linv_p) {
+  using vec4 = typename Mfma<T>::vec4;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (tile, lane)
+  const int64_t npad16 = npad / 16;
+  if (idx >= npad16 * npad16 * 64) return;
+  const int lane = (int)(idx & 63);
+  const int64_t tile = idx >> 6;
+  const int64_t rt = tile / npad16, kt = tile % npad16;
+  const int64_t row = rt * 16 + (lane & 15);
+  const int64_t col = kt * 16 + 4 * (lane >> 4);
+  vec4 v{0, 0, 0, 0};
+  if (kt <= rt && row < n) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (col + r <= row && col + r < n) v[r] = linv[row * npad + col + r];
+  }
+  reinterpret_cast<vec4*>(linv_p)[idx] = v;
+}
+
+template <typename T>
+void launch_pack_linv(hipStream_t st, const T* linv, int64_t n, int64_t npad, T* linv_p) {
+  const int64_t total = (npad / 16) * (npad / 16) * 64;
+  hipLaunchKernelGGL((pack_linv_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                     linv, n, npad, linv_p);
+}
+template void launch_pack_linv<float>(hipStream_t, const float*, int64_t, int64_t, float*);
+template void launch_pack_linv<double>(hipStream_t, const double*, int64_t, int64_t, double*);
+
+// =============================================================================================
+// single-RHS solves through L^-1 and the NLML
+// =============================================================================================
+// white[i] = sum_{k<=i} Linv[i][k] (y[k] - c): one wave per row, wavefront reduction
+template <typename T>
+__global__ __launch_bounds__(256) void white_kernel(const T* __restrict__ linv,
+                                                    const double* __restrict__ y64, int64_t n,
+                                                    int64_t npad, double mean_c,
+                                                    T* __restrict__ white) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+  if (i >= npad) return;
+  double acc = 0.0;
+  if (i < n)
+    for (int64_t k = lane; k <= i; k += 64) acc += (double)linv[i * npad + k] * (y64[k] - mean_c);
+  acc = wave_sum(acc);
+  if (lane == 0) white[i] = (T)acc;
+}
+
+// alpha[j] = sum_{i>=j} Linv[i][j] white[i]: 64 columns per block, 4 row groups, LDS combine
+template <typename T>
+__global__ __launch_bounds__(256) void alpha_kernel(const T* __restrict__ linv,
+                                                    const T* __restrict__ white, int64_t n,
+                                                    int64_t npad, T* __restrict__ alpha) {
+  __shared__ double sh[4][64];
+  const int g = threadIdx.x >> 6, c = threadIdx.x & 63;
+  const int64_t j = (int64_t)blockIdx.x * 64 + c;
+  double acc = 0.0;
+  if (j < n)
+    for (int64_t i = (int64_t)blockIdx.x * 64 + g; i < n; i += 4)
+      if (i >= j) acc += (double)linv[i * npad + j] * (double)white[i];
+  sh[g][c] = acc;
+  __syncthreads();
+  if (g == 0) alpha[j] = (T)(sh[0][c] + sh[1][c] + sh[2][c] + sh[3][c]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nlml_kernel(const T* __restrict__ white, int64_t n,
+                                                   const double* __restrict__ logdet_part,
+                                                   int npanels, double* __restrict__ out) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const double a = (double)white[i];
+    acc += a * a;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double quad = sh[0] + sh[1] + sh[2] + sh[3];
+    double ld = 0.0;
+    for (int p = 0; p < npanels; ++p) ld += logdet_part[p];
+    out[0] = 0.5 * quad + ld + 0.5 * (double)n * 1.83787706640934548356;  // log(2 pi)
+  }
+}
+
+template <typename T>
+void launch_solve_alpha(hipStream_t st, const T* linv, const double* y64, int64_t n, int64_t npad,
+                        double mean_c, const double* logdet_part, int npanels, T* white, T* alpha,
+                        double* nlml_out) {
+  hipLaunchKernelGGL((white_kernel<T>), dim3((unsigned)(npad / 4)), dim3(256), 0, st, linv, y64, n,
+                     npad, mean_c, white);
+  hipLaunchKernelGGL((alpha_kernel<T>), dim3((unsigned)(npad / 64)), dim3(256), 0, st, linv, white,
+                     n, npad, alpha);
+  if (nlml_out)
+    hipLaunchKernelGGL((nlml_kernel<T>), dim3(1), dim3(256), 0, st, white, n, logdet_part, npanels,
+                       nlml_out);
+}
+template void launch_solve_alpha<float>(hipStream_t, const float*, const double*, int64_t, int64_t, double, const double*, int, float*, float*, double*);
+template void launch_solve_alpha<double>(hipStream_t, const double*, const double*, int64_t, int64_t, double, const double*, int, double*, double*, double*);
+
+// =============================================================================================
+// analytic gradient of the NLML  
+// =============================================================================================
+// one block per lower 64x64 tile (ti >= tj); partial[(blk) * (n_ls + 2) + h], h: ls..., variance, noise
+template <typename T>
+__global__ __launch_bounds__(256) void grad_tile_kernel(const T* __restrict__ kinv,
+                                                        const T* __restrict__ alpha,
+                                                        const T* __restrict__ xs,
+                                                        const T* __restrict__ xnorm, int64_t n,
+                                                        int64_t npad, int dp, int n_ls,
+                                                        const double* __restrict__ ls, int kernel,
+                                                        double variance,
+                                                        double* __restrict__ partial) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  T* xi = reinterpret_cast<T*>(lds_raw);  // [64][dp]
+  T* xj = xi + 64 * dp;                   // [64][dp]
+  __shared__ double red[4];
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  const int nt = gridDim.x;
+  const int64_t blk = (int64_t)ti * nt + tj;
+  const int H = n_ls + 2;
+  if (tj > ti) {
+    if ((int)threadIdx.x < H) partial[blk * H + threadIdx.x] = 0.0;
+    return;
+  }
+  for (int e = threadIdx.x; e < 64 * dp; e += 256) {
+    xi[e] = xs[(int64_t)ti * 64 * dp + e];
+    xj[e] = xs[(int64_t)tj * 64 * dp + e];
+  }
+  __syncthreads();
+  double g_var = 0.0, g_noise = 0.0, g_iso = 0.0;
+  double base[16];  // w * W * dk/dr2 per entry, for the ARD passes
+#pragma unroll
+  for (int p = 0; p < 16; ++p) {
+    const int idx = threadIdx.x + 256 * p;
+    const int ii = idx >> 6, jj = idx & 63;
+    const int64_t i = (int64_t)ti * 64 + ii, j = (int64_t)tj * 64 + jj;
+    base[p] = 0.0;
+    if (i >= n || j >= n || j > i) continue;
+    const double w = (i == j) ? 1.0 : 2.0;
+    T s = 0;
+    for (int k = 0; k < dp; ++k) s += xi[ii * dp + k] * xj[jj * dp + k];
+    const double r2 = (double)(T(-2) * s + (xnorm[i] + xnorm[j]));
+    const double ai = (double)alpha[i], aj = (double)alpha[j];
+    const double W = 0.5 * ((double)kinv[i * npad + j] - ai * aj);
+    const double kv = kern_from_r2(kernel, r2, variance);
+    const double dk = dkern_dr2(kernel, r2, variance);
+    g_var += w * W * kv / variance;
+    if (i == j) g_noise += W;
+    const double r2c = (kernel == 3) ? r2 : fmax(r2, 1e-36);
+    base[p] = w * W * dk;
+    g_iso += base[p] * (-2.0 * r2c);
+  }
+  auto block_sum = [&](double v) -> double {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+  };
+  const double sv = block_sum(g_var);
+  const double sn = block_sum(g_noise);
+  if (n_ls == 1) {
+    const double sl = block_sum(g_iso) / ls[0];
+    if (threadIdx.x == 0) partial[blk * H + 0] = sl;
+  } else {
+    for (int d = 0; d < n_ls; ++d) {
+      double acc = 0.0;
+#pragma unroll
+      for (int p = 0; p < 16; ++p) {
+        const int idx = threadIdx.x + 256 * p;
+        const int ii = idx >> 6, jj = idx & 63;
+        const double df = (double)xi[ii * dp + d] - (double)xj[jj * dp + d];
+        acc += base[p] * (-2.0 * df * df);
+      }
+      const double sd = block_sum(acc) / ls[d];
+      if (threadIdx.x == 0) partial[blk * H + d] = sd;
+    }
+  }
+  if (threadIdx.x == 0) {
+    partial[blk * H + n_ls] = sv;
+    partial[blk * H + n_ls + 1] = sn;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void grad_final_kernel(const double* __restrict__ partial,
+                                                         int64_t nblk, int n_ls,
+                                                         const T* __restrict__ alpha, int64_t n,
+                                                         double* __restrict__ grad_out) {
+  __shared__ double red[4];
+  const int H = n_ls + 2;
+  for (int h = 0; h <= H; ++h) {
+    double acc = 0.0;
+    if (h < H) {
+      for (int64_t b = threadIdx.x; b < nblk; b += blockDim.x) acc += partial[b * H + h];
+    } else {
+      for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc -= (double)alpha[i];
+    }
+    acc = wave_sum(acc);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) grad_out[h] = red[0] + red[1] + red[2] + red[3];
+  }
+}
+
+template <typename T>
+void launch_gradient(hipStream_t st, const T* linv, const T* alpha, const T* xs, const T* xnorm,
+                     int64_t n, int64_t npad, int d, int dp, int n_ls, const double* ls,
+                     const KernParams& kp, T* kinv, double* partial, double* grad_out) {
+  (void)d;
+  // Kinv = Linv^T Linv, lower tiles:  opA(i,k) = Linv[k][i],  opB(k,j) = Linv[k][j],  k >= 64 ti
+  GemmDesc g{};
+  g.A = linv; g.sai = 1; g.sak = npad;
+  g.B = linv; g.sbk = npad; g.sbj = 1;
+  g.C = kinv; g.ldc = npad;
+  g.m = (int)npad; g.n = (int)npad; g.k = (int)npad; g.m_last = (int)npad; g.nbatch = 1;
+  g.alpha = 1.0; g.beta = 0.0; g.lower_only = 1; g.kmode = 2;
+  launch_gemm<T>(st, g);
+  const int nt = (int)(npad / 64);
+  const size_t lds = (size_t)2 * 64 * dp * sizeof(T);
+  hipLaunchKernelGGL((grad_tile_kernel<T>), dim3((unsigned)nt, (unsigned)nt), dim3(256), lds, st,
+                     kinv, alpha, xs, xnorm, n, npad, dp, n_ls, ls, kp.kernel, kp.variance, partial);
+  hipLaunchKernelGGL((grad_final_kernel<T>), dim3(1), dim3(256), 0, st, partial,
+                     (int64_t)nt * nt, n_ls, alpha, n, grad_out);
+}
+template void launch_gradient<float>(hipStream_t, const float*, const float*, const float*, const float*, int64_t, int64_t, int, int, int, const double*, const KernParams&, float*, double*, double*);
+template void launch_gradient<double>(hipStream_t, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int, int, const double*, const KernParams&, double*, double*, double*);
+
+// =============================================================================================
+// conversions / interop
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void convert_in_kernel(const double* __restrict__ src,
+                                                         T* __restrict__ dst, int64_t rows,
+                                                         int64_t cols, int64_t ld_dst) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * cols) return;
+  dst[(idx / cols) * ld_dst + idx % cols] = (T)src[idx];
+}
+template <typename T>
+void launch_convert_in(hipStream_t st, const double* src, T* dst, int64_t rows, int64_t cols,
+                       int64_t ld_dst) {
+  const int64_t total = rows * cols;
+  if (total == 0) return;
+  hipLaunchKernelGGL((convert_in_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     st, src, dst, rows, cols, ld_dst);
+}
+template void launch_convert_in<float>(hipStream_t, const double*, float*, int64_t, int64_t, int64_t);
+template void launch_convert_in<double>(hipStream_t, const double*, double*, int64_t, int64_t, int64_t);
+
+template <typename T>
+__global__ __launch_bounds__(256) void convert_out_kernel(const T* __restrict__ src, int64_t ld_src,
+                                                          double* __restrict__ dst, int64_t rows,
+                                                          int64_t cols, int lower_only) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * cols) return;
+  const int64_t i = idx / cols, j = idx % cols;
+  double v = (double)src[i * ld_src + j];
+  if (lower_only == 1 && j > i) v = 0.0;
+  if (lower_only == 2 && j > i) v = (double)src[j * ld_src + i];  // mirror a symmetric lower matrix
+  dst[idx] = v;
+}
+template <typename T>
+void launch_convert_out(hipStream_t st, const T* src, int64_t ld_src, double* dst, int64_t rows,
+                        int64_t cols, int lower_only) {
+  const int64_t total = rows * cols;
+  if (total == 0) return;
+  hipLaunchKernelGGL((convert_out_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     st, src, ld_src, dst, rows, cols, lower_only);
+}
+template void launch_convert_out<float>(hipStream_t, const float*, int64_t, double*, int64_t, int64_t, int);
+template void launch_convert_out<double>(hipStream_t, const double*, int64_t, double*, int64_t, int64_t, int);
+
+template <typename T>
+__global__ __launch_bounds__(256) void install_chol_kernel(const double* __restrict__ L64, int64_t n,
+                                                           int64_t npad, T* __restrict__ K) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= npad * npad) return;
+  const int64_t i = idx / npad, j = idx % npad;
+  T v = 0;
+  if (i < n && j <= i) v = (T)L64[i * n + j];
+  if (i >= n && i == j) v = 1;
+  K[idx] = v;
+}
+template <typename T>
+void launch_install_chol(hipStream_t st, const double* L64, int64_t n, int64_t npad, T* K, T* linv) {
+  const int64_t total = npad * npad;
+  hipLaunchKernelGGL((install_chol_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     st, L64, n, npad, K);
+  hipLaunchKernelGGL((trinv_diag_kernel<T>), dim3((unsigned)(npad / kFitBlock)), dim3(64), 0, st, K,
+                     linv, npad);
+}
+template void launch_install_chol<float>(hipStream_t, const double*, int64_t, int64_t, float*, float*);
+template void launch_install_chol<double>(hipStream_t, const double*, int64_t, int64_t, double*, double*);
+
+}  // namespace gpso

@@ -1,0 +1,306 @@
+// Leaf-UCB predict path (K7-K11 of SURVEY.md 2.4) for gfx950.
+//
+//   prep_leaves    raw leaf coordinates -> x*/lengthscale (T) + squared norms
+//   leaf_tiles     the dominant kernel: for a tile of leaves and a block of BM rows of L^-1,
+//                  generate the cross-Gram tile K_{n*} on the fly (MFMA for the x.x* contraction,
+//                  VALU/transcendental epilogue for the Matern/SE map), feed it -- still in
+//                  registers, in accumulator layout -- as the B operand of the MFMA that applies
+//                  L^-1, and reduce |L^-1 k*|^2 (and k*.alpha on the diagonal block) per leaf.
+//                  Nothing of size N x M ever touches HBM.
+//   leaf_finalize  sum the per-row-block partials, form mean / var(+noise) / ucb = mean + vs*var
+//   seg_argmax_*   first-max arg-max of ucb per segment (np.argmax tie rule)
+//
+// Replaces gpflow_model.predict_y + the numpy UCB/argmax of gpso/gp_surrogate.py:313-328.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace gpso {
+
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename TIN>
+__global__ __launch_bounds__(256) void prep_leaves_kernel(const TIN* __restrict__ xs, int64_t m,
+                                                          int64_t mpad, int d, int dp,
+                                                          const double* __restrict__ ls /*[dp]*/,
+                                                          T* __restrict__ out, T* __restrict__ norm) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= mpad) return;
+  T acc = 0;
+  for (int k = 0; k < dp; ++k) {
+    T v = 0;
+    if (j < m && k < d) v = (T)((double)xs[j * d + k] / ls[k]);
+    out[j * dp + k] = v;
+    acc += v * v;
+  }
+  norm[j] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Packed operand layouts produced at fit time (fit.hip: pack_linv_kernel / scale_x_kernel):
+//   linv_p : 16x16 tiles of L^-1, tile (rt, kt) at ((rt * npad16 + kt) * 256), inside a tile
+//            element (row, k) sits at lane * 4 + (k & 3) with lane = (row & 15) + 16 * ((k & 15) >> 2)
+//            -> one wave reads a whole tile as 64 contiguous vec4 (1 KiB f32 / 2 KiB f64), and
+//            lane l gets L^-1[row l&15][k = 4 (l>>4) + 0..3]: the A operand of MFMA k-step r is
+//            element r.
+//   xs_p   : scaled training inputs as MFMA A fragments: ((kt * dp4 + c) * 64 + lane) holds
+//            x~[16 kt + arow_for_k4(lane & 15)][4 c + (lane >> 4)]
+// With those, accumulator register r of lane l of the generated tile S = x~ x~*^T corresponds to
+// training row 16 kt + 4 (l >> 4) + r and leaf column (l & 15) for BOTH the f32 and f64 MFMA,
+// which is exactly the B-operand shape (k = l >> 4 within k-step r) the second MFMA needs.
+template <typename T, int BM, int CT>
+__global__ __launch_bounds__(256, 2) void leaf_tiles_kernel(
+    const T* __restrict__ linv_p, const T* __restrict__ xs_p, const T* __restrict__ xnorm,
+    const T* __restrict__ alpha, const T* __restrict__ leaves_s, const T* __restrict__ lnorm,
+    T* __restrict__ part_var, T* __restrict__ part_mean, int npad16, int dp4, int64_t mpad, int nbi,
+    int kernel, T variance) {
+  using M = Mfma<T>;
+  using vec4 = typename M::vec4;
+  constexpr int RT = BM / 16;  // row tiles per block
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  T* lds = reinterpret_cast<T*>(lds_raw);
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  const int bi = nbi - 1 - (int)blockIdx.y;  // heaviest row blocks are dispatched first
+  const int64_t col0 = ((int64_t)blockIdx.x * 4 + wave) * (CT * 16);
+  const int dp = dp4 * 4;
+
+  // this wave's leaf fragments (B operand of the generation MFMA), kept in LDS: [t][c][lane]
+  T* xb = lds + (size_t)wave * CT * dp4 * 64;
+  for (int t = 0; t < CT; ++t)
+    for (int c = 0; c < dp4; ++c)
+      xb[(t * dp4 + c) * 64 + lane] =
+          leaves_s[(col0 + t * 16 + (lane & 15)) * dp + 4 * c + (lane >> 4)];
+  T nb[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) nb[t] = lnorm[col0 + t * 16 + (lane & 15)];
+  // (each wave only reads back what it wrote itself: no workgroup barrier needed)
+
+  vec4 acc[RT][CT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int t = 0; t < CT; ++t) acc[rt][t] = vec4{0, 0, 0, 0};
+  T macc[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) macc[t] = 0;
+
+  const int kt_diag0 = bi * RT;   // first k-tile of the diagonal block
+  const int kt_end = kt_diag0 + RT;
+  const vec4* linv4 = reinterpret_cast<const vec4*>(linv_p);
+  const vec4* xn4 = reinterpret_cast<const vec4*>(xnorm);
+  const vec4* al4 = reinterpret_cast<const vec4*>(alpha);
+
+  for (int kt = 0; kt < kt_end; ++kt) {
+    // ---- generate the 16 x (CT*16) cross-Gram tile for training rows [16 kt, 16 kt + 16) ----
+    vec4 s[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) s[t] = vec4{0, 0, 0, 0};
+    for (int c = 0; c < dp4; ++c) {
+      const T xa = xs_p[((size_t)kt * dp4 + c) * 64 + lane];
+#pragma unroll
+      for (int t = 0; t < CT; ++t) s[t] = M::mma(xa, xb[(t * dp4 + c) * 64 + lane], s[t]);
+    }
+    const vec4 na = xn4[kt * 4 + (lane >> 4)];
+    vec4 p[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // GPflow square_distance: -2 x.x* + |x|^2 + |x*|^2
+        const T r2 = (T(-2) * s[t][r] + na[r]) + nb[t];
+        p[t][r] = kern_from_r2(kernel, r2, variance);
+      }
+    if (kt >= kt_diag0) {  // wave-uniform: each k-tile is "diagonal" for exactly one row block
+      const vec4 a4 = al4[kt * 4 + (lane >> 4)];
+#pragma unroll
+      for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) macc[t] += p[t][r] * a4[r];
+    }
+    // ---- apply the BM rows of L^-1: acc[rt][t] += Linv[rows, 16 kt ..] * tile --------------
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      if (kt > kt_diag0 + rt) continue;  // upper-triangular tile of the diagonal block: zeros
+      const vec4 a = linv4[((size_t)(kt_diag0 + rt) * npad16 + kt) * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[rt][t] = M::mma(a[r], p[t][r], acc[rt][t]);
+    }
+  }
+
+  // ---- epilogue: column sums of squares over the BM rows, and the mean partial ----------------
+#pragma unroll
+  for (int t = 0; t < CT; ++t) {
+    T sq = 0;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sq += acc[rt][t][r] * acc[rt][t][r];
+    sq += __shfl_xor(sq, 16);
+    sq += __shfl_xor(sq, 32);
+    T mm = macc[t];
+    mm += __shfl_xor(mm, 16);
+    mm += __shfl_xor(mm, 32);
+    if (lane < 16) {
+      const int64_t col = col0 + t * 16 + lane;
+      part_var[(int64_t)bi * mpad + col] = sq;
+      part_mean[(int64_t)bi * mpad + col] = mm;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void leaf_finalize_kernel(const T* __restrict__ part_var,
+                                                            const T* __restrict__ part_mean,
+                                                            int nbi, int64_t mpad, int64_t m,
+                                                            KernParams kp, double varsigma,
+                                                            double* __restrict__ mean,
+                                                            double* __restrict__ var,
+                                                            double* __restrict__ ucb) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  double v = 0, mu = 0;
+  for (int b = 0; b < nbi; ++b) {
+    v += (double)part_var[(int64_t)b * mpad + j];
+    mu += (double)part_mean[(int64_t)b * mpad + j];
+  }
+  // [gpflow base_conditional] fvar = k** - sum A^2 ; predict_y adds the noise variance
+  const double vy = __dadd_rn(__dsub_rn(kp.variance, v), kp.noise);
+  const double my = __dadd_rn(mu, kp.mean_c);
+  mean[j] = my;
+  var[j] = vy;
+  // gpso/gp_surrogate.py:326  ucb = mean + varsigma * var  (two roundings, as numpy does)
+  if (ucb) ucb[j] = __dadd_rn(my, __dmul_rn(varsigma, vy));
+}
+
+// np.argmax semantics: first maximum wins; NaN counts as the maximum (first NaN wins)
+struct Best {
+  double u;
+  int64_t i;
+};
+__device__ __forceinline__ bool better(const Best& a, const Best& b) {
+  if (a.i < 0) return false;
+  if (b.i < 0) return true;
+  const bool an = a.u != a.u, bn = b.u != b.u;
+  if (an != bn) return an;
+  if (!an && a.u != b.u) return a.u > b.u;
+  return a.i < b.i;
+}
+__device__ __forceinline__ Best block_best(Best mine, Best* sh) {
+  for (int off = 32; off > 0; off >>= 1) {
+    Best o;
+    o.u = __shfl_xor(mine.u, off);
+    o.i = __shfl_xor(mine.i, off);
+    if (better(o, mine)) mine = o;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) sh[wave] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+      if (better(sh[w], mine)) mine = sh[w];
+  }
+  return mine;  // valid on thread 0
+}
+
+// stage 1: grid (nblk, nseg); each block scans a strided share of its segment
+__global__ __launch_bounds__(256) void seg_argmax_stage1(const double* __restrict__ ucb,
+                                                         const int64_t* __restrict__ seg_off,
+                                                         Best* __restrict__ partial) {
+  __shared__ Best sh[4];
+  const int seg = blockIdx.y;
+  const int64_t lo = seg_off[seg], hi = seg_off[seg + 1];
+  Best mine{0.0, -1};
+  for (int64_t j = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < hi;
+       j += (int64_t)gridDim.x * blockDim.x) {
+    Best c{ucb[j], j};
+    if (better(c, mine)) mine = c;
+  }
+  mine = block_best(mine, sh);
+  if (threadIdx.x == 0) partial[(int64_t)seg * gridDim.x + blockIdx.x] = mine;
+}
+
+// stage 2: one block per segment; writes idx (relative to the segment) and the winner's values
+__global__ __launch_bounds__(256) void seg_argmax_stage2(const Best* __restrict__ partial, int nblk,
+                                                         const int64_t* __restrict__ seg_off,
+                                                         const double* __restrict__ mean,
+                                                         const double* __restrict__ var,
+                                                         const double* __restrict__ ucb,
+                                                         int64_t* __restrict__ out_idx,
+                                                         double* __restrict__ out_vals /*[nseg*3]*/) {
+  __shared__ Best sh[4];
+  const int seg = blockIdx.x;
+  Best mine{0.0, -1};
+  for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
+    Best c = partial[(int64_t)seg * nblk + b];
+    if (better(c, mine)) mine = c;
+  }
+  mine = block_best(mine, sh);
+  if (threadIdx.x == 0) {
+    if (mine.i < 0) {  // empty segment
+      out_idx[seg] = -1;
+      out_vals[seg * 3 + 0] = out_vals[seg * 3 + 1] = out_vals[seg * 3 + 2] = __builtin_nan("");
+    } else {
+      out_idx[seg] = mine.i - seg_off[seg];
+      out_vals[seg * 3 + 0] = mean[mine.i];
+      out_vals[seg * 3 + 1] = var[mine.i];
+      out_vals[seg * 3 + 2] = ucb[mine.i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers (declared in kernels.hpp)
+template <typename T, typename TIN>
+void launch_prep_leaves(hipStream_t st, const TIN* xs, int64_t m, int64_t mpad, int d, int dp,
+                        const double* ls, T* out, T* norm) {
+  const int64_t blocks = (mpad + 255) / 256;
+  hipLaunchKernelGGL((prep_leaves_kernel<T, TIN>), dim3((unsigned)blocks), dim3(256), 0, st, xs, m,
+                     mpad, d, dp, ls, out, norm);
+}
+template void launch_prep_leaves<float, float>(hipStream_t, const float*, int64_t, int64_t, int, int, const double*, float*, float*);
+template void launch_prep_leaves<float, double>(hipStream_t, const double*, int64_t, int64_t, int, int, const double*, float*, float*);
+template void launch_prep_leaves<double, float>(hipStream_t, const float*, int64_t, int64_t, int, int, const double*, double*, double*);
+template void launch_prep_leaves<double, double>(hipStream_t, const double*, int64_t, int64_t, int, int, const double*, double*, double*);
+
+template <typename T>
+void launch_leaf_tiles(hipStream_t st, const T* linv_p, const T* xs_p, const T* xnorm,
+                       const T* alpha, const T* leaves_s, const T* lnorm, T* part_var, T* part_mean,
+                       int64_t npad, int dp4, int64_t mpad, const KernParams& kp) {
+  constexpr int BM = LeafTileCfg<T>::BM, CT = LeafTileCfg<T>::CT;
+  const int nbi = (int)(npad / BM);
+  const dim3 grid((unsigned)(mpad / (4 * CT * 16)), (unsigned)nbi);
+  const size_t lds = (size_t)4 * CT * dp4 * 64 * sizeof(T);
+  hipLaunchKernelGGL((leaf_tiles_kernel<T, BM, CT>), grid, dim3(256), lds, st, linv_p, xs_p, xnorm,
+                     alpha, leaves_s, lnorm, part_var, part_mean, (int)(npad / 16), dp4, mpad, nbi,
+                     kp.kernel, (T)kp.variance);
+}
+template void launch_leaf_tiles<float>(hipStream_t, const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, int64_t, int, int64_t, const KernParams&);
+template void launch_leaf_tiles<double>(hipStream_t, const double*, const double*, const double*, const double*, const double*, const double*, double*, double*, int64_t, int, int64_t, const KernParams&);
+
+template <typename T>
+void launch_leaf_finalize(hipStream_t st, const T* part_var, const T* part_mean, int nbi,
+                          int64_t mpad, int64_t m, const KernParams& kp, double varsigma,
+                          double* mean, double* var, double* ucb) {
+  const int64_t blocks = (m + 255) / 256;
+  if (blocks == 0) return;
+  hipLaunchKernelGGL((leaf_finalize_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, part_var,
+                     part_mean, nbi, mpad, m, kp, varsigma, mean, var, ucb);
+}
+template void launch_leaf_finalize<float>(hipStream_t, const float*, const float*, int, int64_t, int64_t, const KernParams&, double, double*, double*, double*);
+template void launch_leaf_finalize<double>(hipStream_t, const double*, const double*, int, int64_t, int64_t, const KernParams&, double, double*, double*, double*);
+
+void launch_seg_argmax(hipStream_t st, const double* mean, const double* var, const double* ucb,
+                       const int64_t* seg_off_dev, int nseg, int nblk, void* partial_dev,
+                       int64_t* out_idx_dev, double* out_vals_dev) {
+  hipLaunchKernelGGL(seg_argmax_stage1, dim3((unsigned)nblk, (unsigned)nseg), dim3(256), 0, st, ucb,
+                     seg_off_dev, reinterpret_cast<Best*>(partial_dev));
+  hipLaunchKernelGGL(seg_argmax_stage2, dim3((unsigned)nseg), dim3(256), 0, st,
+                     reinterpret_cast<const Best*>(partial_dev), nblk, seg_off_dev, mean, var, ucb,
+                     out_idx_dev, out_vals_dev);
+}
+
+}  // namespace gpso

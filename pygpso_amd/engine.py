@@ -1,0 +1,222 @@
+"""
+``HipGPEngine``: one GP posterior resident on one MI355X, driven through the C-ABI.
+
+It plays the role the ``gpflow.models.GPR`` object plays for the reference
+(``gpso/gp_surrogate.py:488-503``): it owns the training data, the hyper-parameters and the
+factorisation, evaluates the training loss (+ gradient) and answers ``predict_y``.  All arithmetic
+happens in the hand-written HIP kernels of ``libgpso_hip.so``; this file only marshals pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _is_device_tensor(x):
+    return hasattr(x, "data_ptr") and getattr(x, "is_cuda", False)
+
+
+class HipGPEngine:
+    def __init__(self, dtype="float64", device=0):
+        self._lib = L.load()
+        self.dtype = {"float64": L.F64, "fp64": L.F64, "f64": L.F64, np.float64: L.F64,
+                      "float32": L.F32, "fp32": L.F32, "f32": L.F32, np.float32: L.F32}[dtype]
+        self.device = int(device)
+        handle = C.c_void_p()
+        rc = self._lib.gpso_create(C.byref(handle), self.device, self.dtype)
+        if rc != L.OK:
+            raise L.GpsoHipError(rc, self._lib.gpso_last_error(None).decode())
+        self._h = handle
+        self.n = 0
+        self.d = 0
+
+    # -- plumbing ----------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gpso_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc < 0:
+            msg = self._lib.gpso_last_error(self._h).decode()
+            if rc == L.E_NOTPD:
+                raise np.linalg.LinAlgError(msg)
+            if rc == L.E_ARG:
+                raise ValueError(msg)
+            raise L.GpsoHipError(rc, msg)
+        return rc
+
+    def set_stream(self, stream_ptr):
+        """Run on an existing hipStream_t (int pointer, e.g. torch.cuda.Stream().cuda_stream)."""
+        self._check(self._lib.gpso_set_stream(self._h, C.c_void_p(stream_ptr or None)))
+
+    def synchronize(self):
+        self._check(self._lib.gpso_synchronize(self._h))
+
+    def last_ms(self, what=0):
+        return float(self._lib.gpso_last_ms(self._h, int(what)))
+
+    @property
+    def padded_n(self):
+        return int(self._lib.gpso_padded_n(self._h))
+
+    # -- fit ---------------------------------------------------------------------------------
+    def set_data(self, X, y):
+        X = L.as_f64(X)
+        if X.ndim != 2:
+            raise ValueError("X must be [N, D]")
+        y = L.as_f64(np.asarray(y).reshape(-1), (X.shape[0],))
+        self._check(self._lib.gpso_set_data(self._h, L.dptr(X), L.dptr(y), X.shape[0], X.shape[1]))
+        self.n, self.d = X.shape
+
+    @staticmethod
+    def _theta_args(kernel, lengthscales, variance, noise, mean_c):
+        kid = L.KERNEL_IDS[kernel] if isinstance(kernel, str) else int(kernel)
+        ls = L.as_f64(np.atleast_1d(lengthscales))
+        return kid, ls, int(ls.shape[0]), float(variance), float(noise), float(mean_c)
+
+    def fit_eval(self, kernel, lengthscales, variance, noise, mean_c, want_grad=True):
+        """One NLML (+ gradient w.r.t. the constrained hyper-parameters) evaluation; leaves the
+        posterior resident.  Returns (nlml, grad or None); grad order (ls..., variance, noise, c)."""
+        kid, ls, n_ls, var, nz, mc = self._theta_args(kernel, lengthscales, variance, noise, mean_c)
+        nlml = C.c_double()
+        grad = np.empty(n_ls + 3, dtype=np.float64) if want_grad else None
+        self._check(self._lib.gpso_fit_eval(self._h, kid, L.dptr(ls), n_ls, var, nz, mc,
+                                            C.byref(nlml), L.dptr(grad) if want_grad else None))
+        return nlml.value, grad
+
+    def set_posterior(self, X, Lchol, alpha, kernel, lengthscales, variance, noise, mean_c):
+        X = L.as_f64(X)
+        n, d = X.shape
+        Lc = L.as_f64(Lchol, (n, n))
+        al = L.as_f64(np.asarray(alpha).reshape(-1), (n,))
+        kid, ls, n_ls, var, nz, mc = self._theta_args(kernel, lengthscales, variance, noise, mean_c)
+        self._check(self._lib.gpso_set_posterior(self._h, L.dptr(X), L.dptr(Lc), L.dptr(al), n, d,
+                                                 kid, L.dptr(ls), n_ls, var, nz, mc))
+        self.n, self.d = n, d
+
+    # -- predict -----------------------------------------------------------------------------
+    def _leaf_args(self, xs):
+        """-> (pointer, xs_dtype, xs_mem, M, keepalive)"""
+        if _is_device_tensor(xs):
+            if xs.dim() != 2 or not xs.is_contiguous():
+                raise ValueError("device leaves must be a contiguous [M, D] tensor")
+            name = str(xs.dtype)
+            if name.endswith("float64"):
+                dt = L.F64
+            elif name.endswith("float32"):
+                dt = L.F32
+            else:
+                raise ValueError(f"unsupported leaf dtype {xs.dtype}")
+            if xs.shape[1] != self.d:
+                raise ValueError(f"leaves have D={xs.shape[1]}, model has D={self.d}")
+            return C.c_void_p(xs.data_ptr()), dt, L.MEM_DEVICE, int(xs.shape[0]), xs
+        a = np.asarray(xs)
+        if a.ndim != 2:
+            raise ValueError("leaves must be [M, D]")
+        if a.shape[0] and a.shape[1] != self.d:
+            raise ValueError(f"leaves have D={a.shape[1]}, model has D={self.d}")
+        if a.dtype == np.float32:
+            a = np.ascontiguousarray(a)
+            dt = L.F32
+        else:
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            dt = L.F64
+        return C.c_void_p(a.ctypes.data), dt, L.MEM_HOST, int(a.shape[0]), a
+
+    def predict(self, xs, out=None):
+        """predict_y: (mean[M], var[M]) float64; var includes the noise variance.  ``out`` may be a
+        pair of float64 CUDA tensors of length M to keep the results on the device."""
+        ptr, dt, mem, m, keep = self._leaf_args(xs)
+        if out is not None:
+            mean_t, var_t = out
+            self._check(self._lib.gpso_predict(self._h, ptr, dt, mem, m, C.c_void_p(mean_t.data_ptr()),
+                                               C.c_void_p(var_t.data_ptr()), L.MEM_DEVICE))
+            return mean_t, var_t
+        mean = np.empty(m, dtype=np.float64)
+        var = np.empty(m, dtype=np.float64)
+        self._check(self._lib.gpso_predict(self._h, ptr, dt, mem, m, C.c_void_p(mean.ctypes.data),
+                                           C.c_void_p(var.ctypes.data), L.MEM_HOST))
+        return mean, var
+
+    def best_ucb(self, xs, varsigma, seg_off=None):
+        """gp_eval_best_ucb per segment -> (idx, mean, var, ucb) arrays of length nseg."""
+        ptr, dt, mem, m, keep = self._leaf_args(xs)
+        if seg_off is None:
+            nseg, so_ptr = 1, None
+        else:
+            so = np.ascontiguousarray(seg_off, dtype=np.int64)
+            nseg, so_ptr = int(so.shape[0] - 1), L.i64ptr(so)
+        idx = np.empty(nseg, dtype=np.int64)
+        mean = np.empty(nseg, dtype=np.float64)
+        var = np.empty(nseg, dtype=np.float64)
+        ucb = np.empty(nseg, dtype=np.float64)
+        self._check(self._lib.gpso_best_ucb(self._h, ptr, dt, mem, m, so_ptr, nseg, float(varsigma),
+                                            L.i64ptr(idx), L.dptr(mean), L.dptr(var), L.dptr(ucb)))
+        return idx, mean, var, ucb
+
+    # -- ternary geometry ------------------------------------------------------------------------
+    def grow_rows(self, depth):
+        return int(self._lib.gpso_grow_rows(int(depth)))
+
+    def grow(self, bounds, depth):
+        """bounds [nseg, D, 2] (or [D, 2]) -> centres [nseg, rows, D] (or [rows, D]) float64."""
+        b = L.as_f64(bounds)
+        single = b.ndim == 2
+        if single:
+            b = b[None]
+        nseg, d, two = b.shape
+        assert two == 2
+        rows = self.grow_rows(depth)
+        out = np.empty((nseg, rows, d), dtype=np.float64)
+        self._check(self._lib.gpso_grow(self._h, L.dptr(b), nseg, d, int(depth), L.dptr(out)))
+        return out[0] if single else out
+
+    def best_ucb_grow(self, bounds, depth, varsigma):
+        b = L.as_f64(bounds)
+        if b.ndim == 2:
+            b = b[None]
+        nseg, d, _ = b.shape
+        if d != self.d:
+            raise ValueError(f"bounds have D={d}, model has D={self.d}")
+        idx = np.empty(nseg, dtype=np.int64)
+        mean = np.empty(nseg, dtype=np.float64)
+        var = np.empty(nseg, dtype=np.float64)
+        ucb = np.empty(nseg, dtype=np.float64)
+        self._check(self._lib.gpso_best_ucb_grow(self._h, L.dptr(b), nseg, int(depth), float(varsigma),
+                                                 L.i64ptr(idx), L.dptr(mean), L.dptr(var), L.dptr(ucb)))
+        return idx, mean, var, ucb
+
+    # -- introspection -----------------------------------------------------------------------
+    def get_matrix(self, which):
+        out = np.empty((self.n, self.n), dtype=np.float64)
+        self._check(self._lib.gpso_get_matrix(self._h, int(which), L.dptr(out)))
+        return out
+
+    def get_vector(self, which):
+        out = np.empty(self.n, dtype=np.float64)
+        self._check(self._lib.gpso_get_vector(self._h, int(which), L.dptr(out)))
+        return out
+
+    def posterior_buffers(self):
+        """[(device_ptr, nbytes), ...] of what a peer rank needs to predict."""
+        ptrs = (C.c_void_p * 8)()
+        nb = (C.c_int64 * 8)()
+        cnt = self._check(self._lib.gpso_posterior_buffers(self._h, ptrs, nb, 8))
+        return [(int(ptrs[i] or 0), int(nb[i])) for i in range(cnt)]
+
+    def alloc_posterior(self, n, d):
+        self._check(self._lib.gpso_alloc_posterior(self._h, int(n), int(d)))
+        self.n, self.d = int(n), int(d)
+
+    def adopt_posterior(self):
+        self._check(self._lib.gpso_adopt_posterior(self._h))
