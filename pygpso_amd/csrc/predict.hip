@@ -173,7 +173,11 @@ __global__ __launch_bounds__(256) void leaf_finalize_kernel(const T* __restrict_
   mean[j] = my;
   var[j] = vy;
   // gpso/gp_surrogate.py:326  ucb = mean + varsigma * var  (two roundings, as numpy does)
-  if (ucb) ucb[j] = __dadd_rn(my, __dmul_rn(varsigma, vy));
+  if (ucb) {
+    double prod = varsigma * vy;
+    asm volatile("" : "+v"(prod));  // keep the product rounded on its own: no fma contraction
+    ucb[j] = my + prod;
+  }
 }
 
 // np.argmax semantics: first maximum wins; NaN counts as the maximum (first NaN wins)

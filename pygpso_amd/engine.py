@@ -117,13 +117,13 @@ class HipGPEngine:
                 dt = L.F32
             else:
                 raise ValueError(f"unsupported leaf dtype {xs.dtype}")
-            if xs.shape[1] != self.d:
+            if self.d and xs.shape[1] != self.d:
                 raise ValueError(f"leaves have D={xs.shape[1]}, model has D={self.d}")
             return C.c_void_p(xs.data_ptr()), dt, L.MEM_DEVICE, int(xs.shape[0]), xs
         a = np.asarray(xs)
         if a.ndim != 2:
             raise ValueError("leaves must be [M, D]")
-        if a.shape[0] and a.shape[1] != self.d:
+        if self.d and a.shape[0] and a.shape[1] != self.d:
             raise ValueError(f"leaves have D={a.shape[1]}, model has D={self.d}")
         if a.dtype == np.float32:
             a = np.ascontiguousarray(a)

@@ -1,0 +1,384 @@
+"""
+GP surrogate of the objective surface -- the drop-in boundary of the hot path.
+
+Mirrors the reference's operator interface (names, argument meaning, error behaviour):
+
+* ``GPPoint`` .............. gpso/gp_surrogate.py:24-36
+* ``GPListOfPoints`` ....... gpso/gp_surrogate.py:39-118  (1e-12 L2 duplicate rule)
+* ``GPSurrogate`` .......... gpso/gp_surrogate.py:121-385 (append / gp_predict / gp_eval_best_ucb /
+                             gp_update / properties)
+* ``GPRSurrogate`` ......... gpso/gp_surrogate.py:388-533 (exact GP regression; ``_gp_train``)
+
+What differs is underneath: ``gpflow_model`` is a ``HipGPR`` whose training loss, gradient and
+``predict_y`` run as HIP kernels on the MI355X (pygpso_amd/csrc), the point store answers the
+duplicate queries with one vectorised pass over a coordinate array instead of a Python scan, and
+``gp_eval_best_ucb_grow`` scores whole ternary sub-trees without materialising them on the host.
+``VGPSurrogate`` (variational GP) is out of scope.
+"""
+from __future__ import annotations
+
+import json
+import logging
+import os
+from collections import namedtuple
+
+import numpy as np
+from scipy.special import erfcinv
+
+from .kernels import KERNEL_CLASSES, Constant, Kernel, Matern52, MeanFunction, Scipy, Zero
+from .model import HipGPR
+from .utils import JSON_EXT, PointLabels
+
+DUPLICATE_TOLERANCE = 1.0e-12
+NORM_PARAMS_BOUNDS = (0, 1)
+
+
+
+class GPPoint(namedtuple("GPPoint", ["normed_coord", "score_mu", "score_sigma", "score_ucb", "label"])):
+    """One stored point: normalised coordinates, mean score, VARIANCE (the field is called
+    score_sigma in the reference but holds the variance, gpso/gp_surrogate.py:305), UCB, label.
+    Equality compares the coordinate arrays element-wise."""
+
+    __slots__ = ()
+
+    def __eq__(self, other):
+        if not isinstance(other, tuple) or len(other) != len(self):
+            return False
+        return bool(np.array_equal(self[0], other[0])) and tuple(self[1:]) == tuple(other[1:])
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+
+class GPListOfPoints(list):
+    """List of ``GPPoint`` whose ``append`` de-duplicates by coordinates.
+
+    Same observable behaviour as the reference: a new point within 1e-12 (L2) of stored points
+    replaces every such point that is not ``evaluated`` and is not appended; the constructor does
+    not de-duplicate.  The distance test runs vectorised over a coordinate matrix kept beside the
+    list.  ``append`` additionally RETURNS the index the point now lives at (first duplicate, or
+    the new last position)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        assert all(isinstance(p, GPPoint) for p in self)
+        self._coords = None
+        self._n = 0
+        self._dirty = True
+
+    # -- coordinate matrix kept in sync -----------------------------------------------------------
+    def _matrix(self):
+        if self._dirty or self._coords is None or self._n != len(self):
+            n = len(self)
+            if n:
+                d = int(np.size(self[0].normed_coord))
+                cap = max(64, 2 * n)
+                self._coords = np.empty((cap, d), dtype=np.float64)
+                for i, p in enumerate(self):
+                    self._coords[i] = p.normed_coord
+            else:
+                self._coords = None
+            self._n = n
+            self._dirty = False
+        return None if self._coords is None else self._coords[: self._n]
+
+    def _matches(self, coords):
+        mat = self._matrix()
+        if mat is None:
+            return np.empty(0, dtype=np.int64)
+        diff = mat - np.asarray(coords, dtype=np.float64).reshape(1, -1)
+        dist = np.sqrt(np.einsum("ij,ij->i", diff, diff))
+        return np.flatnonzero(dist < DUPLICATE_TOLERANCE)
+
+    def __setitem__(self, idx, value):
+        super().__setitem__(idx, value)
+        if isinstance(idx, int) and not self._dirty and self._coords is not None and -self._n <= idx < self._n:
+            self._coords[idx] = value.normed_coord
+        else:
+            self._dirty = True
+
+
+    # -- reference API ----------------------------------------------------------------------------
+    def append(self, point):
+        assert isinstance(point, GPPoint)
+        hits = self._matches(point.normed_coord)
+        if hits.size:
+            for i in hits:
+                if self[int(i)].label != PointLabels.evaluated:
+                    self[int(i)] = point
+            return int(hits[0])
+        self._matrix()
+        n = len(self)
+        if self._coords is None or n >= self._coords.shape[0] or self._coords.shape[1] != np.size(point.normed_coord):
+            super().append(point)
+            self._dirty = True
+            return n
+        self._coords[n] = point.normed_coord
+        super().append(point)
+        self._n = n + 1
+        return n
+
+    def find_index_by_coords(self, coords):
+        hits = self._matches(coords)
+        return int(hits[0]) if hits.size else None
+
+    def find_by_coords(self, coords):
+        i = self.find_index_by_coords(coords)
+        return None if i is None else self[i]
+
+    # -- persistence (same JSON schema as the reference, gpso/gp_surrogate.py:103-118) ------------
+    def save(self, filename):
+        if not filename.endswith(JSON_EXT):
+            filename += JSON_EXT
+        rows = []
+        for p in self:
+            rows.append({
+                "normed_coord": np.asarray(p.normed_coord).tolist(),
+                "score_mu": float(p.score_mu),
+                "score_sigma": float(p.score_sigma),
+                "score_ucb": float(p.score_ucb),
+                "label": p.label.name,
+            })
+        with open(filename, "w") as fh:
+            fh.write(json.dumps(rows))
+
+    @classmethod
+    def from_file(cls, filename):
+        if not filename.endswith(JSON_EXT):
+            filename += JSON_EXT
+        with open(filename) as fh:
+            rows = json.load(fh)
+        return cls([
+            GPPoint(np.array(r["normed_coord"]), r["score_mu"], r["score_sigma"], r["score_ucb"],
+                    PointLabels[r["label"]])
+            for r in rows
+        ])
+
+
+def _invalidating(name):
+    base = getattr(list, name)
+
+    def method(self, *args, **kwargs):
+        self._dirty = True
+        return base(self, *args, **kwargs)
+
+    method.__name__ = name
+    return method
+
+
+for _name in ("extend", "insert", "pop", "remove", "clear", "sort", "reverse", "__delitem__", "__iadd__"):
+    setattr(GPListOfPoints, _name, _invalidating(_name))
+del _name
+
+
+class GPSurrogate:
+    """Base class: point bookkeeping + predict/UCB on top of ``self.gpflow_model``."""
+
+    POINTS_FILE = f"points{JSON_EXT}"
+    GPR_FILE = f"GPRmodel{JSON_EXT}"
+    GPR_INFO = f"GPRinfo{JSON_EXT}"
+
+    @classmethod
+    def from_saved(cls, folder):
+        raise NotImplementedError
+
+    def __init__(self, gp_kernel, gp_meanf=None, optimiser=None, varsigma=erfcinv(0.01), points=None,
+                 gpflow_model=None, dtype="float64", device=0):
+        """
+        :param gp_kernel: kernel spec (``pygpso_amd.kernels.Matern52(...)`` etc.)
+        :param gp_meanf: mean-function spec (``Constant(c)``) or None
+        :param optimiser: object with ``minimize(closure, variables)``; default ``Scipy()`` (L-BFGS-B)
+        :param varsigma: UCB = mean + varsigma * VAR (gpso/gp_surrogate.py:150-155,326)
+        :param points: initial list of ``GPPoint``
+        :param gpflow_model: an initialised ``HipGPR`` (used when loading a saved surrogate)
+        :param dtype: arithmetic type of the device kernels, "float64" (parity) or "float32"
+        :param device: HIP device index
+        """
+        self.gpflow_model = gpflow_model
+        self.gp_varsigma = float(varsigma)
+        assert isinstance(gp_kernel, Kernel)
+        self.gp_kernel = gp_kernel
+        assert gp_meanf is None or isinstance(gp_meanf, MeanFunction)
+        self.gp_meanf = gp_meanf
+        optimiser = optimiser if optimiser is not None else Scipy()
+        assert hasattr(optimiser, "minimize")
+        self.optimiser = optimiser
+        self.dtype = dtype
+        self.device = device
+        self.points = GPListOfPoints(points or list())
+
+    # -- bookkeeping properties (gpso/gp_surrogate.py:174-257) -----------------------------------
+    def _with_label(self, label):
+        return [p for p in self.points if p.label == label]
+
+    @property
+    def num_evaluated(self):
+        return len(self._with_label(PointLabels.evaluated))
+
+    @property
+    def num_gp_based(self):
+        return len(self._with_label(PointLabels.gp_based))
+
+    @property
+    def highest_score(self):
+        cand = self._with_label(PointLabels.evaluated)
+        if cand:
+            return max(cand, key=lambda p: p.score_mu)  # max() keeps the first of equal maxima
+
+    @property
+    def highest_ucb(self):
+        cand = self._with_label(PointLabels.gp_based)
+        if cand:
+            return max(cand, key=lambda p: p.score_ucb)
+
+    @property
+    def current_training_data(self):
+        ev = self._with_label(PointLabels.evaluated)
+        return np.array([p.normed_coord for p in ev]), np.array([p.score_mu for p in ev])
+
+    @property
+    def gp_based_coords(self):
+        return np.array([p.normed_coord for p in self._with_label(PointLabels.gp_based)])
+
+    # -- training-data intake ----------------------------------------------------------------------
+    def _gp_train(self, x, y):
+        raise NotImplementedError
+
+    def append(self, coords, scores):
+        """Store evaluated points (normalised coordinates [n, D], scores [n])."""
+        assert coords.ndim == 2
+        assert scores.ndim == 1
+        assert coords.shape[0] == scores.shape[0]
+        for c, s in zip(coords, scores):
+            self.points.append(GPPoint(c, s, 0.0, 0.0, PointLabels.evaluated))
+
+    # -- predict / UCB ------------------------------------------------------------------------------
+    def _require_model(self):
+        assert isinstance(self.gpflow_model, HipGPR), "GP model not trained yet"
+
+    def gp_predict(self, normed_coords):
+        """predict_y at ``normed_coords`` and store every row as a gp_based point."""
+        self._require_model()
+        mean, var = self.gpflow_model.predict_y(normed_coords)
+        for i in range(normed_coords.shape[0]):
+            m, v = float(mean[i, 0]), float(var[i, 0])
+            self.points.append(GPPoint(normed_coords[i, :], m, v, float(m + self.gp_varsigma * v),
+                                       PointLabels.gp_based))
+
+    def gp_eval_best_ucb(self, normed_coords):
+        """(mean, var, ucb) of the row with the highest ucb = mean + varsigma * var; stores nothing."""
+        self._require_model()
+        _, mean, var, ucb = self.gpflow_model.best_ucb(normed_coords, self.gp_varsigma)
+        return float(mean[0]), float(var[0]), float(ucb[0])
+
+    def gp_eval_best_ucb_grow(self, leaf_bounds, depth):
+        """MI355X path of ``gp_eval_best_ucb(leaf.grow(depth))`` for several leaves at once: the
+        ternary sub-tree centres are generated on the device (bit-identical to ``LeafNode.grow``)
+        and never cross PCIe.  ``leaf_bounds``: [nleaf, D, 2].  Returns a list of (mean, var, ucb)."""
+        self._require_model()
+        _, mean, var, ucb = self.gpflow_model.best_ucb_grow(np.asarray(leaf_bounds, dtype=np.float64),
+                                                             depth, self.gp_varsigma)
+        return [(float(m), float(v), float(u)) for m, v, u in zip(mean, var, ucb)]
+
+    def gp_update(self):
+        """Retrain on the evaluated points, then re-predict every gp_based point."""
+        x_train, y_train = self.current_training_data
+        logging.debug(f"Retraining GPR with x data: {x_train}; y data: {y_train}")
+        self._gp_train(x=x_train, y=y_train[:, np.newaxis])
+        if self.num_gp_based > 0:
+            self.gp_predict(self.gp_based_coords)
+
+    def save(self, folder):
+        raise NotImplementedError
+
+
+class GPRSurrogate(GPSurrogate):
+    """Exact GP regression surrogate (the reference's default)."""
+
+    # hook for tests / multi-GPU: a callable returning the engine object HipGPR should drive
+    # (default None -> a HipGPEngine on ``device``; there is no CPU engine in this package)
+    engine_factory = None
+
+    def __init__(self, gp_kernel, gp_meanf=None, optimiser=None, varsigma=erfcinv(0.01),
+                 gauss_likelihood_sigma=1.0e-3, points=None, gpflow_model=None, dtype="float64",
+                 device=0):
+        """
+        :param gauss_likelihood_sigma: initial noise VARIANCE of the Gaussian likelihood (the
+            reference passes it as ``noise_variance`` despite the name, gpso/gp_surrogate.py:494)
+        """
+        super().__init__(gp_kernel=gp_kernel, gp_meanf=gp_meanf, optimiser=optimiser,
+                         varsigma=varsigma, points=points, gpflow_model=gpflow_model, dtype=dtype,
+                         device=device)
+        self.gp_lik_sigma = gauss_likelihood_sigma
+
+    @classmethod
+    def default(cls, dtype="float64", device=0):
+        """Matern-5/2 (l = 0.25, s2 = 1), constant mean 0, L-BFGS-B, noise 1e-3
+        (gpso/gp_surrogate.py:418-434)."""
+        return cls(
+            gp_kernel=Matern52(lengthscales=np.sum(NORM_PARAMS_BOUNDS) * 0.25, variance=1.0),
+            gp_meanf=Constant(0.0),
+            optimiser=Scipy(),
+            varsigma=erfcinv(0.01),
+            gauss_likelihood_sigma=1.0e-3,
+            dtype=dtype,
+            device=device,
+        )
+
+    def _gp_train(self, x, y):
+        assert x.shape[0] == y.shape[0]
+        assert x.ndim == 2 and y.ndim == 2
+        if self.gpflow_model is None:
+            engine = self.engine_factory() if self.engine_factory is not None else None
+            self.gpflow_model = HipGPR(data=(x, y), kernel=self.gp_kernel, mean_function=self.gp_meanf,
+                                       noise_variance=self.gp_lik_sigma, dtype=self.dtype,
+                                       device=self.device, engine=engine)
+        else:
+            self.gpflow_model.data = (x, y)  # hyper-parameters warm-start from the last optimum
+        self.optimiser.minimize(self.gpflow_model.training_loss, self.gpflow_model.trainable_variables)
+
+    # -- persistence: points JSON (reference schema) + hyper-parameters as plain JSON ---------------
+    def save(self, folder):
+        os.makedirs(folder, exist_ok=True)
+        self.points.save(os.path.join(folder, self.POINTS_FILE))
+        model = self.gpflow_model
+        params = {k: np.asarray(v).tolist() for k, v in model.parameter_dict().items()}
+        with open(os.path.join(folder, self.GPR_FILE), "w") as fh:
+            fh.write(json.dumps(params))
+        info = {
+            "gpr_kernel": model.kernel.name,
+            "gpr_kernel_shape": list(np.shape(model.kernel.lengthscales)),
+            "gpr_meanf": type(model.mean_function).__name__,
+            "gpr_meanf_shape": [],
+            "gp_varsigma": self.gp_varsigma,
+            "gp_likelihood": self.gp_lik_sigma,
+            "optimiser": [type(self.optimiser).__name__],
+            "dtype": self.dtype,
+        }
+        with open(os.path.join(folder, self.GPR_INFO), "w") as fh:
+            fh.write(json.dumps(info))
+
+    @classmethod
+    def from_saved(cls, folder, device=0):
+        points = GPListOfPoints.from_file(os.path.join(folder, cls.POINTS_FILE))
+        ev = [p for p in points if p.label == PointLabels.evaluated]
+        x = np.array([p.normed_coord for p in ev])
+        y = np.array([p.score_mu for p in ev])[:, np.newaxis]
+        with open(os.path.join(folder, cls.GPR_INFO)) as fh:
+            info = json.load(fh)
+        with open(os.path.join(folder, cls.GPR_FILE)) as fh:
+            params = json.load(fh)
+        assert info["gpr_kernel"] in KERNEL_CLASSES
+        kernel = KERNEL_CLASSES[info["gpr_kernel"]](
+            lengthscales=np.array(params[".kernel.lengthscales"]), variance=params[".kernel.variance"])
+        meanf = Constant(params[".mean_function.c"]) if info["gpr_meanf"] == "Constant" else Zero()
+        assert info["optimiser"][0] == "Scipy", f"{info['optimiser']} not currently supported."
+        engine = cls.engine_factory() if cls.engine_factory is not None else None
+        model = HipGPR(data=(x, y), kernel=kernel, mean_function=meanf,
+                       noise_variance=params[".likelihood.variance"], dtype=info.get("dtype", "float64"),
+                       device=device, engine=engine)
+        return cls(gp_kernel=kernel, gp_meanf=meanf, optimiser=Scipy(),
+                   gauss_likelihood_sigma=info["gp_likelihood"], varsigma=info["gp_varsigma"],
+                   points=points, gpflow_model=model, dtype=info.get("dtype", "float64"), device=device)

@@ -1,0 +1,190 @@
+"""
+``HipGPR``: the object the surrogate keeps in ``.gpflow_model``.
+
+Stands where ``gpflow.models.GPR`` stands in the reference (gpso/gp_surrogate.py:488-503,
+298, 325; gpso/plotting.py:351-356 reaches it through ``gp_surr.gpflow_model.predict_y``):
+holds data + hyper-parameters, evaluates ``training_loss`` and answers ``predict_y`` -- by calling
+the HIP engine.  The parameter transforms are GPflow-2's: softplus for
+lengthscales / kernel variance, 1e-6 + softplus for the likelihood variance, identity for the mean.
+"""
+from __future__ import annotations
+
+import types
+
+import numpy as np
+
+from .engine import HipGPEngine
+from .kernels import Constant, Kernel, MeanFunction
+
+NOISE_FLOOR = 1.0e-6  # gpflow.likelihoods.Gaussian DEFAULT_VARIANCE_LOWER_BOUND
+
+
+def _softplus(u):
+    return np.logaddexp(0.0, u)
+
+
+def _softplus_inv(x):
+    x = np.asarray(x, dtype=np.float64)
+    return x + np.log(-np.expm1(-x))
+
+
+def _sigmoid(u):
+    return 0.5 * (1.0 + np.tanh(0.5 * np.asarray(u, dtype=np.float64)))
+
+
+class _Result(np.ndarray):
+    """ndarray that also answers ``.numpy()`` like the tf.Tensor the reference's callers index."""
+
+    def numpy(self):
+        return np.asarray(self)
+
+
+def _as_result(a):
+    return np.asarray(a, dtype=np.float64).reshape(-1, 1).view(_Result)
+
+
+class HipGPR:
+    def __init__(self, data, kernel, mean_function=None, noise_variance=1.0e-3, dtype="float64",
+                 device=0, engine=None):
+        if not isinstance(kernel, Kernel):
+            raise TypeError("kernel must be a pygpso_amd.kernels.Kernel")
+        if mean_function is not None and not isinstance(mean_function, MeanFunction):
+            raise TypeError("mean_function must be a pygpso_amd.kernels.MeanFunction or None")
+        self.kernel = kernel
+        self.mean_function = mean_function if mean_function is not None else Constant(0.0)
+        self._train_mean = isinstance(self.mean_function, Constant)
+        self.likelihood = types.SimpleNamespace(variance=float(noise_variance))
+        self.engine = engine if engine is not None else HipGPEngine(dtype=dtype, device=device)
+        self._data = None
+        self._resident = False  # posterior on the device matches (data, hyper-parameters)?
+        self.num_loss_evals = 0
+        self.data = data
+
+    # -- data ---------------------------------------------------------------------------------
+    @property
+    def data(self):
+        return self._data
+
+    @data.setter
+    def data(self, value):
+        x, y = value
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1, 1)
+        assert x.ndim == 2 and x.shape[0] == y.shape[0]
+        self._data = (x, y)
+        self.engine.set_data(x, y[:, 0])
+        self._resident = False
+
+    # -- hyper-parameters ---------------------------------------------------------------------
+    @property
+    def n_ls(self):
+        return int(np.size(self.kernel.lengthscales))
+
+    def _pack(self):
+        """Unconstrained vector in tf.Module's sorted order: kernel.lengthscales, kernel.variance,
+        likelihood.variance, mean_function.c."""
+        parts = [
+            np.atleast_1d(_softplus_inv(self.kernel.lengthscales)),
+            [float(_softplus_inv(self.kernel.variance))],
+            [float(_softplus_inv(self.likelihood.variance - NOISE_FLOOR))],
+        ]
+        if self._train_mean:
+            parts.append([self.mean_function.c])
+        return np.concatenate(parts).astype(np.float64)
+
+    def _unpack(self, u):
+        u = np.asarray(u, dtype=np.float64)
+        k = self.n_ls
+        ls = _softplus(u[:k])
+        var = float(_softplus(u[k]))
+        noise = NOISE_FLOOR + float(_softplus(u[k + 1]))
+        c = float(u[k + 2]) if self._train_mean else float(self.mean_function.c)
+        return ls, var, noise, c
+
+    def _assign(self, u):
+        ls, var, noise, c = self._unpack(u)
+        self.kernel.lengthscales = ls.copy() if self.kernel.ard else float(ls[0])
+        self.kernel.variance = var
+        self.likelihood.variance = noise
+        if self._train_mean:
+            self.mean_function.c = c
+        self._resident = False
+
+    @property
+    def trainable_variables(self):
+        return self._pack()
+
+    def _theta(self):
+        return (self.kernel.name, np.atleast_1d(np.asarray(self.kernel.lengthscales, dtype=np.float64)),
+                self.kernel.variance, self.likelihood.variance, float(self.mean_function.c))
+
+    # -- loss ---------------------------------------------------------------------------------
+    def _loss_and_grad(self, u):
+        """f(u), df/du for L-BFGS-B: one device evaluation (Gram -> Cholesky -> ... -> gradient)."""
+        ls, var, noise, c = self._unpack(u)
+        f, g = self.engine.fit_eval(self.kernel.name, ls, var, noise, c, want_grad=True)
+        self.num_loss_evals += 1
+        self._resident = False  # resident for u, not necessarily for the stored hyper-parameters
+        k = self.n_ls
+        gu = np.empty(k + 2 + (1 if self._train_mean else 0))
+        gu[: k + 2] = g[: k + 2] * _sigmoid(np.asarray(u[: k + 2]))
+        if self._train_mean:
+            gu[k + 2] = g[k + 2]
+        return f, gu
+
+    def _ensure_resident(self):
+        if not self._resident:
+            name, ls, var, noise, c = self._theta()
+            self._last_nlml, _ = self.engine.fit_eval(name, ls, var, noise, c, want_grad=False)
+            self._resident = True
+
+    def training_loss(self):
+        """Negative log marginal likelihood at the current hyper-parameters."""
+        self._resident = False
+        self._ensure_resident()
+        return self._last_nlml
+
+    def log_marginal_likelihood(self):
+        return -self.training_loss()
+
+    # -- predict ------------------------------------------------------------------------------
+    def predict_y(self, Xnew):
+        """(mean [M,1], var [M,1]); the variance includes the likelihood (noise) variance."""
+        self._ensure_resident()
+        mean, var = self.engine.predict(np.asarray(Xnew))
+        return _as_result(mean), _as_result(var)
+
+    def predict_f(self, Xnew):
+        mean, var = self.predict_y(Xnew)
+        return mean, _as_result(np.asarray(var) - self.likelihood.variance)
+
+    def best_ucb(self, Xnew, varsigma, seg_off=None):
+        self._ensure_resident()
+        return self.engine.best_ucb(Xnew, varsigma, seg_off)
+
+    def best_ucb_grow(self, bounds, depth, varsigma):
+        self._ensure_resident()
+        return self.engine.best_ucb_grow(bounds, depth, varsigma)
+
+    # -- reporting ----------------------------------------------------------------------------
+    def parameter_dict(self):
+        return {
+            ".kernel.lengthscales": np.asarray(self.kernel.lengthscales, dtype=np.float64),
+            ".kernel.variance": np.float64(self.kernel.variance),
+            ".likelihood.variance": np.float64(self.likelihood.variance),
+            ".mean_function.c": np.float64(self.mean_function.c),
+        }
+
+    def summary(self):
+        """Plain-text parameter table in the column order GPflow's print_summary uses."""
+        rows = [
+            ("GPR.mean_function.c", "", self.mean_function.c),
+            ("GPR.kernel.variance", "Softplus", self.kernel.variance),
+            ("GPR.kernel.lengthscales", "Softplus", self.kernel.lengthscales),
+            ("GPR.likelihood.variance", "Softplus + Shift", self.likelihood.variance),
+        ]
+        lines = [f"{'name':<24} {'transform':<17} {'value'}"]
+        for name, tr, val in rows:
+            v = np.array2string(np.asarray(val), precision=6) if np.ndim(val) else f"{val:.6g}"
+            lines.append(f"{name:<24} {tr:<17} {v}")
+        return "\n".join(lines)

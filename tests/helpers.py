@@ -56,7 +56,8 @@ def synthetic_problem(n, d, seed=0, noise=1e-2):
     w = rng.normal(size=(3, d))
     f = (np.sin(2.0 * X @ w[0]) + np.cos(1.5 * X @ w[1]) * np.exp(-0.5 * np.sum((X - 0.4) ** 2, axis=1))
          + 0.3 * (X @ w[2]))
-    f = (f - f.mean()) / f.std()
+    if n > 1:
+        f = (f - f.mean()) / f.std()
     y = f + noise * rng.normal(size=n)
     return X, y
 

@@ -1,0 +1,80 @@
+"""CPU-only checks of the C-ABI boundary: the library builds, loads, exports every symbol the
+header declares, and the product fails loudly (no fallback) when there is no GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as entry
+    from pygpso_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        entry.build()
+    return _lib.load()
+
+
+def _declared_symbols():
+    with open(os.path.join(ROOT, "include", "gpso_hip.h")) as fh:
+        text = re.sub(r"/\*.*?\*/", "", fh.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(gpso_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported_and_bound(lib):
+    from pygpso_amd import _lib
+
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/gpso_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == declared, "ctypes prototypes out of sync with the header"
+
+
+def test_host_only_entry_points(lib):
+    assert lib.gpso_version().decode().startswith("gpso-hip")
+    assert [lib.gpso_grow_rows(d) for d in (0, 1, 2, 5, 8)] == [0, 1, 4, 121, 3280]
+
+
+def test_status_codes_match_header():
+    from pygpso_amd import _lib
+
+    with open(os.path.join(ROOT, "include", "gpso_hip.h")) as fh:
+        text = fh.read()
+    for name, val in re.findall(r"#define (GPSO_[A-Z0-9_]+) \(?(-?\d+)\)?", text):
+        short = name[len("GPSO_"):]
+        assert getattr(_lib, short) == int(val), name
+
+
+def _no_gpu():
+    import torch
+
+    return torch.cuda.device_count() == 0
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="only meaningful without a GPU")
+def test_fails_loudly_without_gpu(lib):
+    from pygpso_amd import GPRSurrogate, HipGPEngine, _lib
+
+    with pytest.raises(_lib.GpsoHipError) as err:
+        HipGPEngine("float64")
+    assert err.value.code == _lib.E_HIP
+    surr = GPRSurrogate.default()
+    x = np.random.default_rng(0).random((5, 2))
+    with pytest.raises(_lib.GpsoHipError):
+        surr._gp_train(x, np.ones((5, 1)))  # no silent CPU path
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "pygpso_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                with open(os.path.join(dirpath, f)) as fh:
+                    src = fh.read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "from tests" not in src and "import tests" not in src, f

@@ -1,0 +1,137 @@
+"""
+The reference's own known-answer tests, run against the HIP path (float64) through the drop-in
+classes.  Bodies follow tests/test_gp_surrogate.py:259-347 and tests/test_optimisation.py:66-152
+of the reference; expected values come from tests/golden/reference_goldens.json.
+"""
+import os
+from shutil import rmtree
+
+import numpy as np
+import pytest
+
+from tests.helpers import kat_fixture, load_goldens, rotated_peaks
+
+pytestmark = pytest.mark.gpu
+G = load_goldens()
+TMP = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_tmp_gpu")
+
+
+def _kat_surrogate():
+    from pygpso_amd import GPPoint, GPRSurrogate, PointLabels
+    from pygpso_amd import kernels as K
+
+    pts = [GPPoint(*p[:4], PointLabels(p[4])) for p in kat_fixture()]
+    return GPRSurrogate(gp_kernel=K.Matern52(), gp_meanf=K.Constant(), points=pts)
+
+
+def test_G1_gp_train():
+    s = _kat_surrogate()
+    x, y = s.current_training_data
+    s._gp_train(x=x, y=y[:, np.newaxis])
+    mean, var = s.gpflow_model.predict_y(np.array([[0.5, 0.5]]))
+    assert float(np.around(mean[0, 0], decimals=8)) == G["G1"]["mean"]
+    assert float(np.around(var[0, 0], decimals=8)) == G["G1"]["var"]
+
+
+def test_G1_gp_train_and_predict():
+    s = _kat_surrogate()
+    x, y = s.current_training_data
+    s._gp_train(x=x, y=y[:, np.newaxis])
+    at = np.array([[0.5, 0.5]])
+    s.gp_predict(at)
+    assert len(s.points) == 11
+    p = s.points[-1]
+    np.testing.assert_equal(p.normed_coord, at.squeeze())
+    assert float(np.around(p.score_mu, decimals=8)) == G["G1"]["mean"]
+    assert float(np.around(p.score_sigma, decimals=8)) == G["G1"]["var"]
+
+
+def test_G2_gp_eval_best_ucb():
+    s = _kat_surrogate()
+    exp_ucb = np.around(G["G2"]["mean"] + s.gp_varsigma * G["G2"]["var"], decimals=8)
+    x, y = s.current_training_data
+    s._gp_train(x=x, y=y[:, np.newaxis])
+    best = s.gp_eval_best_ucb(np.array(G["G2"]["predict_at"]))
+    assert float(np.around(best[0], decimals=8)) == G["G2"]["mean"]
+    assert float(np.around(best[1], decimals=8)) == G["G2"]["var"]
+    assert float(np.around(best[2], decimals=8)) == exp_ucb
+    assert len(s.points) == 10
+
+
+def test_surrogate_save_load_bit_equal_predictions():
+    from pygpso_amd import GPRSurrogate
+
+    s = _kat_surrogate()
+    x, y = s.current_training_data
+    s._gp_train(x=x, y=y[:, np.newaxis])
+    s.save(TMP)
+    try:
+        loaded = GPRSurrogate.from_saved(TMP)
+        m1, v1 = s.gpflow_model.predict_y(x)
+        m2, v2 = loaded.gpflow_model.predict_y(x)
+        np.testing.assert_equal(m1.numpy(), m2.numpy())
+        np.testing.assert_equal(v1.numpy(), v2.numpy())
+        assert list(s.points) == list(loaded.points)
+    finally:
+        rmtree(TMP)
+
+
+def _optimiser(depth, budget):
+    from pygpso_amd import GPSOptimiser, ParameterSpace
+
+    space = ParameterSpace(parameter_names=["x", "y"], parameter_bounds=G["G4"]["bounds"])
+    return GPSOptimiser(parameter_space=space, exploration_method="tree", exploration_depth=depth,
+                        budget=budget, stopping_condition="evaluations", update_cycle=1, n_workers=1)
+
+
+def test_G4_optimise_v1():
+    opt = _optimiser(G["G4"]["depth"], G["G4"]["budget"])
+    best = opt.run(rotated_peaks)
+    np.testing.assert_almost_equal(G["G4"]["best_coords"], best.normed_coord)
+    assert np.around(best.score_mu, decimals=8) == G["G4"]["best_score"]
+
+
+def test_G5_optimise_resume_and_saved():
+    from pygpso_amd import GPSOptimiser
+
+    opt = _optimiser(G["G4"]["depth"], 25)
+    opt.run(rotated_peaks)
+    opt.save_state(TMP)
+    try:
+        best = opt.resume_run(additional_budget=25)
+        np.testing.assert_almost_equal(G["G4"]["best_coords"], best.normed_coord)
+        assert np.around(best.score_mu, decimals=8) == G["G4"]["best_score"]
+        best2, _ = GPSOptimiser.resume_from_saved(TMP, additional_budget=25, objective_function=rotated_peaks)
+        np.testing.assert_almost_equal(G["G4"]["best_coords"], best2.normed_coord)
+        assert np.around(best2.score_mu, decimals=8) == G["G4"]["best_score"]
+    finally:
+        rmtree(TMP)
+
+
+def test_G6_G7_notebook_trace_and_hyperparameters():
+    thetas = []
+
+    from pygpso_amd import GPSOCallback
+    from pygpso_amd.optimisation import CallbackTypes
+
+    class Record(GPSOCallback):
+        callback_type = CallbackTypes.post_update
+
+        def run(self, optimiser):
+            m = optimiser.gp_surr.gpflow_model
+            thetas.append(dict(mean_c=m.mean_function.c, variance=m.kernel.variance,
+                               lengthscale=float(m.kernel.lengthscales), noise=m.likelihood.variance))
+
+    opt = _optimiser(G["G6"]["depth"], G["G6"]["budget"])
+    opt.callbacks = [Record()]
+    best = opt.run(rotated_peaks)
+    assert [t[0] for t in opt.trace] == [t["evaluations"] for t in G["G6"]["trace"]]
+    for got, exp in zip(opt.trace, G["G6"]["trace"]):
+        assert got[1] == exp["highest_score"]  # objective evaluations: bit-for-bit
+        assert abs(got[2] - exp["highest_ucb"]) < 1e-8  # through 14 L-BFGS-B fits on another platform
+    np.testing.assert_almost_equal(best.normed_coord, G["G6"]["best"]["normed_coord"], decimal=8)
+    assert best.score_mu == G["G6"]["best"]["score_mu"]
+    assert len(thetas) == len(G["G7"]["theta_after_each_update"])
+    for got, exp in zip(thetas, G["G7"]["theta_after_each_update"]):
+        for key in ("mean_c", "variance", "lengthscale", "noise"):
+            assert abs(got[key] - exp[key]) <= 6e-6 * abs(exp[key]), (key, got[key], exp[key])

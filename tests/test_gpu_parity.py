@@ -1,0 +1,325 @@
+"""
+GPU parity tests: the HIP path, called through the C-ABI, against the CPU oracle on identical
+seeded inputs.  Run on the GPU box with ``pytest -m gpu``.
+
+Stated tolerances
+  float64 ..... |d mean|, |d var| <= 1e-9 * scale; L, L^-1, alpha, NLML, gradient <= 1e-9 relative
+                (Matern12: 1e-5 -- its sqrt at r = 0 amplifies the rounding noise of the GEMM-form r^2
+                on the diagonal, |r^2| ~ 1e-16 -> r ~ 1e-8, differently in any two implementations)
+  float32 ..... noise/variance ratio >= 1e-3: |d mean| <= 2e-3 * max|y|,
+                |d var| <= 2e-4 * sigma^2, NLML 2e-5 relative; winners compared by oracle-UCB value
+"""
+import numpy as np
+import pytest
+
+from oracle import gpr, tree
+from tests.helpers import synthetic_leaves, synthetic_problem
+
+pytestmark = pytest.mark.gpu
+
+VS = gpr.VARSIGMA_DEFAULT
+
+
+def _engine(dtype="float64"):
+    from pygpso_amd import HipGPEngine
+
+    return HipGPEngine(dtype)
+
+
+def _problem(n, d, kernel="Matern52", noise=1e-3, ard=False, seed=0, variance=1.3):
+    X, y = synthetic_problem(n, d, seed=seed)
+    ls = 0.25 * np.sqrt(d) * (np.linspace(0.8, 1.3, d) if ard else np.ones(1))
+    th = gpr.Theta(kernel, ls, variance, noise, float(y.mean()) if n > 1 else 0.1)
+    return X, y, th
+
+
+def _fit(eng, X, y, th, grad=True):
+    eng.set_data(X, y)
+    return eng.fit_eval(th.kernel, th.lengthscales, th.variance, th.noise, th.mean_c, want_grad=grad)
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(1e-300, np.max(np.abs(b))))
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kernel", ["Matern52", "Matern32", "Matern12", "SquaredExponential"])
+@pytest.mark.parametrize("n,d,ard", [(50, 2, False), (256, 6, False), (300, 5, True), (129, 3, True)])
+def test_fit_stages_fp64(kernel, n, d, ard):
+    from pygpso_amd import _lib as L
+
+    tol = 1e-5 if kernel == "Matern12" else 1e-9
+    X, y, th = _problem(n, d, kernel, ard=ard)
+    post = gpr.posterior(th, X, y)
+    f_ref, g_ref = gpr.nlml_and_grad(th, X, y)
+    eng = _engine()
+    f, g = _fit(eng, X, y, th)
+    Linv_ref = np.linalg.inv(post.L)
+    assert _rel(eng.get_matrix(L.MAT_CHOL), post.L) < tol
+    assert _rel(eng.get_matrix(L.MAT_LINV), Linv_ref) < tol * 10
+    assert _rel(eng.get_matrix(L.MAT_KINV), Linv_ref.T @ Linv_ref) < tol * 10
+    assert _rel(eng.get_vector(L.VEC_ALPHA), post.alpha) < tol * 10
+    assert abs(f - f_ref) <= tol * abs(f_ref)
+    assert g.shape == g_ref.shape
+    assert np.max(np.abs(g - g_ref) / np.maximum(1.0, np.abs(g_ref))) < tol * 10
+
+
+@pytest.mark.parametrize("n,d,m", [(1, 2, 7), (5, 2, 121), (64, 1, 1), (128, 4, 256), (129, 3, 257),
+                                   (256, 6, 4096), (300, 12, 1000), (200, 40, 300), (77, 48, 33)])
+def test_predict_fp64(n, d, m):
+    X, y, th = _problem(n, d)
+    post = gpr.posterior(th, X, y)
+    Xs = synthetic_leaves(m, d)
+    eng = _engine()
+    _fit(eng, X, y, th, grad=False)
+    mean, var = eng.predict(Xs)
+    mean_ref, var_ref = gpr.predict_y(post, Xs)
+    scale = max(1.0, float(np.max(np.abs(y))))
+    assert np.max(np.abs(mean - mean_ref)) <= 1e-9 * scale
+    assert np.max(np.abs(var - var_ref)) <= 1e-9 * th.variance
+    idx, mu, vv, ucb = eng.best_ucb(Xs, VS)
+    i_ref, mu_ref, var_r, ucb_ref = gpr.best_ucb(post, Xs)
+    assert int(idx[0]) == i_ref
+    assert abs(mu[0] - mu_ref) <= 1e-9 * scale and abs(vv[0] - var_r) <= 1e-9 and abs(ucb[0] - ucb_ref) <= 1e-9 * scale
+    # the winner's ucb is exactly mean + varsigma * var of the returned values (two roundings)
+    assert ucb[0] == mu[0] + VS * vv[0]
+
+
+@pytest.mark.parametrize("n,d,m", [(256, 6, 4096), (300, 12, 1000), (2048, 12, 2048)])
+def test_fit_and_predict_fp32(n, d, m):
+    X, y, th = _problem(n, d, noise=1e-3, variance=1.0)
+    post = gpr.posterior(th, X, y)
+    f_ref, g_ref = gpr.nlml_and_grad(th, X, y)
+    Xs = synthetic_leaves(m, d)
+    eng = _engine("float32")
+    f, g = _fit(eng, X, y, th)
+    assert abs(f - f_ref) <= 2e-5 * abs(f_ref)
+    assert np.max(np.abs(g - g_ref) / np.maximum(1.0, np.abs(g_ref))) < 5e-3
+    mean, var = eng.predict(Xs)
+    mean_ref, var_ref = gpr.predict_y(post, Xs)
+    assert np.max(np.abs(mean - mean_ref)) <= 2e-3 * np.max(np.abs(y))
+    assert np.max(np.abs(var - var_ref)) <= 2e-4 * th.variance
+    idx, mu, vv, ucb = eng.best_ucb(Xs, VS)
+    ucb_ref = mean_ref + VS * var_ref
+    assert ucb_ref[int(idx[0])] >= ucb_ref.max() - 4e-3 * np.max(np.abs(y))
+
+
+def test_segments_ragged_empty_and_first_max_ties():
+    X, y, th = _problem(100, 3)
+    post = gpr.posterior(th, X, y)
+    eng = _engine()
+    _fit(eng, X, y, th, grad=False)
+    base = synthetic_leaves(500, 3)
+    # duplicate the overall winner later in the batch: np.argmax must keep the FIRST occurrence
+    i_best = gpr.best_ucb(post, base)[0]
+    Xs = np.vstack([base, base[i_best][None], base[:10]])
+    seg = np.array([0, 0, 1, 257, 500, 501, 511, 511])  # empty, single, ragged ...
+    idx, mu, vv, ucb = eng.best_ucb(Xs, VS, seg)
+    mean_ref, var_ref = gpr.predict_y(post, Xs)
+    ucb_ref = mean_ref + VS * var_ref
+    for s in range(len(seg) - 1):
+        a, b = seg[s], seg[s + 1]
+        if a == b:
+            assert idx[s] == -1 and np.isnan(ucb[s])
+        else:
+            assert idx[s] == int(np.argmax(ucb_ref[a:b])), s
+            assert abs(ucb[s] - ucb_ref[a:b].max()) < 1e-9
+    whole = eng.best_ucb(Xs, VS)
+    assert int(whole[0][0]) == i_best  # not the duplicate at row 500
+    assert ucb[5 - 1] == whole[3][0]  # duplicate row scores bit-identically to the original
+
+
+def test_empty_batch_and_error_paths():
+    from pygpso_amd import _lib as L
+
+    eng = _engine()
+    with pytest.raises(L.GpsoHipError) as e:
+        eng.predict(np.zeros((3, 2)))
+    assert e.value.code == L.E_STATE
+    X, y, th = _problem(20, 2)
+    _fit(eng, X, y, th, grad=False)
+    mean, var = eng.predict(np.zeros((0, 2)))
+    assert mean.shape == (0,) and var.shape == (0,)
+    idx, mu, vv, ucb = eng.best_ucb(np.zeros((0, 2)), VS)
+    assert idx[0] == -1 and np.isnan(mu[0])
+    with pytest.raises(ValueError):
+        eng.predict(np.zeros((3, 5)))  # wrong D
+    with pytest.raises(ValueError):
+        eng.best_ucb(np.zeros((4, 2)), VS, np.array([0, 3]))  # seg_off must end at M
+    with pytest.raises(ValueError):
+        eng.fit_eval("Matern52", [0.3, 0.3, 0.3], 1.0, 1e-3, 0.0)  # n_ls neither 1 nor D
+    with pytest.raises(ValueError):
+        eng.fit_eval("Matern52", [-0.3], 1.0, 1e-3, 0.0)
+    with pytest.raises(KeyError):
+        eng.fit_eval("NoSuchKernel", [0.3], 1.0, 1e-3, 0.0)
+
+
+def test_not_positive_definite_raises_linalgerror():
+    # the reference lets TF's Cholesky failure escape run(); here: LinAlgError naming the pivot
+    X = np.array([[0.1, 0.2], [0.1, 0.2], [0.4, 0.4], [0.7, 0.1]])
+    eng = _engine()
+    eng.set_data(X, np.zeros(4))
+    with pytest.raises(np.linalg.LinAlgError, match="pivot"):
+        eng.fit_eval("SquaredExponential", [0.3], 1.0, -1.0e-3, 0.0)
+    # and the context stays usable afterwards
+    f, _ = eng.fit_eval("SquaredExponential", [0.3], 1.0, 1.0e-3, 0.0)
+    assert np.isfinite(f)
+
+
+def test_deterministic_bitwise():
+    X, y, th = _problem(300, 6)
+    Xs = synthetic_leaves(3000, 6)
+    for dtype in ("float64", "float32"):
+        eng = _engine(dtype)
+        f1, g1 = _fit(eng, X, y, th)
+        a = eng.predict(Xs)
+        f2, g2 = _fit(eng, X, y, th)
+        b = eng.predict(Xs)
+        assert f1 == f2 and np.array_equal(g1, g2)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        eng2 = _engine(dtype)  # a second context gives the same bits
+        _fit(eng2, X, y, th)
+        c = eng2.predict(Xs)
+        assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+
+
+def test_leaf_order_does_not_change_a_leafs_result():
+    X, y, th = _problem(200, 5)
+    Xs = synthetic_leaves(1500, 5)
+    perm = np.random.default_rng(5).permutation(1500)
+    for dtype in ("float64", "float32"):
+        eng = _engine(dtype)
+        _fit(eng, X, y, th, grad=False)
+        m1, v1 = eng.predict(Xs)
+        m2, v2 = eng.predict(Xs[perm])
+        assert np.array_equal(m1[perm], m2) and np.array_equal(v1[perm], v2)
+
+
+def test_set_posterior_interop_matches_device_fit():
+    X, y, th = _problem(150, 4)
+    post = gpr.posterior(th, X, y)
+    Xs = synthetic_leaves(700, 4)
+    eng = _engine()
+    eng.set_posterior(X, post.L, post.alpha, th.kernel, th.lengthscales, th.variance, th.noise, th.mean_c)
+    mean, var = eng.predict(Xs)
+    mean_ref, var_ref = gpr.predict_y(post, Xs)
+    assert np.max(np.abs(mean - mean_ref)) < 1e-9 and np.max(np.abs(var - var_ref)) < 1e-9
+
+
+def test_device_resident_leaves_and_outputs():
+    import torch
+
+    X, y, th = _problem(256, 6)
+    Xs = synthetic_leaves(5000, 6)
+    eng = _engine("float32")
+    _fit(eng, X, y, th, grad=False)
+    m_host, v_host = eng.predict(Xs.astype(np.float32))
+    xs_dev = torch.from_numpy(Xs.astype(np.float32)).cuda()
+    mean_t = torch.empty(5000, dtype=torch.float64, device="cuda")
+    var_t = torch.empty(5000, dtype=torch.float64, device="cuda")
+    eng.predict(xs_dev, out=(mean_t, var_t))
+    assert np.array_equal(mean_t.cpu().numpy(), m_host) and np.array_equal(var_t.cpu().numpy(), v_host)
+    a = eng.best_ucb(xs_dev, VS)
+    b = eng.best_ucb(Xs.astype(np.float32), VS)
+    assert all(np.array_equal(x, y_) for x, y_ in zip(a, b))
+    # float64 leaves into a float32 context are converted on the device
+    c = eng.best_ucb(torch.from_numpy(Xs).cuda(), VS)
+    assert abs(c[3][0] - a[3][0]) < 1e-4
+    # running on a caller-provided stream
+    s = torch.cuda.Stream()
+    eng.set_stream(s.cuda_stream)
+    d = eng.best_ucb(xs_dev, VS)
+    eng.set_stream(None)
+    assert all(np.array_equal(x, y_) for x, y_ in zip(a, d))
+
+
+# ---- ternary generator ---------------------------------------------------------------------------
+@pytest.mark.parametrize("d,depth", [(1, 6), (2, 5), (3, 7), (6, 8), (12, 6), (40, 4)])
+def test_grow_bit_identical(d, depth):
+    rng = np.random.default_rng(d * 100 + depth)
+    boxes = []
+    for _ in range(3):
+        b = [(0.0, 1.0)] * d
+        for _ in range(int(rng.integers(0, 7))):
+            b = tree.split_bounds(b)[int(rng.integers(3))]
+        boxes.append(b)
+    eng = _engine()
+    got = eng.grow(np.array(boxes), depth)
+    assert got.shape == (3, tree.grow_count(depth), d)
+    for s, b in enumerate(boxes):
+        assert np.array_equal(got[s], tree.grow(b, depth)), s
+
+
+def test_best_ucb_grow_equals_scoring_host_grown_leaves():
+    X, y, th = _problem(60, 2)
+    post = gpr.posterior(th, X, y)
+    eng = _engine()
+    _fit(eng, X, y, th, grad=False)
+    kids = tree.split_bounds([(0.0, 1.0), (0.0, 1.0)])
+    boxes = np.array([kids[0], kids[2]])
+    idx, mu, vv, ucb = eng.best_ucb_grow(boxes, 5, VS)
+    for s, b in enumerate((kids[0], kids[2])):
+        coords = tree.grow(b, 5)
+        i_ref, mu_ref, var_ref, ucb_ref = gpr.best_ucb(post, coords)
+        assert int(idx[s]) == i_ref  # first of the duplicated centre rows
+        assert abs(ucb[s] - ucb_ref) < 1e-9
+        one = eng.best_ucb(coords, VS)
+        assert (int(one[0][0]), one[1][0], one[2][0], one[3][0]) == (int(idx[s]), mu[s], vv[s], ucb[s])
+
+
+# ---- BASELINE.json sizes: oracle on a subsample + size-independent properties ----------------------
+def _properties(eng, X, y, th, Xs, post, n_check):
+    m = Xs.shape[0]
+    mean, var = eng.predict(Xs)
+    assert np.all(np.isfinite(mean)) and np.all(np.isfinite(var))
+    # 0 < predictive variance <= prior variance + noise
+    assert var.min() > 0.0 and var.max() <= (th.variance + th.noise) * (1 + 1e-5)
+    # oracle on a random subsample
+    sub = np.random.default_rng(9).choice(m, n_check, replace=False)
+    mean_ref, var_ref = gpr.predict_y(post, Xs[sub])
+    assert np.max(np.abs(mean[sub] - mean_ref)) <= 2e-3 * np.max(np.abs(y))
+    assert np.max(np.abs(var[sub] - var_ref)) <= 2e-4 * th.variance
+    # at the training inputs the posterior interpolates: |mean - y| small, latent variance ~ 0
+    k = min(512, X.shape[0])
+    mt, vt = eng.predict(X[:k])
+    assert np.max(np.abs(mt - y[:k])) < 0.2 and np.all(vt < 4 * th.noise + 1e-3 * th.variance)
+    # the global winner is the best of the per-segment winners
+    seg = np.linspace(0, m, 9).astype(np.int64)
+    idx, mu, vv, ucb = eng.best_ucb(Xs, VS, seg)
+    whole = eng.best_ucb(Xs, VS)
+    j = int(np.argmax(ucb))
+    assert whole[3][0] == ucb[j] and int(whole[0][0]) == seg[j] + idx[j]
+    full_ucb = mean + VS * var
+    assert int(whole[0][0]) == int(np.argmax(full_ucb)) and whole[3][0] == full_ucb.max()
+
+
+def test_config_C2_full_oracle():
+    n, d, m = 256, 6, 4096
+    X, y, th = _problem(n, d, variance=1.0)
+    post = gpr.posterior(th, X, y)
+    Xs = synthetic_leaves(m, d)
+    eng = _engine("float64")
+    _fit(eng, X, y, th)
+    mean, var = eng.predict(Xs)
+    mean_ref, var_ref = gpr.predict_y(post, Xs)
+    assert np.max(np.abs(mean - mean_ref)) < 1e-9 and np.max(np.abs(var - var_ref)) < 1e-9
+    assert int(eng.best_ucb(Xs, VS)[0][0]) == gpr.best_ucb(post, Xs)[0]
+
+
+def test_config_C3_properties_fp32():
+    n, d, m = 2048, 12, 65536
+    X, y, th = _problem(n, d, variance=1.0)
+    post = gpr.posterior(th, X, y)
+    eng = _engine("float32")
+    _fit(eng, X, y, th, grad=False)
+    _properties(eng, X, y, th, synthetic_leaves(m, d), post, 512)
+
+
+def test_config_C4_one_gpu_shard_properties_fp32():
+    n, d, m = 8192, 20, 32768  # 256k leaves / 8 GPUs
+    X, y, th = _problem(n, d, variance=1.0)
+    post = gpr.posterior(th, X, y)
+    eng = _engine("float32")
+    f, _ = _fit(eng, X, y, th, grad=False)
+    assert abs(f - post.nlml) <= 1e-4 * abs(post.nlml)
+    _properties(eng, X, y, th, synthetic_leaves(m, d), post, 128)

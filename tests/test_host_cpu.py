@@ -1,0 +1,308 @@
+"""
+Host-side logic of the drop-in (point store, partition tree, explore/select/update loop, save /
+resume), exercised on CPU with the oracle-backed test double standing in for the HIP engine.
+The test bodies follow the reference's own tests (tests/test_gp_surrogate.py,
+tests/test_param_space.py, tests/test_optimisation.py).
+"""
+import os
+from shutil import rmtree
+
+import numpy as np
+import pytest
+
+from oracle import tree as otree
+from pygpso_amd import (GPListOfPoints, GPPoint, GPRSurrogate, GPSOptimiser, GPSurrogate, LeafNode,
+                        ParameterSpace, PointLabels)
+from pygpso_amd import kernels as K
+from tests.helpers import kat_fixture, load_goldens, rotated_peaks
+from tests.oracle_engine import OracleEngine
+
+G = load_goldens()
+TMP = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_tmp_host")
+
+
+@pytest.fixture(autouse=True)
+def oracle_engine(monkeypatch):
+    monkeypatch.setattr(GPRSurrogate, "engine_factory", OracleEngine)
+    yield
+    if os.path.isdir(TMP):
+        rmtree(TMP)
+
+
+# ---- GPListOfPoints (reference tests/test_gp_surrogate.py:25-110) ---------------------------------
+def _pt(c, mu=1.0, label=PointLabels.gp_based):
+    return GPPoint(np.array(c, dtype=float), mu, 0.5, 0.7, label)
+
+
+def test_points_append_dedup_rules():
+    pts = GPListOfPoints()
+    assert pts.append(_pt([0.1, 0.2], label=PointLabels.evaluated)) == 0
+    assert pts.append(_pt([0.3, 0.2])) == 1
+    assert len(pts) == 2
+    # gp_based duplicate is overwritten in place
+    assert pts.append(_pt([0.3, 0.2], mu=5.0)) == 1 and len(pts) == 2 and pts[1].score_mu == 5.0
+    # evaluated duplicate is never overwritten
+    assert pts.append(_pt([0.1, 0.2], mu=9.0)) == 0 and pts[0].score_mu == 1.0
+    # tolerance is 1e-12 in L2
+    assert pts.find_by_coords(np.array([0.3, 0.2 + 5e-13])) is pts[1]
+    assert pts.find_by_coords(np.array([0.3, 0.2 + 2e-12])) is None
+    # an evaluated point replaces a gp_based one (what _tree_select does)
+    pts.append(_pt([0.3, 0.2], mu=7.0, label=PointLabels.evaluated))
+    assert pts[1].label == PointLabels.evaluated and len(pts) == 2
+    with pytest.raises(AssertionError):
+        pts.append((0.1, 0.2))
+
+
+def test_points_constructor_does_not_dedup_and_all_duplicates_are_replaced():
+    pts = GPListOfPoints([_pt([0.5, 0.5]), _pt([0.5, 0.5]), _pt([0.1, 0.1])])
+    assert len(pts) == 3
+    pts.append(_pt([0.5, 0.5], mu=3.0))
+    assert len(pts) == 3 and pts[0].score_mu == 3.0 and pts[1].score_mu == 3.0
+
+
+def test_points_cache_survives_list_mutation():
+    pts = GPListOfPoints([_pt([0.5, 0.5]), _pt([0.1, 0.1])])
+    assert pts.find_index_by_coords(np.array([0.1, 0.1])) == 1
+    pts.pop(0)
+    assert pts.find_index_by_coords(np.array([0.1, 0.1])) == 0
+    pts.insert(0, _pt([0.9, 0.9]))
+    assert pts.find_index_by_coords(np.array([0.1, 0.1])) == 1
+    for i in range(200):  # growth of the coordinate matrix
+        pts.append(_pt([i / 1000.0, 0.77]))
+    assert pts.find_index_by_coords(np.array([0.199, 0.77])) == 201
+
+
+def test_points_save_load_roundtrip():
+    os.makedirs(TMP, exist_ok=True)
+    pts = GPListOfPoints([GPPoint(*p[:4], PointLabels(p[4])) for p in kat_fixture()])
+    pts.save(os.path.join(TMP, "points"))
+    loaded = GPListOfPoints.from_file(os.path.join(TMP, "points.json"))
+    assert list(loaded) == list(pts)
+
+
+# ---- GPSurrogate base (reference tests/test_gp_surrogate.py:139-189) --------------------------------
+def _fixture_surrogate(cls=GPRSurrogate):
+    pts = [GPPoint(*p[:4], PointLabels(p[4])) for p in kat_fixture()]
+    return cls(gp_kernel=K.Matern52(), gp_meanf=K.Constant(), points=pts)
+
+
+def test_G3_properties():
+    s = _fixture_surrogate(GPSurrogate)
+    assert s.num_evaluated == G["G3"]["num_evaluated"]
+    assert s.num_gp_based == G["G3"]["num_points"] - G["G3"]["num_evaluated"]
+    hi = s.highest_score
+    assert hi.label == PointLabels.evaluated and hi.score_mu == G["G3"]["highest_score"]
+    np.testing.assert_almost_equal(hi.normed_coord, G["G3"]["highest_coords"])
+    x, y = s.current_training_data
+    assert x.shape == (6, 2) and y.shape == (6,)
+    assert s.gp_based_coords.shape == (4, 2)
+    with pytest.raises(NotImplementedError):
+        GPSurrogate.from_saved("")
+    with pytest.raises(NotImplementedError):
+        s._gp_train(None, None)
+    with pytest.raises(NotImplementedError):
+        s.save("")
+
+
+def test_G1_G2_surrogate_interface_with_test_double():
+    s = _fixture_surrogate()
+    x, y = s.current_training_data
+    s._gp_train(x=x, y=y[:, np.newaxis])
+    mean, var = s.gpflow_model.predict_y(np.array(G["G1"]["predict_at"]))
+    assert float(np.around(mean[0, 0], 8)) == G["G1"]["mean"]
+    assert float(np.around(var.numpy()[0, 0], 8)) == G["G1"]["var"]
+    n0 = len(s.points)
+    best = s.gp_eval_best_ucb(np.array(G["G2"]["predict_at"]))
+    assert len(s.points) == n0  # nothing stored
+    assert float(np.around(best[0], 8)) == G["G2"]["mean"]
+    assert float(np.around(best[1], 8)) == G["G2"]["var"]
+    assert float(np.around(best[2], 8)) == np.around(G["G2"]["mean"] + s.gp_varsigma * G["G2"]["var"], 8)
+    s.gp_predict(np.array(G["G1"]["predict_at"]))
+    assert len(s.points) == n0 + 1
+    p = s.points[-1]
+    np.testing.assert_equal(p.normed_coord, np.array(G["G1"]["predict_at"][0]))
+    assert float(np.around(p.score_mu, 8)) == G["G1"]["mean"]
+    assert float(np.around(p.score_sigma, 8)) == G["G1"]["var"]  # the VARIANCE
+    assert p.score_ucb == p.score_mu + s.gp_varsigma * p.score_sigma
+
+
+def test_surrogate_save_load_roundtrip():
+    s = _fixture_surrogate()
+    x, y = s.current_training_data
+    s._gp_train(x=x, y=y[:, np.newaxis])
+    s.save(TMP)
+    loaded = GPRSurrogate.from_saved(TMP)
+    for (k1, v1), (k2, v2) in zip(s.gpflow_model.parameter_dict().items(),
+                                  loaded.gpflow_model.parameter_dict().items()):
+        assert k1 == k2
+        np.testing.assert_allclose(v1, v2)
+    m1, v1 = s.gpflow_model.predict_y(x)
+    m2, v2 = loaded.gpflow_model.predict_y(x)
+    np.testing.assert_equal(m1.numpy(), m2.numpy())
+    np.testing.assert_equal(v1.numpy(), v2.numpy())
+    assert s.gp_varsigma == loaded.gp_varsigma and s.gp_lik_sigma == loaded.gp_lik_sigma
+    assert list(s.points) == list(loaded.points)
+
+
+# ---- parameter space (reference tests/test_param_space.py) ----------------------------------------
+def _space():
+    return ParameterSpace(parameter_names=["x", "y"], parameter_bounds=[[-3, 5], [-3, 3]])
+
+
+def test_space_root_and_normalisation():
+    sp = _space()
+    assert sp.ndim == 2 and sp.max_depth == 0 and sp.depth == 0 and sp.name == "full_domain"
+    assert sp.get_center_as_list(normed=True) == [0.5, 0.5]
+    assert sp.get_center_as_list(normed=False) == [1.0, 0.0]
+    assert sp.get_center_as_dict(normed=False) == {"x": 1.0, "y": 0.0}
+    x = np.array([[1.0, 0.0], [-3.0, 3.0], [0.123, -1.7]])
+    np.testing.assert_allclose(sp.denormalise_coords(sp.normalise_coords(x)), x)
+    ref = otree.MinMax01([[-3, 5], [-3, 3]])
+    np.testing.assert_array_equal(sp.normalise_coords(x), ref.transform(x))
+    np.testing.assert_array_equal(sp.denormalise_coords(x), ref.inverse_transform(x))
+
+
+def test_ternary_split_bounds_and_tree_bookkeeping():
+    sp = _space()
+    kids = sp.ternary_split()
+    assert [k.name for k in kids] == ["full_domain->l", "full_domain->c", "full_domain->r"]
+    for i, k in enumerate(kids):
+        np.testing.assert_allclose(k.norm_bounds[0], (i / 3, (i + 1) / 3))
+        assert tuple(k.norm_bounds[1]) == (0, 1)
+        assert k.depth == 1 and k.parent is sp
+    assert sp.max_depth == 1 and sp[1] is kids[1]
+    grand = kids[0].ternary_split()  # now the second dimension is the widest
+    np.testing.assert_allclose(grand[2].norm_bounds[1], (2 / 3, 1.0))
+    assert sp.max_depth == 2
+    assert [n.name for n in sp.iter_preorder()][:3] == ["full_domain", "full_domain->l", "full_domain->l->l"]
+
+
+def test_get_best_score_leaf_first_in_preorder_wins_ties():
+    sp = _space()
+    kids = sp.ternary_split()
+    assert sp.get_best_score_leaf(depth=1) is kids[0]  # all scores 0.0 -> first in pre-order
+    kids[2].score = 1.0
+    kids[1].score = 1.0
+    assert sp.get_best_score_leaf(depth=1) is kids[1]
+    kids[1].sampled = True
+    assert sp.get_best_score_leaf(depth=1) is kids[2]
+    assert sp.get_best_score_leaf(depth=1, only_not_sampled=False) is kids[1]
+    assert sp.get_best_score_leaf(depth=5) is None
+    g1, g2 = kids[2].ternary_split(), kids[0].ternary_split()
+    for n in g1 + g2:
+        n.score = 3.0
+    assert sp.get_best_score_leaf(depth=2) is g2[0]  # child of `l` precedes children of `r`
+
+
+def test_grow_is_bit_identical_to_reference_recurrence_and_leaves_tree_alone():
+    sp = _space()
+    node = sp.ternary_split()[2].ternary_split()[0].ternary_split()[1]
+    for depth in (0, 1, 4, 7):
+        got = node.grow(depth)
+        ref = otree.grow(node.norm_bounds, depth)
+        assert got.shape == (sum(3 ** i for i in range(depth)), 2)
+        np.testing.assert_array_equal(got, ref)
+    assert node.children == []
+    c = node.grow(4)
+    b = node.bounds_array()
+    assert np.all(c >= b[:, 0]) and np.all(c <= b[:, 1])
+
+
+def test_sample_uniformly_in_bounds_and_seeded():
+    sp = _space()
+    leaf = sp.ternary_split()[0]
+    a = leaf.sample_uniformly(50, seed=3)
+    assert a.shape == (50, 2) and np.all(a[:, 0] <= 1 / 3) and np.all(a >= 0)
+    np.testing.assert_array_equal(a, leaf.sample_uniformly(50, seed=3))
+
+
+def test_space_pickle_roundtrip():
+    os.makedirs(TMP, exist_ok=True)
+    sp = _space()
+    kids = sp.ternary_split()
+    kids[1].score, kids[1].sampled, kids[1].label = 2.5, True, PointLabels.gp_based
+    kids[1].ternary_split()
+    sp.save(os.path.join(TMP, "space"))
+    lo = ParameterSpace.from_file(os.path.join(TMP, "space.pkl"))
+    a, b = list(sp.iter_preorder()), list(lo.iter_preorder())
+    assert len(a) == len(b) == 7 and lo.max_depth == 2
+    for x, y in zip(a, b):
+        assert (x.name, x.score, x.sampled, x.label, x.depth) == (y.name, y.score, y.sampled, y.label, y.depth)
+        np.testing.assert_array_equal(np.array(x.norm_bounds, dtype=float), np.array(y.norm_bounds, dtype=float))
+
+
+# ---- the loop (reference tests/test_optimisation.py) -----------------------------------------------
+def _optimiser(depth, budget, **kw):
+    return GPSOptimiser(parameter_space=_space(), exploration_method="tree", exploration_depth=depth,
+                        budget=budget, stopping_condition="evaluations", update_cycle=1, n_workers=1, **kw)
+
+
+def test_G4_optimise_v1():
+    opt = _optimiser(G["G4"]["depth"], G["G4"]["budget"])
+    best = opt.run(rotated_peaks)
+    np.testing.assert_almost_equal(G["G4"]["best_coords"], best.normed_coord)
+    assert np.around(best.score_mu, decimals=8) == G["G4"]["best_score"]
+    assert best.label == PointLabels.evaluated
+
+
+def test_G5_resume_run_and_resume_from_saved():
+    opt = _optimiser(G["G4"]["depth"], 25)
+    opt.run(rotated_peaks)
+    best = opt.resume_run(additional_budget=25)
+    np.testing.assert_almost_equal(G["G4"]["best_coords"], best.normed_coord)
+    assert np.around(best.score_mu, decimals=8) == G["G4"]["best_score"]
+
+    opt = _optimiser(G["G4"]["depth"], 25)
+    opt.run(rotated_peaks)
+    opt.save_state(TMP)
+    best2, opt2 = GPSOptimiser.resume_from_saved(TMP, additional_budget=25, objective_function=rotated_peaks)
+    np.testing.assert_almost_equal(G["G4"]["best_coords"], best2.normed_coord)
+    assert np.around(best2.score_mu, decimals=8) == G["G4"]["best_score"]
+    assert opt2.n_eval_counter == 55
+
+
+def test_G6_trace_host_grow_and_device_grow_paths_agree():
+    opt = _optimiser(G["G6"]["depth"], G["G6"]["budget"])
+    best = opt.run(rotated_peaks)
+    assert [t[0] for t in opt.trace] == [t["evaluations"] for t in G["G6"]["trace"]]
+    for got, exp in zip(opt.trace, G["G6"]["trace"]):
+        assert got[1] == exp["highest_score"] and abs(got[2] - exp["highest_ucb"]) < 1e-9
+    assert best.score_mu == G["G6"]["best"]["score_mu"]
+    opt_b = _optimiser(G["G6"]["depth"], G["G6"]["budget"])
+    opt_b.device_grow = False  # reference-style: host grow + one call per child
+    best_b = opt_b.run(rotated_peaks)
+    assert opt_b.trace == opt.trace and best_b == best
+
+
+def test_sample_method_runs():
+    opt = GPSOptimiser(parameter_space=_space(), exploration_method="sample", exploration_depth=5,
+                       budget=30)
+    best = opt.run(rotated_peaks, seed=42)
+    assert opt.max_depth == 20 and best.score_mu >= 2.0
+
+
+def test_eval_repeats_and_saver_protocol():
+    saved = []
+
+    class Saver:
+        def save_runs(self, results, scores, params):
+            saved.append((len(results), len(scores), sorted(params)))
+
+    def obj(p):
+        return np.zeros(3), rotated_peaks(p)
+
+    opt = _optimiser(3, 12, saver=Saver())
+    best = opt.run(obj, eval_repeats=4)
+    assert saved and all(s == (4, 4, ["x", "y"]) for s in saved)
+    assert len(saved) == opt.n_eval_counter and best.score_mu > 0
+
+
+def test_bad_arguments():
+    with pytest.raises(ValueError):
+        GPSOptimiser(parameter_space=_space(), exploration_method="nope")
+    with pytest.raises(AssertionError):
+        GPSOptimiser(parameter_space=_space(), stopping_condition="nope")
+    with pytest.raises(AssertionError):
+        GPSOptimiser(parameter_space="space")
+    with pytest.raises(AssertionError):
+        LeafNode(norm_bounds=[(0, 1), (1, 0)], scaler=_space().scaler, parameter_names=["a", "b"])
