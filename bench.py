@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""
+Headline benchmark: leaf-UCB predictions/s (+ GP-fit ms) on synthetic {N_train, D, N_leaves}.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4]
+
+A "step" = one pass of the hot path over one leaf batch: ``gpso_best_ucb`` (prep -> leaf-tile MFMA
+kernel -> finalize -> arg-max) on leaves ALREADY RESIDENT in HBM, posterior resident.  N = 1 runs
+BASELINE.json's single-GPU performance configuration C3 (D=12, N_train=2048, 64k leaves, fp32).
+For N > 1 (launched by ``python -m torch.distributed.run --nproc-per-node N ...``) every rank
+gets the same number of leaves (weak scaling): rank 0 fits, the predict-ready posterior is
+broadcast over RCCL, each rank scores its shard, the winners are all-gathered.
+
+Rank 0 prints ONE JSON line.  ``roofline`` is for the dominant kernel (leaf_tiles_kernel):
+achieved = algorithmic FLOPs per launch (N^2 + 2ND + 20N per leaf) / its average
+duration measured with HIP events on the library's stream inside the timed region.
+``cpu_baseline`` times the CPU oracle (numpy/scipy float64, the stand-in for the reference's
+GPflow path, which cannot be installed here) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (D, N_train, leaves per GPU, dtype, label)
+    "c2": (6, 256, 4096, "float64", "C2: D=6 N_train=256 leaves=4096 fp64 Matern52"),
+    "c3": (12, 2048, 65536, "float32", "C3: D=12 N_train=2048 leaves=65536/GPU fp32 Matern52"),
+    "c4": (20, 8192, 32768, "float32", "C4 (one GPU's share): D=20 N_train=8192 leaves=32768/GPU fp32 Matern52"),
+}
+PEAK_TFLOPS = {"float32": 157.3, "float64": 78.6}  # dense MFMA peaks, MI355X_MICROARCH.md
+
+
+def synthetic(n, d, m, seed=0):
+    from tests.helpers import synthetic_leaves, synthetic_problem
+
+    X, y = synthetic_problem(n, d, seed=seed)
+    return X, y, synthetic_leaves(m, d, seed=seed + 1)
+
+
+def cpu_baseline(X, y, theta, leaves, varsigma, budget_s=12.0):
+    """Time the CPU oracle on a bounded sample of the workload (rank 0, N = 1 only)."""
+    from oracle import gpr
+
+    try:
+        from threadpoolctl import threadpool_info
+
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    th = gpr.Theta(*theta)
+    t0 = time.perf_counter()
+    post = gpr.posterior(th, X, y)
+    fit_s = time.perf_counter() - t0
+    chunk = 2048
+    t0 = time.perf_counter()
+    gpr.best_ucb(post, leaves[:chunk], varsigma)
+    per_chunk = time.perf_counter() - t0
+    n_chunks = int(max(1, min(leaves.shape[0] // chunk, budget_s / max(per_chunk, 1e-6))))
+    sample = leaves[: n_chunks * chunk]
+    t0 = time.perf_counter()
+    gpr.best_ucb(post, sample, varsigma)
+    dt = time.perf_counter() - t0
+    return {
+        "value": sample.shape[0] / dt, "unit": "predictions/s", "cores": int(threads), "kind": "port",
+        "sample": f"first {sample.shape[0]} of the {leaves.shape[0]} leaves, float64 numpy/scipy oracle "
+                  f"(LAPACK potrf/trsm), {dt:.1f} s",
+        "fit_ms_posterior": fit_s * 1e3,
+    }, post
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from pygpso_amd import HipGPEngine
+    from pygpso_amd import distributed as D
+    from scipy.special import erfcinv
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
+                             "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    d, n, m_per_gpu, dtype, label = WORKLOADS[args.workload]
+    m_total = m_per_gpu * world
+    varsigma = float(erfcinv(0.01))
+    X, y, leaves_all = synthetic(n, d, m_total)
+    theta = ("Matern52", 0.25 * math.sqrt(d), 1.0, 1.0e-3, float(y.mean()))
+
+    eng = HipGPEngine(dtype, device=local_rank)
+    # ---- fit on rank 0 (timed separately), broadcast the predict-ready posterior ----------------
+    fit_ms = {}
+    if rank == 0:
+        eng.set_data(X, y)
+        for name, want_grad in (("posterior", False), ("nlml_grad", True)):
+            ts = []
+            for _ in range(5):
+                eng.fit_eval(*theta, want_grad=want_grad)
+                ts.append(eng.last_ms(2))
+            fit_ms[name] = float(np.median(ts))
+        eng.fit_eval(*theta, want_grad=False)
+    bcast_ms = None
+    if world > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        D.broadcast_posterior(eng, src=0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        bcast_ms = (time.perf_counter() - t0) * 1e3
+
+    # ---- this rank's leaf shard, resident in HBM before the timed region --------------------------
+    lo, hi = D.shard_range(m_total, rank, world)
+    np_dtype = np.float32 if dtype == "float32" else np.float64
+    leaves_dev = torch.from_numpy(np.ascontiguousarray(leaves_all[lo:hi].astype(np_dtype))).cuda(local_rank)
+
+    def step():
+        if world > 1:
+            return D.best_ucb_sharded(eng, leaves_dev, lo, varsigma)
+        idx, mean, var, ucb = eng.best_ucb(leaves_dev, varsigma)
+        return int(idx[0]), float(mean[0]), float(var[0]), float(ucb[0])
+
+    for _ in range(args.warmup):
+        winner = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    tile_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        winner = step()
+        tile_ms.append(eng.last_ms(0))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        kern_ms = float(np.mean(tile_ms))
+        flops_per_leaf = n * n + 2 * n * d + 20 * n
+        achieved = flops_per_leaf * (hi - lo) / (kern_ms * 1e-3) / 1e12
+        out = {
+            "metric": "leaf_ucb_predictions_per_sec",
+            "value": m_total * args.steps / elapsed,
+            "unit": "predictions/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32" if dtype == "float32" else "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": label, "D": d, "N_train": n, "leaves_per_gpu": m_per_gpu,
+                "leaves_total": m_total, "kernel": "Matern52", "lengthscale": theta[1],
+                "noise_variance": theta[3], "parallelism": f"leaf-shard x{world}",
+                "leaves_resident_in_hbm": True,
+            },
+            "fit_ms": fit_ms,
+            "posterior_broadcast_ms": bcast_ms,
+            "winner": {"index": winner[0], "ucb": winner[3]},
+            "roofline": {
+                "kernel": "leaf_tiles_kernel", "bound": "mfma", "achieved": achieved,
+                "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[dtype],
+                "traffic": None,
+                "kernel_ms": kern_ms, "flops_per_leaf": flops_per_leaf, "leaves_per_launch": hi - lo,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, post = cpu_baseline(X, y, theta, leaves_all, varsigma)
+            out["cpu_baseline"] = cb
+            # the checker: the GPU winner must be (within fp tolerance) the oracle's winner on the sample
+            from oracle import gpr
+
+            n_s = int(cb["sample"].split()[1])
+            mean_ref, var_ref = gpr.predict_y(post, leaves_all[: max(n_s, 1)])
+            ucb_ref = mean_ref + varsigma * var_ref
+            if winner[0] < n_s:
+                out["winner"]["oracle_ucb_at_index"] = float(ucb_ref[winner[0]])
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
