@@ -85,6 +85,39 @@ __device__ __forceinline__ float kern_from_r2(int kernel, float r2, float varian
   return variance * __expf(-r);
 }
 
+// ---- hot-loop form: k as a function of u = C2 * r^2 with the scale C2 folded into the norms ----
+// (Matern-5/2: C2 = 5 so t = sqrt(u) = sqrt5 r and 1 + sqrt5 r + 5/3 r^2 = 1 + t + t^2/3;
+//  Matern-3/2: C2 = 3; Matern-1/2 and SE: C2 = 1).  KERNEL is a compile-time constant.
+template <int KERNEL>
+struct KernScale {
+  static constexpr double C2 = (KERNEL == 0) ? 5.0 : (KERNEL == 1) ? 3.0 : 1.0;
+};
+
+// float: raw v_sqrt_f32 / v_exp_f32 (1 ulp each), no range fix-ups -- the hot loop's VALU budget
+template <int KERNEL>
+__device__ __forceinline__ float kern_from_scaled(float u, float variance) {
+  constexpr float kNegLog2e = -1.4426950408889634f;
+  if (KERNEL == 3) return variance * __builtin_amdgcn_exp2f(u * (0.5f * kNegLog2e));
+  const float t = __builtin_amdgcn_sqrtf(fmaxf(u, (float)(KernScale<KERNEL>::C2 * 1e-36)));
+  const float e = __builtin_amdgcn_exp2f(t * kNegLog2e);
+  if (KERNEL == 0) return (variance * fmaf(t, fmaf(t, 1.0f / 3.0f, 1.0f), 1.0f)) * e;
+  if (KERNEL == 1) return (variance * (1.0f + t)) * e;
+  return variance * e;
+}
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return fma(a, b, c); }
+
+// double: the accurate library exp/sqrt (this is the parity path)
+template <int KERNEL>
+__device__ __forceinline__ double kern_from_scaled(double u, double variance) {
+  if (KERNEL == 3) return variance * exp(-0.5 * u);
+  const double t = sqrt(fmax(u, KernScale<KERNEL>::C2 * 1e-36));
+  const double e = exp(-t);
+  if (KERNEL == 0) return (variance * fma(t, fma(t, 1.0 / 3.0, 1.0), 1.0)) * e;
+  if (KERNEL == 1) return variance * (1.0 + t) * e;
+  return variance * e;
+}
+
 // d k / d(r^2) * variance-scaled, used by the gradient reductions
 __device__ __forceinline__ double dkern_dr2(int kernel, double r2, double variance) {
   if (kernel == 3) return -0.5 * variance * exp(-0.5 * r2);

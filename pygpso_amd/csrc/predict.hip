@@ -11,6 +11,10 @@
 //   seg_argmax_*   first-max arg-max of ucb per segment (np.argmax tie rule)
 //
 // Replaces gpflow_model.predict_y + the numpy UCB/argmax of gpso/gp_surrogate.py:313-328.
+//
+// Compiled with -ffp-contract=off (Makefile): every fused multiply-add below is written out
+// (fma_t), so all unrolled instances of the per-leaf arithmetic are the same instruction sequence
+// and a leaf's result cannot depend on which column slot of a tile it lands in.
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -46,12 +50,68 @@ __global__ __launch_bounds__(256) void prep_leaves_kernel(const TIN* __restrict_
 // With those, accumulator register r of lane l of the generated tile S = x~ x~*^T corresponds to
 // training row 16 kt + 4 (l >> 4) + r and leaf column (l & 15) for BOTH the f32 and f64 MFMA,
 // which is exactly the B-operand shape (k = l >> 4 within k-step r) the second MFMA needs.
-template <typename T, int BM, int CT>
+// one k-tile (16 training rows) of work for a wave; DIAG = the k-tile lies in the diagonal block
+// of this row block (mean partial + skipping of the all-zero upper tiles of L^-1)
+template <typename T, int RT, int CT, int KERNEL, bool DIAG>
+__device__ __forceinline__ void leaf_tile_step(
+    int kt, int kt_diag0, int lane, int dp4, int npad16, const T* __restrict__ xs_p,
+    const T* xb, const typename Mfma<T>::vec4* __restrict__ xn4,
+    const typename Mfma<T>::vec4* __restrict__ al4, const typename Mfma<T>::vec4* __restrict__ linv4,
+    const T (&nb)[CT], T variance, typename Mfma<T>::vec4 (&acc)[RT][CT], T (&macc)[CT]) {
+  using M = Mfma<T>;
+  using vec4 = typename M::vec4;
+  // L^-1 fragments of this k-tile for all RT row tiles: issued first, consumed last
+  vec4 a[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    if (DIAG && kt > kt_diag0 + rt) {
+      a[rt] = vec4{0, 0, 0, 0};
+    } else {
+      a[rt] = linv4[((size_t)(kt_diag0 + rt) * npad16 + kt) * 64 + lane];
+    }
+  }
+  // ---- generate the 16 x (CT*16) cross-Gram tile for training rows [16 kt, 16 kt + 16) ----
+  vec4 s[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) s[t] = vec4{0, 0, 0, 0};
+  for (int c = 0; c < dp4; ++c) {
+    const T xa = xs_p[((size_t)kt * dp4 + c) * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) s[t] = M::mma(xa, xb[(t * dp4 + c) * 64 + lane], s[t]);
+  }
+  // u = C2 * r^2 with GPflow's GEMM form r^2 = -2 x.x* + (|x|^2 + |x*|^2); nb is pre-scaled by C2
+  constexpr T C2 = (T)KernScale<KERNEL>::C2;
+  const vec4 na = xn4[kt * 4 + (lane >> 4)] * C2;
+  vec4 p[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      p[t][r] = kern_from_scaled<KERNEL>(fma_t((T)(T(-2) * C2), s[t][r], na[r] + nb[t]), variance);
+  if (DIAG) {
+    const vec4 a4 = al4[kt * 4 + (lane >> 4)];
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) macc[t] = fma_t(p[t][r], a4[r], macc[t]);
+  }
+  // ---- apply the rows of L^-1: acc[rt][t] += Linv[rows, 16 kt ..] * tile --------------------
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    if (DIAG && kt > kt_diag0 + rt) continue;  // upper-triangular tile of the diagonal block: zeros
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int t = 0; t < CT; ++t) acc[rt][t] = M::mma(a[rt][r], p[t][r], acc[rt][t]);
+  }
+}
+
+template <typename T, int BM, int CT, int KERNEL>
 __global__ __launch_bounds__(256, 2) void leaf_tiles_kernel(
     const T* __restrict__ linv_p, const T* __restrict__ xs_p, const T* __restrict__ xnorm,
     const T* __restrict__ alpha, const T* __restrict__ leaves_s, const T* __restrict__ lnorm,
     T* __restrict__ part_var, T* __restrict__ part_mean, int npad16, int dp4, int64_t mpad, int nbi,
-    int kernel, T variance) {
+    T variance) {
   using M = Mfma<T>;
   using vec4 = typename M::vec4;
   constexpr int RT = BM / 16;  // row tiles per block
@@ -73,7 +133,8 @@ __global__ __launch_bounds__(256, 2) void leaf_tiles_kernel(
           leaves_s[(col0 + t * 16 + (lane & 15)) * dp + 4 * c + (lane >> 4)];
   T nb[CT];
 #pragma unroll
-  for (int t = 0; t < CT; ++t) nb[t] = lnorm[col0 + t * 16 + (lane & 15)];
+  for (int t = 0; t < CT; ++t)
+    nb[t] = lnorm[col0 + t * 16 + (lane & 15)] * (T)KernScale<KERNEL>::C2;
   // (each wave only reads back what it wrote itself: no workgroup barrier needed)
 
   vec4 acc[RT][CT];
@@ -85,50 +146,17 @@ __global__ __launch_bounds__(256, 2) void leaf_tiles_kernel(
 #pragma unroll
   for (int t = 0; t < CT; ++t) macc[t] = 0;
 
-  const int kt_diag0 = bi * RT;   // first k-tile of the diagonal block
-  const int kt_end = kt_diag0 + RT;
+  const int kt_diag0 = bi * RT;  // first k-tile of the diagonal block
   const vec4* linv4 = reinterpret_cast<const vec4*>(linv_p);
   const vec4* xn4 = reinterpret_cast<const vec4*>(xnorm);
   const vec4* al4 = reinterpret_cast<const vec4*>(alpha);
 
-  for (int kt = 0; kt < kt_end; ++kt) {
-    // ---- generate the 16 x (CT*16) cross-Gram tile for training rows [16 kt, 16 kt + 16) ----
-    vec4 s[CT];
-#pragma unroll
-    for (int t = 0; t < CT; ++t) s[t] = vec4{0, 0, 0, 0};
-    for (int c = 0; c < dp4; ++c) {
-      const T xa = xs_p[((size_t)kt * dp4 + c) * 64 + lane];
-#pragma unroll
-      for (int t = 0; t < CT; ++t) s[t] = M::mma(xa, xb[(t * dp4 + c) * 64 + lane], s[t]);
-    }
-    const vec4 na = xn4[kt * 4 + (lane >> 4)];
-    vec4 p[CT];
-#pragma unroll
-    for (int t = 0; t < CT; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        // GPflow square_distance: -2 x.x* + |x|^2 + |x*|^2
-        const T r2 = (T(-2) * s[t][r] + na[r]) + nb[t];
-        p[t][r] = kern_from_r2(kernel, r2, variance);
-      }
-    if (kt >= kt_diag0) {  // wave-uniform: each k-tile is "diagonal" for exactly one row block
-      const vec4 a4 = al4[kt * 4 + (lane >> 4)];
-#pragma unroll
-      for (int t = 0; t < CT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) macc[t] += p[t][r] * a4[r];
-    }
-    // ---- apply the BM rows of L^-1: acc[rt][t] += Linv[rows, 16 kt ..] * tile --------------
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      if (kt > kt_diag0 + rt) continue;  // upper-triangular tile of the diagonal block: zeros
-      const vec4 a = linv4[((size_t)(kt_diag0 + rt) * npad16 + kt) * 64 + lane];
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int t = 0; t < CT; ++t) acc[rt][t] = M::mma(a[r], p[t][r], acc[rt][t]);
-    }
-  }
+  for (int kt = 0; kt < kt_diag0; ++kt)
+    leaf_tile_step<T, RT, CT, KERNEL, false>(kt, kt_diag0, lane, dp4, npad16, xs_p, xb, xn4, al4,
+                                             linv4, nb, variance, acc, macc);
+  for (int kt = kt_diag0; kt < kt_diag0 + RT; ++kt)
+    leaf_tile_step<T, RT, CT, KERNEL, true>(kt, kt_diag0, lane, dp4, npad16, xs_p, xb, xn4, al4,
+                                            linv4, nb, variance, acc, macc);
 
   // ---- epilogue: column sums of squares over the BM rows, and the mean partial ----------------
 #pragma unroll
@@ -137,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void leaf_tiles_kernel(
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sq += acc[rt][t][r] * acc[rt][t][r];
+      for (int r = 0; r < 4; ++r) sq = fma_t(acc[rt][t][r], acc[rt][t][r], sq);
     sq += __shfl_xor(sq, 16);
     sq += __shfl_xor(sq, 32);
     T mm = macc[t];
@@ -270,17 +298,34 @@ template void launch_prep_leaves<float, double>(hipStream_t, const double*, int6
 template void launch_prep_leaves<double, float>(hipStream_t, const float*, int64_t, int64_t, int, int, const double*, double*, double*);
 template void launch_prep_leaves<double, double>(hipStream_t, const double*, int64_t, int64_t, int, int, const double*, double*, double*);
 
-template <typename T>
-void launch_leaf_tiles(hipStream_t st, const T* linv_p, const T* xs_p, const T* xnorm,
-                       const T* alpha, const T* leaves_s, const T* lnorm, T* part_var, T* part_mean,
-                       int64_t npad, int dp4, int64_t mpad, const KernParams& kp) {
+template <typename T, int KERNEL>
+static void launch_leaf_tiles_k(hipStream_t st, const T* linv_p, const T* xs_p, const T* xnorm,
+                                const T* alpha, const T* leaves_s, const T* lnorm, T* part_var,
+                                T* part_mean, int64_t npad, int dp4, int64_t mpad,
+                                const KernParams& kp) {
   constexpr int BM = LeafTileCfg<T>::BM, CT = LeafTileCfg<T>::CT;
   const int nbi = (int)(npad / BM);
   const dim3 grid((unsigned)(mpad / (4 * CT * 16)), (unsigned)nbi);
   const size_t lds = (size_t)4 * CT * dp4 * 64 * sizeof(T);
-  hipLaunchKernelGGL((leaf_tiles_kernel<T, BM, CT>), grid, dim3(256), lds, st, linv_p, xs_p, xnorm,
-                     alpha, leaves_s, lnorm, part_var, part_mean, (int)(npad / 16), dp4, mpad, nbi,
-                     kp.kernel, (T)kp.variance);
+  hipLaunchKernelGGL((leaf_tiles_kernel<T, BM, CT, KERNEL>), grid, dim3(256), lds, st, linv_p, xs_p,
+                     xnorm, alpha, leaves_s, lnorm, part_var, part_mean, (int)(npad / 16), dp4, mpad,
+                     nbi, (T)kp.variance);
+}
+
+template <typename T>
+void launch_leaf_tiles(hipStream_t st, const T* linv_p, const T* xs_p, const T* xnorm,
+                       const T* alpha, const T* leaves_s, const T* lnorm, T* part_var, T* part_mean,
+                       int64_t npad, int dp4, int64_t mpad, const KernParams& kp) {
+#define GPSO_LT(K)                                                                              \
+  launch_leaf_tiles_k<T, K>(st, linv_p, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, \
+                            npad, dp4, mpad, kp)
+  switch (kp.kernel) {
+    case 0: GPSO_LT(0); break;
+    case 1: GPSO_LT(1); break;
+    case 2: GPSO_LT(2); break;
+    default: GPSO_LT(3); break;
+  }
+#undef GPSO_LT
 }
 template void launch_leaf_tiles<float>(hipStream_t, const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, int64_t, int, int64_t, const KernParams&);
 template void launch_leaf_tiles<double>(hipStream_t, const double*, const double*, const double*, const double*, const double*, const double*, double*, double*, int64_t, int, int64_t, const KernParams&);
