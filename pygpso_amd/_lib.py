@@ -13,7 +13,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgpso_hip.so")
+# GPSO_HIP_LIB overrides the path (experimental builds of the same C-ABI)
+LIB_PATH = os.environ.get("GPSO_HIP_LIB") or os.path.join(_HERE, "libgpso_hip.so")
 
 # status codes / enums (mirror include/gpso_hip.h)
 OK, E_ARG, E_HIP, E_NOTPD, E_OOM, E_STATE, E_RCCL = 0, -1, -2, -3, -4, -5, -6

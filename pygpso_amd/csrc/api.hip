@@ -221,7 +221,8 @@ struct EngineT : Engine {
     launch_potrf<T>(s, as<T>(K), as<T>(linv), n, npad, as<double>(logdet), info_dev);
     launch_trtri<T>(s, as<T>(K), as<T>(linv), as<T>(work), npad);
     launch_solve_alpha<T>(s, as<T>(linv), as<double>(y64), n, npad, mean_c, as<double>(logdet),
-                          (int)(npad / kFitBlock), as<T>(white), as<T>(alpha), as<double>(scal));
+                          (int)(npad / kFitBlock), as<T>(white), as<T>(alpha), as<double>(gpart),
+                          as<double>(scal));
     if (grad)
       launch_gradient<T>(s, as<T>(linv), as<T>(alpha), as<T>(xs), as<T>(xnorm), n, npad, d, dp, n_ls,
                          ls_dev(), kp, as<T>(work), as<double>(gpart), as<double>(scal) + 8);
@@ -286,8 +287,7 @@ struct EngineT : Engine {
   // leaves already on the device as raw coordinates (dtype xs_dtype) -> mean/var(/ucb) device arrays
   int score_device_leaves(const void* xs_dev, int xs_dtype, int64_t m, double varsigma, bool want_ucb,
                           double* mean_dev, double* var_dev, double* ucb_dev) {
-    constexpr int BM = LeafTileCfg<T>::BM;
-    const int nbi = (int)(npad / BM);
+    const int nbi = leaf_tiles_nbi<T>(npad);
     const int64_t chunk = std::min<int64_t>(m, kLeafChunk);
     const int64_t cpad = (chunk + kLeafPad - 1) / kLeafPad * kLeafPad;
     int rc;

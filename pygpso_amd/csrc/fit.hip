@@ -117,15 +117,57 @@ template void launch_gram<double>(hipStream_t, const double*, const double*, int
 // =============================================================================================
 constexpr int kDS = kFitBlock + 1;  // LDS row stride (conflict-free row-per-lane access)
 
-// in-LDS inverse of the lower-triangular block Ls -> Xs (lane c owns column c)
-__device__ __forceinline__ void trinv64_lds(const double* Ls, double* Xs, int lane) {
-  // forward substitution on the identity; loops are wave-uniform (Ls reads broadcast, Xs reads
-  // are one column per lane): X[i][c] = (delta_ic - sum_{k<i} L[i][k] X[k][c]) / L[i][i]
+// dot products over LDS rows with the latency amortised: 8 loads in flight, 4 accumulators
+// (a serial fma chain on ds_read results costs one LDS round trip per element)
+__device__ __forceinline__ double lds_dot_rows(const double* a, const double* b, int n) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int k = 0;
+  for (; k + 8 <= n; k += 8) {
+    const double a0 = a[k], a1 = a[k + 1], a2 = a[k + 2], a3 = a[k + 3];
+    const double a4 = a[k + 4], a5 = a[k + 5], a6 = a[k + 6], a7 = a[k + 7];
+    const double b0 = b[k], b1 = b[k + 1], b2 = b[k + 2], b3 = b[k + 3];
+    const double b4 = b[k + 4], b5 = b[k + 5], b6 = b[k + 6], b7 = b[k + 7];
+    s0 = fma(a0, b0, s0); s1 = fma(a1, b1, s1); s2 = fma(a2, b2, s2); s3 = fma(a3, b3, s3);
+    s0 = fma(a4, b4, s0); s1 = fma(a5, b5, s1); s2 = fma(a6, b6, s2); s3 = fma(a7, b7, s3);
+  }
+  for (; k < n; ++k) s0 = fma(a[k], b[k], s0);
+  return (s0 + s1) + (s2 + s3);
+}
+
+// same, second operand strided (a column of a row-major LDS matrix)
+__device__ __forceinline__ double lds_dot_row_col(const double* a, const double* b, int stride, int n) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int k = 0;
+  for (; k + 8 <= n; k += 8) {
+    const double a0 = a[k], a1 = a[k + 1], a2 = a[k + 2], a3 = a[k + 3];
+    const double a4 = a[k + 4], a5 = a[k + 5], a6 = a[k + 6], a7 = a[k + 7];
+    const double b0 = b[(k)*stride], b1 = b[(k + 1) * stride], b2 = b[(k + 2) * stride], b3 = b[(k + 3) * stride];
+    const double b4 = b[(k + 4) * stride], b5 = b[(k + 5) * stride], b6 = b[(k + 6) * stride], b7 = b[(k + 7) * stride];
+    s0 = fma(a0, b0, s0); s1 = fma(a1, b1, s1); s2 = fma(a2, b2, s2); s3 = fma(a3, b3, s3);
+    s0 = fma(a4, b4, s0); s1 = fma(a5, b5, s1); s2 = fma(a6, b6, s2); s3 = fma(a7, b7, s3);
+  }
+  for (; k < n; ++k) s0 = fma(a[k], b[k * stride], s0);
+  return (s0 + s1) + (s2 + s3);
+}
+
+// 1/sqrt(x) in full double precision without the long library sqrt/div sequences on the critical
+// path: hardware v_rsq_f64 seed + two Newton steps
+__device__ __forceinline__ double rsqrt_newton(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * fma(-0.5 * x, r * r, 1.5);
+  r = r * fma(-0.5 * x, r * r, 1.5);
+  return r;
+}
+
+// in-LDS inverse of the lower-triangular block Ls -> Xs (lane c owns column c):
+// forward substitution on the identity with wave-uniform loops (Ls reads broadcast, Xs reads are
+// one column per lane): X[i][c] = (delta_ic - sum_{k<i} L[i][k] X[k][c]) * (1 / L[i][i])
+__device__ __forceinline__ void trinv64_lds(const double* Ls, const double* inv_diag, double* Xs,
+                                            int lane) {
   const int c = lane;
   for (int i = 0; i < kFitBlock; ++i) {
-    double acc = (i == c) ? 1.0 : 0.0;
-    for (int k = 0; k < i; ++k) acc -= Ls[i * kDS + k] * Xs[k * kDS + c];
-    Xs[i * kDS + c] = (i < c) ? 0.0 : acc / Ls[i * kDS + i];
+    const double acc = ((i == c) ? 1.0 : 0.0) - lds_dot_row_col(Ls + i * kDS, Xs + c, kDS, i);
+    Xs[i * kDS + c] = (i < c) ? 0.0 : acc * inv_diag[i];
   }
 }
 
@@ -138,39 +180,38 @@ __global__ __launch_bounds__(64) void potrf_diag_kernel(T* __restrict__ K, T* __
                                                         int* __restrict__ info) {
   __shared__ double Ls[kFitBlock * kDS];
   __shared__ double Xs[kFitBlock * kDS];
+  __shared__ double inv_diag[kFitBlock];
   const int lane = threadIdx.x;
   T* A = K + k0 * ld + k0;
   for (int r = 0; r < kFitBlock; ++r) Ls[r * kDS + lane] = (double)A[(int64_t)r * ld + lane];
   __syncthreads();
   // left-looking column Cholesky: lane i owns row i; accumulate in double whatever T is
-  double logdet = 0.0;
   for (int j = 0; j < kFitBlock; ++j) {
-    double v = Ls[lane * kDS + j];
-    for (int k = 0; k < j; ++k) v -= Ls[lane * kDS + k] * Ls[j * kDS + k];
+    const double v = Ls[lane * kDS + j] - lds_dot_rows(Ls + lane * kDS, Ls + j * kDS, j);
     double piv = __shfl(v, j);
     if (!(piv > 0.0)) {  // also catches NaN
       if (lane == 0 && k0 + j < n) atomicMin(info, (int)(k0 + j));
       piv = 1.0;
     }
-    const double ljj = sqrt(piv);
-    if (k0 + j < n) logdet += log(ljj);
+    const double rinv = rsqrt_newton(piv);
+    double ljj = piv * rinv;
+    ljj = fma(0.5 * rinv, fma(-ljj, ljj, piv), ljj);  // Heron correction: ljj = sqrt(piv) to 1 ulp
     __syncthreads();
-    if (lane == j) Ls[lane * kDS + j] = ljj;
-    if (lane > j) Ls[lane * kDS + j] = v / ljj;
-    if (lane < j) Ls[lane * kDS + j] = 0.0;  // (reads of column j above the diagonal are done)
+    Ls[lane * kDS + j] = (lane == j) ? ljj : (lane > j) ? v * rinv : 0.0;
+    if (lane == j) inv_diag[j] = rinv;
     __syncthreads();
   }
-  // zero the strict upper triangle so the block is a clean lower-triangular matrix
-  for (int k = lane + 1; k < kFitBlock; ++k) Ls[lane * kDS + k] = 0.0;
-  __syncthreads();
-  trinv64_lds(Ls, Xs, lane);
+  // log-determinant of the block: each lane takes the log of its own diagonal entry
+  double lg = (k0 + lane < n) ? log(Ls[lane * kDS + lane]) : 0.0;
+  lg = wave_sum(lg);
+  trinv64_lds(Ls, inv_diag, Xs, lane);
   __syncthreads();
   T* Xo = linv + k0 * ld + k0;
   for (int r = 0; r < kFitBlock; ++r) {
     A[(int64_t)r * ld + lane] = (T)Ls[r * kDS + lane];
     Xo[(int64_t)r * ld + lane] = (T)Xs[r * kDS + lane];
   }
-  if (lane == 0) logdet_part[k0 / kFitBlock] = logdet;
+  if (lane == 0) logdet_part[k0 / kFitBlock] = lg;
 }
 
 // inverse of every 64x64 diagonal block of an already-factorised L (gpso_set_posterior path)
@@ -179,13 +220,15 @@ __global__ __launch_bounds__(64) void trinv_diag_kernel(const T* __restrict__ L,
                                                         T* __restrict__ linv, int64_t ld) {
   __shared__ double Ls[kFitBlock * kDS];
   __shared__ double Xs[kFitBlock * kDS];
+  __shared__ double inv_diag[kFitBlock];
   const int lane = threadIdx.x;
   const int64_t k0 = (int64_t)blockIdx.x * kFitBlock;
   const T* A = L + k0 * ld + k0;
   for (int r = 0; r < kFitBlock; ++r)
     Ls[r * kDS + lane] = (lane <= r) ? (double)A[(int64_t)r * ld + lane] : 0.0;
+  inv_diag[lane] = 1.0 / (double)A[(int64_t)lane * ld + lane];
   __syncthreads();
-  trinv64_lds(Ls, Xs, lane);
+  trinv64_lds(Ls, inv_diag, Xs, lane);
   __syncthreads();
   T* Xo = linv + k0 * ld + k0;
   for (int r = 0; r < kFitBlock; ++r) Xo[(int64_t)r * ld + lane] = (T)Xs[r * kDS + lane];
@@ -422,21 +465,37 @@ __global__ __launch_bounds__(256) void white_kernel(const T* __restrict__ linv,
   if (lane == 0) white[i] = (T)acc;
 }
 
-// alpha[j] = sum_{i>=j} Linv[i][j] white[i]: 64 columns per block, 4 row groups, LDS combine
+// alpha[j] = sum_{i>=j} Linv[i][j] white[i].  Stage 1: block (column block cb, row chunk rc of 256
+// rows) -> part[rc][j] (double); stage 2 sums the chunks in order (deterministic).
+constexpr int kAlphaChunk = 256;
 template <typename T>
-__global__ __launch_bounds__(256) void alpha_kernel(const T* __restrict__ linv,
-                                                    const T* __restrict__ white, int64_t n,
-                                                    int64_t npad, T* __restrict__ alpha) {
+__global__ __launch_bounds__(256) void alpha_part_kernel(const T* __restrict__ linv,
+                                                         const T* __restrict__ white, int64_t n,
+                                                         int64_t npad, double* __restrict__ part) {
   __shared__ double sh[4][64];
   const int g = threadIdx.x >> 6, c = threadIdx.x & 63;
   const int64_t j = (int64_t)blockIdx.x * 64 + c;
+  const int64_t r0 = (int64_t)blockIdx.y * kAlphaChunk;
   double acc = 0.0;
-  if (j < n)
-    for (int64_t i = (int64_t)blockIdx.x * 64 + g; i < n; i += 4)
-      if (i >= j) acc += (double)linv[i * npad + j] * (double)white[i];
+  if (r0 + kAlphaChunk > (int64_t)blockIdx.x * 64 && j < n) {  // chunk reaches below this column block
+    const int64_t hi = min(n, r0 + kAlphaChunk);
+#pragma unroll 4
+    for (int64_t i = r0 + g; i < hi; i += 4)
+      if (i >= j) acc = fma((double)linv[i * npad + j], (double)white[i], acc);
+  }
   sh[g][c] = acc;
   __syncthreads();
-  if (g == 0) alpha[j] = (T)(sh[0][c] + sh[1][c] + sh[2][c] + sh[3][c]);
+  if (g == 0) part[(int64_t)blockIdx.y * npad + j] = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void alpha_sum_kernel(const double* __restrict__ part, int nchunk,
+                                                        int64_t npad, T* __restrict__ alpha) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= npad) return;
+  double acc = 0.0;
+  for (int c = 0; c < nchunk; ++c) acc += part[(int64_t)c * npad + j];
+  alpha[j] = (T)acc;
 }
 
 template <typename T>
@@ -463,17 +522,20 @@ __global__ __launch_bounds__(256) void nlml_kernel(const T* __restrict__ white, 
 template <typename T>
 void launch_solve_alpha(hipStream_t st, const T* linv, const double* y64, int64_t n, int64_t npad,
                         double mean_c, const double* logdet_part, int npanels, T* white, T* alpha,
-                        double* nlml_out) {
+                        double* alpha_part, double* nlml_out) {
   hipLaunchKernelGGL((white_kernel<T>), dim3((unsigned)(npad / 4)), dim3(256), 0, st, linv, y64, n,
                      npad, mean_c, white);
-  hipLaunchKernelGGL((alpha_kernel<T>), dim3((unsigned)(npad / 64)), dim3(256), 0, st, linv, white,
-                     n, npad, alpha);
+  const int nchunk = (int)((npad + kAlphaChunk - 1) / kAlphaChunk);
+  hipLaunchKernelGGL((alpha_part_kernel<T>), dim3((unsigned)(npad / 64), (unsigned)nchunk), dim3(256),
+                     0, st, linv, white, n, npad, alpha_part);
+  hipLaunchKernelGGL((alpha_sum_kernel<T>), dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, st,
+                     alpha_part, nchunk, npad, alpha);
   if (nlml_out)
     hipLaunchKernelGGL((nlml_kernel<T>), dim3(1), dim3(256), 0, st, white, n, logdet_part, npanels,
                        nlml_out);
 }
-template void launch_solve_alpha<float>(hipStream_t, const float*, const double*, int64_t, int64_t, double, const double*, int, float*, float*, double*);
-template void launch_solve_alpha<double>(hipStream_t, const double*, const double*, int64_t, int64_t, double, const double*, int, double*, double*, double*);
+template void launch_solve_alpha<float>(hipStream_t, const float*, const double*, int64_t, int64_t, double, const double*, int, float*, float*, double*, double*);
+template void launch_solve_alpha<double>(hipStream_t, const double*, const double*, int64_t, int64_t, double, const double*, int, double*, double*, double*, double*);
 
 // =============================================================================================
 // analytic gradient of the NLML  

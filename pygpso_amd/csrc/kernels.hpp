@@ -5,17 +5,14 @@
 namespace gpso {
 
 // tile shape of the dominant predict kernel: BM rows of L^-1 x (4 waves * CT * 16) leaves per workgroup
-template <typename T>
-struct LeafTileCfg;
-template <>
-struct LeafTileCfg<float> {
-  static constexpr int BM = 128, CT = 4;  // 32 accumulator tiles = 128 VGPRs per lane
-};
-template <>
-struct LeafTileCfg<double> {
-  static constexpr int BM = 64, CT = 2;  // 8 accumulator tiles = 64 VGPRs per lane
-};
+// (chosen per launch: f32 uses 256 x 128 when N_pad is a multiple of 256, else 128 x 256; f64 64 x 128;
+//  always 32 (f32) / 8 (f64) accumulator tiles per wave)
 constexpr int kLeafPad = 256;  // leaf batches are padded to a multiple of this
+// rows of L^-1 per workgroup for a given padded N, and the resulting number of row blocks
+template <typename T>
+int leaf_tiles_bm(int64_t npad);
+template <typename T>
+inline int leaf_tiles_nbi(int64_t npad) { return (int)(npad / leaf_tiles_bm<T>(npad)); }
 
 // ---- predict.hip ----------------------------------------------------------------------------------
 template <typename T, typename TIN>
@@ -59,7 +56,7 @@ void launch_pack_linv(hipStream_t st, const T* linv, int64_t n, int64_t npad, T*
 template <typename T>
 void launch_solve_alpha(hipStream_t st, const T* linv, const double* y64, int64_t n, int64_t npad,
                         double mean_c, const double* logdet_part, int npanels, T* white, T* alpha,
-                        double* nlml_out);
+                        double* alpha_part /* [ceil(npad/256) * npad] scratch */, double* nlml_out);
 // Kinv = L^-T L^-1 (lower tiles, mirrored), then the gradient reductions of SURVEY.md A.3;
 // grad_out[n_ls + 3] = d nlml / d (ls..., variance, noise, c)
 template <typename T>

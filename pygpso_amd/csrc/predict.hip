@@ -15,6 +15,8 @@
 // Compiled with -ffp-contract=off (Makefile): every fused multiply-add below is written out
 // (fma_t), so all unrolled instances of the per-leaf arithmetic are the same instruction sequence
 // and a leaf's result cannot depend on which column slot of a tile it lands in.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -52,33 +54,54 @@ __global__ __launch_bounds__(256) void prep_leaves_kernel(const TIN* __restrict_
 // which is exactly the B-operand shape (k = l >> 4 within k-step r) the second MFMA needs.
 // one k-tile (16 training rows) of work for a wave; DIAG = the k-tile lies in the diagonal block
 // of this row block (mean partial + skipping of the all-zero upper tiles of L^-1)
-template <typename T, int RT, int CT, int KERNEL, bool DIAG>
+// PF: the L^-1 fragments of k-tile kt arrive in `a` (loaded one step earlier) and the fragments of
+// kt + 1 are requested at the top of this step, a full step ahead of their use (register double
+// buffer; tiles above the diagonal are stored as zeros, so the prefetch never needs a guard other
+// than the end of the row block).
+template <typename T, int RT, int CT, int KERNEL, bool DIAG, bool PF>
 __device__ __forceinline__ void leaf_tile_step(
     int kt, int kt_diag0, int lane, int dp4, int npad16, const T* __restrict__ xs_p,
     const T* xb, const typename Mfma<T>::vec4* __restrict__ xn4,
     const typename Mfma<T>::vec4* __restrict__ al4, const typename Mfma<T>::vec4* __restrict__ linv4,
-    const T (&nb)[CT], T variance, typename Mfma<T>::vec4 (&acc)[RT][CT], T (&macc)[CT]) {
+    const T (&nb)[CT], T variance, typename Mfma<T>::vec4 (&acc)[RT][CT], T (&macc)[CT],
+    typename Mfma<T>::vec4 (&a)[RT]) {
   using M = Mfma<T>;
   using vec4 = typename M::vec4;
-  // L^-1 fragments of this k-tile for all RT row tiles: issued first, consumed last
-  vec4 a[RT];
+  vec4 an[RT];
+  if (PF) {
+    if (kt + 1 < kt_diag0 + RT) {
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    if (DIAG && kt > kt_diag0 + rt) {
-      a[rt] = vec4{0, 0, 0, 0};
-    } else {
-      a[rt] = linv4[((size_t)(kt_diag0 + rt) * npad16 + kt) * 64 + lane];
+      for (int rt = 0; rt < RT; ++rt)
+        an[rt] = linv4[((size_t)(kt_diag0 + rt) * npad16 + kt + 1) * 64 + lane];
+    }
+  } else {
+    // L^-1 fragments of this k-tile for all RT row tiles: issued first, consumed last
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      if (DIAG && kt > kt_diag0 + rt) {
+        a[rt] = vec4{0, 0, 0, 0};
+      } else {
+#if defined(GPSO_ABLATE) && (GPSO_ABLATE & 2)  // timing-only: no L^-1 traffic
+        a[rt] = vec4{(T)kt, (T)rt, (T)lane, 1};
+#else
+        a[rt] = linv4[((size_t)(kt_diag0 + rt) * npad16 + kt) * 64 + lane];
+#endif
+      }
     }
   }
   // ---- generate the 16 x (CT*16) cross-Gram tile for training rows [16 kt, 16 kt + 16) ----
   vec4 s[CT];
 #pragma unroll
   for (int t = 0; t < CT; ++t) s[t] = vec4{0, 0, 0, 0};
+#if defined(GPSO_ABLATE) && (GPSO_ABLATE & 4)  // timing-only: no generation MFMAs
+  for (int t = 0; t < CT; ++t) s[t] = vec4{(T)kt, (T)t, (T)lane, 1};
+#else
   for (int c = 0; c < dp4; ++c) {
     const T xa = xs_p[((size_t)kt * dp4 + c) * 64 + lane];
 #pragma unroll
     for (int t = 0; t < CT; ++t) s[t] = M::mma(xa, xb[(t * dp4 + c) * 64 + lane], s[t]);
   }
+#endif
   // u = C2 * r^2 with GPflow's GEMM form r^2 = -2 x.x* + (|x|^2 + |x*|^2); nb is pre-scaled by C2
   constexpr T C2 = (T)KernScale<KERNEL>::C2;
   const vec4 na = xn4[kt * 4 + (lane >> 4)] * C2;
@@ -87,7 +110,11 @@ __device__ __forceinline__ void leaf_tile_step(
   for (int t = 0; t < CT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
+#if defined(GPSO_ABLATE) && (GPSO_ABLATE & 1)  // timing-only: skip the kernel map
+      p[t][r] = s[t][r] + na[r];
+#else
       p[t][r] = kern_from_scaled<KERNEL>(fma_t((T)(T(-2) * C2), s[t][r], na[r] + nb[t]), variance);
+#endif
   if (DIAG) {
     const vec4 a4 = al4[kt * 4 + (lane >> 4)];
 #pragma unroll
@@ -103,6 +130,10 @@ __device__ __forceinline__ void leaf_tile_step(
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int t = 0; t < CT; ++t) acc[rt][t] = M::mma(a[rt][r], p[t][r], acc[rt][t]);
+  }
+  if (PF) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) a[rt] = an[rt];
   }
 }
 
@@ -151,12 +182,18 @@ __global__ __launch_bounds__(256, 2) void leaf_tiles_kernel(
   const vec4* xn4 = reinterpret_cast<const vec4*>(xnorm);
   const vec4* al4 = reinterpret_cast<const vec4*>(alpha);
 
+  constexpr bool PF = false;  // (register double-buffering the L^-1 fragments measured as no gain)
+  vec4 a[RT];
+  if (PF) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) a[rt] = linv4[((size_t)(kt_diag0 + rt) * npad16) * 64 + lane];
+  }
   for (int kt = 0; kt < kt_diag0; ++kt)
-    leaf_tile_step<T, RT, CT, KERNEL, false>(kt, kt_diag0, lane, dp4, npad16, xs_p, xb, xn4, al4,
-                                             linv4, nb, variance, acc, macc);
+    leaf_tile_step<T, RT, CT, KERNEL, false, PF>(kt, kt_diag0, lane, dp4, npad16, xs_p, xb, xn4, al4,
+                                                 linv4, nb, variance, acc, macc, a);
   for (int kt = kt_diag0; kt < kt_diag0 + RT; ++kt)
-    leaf_tile_step<T, RT, CT, KERNEL, true>(kt, kt_diag0, lane, dp4, npad16, xs_p, xb, xn4, al4,
-                                            linv4, nb, variance, acc, macc);
+    leaf_tile_step<T, RT, CT, KERNEL, true, PF>(kt, kt_diag0, lane, dp4, npad16, xs_p, xb, xn4, al4,
+                                                linv4, nb, variance, acc, macc, a);
 
   // ---- epilogue: column sums of squares over the BM rows, and the mean partial ----------------
 #pragma unroll
@@ -298,12 +335,18 @@ template void launch_prep_leaves<float, double>(hipStream_t, const double*, int6
 template void launch_prep_leaves<double, float>(hipStream_t, const float*, int64_t, int64_t, int, int, const double*, double*, double*);
 template void launch_prep_leaves<double, double>(hipStream_t, const double*, int64_t, int64_t, int, int, const double*, double*, double*);
 
-template <typename T, int KERNEL>
+template <>
+int leaf_tiles_bm<float>(int64_t npad) {
+  return (npad % 256 == 0) ? 256 : 128;
+}
+template <>
+int leaf_tiles_bm<double>(int64_t) { return 64; }
+
+template <typename T, int BM, int CT, int KERNEL>
 static void launch_leaf_tiles_k(hipStream_t st, const T* linv_p, const T* xs_p, const T* xnorm,
                                 const T* alpha, const T* leaves_s, const T* lnorm, T* part_var,
                                 T* part_mean, int64_t npad, int dp4, int64_t mpad,
                                 const KernParams& kp) {
-  constexpr int BM = LeafTileCfg<T>::BM, CT = LeafTileCfg<T>::CT;
   const int nbi = (int)(npad / BM);
   const dim3 grid((unsigned)(mpad / (4 * CT * 16)), (unsigned)nbi);
   const size_t lds = (size_t)4 * CT * dp4 * 64 * sizeof(T);
@@ -312,20 +355,33 @@ static void launch_leaf_tiles_k(hipStream_t st, const T* linv_p, const T* xs_p, 
                      nbi, (T)kp.variance);
 }
 
+template <typename T, int KERNEL>
+static void launch_leaf_tiles_shape(hipStream_t st, const T* linv_p, const T* xs_p, const T* xnorm,
+                                    const T* alpha, const T* leaves_s, const T* lnorm, T* part_var,
+                                    T* part_mean, int64_t npad, int dp4, int64_t mpad,
+                                    const KernParams& kp) {
+#define GPSO_ARGS st, linv_p, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp
+  if constexpr (sizeof(T) == 4) {
+    if (leaf_tiles_bm<T>(npad) == 256)
+      launch_leaf_tiles_k<T, 256, 2, KERNEL>(GPSO_ARGS);
+    else
+      launch_leaf_tiles_k<T, 128, 4, KERNEL>(GPSO_ARGS);
+  } else {
+    launch_leaf_tiles_k<T, 64, 2, KERNEL>(GPSO_ARGS);
+  }
+}
+
 template <typename T>
 void launch_leaf_tiles(hipStream_t st, const T* linv_p, const T* xs_p, const T* xnorm,
                        const T* alpha, const T* leaves_s, const T* lnorm, T* part_var, T* part_mean,
                        int64_t npad, int dp4, int64_t mpad, const KernParams& kp) {
-#define GPSO_LT(K)                                                                              \
-  launch_leaf_tiles_k<T, K>(st, linv_p, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, \
-                            npad, dp4, mpad, kp)
   switch (kp.kernel) {
-    case 0: GPSO_LT(0); break;
-    case 1: GPSO_LT(1); break;
-    case 2: GPSO_LT(2); break;
-    default: GPSO_LT(3); break;
+    case 0: launch_leaf_tiles_shape<T, 0>(GPSO_ARGS); break;
+    case 1: launch_leaf_tiles_shape<T, 1>(GPSO_ARGS); break;
+    case 2: launch_leaf_tiles_shape<T, 2>(GPSO_ARGS); break;
+    default: launch_leaf_tiles_shape<T, 3>(GPSO_ARGS); break;
   }
-#undef GPSO_LT
+#undef GPSO_ARGS
 }
 template void launch_leaf_tiles<float>(hipStream_t, const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, int64_t, int, int64_t, const KernParams&);
 template void launch_leaf_tiles<double>(hipStream_t, const double*, const double*, const double*, const double*, const double*, const double*, double*, double*, int64_t, int, int64_t, const KernParams&);
