@@ -37,6 +37,18 @@ WORKLOADS = {
     "c4": (20, 8192, 32768, "float32", "C4 (one GPU's share): D=20 N_train=8192 leaves=32768/GPU fp32 Matern52"),
 }
 PEAK_TFLOPS = {"float32": 157.3, "float64": 78.6}  # dense MFMA peaks, MI355X_MICROARCH.md
+# HBM bytes per launch of the dominant kernel come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
+# cannot be read from inside the process); the committed record of the latest collection:
+PMC_TRAFFIC = {"c3": "profiles/r01b_pmc_leaf_tiles_c3.json"}
+
+
+def pmc_traffic(workload):
+    path = os.path.join(ROOT, PMC_TRAFFIC.get(workload, ""))
+    if not os.path.isfile(path):
+        return None, None
+    with open(path) as fh:
+        rec = json.load(fh)
+    return rec.get("traffic_bytes_per_launch"), os.path.relpath(path, ROOT)
 
 
 def synthetic(n, d, m, seed=0):
@@ -168,6 +180,7 @@ def main():
         kern_ms = float(np.mean(tile_ms))
         flops_per_leaf = n * n + 2 * n * d + 20 * n
         achieved = flops_per_leaf * (hi - lo) / (kern_ms * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic(args.workload)
         out = {
             "metric": "leaf_ucb_predictions_per_sec",
             "value": m_total * args.steps / elapsed,
@@ -193,7 +206,10 @@ def main():
             "roofline": {
                 "kernel": "leaf_tiles_kernel", "bound": "mfma", "achieved": achieved,
                 "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[dtype],
-                "traffic": None,
+                "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC, gfx950-corrected)",
+                "traffic_source": traffic_src,
+                "algorithmic_bytes": int((hi - lo) * (d + 3) * (4 if dtype == "float32" else 8)
+                                         + (n * n // 2 + n * d + n) * (4 if dtype == "float32" else 8)),
                 "kernel_ms": kern_ms, "flops_per_leaf": flops_per_leaf, "leaves_per_launch": hi - lo,
             },
         }

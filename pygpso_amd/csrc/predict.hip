@@ -216,6 +216,242 @@ __global__ __launch_bounds__(256, 2) void leaf_tiles_kernel(
   }
 }
 
+// =============================================================================================
+// leaf_tiles v2 (float): same arithmetic per leaf as leaf_tiles_kernel, restructured around the
+// two costs measured on MI355X (ablation builds): L^-1 fragment loads from
+// L1/L2 and the exposed generation phase.
+//   * the BM x 16 panel of L^-1 and the X fragments of the next k-tiles are brought into LDS by
+//     the whole workgroup with direct-to-LDS loads (global_load_lds: no VGPRs, one KiB per wave
+//     instruction, fragment-major source == linear LDS image), double buffered, one barrier per
+//     k-tile; every wave then reads its A operands from LDS just in time;
+//   * the cross-Gram tile of k-tile kt + 1 is generated WHILE the MFMAs of k-tile kt run: the
+//     generation MFMAs go first, the Matern/SE map is sliced into the issue shadow of the apply
+//     MFMAs (sched_group_barrier pipeline), so the matrix pipe no longer waits for the VALU.
+// =============================================================================================
+__device__ __forceinline__ void glds16(const void* gsrc_lane, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const void* gsrc_lane, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+
+#ifndef GPSO_SGB
+#define GPSO_SGB 0
+#endif
+// timing-only ablation switches of the v2 kernel (never set in the shipped build)
+#if defined(GPSO_ABLATE2) && (GPSO_ABLATE2 & 2)
+#define GPSO_NOLOAD 1
+#else
+#define GPSO_NOLOAD 0
+#endif
+#if defined(GPSO_ABLATE2) && (GPSO_ABLATE2 & 16)
+#define GPSO_NOBAR 1
+#else
+#define GPSO_NOBAR 0
+#endif
+template <int RT, int CT, int KERNEL, bool DIAG>
+__device__ __forceinline__ void leaf_v2_step(int kt, int kt_diag0, bool gen, bool gen_diag, int lane,
+                                             int dp4, const f32x4* panel_b /* [RT][64] */,
+                                             const float* xs_b /* [dp4][64] */, const float* xb,
+                                             const f32x4& na, const f32x4* __restrict__ al4,
+                                             const float (&nb)[CT], float variance,
+                                             f32x4 (&acc)[RT][CT], float (&macc)[CT],
+                                             f32x4 (&p_cur)[CT]) {
+  using M = Mfma<float>;
+  constexpr int E = CT * 4;
+  constexpr float C2 = (float)KernScale<KERNEL>::C2;
+  // ---- generation MFMAs for k-tile kt + 1 (short dependent chains; issued ahead of the apply) --
+  f32x4 s[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) s[t] = f32x4{0, 0, 0, 0};
+#if defined(GPSO_ABLATE2) && (GPSO_ABLATE2 & 4)
+  if (false) {
+#else
+  if (gen) {
+#endif
+    for (int c = 0; c < dp4; ++c) {
+      const float xa = xs_b[c * 64 + lane];
+#pragma unroll
+      for (int t = 0; t < CT; ++t) s[t] = M::mma(xa, xb[(t * dp4 + c) * 64 + lane], s[t]);
+    }
+  }
+  f32x4 p_nxt[CT];
+  // A operands from LDS, two row tiles ahead of their use: the reads are pinned in front of the
+  // previous tile's MFMAs (sched_barrier), otherwise the scheduler sinks them to just before their
+  // use and every row tile pays a full LDS round trip
+  f32x4 a[3];
+  a[0] = panel_b[lane];
+  if (RT > 1) a[1] = panel_b[64 + lane];
+  // ---- apply k-tile kt, with the map of k-tile kt + 1 sliced between the MFMAs -----------------
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+#if defined(GPSO_ABLATE2) && (GPSO_ABLATE2 & 8)
+    if (rt + 2 < RT) a[(rt + 2) % 3] = f32x4{(float)kt, (float)rt, (float)lane, 1.0f};
+#else
+    if (rt + 2 < RT) a[(rt + 2) % 3] = panel_b[(rt + 2) * 64 + lane];
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(DIAG && kt > kt_diag0 + rt)) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[rt][t] = M::mma(a[rt % 3][r], p_cur[t][r], acc[rt][t]);
+    }
+#pragma unroll
+    for (int e = rt * E / RT; e < (rt + 1) * E / RT; ++e) {
+      const int t = e >> 2, r = e & 3;
+#if defined(GPSO_ABLATE2) && (GPSO_ABLATE2 & 1)
+      p_nxt[t][r] = s[t][r] + na[r];
+#else
+      p_nxt[t][r] = kern_from_scaled<KERNEL>(fma_t(-2.0f * C2, s[t][r], na[r] + nb[t]), variance);
+#endif
+    }
+    if (GPSO_SGB == 2) __builtin_amdgcn_sched_barrier(0);  // keep each row tile's slice together
+  }
+  if (!DIAG && GPSO_SGB == 1) {
+    // pipeline hint for the straight-line body: per apply-MFMA one slot of VALU (+ transcendental)
+#pragma unroll
+    for (int i = 0; i < RT * E; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);  // 1 VALU
+      if ((i & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);  // 1 transcendental
+    }
+  }
+  if (gen && gen_diag) {  // k-tile kt + 1 lies in the diagonal block: its share of k*.alpha
+    const f32x4 a4 = al4[(kt + 1) * 4 + (lane >> 4)];
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) macc[t] = fma_t(p_nxt[t][r], a4[r], macc[t]);
+  }
+#pragma unroll
+  for (int t = 0; t < CT; ++t) p_cur[t] = p_nxt[t];
+}
+
+template <int BM, int CT, int KERNEL>
+__global__ __launch_bounds__(256, 2) void leaf_tiles_v2_kernel(
+    const float* __restrict__ linv_p, const float* __restrict__ xs_p, const float* __restrict__ xnorm,
+    const float* __restrict__ alpha, const float* __restrict__ leaves_s,
+    const float* __restrict__ lnorm, float* __restrict__ part_var, float* __restrict__ part_mean,
+    int npad16, int dp4, int64_t mpad, int nbi, float variance) {
+  using M = Mfma<float>;
+  constexpr int RT = BM / 16;
+  constexpr float C2 = (float)KernScale<KERNEL>::C2;
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  f32x4* panel = reinterpret_cast<f32x4*>(lds_raw);           // [2][RT][64] f32x4
+  float* xsl = reinterpret_cast<float*>(panel + 2 * RT * 64);  // [2][dp4][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: loops over it stay uniform
+  float* xb = xsl + 2 * dp4 * 64 + (size_t)wave * CT * dp4 * 64;  // [CT][dp4][64] per wave
+
+  const int bi = nbi - 1 - (int)blockIdx.y;
+  const int64_t col0 = ((int64_t)blockIdx.x * 4 + wave) * (CT * 16);
+  const int dp = dp4 * 4;
+  const int kt_diag0 = bi * RT, kt_end = kt_diag0 + RT;
+  const f32x4* linv4 = reinterpret_cast<const f32x4*>(linv_p);
+  const f32x4* xn4 = reinterpret_cast<const f32x4*>(xnorm);
+  const f32x4* al4 = reinterpret_cast<const f32x4*>(alpha);
+
+  auto issue_panel = [&](int kt, int buf) {
+    for (int f = wave; f < RT; f += 4)
+      glds16(linv4 + ((size_t)(kt_diag0 + f) * npad16 + kt) * 64 + lane, panel + (buf * RT + f) * 64);
+  };
+  auto issue_xs = [&](int kt, int buf) {
+    for (int c = wave; c < dp4; c += 4)
+      glds4(xs_p + ((size_t)kt * dp4 + c) * 64 + lane, xsl + (buf * dp4 + c) * 64);
+  };
+
+  // prologue: panel(0) -> P[0], xs(0) -> X[1], xs(1) -> X[0]; this wave's leaf fragments -> xb
+  issue_panel(0, 0);
+  issue_xs(0, 1);
+  if (kt_end > 1) issue_xs(1, 0);
+  for (int t = 0; t < CT; ++t)
+    for (int c = 0; c < dp4; ++c)
+      xb[(t * dp4 + c) * 64 + lane] =
+          leaves_s[(col0 + t * 16 + (lane & 15)) * dp + 4 * c + (lane >> 4)];
+  float nb[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) nb[t] = lnorm[col0 + t * 16 + (lane & 15)] * C2;
+  f32x4 acc[RT][CT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int t = 0; t < CT; ++t) acc[rt][t] = f32x4{0, 0, 0, 0};
+  float macc[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) macc[t] = 0;
+  f32x4 na = xn4[lane >> 4] * C2;  // norms of k-tile 0
+  __syncthreads();                 // (hipcc drains the LDS-DMA queue before the barrier)
+
+  // G(0): not overlapped with anything
+  f32x4 p_cur[CT];
+  {
+    f32x4 s[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) s[t] = f32x4{0, 0, 0, 0};
+    for (int c = 0; c < dp4; ++c) {
+      const float xa = xsl[(1 * dp4 + c) * 64 + lane];
+#pragma unroll
+      for (int t = 0; t < CT; ++t) s[t] = M::mma(xa, xb[(t * dp4 + c) * 64 + lane], s[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        p_cur[t][r] = kern_from_scaled<KERNEL>(fma_t(-2.0f * C2, s[t][r], na[r] + nb[t]), variance);
+    if (kt_diag0 == 0) {
+      const f32x4 a4 = al4[lane >> 4];
+#pragma unroll
+      for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) macc[t] = fma_t(p_cur[t][r], a4[r], macc[t]);
+    }
+  }
+  na = (kt_end > 1) ? xn4[4 + (lane >> 4)] * C2 : na;  // norms of k-tile 1
+  __syncthreads();  // X[1] may be overwritten from here on
+
+  // off-diagonal k-tiles: straight-line steps; then the RT k-tiles of the diagonal block
+#define GPSO_V2_STEP(DIAGF, GEN_DIAG)                                                              \
+  {                                                                                                \
+    const int b = kt & 1;                                                                          \
+    if (kt + 1 < kt_end && !GPSO_NOLOAD) issue_panel(kt + 1, b ^ 1);                               \
+    f32x4 na_nxt = na;                                                                             \
+    if (kt + 2 < kt_end && !GPSO_NOLOAD) {                                                         \
+      issue_xs(kt + 2, b ^ 1);                                                                     \
+      na_nxt = xn4[(kt + 2) * 4 + (lane >> 4)] * C2;                                               \
+    }                                                                                              \
+    leaf_v2_step<RT, CT, KERNEL, DIAGF>(kt, kt_diag0, kt + 1 < kt_end, GEN_DIAG, lane, dp4,        \
+                                        panel + b * RT * 64, xsl + b * dp4 * 64, xb, na, al4, nb,  \
+                                        variance, acc, macc, p_cur);                               \
+    na = na_nxt;                                                                                   \
+    if (!GPSO_NOBAR) __syncthreads(); /* panel(kt+1) / xs(kt+2) landed; buffers b free */          \
+  }
+  for (int kt = 0; kt < kt_diag0; ++kt) GPSO_V2_STEP(false, kt + 1 >= kt_diag0)
+  for (int kt = kt_diag0; kt < kt_end; ++kt) GPSO_V2_STEP(true, true)
+#undef GPSO_V2_STEP
+
+#pragma unroll
+  for (int t = 0; t < CT; ++t) {
+    float sq = 0;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sq = fma_t(acc[rt][t][r], acc[rt][t][r], sq);
+    sq += __shfl_xor(sq, 16);
+    sq += __shfl_xor(sq, 32);
+    float mm = macc[t];
+    mm += __shfl_xor(mm, 16);
+    mm += __shfl_xor(mm, 32);
+    if (lane < 16) {
+      const int64_t col = col0 + t * 16 + lane;
+      part_var[(int64_t)bi * mpad + col] = sq;
+      part_mean[(int64_t)bi * mpad + col] = mm;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void leaf_finalize_kernel(const T* __restrict__ part_var,
@@ -337,6 +573,8 @@ template void launch_prep_leaves<double, double>(hipStream_t, const double*, int
 
 template <>
 int leaf_tiles_bm<float>(int64_t npad) {
+  static const char* force = getenv("GPSO_LEAF_BM");  // experiment switch: 128 | 256
+  if (force && atoi(force) == 128) return 128;
   return (npad % 256 == 0) ? 256 : 128;
 }
 template <>
@@ -355,6 +593,24 @@ static void launch_leaf_tiles_k(hipStream_t st, const T* linv_p, const T* xs_p, 
                      nbi, (T)kp.variance);
 }
 
+template <int BM, int CT, int KERNEL>
+static void launch_leaf_tiles_v2(hipStream_t st, const float* linv_p, const float* xs_p,
+                                 const float* xnorm, const float* alpha, const float* leaves_s,
+                                 const float* lnorm, float* part_var, float* part_mean, int64_t npad,
+                                 int dp4, int64_t mpad, const KernParams& kp) {
+  constexpr int RT = BM / 16;
+  const int nbi = (int)(npad / BM);
+  const dim3 grid((unsigned)(mpad / (4 * CT * 16)), (unsigned)nbi);
+  const size_t lds = (size_t)2 * RT * 64 * 16 + (size_t)2 * dp4 * 64 * 4 + (size_t)4 * CT * dp4 * 64 * 4;
+  hipLaunchKernelGGL((leaf_tiles_v2_kernel<BM, CT, KERNEL>), grid, dim3(256), lds, st, linv_p, xs_p,
+                     xnorm, alpha, leaves_s, lnorm, part_var, part_mean, (int)(npad / 16), dp4, mpad,
+                     nbi, (float)kp.variance);
+}
+template <int BM, int CT, int KERNEL>
+static void launch_leaf_tiles_v2(hipStream_t, const double*, const double*, const double*,
+                                 const double*, const double*, const double*, double*, double*,
+                                 int64_t, int, int64_t, const KernParams&) {}  // (float only)
+
 template <typename T, int KERNEL>
 static void launch_leaf_tiles_shape(hipStream_t st, const T* linv_p, const T* xs_p, const T* xnorm,
                                     const T* alpha, const T* leaves_s, const T* lnorm, T* part_var,
@@ -362,10 +618,17 @@ static void launch_leaf_tiles_shape(hipStream_t st, const T* linv_p, const T* xs
                                     const KernParams& kp) {
 #define GPSO_ARGS st, linv_p, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp
   if constexpr (sizeof(T) == 4) {
-    if (leaf_tiles_bm<T>(npad) == 256)
+    static const bool v1 = getenv("GPSO_LEAF_V1") != nullptr;  // A/B switch (same results)
+    if (!v1) {
+      if (leaf_tiles_bm<T>(npad) == 256)
+        launch_leaf_tiles_v2<256, 2, KERNEL>(GPSO_ARGS);
+      else
+        launch_leaf_tiles_v2<128, 4, KERNEL>(GPSO_ARGS);
+    } else if (leaf_tiles_bm<T>(npad) == 256) {
       launch_leaf_tiles_k<T, 256, 2, KERNEL>(GPSO_ARGS);
-    else
+    } else {
       launch_leaf_tiles_k<T, 128, 4, KERNEL>(GPSO_ARGS);
+    }
   } else {
     launch_leaf_tiles_k<T, 64, 2, KERNEL>(GPSO_ARGS);
   }
