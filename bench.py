@@ -89,6 +89,34 @@ def cpu_baseline(X, y, theta, leaves, varsigma, budget_s=12.0):
     }, post
 
 
+def split_bf16_report(eng, leaves_dev, leaves_all, varsigma, m_total, flops_per_leaf, post, steps):
+    """Time gpso_best_ucb with the L^-1 apply on the bf16 matrix cores (3 / 6 bf16 MFMAs per f32
+    product) and measure the error of each mode -- and of native f32 -- against the float64 oracle."""
+    from oracle import gpr
+
+    rep = {"note": "opt-in gpso_set_option(GPSO_OPT_PREDICT_MATH); the headline value above is native f32"}
+    sample = leaves_all[:2048]
+    ref = gpr.predict_y(post, sample) if post is not None else None
+    for mode in ("native", "bf16x6", "bf16x3"):
+        eng.set_predict_math(mode)
+        eng.best_ucb(leaves_dev, varsigma)
+        t0 = time.perf_counter()
+        ks = []
+        for _ in range(steps):
+            eng.best_ucb(leaves_dev, varsigma)
+            ks.append(eng.last_ms(0))
+        dt = time.perf_counter() - t0
+        entry = {"value": m_total * steps / dt, "unit": "predictions/s", "kernel_ms": float(np.mean(ks)),
+                 "algorithmic_tflops": flops_per_leaf * m_total / (np.mean(ks) * 1e-3) / 1e12}
+        if ref is not None:
+            mean, var = eng.predict(sample.astype(np.float32))
+            entry["max_abs_err_mean_vs_f64_oracle"] = float(np.max(np.abs(mean - ref[0])))
+            entry["max_abs_err_var_vs_f64_oracle"] = float(np.max(np.abs(var - ref[1])))
+        rep[mode] = entry
+    eng.set_predict_math("native")
+    return rep
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +124,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--math", default="native", choices=["native", "bf16x3", "bf16x6"],
+                    help="predict math of float32 workloads (split-bf16 modes are opt-in)")
     args = ap.parse_args()
 
     import torch
@@ -124,7 +154,8 @@ def main():
     X, y, leaves_all = synthetic(n, d, m_total)
     theta = ("Matern52", 0.25 * math.sqrt(d), 1.0, 1.0e-3, float(y.mean()))
 
-    eng = HipGPEngine(dtype, device=local_rank)
+    math_mode = args.math if dtype == "float32" else "native"
+    eng = HipGPEngine(dtype, device=local_rank, predict_math=math_mode)
     # ---- fit on rank 0 (timed separately), broadcast the predict-ready posterior ----------------
     fit_ms = {}
     if rank == 0:
@@ -198,14 +229,18 @@ def main():
                 "workload": label, "D": d, "N_train": n, "leaves_per_gpu": m_per_gpu,
                 "leaves_total": m_total, "kernel": "Matern52", "lengthscale": theta[1],
                 "noise_variance": theta[3], "parallelism": f"leaf-shard x{world}",
-                "leaves_resident_in_hbm": True,
+                "leaves_resident_in_hbm": True, "predict_math": math_mode,
             },
             "fit_ms": fit_ms,
             "posterior_broadcast_ms": bcast_ms,
             "winner": {"index": winner[0], "ucb": winner[3]},
             "roofline": {
-                "kernel": "leaf_tiles_kernel", "bound": "mfma", "achieved": achieved,
+                "kernel": "leaf_tiles_kernel" if math_mode == "native" else f"leaf_tiles_bf16_kernel({math_mode})",
+                "bound": "mfma", "achieved": achieved,
                 "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[dtype],
+                "peak_note": None if math_mode == "native" else
+                "algorithmic f32-equivalent FLOPs against the f32 MFMA peak; the kernel issues "
+                f"{math_mode[-1]} bf16 MFMAs per f32 product on the 2.5 PFLOP/s bf16 pipe",
                 "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC, gfx950-corrected)",
                 "traffic_source": traffic_src,
                 "algorithmic_bytes": int((hi - lo) * (d + 3) * (4 if dtype == "float32" else 8)
@@ -213,6 +248,7 @@ def main():
                 "kernel_ms": kern_ms, "flops_per_leaf": flops_per_leaf, "leaves_per_launch": hi - lo,
             },
         }
+        post = None
         if world == 1 and not args.no_cpu_baseline:
             cb, post = cpu_baseline(X, y, theta, leaves_all, varsigma)
             out["cpu_baseline"] = cb
@@ -224,6 +260,10 @@ def main():
             ucb_ref = mean_ref + varsigma * var_ref
             if winner[0] < n_s:
                 out["winner"]["oracle_ucb_at_index"] = float(ucb_ref[winner[0]])
+        if world == 1 and dtype == "float32" and math_mode == "native":
+            # opt-in split-bf16 predict math, same leaves, same run: throughput + accuracy vs the oracle
+            out["split_bf16"] = split_bf16_report(eng, leaves_dev, leaves_all, varsigma, m_total,
+                                                  flops_per_leaf, post, max(3, args.steps // 2))
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -52,6 +52,12 @@ typedef struct gpso_ctx gpso_ctx;
 #define GPSO_MEM_HOST 0
 #define GPSO_MEM_DEVICE 1
 
+/* options (gpso_set_option) */
+#define GPSO_OPT_PREDICT_MATH 1 /* arithmetic of the L^-1 apply in predict/best_ucb, GPSO_F32 contexts: */
+#define GPSO_MATH_NATIVE 0      /*   f32 MFMA (default)                                                  */
+#define GPSO_MATH_BF16X3 3      /*   2-way bf16 split, 3 bf16 MFMAs per product: |d var| ~ 2e-5 sigma^2  */
+#define GPSO_MATH_BF16X6 6      /*   3-way bf16 split, 6 bf16 MFMAs per product: f32-class accuracy      */
+
 /* which device-resident matrix / vector the debug getters copy out (as float64) */
 #define GPSO_MAT_CHOL 0  /* L, lower Cholesky factor of K + noise*I (upper triangle returned as 0) */
 #define GPSO_MAT_LINV 1  /* L^-1 (lower)                                                        */
@@ -72,6 +78,10 @@ const char* gpso_last_error(const gpso_ctx* ctx);
  * of the context's own stream; NULL restores the private stream. */
 int gpso_set_stream(gpso_ctx* ctx, void* hip_stream);
 int gpso_synchronize(gpso_ctx* ctx);
+/* No counterpart in the reference (GPflow computes in float64 throughout): selects how the
+ * predict path multiplies by L^-1.  The split-bf16 modes need N padded to a multiple of 256
+ * (otherwise the native kernel runs) and keep an extra nsplit * N^2 bf16 copy of L^-1. */
+int gpso_set_option(gpso_ctx* ctx, int option, int value);
 
 /* ---- fit (GPSurrogate.gp_update -> GPRSurrogate._gp_train) --------------------------------- */
 

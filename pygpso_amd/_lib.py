@@ -23,6 +23,9 @@ MATERN52, MATERN32, MATERN12, SQEXP = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
 MAT_CHOL, MAT_LINV, MAT_KINV, MAT_GRAM = 0, 1, 2, 3
 VEC_ALPHA, VEC_WHITE = 0, 1
+OPT_PREDICT_MATH = 1
+MATH_NATIVE, MATH_BF16X3, MATH_BF16X6 = 0, 3, 6
+MATH_IDS = {"native": MATH_NATIVE, "f32": MATH_NATIVE, "bf16x3": MATH_BF16X3, "bf16x6": MATH_BF16X6}
 
 KERNEL_IDS = {
     "Matern52": MATERN52,
@@ -43,6 +46,7 @@ SIGNATURES = {
     "gpso_last_error": (C.c_char_p, [C.c_void_p]),
     "gpso_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gpso_synchronize": (C.c_int, [C.c_void_p]),
+    "gpso_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "gpso_set_data": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, C.c_int64, C.c_int]),
     "gpso_fit_eval": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, C.c_int, C.c_double, C.c_double,
                                 C.c_double, _c_double_p, _c_double_p]),

@@ -51,6 +51,7 @@ struct Engine {
   virtual int alloc_posterior(int64_t n, int d) = 0;
   virtual int adopt_posterior() = 0;
   virtual int64_t padded_n() const = 0;
+  virtual int set_option(int option, int value) = 0;
 };
 
 }  // namespace
@@ -101,17 +102,49 @@ struct EngineT : Engine {
 
   // device buffers
   DevBuf x64, y64, hyper, xs, xnorm, xs_p, K, linv, work, linv_p, white, alpha, logdet, scal, gpart;
+  // split-bf16 copy of L^-1 (float contexts with GPSO_OPT_PREDICT_MATH != native)
+  DevBuf linv_b;
+  int math = GPSO_MATH_NATIVE;
+  bool linv_b_valid = false;
   // predict workspace
   DevBuf leaves_raw, leaves_s, lnorm, pvar, pmean, omean, ovar, oucb, segoff, best, oidx, ovals;
 
   ~EngineT() override {
     for (DevBuf* b : {&x64, &y64, &hyper, &xs, &xnorm, &xs_p, &K, &linv, &work, &linv_p, &white,
                       &alpha, &logdet, &scal, &gpart, &leaves_raw, &leaves_s, &lnorm, &pvar, &pmean,
-                      &omean, &ovar, &oucb, &segoff, &best, &oidx, &ovals})
+                      &omean, &ovar, &oucb, &segoff, &best, &oidx, &ovals, &linv_b})
       if (b->p) (void)hipFree(b->p);
   }
 
   int64_t padded_n() const override { return npad; }
+
+  int nsplit() const { return math == GPSO_MATH_BF16X6 ? 3 : 2; }
+  bool bf16_usable() const { return sizeof(T) == 4 && math != GPSO_MATH_NATIVE && npad > 0 && npad % 256 == 0; }
+
+  // (re)build the bf16 pieces of L^-1 from the f32 L^-1 resident in `linv`
+  int pack_bf16() {
+    linv_b_valid = false;
+    if (!bf16_usable()) return GPSO_OK;
+    int rc = ensure(linv_b, (size_t)nsplit() * npad * npad * 2);
+    if (rc) return rc;
+    if constexpr (sizeof(T) == 4) launch_pack_linv_bf16(st(), nsplit(), as<float>(linv), n, npad, linv_b.p);
+    HIPCHECK(hipGetLastError());
+    linv_b_valid = true;
+    return GPSO_OK;
+  }
+
+  int set_option(int option, int value) override {
+    if (option != GPSO_OPT_PREDICT_MATH) return ctx->fail(GPSO_E_ARG, "unknown option %d", option);
+    if (value != GPSO_MATH_NATIVE && value != GPSO_MATH_BF16X3 && value != GPSO_MATH_BF16X6)
+      return ctx->fail(GPSO_E_ARG, "unknown predict math %d", value);
+    if (value != GPSO_MATH_NATIVE && sizeof(T) != 4)
+      return ctx->fail(GPSO_E_ARG, "split-bf16 predict math needs a GPSO_F32 context");
+    if (value == math) return GPSO_OK;
+    math = value;
+    linv_b_valid = false;
+    if (chol_valid) return pack_bf16();  // L^-1 is resident: make the new mode usable right away
+    return GPSO_OK;
+  }
   hipStream_t st() const { return ctx->stream; }
   double* ls_dev() const { return static_cast<double*>(hyper.p) + kHyperHeader; }
   template <typename U>
@@ -227,6 +260,7 @@ struct EngineT : Engine {
       launch_gradient<T>(s, as<T>(linv), as<T>(alpha), as<T>(xs), as<T>(xnorm), n, npad, d, dp, n_ls,
                          ls_dev(), kp, as<T>(work), as<double>(gpart), as<double>(scal) + 8);
     launch_pack_linv<T>(s, as<T>(linv), n, npad, as<T>(linv_p));
+    if ((rc = pack_bf16())) return rc;
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipEventRecord(ctx->ev[5], s));
     double host[8 + kGradMaxLs + 3];
@@ -274,6 +308,10 @@ struct EngineT : Engine {
     (void)hipMemsetAsync(alpha.p, 0, (size_t)npad * sizeof(T), s);
     launch_convert_in<T>(s, tmp + (size_t)n * n, as<T>(alpha), 1, n, npad);
     launch_pack_linv<T>(s, as<T>(linv), n, npad, as<T>(linv_p));
+    if ((rc = pack_bf16())) {
+      (void)hipFree(tmp);
+      return rc;
+    }
     hipError_t e3 = hipStreamSynchronize(s);
     (void)hipFree(tmp);
     if (e3 != hipSuccess) return ctx->fail(GPSO_E_HIP, "set_posterior: %s", hipGetErrorString(e3));
@@ -307,8 +345,15 @@ struct EngineT : Engine {
       else
         launch_prep_leaves<T, float>(s, reinterpret_cast<const float*>(src), mc, mp, d, dp, ls_dev(), as<T>(leaves_s), as<T>(lnorm));
       HIPCHECK(hipEventRecord(ctx->ev[0], s));
-      launch_leaf_tiles<T>(s, as<T>(linv_p), as<T>(xs_p), as<T>(xnorm), as<T>(alpha), as<T>(leaves_s),
-                           as<T>(lnorm), as<T>(pvar), as<T>(pmean), npad, dp / 4, mp, kp);
+      if (bf16_usable() && linv_b_valid) {
+        if constexpr (sizeof(T) == 4)
+          launch_leaf_tiles_bf16(s, nsplit(), linv_b.p, as<float>(xs_p), as<float>(xnorm), as<float>(alpha),
+                                 as<float>(leaves_s), as<float>(lnorm), as<float>(pvar), as<float>(pmean),
+                                 npad, dp / 4, mp, kp);
+      } else {
+        launch_leaf_tiles<T>(s, as<T>(linv_p), as<T>(xs_p), as<T>(xnorm), as<T>(alpha), as<T>(leaves_s),
+                             as<T>(lnorm), as<T>(pvar), as<T>(pmean), npad, dp / 4, mp, kp);
+      }
       HIPCHECK(hipEventRecord(ctx->ev[1], s));
       launch_leaf_finalize<T>(s, as<T>(pvar), as<T>(pmean), nbi, mp, mc, kp, varsigma, mean_dev + off,
                               var_dev + off, want_ucb ? ucb_dev + off : nullptr);
@@ -529,6 +574,13 @@ struct EngineT : Engine {
     ptrs[2] = xs_p.p;   nbytes[2] = (int64_t)(npad * dp * s);
     ptrs[3] = xnorm.p;  nbytes[3] = (int64_t)(npad * s);
     ptrs[4] = alpha.p;  nbytes[4] = (int64_t)(npad * s);
+    if (bf16_usable()) {
+      if (cap < 6) return ctx->fail(GPSO_E_ARG, "need room for 6 buffers");
+      int rc = ensure(linv_b, (size_t)nsplit() * npad * npad * 2);
+      if (rc) return rc;
+      ptrs[5] = linv_b.p; nbytes[5] = (int64_t)nsplit() * npad * npad * 2;
+      return 6;
+    }
     return 5;
   }
 
@@ -555,6 +607,7 @@ struct EngineT : Engine {
     ls_host.assign(h + kHyperHeader, h + kHyperHeader + n_ls);
     have_post = true;
     chol_valid = have_kinv = false;
+    linv_b_valid = bf16_usable();  // the bf16 pieces travel with the posterior when the mode is on
     return GPSO_OK;
   }
 };
@@ -641,6 +694,11 @@ int gpso_synchronize(gpso_ctx* ctx) {
   ENTER();
   HIPCHECK(hipStreamSynchronize(ctx->stream));
   return GPSO_OK;
+}
+
+int gpso_set_option(gpso_ctx* ctx, int option, int value) {
+  ENTER();
+  return ctx->eng->set_option(option, value);
 }
 
 int gpso_set_data(gpso_ctx* ctx, const double* X, const double* y, int64_t n, int d) {

@@ -22,6 +22,14 @@ template <typename T>
 void launch_leaf_tiles(hipStream_t st, const T* linv_p, const T* xs_p, const T* xnorm,
                        const T* alpha, const T* leaves_s, const T* lnorm, T* part_var, T* part_mean,
                        int64_t npad, int dp4, int64_t mpad, const KernParams& kp);
+// split-bf16 apply (float contexts): nsplit = 2 -> bf16x3, 3 -> bf16x6; needs npad % 256 == 0.
+// linv_b = nsplit * npad * npad bf16, produced by launch_pack_linv_bf16 from the f32 L^-1
+void launch_pack_linv_bf16(hipStream_t st, int nsplit, const float* linv, int64_t n, int64_t npad,
+                           void* linv_b);
+void launch_leaf_tiles_bf16(hipStream_t st, int nsplit, const void* linv_b, const float* xs_p,
+                            const float* xnorm, const float* alpha, const float* leaves_s,
+                            const float* lnorm, float* part_var, float* part_mean, int64_t npad,
+                            int dp4, int64_t mpad, const KernParams& kp);
 template <typename T>
 void launch_leaf_finalize(hipStream_t st, const T* part_var, const T* part_mean, int nbi,
                           int64_t mpad, int64_t m, const KernParams& kp, double varsigma,

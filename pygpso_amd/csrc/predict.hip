@@ -452,6 +452,283 @@ __global__ __launch_bounds__(256, 2) void leaf_tiles_v2_kernel(
   }
 }
 
+// =============================================================================================
+// leaf_tiles, split-bf16 apply (float contexts, opt-in "predict math" bf16x3 / bf16x6)
+//
+// The bf16 matrix cores run at 16x the rate of the f32 MFMA.  L^-1 (at fit time) and the generated
+// cross-Gram tile (here) are split into NS bf16 pieces x = h0 + h1 (+ h2), each piece the bf16
+// rounding of the remainder; the product is recovered from 3 (NS = 2: h0h0 + h0h1 + h1h0) or 6
+// (NS = 3: + h1h1 + h0h2 + h2h0) v_mfma_f32_16x16x32_bf16 with f32 accumulation.  Measured accuracy
+// of the variance at C3 vs float64: native f32 1e-6, bf16x6 7e-7, bf16x3 2e-5 (x sigma^2).
+// The x.x* contraction and the Matern map stay in f32 (r^2 is a cancellation).
+//
+// Workgroup: 8 waves (one per CU, 2 per SIMD), 256 rows of L^-1 x 256 leaves; per k-step of 32
+// training points the NS x 16 A fragments (1 KiB each, 8 bf16 per lane) arrive in LDS by
+// global_load_lds, double buffered.  K-index convention of a fragment (same for A and B, so any
+// assignment is valid): element j < 4 of lane l <-> point 32 q + 4 (l >> 4) + j, element j >= 4
+// <-> point 32 q + 16 + 4 (l >> 4) + (j - 4): the two generated 16-point tiles of the step drop
+// into the B operand without any lane movement.
+// =============================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// (a, b) -> packed bf16 pair (round to nearest even); a, b are replaced by the remainders
+__device__ __forceinline__ unsigned bf16_split_pair(float& a, float& b) {
+  const f32x2 v = {a, b};
+  const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  a -= __builtin_bit_cast(float, u << 16);
+  b -= __builtin_bit_cast(float, u & 0xffff0000u);
+  return u;
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void pack_linv_bf16_kernel(const float* __restrict__ linv, int64_t n,
+                                                             int64_t npad, u32x4* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (rt, kq, lane)
+  const int64_t npad16 = npad / 16, npad32 = npad / 32;
+  if (idx >= npad16 * npad32 * 64) return;
+  const int lane = (int)(idx & 63);
+  const int64_t kq = (idx >> 6) % npad32, rt = (idx >> 6) / npad32;
+  const int64_t row = rt * 16 + (lane & 15);
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int64_t col = kq * 32 + (j >> 2) * 16 + 4 * (lane >> 4) + (j & 3);
+    v[j] = (row < n && col <= row) ? linv[row * npad + col] : 0.0f;
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    u32x4 f;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) f[h] = bf16_split_pair(v[2 * h], v[2 * h + 1]);
+    out[((int64_t)s * npad16 + rt) * npad32 * 64 + kq * 64 + lane] = f;
+  }
+}
+
+template <int NS, int KERNEL, bool DIAG>
+__device__ __forceinline__ void leaf_bf16_step(int q, int q_diag0, int lane, int dp4,
+                                               const u32x4* panel_b /* [NS][16][64] */,
+                                               const float* xs_b /* [2][dp4][64] */, const float* xb,
+                                               const f32x4* __restrict__ xn4,
+                                               const f32x4* __restrict__ al4, const float (&nb)[2],
+                                               float variance, f32x4 (&acc)[16][2], float (&macc)[2]) {
+  using M = Mfma<float>;
+  constexpr int RT = 16, CT = 2;
+  constexpr float C2 = (float)KernScale<KERNEL>::C2;
+  // ---- generate the two 16-point tiles of this k-step (f32) -------------------------------------
+  f32x4 s[2][CT];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int t = 0; t < CT; ++t) s[h][t] = f32x4{0, 0, 0, 0};
+  for (int c = 0; c < dp4; ++c) {
+    const float x0 = xs_b[c * 64 + lane], x1 = xs_b[(dp4 + c) * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      const float l = xb[(t * dp4 + c) * 64 + lane];
+      s[0][t] = M::mma(x0, l, s[0][t]);
+      s[1][t] = M::mma(x1, l, s[1][t]);
+    }
+  }
+  float p[CT][8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const f32x4 na = xn4[(2 * q + h) * 4 + (lane >> 4)] * C2;
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        p[t][4 * h + r] = kern_from_scaled<KERNEL>(fma_t(-2.0f * C2, s[h][t][r], na[r] + nb[t]), variance);
+  }
+  if (DIAG) {  // this k-step lies in the diagonal block: its share of k*.alpha (f32, before the split)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f32x4 a4 = al4[(2 * q + h) * 4 + (lane >> 4)];
+#pragma unroll
+      for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) macc[t] = fma_t(p[t][4 * h + r], a4[r], macc[t]);
+    }
+  }
+  // ---- split into bf16 pieces: B operands ---------------------------------------------------------
+  bf16x8 bfrag[NS][CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t)
+#pragma unroll
+    for (int sp = 0; sp < NS; ++sp) {
+      u32x4 f;
+#pragma unroll
+      for (int h = 0; h < 4; ++h) f[h] = bf16_split_pair(p[t][2 * h], p[t][2 * h + 1]);
+      bfrag[sp][t] = __builtin_bit_cast(bf16x8, f);
+    }
+  // ---- apply: acc[rt][t] += sum over the kept piece products, small terms first -------------------
+  u32x4 a[2][NS];
+#pragma unroll
+  for (int sp = 0; sp < NS; ++sp) a[0][sp] = panel_b[(sp * RT + 0) * 64 + lane];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    if (rt + 1 < RT) {
+#pragma unroll
+      for (int sp = 0; sp < NS; ++sp) a[(rt + 1) & 1][sp] = panel_b[(sp * RT + rt + 1) * 64 + lane];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (DIAG && 2 * (q - q_diag0) > rt) continue;  // all-zero tiles above the diagonal
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      f32x4 c = acc[rt][t];
+#define GPSO_BF(SA, SB) \
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[rt & 1][SA]), bfrag[SB][t], c, 0, 0, 0)
+      if (NS == 3) {
+        GPSO_BF(2, 0);
+        GPSO_BF(0, 2);
+        GPSO_BF(1, 1);
+      }
+      GPSO_BF(1, 0);
+      GPSO_BF(0, 1);
+      GPSO_BF(0, 0);
+#undef GPSO_BF
+      acc[rt][t] = c;
+    }
+  }
+}
+
+template <int NS, int KERNEL>
+__global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
+    const u32x4* __restrict__ linv_b, const float* __restrict__ xs_p, const float* __restrict__ xnorm,
+    const float* __restrict__ alpha, const float* __restrict__ leaves_s,
+    const float* __restrict__ lnorm, float* __restrict__ part_var, float* __restrict__ part_mean,
+    int npad16, int dp4, int64_t mpad, int nbi, float variance) {
+  constexpr int RT = 16, CT = 2, NW = 8;
+  constexpr float C2 = (float)KernScale<KERNEL>::C2;
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  u32x4* panel = reinterpret_cast<u32x4*>(lds_raw);                 // [2][NS][RT][64]
+  float* xsl = reinterpret_cast<float*>(panel + 2 * NS * RT * 64);  // [2][2][dp4][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* xb = xsl + 4 * dp4 * 64 + (size_t)wave * CT * dp4 * 64;  // [CT][dp4][64] per wave
+
+  const int bi = nbi - 1 - (int)blockIdx.y;
+  const int64_t col0 = ((int64_t)blockIdx.x * NW + wave) * (CT * 16);
+  const int dp = dp4 * 4;
+  const int npad32 = npad16 / 2;
+  const int q_diag0 = bi * (RT / 2), q_end = q_diag0 + RT / 2;
+  const f32x4* xn4 = reinterpret_cast<const f32x4*>(xnorm);
+  const f32x4* al4 = reinterpret_cast<const f32x4*>(alpha);
+
+  auto issue = [&](int q, int buf) {
+    for (int f = wave; f < NS * RT; f += NW) {
+      const int sp = f / RT, rt = f % RT;
+      glds16(linv_b + (((size_t)sp * npad16 + (bi * RT + rt)) * npad32 + q) * 64 + lane,
+             panel + ((buf * NS + sp) * RT + rt) * 64);
+    }
+    for (int i = wave; i < 2 * dp4; i += NW) {
+      const int h = i / dp4, c = i % dp4;
+      glds4(xs_p + ((size_t)(2 * q + h) * dp4 + c) * 64 + lane, xsl + ((buf * 2 + h) * dp4 + c) * 64);
+    }
+  };
+
+  issue(0, 0);
+  for (int t = 0; t < CT; ++t)
+    for (int c = 0; c < dp4; ++c)
+      xb[(t * dp4 + c) * 64 + lane] =
+          leaves_s[(col0 + t * 16 + (lane & 15)) * dp + 4 * c + (lane >> 4)];
+  float nb[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) nb[t] = lnorm[col0 + t * 16 + (lane & 15)] * C2;
+  f32x4 acc[RT][CT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int t = 0; t < CT; ++t) acc[rt][t] = f32x4{0, 0, 0, 0};
+  float macc[CT] = {0, 0};
+  __syncthreads();
+
+  for (int q = 0; q < q_diag0; ++q) {
+    const int b = q & 1;
+    issue(q + 1, b ^ 1);
+    leaf_bf16_step<NS, KERNEL, false>(q, q_diag0, lane, dp4, panel + b * NS * RT * 64,
+                                      xsl + b * 2 * dp4 * 64, xb, xn4, al4, nb, variance, acc, macc);
+    __syncthreads();
+  }
+  for (int q = q_diag0; q < q_end; ++q) {
+    const int b = q & 1;
+    if (q + 1 < q_end) issue(q + 1, b ^ 1);
+    leaf_bf16_step<NS, KERNEL, true>(q, q_diag0, lane, dp4, panel + b * NS * RT * 64,
+                                     xsl + b * 2 * dp4 * 64, xb, xn4, al4, nb, variance, acc, macc);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int t = 0; t < CT; ++t) {
+    float sq = 0;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sq = fma_t(acc[rt][t][r], acc[rt][t][r], sq);
+    sq += __shfl_xor(sq, 16);
+    sq += __shfl_xor(sq, 32);
+    float mm = macc[t];
+    mm += __shfl_xor(mm, 16);
+    mm += __shfl_xor(mm, 32);
+    if (lane < 16) {
+      const int64_t col = col0 + t * 16 + lane;
+      part_var[(int64_t)bi * mpad + col] = sq;
+      part_mean[(int64_t)bi * mpad + col] = mm;
+    }
+  }
+}
+
+template <int NS>
+static void launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const float* xs_p,
+                                      const float* xnorm, const float* alpha, const float* leaves_s,
+                                      const float* lnorm, float* part_var, float* part_mean,
+                                      int64_t npad, int dp4, int64_t mpad, const KernParams& kp) {
+  const int nbi = (int)(npad / 256);
+  const dim3 grid((unsigned)(mpad / 256), (unsigned)nbi);
+  const size_t lds = (size_t)2 * NS * 16 * 64 * 16 + (size_t)4 * dp4 * 64 * 4 + (size_t)8 * 2 * dp4 * 64 * 4;
+#define GPSO_L(K)                                                                                  \
+  hipLaunchKernelGGL((leaf_tiles_bf16_kernel<NS, K>), grid, dim3(512), lds, st,                    \
+                     static_cast<const u32x4*>(linv_b), xs_p, xnorm, alpha, leaves_s, lnorm,       \
+                     part_var, part_mean, (int)(npad / 16), dp4, mpad, nbi, (float)kp.variance)
+  static bool attr_set = false;
+  if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in attribute
+    (void)hipFuncSetAttribute((const void*)leaf_tiles_bf16_kernel<NS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)leaf_tiles_bf16_kernel<NS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)leaf_tiles_bf16_kernel<NS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)leaf_tiles_bf16_kernel<NS, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  switch (kp.kernel) {
+    case 0: GPSO_L(0); break;
+    case 1: GPSO_L(1); break;
+    case 2: GPSO_L(2); break;
+    default: GPSO_L(3); break;
+  }
+#undef GPSO_L
+}
+
+void launch_leaf_tiles_bf16(hipStream_t st, int nsplit, const void* linv_b, const float* xs_p,
+                            const float* xnorm, const float* alpha, const float* leaves_s,
+                            const float* lnorm, float* part_var, float* part_mean, int64_t npad,
+                            int dp4, int64_t mpad, const KernParams& kp) {
+  if (nsplit == 3)
+    launch_leaf_tiles_bf16_ns<3>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp);
+  else
+    launch_leaf_tiles_bf16_ns<2>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp);
+}
+
+void launch_pack_linv_bf16(hipStream_t st, int nsplit, const float* linv, int64_t n, int64_t npad,
+                           void* linv_b) {
+  const int64_t total = (npad / 16) * (npad / 32) * 64;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (nsplit == 3)
+    hipLaunchKernelGGL((pack_linv_bf16_kernel<3>), grid, dim3(256), 0, st, linv, n, npad, static_cast<u32x4*>(linv_b));
+  else
+    hipLaunchKernelGGL((pack_linv_bf16_kernel<2>), grid, dim3(256), 0, st, linv, n, npad, static_cast<u32x4*>(linv_b));
+}
+
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void leaf_finalize_kernel(const T* __restrict__ part_var,

@@ -20,7 +20,9 @@ def _is_device_tensor(x):
 
 
 class HipGPEngine:
-    def __init__(self, dtype="float64", device=0):
+    def __init__(self, dtype="float64", device=0, predict_math="native"):
+        """``predict_math`` (float32 engines only): "native" f32 MFMA, or the split-bf16 modes
+        "bf16x6" (f32-class accuracy) / "bf16x3" (|d var| ~ 2e-5 sigma^2) on the bf16 matrix cores."""
         self._lib = L.load()
         self.dtype = {"float64": L.F64, "fp64": L.F64, "f64": L.F64, np.float64: L.F64,
                       "float32": L.F32, "fp32": L.F32, "f32": L.F32, np.float32: L.F32}[dtype]
@@ -32,6 +34,8 @@ class HipGPEngine:
         self._h = handle
         self.n = 0
         self.d = 0
+        if predict_math not in (None, "native", "f32"):
+            self.set_predict_math(predict_math)
 
     # -- plumbing ----------------------------------------------------------------------------
     def close(self):
@@ -54,6 +58,9 @@ class HipGPEngine:
                 raise ValueError(msg)
             raise L.GpsoHipError(rc, msg)
         return rc
+
+    def set_predict_math(self, mode):
+        self._check(self._lib.gpso_set_option(self._h, L.OPT_PREDICT_MATH, L.MATH_IDS[mode]))
 
     def set_stream(self, stream_ptr):
         """Run on an existing hipStream_t (int pointer, e.g. torch.cuda.Stream().cuda_stream)."""

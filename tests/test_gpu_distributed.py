@@ -22,6 +22,28 @@ def _fitted(dtype):
     return eng
 
 
+def test_posterior_handoff_carries_the_bf16_pieces():
+    import torch
+
+    from pygpso_amd import HipGPEngine
+    from pygpso_amd import distributed as D
+
+    X, y = synthetic_problem(512, 5, seed=0)
+    src = HipGPEngine("float32", predict_math="bf16x6")
+    src.set_data(X, y)
+    src.fit_eval("Matern52", [0.5], 1.0, 1e-3, float(y.mean()), want_grad=False)
+    dst = HipGPEngine("float32", predict_math="bf16x6")
+    dst.alloc_posterior(src.n, src.d)
+    a, b = D.engine_posterior_tensors(src), D.engine_posterior_tensors(dst)
+    assert len(a) == len(b) == 6
+    for s_, t_ in zip(a, b):
+        t_.copy_(s_)
+    torch.cuda.synchronize()
+    dst.adopt_posterior()
+    Xs = synthetic_leaves(1500, 5)
+    assert all(np.array_equal(p, q) for p, q in zip(src.predict(Xs), dst.predict(Xs)))
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_posterior_handoff_between_two_contexts(dtype):
     """What a broadcast does, spelled out with device-to-device copies: the receiver predicts

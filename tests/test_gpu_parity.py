@@ -104,6 +104,58 @@ def test_fit_and_predict_fp32(n, d, m):
     assert ucb_ref[int(idx[0])] >= ucb_ref.max() - 4e-3 * np.max(np.abs(y))
 
 
+# ---- split-bf16 predict math (float32 contexts): stated tolerances vs the float64 oracle ----------
+#   bf16x6: the f32 tolerances (|d mean| <= 2e-3 max|y|, |d var| <= 2e-4 sigma^2); measured ~3e-6 sigma^2
+#   bf16x3: same bound on the mean (the mean never goes through the split), |d var| <= 2e-4 sigma^2;
+#           measured ~2e-5 sigma^2
+@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3"])
+@pytest.mark.parametrize("n,d,m,kernel", [(256, 6, 4096, "Matern52"), (512, 12, 3000, "SquaredExponential"),
+                                          (2048, 12, 4096, "Matern52"), (1024, 40, 2048, "Matern32"),
+                                          (300, 5, 1000, "Matern52")])  # last: N_pad % 256 != 0 -> native kernel
+def test_split_bf16_predict_math(mode, n, d, m, kernel):
+    from pygpso_amd import HipGPEngine
+
+    X, y, th = _problem(n, d, kernel, noise=1e-3, variance=1.0)
+    post = gpr.posterior(th, X, y)
+    Xs = synthetic_leaves(m, d)
+    eng = HipGPEngine("float32", predict_math=mode)
+    _fit(eng, X, y, th, grad=False)
+    mean, var = eng.predict(Xs)
+    mean_ref, var_ref = gpr.predict_y(post, Xs)
+    assert np.max(np.abs(mean - mean_ref)) <= 2e-3 * np.max(np.abs(y))
+    assert np.max(np.abs(var - var_ref)) <= 2e-4 * th.variance
+    if mode == "bf16x6":  # f32-class: within 4x of what the native f32 kernel achieves on the same problem
+        nat = HipGPEngine("float32")
+        _fit(nat, X, y, th, grad=False)
+        _, var_nat = nat.predict(Xs)
+        assert np.max(np.abs(var - var_ref)) <= 4 * np.max(np.abs(var_nat - var_ref)) + 1e-6
+    idx, mu, vv, ucb = eng.best_ucb(Xs, VS)
+    ucb_ref = mean_ref + VS * var_ref
+    assert ucb_ref[int(idx[0])] >= ucb_ref.max() - 4e-3 * np.max(np.abs(y))
+    # position independence and determinism hold in these modes too
+    perm = np.random.default_rng(1).permutation(m)
+    m2, v2 = eng.predict(Xs[perm])
+    assert np.array_equal(mean[perm], m2) and np.array_equal(var[perm], v2)
+
+
+def test_predict_math_option_rules():
+    from pygpso_amd import HipGPEngine, _lib as L
+
+    with pytest.raises(ValueError):
+        HipGPEngine("float64", predict_math="bf16x6")  # float32 contexts only
+    X, y, th = _problem(512, 4)
+    Xs = synthetic_leaves(700, 4)
+    eng = HipGPEngine("float32")
+    _fit(eng, X, y, th, grad=False)
+    a = eng.predict(Xs)
+    eng.set_predict_math("bf16x6")  # switching after the fit repacks L^-1 on the spot
+    b = eng.predict(Xs)
+    eng.set_predict_math("native")
+    c = eng.predict(Xs)
+    assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+    assert np.max(np.abs(a[1] - b[1])) < 1e-4 and not np.array_equal(a[1], b[1])
+
+
 def test_segments_ragged_empty_and_first_max_ties():
     X, y, th = _problem(100, 3)
     post = gpr.posterior(th, X, y)
