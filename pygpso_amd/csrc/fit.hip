@@ -113,45 +113,21 @@ template void launch_gram<float>(hipStream_t, const float*, const float*, int64_
 template void launch_gram<double>(hipStream_t, const double*, const double*, int64_t, int64_t, int, const KernParams&, double*);
 
 // =============================================================================================
-// 64x64 diagonal block: Cholesky + triangular inverse, one wave, operands in LDS
+// 64x64 diagonal block: Cholesky + triangular inverse in LDS, 4 waves, blocked by 16 columns
 // =============================================================================================
+// The block is latency-bound (a chain of 64 pivots), so the work between two pivots is kept short:
+//   factor   per 16-column panel: left-looking columns whose dot products only span the panel
+//            (<= 15 terms, wave 0, lane = row), then ONE batched rank-16 update of the trailing
+//            columns by all 256 threads (the panel row of each lane lives in registers);
+//   invert   the four 16x16 diagonal blocks in parallel (one per wave), then the off-diagonal
+//            blocks by distance: X[ib][jb] = -Xd[ib] * sum_kb L[ib][kb] X[kb][jb], one thread per
+//            element of a 16x16 block.
+// Accumulation is in double whatever T is; sqrt / divide are v_rsq_f64 + Newton (the library
+// sqrt/div sequences would sit on the pivot chain).
 constexpr int kDS = kFitBlock + 1;  // LDS row stride (conflict-free row-per-lane access)
+constexpr int kPB = 16;             // panel width inside the block
 
-// dot products over LDS rows with the latency amortised: 8 loads in flight, 4 accumulators
-// (a serial fma chain on ds_read results costs one LDS round trip per element)
-__device__ __forceinline__ double lds_dot_rows(const double* a, const double* b, int n) {
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int k = 0;
-  for (; k + 8 <= n; k += 8) {
-    const double a0 = a[k], a1 = a[k + 1], a2 = a[k + 2], a3 = a[k + 3];
-    const double a4 = a[k + 4], a5 = a[k + 5], a6 = a[k + 6], a7 = a[k + 7];
-    const double b0 = b[k], b1 = b[k + 1], b2 = b[k + 2], b3 = b[k + 3];
-    const double b4 = b[k + 4], b5 = b[k + 5], b6 = b[k + 6], b7 = b[k + 7];
-    s0 = fma(a0, b0, s0); s1 = fma(a1, b1, s1); s2 = fma(a2, b2, s2); s3 = fma(a3, b3, s3);
-    s0 = fma(a4, b4, s0); s1 = fma(a5, b5, s1); s2 = fma(a6, b6, s2); s3 = fma(a7, b7, s3);
-  }
-  for (; k < n; ++k) s0 = fma(a[k], b[k], s0);
-  return (s0 + s1) + (s2 + s3);
-}
-
-// same, second operand strided (a column of a row-major LDS matrix)
-__device__ __forceinline__ double lds_dot_row_col(const double* a, const double* b, int stride, int n) {
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int k = 0;
-  for (; k + 8 <= n; k += 8) {
-    const double a0 = a[k], a1 = a[k + 1], a2 = a[k + 2], a3 = a[k + 3];
-    const double a4 = a[k + 4], a5 = a[k + 5], a6 = a[k + 6], a7 = a[k + 7];
-    const double b0 = b[(k)*stride], b1 = b[(k + 1) * stride], b2 = b[(k + 2) * stride], b3 = b[(k + 3) * stride];
-    const double b4 = b[(k + 4) * stride], b5 = b[(k + 5) * stride], b6 = b[(k + 6) * stride], b7 = b[(k + 7) * stride];
-    s0 = fma(a0, b0, s0); s1 = fma(a1, b1, s1); s2 = fma(a2, b2, s2); s3 = fma(a3, b3, s3);
-    s0 = fma(a4, b4, s0); s1 = fma(a5, b5, s1); s2 = fma(a6, b6, s2); s3 = fma(a7, b7, s3);
-  }
-  for (; k < n; ++k) s0 = fma(a[k], b[k * stride], s0);
-  return (s0 + s1) + (s2 + s3);
-}
-
-// 1/sqrt(x) in full double precision without the long library sqrt/div sequences on the critical
-// path: hardware v_rsq_f64 seed + two Newton steps
+// 1/sqrt(x) in full double precision: hardware v_rsq_f64 seed + two Newton steps
 __device__ __forceinline__ double rsqrt_newton(double x) {
   double r = __builtin_amdgcn_rsq(x);
   r = r * fma(-0.5 * x, r * r, 1.5);
@@ -159,79 +135,166 @@ __device__ __forceinline__ double rsqrt_newton(double x) {
   return r;
 }
 
-// in-LDS inverse of the lower-triangular block Ls -> Xs (lane c owns column c):
-// forward substitution on the identity with wave-uniform loops (Ls reads broadcast, Xs reads are
-// one column per lane): X[i][c] = (delta_ic - sum_{k<i} L[i][k] X[k][c]) * (1 / L[i][i])
-__device__ __forceinline__ void trinv64_lds(const double* Ls, const double* inv_diag, double* Xs,
-                                            int lane) {
-  const int c = lane;
-  for (int i = 0; i < kFitBlock; ++i) {
-    const double acc = ((i == c) ? 1.0 : 0.0) - lds_dot_row_col(Ls + i * kDS, Xs + c, kDS, i);
-    Xs[i * kDS + c] = (i < c) ? 0.0 : acc * inv_diag[i];
+// all 256 threads; Ls holds the symmetric block (lower part used); on return Ls = L (zeros above
+// the diagonal) and inv_diag[i] = 1 / L[i][i].  Pivot failures -> atomicMin(info, global index).
+__device__ __forceinline__ void chol64_lds(double* Ls, double* inv_diag, int64_t k0, int64_t n,
+                                           int* info) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c0 = 0; c0 < kFitBlock; c0 += kPB) {
+    if (wave == 0) {
+      // panel columns c0 .. c0+15; lane = row; row `lane` of the panel is re-read from LDS as it
+      // is finalised by other lanes (same wave: LDS operations complete in order)
+      for (int jj = 0; jj < kPB; ++jj) {
+        const int j = c0 + jj;
+        double v = Ls[lane * kDS + j];
+        {
+          double s0 = 0.0, s1 = 0.0;
+          int k = c0;
+          for (; k + 2 <= j; k += 2) {
+            s0 = fma(Ls[lane * kDS + k], Ls[j * kDS + k], s0);
+            s1 = fma(Ls[lane * kDS + k + 1], Ls[j * kDS + k + 1], s1);
+          }
+          if (k < j) s0 = fma(Ls[lane * kDS + k], Ls[j * kDS + k], s0);
+          v -= s0 + s1;
+        }
+        double piv = __shfl(v, j);
+        if (!(piv > 0.0)) {  // also catches NaN
+          if (lane == 0 && k0 + j < n) atomicMin(info, (int)(k0 + j));
+          piv = 1.0;
+        }
+        const double rinv = rsqrt_newton(piv);
+        double ljj = piv * rinv;
+        ljj = fma(0.5 * rinv, fma(-ljj, ljj, piv), ljj);  // Heron correction
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        Ls[lane * kDS + j] = (lane == j) ? ljj : (lane > j) ? v * rinv : 0.0;
+        if (lane == j) inv_diag[j] = rinv;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      }
+    }
+    __syncthreads();
+    // trailing update: A[i][m] -= sum_{k<16} L[i][c0+k] L[m][c0+k] for c0+16 <= m <= i
+    if (c0 + kPB < kFitBlock) {
+      double li[kPB];
+#pragma unroll
+      for (int k = 0; k < kPB; ++k) li[k] = Ls[lane * kDS + c0 + k];
+      for (int m = c0 + kPB + wave; m < kFitBlock; m += 4) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < kPB; k += 2) {
+          s0 = fma(li[k], Ls[m * kDS + c0 + k], s0);
+          s1 = fma(li[k + 1], Ls[m * kDS + c0 + k + 1], s1);
+        }
+        if (lane >= m) Ls[lane * kDS + m] -= s0 + s1;
+      }
+    }
+    __syncthreads();
   }
 }
 
-// One wave. A: 64x64 block at K + k0*ld + k0. Writes L11 (upper part zeroed) back, inv(L11) into
-// linv's diagonal block, the block's log-det partial (rows < n only) and the failing pivot.
+// all 256 threads; Ls = lower-triangular L (zeros above), inv_diag = 1/diag -> Xs = L^-1
+__device__ __forceinline__ void trinv64_lds(const double* Ls, const double* inv_diag, double* Xs,
+                                            double* Ts /* [3][16][17] scratch */) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < kFitBlock * kDS; e += 256) Xs[e] = 0.0;
+  __syncthreads();
+  // diagonal 16x16 blocks: wave w inverts block w, lane c < 16 owns column c of that block
+  if (lane < kPB) {
+    const int b0 = wave * kPB, c = lane;
+    for (int i = 0; i < kPB; ++i) {
+      double s0 = (i == c) ? 1.0 : 0.0, s1 = 0.0;
+      int k = 0;
+      for (; k + 2 <= i; k += 2) {
+        s0 = fma(-Ls[(b0 + i) * kDS + b0 + k], Xs[(b0 + k) * kDS + b0 + c], s0);
+        s1 = fma(-Ls[(b0 + i) * kDS + b0 + k + 1], Xs[(b0 + k + 1) * kDS + b0 + c], s1);
+      }
+      if (k < i) s0 = fma(-Ls[(b0 + i) * kDS + b0 + k], Xs[(b0 + k) * kDS + b0 + c], s0);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      Xs[(b0 + i) * kDS + b0 + c] = (i < c) ? 0.0 : (s0 + s1) * inv_diag[b0 + i];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+  }
+  __syncthreads();
+  // off-diagonal blocks by distance; one thread per element (r, c) of a 16x16 block
+  const int r = tid >> 4, c = tid & 15;
+  for (int dist = 1; dist < 4; ++dist) {
+    const int nblk = 4 - dist;
+    for (int bq = 0; bq < nblk; ++bq) {  // T = sum_kb L[ib][kb] X[kb][jb]
+      const int jb = bq, ib = bq + dist;
+      double s0 = 0.0, s1 = 0.0;
+      for (int k = jb * kPB; k < ib * kPB; k += 2) {
+        s0 = fma(Ls[(ib * kPB + r) * kDS + k], Xs[k * kDS + jb * kPB + c], s0);
+        s1 = fma(Ls[(ib * kPB + r) * kDS + k + 1], Xs[(k + 1) * kDS + jb * kPB + c], s1);
+      }
+      Ts[(bq * kPB + r) * 17 + c] = s0 + s1;
+    }
+    __syncthreads();
+    for (int bq = 0; bq < nblk; ++bq) {  // X[ib][jb] = -Xd[ib] * T   (Xd lower triangular)
+      const int jb = bq, ib = bq + dist;
+      double s0 = 0.0;
+      for (int k = 0; k <= r; ++k)
+        s0 = fma(Xs[(ib * kPB + r) * kDS + ib * kPB + k], Ts[(bq * kPB + k) * 17 + c], s0);
+      Xs[(ib * kPB + r) * kDS + jb * kPB + c] = -s0;
+    }
+    __syncthreads();
+  }
+}
+
+// A: 64x64 block at K + k0*ld + k0.  Writes L11 (upper part zeroed) back, inv(L11) into linv's
+// diagonal block, the block's log-det partial (rows < n only) and the failing pivot.
 template <typename T>
-__global__ __launch_bounds__(64) void potrf_diag_kernel(T* __restrict__ K, T* __restrict__ linv,
-                                                        int64_t ld, int64_t k0, int64_t n,
-                                                        double* __restrict__ logdet_part,
-                                                        int* __restrict__ info) {
+__global__ __launch_bounds__(256) void potrf_diag_kernel(T* __restrict__ K, T* __restrict__ linv,
+                                                         int64_t ld, int64_t k0, int64_t n,
+                                                         double* __restrict__ logdet_part,
+                                                         int* __restrict__ info) {
   __shared__ double Ls[kFitBlock * kDS];
   __shared__ double Xs[kFitBlock * kDS];
+  __shared__ double Ts[3 * kPB * 17];
   __shared__ double inv_diag[kFitBlock];
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
   T* A = K + k0 * ld + k0;
-  for (int r = 0; r < kFitBlock; ++r) Ls[r * kDS + lane] = (double)A[(int64_t)r * ld + lane];
-  __syncthreads();
-  // left-looking column Cholesky: lane i owns row i; accumulate in double whatever T is
-  for (int j = 0; j < kFitBlock; ++j) {
-    const double v = Ls[lane * kDS + j] - lds_dot_rows(Ls + lane * kDS, Ls + j * kDS, j);
-    double piv = __shfl(v, j);
-    if (!(piv > 0.0)) {  // also catches NaN
-      if (lane == 0 && k0 + j < n) atomicMin(info, (int)(k0 + j));
-      piv = 1.0;
-    }
-    const double rinv = rsqrt_newton(piv);
-    double ljj = piv * rinv;
-    ljj = fma(0.5 * rinv, fma(-ljj, ljj, piv), ljj);  // Heron correction: ljj = sqrt(piv) to 1 ulp
-    __syncthreads();
-    Ls[lane * kDS + j] = (lane == j) ? ljj : (lane > j) ? v * rinv : 0.0;
-    if (lane == j) inv_diag[j] = rinv;
-    __syncthreads();
+  for (int e = tid; e < kFitBlock * kFitBlock; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    Ls[r * kDS + c] = (c <= r) ? (double)A[(int64_t)r * ld + c] : 0.0;
   }
-  // log-determinant of the block: each lane takes the log of its own diagonal entry
-  double lg = (k0 + lane < n) ? log(Ls[lane * kDS + lane]) : 0.0;
-  lg = wave_sum(lg);
-  trinv64_lds(Ls, inv_diag, Xs, lane);
   __syncthreads();
+  chol64_lds(Ls, inv_diag, k0, n, info);
+  if (tid < kFitBlock) {  // log-determinant of the block (wave 0)
+    double lg = (k0 + tid < n) ? log(Ls[tid * kDS + tid]) : 0.0;
+    lg = wave_sum(lg);
+    if (tid == 0) logdet_part[k0 / kFitBlock] = lg;
+  }
+  trinv64_lds(Ls, inv_diag, Xs, Ts);
   T* Xo = linv + k0 * ld + k0;
-  for (int r = 0; r < kFitBlock; ++r) {
-    A[(int64_t)r * ld + lane] = (T)Ls[r * kDS + lane];
-    Xo[(int64_t)r * ld + lane] = (T)Xs[r * kDS + lane];
+  for (int e = tid; e < kFitBlock * kFitBlock; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    A[(int64_t)r * ld + c] = (T)Ls[r * kDS + c];
+    Xo[(int64_t)r * ld + c] = (T)Xs[r * kDS + c];
   }
-  if (lane == 0) logdet_part[k0 / kFitBlock] = lg;
 }
 
 // inverse of every 64x64 diagonal block of an already-factorised L (gpso_set_posterior path)
 template <typename T>
-__global__ __launch_bounds__(64) void trinv_diag_kernel(const T* __restrict__ L,
-                                                        T* __restrict__ linv, int64_t ld) {
+__global__ __launch_bounds__(256) void trinv_diag_kernel(const T* __restrict__ L,
+                                                         T* __restrict__ linv, int64_t ld) {
   __shared__ double Ls[kFitBlock * kDS];
   __shared__ double Xs[kFitBlock * kDS];
+  __shared__ double Ts[3 * kPB * 17];
   __shared__ double inv_diag[kFitBlock];
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
   const int64_t k0 = (int64_t)blockIdx.x * kFitBlock;
   const T* A = L + k0 * ld + k0;
-  for (int r = 0; r < kFitBlock; ++r)
-    Ls[r * kDS + lane] = (lane <= r) ? (double)A[(int64_t)r * ld + lane] : 0.0;
-  inv_diag[lane] = 1.0 / (double)A[(int64_t)lane * ld + lane];
+  for (int e = tid; e < kFitBlock * kFitBlock; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    Ls[r * kDS + c] = (c <= r) ? (double)A[(int64_t)r * ld + c] : 0.0;
+  }
+  if (tid < kFitBlock) inv_diag[tid] = 1.0 / (double)A[(int64_t)tid * ld + tid];
   __syncthreads();
-  trinv64_lds(Ls, inv_diag, Xs, lane);
-  __syncthreads();
+  trinv64_lds(Ls, inv_diag, Xs, Ts);
   T* Xo = linv + k0 * ld + k0;
-  for (int r = 0; r < kFitBlock; ++r) Xo[(int64_t)r * ld + lane] = (T)Xs[r * kDS + lane];
+  for (int e = tid; e < kFitBlock * kFitBlock; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    Xo[(int64_t)r * ld + c] = (T)Xs[r * kDS + c];
+  }
 }
 
 // =============================================================================================
@@ -285,16 +348,28 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmDesc g) {
 
   const bool a_kcontig = (g.sak == 1);
   const bool b_kcontig = (g.sbk == 1);
+  // per-thread staging coordinates (branch-free: the generic strides are selected once)
+  int ai[8], ak[8], bj[8], bk[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int idx = tid + 256 * p;
+    ai[p] = a_kcontig ? (idx >> 5) : (idx & 63);
+    ak[p] = a_kcontig ? (idx & 31) : (idx >> 6);
+    bj[p] = b_kcontig ? (idx >> 5) : (idx & 63);
+    bk[p] = b_kcontig ? (idx & 31) : (idx >> 6);
+  }
   for (int k0 = k_lo; k0 < k_hi; k0 += kGK) {
+    // all 16 global loads of the stage are issued before the first LDS store (one round trip)
+    T av[8], bv[8];
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
-      const int idx = tid + 256 * p;
-      int i, k;
-      if (a_kcontig) { k = idx & 31; i = idx >> 5; } else { i = idx & 63; k = idx >> 6; }
-      As[i * kGS + k] = A[(int64_t)(ti * 64 + i) * g.sai + (int64_t)(k0 + k) * g.sak];
-      int j, kb;
-      if (b_kcontig) { kb = idx & 31; j = idx >> 5; } else { j = idx & 63; kb = idx >> 6; }
-      Bs[j * kGS + kb] = B[(int64_t)(k0 + kb) * g.sbk + (int64_t)(tj * 64 + j) * g.sbj];
+      av[p] = A[(int64_t)(ti * 64 + ai[p]) * g.sai + (int64_t)(k0 + ak[p]) * g.sak];
+      bv[p] = B[(int64_t)(k0 + bk[p]) * g.sbk + (int64_t)(tj * 64 + bj[p]) * g.sbj];
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      As[ai[p] * kGS + ak[p]] = av[p];
+      Bs[bj[p] * kGS + bk[p]] = bv[p];
     }
     __syncthreads();
 #pragma unroll
@@ -346,7 +421,7 @@ void launch_potrf(hipStream_t st, T* K, T* linv, int64_t n, int64_t npad, double
   const int nb = (int)(npad / kFitBlock);
   for (int p = 0; p < nb; ++p) {
     const int64_t k0 = (int64_t)p * kFitBlock;
-    hipLaunchKernelGGL((potrf_diag_kernel<T>), dim3(1), dim3(64), 0, st, K, linv, npad, k0, n,
+    hipLaunchKernelGGL((potrf_diag_kernel<T>), dim3(1), dim3(256), 0, st, K, linv, npad, k0, n,
                        logdet_part, info);
     const int m = (int)(npad - k0 - kFitBlock);
     if (m <= 0) break;
@@ -728,7 +803,7 @@ void launch_install_chol(hipStream_t st, const double* L64, int64_t n, int64_t n
   const int64_t total = npad * npad;
   hipLaunchKernelGGL((install_chol_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      st, L64, n, npad, K);
-  hipLaunchKernelGGL((trinv_diag_kernel<T>), dim3((unsigned)(npad / kFitBlock)), dim3(64), 0, st, K,
+  hipLaunchKernelGGL((trinv_diag_kernel<T>), dim3((unsigned)(npad / kFitBlock)), dim3(256), 0, st, K,
                      linv, npad);
 }
 template void launch_install_chol<float>(hipStream_t, const double*, int64_t, int64_t, float*, float*);
