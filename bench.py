@@ -144,7 +144,10 @@ def main():
                              "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         args.gpus = world
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # launched by torch.distributed.run (RANK set): always take the distributed code path, also for
+    # --nproc-per-node 1, so the RCCL plumbing is exercised identically at every N
+    use_dist = "RANK" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -158,24 +161,37 @@ def main():
     eng = HipGPEngine(dtype, device=local_rank, predict_math=math_mode)
     # ---- fit on rank 0 (timed separately), broadcast the predict-ready posterior ----------------
     fit_ms = {}
-    if rank == 0:
+
+    def fit_here(timed):
         eng.set_data(X, y)
-        for name, want_grad in (("posterior", False), ("nlml_grad", True)):
-            ts = []
-            for _ in range(5):
-                eng.fit_eval(*theta, want_grad=want_grad)
-                ts.append(eng.last_ms(2))
-            fit_ms[name] = float(np.median(ts))
+        if timed:
+            for name, want_grad in (("posterior", False), ("nlml_grad", True)):
+                ts = []
+                for _ in range(5):
+                    eng.fit_eval(*theta, want_grad=want_grad)
+                    ts.append(eng.last_ms(2))
+                fit_ms[name] = float(np.median(ts))
         eng.fit_eval(*theta, want_grad=False)
+
+    if rank == 0:
+        fit_here(timed=True)
     bcast_ms = None
-    if world > 1:
+    distribution = "single GPU"
+    if use_dist:
         torch.cuda.synchronize()
         dist.barrier()
-        t0 = time.perf_counter()
-        D.broadcast_posterior(eng, src=0)
-        torch.cuda.synchronize()
-        dist.barrier()
-        bcast_ms = (time.perf_counter() - t0) * 1e3
+        if D.can_view_engine_memory(eng):
+            t0 = time.perf_counter()
+            D.broadcast_posterior(eng, src=0)
+            torch.cuda.synchronize()
+            dist.barrier()
+            bcast_ms = (time.perf_counter() - t0) * 1e3
+            distribution = "fit on rank 0, RCCL broadcast of the predict-ready posterior"
+        else:  # stated, not silent: every rank factorises the same data (bit-identical results)
+            if rank != 0:
+                fit_here(timed=False)
+            dist.barrier()
+            distribution = "replicated fit on every rank (device buffers could not be viewed by torch)"
 
     # ---- this rank's leaf shard, resident in HBM before the timed region --------------------------
     lo, hi = D.shard_range(m_total, rank, world)
@@ -183,7 +199,7 @@ def main():
     leaves_dev = torch.from_numpy(np.ascontiguousarray(leaves_all[lo:hi].astype(np_dtype))).cuda(local_rank)
 
     def step():
-        if world > 1:
+        if use_dist:
             return D.best_ucb_sharded(eng, leaves_dev, lo, varsigma)
         idx, mean, var, ucb = eng.best_ucb(leaves_dev, varsigma)
         return int(idx[0]), float(mean[0]), float(var[0]), float(ucb[0])
@@ -191,7 +207,7 @@ def main():
     for _ in range(args.warmup):
         winner = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     tile_ms = []
     t0 = time.perf_counter()
@@ -199,10 +215,10 @@ def main():
         winner = step()
         tile_ms.append(eng.last_ms(0))
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -233,6 +249,7 @@ def main():
             },
             "fit_ms": fit_ms,
             "posterior_broadcast_ms": bcast_ms,
+            "posterior_distribution": distribution,
             "winner": {"index": winner[0], "ucb": winner[3]},
             "roofline": {
                 "kernel": "leaf_tiles_kernel" if math_mode == "native" else f"leaf_tiles_bf16_kernel({math_mode})",
@@ -265,7 +282,7 @@ def main():
             out["split_bf16"] = split_bf16_report(eng, leaves_dev, leaves_all, varsigma, m_total,
                                                   flops_per_leaf, post, max(3, args.steps // 2))
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

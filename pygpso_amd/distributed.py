@@ -48,6 +48,30 @@ def shard_range(m, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def can_view_engine_memory(engine, group=None):
+    """True on every rank iff EVERY rank can hand the engine's device buffers to torch (agreed with
+    a MIN all-reduce on a torch-allocated tensor, so a rank that cannot does not leave the others
+    waiting inside a broadcast).  Callers that get False re-fit on each rank instead."""
+    ok = 1
+    try:
+        if hasattr(engine, "posterior_tensors"):
+            pass  # the engine already keeps its state in torch tensors
+        elif engine.n > 0:
+            for t in engine_posterior_tensors(engine):
+                _ = t.numel()
+        else:
+            probe = device_bytes_as_tensor(torch.zeros(16, dtype=torch.uint8, device=torch.device(
+                "cuda", engine.device)).data_ptr(), 16, engine.device)
+            _ = probe.numel()
+    except Exception:  # noqa: BLE001 - any failure means "do not broadcast"
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32)
+    if dist.get_backend(group) == "nccl":
+        flag = flag.cuda(engine.device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(flag.item()))
+
+
 def broadcast_posterior(engine, src=0, group=None):
     """Make the posterior resident on rank ``src`` resident on every rank of ``group``."""
     rank = dist.get_rank(group)

@@ -42,6 +42,7 @@ def _worker(rank, world, port, m, dup, out):
         if rank == 0:  # only the root fits
             eng.set_data(X, y)
             eng.fit_eval("Matern52", [0.4], 1.0, 1e-3, 0.0, want_grad=False)
+        assert D.can_view_engine_memory(eng) is True  # agreed across ranks before any bulk collective
         D.broadcast_posterior(eng, src=0)
         lo, hi = D.shard_range(m, rank, world)
         got = D.best_ucb_sharded(eng, leaves[lo:hi], lo, gpr.VARSIGMA_DEFAULT)

@@ -83,6 +83,7 @@ def test_nccl_world_of_one():
                             device_id=torch.device("cuda", 0))
     try:
         eng = _fitted("float32")
+        assert D.can_view_engine_memory(eng) is True
         D.broadcast_posterior(eng, src=0)  # RCCL broadcast straight on the library's buffers
         Xs = synthetic_leaves(3000, 5)
         leaves = torch.from_numpy(Xs.astype(np.float32)).cuda()
