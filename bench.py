@@ -35,6 +35,7 @@ WORKLOADS = {
     "c2": (6, 256, 4096, "float64", "C2: D=6 N_train=256 leaves=4096 fp64 Matern52"),
     "c3": (12, 2048, 65536, "float32", "C3: D=12 N_train=2048 leaves=65536/GPU fp32 Matern52"),
     "c4": (20, 8192, 32768, "float32", "C4 (one GPU's share): D=20 N_train=8192 leaves=32768/GPU fp32 Matern52"),
+    "c5": (40, 16384, 131072, "float32", "C5 (one GPU's share): D=40 N_train=16384 leaves=131072/GPU fp32 Matern52"),
 }
 PEAK_TFLOPS = {"float32": 157.3, "float64": 78.6}  # dense MFMA peaks, MI355X_MICROARCH.md
 # HBM bytes per launch of the dominant kernel come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
@@ -123,6 +124,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--noise", type=float, default=1.0e-3, help="noise variance of the synthetic posterior")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--math", default="native", choices=["native", "bf16x3", "bf16x6"],
                     help="predict math of float32 workloads (split-bf16 modes are opt-in)")
@@ -155,7 +157,7 @@ def main():
     m_total = m_per_gpu * world
     varsigma = float(erfcinv(0.01))
     X, y, leaves_all = synthetic(n, d, m_total)
-    theta = ("Matern52", 0.25 * math.sqrt(d), 1.0, 1.0e-3, float(y.mean()))
+    theta = ("Matern52", 0.25 * math.sqrt(d), 1.0, args.noise, float(y.mean()))
 
     math_mode = args.math if dtype == "float32" else "native"
     eng = HipGPEngine(dtype, device=local_rank, predict_math=math_mode)

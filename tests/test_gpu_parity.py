@@ -345,6 +345,63 @@ def _properties(eng, X, y, th, Xs, post, n_check):
     assert int(whole[0][0]) == int(np.argmax(full_ucb)) and whole[3][0] == full_ucb.max()
 
 
+def test_more_than_one_chunk_of_leaves_and_many_segments():
+    """> 2^20 leaves are processed in chunks inside one call; 500 ragged segments in one launch."""
+    X, y, th = _problem(100, 2)
+    post = gpr.posterior(th, X, y)
+    eng = _engine()
+    _fit(eng, X, y, th, grad=False)
+    m = (1 << 20) + 12345
+    Xs = synthetic_leaves(m, 2, seed=7)
+    cuts = np.sort(np.random.default_rng(8).choice(np.arange(1, m), 499, replace=False))
+    seg = np.concatenate([[0], cuts, [m]])
+    idx, mu, vv, ucb = eng.best_ucb(Xs, VS, seg)
+    mean, var = eng.predict(Xs)
+    full = mean + VS * var
+    for s in (0, 1, 250, 498, 499):  # spot-check segments, including the ones across the chunk seam
+        a, b = seg[s], seg[s + 1]
+        assert idx[s] == int(np.argmax(full[a:b])) and ucb[s] == full[a:b].max()
+    k = int(np.searchsorted(seg, 1 << 20)) - 1  # the segment containing the chunk boundary
+    assert idx[k] == int(np.argmax(full[seg[k]:seg[k + 1]]))
+    sub = np.random.default_rng(9).choice(m, 4096, replace=False)
+    mean_ref, var_ref = gpr.predict_y(post, Xs[sub])
+    assert np.max(np.abs(mean[sub] - mean_ref)) < 1e-9 and np.max(np.abs(var[sub] - var_ref)) < 1e-9
+
+
+def test_dimension_and_size_limits():
+    eng = _engine()
+    with pytest.raises(ValueError):
+        eng.set_data(np.zeros((4, 49)), np.zeros(4))  # D > 48
+    with pytest.raises(ValueError):
+        eng.set_data(np.zeros((0, 3)), np.zeros(0))  # no training point
+    X, y, th = _problem(33, 48)  # D = 48 is the maximum
+    _fit(eng, X, y, th)
+    assert eng.predict(synthetic_leaves(5, 48))[0].shape == (5,)
+
+
+def test_config_C5_one_gpu_share_properties_fp32():
+    """D = 40, N_train = 16384 (config C5); the float64 oracle is too slow for a test at this size,
+    so: size-independent properties + agreement of the three predict-math modes."""
+    from pygpso_amd import HipGPEngine
+
+    n, d, m = 16384, 40, 8192
+    X, y, th = _problem(n, d, variance=1.0, noise=1e-2)
+    Xs = synthetic_leaves(m, d).astype(np.float32)
+    eng = HipGPEngine("float32")
+    f, _ = _fit(eng, X, y, th, grad=False)
+    assert np.isfinite(f)
+    mean, var = eng.predict(Xs)
+    assert np.all(np.isfinite(mean)) and var.min() > 0 and var.max() <= (th.variance + th.noise) * (1 + 1e-5)
+    mt, vt = eng.predict(X[:512].astype(np.float32))
+    assert np.max(np.abs(mt - y[:512])) < 0.5 and np.all(vt < 4 * th.noise + 1e-3)
+    eng.set_predict_math("bf16x6")
+    m6, v6 = eng.predict(Xs)
+    eng.set_predict_math("bf16x3")
+    m3, v3 = eng.predict(Xs)
+    assert np.max(np.abs(v6 - var)) <= 5e-5 and np.max(np.abs(v3 - var)) <= 2e-4
+    assert np.array_equal(m6, mean) and np.array_equal(m3, mean)  # the mean never goes through the split
+
+
 def test_config_C2_full_oracle():
     n, d, m = 256, 6, 4096
     X, y, th = _problem(n, d, variance=1.0)
