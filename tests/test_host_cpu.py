@@ -297,6 +297,17 @@ def test_eval_repeats_and_saver_protocol():
     assert len(saved) == opt.n_eval_counter and best.score_mu > 0
 
 
+def test_objective_workers_are_spawned_not_forked():
+    # n_workers > 1: a spawn pool (a process that holds a HIP context must never fork); the objective
+    # has to be importable by the workers, like any multiprocessing target
+    opt = _optimiser(3, 10)
+    opt.n_workers = 2
+    best = opt.run(rotated_peaks, eval_repeats=2)
+    ser = _optimiser(3, 10)
+    best_ser = ser.run(rotated_peaks, eval_repeats=2)
+    assert best == best_ser and opt.trace == ser.trace
+
+
 def test_bad_arguments():
     with pytest.raises(ValueError):
         GPSOptimiser(parameter_space=_space(), exploration_method="nope")
