@@ -319,85 +319,110 @@ struct GemmDesc {
 constexpr int kGK = 32;       // k-step staged in LDS
 constexpr int kGS = kGK + 4;  // LDS row stride (keeps vec4 alignment)
 
-template <typename T>
+// WT = wave tile edge in 16-element units: the workgroup (4 waves, 2 x 2) computes a TS x TS tile
+// with TS = 32 * WT (64 for WT = 2, 128 for WT = 4).  Staging: every thread moves TS/8 vec4 per
+// operand and k-step with 16-byte global loads along whichever index is contiguous, prefetched into
+// registers one k-step ahead of the MFMAs (the first version waited per scalar load: 14 us for a
+// 64^3 product).  kmode trims the k range of triangular operands at tile granularity.
+template <typename T, int WT>
 __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmDesc g) {
   using M = Mfma<T>;
   using vec4 = typename M::vec4;
-  __shared__ __align__(32) T As[64 * kGS];
-  __shared__ __align__(32) T Bs[64 * kGS];
+  constexpr int TS = 32 * WT;
+  constexpr int NV = TS / 32;  // vec4 per thread, operand and k-step: TS * 32 / 4 / 256
+  __shared__ __align__(32) T As[TS * kGS];
+  __shared__ __align__(32) T Bs[TS * kGS];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int ti = blockIdx.y, tj = blockIdx.x, bz = blockIdx.z;
   if (g.lower_only && tj > ti) return;
   const int m_here = (bz == g.nbatch - 1) ? g.m_last : g.m;
-  if (ti * 64 >= m_here) return;
+  if (ti * TS >= m_here) return;
   const T* A = static_cast<const T*>(g.A) + (int64_t)bz * g.batchA;
   const T* B = static_cast<const T*>(g.B) + (int64_t)bz * g.batchB;
   T* C = static_cast<T*>(g.C) + (int64_t)bz * g.batchC;
 
   int k_lo = 0, k_hi = g.k;
-  if (g.kmode == 1) k_lo = 64 * tj;
-  if (g.kmode == 2) k_lo = 64 * ti;
-  if (g.kmode == 3) k_hi = min(g.k, 64 * (ti + 1));
+  if (g.kmode == 1) k_lo = TS * tj;
+  if (g.kmode == 2) k_lo = TS * ti;
+  if (g.kmode == 3) k_hi = min(g.k, TS * (ti + 1));
 
   const int wr = wave >> 1, wc = wave & 1;
-  vec4 acc[2][2];
+  vec4 acc[WT][WT];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < WT; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = vec4{0, 0, 0, 0};
+    for (int b = 0; b < WT; ++b) acc[a][b] = vec4{0, 0, 0, 0};
 
-  const bool a_kcontig = (g.sak == 1);
-  const bool b_kcontig = (g.sbk == 1);
-  // per-thread staging coordinates (branch-free: the generic strides are selected once)
-  int ai[8], ak[8], bj[8], bk[8];
+  // staging coordinates of this thread's v-th vec4: (row, k) of the 4-element group and the
+  // direction it runs in (along k when the operand is k-contiguous, along the row index otherwise)
+  const bool a_kc = (g.sak == 1), b_kc = (g.sbk == 1);
+  vec4 av[NV], bv[NV];
+  auto load = [&](int k0) {
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const int idx = tid + 256 * p;
-    ai[p] = a_kcontig ? (idx >> 5) : (idx & 63);
-    ak[p] = a_kcontig ? (idx & 31) : (idx >> 6);
-    bj[p] = b_kcontig ? (idx >> 5) : (idx & 63);
-    bk[p] = b_kcontig ? (idx & 31) : (idx >> 6);
-  }
+    for (int v = 0; v < NV; ++v) {
+      const int idx = tid + 256 * v;
+      // k-contiguous: 8 groups per row  -> row = idx / 8, k = 4 * (idx % 8)
+      // row-contiguous: TS/4 groups per k -> k = idx / (TS/4), row = 4 * (idx % (TS/4))
+      const int ar = a_kc ? (idx >> 3) : 4 * (idx % (TS / 4));
+      const int ak = a_kc ? 4 * (idx & 7) : idx / (TS / 4);
+      av[v] = *reinterpret_cast<const vec4*>(A + (int64_t)(ti * TS + ar) * g.sai + (int64_t)(k0 + ak) * g.sak);
+      const int br = b_kc ? (idx >> 3) : 4 * (idx % (TS / 4));
+      const int bk = b_kc ? 4 * (idx & 7) : idx / (TS / 4);
+      bv[v] = *reinterpret_cast<const vec4*>(B + (int64_t)(k0 + bk) * g.sbk + (int64_t)(tj * TS + br) * g.sbj);
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int idx = tid + 256 * v;
+      if (a_kc) {
+        *reinterpret_cast<vec4*>(&As[(idx >> 3) * kGS + 4 * (idx & 7)]) = av[v];
+      } else {
+        const int r0 = 4 * (idx % (TS / 4)), k = idx / (TS / 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) As[(r0 + e) * kGS + k] = av[v][e];
+      }
+      if (b_kc) {
+        *reinterpret_cast<vec4*>(&Bs[(idx >> 3) * kGS + 4 * (idx & 7)]) = bv[v];
+      } else {
+        const int r0 = 4 * (idx % (TS / 4)), k = idx / (TS / 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Bs[(r0 + e) * kGS + k] = bv[v][e];
+      }
+    }
+  };
+
+  if (k_lo < k_hi) load(k_lo);
   for (int k0 = k_lo; k0 < k_hi; k0 += kGK) {
-    // all 16 global loads of the stage are issued before the first LDS store (one round trip)
-    T av[8], bv[8];
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      av[p] = A[(int64_t)(ti * 64 + ai[p]) * g.sai + (int64_t)(k0 + ak[p]) * g.sak];
-      bv[p] = B[(int64_t)(k0 + bk[p]) * g.sbk + (int64_t)(tj * 64 + bj[p]) * g.sbj];
-    }
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      As[ai[p] * kGS + ak[p]] = av[p];
-      Bs[bj[p] * kGS + bk[p]] = bv[p];
-    }
+    store();
     __syncthreads();
+    if (k0 + kGK < k_hi) load(k0 + kGK);  // in flight while the MFMAs below run
 #pragma unroll
     for (int kk = 0; kk < kGK / 16; ++kk) {
-      vec4 a4[2], b4[2];
+      vec4 a4[WT], b4[WT];
 #pragma unroll
-      for (int x = 0; x < 2; ++x) {
-        a4[x] = *reinterpret_cast<const vec4*>(&As[(wr * 32 + x * 16 + (lane & 15)) * kGS + kk * 16 + 4 * (lane >> 4)]);
-        b4[x] = *reinterpret_cast<const vec4*>(&Bs[(wc * 32 + x * 16 + (lane & 15)) * kGS + kk * 16 + 4 * (lane >> 4)]);
+      for (int x = 0; x < WT; ++x) {
+        a4[x] = *reinterpret_cast<const vec4*>(&As[(wr * 16 * WT + x * 16 + (lane & 15)) * kGS + kk * 16 + 4 * (lane >> 4)]);
+        b4[x] = *reinterpret_cast<const vec4*>(&Bs[(wc * 16 * WT + x * 16 + (lane & 15)) * kGS + kk * 16 + 4 * (lane >> 4)]);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < WT; ++a)
 #pragma unroll
-          for (int b = 0; b < 2; ++b) acc[a][b] = M::mma(a4[a][r], b4[b][r], acc[a][b]);
+          for (int b = 0; b < WT; ++b) acc[a][b] = M::mma(a4[a][r], b4[b][r], acc[a][b]);
     }
     __syncthreads();
   }
   const T alpha = (T)g.alpha, beta = (T)g.beta;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < WT; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < WT; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int64_t i = ti * 64 + wr * 32 + a * 16 + M::crow(lane, r);
-        const int64_t j = tj * 64 + wc * 32 + b * 16 + (lane & 15);
+        const int64_t i = ti * TS + wr * 16 * WT + a * 16 + M::crow(lane, r);
+        const int64_t j = tj * TS + wc * 16 * WT + b * 16 + (lane & 15);
         T* c = C + i * g.ldc + j;
         T v = alpha * acc[a][b][r];
         if (g.beta != 0.0) v += beta * (*c);
@@ -408,8 +433,16 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmDesc g) {
 template <typename T>
 static void launch_gemm(hipStream_t st, const GemmDesc& g) {
   if (g.m <= 0 || g.n <= 0 || g.nbatch <= 0) return;
-  const dim3 grid((unsigned)(g.n / 64), (unsigned)(g.m / 64), (unsigned)g.nbatch);
-  hipLaunchKernelGGL((gemm_tile_kernel<T>), grid, dim3(256), 0, st, g);
+  // 128 x 128 tiles when every extent allows it and there is enough work to fill the chip with them
+  const bool big = (g.m % 128 == 0) && (g.n % 128 == 0) && (g.m_last % 128 == 0) &&
+                   ((int64_t)(g.m / 128) * (g.n / 128) * g.nbatch >= 128);
+  if (big) {
+    const dim3 grid((unsigned)(g.n / 128), (unsigned)(g.m / 128), (unsigned)g.nbatch);
+    hipLaunchKernelGGL((gemm_tile_kernel<T, 4>), grid, dim3(256), 0, st, g);
+  } else {
+    const dim3 grid((unsigned)(g.n / 64), (unsigned)(g.m / 64), (unsigned)g.nbatch);
+    hipLaunchKernelGGL((gemm_tile_kernel<T, 2>), grid, dim3(256), 0, st, g);
+  }
 }
 
 // =============================================================================================
