@@ -135,6 +135,26 @@ __device__ __forceinline__ double rsqrt_newton(double x) {
   return r;
 }
 
+// one wave: D (16x16) = sum_{k<K} A(i,k) B(k,j) with both operands in LDS (generic strides), on the
+// f64 MFMA (16x16x4).  Element r of lane l of the result is D[(l >> 4) + 4 r][l & 15].
+__device__ __forceinline__ f64x4 mma16_lds(const double* Ab, int sai, int sak, const double* Bb,
+                                           int sbk, int sbj, int K, int lane) {
+  f64x4 acc{0, 0, 0, 0};
+  for (int k0 = 0; k0 < K; k0 += 4) {
+    const double a = Ab[(lane & 15) * sai + (k0 + (lane >> 4)) * sak];
+    const double b = Bb[(k0 + (lane >> 4)) * sbk + (lane & 15) * sbj];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+__device__ __forceinline__ double readlane_f64(double x, int src_lane /* wave-uniform */) {
+  const long long b = __builtin_bit_cast(long long, x);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src_lane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src_lane);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
 // all 256 threads; Ls holds the symmetric block (lower part used); on return Ls = L (zeros above
 // the diagonal) and inv_diag[i] = 1 / L[i][i].  Pivot failures -> atomicMin(info, global index).
 __device__ __forceinline__ void chol64_lds(double* Ls, double* inv_diag, int64_t k0, int64_t n,
@@ -142,22 +162,19 @@ __device__ __forceinline__ void chol64_lds(double* Ls, double* inv_diag, int64_t
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int c0 = 0; c0 < kFitBlock; c0 += kPB) {
     if (wave == 0) {
-      // panel columns c0 .. c0+15; lane = row; row `lane` of the panel is re-read from LDS as it
-      // is finalised by other lanes (same wave: LDS operations complete in order)
+      // panel columns c0 .. c0+15; lane = row.  The 16 panel entries of the row live in registers
+      // and the pivot row is broadcast with v_readlane (uniform lane index): the 16-pivot chain of
+      // a panel runs without a single LDS round trip.
+      double li[kPB];
+#pragma unroll
+      for (int k = 0; k < kPB; ++k) li[k] = Ls[lane * kDS + c0 + k];
+#pragma unroll
       for (int jj = 0; jj < kPB; ++jj) {
         const int j = c0 + jj;
-        double v = Ls[lane * kDS + j];
-        {
-          double s0 = 0.0, s1 = 0.0;
-          int k = c0;
-          for (; k + 2 <= j; k += 2) {
-            s0 = fma(Ls[lane * kDS + k], Ls[j * kDS + k], s0);
-            s1 = fma(Ls[lane * kDS + k + 1], Ls[j * kDS + k + 1], s1);
-          }
-          if (k < j) s0 = fma(Ls[lane * kDS + k], Ls[j * kDS + k], s0);
-          v -= s0 + s1;
-        }
-        double piv = __shfl(v, j);
+        double v = li[jj];
+#pragma unroll
+        for (int kk = 0; kk < jj; ++kk) v = fma(-li[kk], readlane_f64(li[kk], j), v);
+        double piv = readlane_f64(v, j);
         if (!(piv > 0.0)) {  // also catches NaN
           if (lane == 0 && k0 + j < n) atomicMin(info, (int)(k0 + j));
           piv = 1.0;
@@ -165,26 +182,27 @@ __device__ __forceinline__ void chol64_lds(double* Ls, double* inv_diag, int64_t
         const double rinv = rsqrt_newton(piv);
         double ljj = piv * rinv;
         ljj = fma(0.5 * rinv, fma(-ljj, ljj, piv), ljj);  // Heron correction
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        Ls[lane * kDS + j] = (lane == j) ? ljj : (lane > j) ? v * rinv : 0.0;
+        li[jj] = (lane == j) ? ljj : (lane > j) ? v * rinv : 0.0;
         if (lane == j) inv_diag[j] = rinv;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       }
+#pragma unroll
+      for (int k = 0; k < kPB; ++k) Ls[lane * kDS + c0 + k] = li[k];
     }
     __syncthreads();
-    // trailing update: A[i][m] -= sum_{k<16} L[i][c0+k] L[m][c0+k] for c0+16 <= m <= i
-    if (c0 + kPB < kFitBlock) {
-      double li[kPB];
-#pragma unroll
-      for (int k = 0; k < kPB; ++k) li[k] = Ls[lane * kDS + c0 + k];
-      for (int m = c0 + kPB + wave; m < kFitBlock; m += 4) {
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-        for (int k = 0; k < kPB; k += 2) {
-          s0 = fma(li[k], Ls[m * kDS + c0 + k], s0);
-          s1 = fma(li[k + 1], Ls[m * kDS + c0 + k + 1], s1);
+    // trailing update on the f64 MFMA: for the 16x16 tiles (ib >= mb) right of the panel,
+    // A[ib][mb] -= L[ib][panel] L[mb][panel]^T; one tile per wave and step
+    {
+      const int p = c0 / kPB, nt = 3 - p;  // trailing tiles per side
+      for (int t = wave; t < nt * (nt + 1) / 2; t += 4) {
+        int ib = 0, mb = t;  // t -> (ib, mb) in the lower triangle, row-major
+        while (mb > ib) {
+          mb -= ib + 1;
+          ++ib;
         }
-        if (lane >= m) Ls[lane * kDS + m] -= s0 + s1;
+        const int r0 = (p + 1 + ib) * kPB, m0 = (p + 1 + mb) * kPB;
+        const f64x4 d = mma16_lds(Ls + r0 * kDS + c0, kDS, 1, Ls + m0 * kDS + c0, 1, kDS, kPB, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ls[(r0 + (lane >> 4) + 4 * r) * kDS + m0 + (lane & 15)] -= d[r];
       }
     }
     __syncthreads();
@@ -197,43 +215,42 @@ __device__ __forceinline__ void trinv64_lds(const double* Ls, const double* inv_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int e = tid; e < kFitBlock * kDS; e += 256) Xs[e] = 0.0;
   __syncthreads();
-  // diagonal 16x16 blocks: wave w inverts block w, lane c < 16 owns column c of that block
+  // diagonal 16x16 blocks: wave w inverts block w, lane c < 16 owns column c of that block, kept
+  // in registers (static indices); the L reads are wave-uniform LDS broadcasts off the chain
   if (lane < kPB) {
     const int b0 = wave * kPB, c = lane;
+    double xi[kPB];
+#pragma unroll
     for (int i = 0; i < kPB; ++i) {
-      double s0 = (i == c) ? 1.0 : 0.0, s1 = 0.0;
-      int k = 0;
-      for (; k + 2 <= i; k += 2) {
-        s0 = fma(-Ls[(b0 + i) * kDS + b0 + k], Xs[(b0 + k) * kDS + b0 + c], s0);
-        s1 = fma(-Ls[(b0 + i) * kDS + b0 + k + 1], Xs[(b0 + k + 1) * kDS + b0 + c], s1);
-      }
-      if (k < i) s0 = fma(-Ls[(b0 + i) * kDS + b0 + k], Xs[(b0 + k) * kDS + b0 + c], s0);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      Xs[(b0 + i) * kDS + b0 + c] = (i < c) ? 0.0 : (s0 + s1) * inv_diag[b0 + i];
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      double s0 = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < i; ++k) s0 = fma(-Ls[(b0 + i) * kDS + b0 + k], xi[k], s0);
+      xi[i] = (i < c) ? 0.0 : s0 * inv_diag[b0 + i];
     }
+#pragma unroll
+    for (int i = 0; i < kPB; ++i) Xs[(b0 + i) * kDS + b0 + c] = xi[i];
   }
   __syncthreads();
-  // off-diagonal blocks by distance; one thread per element (r, c) of a 16x16 block
-  const int r = tid >> 4, c = tid & 15;
+  // off-diagonal blocks by distance, one 16x16 block per wave on the f64 MFMA:
+  //   T = sum_kb L[ib][kb] X[kb][jb]   (K = 16 * dist contiguous columns of L)
+  //   X[ib][jb] = -Xd[ib] * T
   for (int dist = 1; dist < 4; ++dist) {
     const int nblk = 4 - dist;
-    for (int bq = 0; bq < nblk; ++bq) {  // T = sum_kb L[ib][kb] X[kb][jb]
-      const int jb = bq, ib = bq + dist;
-      double s0 = 0.0, s1 = 0.0;
-      for (int k = jb * kPB; k < ib * kPB; k += 2) {
-        s0 = fma(Ls[(ib * kPB + r) * kDS + k], Xs[k * kDS + jb * kPB + c], s0);
-        s1 = fma(Ls[(ib * kPB + r) * kDS + k + 1], Xs[(k + 1) * kDS + jb * kPB + c], s1);
-      }
-      Ts[(bq * kPB + r) * 17 + c] = s0 + s1;
+    if (wave < nblk) {
+      const int jb = wave, ib = wave + dist;
+      const f64x4 t = mma16_lds(Ls + ib * kPB * kDS + jb * kPB, kDS, 1, Xs + jb * kPB * kDS + jb * kPB,
+                                kDS, 1, kPB * dist, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ts[(wave * kPB + (lane >> 4) + 4 * r) * 17 + (lane & 15)] = t[r];
     }
     __syncthreads();
-    for (int bq = 0; bq < nblk; ++bq) {  // X[ib][jb] = -Xd[ib] * T   (Xd lower triangular)
-      const int jb = bq, ib = bq + dist;
-      double s0 = 0.0;
-      for (int k = 0; k <= r; ++k)
-        s0 = fma(Xs[(ib * kPB + r) * kDS + ib * kPB + k], Ts[(bq * kPB + k) * 17 + c], s0);
-      Xs[(ib * kPB + r) * kDS + jb * kPB + c] = -s0;
+    if (wave < nblk) {
+      const int jb = wave, ib = wave + dist;
+      const f64x4 x = mma16_lds(Xs + ib * kPB * kDS + ib * kPB, kDS, 1, Ts + wave * kPB * 17, 17, 1,
+                                kPB, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        Xs[(ib * kPB + (lane >> 4) + 4 * r) * kDS + jb * kPB + (lane & 15)] = -x[r];
     }
     __syncthreads();
   }
