@@ -13,6 +13,7 @@
 //
 // Replaces what gpflow GPR.training_loss + its autodiff do per L-BFGS-B evaluation
 // (gpso/gp_surrogate.py:500-503).
+#include <algorithm>
 #include <climits>
 
 #include "common.hpp"
@@ -465,33 +466,55 @@ static void launch_gemm(hipStream_t st, const GemmDesc& g) {
 // =============================================================================================
 // blocked Cholesky
 // =============================================================================================
+// Two-level right-looking blocking: 64-wide inner panels (diagonal block kernel + panel GEMM) whose
+// rank-64 trailing updates stay INSIDE a 256-wide outer panel; the rest of the matrix is updated
+// once per outer panel with a rank-256 SYRK.  The trailing matrix is thus streamed through HBM
+// N/256 times instead of N/64 times and the big update has a GEMM-worthy inner dimension.
+constexpr int kOuterPanel = 256;
+
 template <typename T>
 void launch_potrf(hipStream_t st, T* K, T* linv, int64_t n, int64_t npad, double* logdet_part,
                   int* info) {
-  const int nb = (int)(npad / kFitBlock);
-  for (int p = 0; p < nb; ++p) {
-    const int64_t k0 = (int64_t)p * kFitBlock;
-    hipLaunchKernelGGL((potrf_diag_kernel<T>), dim3(1), dim3(256), 0, st, K, linv, npad, k0, n,
-                       logdet_part, info);
-    const int m = (int)(npad - k0 - kFitBlock);
-    if (m <= 0) break;
-    T* A21 = K + (k0 + kFitBlock) * npad + k0;
-    // L21 = A21 * inv(L11)^T    (in place: every workgroup reads only the rows it overwrites)
-    GemmDesc t{};
-    t.A = A21; t.sai = npad; t.sak = 1;
-    t.B = linv + k0 * npad + k0; t.sbk = 1; t.sbj = npad;  // opB(k,j) = inv11[j][k]
-    t.C = A21; t.ldc = npad;
-    t.m = m; t.n = kFitBlock; t.k = kFitBlock; t.m_last = m; t.nbatch = 1;
-    t.alpha = 1.0; t.beta = 0.0;
-    launch_gemm<T>(st, t);
-    // A22 -= L21 L21^T   (lower tiles)
-    GemmDesc s{};
-    s.A = A21; s.sai = npad; s.sak = 1;
-    s.B = A21; s.sbk = 1; s.sbj = npad;
-    s.C = K + (k0 + kFitBlock) * npad + (k0 + kFitBlock); s.ldc = npad;
-    s.m = m; s.n = m; s.k = kFitBlock; s.m_last = m; s.nbatch = 1;
-    s.alpha = -1.0; s.beta = 1.0; s.lower_only = 1;
-    launch_gemm<T>(st, s);
+  for (int64_t P = 0; P < npad; P += kOuterPanel) {
+    const int64_t Pend = std::min<int64_t>(P + kOuterPanel, npad);
+    for (int64_t k0 = P; k0 < Pend; k0 += kFitBlock) {
+      hipLaunchKernelGGL((potrf_diag_kernel<T>), dim3(1), dim3(256), 0, st, K, linv, npad, k0, n,
+                         logdet_part, info);
+      const int m = (int)(npad - k0 - kFitBlock);
+      if (m <= 0) break;
+      T* A21 = K + (k0 + kFitBlock) * npad + k0;
+      // L21 = A21 * inv(L11)^T    (in place: every workgroup reads only the rows it overwrites)
+      GemmDesc t{};
+      t.A = A21; t.sai = npad; t.sak = 1;
+      t.B = linv + k0 * npad + k0; t.sbk = 1; t.sbj = npad;  // opB(k,j) = inv11[j][k]
+      t.C = A21; t.ldc = npad;
+      t.m = m; t.n = kFitBlock; t.k = kFitBlock; t.m_last = m; t.nbatch = 1;
+      t.alpha = 1.0; t.beta = 0.0;
+      launch_gemm<T>(st, t);
+      // inner update: only the remaining columns of this outer panel, all rows below
+      const int w = (int)(Pend - k0 - kFitBlock);
+      if (w > 0) {
+        GemmDesc s{};
+        s.A = A21; s.sai = npad; s.sak = 1;
+        s.B = A21; s.sbk = 1; s.sbj = npad;  // rows k0+64 .. Pend of L21, transposed
+        s.C = K + (k0 + kFitBlock) * npad + (k0 + kFitBlock); s.ldc = npad;
+        s.m = m; s.n = w; s.k = kFitBlock; s.m_last = m; s.nbatch = 1;
+        s.alpha = -1.0; s.beta = 1.0;
+        launch_gemm<T>(st, s);
+      }
+    }
+    // outer update: A[Pend.., Pend..] -= L[Pend.., P..Pend) L[Pend.., P..Pend)^T   (lower tiles)
+    const int m2 = (int)(npad - Pend);
+    if (m2 > 0) {
+      T* Lp = K + Pend * npad + P;
+      GemmDesc s{};
+      s.A = Lp; s.sai = npad; s.sak = 1;
+      s.B = Lp; s.sbk = 1; s.sbj = npad;
+      s.C = K + Pend * npad + Pend; s.ldc = npad;
+      s.m = m2; s.n = m2; s.k = (int)(Pend - P); s.m_last = m2; s.nbatch = 1;
+      s.alpha = -1.0; s.beta = 1.0; s.lower_only = 1;
+      launch_gemm<T>(st, s);
+    }
   }
 }
 template void launch_potrf<float>(hipStream_t, float*, float*, int64_t, int64_t, double*, int*);
