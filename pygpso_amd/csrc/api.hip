@@ -62,6 +62,8 @@ struct gpso_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev[6] = {};
+  std::vector<hipEvent_t> tile_ev;  // start/stop pairs around the leaf-tile kernel, one per chunk
+  int tile_pairs = 0;               // pairs recorded by the call in flight
   double last_ms[3] = {0, 0, 0};
   std::string err;
   Engine* eng = nullptr;
@@ -334,7 +336,7 @@ struct EngineT : Engine {
     if ((rc = ensure(pvar, (size_t)nbi * cpad * sizeof(T)))) return rc;
     if ((rc = ensure(pmean, (size_t)nbi * cpad * sizeof(T)))) return rc;
     hipStream_t s = st();
-    float tile_ms = 0;
+    ctx->tile_pairs = 0;
     const size_t in_elem = (xs_dtype == GPSO_F64) ? 8 : 4;
     for (int64_t off = 0; off < m; off += chunk) {
       const int64_t mc = std::min<int64_t>(chunk, m - off);
@@ -344,7 +346,12 @@ struct EngineT : Engine {
         launch_prep_leaves<T, double>(s, reinterpret_cast<const double*>(src), mc, mp, d, dp, ls_dev(), as<T>(leaves_s), as<T>(lnorm));
       else
         launch_prep_leaves<T, float>(s, reinterpret_cast<const float*>(src), mc, mp, d, dp, ls_dev(), as<T>(leaves_s), as<T>(lnorm));
-      HIPCHECK(hipEventRecord(ctx->ev[0], s));
+      while ((int)ctx->tile_ev.size() < 2 * (ctx->tile_pairs + 1)) {
+        hipEvent_t e;
+        HIPCHECK(hipEventCreate(&e));
+        ctx->tile_ev.push_back(e);
+      }
+      HIPCHECK(hipEventRecord(ctx->tile_ev[2 * ctx->tile_pairs], s));
       if (bf16_usable() && linv_b_valid) {
         if constexpr (sizeof(T) == 4)
           launch_leaf_tiles_bf16(s, nsplit(), linv_b.p, as<float>(xs_p), as<float>(xnorm), as<float>(alpha),
@@ -354,17 +361,24 @@ struct EngineT : Engine {
         launch_leaf_tiles<T>(s, as<T>(linv_p), as<T>(xs_p), as<T>(xnorm), as<T>(alpha), as<T>(leaves_s),
                              as<T>(lnorm), as<T>(pvar), as<T>(pmean), npad, dp / 4, mp, kp);
       }
-      HIPCHECK(hipEventRecord(ctx->ev[1], s));
+      HIPCHECK(hipEventRecord(ctx->tile_ev[2 * ctx->tile_pairs + 1], s));
+      ++ctx->tile_pairs;
       launch_leaf_finalize<T>(s, as<T>(pvar), as<T>(pmean), nbi, mp, mc, kp, varsigma, mean_dev + off,
                               var_dev + off, want_ucb ? ucb_dev + off : nullptr);
-      // the event pair is reused per chunk: wait for this one before re-recording
-      HIPCHECK(hipEventSynchronize(ctx->ev[1]));
-      float ms = 0;
-      if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) tile_ms += ms;
     }
     HIPCHECK(hipGetLastError());
-    ctx->last_ms[0] = tile_ms;
-    return GPSO_OK;
+    return GPSO_OK;  // (no host wait here: the kernel time is read after the call's final sync)
+  }
+
+  // after the stream has been synchronised: total leaf-tile kernel time of the call
+  void collect_tile_ms() {
+    float total = 0;
+    for (int i = 0; i < ctx->tile_pairs; ++i) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, ctx->tile_ev[2 * i], ctx->tile_ev[2 * i + 1]) == hipSuccess) total += ms;
+    }
+    ctx->last_ms[0] = total;
+    ctx->tile_pairs = 0;
   }
 
   int stage_leaves(const void* xs, int xs_dtype, int xs_mem, int64_t m, const void** dev_ptr) {
@@ -413,6 +427,7 @@ struct EngineT : Engine {
     }
     HIPCHECK(hipEventRecord(ctx->ev[3], s));
     HIPCHECK(hipStreamSynchronize(s));
+    collect_tile_ms();
     float ms = 0;
     if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ms[1] = ms;
     return GPSO_OK;
@@ -452,6 +467,7 @@ struct EngineT : Engine {
     HIPCHECK(hipEventRecord(ctx->ev[3], s));
     HIPCHECK(hipStreamSynchronize(s));
     HIPCHECK(hipGetLastError());
+    collect_tile_ms();
     for (int i = 0; i < nseg; ++i) {
       if (idx) idx[i] = ids[i];
       if (mean) mean[i] = vals[3 * i];
@@ -671,6 +687,7 @@ void gpso_destroy(gpso_ctx* ctx) {
   delete ctx->eng;
   for (auto& ev : ctx->ev)
     if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : ctx->tile_ev) (void)hipEventDestroy(ev);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
