@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle sweep (run on the GPU box): shapes, kernels, dtypes, predict-math
+modes, ARD, segmentations.  Exits non-zero on the first violation of the stated tolerances."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import gpr, tree
+from pygpso_amd import HipGPEngine
+from tests.helpers import synthetic_problem, synthetic_leaves
+
+rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1234")))
+N_CASES = int(os.environ.get("FUZZ_CASES", "60"))
+KERNELS = ["Matern52", "Matern32", "Matern12", "SquaredExponential"]
+bad = 0
+t0 = time.time()
+for case in range(N_CASES):
+    dtype = rng.choice(["float64", "float32"])
+    n = int(rng.choice([1, 2, 7, 33, 64, 65, 127, 128, 129, 200, 255, 256, 257, 400, 512, 700, 1024]))
+    d = int(rng.choice([1, 2, 3, 4, 5, 6, 9, 12, 17, 20, 33, 40, 48]))
+    m = int(rng.choice([1, 2, 15, 16, 17, 100, 255, 256, 257, 1000, 4097]))
+    kernel = str(rng.choice(KERNELS))
+    ard = bool(rng.random() < 0.3) and d > 1
+    math = "native"
+    if dtype == "float32":
+        math = str(rng.choice(["native", "bf16x6", "bf16x3"]))
+    noise = float(rng.choice([1e-3, 1e-2, 1e-1])) if dtype == "float32" else float(rng.choice([1e-6, 1e-4, 1e-2]))
+    X, y = synthetic_problem(n, d, seed=int(rng.integers(1 << 30)))
+    Xs = synthetic_leaves(m, d, seed=int(rng.integers(1 << 30)))
+    ls = 0.25 * np.sqrt(d) * (rng.uniform(0.7, 1.5, size=d) if ard else np.ones(1))
+    th = gpr.Theta(kernel, ls, float(rng.uniform(0.5, 2.0)), noise, float(y.mean()) if n > 1 else 0.0)
+    try:
+        post = gpr.posterior(th, X, y)
+    except np.linalg.LinAlgError:
+        continue
+    f_ref, g_ref = gpr.nlml_and_grad(th, X, y)
+    eng = HipGPEngine(dtype, predict_math=math)
+    eng.set_data(X, y)
+    f, g = eng.fit_eval(kernel, ls, th.variance, th.noise, th.mean_c, want_grad=True)
+    mean, var = eng.predict(Xs)
+    mean_ref, var_ref = gpr.predict_y(post, Xs)
+    ys = max(1.0, float(np.max(np.abs(y))))
+    if dtype == "float64":
+        cond = th.variance / th.noise
+        tol = (1e-5 if kernel == "Matern12" else 1e-9) * max(1.0, cond * 1e-4)
+        e_f, e_g, e_m, e_v = 1e-9 * max(1, cond * 1e-4), 1e-6 * max(1.0, cond * 1e-4), tol * ys, tol * th.variance
+        if kernel == "Matern12":
+            e_f, e_g = 1e-5, 1e-3
+    else:
+        e_f, e_g, e_m, e_v = 5e-5, 2e-2, 3e-3 * ys, 3e-4 * th.variance
+    errs = dict(nlml=abs(f - f_ref) / max(1.0, abs(f_ref)), grad=float(np.max(np.abs(g - g_ref) / np.maximum(1.0, np.abs(g_ref)))),
+                mean=float(np.max(np.abs(mean - mean_ref))), var=float(np.max(np.abs(var - var_ref))))
+    ok = errs["nlml"] <= e_f and errs["grad"] <= e_g and errs["mean"] <= e_m and errs["var"] <= e_v
+    # segmented best-ucb against numpy on the GPU's own mean/var (exact rule check) ...
+    k = int(rng.integers(1, 6))
+    cuts = np.sort(rng.integers(0, m + 1, size=k - 1)) if k > 1 else np.array([], dtype=np.int64)
+    seg = np.concatenate([[0], cuts, [m]]).astype(np.int64)
+    idx, mu, vv, ucb = eng.best_ucb(Xs, gpr.VARSIGMA_DEFAULT, seg)
+    full = mean + gpr.VARSIGMA_DEFAULT * var
+    for s in range(k):
+        a, b = seg[s], seg[s + 1]
+        if a == b:
+            ok &= idx[s] == -1
+        else:
+            ok &= (idx[s] == int(np.argmax(full[a:b]))) and (ucb[s] == full[a:b].max())
+    # ... and the on-device ternary generator on a random box
+    if d <= 12 and case % 3 == 0:
+        b = [(0.0, 1.0)] * d
+        for _ in range(int(rng.integers(0, 6))):
+            b = tree.split_bounds(b)[int(rng.integers(3))]
+        depth = int(rng.integers(1, 7))
+        ok &= np.array_equal(eng.grow(np.array(b), depth), tree.grow(b, depth))
+    status = "ok " if ok else "BAD"
+    bad += (not ok)
+    print(f"{status} {dtype:7s} {math:7s} {kernel:18s} n={n:5d} d={d:2d} m={m:5d} ard={int(ard)} noise={noise:g} "
+          + " ".join(f"{k_}={v:.1e}" for k_, v in errs.items()))
+print(f"{N_CASES} cases, {bad} bad, {time.time() - t0:.1f} s")
+sys.exit(1 if bad else 0)
