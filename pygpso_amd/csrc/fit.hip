@@ -726,17 +726,24 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(const T* __restrict__ ki
     if (i >= n || j >= n || j > i) continue;
     const double w = (i == j) ? 1.0 : 2.0;
     T s = 0;
-    for (int k = 0; k < dp; ++k) s += xi[ii * dp + k] * xj[jj * dp + k];
-    const double r2 = (double)(T(-2) * s + (xnorm[i] + xnorm[j]));
+    double r2d = 0.0;  // squared distance from direct differences: >= 0 and free of cancellation
+    for (int k = 0; k < dp; ++k) {
+      s += xi[ii * dp + k] * xj[jj * dp + k];
+      const double df = (double)xi[ii * dp + k] - (double)xj[jj * dp + k];
+      r2d = fma(df, df, r2d);
+    }
+    const double r2 = (double)(T(-2) * s + (xnorm[i] + xnorm[j]));  // GEMM form: the K the loss saw
     const double ai = (double)alpha[i], aj = (double)alpha[j];
     const double W = 0.5 * ((double)kinv[i * npad + j] - ai * aj);
     const double kv = kern_from_r2(kernel, r2, variance);
-    const double dk = dkern_dr2(kernel, r2, variance);
+    // the derivative is taken at the direct-difference distance: the Matern-1/2 factor 1/r would
+    // otherwise amplify a GEMM-form r^2 that cancelled to ~0 (or to the 1e-36 clamp) between
+    // near-coincident points in float32, while the per-dimension terms below use direct differences
+    const double dk = dkern_dr2(kernel, r2d, variance);
     g_var += w * W * kv / variance;
     if (i == j) g_noise += W;
-    const double r2c = (kernel == 3) ? r2 : fmax(r2, 1e-36);
     base[p] = w * W * dk;
-    g_iso += base[p] * (-2.0 * r2c);
+    g_iso += base[p] * (-2.0 * r2d);
   }
   auto block_sum = [&](double v) -> double {
     v = wave_sum(v);
