@@ -115,19 +115,48 @@ def reduce_winners(rows):
     return best
 
 
+class _WinnerExchange:
+    """Preallocated buffers for the per-predict all-gather of (ucb, global idx, mean, var): pinned
+    host staging + device tensors, one collective and ONE stream synchronisation per step."""
+
+    def __init__(self, engine, group):
+        self.world = dist.get_world_size(group)
+        self.nccl = dist.get_backend(group) == "nccl"
+        if self.nccl:
+            dev = torch.device("cuda", engine.device)
+            self.mine_host = torch.empty(4, dtype=torch.float64).pin_memory()
+            self.rows_host = torch.empty(self.world * 4, dtype=torch.float64).pin_memory()
+            self.mine_dev = torch.empty(4, dtype=torch.float64, device=dev)
+            self.rows_dev = torch.empty(self.world * 4, dtype=torch.float64, device=dev)
+        else:
+            self.mine_host = torch.empty(4, dtype=torch.float64)
+            self.rows_host = torch.empty(self.world * 4, dtype=torch.float64)
+
+    def exchange(self, ucb, gidx, mean, var, group):
+        m = self.mine_host
+        m[0], m[1], m[2], m[3] = ucb, gidx, mean, var
+        if self.nccl:
+            self.mine_dev.copy_(m, non_blocking=True)
+            dist.all_gather_into_tensor(self.rows_dev, self.mine_dev, group=group)
+            self.rows_host.copy_(self.rows_dev, non_blocking=True)
+            torch.cuda.current_stream(self.mine_dev.device).synchronize()
+        else:
+            dist.all_gather_into_tensor(self.rows_host, m, group=group)
+        return self.rows_host.numpy().reshape(self.world, 4)
+
+
+_exchanges = {}
+
+
 def best_ucb_sharded(engine, local_leaves, offset, varsigma, group=None):
     """Score this rank's leaf shard (rows ``offset ..`` of the global batch) and agree on the global
     winner.  Returns (global_idx, mean, var, ucb) -- identical on every rank, and identical to
     ``engine.best_ucb(all_leaves)`` on one GPU."""
     idx, mean, var, ucb = engine.best_ucb(local_leaves, varsigma)
     gidx = float(idx[0] + offset) if idx[0] >= 0 else -1.0  # < 2^53: exact in float64
-    mine = torch.tensor([ucb[0], gidx, mean[0], var[0]], dtype=torch.float64)
-    backend = dist.get_backend(group)
-    if backend == "nccl":
-        mine = mine.cuda(engine.device)
-    world = dist.get_world_size(group)
-    rows = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(rows, mine, group=group)
-    table = torch.stack(rows).cpu().numpy()
-    w = reduce_winners(table)
+    key = (id(engine), id(group))
+    ex = _exchanges.get(key)
+    if ex is None:
+        ex = _exchanges[key] = _WinnerExchange(engine, group)
+    w = reduce_winners(ex.exchange(float(ucb[0]), gidx, float(mean[0]), float(var[0]), group))
     return int(w[1]), float(w[2]), float(w[3]), float(w[0])
