@@ -308,6 +308,28 @@ def test_objective_workers_are_spawned_not_forked():
     assert best == best_ser and opt.trace == ser.trace
 
 
+def test_conditional_surrogate_grids_match_per_pair_predictions():
+    # what gpso/plotting.py:330-356 computes pair by pair, as one batch
+    from pygpso_amd import conditional_surrogate_grids
+
+    space = ParameterSpace(parameter_names=["a", "b", "c"], parameter_bounds=[[-1, 1]] * 3)
+    opt = GPSOptimiser(parameter_space=space, exploration_depth=3, budget=14)
+    opt.run(lambda p: float(np.exp(-np.sum((np.asarray(p) - 0.2) ** 2))))
+    g = 7
+    grids = conditional_surrogate_grids(opt.gp_surr, granularity=g)
+    assert sorted(grids) == [(0, 1), (0, 2), (1, 2)]
+    best = opt.gp_surr.highest_score.normed_coord
+    ax = np.linspace(0, 1, g)
+    xg, yg = np.meshgrid(ax, ax)
+    for (i, j), (mean, var) in grids.items():
+        at = np.vstack([best] * g * g)
+        at[:, i], at[:, j] = xg.flatten(), yg.flatten()
+        m_ref, v_ref = opt.gp_surr.gpflow_model.predict_y(at)
+        np.testing.assert_allclose(mean, m_ref.numpy().reshape(g, g), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(var, v_ref.numpy().reshape(g, g), rtol=0, atol=1e-12)
+    assert conditional_surrogate_grids(_fixture_surrogate(GPSurrogate), through=np.array([0.5])) == {}
+
+
 def test_bad_arguments():
     with pytest.raises(ValueError):
         GPSOptimiser(parameter_space=_space(), exploration_method="nope")
