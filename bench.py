@@ -35,6 +35,7 @@ WORKLOADS = {
     "c2": (6, 256, 4096, "float64", "C2: D=6 N_train=256 leaves=4096 fp64 Matern52"),
     "c3": (12, 2048, 65536, "float32", "C3: D=12 N_train=2048 leaves=65536/GPU fp32 Matern52"),
     "c4": (20, 8192, 32768, "float32", "C4 (one GPU's share): D=20 N_train=8192 leaves=32768/GPU fp32 Matern52"),
+    "c3f64": (12, 2048, 65536, "float64", "C3 shape in fp64: D=12 N_train=2048 leaves=65536/GPU fp64 Matern52"),
     "c5": (40, 16384, 131072, "float32", "C5 (one GPU's share): D=40 N_train=16384 leaves=131072/GPU fp32 Matern52"),
 }
 PEAK_TFLOPS = {"float32": 157.3, "float64": 78.6}  # dense MFMA peaks, MI355X_MICROARCH.md

@@ -107,12 +107,44 @@ __device__ __forceinline__ float kern_from_scaled(float u, float variance) {
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return fmaf(a, b, c); }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return fma(a, b, c); }
 
-// double: the accurate library exp/sqrt (this is the parity path)
+// exp(x) for x <= ~0 in full double precision without the library's special-case handling:
+// x = k ln2 + r, |r| <= ln2 / 2, degree-13 Taylor in r (remainder < 2e-17), v_ldexp_f64.
+__device__ __forceinline__ double exp_lean(double x) {
+  const double kf = __builtin_rint(x * 1.4426950408889634074);
+  double r = fma(-kf, 6.93147180369123816490e-01, x);
+  r = fma(-kf, 1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;  // 1/13!
+  p = fma(p, r, 2.08767569878681e-09);    // 1/12!
+  p = fma(p, r, 2.505210838544172e-08);   // 1/11!
+  p = fma(p, r, 2.755731922398589e-07);   // 1/10!
+  p = fma(p, r, 2.7557319223985893e-06);  // 1/9!
+  p = fma(p, r, 2.48015873015873e-05);    // 1/8!
+  p = fma(p, r, 1.984126984126984e-04);   // 1/7!
+  p = fma(p, r, 1.388888888888889e-03);   // 1/6!
+  p = fma(p, r, 8.333333333333333e-03);   // 1/5!
+  p = fma(p, r, 4.1666666666666664e-02);  // 1/4!
+  p = fma(p, r, 1.6666666666666666e-01);  // 1/3!
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return __builtin_ldexp(p, (int)fmax(kf, -1100.0));
+}
+
+// sqrt(x), x > 0: v_rsq_f64 seed, two Newton steps, one Heron correction (as in the Cholesky)
+__device__ __forceinline__ double sqrt_lean(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * fma(-0.5 * x, r * r, 1.5);
+  r = r * fma(-0.5 * x, r * r, 1.5);
+  double s = x * r;
+  return fma(0.5 * r, fma(-s, s, x), s);
+}
+
+// double (the parity path): full double precision, lean exp / sqrt (|rel err| ~ 1e-16)
 template <int KERNEL>
 __device__ __forceinline__ double kern_from_scaled(double u, double variance) {
-  if (KERNEL == 3) return variance * exp(-0.5 * u);
-  const double t = sqrt(fmax(u, KernScale<KERNEL>::C2 * 1e-36));
-  const double e = exp(-t);
+  if (KERNEL == 3) return variance * exp_lean(-0.5 * u);
+  const double t = sqrt_lean(fmax(u, KernScale<KERNEL>::C2 * 1e-36));
+  const double e = exp_lean(-t);
   if (KERNEL == 0) return (variance * fma(t, fma(t, 1.0 / 3.0, 1.0), 1.0)) * e;
   if (KERNEL == 1) return variance * (1.0 + t) * e;
   return variance * e;

@@ -237,9 +237,6 @@ __device__ __forceinline__ void glds4(const void* gsrc_lane, void* lds_wave_base
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
 
-#ifndef GPSO_SGB
-#define GPSO_SGB 0
-#endif
 // timing-only ablation switches of the v2 kernel (never set in the shipped build)
 #if defined(GPSO_ABLATE2) && (GPSO_ABLATE2 & 2)
 #define GPSO_NOLOAD 1
@@ -251,46 +248,78 @@ __device__ __forceinline__ void glds4(const void* gsrc_lane, void* lds_wave_base
 #else
 #define GPSO_NOBAR 0
 #endif
-template <int RT, int CT, int KERNEL, bool DIAG>
-__device__ __forceinline__ void leaf_v2_step(int kt, int kt_diag0, bool gen, bool gen_diag, int lane,
-                                             int dp4, const f32x4* panel_b /* [RT][64] */,
-                                             const float* xs_b /* [dp4][64] */, const float* xb,
-                                             const f32x4& na, const f32x4* __restrict__ al4,
-                                             const float (&nb)[CT], float variance,
-                                             f32x4 (&acc)[RT][CT], float (&macc)[CT],
-                                             f32x4 (&p_cur)[CT]) {
-  using M = Mfma<float>;
+
+// LDS images written by global_load_lds are "slabs" of 64 lanes x 16 B (vec4 of double = two slabs)
+// resp. 64 lanes x 4 B (a double = two word planes): the DMA destination is wave-base + lane * size.
+template <typename T>
+struct V2Lds;
+template <>
+struct V2Lds<float> {
+  static constexpr int SLABS = 1, WORDS = 1;
+  static __device__ __forceinline__ f32x4 frag(const unsigned char* base, int lane) {
+    return *reinterpret_cast<const f32x4*>(base + lane * 16);
+  }
+  static __device__ __forceinline__ float word(const unsigned* base, int lane) {
+    return __builtin_bit_cast(float, base[lane]);
+  }
+};
+template <>
+struct V2Lds<double> {
+  static constexpr int SLABS = 2, WORDS = 2;
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ f64x4 frag(const unsigned char* base, int lane) {
+    const f64x2 lo = *reinterpret_cast<const f64x2*>(base + lane * 16);
+    const f64x2 hi = *reinterpret_cast<const f64x2*>(base + 1024 + lane * 16);
+    return f64x4{lo[0], lo[1], hi[0], hi[1]};
+  }
+  static __device__ __forceinline__ double word(const unsigned* base, int lane) {
+    const unsigned long long b = (unsigned long long)base[lane] | ((unsigned long long)base[64 + lane] << 32);
+    return __builtin_bit_cast(double, b);
+  }
+};
+
+template <typename T, int RT, int CT, int KERNEL, bool DIAG>
+__device__ __forceinline__ void leaf_v2_step(
+    int kt, int kt_diag0, bool gen, bool gen_diag, int lane, int dp4,
+    const unsigned char* panel_b /* [RT][SLABS] KiB */, const unsigned* xs_b /* [dp4][WORDS][64] */,
+    const T* xb, const typename Mfma<T>::vec4& na, const typename Mfma<T>::vec4* __restrict__ al4,
+    const T (&nb)[CT], T variance, typename Mfma<T>::vec4 (&acc)[RT][CT], T (&macc)[CT],
+    typename Mfma<T>::vec4 (&p_cur)[CT]) {
+  using M = Mfma<T>;
+  using vec4 = typename M::vec4;
+  using L = V2Lds<T>;
   constexpr int E = CT * 4;
-  constexpr float C2 = (float)KernScale<KERNEL>::C2;
+  constexpr int FB = L::SLABS * 1024;  // bytes of one A fragment in LDS
+  constexpr T C2 = (T)KernScale<KERNEL>::C2;
   // ---- generation MFMAs for k-tile kt + 1 (short dependent chains; issued ahead of the apply) --
-  f32x4 s[CT];
+  vec4 s[CT];
 #pragma unroll
-  for (int t = 0; t < CT; ++t) s[t] = f32x4{0, 0, 0, 0};
+  for (int t = 0; t < CT; ++t) s[t] = vec4{0, 0, 0, 0};
 #if defined(GPSO_ABLATE2) && (GPSO_ABLATE2 & 4)
   if (false) {
 #else
   if (gen) {
 #endif
     for (int c = 0; c < dp4; ++c) {
-      const float xa = xs_b[c * 64 + lane];
+      const T xa = L::word(xs_b + c * L::WORDS * 64, lane);
 #pragma unroll
       for (int t = 0; t < CT; ++t) s[t] = M::mma(xa, xb[(t * dp4 + c) * 64 + lane], s[t]);
     }
   }
-  f32x4 p_nxt[CT];
+  vec4 p_nxt[CT];
   // A operands from LDS, two row tiles ahead of their use: the reads are pinned in front of the
   // previous tile's MFMAs (sched_barrier), otherwise the scheduler sinks them to just before their
   // use and every row tile pays a full LDS round trip
-  f32x4 a[3];
-  a[0] = panel_b[lane];
-  if (RT > 1) a[1] = panel_b[64 + lane];
+  vec4 a[3];
+  a[0] = L::frag(panel_b, lane);
+  if (RT > 1) a[1] = L::frag(panel_b + FB, lane);
   // ---- apply k-tile kt, with the map of k-tile kt + 1 sliced between the MFMAs -----------------
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
 #if defined(GPSO_ABLATE2) && (GPSO_ABLATE2 & 8)
-    if (rt + 2 < RT) a[(rt + 2) % 3] = f32x4{(float)kt, (float)rt, (float)lane, 1.0f};
+    if (rt + 2 < RT) a[(rt + 2) % 3] = vec4{(T)kt, (T)rt, (T)lane, 1};
 #else
-    if (rt + 2 < RT) a[(rt + 2) % 3] = panel_b[(rt + 2) * 64 + lane];
+    if (rt + 2 < RT) a[(rt + 2) % 3] = L::frag(panel_b + (rt + 2) * FB, lane);
 #endif
     __builtin_amdgcn_sched_barrier(0);
     if (!(DIAG && kt > kt_diag0 + rt)) {
@@ -305,22 +334,12 @@ __device__ __forceinline__ void leaf_v2_step(int kt, int kt_diag0, bool gen, boo
 #if defined(GPSO_ABLATE2) && (GPSO_ABLATE2 & 1)
       p_nxt[t][r] = s[t][r] + na[r];
 #else
-      p_nxt[t][r] = kern_from_scaled<KERNEL>(fma_t(-2.0f * C2, s[t][r], na[r] + nb[t]), variance);
+      p_nxt[t][r] = kern_from_scaled<KERNEL>(fma_t((T)(T(-2) * C2), s[t][r], na[r] + nb[t]), variance);
 #endif
-    }
-    if (GPSO_SGB == 2) __builtin_amdgcn_sched_barrier(0);  // keep each row tile's slice together
-  }
-  if (!DIAG && GPSO_SGB == 1) {
-    // pipeline hint for the straight-line body: per apply-MFMA one slot of VALU (+ transcendental)
-#pragma unroll
-    for (int i = 0; i < RT * E; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);  // 1 VALU
-      if ((i & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);  // 1 transcendental
     }
   }
   if (gen && gen_diag) {  // k-tile kt + 1 lies in the diagonal block: its share of k*.alpha
-    const f32x4 a4 = al4[(kt + 1) * 4 + (lane >> 4)];
+    const vec4 a4 = al4[(kt + 1) * 4 + (lane >> 4)];
 #pragma unroll
     for (int t = 0; t < CT; ++t)
 #pragma unroll
@@ -330,37 +349,54 @@ __device__ __forceinline__ void leaf_v2_step(int kt, int kt_diag0, bool gen, boo
   for (int t = 0; t < CT; ++t) p_cur[t] = p_nxt[t];
 }
 
-template <int BM, int CT, int KERNEL>
+template <typename T, int CT, int DP4MAX>
+__host__ __device__ inline size_t leaf_v2_lds_bytes(int rt, int dp4) {
+  return (size_t)2 * rt * (sizeof(T) * 4 / 16) * 1024 + (size_t)2 * dp4 * (sizeof(T) / 4) * 256 +
+         (size_t)4 * CT * dp4 * 64 * sizeof(T);
+}
+
+template <typename T, int BM, int CT, int KERNEL>
 __global__ __launch_bounds__(256, 2) void leaf_tiles_v2_kernel(
-    const float* __restrict__ linv_p, const float* __restrict__ xs_p, const float* __restrict__ xnorm,
-    const float* __restrict__ alpha, const float* __restrict__ leaves_s,
-    const float* __restrict__ lnorm, float* __restrict__ part_var, float* __restrict__ part_mean,
-    int npad16, int dp4, int64_t mpad, int nbi, float variance) {
-  using M = Mfma<float>;
+    const T* __restrict__ linv_p, const T* __restrict__ xs_p, const T* __restrict__ xnorm,
+    const T* __restrict__ alpha, const T* __restrict__ leaves_s, const T* __restrict__ lnorm,
+    T* __restrict__ part_var, T* __restrict__ part_mean, int npad16, int dp4, int64_t mpad, int nbi,
+    T variance) {
+  using M = Mfma<T>;
+  using vec4 = typename M::vec4;
+  using L = V2Lds<T>;
   constexpr int RT = BM / 16;
-  constexpr float C2 = (float)KernScale<KERNEL>::C2;
+  constexpr int FB = L::SLABS * 1024;     // bytes of one A fragment
+  constexpr int XB = L::WORDS * 64 * 4;   // bytes of one X fragment
+  constexpr T C2 = (T)KernScale<KERNEL>::C2;
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  f32x4* panel = reinterpret_cast<f32x4*>(lds_raw);           // [2][RT][64] f32x4
-  float* xsl = reinterpret_cast<float*>(panel + 2 * RT * 64);  // [2][dp4][64]
+  unsigned char* panel = lds_raw;                              // [2][RT] fragments of FB bytes
+  unsigned char* xsl = panel + (size_t)2 * RT * FB;            // [2][dp4] fragments of XB bytes
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: loops over it stay uniform
-  float* xb = xsl + 2 * dp4 * 64 + (size_t)wave * CT * dp4 * 64;  // [CT][dp4][64] per wave
+  T* xb = reinterpret_cast<T*>(xsl + (size_t)2 * dp4 * XB) + (size_t)wave * CT * dp4 * 64;
 
   const int bi = nbi - 1 - (int)blockIdx.y;
   const int64_t col0 = ((int64_t)blockIdx.x * 4 + wave) * (CT * 16);
   const int dp = dp4 * 4;
   const int kt_diag0 = bi * RT, kt_end = kt_diag0 + RT;
-  const f32x4* linv4 = reinterpret_cast<const f32x4*>(linv_p);
-  const f32x4* xn4 = reinterpret_cast<const f32x4*>(xnorm);
-  const f32x4* al4 = reinterpret_cast<const f32x4*>(alpha);
+  const vec4* linv4 = reinterpret_cast<const vec4*>(linv_p);
+  const vec4* xn4 = reinterpret_cast<const vec4*>(xnorm);
+  const vec4* al4 = reinterpret_cast<const vec4*>(alpha);
 
   auto issue_panel = [&](int kt, int buf) {
-    for (int f = wave; f < RT; f += 4)
-      glds16(linv4 + ((size_t)(kt_diag0 + f) * npad16 + kt) * 64 + lane, panel + (buf * RT + f) * 64);
+    for (int f = wave; f < RT; f += 4) {
+      const unsigned char* src =
+          reinterpret_cast<const unsigned char*>(linv4 + ((size_t)(kt_diag0 + f) * npad16 + kt) * 64 + lane);
+#pragma unroll
+      for (int h = 0; h < L::SLABS; ++h) glds16(src + 16 * h, panel + (size_t)(buf * RT + f) * FB + h * 1024);
+    }
   };
   auto issue_xs = [&](int kt, int buf) {
-    for (int c = wave; c < dp4; c += 4)
-      glds4(xs_p + ((size_t)kt * dp4 + c) * 64 + lane, xsl + (buf * dp4 + c) * 64);
+    for (int c = wave; c < dp4; c += 4) {
+      const unsigned* src = reinterpret_cast<const unsigned*>(xs_p + ((size_t)kt * dp4 + c) * 64 + lane);
+#pragma unroll
+      for (int w = 0; w < L::WORDS; ++w) glds4(src + w, xsl + (size_t)(buf * dp4 + c) * XB + w * 256);
+    }
   };
 
   // prologue: panel(0) -> P[0], xs(0) -> X[1], xs(1) -> X[0]; this wave's leaf fragments -> xb
@@ -371,28 +407,29 @@ __global__ __launch_bounds__(256, 2) void leaf_tiles_v2_kernel(
     for (int c = 0; c < dp4; ++c)
       xb[(t * dp4 + c) * 64 + lane] =
           leaves_s[(col0 + t * 16 + (lane & 15)) * dp + 4 * c + (lane >> 4)];
-  float nb[CT];
+  T nb[CT];
 #pragma unroll
   for (int t = 0; t < CT; ++t) nb[t] = lnorm[col0 + t * 16 + (lane & 15)] * C2;
-  f32x4 acc[RT][CT];
+  vec4 acc[RT][CT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int t = 0; t < CT; ++t) acc[rt][t] = f32x4{0, 0, 0, 0};
-  float macc[CT];
+    for (int t = 0; t < CT; ++t) acc[rt][t] = vec4{0, 0, 0, 0};
+  T macc[CT];
 #pragma unroll
   for (int t = 0; t < CT; ++t) macc[t] = 0;
-  f32x4 na = xn4[lane >> 4] * C2;  // norms of k-tile 0
-  __syncthreads();                 // (hipcc drains the LDS-DMA queue before the barrier)
+  vec4 na = xn4[lane >> 4] * C2;  // norms of k-tile 0
+  __syncthreads();                // (hipcc drains the LDS-DMA queue before the barrier)
 
   // G(0): not overlapped with anything
-  f32x4 p_cur[CT];
+  vec4 p_cur[CT];
   {
-    f32x4 s[CT];
+    vec4 s[CT];
 #pragma unroll
-    for (int t = 0; t < CT; ++t) s[t] = f32x4{0, 0, 0, 0};
+    for (int t = 0; t < CT; ++t) s[t] = vec4{0, 0, 0, 0};
+    const unsigned* x1 = reinterpret_cast<const unsigned*>(xsl + (size_t)1 * dp4 * XB);
     for (int c = 0; c < dp4; ++c) {
-      const float xa = xsl[(1 * dp4 + c) * 64 + lane];
+      const T xa = L::word(x1 + c * L::WORDS * 64, lane);
 #pragma unroll
       for (int t = 0; t < CT; ++t) s[t] = M::mma(xa, xb[(t * dp4 + c) * 64 + lane], s[t]);
     }
@@ -400,9 +437,9 @@ __global__ __launch_bounds__(256, 2) void leaf_tiles_v2_kernel(
     for (int t = 0; t < CT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        p_cur[t][r] = kern_from_scaled<KERNEL>(fma_t(-2.0f * C2, s[t][r], na[r] + nb[t]), variance);
+        p_cur[t][r] = kern_from_scaled<KERNEL>(fma_t((T)(T(-2) * C2), s[t][r], na[r] + nb[t]), variance);
     if (kt_diag0 == 0) {
-      const f32x4 a4 = al4[lane >> 4];
+      const vec4 a4 = al4[lane >> 4];
 #pragma unroll
       for (int t = 0; t < CT; ++t)
 #pragma unroll
@@ -417,14 +454,15 @@ __global__ __launch_bounds__(256, 2) void leaf_tiles_v2_kernel(
   {                                                                                                \
     const int b = kt & 1;                                                                          \
     if (kt + 1 < kt_end && !GPSO_NOLOAD) issue_panel(kt + 1, b ^ 1);                               \
-    f32x4 na_nxt = na;                                                                             \
+    vec4 na_nxt = na;                                                                              \
     if (kt + 2 < kt_end && !GPSO_NOLOAD) {                                                         \
       issue_xs(kt + 2, b ^ 1);                                                                     \
       na_nxt = xn4[(kt + 2) * 4 + (lane >> 4)] * C2;                                               \
     }                                                                                              \
-    leaf_v2_step<RT, CT, KERNEL, DIAGF>(kt, kt_diag0, kt + 1 < kt_end, GEN_DIAG, lane, dp4,        \
-                                        panel + b * RT * 64, xsl + b * dp4 * 64, xb, na, al4, nb,  \
-                                        variance, acc, macc, p_cur);                               \
+    leaf_v2_step<T, RT, CT, KERNEL, DIAGF>(                                                        \
+        kt, kt_diag0, kt + 1 < kt_end, GEN_DIAG, lane, dp4, panel + (size_t)b * RT * FB,           \
+        reinterpret_cast<const unsigned*>(xsl + (size_t)b * dp4 * XB), xb, na, al4, nb, variance,  \
+        acc, macc, p_cur);                                                                         \
     na = na_nxt;                                                                                   \
     if (!GPSO_NOBAR) __syncthreads(); /* panel(kt+1) / xs(kt+2) landed; buffers b free */          \
   }
@@ -434,14 +472,14 @@ __global__ __launch_bounds__(256, 2) void leaf_tiles_v2_kernel(
 
 #pragma unroll
   for (int t = 0; t < CT; ++t) {
-    float sq = 0;
+    T sq = 0;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) sq = fma_t(acc[rt][t][r], acc[rt][t][r], sq);
     sq += __shfl_xor(sq, 16);
     sq += __shfl_xor(sq, 32);
-    float mm = macc[t];
+    T mm = macc[t];
     mm += __shfl_xor(mm, 16);
     mm += __shfl_xor(mm, 32);
     if (lane < 16) {
@@ -855,7 +893,11 @@ int leaf_tiles_bm<float>(int64_t npad) {
   return (npad % 256 == 0) ? 256 : 128;
 }
 template <>
-int leaf_tiles_bm<double>(int64_t) { return 64; }
+int leaf_tiles_bm<double>(int64_t npad) {
+  static const bool v1 = getenv("GPSO_LEAF_V1") != nullptr;
+  if (v1) return 64;
+  return (npad % 256 == 0) ? 256 : 128;
+}
 
 template <typename T, int BM, int CT, int KERNEL>
 static void launch_leaf_tiles_k(hipStream_t st, const T* linv_p, const T* xs_p, const T* xnorm,
@@ -870,23 +912,27 @@ static void launch_leaf_tiles_k(hipStream_t st, const T* linv_p, const T* xs_p, 
                      nbi, (T)kp.variance);
 }
 
-template <int BM, int CT, int KERNEL>
-static void launch_leaf_tiles_v2(hipStream_t st, const float* linv_p, const float* xs_p,
-                                 const float* xnorm, const float* alpha, const float* leaves_s,
-                                 const float* lnorm, float* part_var, float* part_mean, int64_t npad,
-                                 int dp4, int64_t mpad, const KernParams& kp) {
+template <typename T, int BM, int CT, int KERNEL>
+static void launch_leaf_tiles_v2(hipStream_t st, const T* linv_p, const T* xs_p, const T* xnorm,
+                                 const T* alpha, const T* leaves_s, const T* lnorm, T* part_var,
+                                 T* part_mean, int64_t npad, int dp4, int64_t mpad,
+                                 const KernParams& kp) {
   constexpr int RT = BM / 16;
   const int nbi = (int)(npad / BM);
   const dim3 grid((unsigned)(mpad / (4 * CT * 16)), (unsigned)nbi);
-  const size_t lds = (size_t)2 * RT * 64 * 16 + (size_t)2 * dp4 * 64 * 4 + (size_t)4 * CT * dp4 * 64 * 4;
-  hipLaunchKernelGGL((leaf_tiles_v2_kernel<BM, CT, KERNEL>), grid, dim3(256), lds, st, linv_p, xs_p,
+  const size_t lds = leaf_v2_lds_bytes<T, CT, 0>(RT, dp4);
+  if (lds > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)leaf_tiles_v2_kernel<T, BM, CT, KERNEL>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL((leaf_tiles_v2_kernel<T, BM, CT, KERNEL>), grid, dim3(256), lds, st, linv_p, xs_p,
                      xnorm, alpha, leaves_s, lnorm, part_var, part_mean, (int)(npad / 16), dp4, mpad,
-                     nbi, (float)kp.variance);
+                     nbi, (T)kp.variance);
 }
-template <int BM, int CT, int KERNEL>
-static void launch_leaf_tiles_v2(hipStream_t, const double*, const double*, const double*,
-                                 const double*, const double*, const double*, double*, double*,
-                                 int64_t, int, int64_t, const KernParams&) {}  // (float only)
 
 template <typename T, int KERNEL>
 static void launch_leaf_tiles_shape(hipStream_t st, const T* linv_p, const T* xs_p, const T* xnorm,
@@ -894,20 +940,27 @@ static void launch_leaf_tiles_shape(hipStream_t st, const T* linv_p, const T* xs
                                     T* part_mean, int64_t npad, int dp4, int64_t mpad,
                                     const KernParams& kp) {
 #define GPSO_ARGS st, linv_p, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp
+  static const bool v1 = getenv("GPSO_LEAF_V1") != nullptr;  // A/B switch (same results)
   if constexpr (sizeof(T) == 4) {
-    static const bool v1 = getenv("GPSO_LEAF_V1") != nullptr;  // A/B switch (same results)
     if (!v1) {
       if (leaf_tiles_bm<T>(npad) == 256)
-        launch_leaf_tiles_v2<256, 2, KERNEL>(GPSO_ARGS);
+        launch_leaf_tiles_v2<T, 256, 2, KERNEL>(GPSO_ARGS);
       else
-        launch_leaf_tiles_v2<128, 4, KERNEL>(GPSO_ARGS);
+        launch_leaf_tiles_v2<T, 128, 4, KERNEL>(GPSO_ARGS);
     } else if (leaf_tiles_bm<T>(npad) == 256) {
       launch_leaf_tiles_k<T, 256, 2, KERNEL>(GPSO_ARGS);
     } else {
       launch_leaf_tiles_k<T, 128, 4, KERNEL>(GPSO_ARGS);
     }
   } else {
-    launch_leaf_tiles_k<T, 64, 2, KERNEL>(GPSO_ARGS);
+    // float64: 16 accumulator tiles of 8 VGPRs; 256 (128) rows x 16 leaves per wave keeps the number
+    // of generated entries per MFMA low (the f64 kernel map is VALU-expensive)
+    if (v1)
+      launch_leaf_tiles_k<T, 64, 2, KERNEL>(GPSO_ARGS);
+    else if (leaf_tiles_bm<T>(npad) == 256)
+      launch_leaf_tiles_v2<T, 256, 1, KERNEL>(GPSO_ARGS);
+    else
+      launch_leaf_tiles_v2<T, 128, 2, KERNEL>(GPSO_ARGS);
   }
 }
 
