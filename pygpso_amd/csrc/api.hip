@@ -108,6 +108,7 @@ struct EngineT : Engine {
   DevBuf linv_b;
   int math = GPSO_MATH_NATIVE;
   bool linv_b_valid = false;
+  std::vector<int64_t> segoff_cache;  // what the device copy of seg_off currently holds
   // predict workspace
   DevBuf leaves_raw, leaves_s, lnorm, pvar, pmean, omean, ovar, oucb, segoff, best, oidx, ovals;
 
@@ -442,8 +443,7 @@ struct EngineT : Engine {
     if ((rc = ensure(oucb, (size_t)m * 8))) return rc;
     if ((rc = ensure(segoff, (size_t)(nseg + 1) * 8))) return rc;
     if ((rc = ensure(best, (size_t)nseg * kArgmaxBlocks * kArgmaxPartialBytes))) return rc;
-    if ((rc = ensure(oidx, (size_t)nseg * 8))) return rc;
-    if ((rc = ensure(ovals, (size_t)nseg * 3 * 8))) return rc;
+    if ((rc = ensure(ovals, (size_t)nseg * 4 * 8))) return rc;
     std::vector<int64_t> so(nseg + 1);
     if (seg_off) {
       for (int i = 0; i <= nseg; ++i) so[i] = seg_off[i];
@@ -455,24 +455,26 @@ struct EngineT : Engine {
       so[0] = 0;
       so[1] = m;
     }
-    HIPCHECK(hipMemcpyAsync(segoff.p, so.data(), (size_t)(nseg + 1) * 8, hipMemcpyHostToDevice, s));
+    if (so != segoff_cache) {  // the segmentation rarely changes between calls: upload only then
+      HIPCHECK(hipMemcpyAsync(segoff.p, so.data(), (size_t)(nseg + 1) * 8, hipMemcpyHostToDevice, s));
+      HIPCHECK(hipStreamSynchronize(s));
+      segoff_cache = so;
+    }
     if (m > 0)
       if ((rc = score_device_leaves(dev, xs_dtype, m, varsigma, true, as<double>(omean), as<double>(ovar), as<double>(oucb)))) return rc;
     launch_seg_argmax(s, as<double>(omean), as<double>(ovar), as<double>(oucb), as<int64_t>(segoff),
-                      nseg, kArgmaxBlocks, best.p, as<int64_t>(oidx), as<double>(ovals));
-    std::vector<double> vals((size_t)nseg * 3);
-    std::vector<int64_t> ids(nseg);
-    HIPCHECK(hipMemcpyAsync(vals.data(), ovals.p, (size_t)nseg * 24, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipMemcpyAsync(ids.data(), oidx.p, (size_t)nseg * 8, hipMemcpyDeviceToHost, s));
+                      nseg, kArgmaxBlocks, best.p, as<double>(ovals));
+    std::vector<double> vals((size_t)nseg * 4);
+    HIPCHECK(hipMemcpyAsync(vals.data(), ovals.p, (size_t)nseg * 32, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipEventRecord(ctx->ev[3], s));
     HIPCHECK(hipStreamSynchronize(s));
     HIPCHECK(hipGetLastError());
     collect_tile_ms();
     for (int i = 0; i < nseg; ++i) {
-      if (idx) idx[i] = ids[i];
-      if (mean) mean[i] = vals[3 * i];
-      if (var) var[i] = vals[3 * i + 1];
-      if (ucb) ucb[i] = vals[3 * i + 2];
+      if (idx) std::memcpy(&idx[i], &vals[4 * i + 3], 8);
+      if (mean) mean[i] = vals[4 * i];
+      if (var) var[i] = vals[4 * i + 1];
+      if (ucb) ucb[i] = vals[4 * i + 2];
     }
     float ms = 0;
     if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ms[1] = ms;

@@ -36,7 +36,7 @@ void launch_leaf_finalize(hipStream_t st, const T* part_var, const T* part_mean,
                           double* mean, double* var, double* ucb);
 void launch_seg_argmax(hipStream_t st, const double* mean, const double* var, const double* ucb,
                        const int64_t* seg_off_dev, int nseg, int nblk, void* partial_dev,
-                       int64_t* out_idx_dev, double* out_vals_dev);
+                       double* out_vals_dev /* [nseg*4]: mean, var, ucb, bit-cast int64 index */);
 constexpr int kArgmaxBlocks = 64;      // stage-1 blocks per segment
 constexpr size_t kArgmaxPartialBytes = 16;  // sizeof(Best)
 

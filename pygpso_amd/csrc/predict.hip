@@ -849,8 +849,7 @@ __global__ __launch_bounds__(256) void seg_argmax_stage2(const Best* __restrict_
                                                          const double* __restrict__ mean,
                                                          const double* __restrict__ var,
                                                          const double* __restrict__ ucb,
-                                                         int64_t* __restrict__ out_idx,
-                                                         double* __restrict__ out_vals /*[nseg*3]*/) {
+                                                         double* __restrict__ out_vals /*[nseg*4]*/) {
   __shared__ Best sh[4];
   const int seg = blockIdx.x;
   Best mine{0.0, -1};
@@ -860,14 +859,16 @@ __global__ __launch_bounds__(256) void seg_argmax_stage2(const Best* __restrict_
   }
   mine = block_best(mine, sh);
   if (threadIdx.x == 0) {
+    // one record per segment: mean, var, ucb and -- bit-cast into the 4th slot -- the winner's
+    // index relative to the segment (a single device-to-host copy brings everything back)
     if (mine.i < 0) {  // empty segment
-      out_idx[seg] = -1;
-      out_vals[seg * 3 + 0] = out_vals[seg * 3 + 1] = out_vals[seg * 3 + 2] = __builtin_nan("");
+      out_vals[seg * 4 + 0] = out_vals[seg * 4 + 1] = out_vals[seg * 4 + 2] = __builtin_nan("");
+      out_vals[seg * 4 + 3] = __builtin_bit_cast(double, (int64_t)-1);
     } else {
-      out_idx[seg] = mine.i - seg_off[seg];
-      out_vals[seg * 3 + 0] = mean[mine.i];
-      out_vals[seg * 3 + 1] = var[mine.i];
-      out_vals[seg * 3 + 2] = ucb[mine.i];
+      out_vals[seg * 4 + 0] = mean[mine.i];
+      out_vals[seg * 4 + 1] = var[mine.i];
+      out_vals[seg * 4 + 2] = ucb[mine.i];
+      out_vals[seg * 4 + 3] = __builtin_bit_cast(double, (int64_t)(mine.i - seg_off[seg]));
     }
   }
 }
@@ -993,12 +994,12 @@ template void launch_leaf_finalize<double>(hipStream_t, const double*, const dou
 
 void launch_seg_argmax(hipStream_t st, const double* mean, const double* var, const double* ucb,
                        const int64_t* seg_off_dev, int nseg, int nblk, void* partial_dev,
-                       int64_t* out_idx_dev, double* out_vals_dev) {
+                       double* out_vals_dev) {
   hipLaunchKernelGGL(seg_argmax_stage1, dim3((unsigned)nblk, (unsigned)nseg), dim3(256), 0, st, ucb,
                      seg_off_dev, reinterpret_cast<Best*>(partial_dev));
   hipLaunchKernelGGL(seg_argmax_stage2, dim3((unsigned)nseg), dim3(256), 0, st,
                      reinterpret_cast<const Best*>(partial_dev), nblk, seg_off_dev, mean, var, ucb,
-                     out_idx_dev, out_vals_dev);
+                     out_vals_dev);
 }
 
 }  // namespace gpso
