@@ -80,13 +80,20 @@ def cpu_baseline(X, y, theta, leaves, varsigma, budget_s=12.0):
     per_chunk = time.perf_counter() - t0
     n_chunks = int(max(1, min(leaves.shape[0] // chunk, budget_s / max(per_chunk, 1e-6))))
     sample = leaves[: n_chunks * chunk]
-    t0 = time.perf_counter()
-    gpr.best_ucb(post, sample, varsigma)
-    dt = time.perf_counter() - t0
+    # repeat whole passes over the sample until ~budget_s of CPU work has been timed; report the median
+    rates, spent = [], 0.0
+    while spent < budget_s or len(rates) < 2:
+        t0 = time.perf_counter()
+        gpr.best_ucb(post, sample, varsigma)
+        dt = time.perf_counter() - t0
+        rates.append(sample.shape[0] / dt)
+        spent += dt
+        if len(rates) >= 8:
+            break
     return {
-        "value": sample.shape[0] / dt, "unit": "predictions/s", "cores": int(threads), "kind": "port",
+        "value": float(np.median(rates)), "unit": "predictions/s", "cores": int(threads), "kind": "port",
         "sample": f"first {sample.shape[0]} of the {leaves.shape[0]} leaves, float64 numpy/scipy oracle "
-                  f"(LAPACK potrf/trsm), {dt:.1f} s",
+                  f"(LAPACK potrf/trsm), median of {len(rates)} passes, {spent:.1f} s of CPU work",
         "fit_ms_posterior": fit_s * 1e3,
     }, post
 
@@ -277,7 +284,7 @@ def main():
             # the checker: the GPU winner must be (within fp tolerance) the oracle's winner on the sample
             from oracle import gpr
 
-            n_s = int(cb["sample"].split()[1])
+            n_s = int(cb["sample"].split()[1])  # "first <n> of the ..."
             mean_ref, var_ref = gpr.predict_y(post, leaves_all[: max(n_s, 1)])
             ucb_ref = mean_ref + varsigma * var_ref
             if winner[0] < n_s:
