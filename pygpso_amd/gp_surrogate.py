@@ -285,7 +285,8 @@ class GPSurrogate:
     def gp_update(self):
         """Retrain on the evaluated points, then re-predict every gp_based point."""
         x_train, y_train = self.current_training_data
-        logging.debug(f"Retraining GPR with x data: {x_train}; y data: {y_train}")
+        if logging.getLogger().isEnabledFor(logging.DEBUG):  # (formatting the arrays is not free)
+            logging.debug(f"Retraining GPR with x data: {x_train}; y data: {y_train}")
         self._gp_train(x=x_train, y=y_train[:, np.newaxis])
         if self.num_gp_based > 0:
             self.gp_predict(self.gp_based_coords)
