@@ -548,10 +548,9 @@ __global__ __launch_bounds__(256) void pack_linv_bf16_kernel(const float* __rest
 template <int NS, int KERNEL, bool DIAG>
 __device__ __forceinline__ void leaf_bf16_step(int q, int q_diag0, int lane, int dp4,
                                                const u32x4* panel_b /* [NS][16][64] */,
-                                               const float* xs_b /* [2][dp4][64] */, const float* xb,
-                                               const f32x4* __restrict__ xn4,
-                                               const f32x4* __restrict__ al4, const float (&nb)[2],
-                                               float variance, f32x4 (&acc)[16][2], float (&macc)[2]) {
+                                               const float* xs_b /* [2][dp4][64] | norms[64] | alpha[64] */,
+                                               const float* xb, const float (&nb)[2], float variance,
+                                               f32x4 (&acc)[16][2], float (&macc)[2]) {
   using M = Mfma<float>;
   constexpr int RT = 16, CT = 2;
   constexpr float C2 = (float)KernScale<KERNEL>::C2;
@@ -571,9 +570,12 @@ __device__ __forceinline__ void leaf_bf16_step(int q, int q_diag0, int lane, int
     }
   }
   float p[CT][8];
+  // norms and alpha of the 32 points of this k-step arrived in LDS with the panel (no ordinary global
+  // load inside the loop: one issued after the LDS-DMA makes hipcc drain the DMA queue at its use)
+  const float* nrm = xs_b + 2 * dp4 * 64;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const f32x4 na = xn4[(2 * q + h) * 4 + (lane >> 4)] * C2;
+    const f32x4 na = *reinterpret_cast<const f32x4*>(nrm + 16 * h + 4 * (lane >> 4)) * C2;
 #pragma unroll
     for (int t = 0; t < CT; ++t)
 #pragma unroll
@@ -583,7 +585,7 @@ __device__ __forceinline__ void leaf_bf16_step(int q, int q_diag0, int lane, int
   if (DIAG) {  // this k-step lies in the diagonal block: its share of k*.alpha (f32, before the split)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const f32x4 a4 = al4[(2 * q + h) * 4 + (lane >> 4)];
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(nrm + 64 + 16 * h + 4 * (lane >> 4));
 #pragma unroll
       for (int t = 0; t < CT; ++t)
 #pragma unroll
@@ -645,15 +647,14 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   float* xsl = reinterpret_cast<float*>(panel + 2 * NS * RT * 64);  // [2][2][dp4][64]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float* xb = xsl + 4 * dp4 * 64 + (size_t)wave * CT * dp4 * 64;  // [CT][dp4][64] per wave
+  const int xstride = 2 * dp4 * 64 + 128;  // floats per X buffer: 2 k-tiles of fragments, norms, alpha
+  float* xb = xsl + 2 * xstride + (size_t)wave * CT * dp4 * 64;  // [CT][dp4][64] per wave
 
   const int bi = nbi - 1 - (int)blockIdx.y;
   const int64_t col0 = ((int64_t)blockIdx.x * NW + wave) * (CT * 16);
   const int dp = dp4 * 4;
   const int npad32 = npad16 / 2;
   const int q_diag0 = bi * (RT / 2), q_end = q_diag0 + RT / 2;
-  const f32x4* xn4 = reinterpret_cast<const f32x4*>(xnorm);
-  const f32x4* al4 = reinterpret_cast<const f32x4*>(alpha);
 
   auto issue = [&](int q, int buf) {
     for (int f = wave; f < NS * RT; f += NW) {
@@ -663,8 +664,11 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     }
     for (int i = wave; i < 2 * dp4; i += NW) {
       const int h = i / dp4, c = i % dp4;
-      glds4(xs_p + ((size_t)(2 * q + h) * dp4 + c) * 64 + lane, xsl + ((buf * 2 + h) * dp4 + c) * 64);
+      glds4(xs_p + ((size_t)(2 * q + h) * dp4 + c) * 64 + lane, xsl + buf * xstride + (h * dp4 + c) * 64);
     }
+    // 32 norms / 32 alphas of the k-step (lanes 32-63 fetch duplicates into the unused half)
+    if (wave == NW - 1) glds4(xnorm + 32 * q + (lane & 31), xsl + buf * xstride + 2 * dp4 * 64);
+    if (wave == NW - 2) glds4(alpha + 32 * q + (lane & 31), xsl + buf * xstride + 2 * dp4 * 64 + 64);
   };
 
   issue(0, 0);
@@ -687,14 +691,14 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     const int b = q & 1;
     issue(q + 1, b ^ 1);
     leaf_bf16_step<NS, KERNEL, false>(q, q_diag0, lane, dp4, panel + b * NS * RT * 64,
-                                      xsl + b * 2 * dp4 * 64, xb, xn4, al4, nb, variance, acc, macc);
+                                      xsl + b * xstride, xb, nb, variance, acc, macc);
     __syncthreads();
   }
   for (int q = q_diag0; q < q_end; ++q) {
     const int b = q & 1;
     if (q + 1 < q_end) issue(q + 1, b ^ 1);
     leaf_bf16_step<NS, KERNEL, true>(q, q_diag0, lane, dp4, panel + b * NS * RT * 64,
-                                     xsl + b * 2 * dp4 * 64, xb, xn4, al4, nb, variance, acc, macc);
+                                     xsl + b * xstride, xb, nb, variance, acc, macc);
     __syncthreads();
   }
 
@@ -725,7 +729,7 @@ static void launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const 
                                       int64_t npad, int dp4, int64_t mpad, const KernParams& kp) {
   const int nbi = (int)(npad / 256);
   const dim3 grid((unsigned)(mpad / 256), (unsigned)nbi);
-  const size_t lds = (size_t)2 * NS * 16 * 64 * 16 + (size_t)4 * dp4 * 64 * 4 + (size_t)8 * 2 * dp4 * 64 * 4;
+  const size_t lds = (size_t)2 * NS * 16 * 64 * 16 + (size_t)2 * (2 * dp4 * 64 + 128) * 4 + (size_t)8 * 2 * dp4 * 64 * 4;
 #define GPSO_L(K)                                                                                  \
   hipLaunchKernelGGL((leaf_tiles_bf16_kernel<NS, K>), grid, dim3(512), lds, st,                    \
                      static_cast<const u32x4*>(linv_b), xs_p, xnorm, alpha, leaves_s, lnorm,       \
