@@ -103,7 +103,7 @@ struct EngineT : Engine {
   std::vector<double> ls_host;
 
   // device buffers
-  DevBuf x64, y64, hyper, xs, xnorm, xs_p, K, linv, work, linv_p, white, alpha, logdet, scal, gpart;
+  DevBuf x64, y64, hyper, xs, xnorm, xs_p, K, Lf, linv, work, linv_p, white, alpha, logdet, scal, gpart;
   // split-bf16 copy of L^-1 (float contexts with GPSO_OPT_PREDICT_MATH != native)
   DevBuf linv_b;
   int math = GPSO_MATH_NATIVE;
@@ -113,7 +113,7 @@ struct EngineT : Engine {
   DevBuf leaves_raw, leaves_s, lnorm, pvar, pmean, omean, ovar, oucb, segoff, best, oidx, ovals;
 
   ~EngineT() override {
-    for (DevBuf* b : {&x64, &y64, &hyper, &xs, &xnorm, &xs_p, &K, &linv, &work, &linv_p, &white,
+    for (DevBuf* b : {&x64, &y64, &hyper, &xs, &xnorm, &xs_p, &K, &Lf, &linv, &work, &linv_p, &white,
                       &alpha, &logdet, &scal, &gpart, &leaves_raw, &leaves_s, &lnorm, &pvar, &pmean,
                       &omean, &ovar, &oucb, &segoff, &best, &oidx, &ovals, &linv_b})
       if (b->p) (void)hipFree(b->p);
@@ -192,6 +192,7 @@ struct EngineT : Engine {
     int rc;
     const size_t s = sizeof(T);
     if ((rc = ensure(K, (size_t)npad * npad * s))) return rc;
+    if ((rc = ensure(Lf, (size_t)npad * npad * s))) return rc;
     if ((rc = ensure(linv, (size_t)npad * npad * s))) return rc;
     if ((rc = ensure(work, (size_t)npad * npad * s))) return rc;
     if ((rc = ensure(white, (size_t)npad * s))) return rc;
@@ -254,8 +255,8 @@ struct EngineT : Engine {
     const int imax = INT_MAX;
     int* info_dev = reinterpret_cast<int*>(as<double>(scal) + 1);
     HIPCHECK(hipMemcpyAsync(info_dev, &imax, sizeof(int), hipMemcpyHostToDevice, s));
-    launch_potrf<T>(s, as<T>(K), as<T>(linv), n, npad, as<double>(logdet), info_dev);
-    launch_trtri<T>(s, as<T>(K), as<T>(linv), as<T>(work), npad);
+    launch_potrf<T>(s, as<T>(K), as<T>(Lf), as<T>(linv), n, npad, as<double>(logdet), info_dev);
+    launch_trtri<T>(s, as<T>(Lf), as<T>(linv), as<T>(work), npad);
     launch_solve_alpha<T>(s, as<T>(linv), as<double>(y64), n, npad, mean_c, as<double>(logdet),
                           (int)(npad / kFitBlock), as<T>(white), as<T>(alpha), as<double>(gpart),
                           as<double>(scal));
@@ -306,8 +307,8 @@ struct EngineT : Engine {
     }
     launch_scale_x<T>(s, as<double>(x64), n, npad, d, dp, ls_dev(), as<T>(xs), as<T>(xnorm), as<T>(xs_p));
     (void)hipMemsetAsync(linv.p, 0, (size_t)npad * npad * sizeof(T), s);
-    launch_install_chol<T>(s, tmp, n, npad, as<T>(K), as<T>(linv));
-    launch_trtri<T>(s, as<T>(K), as<T>(linv), as<T>(work), npad);
+    launch_install_chol<T>(s, tmp, n, npad, as<T>(Lf), as<T>(linv));
+    launch_trtri<T>(s, as<T>(Lf), as<T>(linv), as<T>(work), npad);
     (void)hipMemsetAsync(alpha.p, 0, (size_t)npad * sizeof(T), s);
     launch_convert_in<T>(s, tmp + (size_t)n * n, as<T>(alpha), 1, n, npad);
     launch_pack_linv<T>(s, as<T>(linv), n, npad, as<T>(linv_p));
@@ -544,7 +545,7 @@ struct EngineT : Engine {
     switch (which) {
       case GPSO_MAT_CHOL:
         if (!chol_valid) return ctx->fail(GPSO_E_STATE, "no factor resident");
-        src = as<T>(K);
+        src = as<T>(Lf);
         break;
       case GPSO_MAT_LINV:
         if (!chol_valid) return ctx->fail(GPSO_E_STATE, "no factor resident");

@@ -125,6 +125,9 @@ template void launch_gram<double>(hipStream_t, const double*, const double*, int
 //            element of a 16x16 block.
 // Accumulation is in double whatever T is; sqrt / divide are v_rsq_f64 + Newton (the library
 // sqrt/div sequences would sit on the pivot chain).
+#ifndef GPSO_STAMP
+#define GPSO_STAMP(i)  // tools/micro/diag_phases.hip defines this to record s_memtime stamps
+#endif
 constexpr int kDS = kFitBlock + 1;  // LDS row stride (conflict-free row-per-lane access)
 constexpr int kPB = 16;             // panel width inside the block
 
@@ -162,34 +165,40 @@ __device__ __forceinline__ void chol64_lds(double* Ls, double* inv_diag, int64_t
                                            int* info) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int c0 = 0; c0 < kFitBlock; c0 += kPB) {
+    GPSO_STAMP(2 * (c0 / kPB));
     if (wave == 0) {
       // panel columns c0 .. c0+15; lane = row.  The 16 panel entries of the row live in registers
-      // and the pivot row is broadcast with v_readlane (uniform lane index): the 16-pivot chain of
-      // a panel runs without a single LDS round trip.
+      // and finished columns are broadcast with v_readlane (uniform lane index): the 16-pivot chain
+      // of a panel runs without a single LDS round trip.
       double li[kPB];
 #pragma unroll
       for (int k = 0; k < kPB; ++k) li[k] = Ls[lane * kDS + c0 + k];
+      int bad = kPB;  // first failing pivot of the panel (wave-uniform)
 #pragma unroll
       for (int jj = 0; jj < kPB; ++jj) {
+        // right-looking: column jj is final here; the only work on the pivot chain is
+        // readlane -> rsqrt -> scale -> update of column jj+1, the other updates are independent
         const int j = c0 + jj;
-        double v = li[jj];
-#pragma unroll
-        for (int kk = 0; kk < jj; ++kk) v = fma(-li[kk], readlane_f64(li[kk], j), v);
-        double piv = readlane_f64(v, j);
+        double piv = readlane_f64(li[jj], j);
         if (!(piv > 0.0)) {  // also catches NaN
-          if (lane == 0 && k0 + j < n) atomicMin(info, (int)(k0 + j));
+          bad = min(bad, jj);
           piv = 1.0;
         }
         const double rinv = rsqrt_newton(piv);
         double ljj = piv * rinv;
         ljj = fma(0.5 * rinv, fma(-ljj, ljj, piv), ljj);  // Heron correction
-        li[jj] = (lane == j) ? ljj : (lane > j) ? v * rinv : 0.0;
+        const double l = (lane == j) ? ljj : (lane > j) ? li[jj] * rinv : 0.0;
+        li[jj] = l;
         if (lane == j) inv_diag[j] = rinv;
+#pragma unroll
+        for (int kk = jj + 1; kk < kPB; ++kk) li[kk] = fma(-l, readlane_f64(l, c0 + kk), li[kk]);
       }
+      if (bad < kPB && lane == 0 && k0 + c0 + bad < n) atomicMin(info, (int)(k0 + c0 + bad));
 #pragma unroll
       for (int k = 0; k < kPB; ++k) Ls[lane * kDS + c0 + k] = li[k];
     }
     __syncthreads();
+    GPSO_STAMP(2 * (c0 / kPB) + 1);
     // trailing update on the f64 MFMA: for the 16x16 tiles (ib >= mb) right of the panel,
     // A[ib][mb] -= L[ib][panel] L[mb][panel]^T; one tile per wave and step
     {
@@ -254,39 +263,6 @@ __device__ __forceinline__ void trinv64_lds(const double* Ls, const double* inv_
         Xs[(ib * kPB + (lane >> 4) + 4 * r) * kDS + jb * kPB + (lane & 15)] = -x[r];
     }
     __syncthreads();
-  }
-}
-
-// A: 64x64 block at K + k0*ld + k0.  Writes L11 (upper part zeroed) back, inv(L11) into linv's
-// diagonal block, the block's log-det partial (rows < n only) and the failing pivot.
-template <typename T>
-__global__ __launch_bounds__(256) void potrf_diag_kernel(T* __restrict__ K, T* __restrict__ linv,
-                                                         int64_t ld, int64_t k0, int64_t n,
-                                                         double* __restrict__ logdet_part,
-                                                         int* __restrict__ info) {
-  __shared__ double Ls[kFitBlock * kDS];
-  __shared__ double Xs[kFitBlock * kDS];
-  __shared__ double Ts[3 * kPB * 17];
-  __shared__ double inv_diag[kFitBlock];
-  const int tid = threadIdx.x;
-  T* A = K + k0 * ld + k0;
-  for (int e = tid; e < kFitBlock * kFitBlock; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    Ls[r * kDS + c] = (c <= r) ? (double)A[(int64_t)r * ld + c] : 0.0;
-  }
-  __syncthreads();
-  chol64_lds(Ls, inv_diag, k0, n, info);
-  if (tid < kFitBlock) {  // log-determinant of the block (wave 0)
-    double lg = (k0 + tid < n) ? log(Ls[tid * kDS + tid]) : 0.0;
-    lg = wave_sum(lg);
-    if (tid == 0) logdet_part[k0 / kFitBlock] = lg;
-  }
-  trinv64_lds(Ls, inv_diag, Xs, Ts);
-  T* Xo = linv + k0 * ld + k0;
-  for (int e = tid; e < kFitBlock * kFitBlock; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    A[(int64_t)r * ld + c] = (T)Ls[r * kDS + c];
-    Xo[(int64_t)r * ld + c] = (T)Xs[r * kDS + c];
   }
 }
 
@@ -464,61 +440,249 @@ static void launch_gemm(hipStream_t st, const GemmDesc& g) {
 }
 
 // =============================================================================================
-// blocked Cholesky
+// look-ahead Cholesky step: ONE launch per 64-column step, diagonal chain and bulk update overlap
 // =============================================================================================
-// Two-level right-looking blocking: 64-wide inner panels (diagonal block kernel + panel GEMM) whose
-// rank-64 trailing updates stay INSIDE a 256-wide outer panel; the rest of the matrix is updated
-// once per outer panel with a rank-256 SYRK.  The trailing matrix is thus streamed through HBM
-// N/256 times instead of N/64 times and the big update has a GEMM-worthy inner dimension.
-constexpr int kOuterPanel = 256;
+// The 64x64 diagonal factorisation is a chain of pivots that one workgroup runs for ~20 us while
+// the rest of the chip idles, and at N = 2048 that chain was half of the fit.  Here the launch that
+// follows diagonal block k does both
+//   role D  (workgroup 0):  diagonal block k+1: its own panel tile L10 = K[k+1,k] X_k^T, the
+//                           rank-64 update of ITS tile only, S = K[k+1,k+1] - L10 L10^T, then
+//                           chol(S) -> Lf[k+1,k+1] and its inverse -> linv[k+1,k+1];
+//   role PU (all others):   tile (i,j), k+1 <= j <= jmax, i >= j, (i,j) != (k+1,k+1):
+//                           Li = K[i,k] X_k^T, Lj = K[j,k] X_k^T (recomputed per tile: 64^3 each),
+//                           K[i,j] -= Li Lj^T; the j == k+1 tiles also store Li -> Lf[i,k].
+// Both roles only READ column k of K and WRITE disjoint tiles, so no ordering inside the launch is
+// needed; L goes to its own matrix Lf (out of place) because other tiles still read K[i,k] while
+// Li is produced.  K ends up holding Schur-complement debris.
+constexpr int kTL = kFitBlock + 4;  // LDS row stride of a T tile: vec4 fragment reads conflict-free
+
+// wave tile product on MFMA: acc[tj] (16x16, rows 16w.. of A) = A_rows[16 x 64] * B[64 x 64]^T,
+// both operands row-major [row][k] in LDS with stride kTL.  k runs in the permuted order
+// 16 kk + 4 (lane >> 4) + e on both sides.
+template <typename T>
+__device__ __forceinline__ void mma_abt(const T* A_rows, const T* B, int lane,
+                                        typename Mfma<T>::vec4 (&acc)[4]) {
+  using M = Mfma<T>;
+  using vec4 = typename M::vec4;
+#pragma unroll
+  for (int tj = 0; tj < 4; ++tj) acc[tj] = vec4{0, 0, 0, 0};
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const int ko = 16 * kk + 4 * (lane >> 4);
+    const vec4 a4 = *reinterpret_cast<const vec4*>(A_rows + (lane & 15) * kTL + ko);
+    vec4 b4[4];
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+      b4[tj] = *reinterpret_cast<const vec4*>(B + (16 * tj + (lane & 15)) * kTL + ko);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) acc[tj] = M::mma(a4[e], b4[tj][e], acc[tj]);
+  }
+}
+
+// all 256 threads: 64x64 tile at src (row stride ld) -> LDS tile (stride kTL), 16-byte loads
+template <typename T>
+__device__ __forceinline__ void tile_to_lds(const T* __restrict__ src, int64_t ld, T* dst, int tid) {
+  using vec4 = typename Mfma<T>::vec4;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int idx = tid + 256 * v, r = idx >> 4, c = 4 * (idx & 15);
+    *reinterpret_cast<vec4*>(dst + r * kTL + c) = *reinterpret_cast<const vec4*>(src + (int64_t)r * ld + c);
+  }
+}
+
+// LDS carving of the step kernel.  role PU: three T tiles.  role D: Ls (f64) | { two T tiles, later
+// overlaid by Xs (f64) } | Ts | inv_diag.  float: 73 KB (2 workgroups per CU), double: 107 KB.
+template <typename T>
+struct StepLds {
+  static constexpr int kTileBytes = kFitBlock * kTL * (int)sizeof(T);
+  static constexpr int kF64Bytes = kFitBlock * kDS * 8;
+  static constexpr int kOver = (2 * kTileBytes > kF64Bytes) ? 2 * kTileBytes : kF64Bytes;
+  static constexpr int kBytesD = kF64Bytes + kOver + 3 * kPB * 17 * 8 + kFitBlock * 8;
+  static constexpr int kBytes = (3 * kTileBytes > kBytesD) ? 3 * kTileBytes : kBytesD;
+};
 
 template <typename T>
-void launch_potrf(hipStream_t st, T* K, T* linv, int64_t n, int64_t npad, double* logdet_part,
-                  int* info) {
-  for (int64_t P = 0; P < npad; P += kOuterPanel) {
-    const int64_t Pend = std::min<int64_t>(P + kOuterPanel, npad);
-    for (int64_t k0 = P; k0 < Pend; k0 += kFitBlock) {
-      hipLaunchKernelGGL((potrf_diag_kernel<T>), dim3(1), dim3(256), 0, st, K, linv, npad, k0, n,
-                         logdet_part, info);
-      const int m = (int)(npad - k0 - kFitBlock);
-      if (m <= 0) break;
-      T* A21 = K + (k0 + kFitBlock) * npad + k0;
-      // L21 = A21 * inv(L11)^T    (in place: every workgroup reads only the rows it overwrites)
-      GemmDesc t{};
-      t.A = A21; t.sai = npad; t.sak = 1;
-      t.B = linv + k0 * npad + k0; t.sbk = 1; t.sbj = npad;  // opB(k,j) = inv11[j][k]
-      t.C = A21; t.ldc = npad;
-      t.m = m; t.n = kFitBlock; t.k = kFitBlock; t.m_last = m; t.nbatch = 1;
-      t.alpha = 1.0; t.beta = 0.0;
-      launch_gemm<T>(st, t);
-      // inner update: only the remaining columns of this outer panel, all rows below
-      const int w = (int)(Pend - k0 - kFitBlock);
-      if (w > 0) {
-        GemmDesc s{};
-        s.A = A21; s.sai = npad; s.sak = 1;
-        s.B = A21; s.sbk = 1; s.sbj = npad;  // rows k0+64 .. Pend of L21, transposed
-        s.C = K + (k0 + kFitBlock) * npad + (k0 + kFitBlock); s.ldc = npad;
-        s.m = m; s.n = w; s.k = kFitBlock; s.m_last = m; s.nbatch = 1;
-        s.alpha = -1.0; s.beta = 1.0;
-        launch_gemm<T>(st, s);
+__global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* __restrict__ Lf,
+                                                         T* __restrict__ linv, int64_t ld, int k,
+                                                         int jmax, int ntile, int64_t n,
+                                                         double* __restrict__ logdet_part,
+                                                         int* __restrict__ info) {
+  using M = Mfma<T>;
+  using vec4 = typename M::vec4;
+  using Lay = StepLds<T>;
+  constexpr int kF64Bytes = Lay::kF64Bytes, kOver = Lay::kOver;
+  extern __shared__ __align__(32) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t T64 = kFitBlock;
+
+  if (blockIdx.x == 0 && blockIdx.y == 0) {
+    // ---------------- role D: diagonal block kd = k + 1 ----------------------------------------
+    const int kd = k + 1;
+    if (kd >= ntile) return;
+    double* Ls = reinterpret_cast<double*>(lds);
+    T* TA = reinterpret_cast<T*>(lds + kF64Bytes);
+    T* TX = TA + kFitBlock * kTL;
+    double* Xs = reinterpret_cast<double*>(lds + kF64Bytes);  // overlays TA / TX once they are dead
+    double* Ts = reinterpret_cast<double*>(lds + kF64Bytes + kOver);
+    double* inv_diag = Ts + 3 * kPB * 17;
+    const T* Akk = K + (kd * T64) * ld + kd * T64;
+    if (k >= 0) {
+      tile_to_lds<T>(K + (kd * T64) * ld + k * T64, ld, TA, tid);
+      tile_to_lds<T>(linv + (k * T64) * ld + k * T64, ld, TX, tid);
+      __syncthreads();
+      vec4 acc[4];
+      mma_abt<T>(TA + wave * 16 * kTL, TX, lane, acc);  // L10 rows of this wave
+      T* Lo = Lf + (kd * T64) * ld + k * T64;
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wave * 16 + M::crow(lane, r), col = 16 * tj + (lane & 15);
+          TA[row * kTL + col] = acc[tj][r];  // rows of this wave only: no other wave reads them yet
+          Lo[(int64_t)row * ld + col] = acc[tj][r];
+        }
+      __syncthreads();
+      mma_abt<T>(TA + wave * 16 * kTL, TA, lane, acc);
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wave * 16 + M::crow(lane, r), col = 16 * tj + (lane & 15);
+          const T upd = Akk[(int64_t)row * ld + col] - acc[tj][r];
+          Ls[row * kDS + col] = (col <= row) ? (double)upd : 0.0;
+        }
+    } else {
+      for (int e = tid; e < kFitBlock * kFitBlock; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        Ls[r * kDS + c] = (c <= r) ? (double)Akk[(int64_t)r * ld + c] : 0.0;
       }
     }
-    // outer update: A[Pend.., Pend..] -= L[Pend.., P..Pend) L[Pend.., P..Pend)^T   (lower tiles)
-    const int m2 = (int)(npad - Pend);
-    if (m2 > 0) {
-      T* Lp = K + Pend * npad + P;
-      GemmDesc s{};
-      s.A = Lp; s.sai = npad; s.sak = 1;
-      s.B = Lp; s.sbk = 1; s.sbj = npad;
-      s.C = K + Pend * npad + Pend; s.ldc = npad;
-      s.m = m2; s.n = m2; s.k = (int)(Pend - P); s.m_last = m2; s.nbatch = 1;
-      s.alpha = -1.0; s.beta = 1.0; s.lower_only = 1;
-      launch_gemm<T>(st, s);
+    __syncthreads();
+    const int64_t k0 = kd * T64;
+    chol64_lds(Ls, inv_diag, k0, n, info);
+    if (tid < kFitBlock) {  // log-determinant of the block (wave 0)
+      double lg = (k0 + tid < n) ? log(Ls[tid * kDS + tid]) : 0.0;
+      lg = wave_sum(lg);
+      if (tid == 0) logdet_part[kd] = lg;
+    }
+    trinv64_lds(Ls, inv_diag, Xs, Ts);
+    T* Lo = Lf + k0 * ld + k0;
+    T* Xo = linv + k0 * ld + k0;
+    for (int e = tid; e < kFitBlock * kFitBlock; e += 256) {
+      const int r = e >> 6, c = e & 63;
+      Lo[(int64_t)r * ld + c] = (T)Ls[r * kDS + c];
+      Xo[(int64_t)r * ld + c] = (T)Xs[r * kDS + c];
+    }
+    return;
+  }
+  // ---------------- role PU: tile (i, j) of the trailing update -----------------------------------
+  if (blockIdx.x == 0 || k < 0) return;
+  const int j = k + 1 + (int)blockIdx.y;
+  const int i = j + (int)blockIdx.x - 1;
+  if (j > jmax || i >= ntile || (i == k + 1 && j == k + 1)) return;
+  T* TI = reinterpret_cast<T*>(lds);
+  T* TJ = TI + kFitBlock * kTL;
+  T* TX = TJ + kFitBlock * kTL;
+  tile_to_lds<T>(K + (i * T64) * ld + k * T64, ld, TI, tid);
+  if (i != j) tile_to_lds<T>(K + (j * T64) * ld + k * T64, ld, TJ, tid);
+  tile_to_lds<T>(linv + (k * T64) * ld + k * T64, ld, TX, tid);
+  __syncthreads();
+  vec4 acc[4];
+  mma_abt<T>(TI + wave * 16 * kTL, TX, lane, acc);
+  {
+    T* Lo = Lf + (i * T64) * ld + k * T64;
+    const bool keep = (j == k + 1);
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wave * 16 + M::crow(lane, r), col = 16 * tj + (lane & 15);
+        TI[row * kTL + col] = acc[tj][r];
+        if (keep) Lo[(int64_t)row * ld + col] = acc[tj][r];
+      }
+  }
+  if (i != j) {
+    mma_abt<T>(TJ + wave * 16 * kTL, TX, lane, acc);
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        TJ[(wave * 16 + M::crow(lane, r)) * kTL + 16 * tj + (lane & 15)] = acc[tj][r];
+  }
+  __syncthreads();
+  mma_abt<T>(TI + wave * 16 * kTL, (i != j) ? TJ : TI, lane, acc);
+  T* C = K + (i * T64) * ld + j * T64;
+#pragma unroll
+  for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      T* c = C + (int64_t)(wave * 16 + M::crow(lane, r)) * ld + 16 * tj + (lane & 15);
+      *c -= acc[tj][r];
+    }
+}
+
+// =============================================================================================
+// blocked Cholesky
+// =============================================================================================
+// Right-looking in 64-wide steps, one potrf_step_kernel launch per step (see above).
+//   npad <= kSingleLevelMax: every step updates the whole trailing matrix (rank 64); at these sizes
+//       the matrix lives in the L2 / Infinity Cache and a step's bulk work is shorter than the
+//       diagonal chain it hides behind.
+//   larger: two-level.  Steps update only the columns of the current outer panel plus ONE
+//       look-ahead tile column (so that the first diagonal block of the next panel never waits for
+//       the big update); everything right of that gets one rank-(panel) SYRK per outer panel, which
+//       streams the trailing matrix N/256 times instead of N/64 times.  Panel boundaries sit at
+//       192 + 256 p so that the SYRK region starts on a multiple of 128 (128x128 GEMM tiles).
+constexpr int kOuterPanel = 256;
+constexpr int64_t kSingleLevelMax = 4096;
+
+template <typename T>
+void launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, int64_t n, int64_t npad,
+                  double* logdet_part, int* info) {
+  const int ntile = (int)(npad / kFitBlock);
+  const bool single = npad <= kSingleLevelMax;
+  static bool attr_set = false;  // per instantiation; the step kernel needs more than 64 KB of LDS
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_step_kernel<T>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, StepLds<T>::kBytes);
+    attr_set = true;
+  }
+  auto step = [&](int k, int jmax) {
+    // grid.x = 1 (role D / idle) + rows below the diagonal of the tile column, grid.y = tile columns
+    const int ncol = (k < 0) ? 1 : std::max(1, jmax - k);
+    const int nrow = (k < 0) ? 0 : std::max(1, ntile - (k + 1));
+    hipLaunchKernelGGL((potrf_step_kernel<T>), dim3((unsigned)(1 + nrow), (unsigned)ncol), dim3(256),
+                       StepLds<T>::kBytes, st, K, Lf, linv, npad, k, jmax, ntile, n, logdet_part, info);
+  };
+  step(-1, -1);  // diagonal block 0
+  int p_end = single ? ntile : std::min(ntile, (kOuterPanel - kFitBlock) / kFitBlock);  // tiles
+  int p_beg = 0;
+  for (int k = 0; k < ntile - 1; ++k) {
+    const int jmax = std::min(ntile - 1, p_end);  // p_end itself is the look-ahead column
+    step(k, jmax);
+    if (k + 1 == p_end) {  // last step of the outer panel [p_beg, p_end): deferred rank update
+      const int64_t r0 = (int64_t)(p_end + 1) * kFitBlock;
+      const int m2 = (int)(npad - r0);
+      if (m2 > 0) {
+        const T* Lp = Lf + r0 * npad + (int64_t)p_beg * kFitBlock;
+        GemmDesc s{};
+        s.A = Lp; s.sai = npad; s.sak = 1;
+        s.B = Lp; s.sbk = 1; s.sbj = npad;
+        s.C = K + r0 * npad + r0; s.ldc = npad;
+        s.m = m2; s.n = m2; s.k = (p_end - p_beg) * kFitBlock; s.m_last = m2; s.nbatch = 1;
+        s.alpha = -1.0; s.beta = 1.0; s.lower_only = 1;
+        launch_gemm<T>(st, s);
+      }
+      p_beg = p_end;
+      p_end = std::min(ntile, p_end + kOuterPanel / kFitBlock);
     }
   }
 }
-template void launch_potrf<float>(hipStream_t, float*, float*, int64_t, int64_t, double*, int*);
-template void launch_potrf<double>(hipStream_t, double*, double*, int64_t, int64_t, double*, int*);
+template void launch_potrf<float>(hipStream_t, float*, float*, float*, int64_t, int64_t, double*, int*);
+template void launch_potrf<double>(hipStream_t, double*, double*, double*, int64_t, int64_t, double*, int*);
 
 // =============================================================================================
 // triangular inverse by level doubling

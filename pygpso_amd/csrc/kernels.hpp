@@ -52,7 +52,7 @@ void launch_gram(hipStream_t st, const T* xs, const T* xnorm, int64_t n, int64_t
 // blocked right-looking Cholesky in place (lower); also writes the inverted 64x64 diagonal blocks
 // into linv, per-panel log-determinant partials, and the first failing pivot (or INT_MAX) to info
 template <typename T>
-void launch_potrf(hipStream_t st, T* K, T* linv, int64_t n, int64_t npad, double* logdet_part,
+void launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, int64_t n, int64_t npad, double* logdet_part,
                   int* info);
 // L^-1 by level-doubling: needs the diagonal-block inverses already in linv; work = npad x npad scratch
 template <typename T>
