@@ -196,7 +196,7 @@ struct EngineT : Engine {
     if ((rc = ensure(linv, (size_t)npad * npad * s))) return rc;
     if ((rc = ensure(work, (size_t)npad * npad * s))) return rc;
     if ((rc = ensure(white, (size_t)npad * s))) return rc;
-    if ((rc = ensure(logdet, (size_t)(npad / kFitBlock) * 8))) return rc;
+    if ((rc = ensure(logdet, (size_t)npad * 8))) return rc;
     if ((rc = ensure(scal, (size_t)(8 + kGradMaxLs + 3) * 8))) return rc;
     const size_t nt = (size_t)(npad / 64);
     if ((rc = ensure(gpart, nt * nt * (size_t)(kGradMaxLs + 2) * 8))) return rc;
@@ -258,7 +258,7 @@ struct EngineT : Engine {
     launch_potrf<T>(s, as<T>(K), as<T>(Lf), as<T>(linv), n, npad, as<double>(logdet), info_dev);
     launch_trtri<T>(s, as<T>(Lf), as<T>(linv), as<T>(work), npad);
     launch_solve_alpha<T>(s, as<T>(linv), as<double>(y64), n, npad, mean_c, as<double>(logdet),
-                          (int)(npad / kFitBlock), as<T>(white), as<T>(alpha), as<double>(gpart),
+                          as<T>(white), as<T>(alpha), as<double>(gpart),
                           as<double>(scal));
     if (grad)
       launch_gradient<T>(s, as<T>(linv), as<T>(alpha), as<T>(xs), as<T>(xnorm), n, npad, d, dp, n_ls,

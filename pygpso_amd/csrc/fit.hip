@@ -131,24 +131,33 @@ template void launch_gram<double>(hipStream_t, const double*, const double*, int
 constexpr int kDS = kFitBlock + 1;  // LDS row stride (conflict-free row-per-lane access)
 constexpr int kPB = 16;             // panel width inside the block
 
-// 1/sqrt(x) in full double precision: hardware v_rsq_f64 seed + two Newton steps
+// 1/sqrt(x): hardware v_rsq_f64 seed (~2^-23 relative) + NEWTON Newton steps: two give full double
+// precision; one (~2e-14) is far below float rounding and is what float contexts use
+template <int NEWTON>
 __device__ __forceinline__ double rsqrt_newton(double x) {
   double r = __builtin_amdgcn_rsq(x);
-  r = r * fma(-0.5 * x, r * r, 1.5);
-  r = r * fma(-0.5 * x, r * r, 1.5);
+  const double hx = -0.5 * x;
+#pragma unroll
+  for (int s = 0; s < NEWTON; ++s) r = r * fma(hx, r * r, 1.5);
   return r;
 }
 
 // one wave: D (16x16) = sum_{k<K} A(i,k) B(k,j) with both operands in LDS (generic strides), on the
-// f64 MFMA (16x16x4).  Element r of lane l of the result is D[(l >> 4) + 4 r][l & 15].
+// f64 MFMA (16x16x4).  Element r of lane l of the result is D[(l >> 4) + 4 r][l & 15].  K is a
+// compile-time constant so that every fragment is in flight before the first MFMA issues (with a
+// run-time trip count each k-step paid a full LDS round trip).
+template <int K>
 __device__ __forceinline__ f64x4 mma16_lds(const double* Ab, int sai, int sak, const double* Bb,
-                                           int sbk, int sbj, int K, int lane) {
-  f64x4 acc{0, 0, 0, 0};
-  for (int k0 = 0; k0 < K; k0 += 4) {
-    const double a = Ab[(lane & 15) * sai + (k0 + (lane >> 4)) * sak];
-    const double b = Bb[(k0 + (lane >> 4)) * sbk + (lane & 15) * sbj];
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                                           int sbk, int sbj, int lane) {
+  double a[K / 4], b[K / 4];
+#pragma unroll
+  for (int s = 0; s < K / 4; ++s) {
+    a[s] = Ab[(lane & 15) * sai + (4 * s + (lane >> 4)) * sak];
+    b[s] = Bb[(4 * s + (lane >> 4)) * sbk + (lane & 15) * sbj];
   }
+  f64x4 acc{0, 0, 0, 0};
+#pragma unroll
+  for (int s = 0; s < K / 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
   return acc;
 }
 
@@ -159,41 +168,33 @@ __device__ __forceinline__ double readlane_f64(double x, int src_lane /* wave-un
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
-// all 256 threads; Ls holds the symmetric block (lower part used); on return Ls = L (zeros above
-// the diagonal) and inv_diag[i] = 1 / L[i][i].  Pivot failures -> atomicMin(info, global index).
-__device__ __forceinline__ void chol64_lds(double* Ls, double* inv_diag, int64_t k0, int64_t n,
-                                           int* info) {
+// all 256 threads; Ls holds the symmetric block (lower part used); on return the lower part of Ls
+// is L (entries above the diagonal are unspecified: nothing reads them and the stores mask them).
+// A non-positive pivot turns its column into NaN (v_rsq of a non-positive number), which spreads
+// only to later columns: the first non-finite / non-positive diagonal entry is the failing pivot,
+// reported with atomicMin(info, global index) for rows < n.
+template <int NEWTON>
+__device__ __forceinline__ void chol64_lds(double* Ls, int64_t k0, int64_t n, int* info) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int c0 = 0; c0 < kFitBlock; c0 += kPB) {
     GPSO_STAMP(2 * (c0 / kPB));
     if (wave == 0) {
       // panel columns c0 .. c0+15; lane = row.  The 16 panel entries of the row live in registers
       // and finished columns are broadcast with v_readlane (uniform lane index): the 16-pivot chain
-      // of a panel runs without a single LDS round trip.
+      // of a panel runs without a single LDS round trip, without branches and without selects.
       double li[kPB];
 #pragma unroll
       for (int k = 0; k < kPB; ++k) li[k] = Ls[lane * kDS + c0 + k];
-      int bad = kPB;  // first failing pivot of the panel (wave-uniform)
 #pragma unroll
       for (int jj = 0; jj < kPB; ++jj) {
         // right-looking: column jj is final here; the only work on the pivot chain is
         // readlane -> rsqrt -> scale -> update of column jj+1, the other updates are independent
-        const int j = c0 + jj;
-        double piv = readlane_f64(li[jj], j);
-        if (!(piv > 0.0)) {  // also catches NaN
-          bad = min(bad, jj);
-          piv = 1.0;
-        }
-        const double rinv = rsqrt_newton(piv);
-        double ljj = piv * rinv;
-        ljj = fma(0.5 * rinv, fma(-ljj, ljj, piv), ljj);  // Heron correction
-        const double l = (lane == j) ? ljj : (lane > j) ? li[jj] * rinv : 0.0;
+        const double rinv = rsqrt_newton<NEWTON>(readlane_f64(li[jj], c0 + jj));
+        const double l = li[jj] * rinv;
         li[jj] = l;
-        if (lane == j) inv_diag[j] = rinv;
 #pragma unroll
         for (int kk = jj + 1; kk < kPB; ++kk) li[kk] = fma(-l, readlane_f64(l, c0 + kk), li[kk]);
       }
-      if (bad < kPB && lane == 0 && k0 + c0 + bad < n) atomicMin(info, (int)(k0 + c0 + bad));
 #pragma unroll
       for (int k = 0; k < kPB; ++k) Ls[lane * kDS + c0 + k] = li[k];
     }
@@ -210,59 +211,125 @@ __device__ __forceinline__ void chol64_lds(double* Ls, double* inv_diag, int64_t
           ++ib;
         }
         const int r0 = (p + 1 + ib) * kPB, m0 = (p + 1 + mb) * kPB;
-        const f64x4 d = mma16_lds(Ls + r0 * kDS + c0, kDS, 1, Ls + m0 * kDS + c0, 1, kDS, kPB, lane);
+        const f64x4 d = mma16_lds<kPB>(Ls + r0 * kDS + c0, kDS, 1, Ls + m0 * kDS + c0, 1, kDS, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) Ls[(r0 + (lane >> 4) + 4 * r) * kDS + m0 + (lane & 15)] -= d[r];
       }
     }
     __syncthreads();
   }
+  if (wave == 0) {
+    const double dg = Ls[lane * kDS + lane];
+    const bool ok = (dg > 0.0) && (dg < 1.0e300);  // false for NaN / inf as well
+    const unsigned long long badmask = __ballot(!ok && (k0 + lane < n));
+    if (badmask != 0 && lane == 0) atomicMin(info, (int)(k0 + __builtin_ctzll(badmask)));
+  }
 }
 
-// all 256 threads; Ls = lower-triangular L (zeros above), inv_diag = 1/diag -> Xs = L^-1
-__device__ __forceinline__ void trinv64_lds(const double* Ls, const double* inv_diag, double* Xs,
-                                            double* Ts /* [3][16][17] scratch */) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int e = tid; e < kFitBlock * kDS; e += 256) Xs[e] = 0.0;
+// all 256 threads; lower part of Ls = L  ->  lower part of Xs = L^-1 (entries above the diagonal
+// BLOCKS are never written: stores mask them).  Recursive in two levels so that every stage keeps
+// the MFMA busy on all waves and only six barriers sit on the chain:
+//   1/diag -> four 16x16 diagonal inverses (one per wave, lane = column, right-looking so the
+//   dependent chain is 16 multiply-adds) -> blocks (1,0), (3,2): X = -Xd (L Xd) -> the 32x32
+//   block [2:4][0:2]: X21 = -X22 (L21 X11), one 16x16 tile per wave in both products.
+constexpr int kTsLd = 33;                  // row stride of the 32x32 scratch
+constexpr int kTsDoubles = 32 * kTsLd;
+__device__ __forceinline__ void trinv64_lds(const double* Ls, double* inv_diag, double* Xs,
+                                            double* Ts /* [32][33] scratch */) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid < kFitBlock) inv_diag[tid] = 1.0 / Ls[tid * kDS + tid];
   __syncthreads();
-  // diagonal 16x16 blocks: wave w inverts block w, lane c < 16 owns column c of that block, kept
-  // in registers (static indices); the L reads are wave-uniform LDS broadcasts off the chain
+  GPSO_STAMP(8);
   if (lane < kPB) {
     const int b0 = wave * kPB, c = lane;
     double xi[kPB];
 #pragma unroll
-    for (int i = 0; i < kPB; ++i) {
-      double s0 = (i == c) ? 1.0 : 0.0;
+    for (int i = 0; i < kPB; ++i) xi[i] = (i == c) ? 1.0 : 0.0;
+    const double* Ld = Ls + b0 * kDS + b0;
+    double idg[kPB];
 #pragma unroll
-      for (int k = 0; k < i; ++k) s0 = fma(-Ls[(b0 + i) * kDS + b0 + k], xi[k], s0);
-      xi[i] = (i < c) ? 0.0 : s0 * inv_diag[b0 + i];
+    for (int k = 0; k < kPB; ++k) idg[k] = inv_diag[b0 + k];
+#pragma unroll
+    for (int k = 0; k < kPB; ++k) {
+      double lk[kPB];  // column k of the block, fetched before it is needed (uniform addresses)
+#pragma unroll
+      for (int i = k + 1; i < kPB; ++i) lk[i] = Ld[i * kDS + k];
+      const double xk = xi[k] * idg[k];  // rows k < c stay exactly zero
+      xi[k] = xk;
+#pragma unroll
+      for (int i = k + 1; i < kPB; ++i) xi[i] = fma(-lk[i], xk, xi[i]);
     }
 #pragma unroll
     for (int i = 0; i < kPB; ++i) Xs[(b0 + i) * kDS + b0 + c] = xi[i];
   }
   __syncthreads();
-  // off-diagonal blocks by distance, one 16x16 block per wave on the f64 MFMA:
-  //   T = sum_kb L[ib][kb] X[kb][jb]   (K = 16 * dist contiguous columns of L)
-  //   X[ib][jb] = -Xd[ib] * T
-  for (int dist = 1; dist < 4; ++dist) {
-    const int nblk = 4 - dist;
-    if (wave < nblk) {
-      const int jb = wave, ib = wave + dist;
-      const f64x4 t = mma16_lds(Ls + ib * kPB * kDS + jb * kPB, kDS, 1, Xs + jb * kPB * kDS + jb * kPB,
-                                kDS, 1, kPB * dist, lane);
+  GPSO_STAMP(9);
+  // level 16: blocks (1,0) and (3,2)
+  if (wave < 2) {
+    const int jb = 2 * wave, ib = jb + 1;
+    const f64x4 t = mma16_lds<kPB>(Ls + ib * kPB * kDS + jb * kPB, kDS, 1,
+                                   Xs + jb * kPB * kDS + jb * kPB, kDS, 1, lane);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Ts[(wave * kPB + (lane >> 4) + 4 * r) * 17 + (lane & 15)] = t[r];
-    }
-    __syncthreads();
-    if (wave < nblk) {
-      const int jb = wave, ib = wave + dist;
-      const f64x4 x = mma16_lds(Xs + ib * kPB * kDS + ib * kPB, kDS, 1, Ts + wave * kPB * 17, 17, 1,
-                                kPB, lane);
+    for (int r = 0; r < 4; ++r) Ts[(wave * kPB + (lane >> 4) + 4 * r) * kTsLd + (lane & 15)] = t[r];
+  }
+  __syncthreads();
+  GPSO_STAMP(10);
+  if (wave < 2) {
+    const int jb = 2 * wave, ib = jb + 1;
+    const f64x4 x = mma16_lds<kPB>(Xs + ib * kPB * kDS + ib * kPB, kDS, 1, Ts + wave * kPB * kTsLd,
+                                   kTsLd, 1, lane);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        Xs[(ib * kPB + (lane >> 4) + 4 * r) * kDS + jb * kPB + (lane & 15)] = -x[r];
+    for (int r = 0; r < 4; ++r)
+      Xs[(ib * kPB + (lane >> 4) + 4 * r) * kDS + jb * kPB + (lane & 15)] = -x[r];
+  }
+  __syncthreads();
+  GPSO_STAMP(11);
+  // level 32: tile (a, b) of the 32x32 block per wave
+  {
+    const int a = wave >> 1, b = wave & 1;
+    // T = L21 X11; X11 is lower triangular: column block b only needs k >= 16 b
+    const double* Ab = Ls + (32 + kPB * a) * kDS + kPB * b;
+    const double* Bb = Xs + (kPB * b) * kDS + kPB * b;
+    const f64x4 t = (b == 0) ? mma16_lds<32>(Ab, kDS, 1, Bb, kDS, 1, lane)
+                             : mma16_lds<16>(Ab, kDS, 1, Bb, kDS, 1, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ts[(kPB * a + (lane >> 4) + 4 * r) * kTsLd + kPB * b + (lane & 15)] = t[r];
+  }
+  __syncthreads();
+  GPSO_STAMP(12);
+  {
+    const int a = wave >> 1, b = wave & 1;
+    // X21 = -X22 T; X22 is lower triangular: row block a only needs k < 16 (a + 1)
+    const double* Ab = Xs + (32 + kPB * a) * kDS + 32;
+    const f64x4 x = (a == 1) ? mma16_lds<32>(Ab, kDS, 1, Ts + kPB * b, kTsLd, 1, lane)
+                             : mma16_lds<16>(Ab, kDS, 1, Ts + kPB * b, kTsLd, 1, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      Xs[(32 + kPB * a + (lane >> 4) + 4 * r) * kDS + kPB * b + (lane & 15)] = -x[r];
+  }
+  __syncthreads();
+  GPSO_STAMP(13);
+}
+
+// all 256 threads: lower part of a 64x64 f64 LDS tile (stride kDS) -> global T tile, zeros above
+// the diagonal; a thread owns 16 consecutive columns of one row (four 16-byte stores)
+template <typename T>
+__device__ __forceinline__ void lower_tile_to_global(const double* S, T* __restrict__ dst, int64_t ld, int tid) {
+  using vec4 = typename Mfma<T>::vec4;
+  const int r = tid >> 2, cb = 16 * (tid & 3);
+  T* o = dst + (int64_t)r * ld + cb;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    vec4 x{0, 0, 0, 0};
+    if (cb + 4 * v <= r) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = cb + 4 * v + e;
+        x[e] = (c <= r) ? (T)S[r * kDS + c] : (T)0;
+      }
     }
-    __syncthreads();
+    *reinterpret_cast<vec4*>(o + 4 * v) = x;
   }
 }
 
@@ -272,7 +339,7 @@ __global__ __launch_bounds__(256) void trinv_diag_kernel(const T* __restrict__ L
                                                          T* __restrict__ linv, int64_t ld) {
   __shared__ double Ls[kFitBlock * kDS];
   __shared__ double Xs[kFitBlock * kDS];
-  __shared__ double Ts[3 * kPB * 17];
+  __shared__ double Ts[kTsDoubles];
   __shared__ double inv_diag[kFitBlock];
   const int tid = threadIdx.x;
   const int64_t k0 = (int64_t)blockIdx.x * kFitBlock;
@@ -281,14 +348,9 @@ __global__ __launch_bounds__(256) void trinv_diag_kernel(const T* __restrict__ L
     const int r = e >> 6, c = e & 63;
     Ls[r * kDS + c] = (c <= r) ? (double)A[(int64_t)r * ld + c] : 0.0;
   }
-  if (tid < kFitBlock) inv_diag[tid] = 1.0 / (double)A[(int64_t)tid * ld + tid];
   __syncthreads();
   trinv64_lds(Ls, inv_diag, Xs, Ts);
-  T* Xo = linv + k0 * ld + k0;
-  for (int e = tid; e < kFitBlock * kFitBlock; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    Xo[(int64_t)r * ld + c] = (T)Xs[r * kDS + c];
-  }
+  lower_tile_to_global<T>(Xs, linv + k0 * ld + k0, ld, tid);
 }
 
 // =============================================================================================
@@ -448,9 +510,10 @@ static void launch_gemm(hipStream_t st, const GemmDesc& g) {
 //   role D  (workgroup 0):  diagonal block k+1: its own panel tile L10 = K[k+1,k] X_k^T, the
 //                           rank-64 update of ITS tile only, S = K[k+1,k+1] - L10 L10^T, then
 //                           chol(S) -> Lf[k+1,k+1] and its inverse -> linv[k+1,k+1];
-//   role PU (all others):   tile (i,j), k+1 <= j <= jmax, i >= j, (i,j) != (k+1,k+1):
+//   role PU (all others):   tile (i,j), k+1 <= j <= jmax, i >= j:
 //                           Li = K[i,k] X_k^T, Lj = K[j,k] X_k^T (recomputed per tile: 64^3 each),
-//                           K[i,j] -= Li Lj^T; the j == k+1 tiles also store Li -> Lf[i,k].
+//                           K[i,j] -= Li Lj^T; the j == k+1 tiles also store Li -> Lf[i,k]
+//                           (tile (k+1,k+1) only stores: its update is role D's).
 // Both roles only READ column k of K and WRITE disjoint tiles, so no ordering inside the launch is
 // needed; L goes to its own matrix Lf (out of place) because other tiles still read K[i,k] while
 // Li is produced.  K ends up holding Schur-complement debris.
@@ -459,7 +522,9 @@ constexpr int kTL = kFitBlock + 4;  // LDS row stride of a T tile: vec4 fragment
 // wave tile product on MFMA: acc[tj] (16x16, rows 16w.. of A) = A_rows[16 x 64] * B[64 x 64]^T,
 // both operands row-major [row][k] in LDS with stride kTL.  k runs in the permuted order
 // 16 kk + 4 (lane >> 4) + e on both sides.
-template <typename T>
+// B_LOWER: B is lower triangular (B[row][k] = 0 for k > row), so column tile tj only needs the
+// k-blocks kk <= tj: 40 instead of 64 MFMAs.
+template <typename T, bool B_LOWER>
 __device__ __forceinline__ void mma_abt(const T* A_rows, const T* B, int lane,
                                         typename Mfma<T>::vec4 (&acc)[4]) {
   using M = Mfma<T>;
@@ -472,14 +537,32 @@ __device__ __forceinline__ void mma_abt(const T* A_rows, const T* B, int lane,
     const vec4 a4 = *reinterpret_cast<const vec4*>(A_rows + (lane & 15) * kTL + ko);
     vec4 b4[4];
 #pragma unroll
-    for (int tj = 0; tj < 4; ++tj)
+    for (int tj = B_LOWER ? kk : 0; tj < 4; ++tj)
       b4[tj] = *reinterpret_cast<const vec4*>(B + (16 * tj + (lane & 15)) * kTL + ko);
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int tj = 0; tj < 4; ++tj) acc[tj] = M::mma(a4[e], b4[tj][e], acc[tj]);
+      for (int tj = B_LOWER ? kk : 0; tj < 4; ++tj) acc[tj] = M::mma(a4[e], b4[tj][e], acc[tj]);
   }
 }
+
+// one 16x16 tile: acc = A_rows[16 x 64] * B_rows[16 x 64]^T
+template <typename T>
+__device__ __forceinline__ typename Mfma<T>::vec4 mma_abt_tile(const T* A_rows, const T* B_rows, int lane) {
+  using M = Mfma<T>;
+  using vec4 = typename M::vec4;
+  vec4 acc{0, 0, 0, 0};
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const int ko = 16 * kk + 4 * (lane >> 4);
+    const vec4 a4 = *reinterpret_cast<const vec4*>(A_rows + (lane & 15) * kTL + ko);
+    const vec4 b4 = *reinterpret_cast<const vec4*>(B_rows + (lane & 15) * kTL + ko);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = M::mma(a4[e], b4[e], acc);
+  }
+  return acc;
+}
+
 
 // all 256 threads: 64x64 tile at src (row stride ld) -> LDS tile (stride kTL), 16-byte loads
 template <typename T>
@@ -499,7 +582,7 @@ struct StepLds {
   static constexpr int kTileBytes = kFitBlock * kTL * (int)sizeof(T);
   static constexpr int kF64Bytes = kFitBlock * kDS * 8;
   static constexpr int kOver = (2 * kTileBytes > kF64Bytes) ? 2 * kTileBytes : kF64Bytes;
-  static constexpr int kBytesD = kF64Bytes + kOver + 3 * kPB * 17 * 8 + kFitBlock * 8;
+  static constexpr int kBytesD = kF64Bytes + kOver + kTsDoubles * 8 + kFitBlock * 8;
   static constexpr int kBytes = (3 * kTileBytes > kBytesD) ? 3 * kTileBytes : kBytesD;
 };
 
@@ -507,7 +590,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* __restrict__ Lf,
                                                          T* __restrict__ linv, int64_t ld, int k,
                                                          int jmax, int ntile, int64_t n,
-                                                         double* __restrict__ logdet_part,
+                                                         double* __restrict__ diag64,
                                                          int* __restrict__ info) {
   using M = Mfma<T>;
   using vec4 = typename M::vec4;
@@ -527,33 +610,56 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
     T* TX = TA + kFitBlock * kTL;
     double* Xs = reinterpret_cast<double*>(lds + kF64Bytes);  // overlays TA / TX once they are dead
     double* Ts = reinterpret_cast<double*>(lds + kF64Bytes + kOver);
-    double* inv_diag = Ts + 3 * kPB * 17;
+    double* inv_diag = Ts + kTsDoubles;
     const T* Akk = K + (kd * T64) * ld + kd * T64;
+    GPSO_STAMP(14);
     if (k >= 0) {
+      // S = A[kd,kd] - L10 L10^T needs the lower 16x16 tiles only: three per wave (the last wave:
+      // one).  This lane's entries of A[kd,kd] for those tiles are fetched first and stay in flight
+      // while L10 is formed.
+      constexpr int kSti[4][3] = {{0, 3, 3}, {1, 1, 3}, {2, 2, 2}, {3, -1, -1}};
+      constexpr int kStj[4][3] = {{0, 0, 1}, {0, 1, 2}, {0, 1, 2}, {3, -1, -1}};
+      int sti[3], stj[3];
+      T akk[3][4];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        sti[t] = stj[t] = -1;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+          if (wave == w) {
+            sti[t] = kSti[w][t];
+            stj[t] = kStj[w][t];
+          }
+        if (sti[t] >= 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            akk[t][r] = Akk[(int64_t)(16 * sti[t] + M::crow(lane, r)) * ld + 16 * stj[t] + (lane & 15)];
+        }
+      }
       tile_to_lds<T>(K + (kd * T64) * ld + k * T64, ld, TA, tid);
       tile_to_lds<T>(linv + (k * T64) * ld + k * T64, ld, TX, tid);
       __syncthreads();
       vec4 acc[4];
-      mma_abt<T>(TA + wave * 16 * kTL, TX, lane, acc);  // L10 rows of this wave
-      T* Lo = Lf + (kd * T64) * ld + k * T64;
+      mma_abt<T, true>(TA + wave * 16 * kTL, TX, lane, acc);  // L10 rows of this wave
+      // (Lf[kd,k] is stored by the role-PU workgroup of tile (kd,kd), which forms the same L10)
 #pragma unroll
       for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = wave * 16 + M::crow(lane, r), col = 16 * tj + (lane & 15);
-          TA[row * kTL + col] = acc[tj][r];  // rows of this wave only: no other wave reads them yet
-          Lo[(int64_t)row * ld + col] = acc[tj][r];
-        }
+        for (int r = 0; r < 4; ++r)  // rows of this wave only: no other wave reads them yet
+          TA[(wave * 16 + M::crow(lane, r)) * kTL + 16 * tj + (lane & 15)] = acc[tj][r];
       __syncthreads();
-      mma_abt<T>(TA + wave * 16 * kTL, TA, lane, acc);
 #pragma unroll
-      for (int tj = 0; tj < 4; ++tj)
+      for (int t = 0; t < 3; ++t) {
+        const int ti = sti[t], tj = stj[t];
+        if (ti < 0) break;
+        const vec4 a = mma_abt_tile<T>(TA + ti * 16 * kTL, TA + tj * 16 * kTL, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = wave * 16 + M::crow(lane, r), col = 16 * tj + (lane & 15);
-          const T upd = Akk[(int64_t)row * ld + col] - acc[tj][r];
+          const int row = 16 * ti + M::crow(lane, r), col = 16 * tj + (lane & 15);
+          const T upd = akk[t][r] - a[r];
           Ls[row * kDS + col] = (col <= row) ? (double)upd : 0.0;
         }
+      }
     } else {
       for (int e = tid; e < kFitBlock * kFitBlock; e += 256) {
         const int r = e >> 6, c = e & 63;
@@ -562,27 +668,23 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
     }
     __syncthreads();
     const int64_t k0 = kd * T64;
-    chol64_lds(Ls, inv_diag, k0, n, info);
-    if (tid < kFitBlock) {  // log-determinant of the block (wave 0)
-      double lg = (k0 + tid < n) ? log(Ls[tid * kDS + tid]) : 0.0;
-      lg = wave_sum(lg);
-      if (tid == 0) logdet_part[kd] = lg;
-    }
+    GPSO_STAMP(15);
+    chol64_lds<(sizeof(T) == 4) ? 1 : 2>(Ls, k0, n, info);
+    // the unrounded diagonal: its logarithms are summed by nlml_kernel, off this chain
+    if (tid < kFitBlock) diag64[k0 + tid] = Ls[tid * kDS + tid];
+    GPSO_STAMP(7);
     trinv64_lds(Ls, inv_diag, Xs, Ts);
-    T* Lo = Lf + k0 * ld + k0;
-    T* Xo = linv + k0 * ld + k0;
-    for (int e = tid; e < kFitBlock * kFitBlock; e += 256) {
-      const int r = e >> 6, c = e & 63;
-      Lo[(int64_t)r * ld + c] = (T)Ls[r * kDS + c];
-      Xo[(int64_t)r * ld + c] = (T)Xs[r * kDS + c];
-    }
+    lower_tile_to_global<T>(Xs, linv + k0 * ld + k0, ld, tid);  // what the next launch waits for
+    lower_tile_to_global<T>(Ls, Lf + k0 * ld + k0, ld, tid);
+    GPSO_STAMP(16);
     return;
   }
   // ---------------- role PU: tile (i, j) of the trailing update -----------------------------------
   if (blockIdx.x == 0 || k < 0) return;
   const int j = k + 1 + (int)blockIdx.y;
   const int i = j + (int)blockIdx.x - 1;
-  if (j > jmax || i >= ntile || (i == k + 1 && j == k + 1)) return;
+  if (j > jmax || i >= ntile) return;
+  const bool diag_next = (i == k + 1);  // tile (k+1,k+1): role D updates it; only L10 is stored here
   T* TI = reinterpret_cast<T*>(lds);
   T* TJ = TI + kFitBlock * kTL;
   T* TX = TJ + kFitBlock * kTL;
@@ -591,7 +693,7 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
   tile_to_lds<T>(linv + (k * T64) * ld + k * T64, ld, TX, tid);
   __syncthreads();
   vec4 acc[4];
-  mma_abt<T>(TI + wave * 16 * kTL, TX, lane, acc);
+  mma_abt<T, true>(TI + wave * 16 * kTL, TX, lane, acc);
   {
     T* Lo = Lf + (i * T64) * ld + k * T64;
     const bool keep = (j == k + 1);
@@ -604,8 +706,9 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
         if (keep) Lo[(int64_t)row * ld + col] = acc[tj][r];
       }
   }
+  if (diag_next && j == k + 1) return;
   if (i != j) {
-    mma_abt<T>(TJ + wave * 16 * kTL, TX, lane, acc);
+    mma_abt<T, true>(TJ + wave * 16 * kTL, TX, lane, acc);
 #pragma unroll
     for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
@@ -613,7 +716,7 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
         TJ[(wave * 16 + M::crow(lane, r)) * kTL + 16 * tj + (lane & 15)] = acc[tj][r];
   }
   __syncthreads();
-  mma_abt<T>(TI + wave * 16 * kTL, (i != j) ? TJ : TI, lane, acc);
+  mma_abt<T, false>(TI + wave * 16 * kTL, (i != j) ? TJ : TI, lane, acc);
   T* C = K + (i * T64) * ld + j * T64;
 #pragma unroll
   for (int tj = 0; tj < 4; ++tj)
@@ -640,8 +743,8 @@ constexpr int kOuterPanel = 256;
 constexpr int64_t kSingleLevelMax = 4096;
 
 template <typename T>
-void launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, int64_t n, int64_t npad,
-                  double* logdet_part, int* info) {
+void launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, int64_t n, int64_t npad, double* diag64,
+                  int* info) {
   const int ntile = (int)(npad / kFitBlock);
   const bool single = npad <= kSingleLevelMax;
   static bool attr_set = false;  // per instantiation; the step kernel needs more than 64 KB of LDS
@@ -655,7 +758,7 @@ void launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, int64_t n, int64_t npad,
     const int ncol = (k < 0) ? 1 : std::max(1, jmax - k);
     const int nrow = (k < 0) ? 0 : std::max(1, ntile - (k + 1));
     hipLaunchKernelGGL((potrf_step_kernel<T>), dim3((unsigned)(1 + nrow), (unsigned)ncol), dim3(256),
-                       StepLds<T>::kBytes, st, K, Lf, linv, npad, k, jmax, ntile, n, logdet_part, info);
+                       StepLds<T>::kBytes, st, K, Lf, linv, npad, k, jmax, ntile, n, diag64, info);
   };
   step(-1, -1);  // diagonal block 0
   int p_end = single ? ntile : std::min(ntile, (kOuterPanel - kFitBlock) / kFitBlock);  // tiles
@@ -812,28 +915,32 @@ __global__ __launch_bounds__(256) void alpha_sum_kernel(const double* __restrict
 
 template <typename T>
 __global__ __launch_bounds__(256) void nlml_kernel(const T* __restrict__ white, int64_t n,
-                                                   const double* __restrict__ logdet_part,
-                                                   int npanels, double* __restrict__ out) {
-  __shared__ double sh[4];
-  double acc = 0.0;
+                                                   const double* __restrict__ diag64,
+                                                   double* __restrict__ out) {
+  __shared__ double sh[8];
+  double acc = 0.0, lg = 0.0;
   for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
     const double a = (double)white[i];
     acc += a * a;
+    lg += log(diag64[i]);
   }
   acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  lg = wave_sum(lg);
+  if ((threadIdx.x & 63) == 0) {
+    sh[threadIdx.x >> 6] = acc;
+    sh[4 + (threadIdx.x >> 6)] = lg;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double quad = sh[0] + sh[1] + sh[2] + sh[3];
-    double ld = 0.0;
-    for (int p = 0; p < npanels; ++p) ld += logdet_part[p];
+    const double quad = sh[0] + sh[1] + sh[2] + sh[3];
+    const double ld = sh[4] + sh[5] + sh[6] + sh[7];
     out[0] = 0.5 * quad + ld + 0.5 * (double)n * 1.83787706640934548356;  // log(2 pi)
   }
 }
 
 template <typename T>
 void launch_solve_alpha(hipStream_t st, const T* linv, const double* y64, int64_t n, int64_t npad,
-                        double mean_c, const double* logdet_part, int npanels, T* white, T* alpha,
+                        double mean_c, const double* diag64, T* white, T* alpha,
                         double* alpha_part, double* nlml_out) {
   hipLaunchKernelGGL((white_kernel<T>), dim3((unsigned)(npad / 4)), dim3(256), 0, st, linv, y64, n,
                      npad, mean_c, white);
@@ -843,11 +950,10 @@ void launch_solve_alpha(hipStream_t st, const T* linv, const double* y64, int64_
   hipLaunchKernelGGL((alpha_sum_kernel<T>), dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, st,
                      alpha_part, nchunk, npad, alpha);
   if (nlml_out)
-    hipLaunchKernelGGL((nlml_kernel<T>), dim3(1), dim3(256), 0, st, white, n, logdet_part, npanels,
-                       nlml_out);
+    hipLaunchKernelGGL((nlml_kernel<T>), dim3(1), dim3(256), 0, st, white, n, diag64, nlml_out);
 }
-template void launch_solve_alpha<float>(hipStream_t, const float*, const double*, int64_t, int64_t, double, const double*, int, float*, float*, double*, double*);
-template void launch_solve_alpha<double>(hipStream_t, const double*, const double*, int64_t, int64_t, double, const double*, int, double*, double*, double*, double*);
+template void launch_solve_alpha<float>(hipStream_t, const float*, const double*, int64_t, int64_t, double, const double*, float*, float*, double*, double*);
+template void launch_solve_alpha<double>(hipStream_t, const double*, const double*, int64_t, int64_t, double, const double*, double*, double*, double*, double*);
 
 // =============================================================================================
 // analytic gradient of the NLML  

@@ -49,10 +49,11 @@ void launch_scale_x(hipStream_t st, const double* x64, int64_t n, int64_t npad, 
 template <typename T>
 void launch_gram(hipStream_t st, const T* xs, const T* xnorm, int64_t n, int64_t npad, int dp,
                  const KernParams& kp, T* K);
-// blocked right-looking Cholesky in place (lower); also writes the inverted 64x64 diagonal blocks
-// into linv, per-panel log-determinant partials, and the first failing pivot (or INT_MAX) to info
+// blocked right-looking Cholesky, K (destroyed) -> Lf (lower); also writes the inverted 64x64 diagonal
+// blocks into linv, the unrounded diagonal of L to diag64[npad], and the first failing pivot (or
+// INT_MAX) to info
 template <typename T>
-void launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, int64_t n, int64_t npad, double* logdet_part,
+void launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, int64_t n, int64_t npad, double* diag64,
                   int* info);
 // L^-1 by level-doubling: needs the diagonal-block inverses already in linv; work = npad x npad scratch
 template <typename T>
@@ -60,10 +61,10 @@ void launch_trtri(hipStream_t st, const T* L, T* linv, T* work, int64_t npad);
 // zero rows/cols >= n and re-tile L^-1 into the MFMA fragment-major layout the predict kernel reads
 template <typename T>
 void launch_pack_linv(hipStream_t st, const T* linv, int64_t n, int64_t npad, T* linv_p);
-// a = L^-1 (y - c), alpha = L^-T a, nlml = 1/2 a.a + sum logdet_part + n/2 log 2pi  (double accumulators)
+// a = L^-1 (y - c), alpha = L^-T a, nlml = 1/2 a.a + sum log diag64 + n/2 log 2pi  (double accumulators)
 template <typename T>
 void launch_solve_alpha(hipStream_t st, const T* linv, const double* y64, int64_t n, int64_t npad,
-                        double mean_c, const double* logdet_part, int npanels, T* white, T* alpha,
+                        double mean_c, const double* diag64, T* white, T* alpha,
                         double* alpha_part /* [ceil(npad/256) * npad] scratch */, double* nlml_out);
 // Kinv = L^-T L^-1 (lower tiles, mirrored), then the gradient reductions of SURVEY.md A.3;
 // grad_out[n_ls + 3] = d nlml / d (ls..., variance, noise, c)

@@ -1,75 +1,41 @@
-// Phase timing of the 64x64 diagonal-block kernel (s_memtime stamps); build + run on the GPU box:
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I pygpso_amd/csrc tools/micro/diag_phases.hip -o /tmp/diag_phases
-__device__ long long g_stamps[16];
+// Phase timing of the Cholesky step kernel's diagonal role (s_memtime stamps from inside the real
+// launch_potrf at N = 2048) plus the wall time of the whole factorisation.  Build and run on the GPU box:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I pygpso_amd/csrc tools/micro/diag_phases.hip -o tools/micro/diag_phases.bin
+__device__ long long g_stamps[24];
 #define GPSO_STAMP(i) do { if (threadIdx.x == 0) g_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #include "../../pygpso_amd/csrc/fit.hip"
 #include <cstdio>
+#include <cmath>
 #include <vector>
-#include <random>
 using namespace gpso;
 
-template <typename T>
-__global__ __launch_bounds__(256) void diag_phases_kernel(T* K, T* linv, int64_t ld, int64_t n,
-                                                          double* logdet_part, int* info,
-                                                          long long* stamps) {
-  __shared__ double Ls[kFitBlock * kDS];
-  __shared__ double Xs[kFitBlock * kDS];
-  __shared__ double Ts[3 * kPB * 17];
-  __shared__ double inv_diag[kFitBlock];
-  const int tid = threadIdx.x;
-  long long t0 = __builtin_amdgcn_s_memtime();
-  T* A = K;
-  for (int e = tid; e < kFitBlock * kFitBlock; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    Ls[r * kDS + c] = (c <= r) ? (double)A[(int64_t)r * ld + c] : 0.0;
-  }
-  __syncthreads();
-  long long t1 = __builtin_amdgcn_s_memtime();
-  chol64_lds(Ls, inv_diag, 0, n, info);
-  long long t2 = __builtin_amdgcn_s_memtime();
-  if (tid < kFitBlock) {
-    double lg = log(Ls[tid * kDS + tid]);
-    lg = wave_sum(lg);
-    if (tid == 0) logdet_part[0] = lg;
-  }
-  long long t3 = __builtin_amdgcn_s_memtime();
-  trinv64_lds(Ls, inv_diag, Xs, Ts);
-  long long t4 = __builtin_amdgcn_s_memtime();
-  T* Xo = linv;
-  for (int e = tid; e < kFitBlock * kFitBlock; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    A[(int64_t)r * ld + c] = (T)Ls[r * kDS + c];
-    Xo[(int64_t)r * ld + c] = (T)Xs[r * kDS + c];
-  }
-  __syncthreads();
-  long long t5 = __builtin_amdgcn_s_memtime();
-  if (tid == 0) { stamps[0] = t1 - t0; stamps[1] = t2 - t1; stamps[2] = t3 - t2; stamps[3] = t4 - t3; stamps[4] = t5 - t4; }
-}
-
-int main() {
-  const int ld = 2048;
-  std::vector<float> h((size_t)64 * ld, 0.f);
-  std::mt19937 rng(1);
-  std::normal_distribution<float> nd;
-  std::vector<float> B(64 * 64);
-  for (auto& v : B) v = nd(rng);
-  for (int i = 0; i < 64; ++i)
-    for (int j = 0; j < 64; ++j) {
-      float s = (i == j) ? 64.f : 0.f;
-      for (int k = 0; k < 64; ++k) s += B[i * 64 + k] * B[j * 64 + k];
-      h[(size_t)i * ld + j] = s;
-    }
-  float *K, *X; double* lg; int* info; long long* st;
-  hipMalloc(&K, h.size() * 4); hipMalloc(&X, h.size() * 4); hipMalloc(&lg, 8 * 64); hipMalloc(&info, 4); hipMalloc(&st, 8 * 8);
-  for (int rep = 0; rep < 3; ++rep) {
+int main(int argc, char** argv) {
+  const int64_t n = (argc > 1) ? atoll(argv[1]) : 2048;
+  std::vector<float> h((size_t)n * n);
+  for (int64_t i = 0; i < n; ++i)
+    for (int64_t j = 0; j < n; ++j)
+      h[(size_t)i * n + j] = (float)(std::exp(-std::fabs((double)(i - j)) / 40.0) + (i == j ? 1e-2 : 0.0));
+  float *K, *Lf, *X; double* dg; int* info;
+  hipMalloc(&K, h.size() * 4); hipMalloc(&Lf, h.size() * 4); hipMalloc(&X, h.size() * 4);
+  hipMalloc(&dg, 8 * n); hipMalloc(&info, 4);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int rep = 0; rep < 5; ++rep) {
     hipMemcpy(K, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-    hipLaunchKernelGGL((diag_phases_kernel<float>), dim3(1), dim3(256), 0, 0, K, X, (int64_t)ld, (int64_t)64, lg, info, st);
+    hipMemset(X, 0, h.size() * 4);
+    int imax = 2147483647; hipMemcpy(info, &imax, 4, hipMemcpyHostToDevice);
+    hipEventRecord(e0, 0);
+    launch_potrf<float>(0, K, Lf, X, n, n, dg, info);
+    hipEventRecord(e1, 0);
     hipDeviceSynchronize();
-    long long s[5]; hipMemcpy(s, st, 40, hipMemcpyDeviceToHost);
-    // s_memtime counts at 100 MHz on gfx9
-    long long g[16]; hipMemcpyFromSymbol(g, HIP_SYMBOL(g_stamps), sizeof(g));
-    printf("chol panels/updates:"); for (int i = 1; i < 8; ++i) printf(" %lld", g[i] - g[i - 1]); printf("\n");
-    printf("load %lld chol %lld logdet %lld trinv %lld store %lld   (shader clocks)\n", s[0], s[1], s[2], s[3], s[4]);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    long long g[24]; hipMemcpyFromSymbol(g, HIP_SYMBOL(g_stamps), sizeof(g));
+    int inf; hipMemcpy(&inf, info, 4, hipMemcpyDeviceToHost);
+    printf("potrf %.1f us (%lld steps, info %d) | last step, shader clocks: load+L10+S %lld | panels/updates",
+           ms * 1e3, (long long)(n / 64), inf == imax ? -1 : inf, g[15] - g[14]);
+    for (int i = 1; i < 7; ++i) printf(" %lld", g[i] - g[i - 1]);
+    printf(" | last panel+check %lld | trinv:", g[7 + 1] - g[6] - (g[8] - g[7]));
+    for (int i = 8; i < 14; ++i) printf(" %lld", g[i] - g[i - 1]);
+    printf(" | store %lld | total %lld\n", g[16] - g[13], g[16] - g[14]);
   }
   return 0;
 }
