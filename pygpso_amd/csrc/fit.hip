@@ -18,6 +18,7 @@
 
 #include "common.hpp"
 #include "kernels.hpp"
+#include <type_traits>
 
 namespace gpso {
 
@@ -161,6 +162,21 @@ __device__ __forceinline__ f64x4 mma16_lds(const double* Ab, int sai, int sak, c
   return acc;
 }
 
+// value of lane (16 * (lane / 16) + N) for every lane: 64-bit DPP row_newbcast, one v_mov_b64_dpp
+template <int N>
+__device__ __forceinline__ double row_bcast_f64(double x) {
+  return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + N, 0xf, 0xf, false);
+}
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, I1)
+template <int I, int I1, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < I1) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, I1>(f);
+  }
+}
+
 __device__ __forceinline__ double readlane_f64(double x, int src_lane /* wave-uniform */) {
   const long long b = __builtin_bit_cast(long long, x);
   const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src_lane);
@@ -168,35 +184,124 @@ __device__ __forceinline__ double readlane_f64(double x, int src_lane /* wave-un
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
+// one thread: row r, columns cb .. cb+15 of the lower-triangular f64 LDS tile -> global T tile; 16-byte stores, vec4 groups entirely above the
+// diagonal are skipped (nothing reads them: Lf's upper part is never used, linv is pre-zeroed)
+template <typename T, int V0 = 0, int V1 = 4>
+__device__ __forceinline__ void lower_cols_to_global(const double* S, T* __restrict__ dst, int64_t ld,
+                                                     int r, int cb) {
+  using vec4 = typename Mfma<T>::vec4;
+  T* o = dst + (int64_t)r * ld + cb;
+#pragma unroll
+  for (int v = V0; v < V1; ++v) {
+    if (cb + 4 * v <= r) {
+      vec4 x;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = cb + 4 * v + e;
+        x[e] = (c <= r) ? (T)S[r * kDS + c] : (T)0;
+      }
+      *reinterpret_cast<vec4*>(o + 4 * v) = x;
+    }
+  }
+}
+
+// all 256 threads: lower part of a 64x64 f64 LDS tile (stride kDS) -> global T tile (the destination's
+// upper part must be pre-zeroed or unused); a thread owns 16 (or 32) consecutive columns of one row (16-byte stores)
+// (NT = 256: all threads, 16 columns each; NT = 128: t in [0, 128), 32 columns each)
+template <typename T, int NT = 256>
+__device__ __forceinline__ void lower_tile_to_global(const double* S, T* __restrict__ dst, int64_t ld, int t) {
+  using vec4 = typename Mfma<T>::vec4;
+  constexpr int kPerRow = NT / kFitBlock, kCols = kFitBlock / kPerRow;
+  const int r = t / kPerRow, cb = kCols * (t % kPerRow);
+  T* o = dst + (int64_t)r * ld + cb;
+#pragma unroll
+  for (int v = 0; v < kCols / 4; ++v) {
+    if (cb + 4 * v <= r) {  // groups entirely above the diagonal: destination is pre-zeroed / never read
+      vec4 x;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = cb + 4 * v + e;
+        x[e] = (c <= r) ? (T)S[r * kDS + c] : (T)0;
+      }
+      *reinterpret_cast<vec4*>(o + 4 * v) = x;
+    }
+  }
+}
+
+// 1 / x in full double precision: v_rcp_f64 seed + two Newton steps (the library division is ~30
+// instructions)
+__device__ __forceinline__ double rcp_newton(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
+// One wave, four columns of the inverse of the 16x16 lower-triangular block at Ls[b0.., b0..]:
+// the 16-lane row g = lane / 16 of the wave computes column c = cbase + g, lane % 16 = row i.
+// Forward substitution right-looking; the finished entry X[k][c] reaches the rows below through a
+// row-local 64-bit DPP broadcast, so a step is mul -> v_mov_b64_dpp -> fma on all 64 lanes
+// (~55 instructions for the four columns).
+__device__ __forceinline__ void diag_inv16(const double* Ls, double* Xs, int b0, int cbase, int lane) {
+  const int i = lane & 15, c = cbase + (lane >> 4);
+  const double* Lrow = Ls + (b0 + i) * kDS + b0;
+  double ld[kPB];
+#pragma unroll
+  for (int k = 0; k < kPB; ++k) {
+    const double v = Lrow[k];
+    ld[k] = (k < i) ? v : 0.0;  // entries on / above the diagonal are unspecified in Ls: select, not multiply
+  }
+  const double invd = rcp_newton(Lrow[i]);
+  double r = (i == c) ? 1.0 : 0.0;  // residual e_c - sum_{k<i} L[i][k] X[k][c]
+  static_for<0, kPB - 1>([&](auto k_) {
+    constexpr int k = decltype(k_)::value;
+    const double xk = row_bcast_f64<k>(r * invd);  // X[k][c]
+    r = fma(-ld[k], xk, r);
+  });
+  Xs[(b0 + i) * kDS + b0 + c] = r * invd;
+}
+
 // all 256 threads; Ls holds the symmetric block (lower part used); on return the lower part of Ls
 // is L (entries above the diagonal are unspecified: nothing reads them and the stores mask them).
 // A non-positive pivot turns its column into NaN (v_rsq of a non-positive number), which spreads
 // only to later columns: the first non-finite / non-positive diagonal entry is the failing pivot,
 // reported with atomicMin(info, global index) for rows < n.
-template <int NEWTON>
-__device__ __forceinline__ void chol64_lds(double* Ls, int64_t k0, int64_t n, int* info) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// While wave 0 factors panel p, wave 1 inverts the 16x16 diagonal block of panel p-1 into Xs (off
+// the pivot chain); the last diagonal block is left to trinv64_lds.
+// Wave 2 stores the 16 finished columns of panel p-1 to Lout (global) at the same time; the last 16
+// columns are left to the caller.
+template <int NEWTON, typename T>
+__device__ __forceinline__ void chol64_lds(double* Ls, double* Xs, T* __restrict__ Lout, int64_t ld,
+                                           int64_t k0, int64_t n, int* info) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int c0 = 0; c0 < kFitBlock; c0 += kPB) {
     GPSO_STAMP(2 * (c0 / kPB));
     if (wave == 0) {
       // panel columns c0 .. c0+15; lane = row.  The 16 panel entries of the row live in registers
       // and finished columns are broadcast with v_readlane (uniform lane index): the 16-pivot chain
-      // of a panel runs without a single LDS round trip, without branches and without selects.
+      // of a panel runs without a single LDS round trip, without branches and without selects;
+      // the column updates are independent work that fills the latency of that chain.
       double li[kPB];
 #pragma unroll
       for (int k = 0; k < kPB; ++k) li[k] = Ls[lane * kDS + c0 + k];
 #pragma unroll
       for (int jj = 0; jj < kPB; ++jj) {
-        // right-looking: column jj is final here; the only work on the pivot chain is
-        // readlane -> rsqrt -> scale -> update of column jj+1, the other updates are independent
+        // right-looking: column jj is final here.  On the pivot chain: readlane -> rsqrt -> scale ->
+        // update of column jj+1 (multiplier by v_readlane).  Off the chain: the finished column goes
+        // straight to its final place in LDS and the multipliers of the later columns come back as
+        // wave-uniform LDS reads (one instruction per multiplier instead of two v_readlane).
         const double rinv = rsqrt_newton<NEWTON>(readlane_f64(li[jj], c0 + jj));
         const double l = li[jj] * rinv;
-        li[jj] = l;
+        Ls[lane * kDS + c0 + jj] = l;
+        if (jj + 1 < kPB) li[jj + 1] = fma(-l, readlane_f64(l, c0 + jj + 1), li[jj + 1]);
 #pragma unroll
-        for (int kk = jj + 1; kk < kPB; ++kk) li[kk] = fma(-l, readlane_f64(l, c0 + kk), li[kk]);
+        for (int kk = jj + 2; kk < kPB; ++kk) li[kk] = fma(-l, Ls[(c0 + kk) * kDS + c0 + jj], li[kk]);
       }
-#pragma unroll
-      for (int k = 0; k < kPB; ++k) Ls[lane * kDS + c0 + k] = li[k];
+    } else if (wave == 1 && c0 > 0) {
+      for (int cb = 0; cb < kPB; cb += 4) diag_inv16(Ls, Xs, c0 - kPB, cb, lane);
+    } else if (wave == 2 && c0 > 0) {
+      lower_cols_to_global<T>(Ls, Lout, ld, lane, c0 - kPB);
     }
     __syncthreads();
     GPSO_STAMP(2 * (c0 / kPB) + 1);
@@ -228,40 +333,25 @@ __device__ __forceinline__ void chol64_lds(double* Ls, int64_t k0, int64_t n, in
 
 // all 256 threads; lower part of Ls = L  ->  lower part of Xs = L^-1 (entries above the diagonal
 // BLOCKS are never written: stores mask them).  Recursive in two levels so that every stage keeps
-// the MFMA busy on all waves and only six barriers sit on the chain:
-//   1/diag -> four 16x16 diagonal inverses (one per wave, lane = column, right-looking so the
-//   dependent chain is 16 multiply-adds) -> blocks (1,0), (3,2): X = -Xd (L Xd) -> the 32x32
-//   block [2:4][0:2]: X21 = -X22 (L21 X11), one 16x16 tile per wave in both products.
+// the MFMA busy on all waves and only five barriers sit on the chain:
+//   16x16 diagonal inverses (diag_inv16; FIRST3_DONE: blocks 0..2 were already inverted beside the
+//   factorisation and only block 3 is left, four columns per wave) -> blocks (1,0), (3,2):
+//   X = -Xd (L Xd) -> the 32x32 block [2:4][0:2]: X21 = -X22 (L21 X11), one 16x16 tile per wave in
+//   both products.
 constexpr int kTsLd = 33;                  // row stride of the 32x32 scratch
 constexpr int kTsDoubles = 32 * kTsLd;
-__device__ __forceinline__ void trinv64_lds(const double* Ls, double* inv_diag, double* Xs,
-                                            double* Ts /* [32][33] scratch */) {
+// Lout != nullptr: waves 2 and 3, idle in the level-16 stages, store the last 16 columns of the L
+// tile there (chol64_lds stored the others beside the factorisation).
+template <bool FIRST3_DONE, typename T>
+__device__ __forceinline__ void trinv64_lds(const double* Ls, double* Xs,
+                                            double* Ts /* [32][33] scratch */, T* Lout, int64_t ld) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (tid < kFitBlock) inv_diag[tid] = 1.0 / Ls[tid * kDS + tid];
-  __syncthreads();
   GPSO_STAMP(8);
-  if (lane < kPB) {
-    const int b0 = wave * kPB, c = lane;
-    double xi[kPB];
-#pragma unroll
-    for (int i = 0; i < kPB; ++i) xi[i] = (i == c) ? 1.0 : 0.0;
-    const double* Ld = Ls + b0 * kDS + b0;
-    double idg[kPB];
-#pragma unroll
-    for (int k = 0; k < kPB; ++k) idg[k] = inv_diag[b0 + k];
-#pragma unroll
-    for (int k = 0; k < kPB; ++k) {
-      double lk[kPB];  // column k of the block, fetched before it is needed (uniform addresses)
-#pragma unroll
-      for (int i = k + 1; i < kPB; ++i) lk[i] = Ld[i * kDS + k];
-      const double xk = xi[k] * idg[k];  // rows k < c stay exactly zero
-      xi[k] = xk;
-#pragma unroll
-      for (int i = k + 1; i < kPB; ++i) xi[i] = fma(-lk[i], xk, xi[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < kPB; ++i) Xs[(b0 + i) * kDS + b0 + c] = xi[i];
+  if (FIRST3_DONE) {
+    diag_inv16(Ls, Xs, 3 * kPB, 4 * wave, lane);
+  } else {
+    for (int cb = 0; cb < kPB; cb += 4) diag_inv16(Ls, Xs, wave * kPB, cb, lane);
   }
   __syncthreads();
   GPSO_STAMP(9);
@@ -272,6 +362,9 @@ __device__ __forceinline__ void trinv64_lds(const double* Ls, double* inv_diag, 
                                    Xs + jb * kPB * kDS + jb * kPB, kDS, 1, lane);
 #pragma unroll
     for (int r = 0; r < 4; ++r) Ts[(wave * kPB + (lane >> 4) + 4 * r) * kTsLd + (lane & 15)] = t[r];
+  } else if (Lout != nullptr && lane < kPB) {
+    if (wave == 2) lower_cols_to_global<T, 0, 2>(Ls, Lout, ld, 3 * kPB + lane, 3 * kPB);
+    if (wave == 3) lower_cols_to_global<T, 2, 4>(Ls, Lout, ld, 3 * kPB + lane, 3 * kPB);
   }
   __syncthreads();
   GPSO_STAMP(10);
@@ -312,27 +405,6 @@ __device__ __forceinline__ void trinv64_lds(const double* Ls, double* inv_diag, 
   GPSO_STAMP(13);
 }
 
-// all 256 threads: lower part of a 64x64 f64 LDS tile (stride kDS) -> global T tile, zeros above
-// the diagonal; a thread owns 16 consecutive columns of one row (four 16-byte stores)
-template <typename T>
-__device__ __forceinline__ void lower_tile_to_global(const double* S, T* __restrict__ dst, int64_t ld, int tid) {
-  using vec4 = typename Mfma<T>::vec4;
-  const int r = tid >> 2, cb = 16 * (tid & 3);
-  T* o = dst + (int64_t)r * ld + cb;
-#pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    vec4 x{0, 0, 0, 0};
-    if (cb + 4 * v <= r) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int c = cb + 4 * v + e;
-        x[e] = (c <= r) ? (T)S[r * kDS + c] : (T)0;
-      }
-    }
-    *reinterpret_cast<vec4*>(o + 4 * v) = x;
-  }
-}
-
 // inverse of every 64x64 diagonal block of an already-factorised L (gpso_set_posterior path)
 template <typename T>
 __global__ __launch_bounds__(256) void trinv_diag_kernel(const T* __restrict__ L,
@@ -340,7 +412,6 @@ __global__ __launch_bounds__(256) void trinv_diag_kernel(const T* __restrict__ L
   __shared__ double Ls[kFitBlock * kDS];
   __shared__ double Xs[kFitBlock * kDS];
   __shared__ double Ts[kTsDoubles];
-  __shared__ double inv_diag[kFitBlock];
   const int tid = threadIdx.x;
   const int64_t k0 = (int64_t)blockIdx.x * kFitBlock;
   const T* A = L + k0 * ld + k0;
@@ -349,7 +420,7 @@ __global__ __launch_bounds__(256) void trinv_diag_kernel(const T* __restrict__ L
     Ls[r * kDS + c] = (c <= r) ? (double)A[(int64_t)r * ld + c] : 0.0;
   }
   __syncthreads();
-  trinv64_lds(Ls, inv_diag, Xs, Ts);
+  trinv64_lds<false, T>(Ls, Xs, Ts, nullptr, 0);
   lower_tile_to_global<T>(Xs, linv + k0 * ld + k0, ld, tid);
 }
 
@@ -576,13 +647,13 @@ __device__ __forceinline__ void tile_to_lds(const T* __restrict__ src, int64_t l
 }
 
 // LDS carving of the step kernel.  role PU: three T tiles.  role D: Ls (f64) | { two T tiles, later
-// overlaid by Xs (f64) } | Ts | inv_diag.  float: 73 KB (2 workgroups per CU), double: 107 KB.
+// overlaid by Xs (f64) } | Ts.  float: 73 KB (2 workgroups per CU), double: 107 KB.
 template <typename T>
 struct StepLds {
   static constexpr int kTileBytes = kFitBlock * kTL * (int)sizeof(T);
   static constexpr int kF64Bytes = kFitBlock * kDS * 8;
   static constexpr int kOver = (2 * kTileBytes > kF64Bytes) ? 2 * kTileBytes : kF64Bytes;
-  static constexpr int kBytesD = kF64Bytes + kOver + kTsDoubles * 8 + kFitBlock * 8;
+  static constexpr int kBytesD = kF64Bytes + kOver + kTsDoubles * 8;
   static constexpr int kBytes = (3 * kTileBytes > kBytesD) ? 3 * kTileBytes : kBytesD;
 };
 
@@ -610,7 +681,6 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
     T* TX = TA + kFitBlock * kTL;
     double* Xs = reinterpret_cast<double*>(lds + kF64Bytes);  // overlays TA / TX once they are dead
     double* Ts = reinterpret_cast<double*>(lds + kF64Bytes + kOver);
-    double* inv_diag = Ts + kTsDoubles;
     const T* Akk = K + (kd * T64) * ld + kd * T64;
     GPSO_STAMP(14);
     if (k >= 0) {
@@ -639,6 +709,7 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
       tile_to_lds<T>(K + (kd * T64) * ld + k * T64, ld, TA, tid);
       tile_to_lds<T>(linv + (k * T64) * ld + k * T64, ld, TX, tid);
       __syncthreads();
+      GPSO_STAMP(17);
       vec4 acc[4];
       mma_abt<T, true>(TA + wave * 16 * kTL, TX, lane, acc);  // L10 rows of this wave
       // (Lf[kd,k] is stored by the role-PU workgroup of tile (kd,kd), which forms the same L10)
@@ -648,11 +719,28 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
         for (int r = 0; r < 4; ++r)  // rows of this wave only: no other wave reads them yet
           TA[(wave * 16 + M::crow(lane, r)) * kTL + 16 * tj + (lane & 15)] = acc[tj][r];
       __syncthreads();
+      GPSO_STAMP(18);
+      // all fragments of the (up to) three tiles are fetched before the first MFMA issues
+      vec4 fa[3][4], fb[3][4];
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        if (sti[t] >= 0) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const int ko = 16 * kk + 4 * (lane >> 4);
+            fa[t][kk] = *reinterpret_cast<const vec4*>(TA + (16 * sti[t] + (lane & 15)) * kTL + ko);
+            fb[t][kk] = *reinterpret_cast<const vec4*>(TA + (16 * stj[t] + (lane & 15)) * kTL + ko);
+          }
+        }
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
         const int ti = sti[t], tj = stj[t];
         if (ti < 0) break;
-        const vec4 a = mma_abt_tile<T>(TA + ti * 16 * kTL, TA + tj * 16 * kTL, lane);
+        vec4 a{0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a = M::mma(fa[t][kk][e], fb[t][kk][e], a);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * ti + M::crow(lane, r), col = 16 * tj + (lane & 15);
@@ -669,13 +757,12 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
     __syncthreads();
     const int64_t k0 = kd * T64;
     GPSO_STAMP(15);
-    chol64_lds<(sizeof(T) == 4) ? 1 : 2>(Ls, k0, n, info);
+    chol64_lds<(sizeof(T) == 4) ? 1 : 2, T>(Ls, Xs, Lf + k0 * ld + k0, ld, k0, n, info);
     // the unrounded diagonal: its logarithms are summed by nlml_kernel, off this chain
     if (tid < kFitBlock) diag64[k0 + tid] = Ls[tid * kDS + tid];
     GPSO_STAMP(7);
-    trinv64_lds(Ls, inv_diag, Xs, Ts);
-    lower_tile_to_global<T>(Xs, linv + k0 * ld + k0, ld, tid);  // what the next launch waits for
-    lower_tile_to_global<T>(Ls, Lf + k0 * ld + k0, ld, tid);
+    trinv64_lds<true, T>(Ls, Xs, Ts, Lf + k0 * ld + k0, ld);
+    lower_tile_to_global<T>(Xs, linv + k0 * ld + k0, ld, tid);
     GPSO_STAMP(16);
     return;
   }

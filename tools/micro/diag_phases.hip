@@ -30,8 +30,8 @@ int main(int argc, char** argv) {
     float ms; hipEventElapsedTime(&ms, e0, e1);
     long long g[24]; hipMemcpyFromSymbol(g, HIP_SYMBOL(g_stamps), sizeof(g));
     int inf; hipMemcpy(&inf, info, 4, hipMemcpyDeviceToHost);
-    printf("potrf %.1f us (%lld steps, info %d) | last step, shader clocks: load+L10+S %lld | panels/updates",
-           ms * 1e3, (long long)(n / 64), inf == imax ? -1 : inf, g[15] - g[14]);
+    printf("potrf %.1f us (%lld steps, info %d) | last step, shader clocks: load %lld L10 %lld S %lld | panels/updates",
+           ms * 1e3, (long long)(n / 64), inf == imax ? -1 : inf, g[17] - g[14], g[18] - g[17], g[15] - g[18]);
     for (int i = 1; i < 7; ++i) printf(" %lld", g[i] - g[i - 1]);
     printf(" | last panel+check %lld | trinv:", g[7 + 1] - g[6] - (g[8] - g[7]));
     for (int i = 8; i < 14; ++i) printf(" %lld", g[i] - g[i - 1]);
