@@ -255,8 +255,9 @@ struct EngineT : Engine {
     const int imax = INT_MAX;
     int* info_dev = reinterpret_cast<int*>(as<double>(scal) + 1);
     HIPCHECK(hipMemcpyAsync(info_dev, &imax, sizeof(int), hipMemcpyHostToDevice, s));
-    launch_potrf<T>(s, as<T>(K), as<T>(Lf), as<T>(linv), n, npad, as<double>(logdet), info_dev);
-    launch_trtri<T>(s, as<T>(Lf), as<T>(linv), as<T>(work), npad);
+    if (!launch_potrf<T>(s, as<T>(K), as<T>(Lf), as<T>(linv), as<T>(work), n, npad, as<double>(logdet),
+                         info_dev))
+      launch_trtri<T>(s, as<T>(Lf), as<T>(linv), as<T>(work), npad);
     launch_solve_alpha<T>(s, as<T>(linv), as<double>(y64), n, npad, mean_c, as<double>(logdet),
                           as<T>(white), as<T>(alpha), as<double>(gpart),
                           as<double>(scal));

@@ -15,6 +15,7 @@
 // (gpso/gp_surrogate.py:500-503).
 #include <algorithm>
 #include <climits>
+#include <cstdlib>
 
 #include "common.hpp"
 #include "kernels.hpp"
@@ -646,6 +647,33 @@ __device__ __forceinline__ void tile_to_lds(const T* __restrict__ src, int64_t l
   }
 }
 
+// all 256 threads: 64x64 global tile -> LDS tile TRANSPOSED (dst[c][r] = src[r][c])
+template <typename T>
+__device__ __forceinline__ void tile_to_lds_t(const T* __restrict__ src, int64_t ld, T* dst, int tid) {
+  using vec4 = typename Mfma<T>::vec4;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int idx = tid + 256 * v, r = idx >> 4, c = 4 * (idx & 15);
+    const vec4 x = *reinterpret_cast<const vec4*>(src + (int64_t)r * ld + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dst[(c + e) * kTL + r] = x[e];
+  }
+}
+
+// all 256 threads: LDS tile holding the TRANSPOSE -> 64x64 global tile (dst[m][c] = src[c][m]), 16-byte stores
+template <typename T>
+__device__ __forceinline__ void lds_t_to_tile(const T* src, T* __restrict__ dst, int64_t ld, int tid) {
+  using vec4 = typename Mfma<T>::vec4;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int idx = tid + 256 * v, m = idx >> 4, c = 4 * (idx & 15);
+    vec4 x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = src[(c + e) * kTL + m];
+    *reinterpret_cast<vec4*>(dst + (int64_t)m * ld + c) = x;
+  }
+}
+
 // LDS carving of the step kernel.  role PU: three T tiles.  role D: Ls (f64) | { two T tiles, later
 // overlaid by Xs (f64) } | Ts.  float: 73 KB (2 workgroups per CU), double: 107 KB.
 template <typename T>
@@ -662,7 +690,7 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
                                                          T* __restrict__ linv, int64_t ld, int k,
                                                          int jmax, int ntile, int64_t n,
                                                          double* __restrict__ diag64,
-                                                         int* __restrict__ info) {
+                                                         int* __restrict__ info, T* __restrict__ W) {
   using M = Mfma<T>;
   using vec4 = typename M::vec4;
   using Lay = StepLds<T>;
@@ -672,6 +700,52 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t T64 = kFitBlock;
 
+  if (blockIdx.z == 1) {
+    // ---------------- role PB: tile (i, jp) of the inverse's right-hand side, jp <= k < i ----------
+    // L X = I solved by the same elimination: B starts as the identity, step k finishes row block k,
+    // X[k,jp] = X_kk B[k,jp], and updates the rows below, B[i,jp] -= L[i,k] X[k,jp].  B is kept
+    // TRANSPOSED in the scratch matrix, W[jp,i] = B[i,jp]^T, so that every product is the A B^T form
+    // of mma_abt:  Xkj^T = W[jp,k] X_kk^T,  W[jp,i] -= Xkj^T Li^T.  (jp == k: B[k,k] = I, Xkj = X_kk,
+    // and the first contribution overwrites W.)  The i == k+1 tiles also store X[k,jp] -> linv.
+    const int jp = (int)blockIdx.y, i = k + (int)blockIdx.x;
+    if (blockIdx.x == 0 || k < 0 || jp > k || i >= ntile) return;
+    T* TI = reinterpret_cast<T*>(lds);
+    T* TW = TI + kFitBlock * kTL;
+    T* TX = TW + kFitBlock * kTL;
+    const T* Xkk = linv + (k * T64) * ld + k * T64;
+    tile_to_lds<T>(K + (i * T64) * ld + k * T64, ld, TI, tid);
+    tile_to_lds<T>(Xkk, ld, TX, tid);
+    if (jp < k) tile_to_lds<T>(W + (jp * T64) * ld + k * T64, ld, TW, tid);
+    else tile_to_lds_t<T>(Xkk, ld, TW, tid);
+    __syncthreads();
+    vec4 acc[4];
+    mma_abt<T, true>(TI + wave * 16 * kTL, TX, lane, acc);  // Li
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        TI[(wave * 16 + M::crow(lane, r)) * kTL + 16 * tj + (lane & 15)] = acc[tj][r];
+    if (jp < k) {
+      mma_abt<T, true>(TW + wave * 16 * kTL, TX, lane, acc);  // Xkj^T rows of this wave
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          TW[(wave * 16 + M::crow(lane, r)) * kTL + 16 * tj + (lane & 15)] = acc[tj][r];
+    }
+    __syncthreads();
+    if (i == k + 1 && jp < k) lds_t_to_tile<T>(TW, linv + (k * T64) * ld + jp * T64, ld, tid);
+    mma_abt<T, false>(TW + wave * 16 * kTL, TI, lane, acc);
+    T* C = W + (jp * T64) * ld + i * T64;
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        T* c = C + (int64_t)(wave * 16 + M::crow(lane, r)) * ld + 16 * tj + (lane & 15);
+        *c = (jp < k) ? *c - acc[tj][r] : -acc[tj][r];
+      }
+    return;
+  }
   if (blockIdx.x == 0 && blockIdx.y == 0) {
     // ---------------- role D: diagonal block kd = k + 1 ----------------------------------------
     const int kd = k + 1;
@@ -814,13 +888,42 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
     }
 }
 
+// last row block of the inverse (no rows below it, so no step launch finished it):
+// X[k,jp] = X_kk B[k,jp] for jp < k = ntile - 1, one workgroup per tile
+template <typename T>
+__global__ __launch_bounds__(256) void inv_lastrow_kernel(T* __restrict__ linv, const T* __restrict__ W,
+                                                          int64_t ld, int k) {
+  using M = Mfma<T>;
+  using vec4 = typename M::vec4;
+  extern __shared__ __align__(32) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int jp = (int)blockIdx.x;
+  const int64_t T64 = kFitBlock;
+  T* TW = reinterpret_cast<T*>(lds);
+  T* TX = TW + kFitBlock * kTL;
+  tile_to_lds<T>(W + (jp * T64) * ld + k * T64, ld, TW, tid);
+  tile_to_lds<T>(linv + (k * T64) * ld + k * T64, ld, TX, tid);
+  __syncthreads();
+  vec4 acc[4];
+  mma_abt<T, true>(TW + wave * 16 * kTL, TX, lane, acc);
+#pragma unroll
+  for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      TW[(wave * 16 + M::crow(lane, r)) * kTL + 16 * tj + (lane & 15)] = acc[tj][r];
+  __syncthreads();
+  lds_t_to_tile<T>(TW, linv + (k * T64) * ld + jp * T64, ld, tid);
+}
+
 // =============================================================================================
 // blocked Cholesky
 // =============================================================================================
 // Right-looking in 64-wide steps, one potrf_step_kernel launch per step (see above).
 //   npad <= kSingleLevelMax: every step updates the whole trailing matrix (rank 64); at these sizes
 //       the matrix lives in the L2 / Infinity Cache and a step's bulk work is shorter than the
-//       diagonal chain it hides behind.
+//       diagonal chain it hides behind.  The off-diagonal blocks of L^-1 ride along in the same
+//       launches (role PB + one last-row launch), so no separate triangular inverse follows.
 //   larger: two-level.  Steps update only the columns of the current outer panel plus ONE
 //       look-ahead tile column (so that the first diagonal block of the next panel never waits for
 //       the big update); everything right of that gets one rank-(panel) SYRK per outer panel, which
@@ -828,24 +931,34 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
 //       192 + 256 p so that the SYRK region starts on a multiple of 128 (128x128 GEMM tiles).
 constexpr int kOuterPanel = 256;
 constexpr int64_t kSingleLevelMax = 4096;
+static int64_t single_level_max() {  // GPSO_SINGLE_LEVEL_MAX: tuning override
+  static const int64_t v = [] {
+    const char* e = std::getenv("GPSO_SINGLE_LEVEL_MAX");
+    return e ? (int64_t)std::atoll(e) : kSingleLevelMax;
+  }();
+  return v;
+}
 
 template <typename T>
-void launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, int64_t n, int64_t npad, double* diag64,
-                  int* info) {
+bool launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, int64_t n, int64_t npad,
+                  double* diag64, int* info) {
   const int ntile = (int)(npad / kFitBlock);
-  const bool single = npad <= kSingleLevelMax;
+  const bool single = npad <= single_level_max();
   static bool attr_set = false;  // per instantiation; the step kernel needs more than 64 KB of LDS
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_step_kernel<T>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, StepLds<T>::kBytes);
     attr_set = true;
   }
+  const int lds_bytes = StepLds<T>::kBytes;
   auto step = [&](int k, int jmax) {
     // grid.x = 1 (role D / idle) + rows below the diagonal of the tile column, grid.y = tile columns
-    const int ncol = (k < 0) ? 1 : std::max(1, jmax - k);
+    // with the inverse riding along (single level): blockIdx.z == 1 -> role PB, tile columns 0 .. k
+    const int ncol = (k < 0) ? 1 : std::max(single ? k + 1 : 1, jmax - k);
     const int nrow = (k < 0) ? 0 : std::max(1, ntile - (k + 1));
-    hipLaunchKernelGGL((potrf_step_kernel<T>), dim3((unsigned)(1 + nrow), (unsigned)ncol), dim3(256),
-                       StepLds<T>::kBytes, st, K, Lf, linv, npad, k, jmax, ntile, n, diag64, info);
+    hipLaunchKernelGGL((potrf_step_kernel<T>),
+                       dim3((unsigned)(1 + nrow), (unsigned)ncol, (single && k >= 0) ? 2u : 1u),
+                       dim3(256), lds_bytes, st, K, Lf, linv, npad, k, jmax, ntile, n, diag64, info, work);
   };
   step(-1, -1);  // diagonal block 0
   int p_end = single ? ntile : std::min(ntile, (kOuterPanel - kFitBlock) / kFitBlock);  // tiles
@@ -870,9 +983,20 @@ void launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, int64_t n, int64_t npad,
       p_end = std::min(ntile, p_end + kOuterPanel / kFitBlock);
     }
   }
+  if (single && ntile > 1) {
+    static bool attr2 = false;
+    if (!attr2) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&inv_lastrow_kernel<T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * StepLds<T>::kTileBytes);
+      attr2 = true;
+    }
+    hipLaunchKernelGGL((inv_lastrow_kernel<T>), dim3((unsigned)(ntile - 1)), dim3(256),
+                       2 * StepLds<T>::kTileBytes, st, linv, work, npad, ntile - 1);
+  }
+  return single;  // true: linv already holds the complete inverse
 }
-template void launch_potrf<float>(hipStream_t, float*, float*, float*, int64_t, int64_t, double*, int*);
-template void launch_potrf<double>(hipStream_t, double*, double*, double*, int64_t, int64_t, double*, int*);
+template bool launch_potrf<float>(hipStream_t, float*, float*, float*, float*, int64_t, int64_t, double*, int*);
+template bool launch_potrf<double>(hipStream_t, double*, double*, double*, double*, int64_t, int64_t, double*, int*);
 
 // =============================================================================================
 // triangular inverse by level doubling

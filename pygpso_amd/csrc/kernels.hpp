@@ -52,9 +52,11 @@ void launch_gram(hipStream_t st, const T* xs, const T* xnorm, int64_t n, int64_t
 // blocked right-looking Cholesky, K (destroyed) -> Lf (lower); also writes the inverted 64x64 diagonal
 // blocks into linv, the unrounded diagonal of L to diag64[npad], and the first failing pivot (or
 // INT_MAX) to info
+// Returns true when linv already holds the COMPLETE inverse (small sizes: it is built beside the
+// factorisation, using work as scratch) and launch_trtri must be skipped.
 template <typename T>
-void launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, int64_t n, int64_t npad, double* diag64,
-                  int* info);
+bool launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, int64_t n, int64_t npad,
+                  double* diag64, int* info);
 // L^-1 by level-doubling: needs the diagonal-block inverses already in linv; work = npad x npad scratch
 template <typename T>
 void launch_trtri(hipStream_t st, const T* L, T* linv, T* work, int64_t npad);

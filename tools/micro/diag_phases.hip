@@ -15,8 +15,8 @@ int main(int argc, char** argv) {
   for (int64_t i = 0; i < n; ++i)
     for (int64_t j = 0; j < n; ++j)
       h[(size_t)i * n + j] = (float)(std::exp(-std::fabs((double)(i - j)) / 40.0) + (i == j ? 1e-2 : 0.0));
-  float *K, *Lf, *X; double* dg; int* info;
-  hipMalloc(&K, h.size() * 4); hipMalloc(&Lf, h.size() * 4); hipMalloc(&X, h.size() * 4);
+  float *K, *Lf, *X, *Wk; double* dg; int* info;
+  hipMalloc(&K, h.size() * 4); hipMalloc(&Lf, h.size() * 4); hipMalloc(&X, h.size() * 4); hipMalloc(&Wk, h.size() * 4);
   hipMalloc(&dg, 8 * n); hipMalloc(&info, 4);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 5; ++rep) {
@@ -24,13 +24,13 @@ int main(int argc, char** argv) {
     hipMemset(X, 0, h.size() * 4);
     int imax = 2147483647; hipMemcpy(info, &imax, 4, hipMemcpyHostToDevice);
     hipEventRecord(e0, 0);
-    launch_potrf<float>(0, K, Lf, X, n, n, dg, info);
+    if (!launch_potrf<float>(0, K, Lf, X, Wk, n, n, dg, info)) launch_trtri<float>(0, Lf, X, Wk, n);
     hipEventRecord(e1, 0);
     hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     long long g[24]; hipMemcpyFromSymbol(g, HIP_SYMBOL(g_stamps), sizeof(g));
     int inf; hipMemcpy(&inf, info, 4, hipMemcpyDeviceToHost);
-    printf("potrf %.1f us (%lld steps, info %d) | last step, shader clocks: load %lld L10 %lld S %lld | panels/updates",
+    printf("potrf+inverse %.1f us (%lld steps, info %d) | last step, shader clocks: load %lld L10 %lld S %lld | panels/updates",
            ms * 1e3, (long long)(n / 64), inf == imax ? -1 : inf, g[17] - g[14], g[18] - g[17], g[15] - g[18]);
     for (int i = 1; i < 7; ++i) printf(" %lld", g[i] - g[i - 1]);
     printf(" | last panel+check %lld | trinv:", g[7 + 1] - g[6] - (g[8] - g[7]));
