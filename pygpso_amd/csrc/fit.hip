@@ -558,15 +558,258 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmDesc g) {
       }
 }
 
+// =============================================================================================
+// tile GEMM through LDS-DMA (same contract as gemm_tile_kernel), 128x128 or 64x64 tiles
+// =============================================================================================
+// The register-staged kernel above spends most of a k-step waiting (a lone 128x128x256 tile took
+// 38 us against 14 us of MFMA time).  Here the A and B panels of a k-step go global -> LDS with
+// global_load_lds into fragment-major double buffers -- every 16-byte DMA lands exactly where the
+// lane that will feed it to the MFMA reads it, so fragment reads are conflict-free and linear in the
+// lane id -- with ONE barrier per k-step and the next step's DMA in flight under the MFMAs.
+//   k-block = 16 consecutive k.  A lane's fragment is the 4 values k = 4 (lane / 16) + e, e < 4, of
+//   row (lane % 16) of a 16-row block; MFMA step e takes element e on both operands (the k order
+//   inside a block is a permutation shared by A and B).
+//   k-contiguous operand (KC): one 16-byte DMA per lane brings its own fragment (float; two for
+//   double): LDS [row block][slab][lane] x 16 B.
+//   row-contiguous operand (RC: consecutive rows adjacent in memory, k strided): a DMA instruction
+//   is tied to one e; a lane brings 4 (double: 2) consecutive rows at k = 4 g + e, and the lane
+//   order (row block, g, row quad) makes the LDS image [e][row block][lane] words.
+//   Per operand and k-block: float 8 DMA instructions / 8 KB, double 16 / 16 KB.  A k-step is two
+//   k-blocks for float and one for double: 16 DMA instructions and 16 KB per operand either way,
+//   64 KB of LDS for the two buffers of both operands (2 workgroups per CU).
+// C is read once, up front, into the accumulators (scaled by beta / alpha) so that the epilogue is
+// stores only.
+__device__ __forceinline__ void gemm_glds16(const void* gsrc_lane, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T, int TS>
+struct G128 {
+  static constexpr int kSlabs = sizeof(T) / 4;              // 16-byte DMAs per KC fragment
+  static constexpr int kBlocksPerStep = (sizeof(T) == 4) ? 2 : 1;
+  static constexpr int kStepK = 16 * kBlocksPerStep;
+  static constexpr int kRb = TS / 16;                        // 16-row blocks of an operand
+  static constexpr int kBlockBytes = TS * 16 * (int)sizeof(T);  // one operand, one k-block
+  static constexpr int kOperandBytes = kBlockBytes * kBlocksPerStep;
+  static constexpr int kBufBytes = 2 * kOperandBytes;        // A + B of one step
+  static constexpr int kInstrPerBlock = kRb * kSlabs;
+  static constexpr int kInstrPerStep = kInstrPerBlock * kBlocksPerStep;  // per operand: 16 | 8
+  static constexpr int kRowsPerLaneRC = 16 / (int)sizeof(T);           // 4 | 2
+  static constexpr int kRbPerInstrRC = kRowsPerLaneRC;                 // row blocks covered by one RC DMA
+  static constexpr int kWT = TS / 32;                        // MFMA tiles per side of a wave tile
+  static constexpr int kNbuf = (TS == 128) ? 2 : 4;          // LDS ring depth (64 KB either way)
+};
+
+// global element offset (row-stride s_row, k-stride s_k; one of them is 1) this lane's DMA number
+// `ins` of a k-block starts at, and the LDS byte offset (inside the operand's k-block image) of the
+// wave-wide destination
+template <typename T, int TS, bool KC>
+__device__ __forceinline__ void g128_dma_coords(int ins, int lane, int& row, int& k, int& lds_off) {
+  using G = G128<T, TS>;
+  if (KC) {
+    const int rb = ins / G::kSlabs, slab = ins % G::kSlabs;
+    row = rb * 16 + (lane & 15);
+    k = 4 * (lane >> 4) + slab * (4 / G::kSlabs);
+    lds_off = (rb * G::kSlabs + slab) * 1024;
+  } else {
+    constexpr int RPL = G::kRowsPerLaneRC;       // rows per lane
+    constexpr int QN = 16 / RPL;                 // lanes per 16 rows
+    constexpr int NH = G::kRb / G::kRbPerInstrRC;  // DMAs per e
+    const int e = ins / NH, h = ins % NH;
+    const int q = lane % QN, g = (lane / QN) & 3, rbq = lane / (4 * QN);
+    row = (h * G::kRbPerInstrRC + rbq) * 16 + RPL * q;
+    k = 4 * g + e;
+    lds_off = (e * NH + h) * 1024;
+  }
+}
+
+// fragment (4 k values) of row block rb for this lane out of an operand's k-block image
+template <typename T, int TS, bool KC>
+__device__ __forceinline__ typename Mfma<T>::vec4 g128_frag(const unsigned char* blk, int rb, int lane) {
+  using G = G128<T, TS>;
+  using vec4 = typename Mfma<T>::vec4;
+  if constexpr (KC) {
+    if constexpr (sizeof(T) == 4) {
+      return *reinterpret_cast<const vec4*>(blk + rb * 1024 + lane * 16);
+    } else {
+      typedef double f64x2 __attribute__((ext_vector_type(2)));
+      const f64x2 lo = *reinterpret_cast<const f64x2*>(blk + rb * 2048 + lane * 16);
+      const f64x2 hi = *reinterpret_cast<const f64x2*>(blk + rb * 2048 + 1024 + lane * 16);
+      return vec4{lo[0], lo[1], hi[0], hi[1]};
+    }
+  } else {
+    constexpr int NH = G::kRb / G::kRbPerInstrRC;
+    const int h = rb / G::kRbPerInstrRC, rbq = rb % G::kRbPerInstrRC;
+    vec4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      v[e] = *reinterpret_cast<const T*>(blk + (e * NH + h) * 1024 + rbq * (1024 / G::kRbPerInstrRC) +
+                                         lane * (int)sizeof(T));
+    return v;
+  }
+}
+
+// TS = 128 (wave tile 64 x 64) or 64 (32 x 32): the smaller tile when 128-tiles would leave most of the
+// chip idle or make a few long-K tiles the critical path.  kmode / lower_only act at TS granularity.
+// NBUF LDS buffers form a ring: the DMA of step t + NBUF - 1 is issued while step t computes (a 64-tile
+// step is ~0.45 us of MFMA work, less than a DMA round trip, so it runs 3 steps ahead).
+template <typename T, int TS, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmDesc g) {
+  using M = Mfma<T>;
+  using vec4 = typename M::vec4;
+  using G = G128<T, TS>;
+  constexpr int WT = G::kWT, WE = TS / 2;  // wave tile: WT x WT MFMA tiles, WE rows / columns
+  constexpr int NBUF = G::kNbuf;
+  extern __shared__ __align__(32) unsigned char lds[];  // [NBUF buffers][A | B][k-block] images
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ti = blockIdx.y, tj = blockIdx.x, bz = blockIdx.z;
+  if (g.lower_only && tj > ti) return;
+  const int m_here = (bz == g.nbatch - 1) ? g.m_last : g.m;
+  if (ti * TS >= m_here) return;
+  const T* A = static_cast<const T*>(g.A) + (int64_t)bz * g.batchA;
+  const T* B = static_cast<const T*>(g.B) + (int64_t)bz * g.batchB;
+  T* C = static_cast<T*>(g.C) + (int64_t)bz * g.batchC;
+
+  int k_lo = 0, k_hi = g.k;
+  if (g.kmode == 1) k_lo = TS * tj;
+  if (g.kmode == 2) k_lo = TS * ti;
+  if (g.kmode == 3) k_hi = min(g.k, TS * (ti + 1));
+
+  // this wave's DMA instructions: numbers wave, wave + 4, ... of the kInstrPerStep per operand
+  constexpr int NI = G::kInstrPerStep / 4;  // per wave, operand and step
+  const T* a_src[NI];
+  const T* b_src[NI];
+  int a_dst[NI], b_dst[NI];
+#pragma unroll
+  for (int s = 0; s < NI; ++s) {
+    const int n = wave + 4 * s;
+    const int kb = n / G::kInstrPerBlock, ins = n % G::kInstrPerBlock;
+    int row, k, off;
+    g128_dma_coords<T, TS, A_KC>(ins, lane, row, k, off);
+    a_src[s] = A + (int64_t)(ti * TS + row) * g.sai + (int64_t)(k_lo + kb * 16 + k) * g.sak;
+    a_dst[s] = kb * G::kBlockBytes + off;
+    g128_dma_coords<T, TS, B_KC>(ins, lane, row, k, off);
+    b_src[s] = B + (int64_t)(tj * TS + row) * g.sbj + (int64_t)(k_lo + kb * 16 + k) * g.sbk;
+    b_dst[s] = G::kOperandBytes + kb * G::kBlockBytes + off;
+  }
+  const int64_t a_adv = (int64_t)G::kStepK * g.sak, b_adv = (int64_t)G::kStepK * g.sbk;
+  auto issue = [&](int buf) {
+#pragma unroll
+    for (int s = 0; s < NI; ++s) {
+      gemm_glds16(a_src[s], lds + buf * G::kBufBytes + a_dst[s]);
+      gemm_glds16(b_src[s], lds + buf * G::kBufBytes + b_dst[s]);
+      a_src[s] += a_adv;
+      b_src[s] += b_adv;
+    }
+  };
+
+  const int wr = wave >> 1, wc = wave & 1;
+  vec4 acc[WT][WT];
+#pragma unroll
+  for (int d = 0; d < NBUF - 1; ++d)
+    if (k_lo + d * G::kStepK < k_hi) issue(d);
+  if (g.beta != 0.0) {  // all loads of the C tile in flight together, beside the first DMAs
+    const T scale = (T)(g.beta / g.alpha);
+    const T* c0 = C + (int64_t)(ti * TS + wr * WE) * g.ldc + tj * TS + wc * WE + (lane & 15);
+#pragma unroll
+    for (int a = 0; a < WT; ++a)
+#pragma unroll
+      for (int b = 0; b < WT; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[a][b][r] = c0[(int64_t)(a * 16 + M::crow(lane, r)) * g.ldc + b * 16];
+#pragma unroll
+    for (int a = 0; a < WT; ++a)
+#pragma unroll
+      for (int b = 0; b < WT; ++b) acc[a][b] *= scale;
+  } else {
+#pragma unroll
+    for (int a = 0; a < WT; ++a)
+#pragma unroll
+      for (int b = 0; b < WT; ++b) acc[a][b] = vec4{0, 0, 0, 0};
+  }
+  // s_waitcnt vmcnt(N): everything but the N most recent memory instructions of this wave has landed.
+  // With NBUF - 2 newer steps in flight (2 NI DMAs each) that is exactly the current step's data; in
+  // the tail (fewer newer steps) wait for everything.
+  constexpr int kAhead = (NBUF - 2) * 2 * NI;
+  constexpr int kWaitAhead = 0x0f70 | (kAhead & 0xf) | ((kAhead >> 4) << 14);
+  int buf = 0;
+  for (int k0 = k_lo; k0 < k_hi; k0 += G::kStepK) {
+    if (k0 + (NBUF - 2) * G::kStepK < k_hi) __builtin_amdgcn_s_waitcnt(kWaitAhead);
+    else __builtin_amdgcn_s_waitcnt(0x0f70);
+    // raw s_barrier: __syncthreads() carries a release fence that the compiler lowers to vmcnt(0),
+    // which would drain the DMAs running ahead.  After it: everyone's DMA of this step has landed
+    // and everyone is done with step - 1.
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (k0 + (NBUF - 1) * G::kStepK < k_hi) issue((buf + NBUF - 1) % NBUF);  // into the buffer of step - 1
+    const unsigned char* cur = lds + buf * G::kBufBytes;
+#pragma unroll
+    for (int kb = 0; kb < G::kBlocksPerStep; ++kb) {
+      vec4 a4[WT], b4[WT];
+#pragma unroll
+      for (int x = 0; x < WT; ++x) {
+        a4[x] = g128_frag<T, TS, A_KC>(cur + kb * G::kBlockBytes, wr * WT + x, lane);
+        b4[x] = g128_frag<T, TS, B_KC>(cur + G::kOperandBytes + kb * G::kBlockBytes, wc * WT + x, lane);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int a = 0; a < WT; ++a)
+#pragma unroll
+          for (int b = 0; b < WT; ++b) acc[a][b] = M::mma(a4[a][e], b4[b][e], acc[a][b]);
+    }
+    buf = (buf + 1 == NBUF) ? 0 : buf + 1;
+  }
+  const T alpha = (T)g.alpha;
+#pragma unroll
+  for (int a = 0; a < WT; ++a)
+#pragma unroll
+    for (int b = 0; b < WT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t i = ti * TS + wr * WE + a * 16 + M::crow(lane, r);
+        const int64_t j = tj * TS + wc * WE + b * 16 + (lane & 15);
+        C[i * g.ldc + j] = alpha * acc[a][b][r];
+      }
+}
+
+template <typename T, int TS, bool A_KC, bool B_KC>
+static void launch_gemm128(hipStream_t st, const GemmDesc& g) {
+  static bool attr_set = false;
+  constexpr int kLds = G128<T, TS>::kNbuf * G128<T, TS>::kBufBytes;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm128_kernel<T, TS, A_KC, B_KC>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)(g.n / TS), (unsigned)(g.m / TS), (unsigned)g.nbatch);
+  hipLaunchKernelGGL((gemm128_kernel<T, TS, A_KC, B_KC>), grid, dim3(256), kLds, st, g);
+}
+
+template <typename T, int TS>
+static void launch_gemm_dma(hipStream_t st, const GemmDesc& g, bool a_kc, bool b_kc) {
+  if (a_kc && b_kc) launch_gemm128<T, TS, true, true>(st, g);
+  else if (a_kc) launch_gemm128<T, TS, true, false>(st, g);
+  else if (b_kc) launch_gemm128<T, TS, false, true>(st, g);
+  else launch_gemm128<T, TS, false, false>(st, g);
+}
+
 template <typename T>
 static void launch_gemm(hipStream_t st, const GemmDesc& g) {
   if (g.m <= 0 || g.n <= 0 || g.nbatch <= 0) return;
-  // 128 x 128 tiles when every extent allows it and there is enough work to fill the chip with them
-  const bool big = (g.m % 128 == 0) && (g.n % 128 == 0) && (g.m_last % 128 == 0) &&
-                   ((int64_t)(g.m / 128) * (g.n / 128) * g.nbatch >= 128);
-  if (big) {
-    const dim3 grid((unsigned)(g.n / 128), (unsigned)(g.m / 128), (unsigned)g.nbatch);
-    hipLaunchKernelGGL((gemm_tile_kernel<T, 4>), grid, dim3(256), 0, st, g);
+  const bool a_kc = (g.sak == 1), a_rc = (g.sai == 1), b_kc = (g.sbk == 1), b_rc = (g.sbj == 1);
+  const bool dma_ok = (a_kc || a_rc) && (b_kc || b_rc) && g.alpha != 0.0 && g.k % 64 == 0;
+  // 128 x 128 tiles when every extent allows it and they still give every CU about two tiles
+  // (lower_only launches compute only half of the grid); 64 x 64 tiles otherwise
+  const bool div128 = (g.m % 128 == 0) && (g.n % 128 == 0) && (g.m_last % 128 == 0) && (g.k % 128 == 0);
+  const int64_t tiles128 = (int64_t)(g.m / 128) * (g.n / 128) * g.nbatch / (g.lower_only ? 2 : 1);
+  if (dma_ok && div128 && tiles128 >= 512) {
+    launch_gemm_dma<T, 128>(st, g, a_kc, b_kc);
+  } else if (dma_ok) {
+    launch_gemm_dma<T, 64>(st, g, a_kc, b_kc);
   } else {
     const dim3 grid((unsigned)(g.n / 64), (unsigned)(g.m / 64), (unsigned)g.nbatch);
     hipLaunchKernelGGL((gemm_tile_kernel<T, 2>), grid, dim3(256), 0, st, g);
