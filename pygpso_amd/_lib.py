@@ -24,6 +24,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 MAT_CHOL, MAT_LINV, MAT_KINV, MAT_GRAM = 0, 1, 2, 3
 VEC_ALPHA, VEC_WHITE = 0, 1
 OPT_PREDICT_MATH = 1
+OPT_FIT_SINGLE_LEVEL_MAX = 2
 MATH_NATIVE, MATH_BF16X3, MATH_BF16X6 = 0, 3, 6
 MATH_IDS = {"native": MATH_NATIVE, "f32": MATH_NATIVE, "bf16x3": MATH_BF16X3, "bf16x6": MATH_BF16X6}
 

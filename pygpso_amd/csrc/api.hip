@@ -107,6 +107,7 @@ struct EngineT : Engine {
   // split-bf16 copy of L^-1 (float contexts with GPSO_OPT_PREDICT_MATH != native)
   DevBuf linv_b;
   int math = GPSO_MATH_NATIVE;
+  int64_t single_level_max = -1;  // < 0: library default
   bool linv_b_valid = false;
   std::vector<int64_t> segoff_cache;  // what the device copy of seg_off currently holds
   // predict workspace
@@ -137,6 +138,11 @@ struct EngineT : Engine {
   }
 
   int set_option(int option, int value) override {
+    if (option == GPSO_OPT_FIT_SINGLE_LEVEL_MAX) {
+      if (value < 0) return ctx->fail(GPSO_E_ARG, "single-level limit %d must be >= 0", value);
+      single_level_max = value;
+      return GPSO_OK;
+    }
     if (option != GPSO_OPT_PREDICT_MATH) return ctx->fail(GPSO_E_ARG, "unknown option %d", option);
     if (value != GPSO_MATH_NATIVE && value != GPSO_MATH_BF16X3 && value != GPSO_MATH_BF16X6)
       return ctx->fail(GPSO_E_ARG, "unknown predict math %d", value);
@@ -256,7 +262,7 @@ struct EngineT : Engine {
     int* info_dev = reinterpret_cast<int*>(as<double>(scal) + 1);
     HIPCHECK(hipMemcpyAsync(info_dev, &imax, sizeof(int), hipMemcpyHostToDevice, s));
     if (!launch_potrf<T>(s, as<T>(K), as<T>(Lf), as<T>(linv), as<T>(work), n, npad, as<double>(logdet),
-                         info_dev))
+                         info_dev, single_level_max))
       launch_trtri<T>(s, as<T>(Lf), as<T>(linv), as<T>(work), npad);
     launch_solve_alpha<T>(s, as<T>(linv), as<double>(y64), n, npad, mean_c, as<double>(logdet),
                           as<T>(white), as<T>(alpha), as<double>(gpart),

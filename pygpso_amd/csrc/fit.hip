@@ -1163,7 +1163,7 @@ __global__ __launch_bounds__(256) void inv_lastrow_kernel(T* __restrict__ linv, 
 // blocked Cholesky
 // =============================================================================================
 // Right-looking in 64-wide steps, one potrf_step_kernel launch per step (see above).
-//   npad <= kSingleLevelMax: every step updates the whole trailing matrix (rank 64); at these sizes
+//   npad <= kSingleLevelMax (or the GPSO_OPT_FIT_SINGLE_LEVEL_MAX option): every step updates the whole trailing matrix (rank 64); at these sizes
 //       the matrix lives in the L2 / Infinity Cache and a step's bulk work is shorter than the
 //       diagonal chain it hides behind.  The off-diagonal blocks of L^-1 ride along in the same
 //       launches (role PB + one last-row launch), so no separate triangular inverse follows.
@@ -1173,20 +1173,15 @@ __global__ __launch_bounds__(256) void inv_lastrow_kernel(T* __restrict__ linv, 
 //       streams the trailing matrix N/256 times instead of N/64 times.  Panel boundaries sit at
 //       192 + 256 p so that the SYRK region starts on a multiple of 128 (128x128 GEMM tiles).
 constexpr int kOuterPanel = 256;
-constexpr int64_t kSingleLevelMax = 4096;
-static int64_t single_level_max() {  // GPSO_SINGLE_LEVEL_MAX: tuning override
-  static const int64_t v = [] {
-    const char* e = std::getenv("GPSO_SINGLE_LEVEL_MAX");
-    return e ? (int64_t)std::atoll(e) : kSingleLevelMax;
-  }();
-  return v;
-}
+// measured crossovers: float 3072 (a tie there; at 3584 two-level is 15% faster), double 2048
+template <typename T>
+constexpr int64_t kSingleLevelMax = (sizeof(T) == 4) ? 3072 : 2048;
 
 template <typename T>
 bool launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, int64_t n, int64_t npad,
-                  double* diag64, int* info) {
+                  double* diag64, int* info, int64_t single_max) {
   const int ntile = (int)(npad / kFitBlock);
-  const bool single = npad <= single_level_max();
+  const bool single = npad <= (single_max >= 0 ? single_max : kSingleLevelMax<T>);
   static bool attr_set = false;  // per instantiation; the step kernel needs more than 64 KB of LDS
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_step_kernel<T>),
@@ -1238,8 +1233,8 @@ bool launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, int64_t n, int6
   }
   return single;  // true: linv already holds the complete inverse
 }
-template bool launch_potrf<float>(hipStream_t, float*, float*, float*, float*, int64_t, int64_t, double*, int*);
-template bool launch_potrf<double>(hipStream_t, double*, double*, double*, double*, int64_t, int64_t, double*, int*);
+template bool launch_potrf<float>(hipStream_t, float*, float*, float*, float*, int64_t, int64_t, double*, int*, int64_t);
+template bool launch_potrf<double>(hipStream_t, double*, double*, double*, double*, int64_t, int64_t, double*, int*, int64_t);
 
 // =============================================================================================
 // triangular inverse by level doubling

@@ -56,7 +56,7 @@ void launch_gram(hipStream_t st, const T* xs, const T* xnorm, int64_t n, int64_t
 // factorisation, using work as scratch) and launch_trtri must be skipped.
 template <typename T>
 bool launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, int64_t n, int64_t npad,
-                  double* diag64, int* info);
+                  double* diag64, int* info, int64_t single_level_max /* < 0: default */);
 // L^-1 by level-doubling: needs the diagonal-block inverses already in linv; work = npad x npad scratch
 template <typename T>
 void launch_trtri(hipStream_t st, const T* L, T* linv, T* work, int64_t npad);

@@ -62,6 +62,10 @@ class HipGPEngine:
     def set_predict_math(self, mode):
         self._check(self._lib.gpso_set_option(self._h, L.OPT_PREDICT_MATH, L.MATH_IDS[mode]))
 
+    def set_fit_single_level_max(self, npad_max):
+        """Tuning / test hook (GPSO_OPT_FIT_SINGLE_LEVEL_MAX): 0 forces the two-level Cholesky path."""
+        self._check(self._lib.gpso_set_option(self._h, L.OPT_FIT_SINGLE_LEVEL_MAX, int(npad_max)))
+
     def set_stream(self, stream_ptr):
         """Run on an existing hipStream_t (int pointer, e.g. torch.cuda.Stream().cuda_stream)."""
         self._check(self._lib.gpso_set_stream(self._h, C.c_void_p(stream_ptr or None)))

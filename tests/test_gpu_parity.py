@@ -206,6 +206,35 @@ def test_empty_batch_and_error_paths():
         eng.fit_eval("NoSuchKernel", [0.3], 1.0, 1e-3, 0.0)
 
 
+@pytest.mark.parametrize("dtype,n,d", [("float64", 700, 5), ("float64", 1100, 3), ("float32", 900, 6)])
+def test_two_level_cholesky_path_matches_oracle(dtype, n, d):
+    """Sizes above 4096 factorise two-level (outer rank-256 SYRK + look-ahead column) and invert L by
+    level doubling; GPSO_OPT_FIT_SINGLE_LEVEL_MAX = 0 forces that path at a size the oracle can check."""
+    from pygpso_amd import _lib as L
+
+    X, y, th = _problem(n, d, noise=1e-3 if dtype == "float64" else 1e-2)
+    post = gpr.posterior(th, X, y)
+    f_ref, g_ref = gpr.nlml_and_grad(th, X, y)
+    eng = _engine(dtype)
+    eng.set_fit_single_level_max(0)
+    f, g = _fit(eng, X, y, th)
+    Linv_ref = np.linalg.inv(post.L)
+    tol = 1e-9 if dtype == "float64" else 2e-4
+    assert _rel(eng.get_matrix(L.MAT_CHOL), post.L) < tol
+    assert _rel(eng.get_matrix(L.MAT_LINV), Linv_ref) < tol * 10
+    assert _rel(eng.get_matrix(L.MAT_KINV), Linv_ref.T @ Linv_ref) < tol * 10
+    assert abs(f - f_ref) <= (tol if dtype == "float64" else 2e-5) * abs(f_ref)
+    assert np.max(np.abs(g - g_ref) / np.maximum(1.0, np.abs(g_ref))) < tol * (10 if dtype == "float64" else 100)
+    # and the two paths agree with each other on predictions
+    Xs = synthetic_leaves(300, d)
+    m2, v2 = eng.predict(Xs)
+    eng1 = _engine(dtype)
+    _fit(eng1, X, y, th)
+    m1, v1 = eng1.predict(Xs)
+    ptol = 1e-9 if dtype == "float64" else 2e-3
+    assert np.max(np.abs(m1 - m2)) < ptol * max(1.0, np.max(np.abs(y))) and np.max(np.abs(v1 - v2)) < ptol
+
+
 def test_not_positive_definite_raises_linalgerror():
     # the reference lets TF's Cholesky failure escape run(); here: LinAlgError naming the pivot
     X = np.array([[0.1, 0.2], [0.1, 0.2], [0.4, 0.4], [0.7, 0.1]])

@@ -11,6 +11,8 @@ def drive(n, d, dtype, reps, grad):
     from tests.helpers import synthetic_problem
     X, y = synthetic_problem(n, d, seed=0)
     eng = HipGPEngine(dtype)
+    if os.environ.get("GPSO_FIT_SINGLE_MAX"):
+        eng.set_fit_single_level_max(int(os.environ["GPSO_FIT_SINGLE_MAX"]))
     eng.set_data(X, y)
     ls = np.array([0.25 * np.sqrt(d)])
     for _ in range(reps):

@@ -46,7 +46,7 @@ for case in range(N_CASES):
     ev = np.linalg.eigvalsh(Ky)
     cond = float(ev[-1] / max(ev[0], 1e-300))
     if dtype == "float64":
-        amp = max(1.0, cond * 2.2e-16 * 3e8)  # 1e-9 budget ~ cond 1.5e5
+        amp = max(1.0, cond * 2.2e-16 * 1e9)  # forward-error allowance 1.0 * cond * eps once that exceeds 1e-9
         base = 1e-5 if kernel == "Matern12" else 1e-9
         e_f, e_g, e_m, e_v = base * amp, 1e3 * base * amp, base * amp * ys, base * amp * th.variance
     else:
