@@ -1163,7 +1163,8 @@ __global__ __launch_bounds__(256) void inv_lastrow_kernel(T* __restrict__ linv, 
 // blocked Cholesky
 // =============================================================================================
 // Right-looking in 64-wide steps, one potrf_step_kernel launch per step (see above).
-//   npad <= kSingleLevelMax (or the GPSO_OPT_FIT_SINGLE_LEVEL_MAX option): every step updates the whole trailing matrix (rank 64); at these sizes
+//   npad <= kSingleLevelMax (or the GPSO_OPT_FIT_SINGLE_LEVEL_MAX option): every step updates the
+//       whole trailing matrix (rank 64); at these sizes
 //       the matrix lives in the L2 / Infinity Cache and a step's bulk work is shorter than the
 //       diagonal chain it hides behind.  The off-diagonal blocks of L^-1 ride along in the same
 //       launches (role PB + one last-row launch), so no separate triangular inverse follows.
