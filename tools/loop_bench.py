@@ -31,6 +31,12 @@ def main():
     from oracle import gpso_loop
     from pygpso_amd import GPSOptimiser, ParameterSpace
 
+    # first pass: includes the one-off costs (library + code-object load, context creation, allocations)
+    t0 = time.perf_counter()
+    space = ParameterSpace(parameter_names=[f"p{i}" for i in range(a.dim)], parameter_bounds=bounds)
+    GPSOptimiser(space, exploration_depth=a.depth, budget=a.budget).run(objective)
+    t_cold = time.perf_counter() - t0
+
     t0 = time.perf_counter()
     space = ParameterSpace(parameter_names=[f"p{i}" for i in range(a.dim)], parameter_bounds=bounds)
     opt = GPSOptimiser(space, exploration_depth=a.depth, budget=a.budget)
@@ -61,7 +67,7 @@ def main():
         "evaluations": opt.n_eval_counter, "iterations": opt.iterations,
         "gp_loss_evaluations": model.num_loss_evals,
         "leaf_predictions_cpu_run": st.n_leaf_predictions,
-        "hip_seconds": t_gpu, "hip_phase_seconds": phases,
+        "hip_seconds": t_gpu, "hip_seconds_first_run_in_process": t_cold, "hip_phase_seconds": phases,
         "cpu_oracle_seconds": t_cpu, "speedup": t_cpu / t_gpu,
         "same_evaluation_counts": [t[0] for t in opt.trace] == [t[0] for t in st.trace],
         "best_score_hip": best.score_mu, "best_score_cpu": best_ref["mu"],
