@@ -103,7 +103,7 @@ struct EngineT : Engine {
   std::vector<double> ls_host;
 
   // device buffers
-  DevBuf x64, y64, hyper, xs, xnorm, xs_p, K, Lf, linv, work, linv_p, white, alpha, logdet, scal, gpart;
+  DevBuf x64, y64, hyper, xs, xnorm, xs_p, K, Lf, linv, work, kinvb, linv_p, white, alpha, logdet, scal, gpart;
   // split-bf16 copy of L^-1 (float contexts with GPSO_OPT_PREDICT_MATH != native)
   DevBuf linv_b;
   int math = GPSO_MATH_NATIVE;
@@ -114,7 +114,7 @@ struct EngineT : Engine {
   DevBuf leaves_raw, leaves_s, lnorm, pvar, pmean, omean, ovar, oucb, segoff, best, oidx, ovals;
 
   ~EngineT() override {
-    for (DevBuf* b : {&x64, &y64, &hyper, &xs, &xnorm, &xs_p, &K, &Lf, &linv, &work, &linv_p, &white,
+    for (DevBuf* b : {&x64, &y64, &hyper, &xs, &xnorm, &xs_p, &K, &Lf, &linv, &work, &kinvb, &linv_p, &white,
                       &alpha, &logdet, &scal, &gpart, &leaves_raw, &leaves_s, &lnorm, &pvar, &pmean,
                       &omean, &ovar, &oucb, &segoff, &best, &oidx, &ovals, &linv_b})
       if (b->p) (void)hipFree(b->p);
@@ -261,15 +261,17 @@ struct EngineT : Engine {
     const int imax = INT_MAX;
     int* info_dev = reinterpret_cast<int*>(as<double>(scal) + 1);
     HIPCHECK(hipMemcpyAsync(info_dev, &imax, sizeof(int), hipMemcpyHostToDevice, s));
-    if (!launch_potrf<T>(s, as<T>(K), as<T>(Lf), as<T>(linv), as<T>(work), n, npad, as<double>(logdet),
-                         info_dev, single_level_max))
-      launch_trtri<T>(s, as<T>(Lf), as<T>(linv), as<T>(work), npad);
+    if (grad && (rc = ensure(kinvb, (size_t)npad * npad * sizeof(T)))) return rc;
+    const int done = launch_potrf<T>(s, as<T>(K), as<T>(Lf), as<T>(linv), as<T>(work),
+                                     grad ? as<T>(kinvb) : nullptr, n, npad, as<double>(logdet), info_dev,
+                                     single_level_max);
+    if (!(done & 1)) launch_trtri<T>(s, as<T>(Lf), as<T>(linv), as<T>(work), npad);
     launch_solve_alpha<T>(s, as<T>(linv), as<double>(y64), n, npad, mean_c, as<double>(logdet),
                           as<T>(white), as<T>(alpha), as<double>(gpart),
                           as<double>(scal));
     if (grad)
       launch_gradient<T>(s, as<T>(linv), as<T>(alpha), as<T>(xs), as<T>(xnorm), n, npad, d, dp, n_ls,
-                         ls_dev(), kp, as<T>(work), as<double>(gpart), as<double>(scal) + 8);
+                         ls_dev(), kp, as<T>(kinvb), (done & 2) != 0, as<double>(gpart), as<double>(scal) + 8);
     launch_pack_linv<T>(s, as<T>(linv), n, npad, as<T>(linv_p));
     if ((rc = pack_bf16())) return rc;
     HIPCHECK(hipGetLastError());
@@ -560,7 +562,7 @@ struct EngineT : Engine {
         break;
       case GPSO_MAT_KINV:
         if (!have_kinv) return ctx->fail(GPSO_E_STATE, "Kinv only exists after gpso_fit_eval with grad");
-        src = as<T>(work);
+        src = as<T>(kinvb);
         lower = 2;
         break;
       default:

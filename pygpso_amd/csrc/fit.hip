@@ -861,6 +861,33 @@ __device__ __forceinline__ void mma_abt(const T* A_rows, const T* B, int lane,
   }
 }
 
+// wave tile product with both operands stored [k][row] (row-major tiles of X read "down the
+// columns"): acc[tj][a][b] = sum_m A[m][a0 + a] * B[m][16 tj + b].  Fragments are 4-byte column
+// reads (stride kTL = 68 words: the four k groups of a wave land 16 banks apart, conflict-free).
+template <typename T>
+__device__ __forceinline__ void mma_atb(const T* A, int a0, const T* B, int lane,
+                                        typename Mfma<T>::vec4 (&acc)[4]) {
+  using M = Mfma<T>;
+  using vec4 = typename M::vec4;
+#pragma unroll
+  for (int tj = 0; tj < 4; ++tj) acc[tj] = vec4{0, 0, 0, 0};
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    T a[4], b[4][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int m = 16 * kk + 4 * (lane >> 4) + e;
+      a[e] = A[m * kTL + a0 + (lane & 15)];
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) b[tj][e] = B[m * kTL + 16 * tj + (lane & 15)];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) acc[tj] = M::mma(a[e], b[tj][e], acc[tj]);
+  }
+}
+
 // one 16x16 tile: acc = A_rows[16 x 64] * B_rows[16 x 64]^T
 template <typename T>
 __device__ __forceinline__ typename Mfma<T>::vec4 mma_abt_tile(const T* A_rows, const T* B_rows, int lane) {
@@ -917,6 +944,55 @@ __device__ __forceinline__ void lds_t_to_tile(const T* src, T* __restrict__ dst,
   }
 }
 
+// K^-1 = X^T X (X = L^-1) one row block of X at a time: tile (i, j), j <= i, gains
+// sum_{r in [max(r0, i), r1)} X[r,i]^T X[r,j].  The contribution of r = i is the tile's first, so it
+// overwrites; later ones accumulate.  All 256 threads; uses two T tiles of LDS.
+template <typename T>
+__device__ __forceinline__ void kinv_accum_tile(const T* __restrict__ linv, T* __restrict__ kinv,
+                                                int64_t ld, int i, int j, int r0, int r1,
+                                                unsigned char* lds, int tid, int lane, int wave) {
+  using M = Mfma<T>;
+  using vec4 = typename M::vec4;
+  T* TA = reinterpret_cast<T*>(lds);
+  T* TB = TA + kFitBlock * kTL;
+  const int64_t T64 = kFitBlock;
+  const int rb = max(r0, i);
+  if (rb >= r1) return;
+  vec4 sum[4];
+#pragma unroll
+  for (int tj = 0; tj < 4; ++tj) sum[tj] = vec4{0, 0, 0, 0};
+  for (int r = rb; r < r1; ++r) {
+    tile_to_lds<T>(linv + (r * T64) * ld + i * T64, ld, TA, tid);
+    if (i != j) tile_to_lds<T>(linv + (r * T64) * ld + j * T64, ld, TB, tid);
+    __syncthreads();
+    vec4 acc[4];
+    mma_atb<T>(TA, wave * 16, (i != j) ? TB : TA, lane, acc);
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) sum[tj] += acc[tj];
+    __syncthreads();
+  }
+  T* C = kinv + (i * T64) * ld + j * T64;
+#pragma unroll
+  for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      T* c = C + (int64_t)(wave * 16 + M::crow(lane, r)) * ld + 16 * tj + (lane & 15);
+      *c = (rb == i) ? sum[tj][r] : *c + sum[tj][r];
+    }
+}
+
+// row blocks [r0, ntile) of X into K^-1 (the ones no step launch could take: the last two)
+template <typename T>
+__global__ __launch_bounds__(256) void kinv_rows_kernel(const T* __restrict__ linv, T* __restrict__ kinv,
+                                                        int64_t ld, int r0, int ntile) {
+  extern __shared__ __align__(32) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = (int)blockIdx.x, i = (int)blockIdx.y;
+  if (j > i) return;
+  kinv_accum_tile<T>(linv, kinv, ld, i, j, r0, ntile, lds, tid, lane, wave);
+}
+
 // LDS carving of the step kernel.  role PU: three T tiles.  role D: Ls (f64) | { two T tiles, later
 // overlaid by Xs (f64) } | Ts.  float: 73 KB (2 workgroups per CU), double: 107 KB.
 template <typename T>
@@ -933,7 +1009,8 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
                                                          T* __restrict__ linv, int64_t ld, int k,
                                                          int jmax, int ntile, int64_t n,
                                                          double* __restrict__ diag64,
-                                                         int* __restrict__ info, T* __restrict__ W) {
+                                                         int* __restrict__ info, T* __restrict__ W,
+                                                         T* __restrict__ kinv) {
   using M = Mfma<T>;
   using vec4 = typename M::vec4;
   using Lay = StepLds<T>;
@@ -943,6 +1020,14 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t T64 = kFitBlock;
 
+  if (blockIdx.z == 2) {
+    // ---------------- role KI: row block k - 1 of X = L^-1 (complete since the previous launch) into
+    // K^-1 = X^T X, tile (i, j), j <= i <= k - 1
+    const int i = (int)blockIdx.x - 1, j = (int)blockIdx.y;
+    if (kinv == nullptr || blockIdx.x == 0 || k < 1 || i > k - 1 || j > i) return;
+    kinv_accum_tile<T>(linv, kinv, ld, i, j, k - 1, k, lds, tid, lane, wave);
+    return;
+  }
   if (blockIdx.z == 1) {
     // ---------------- role PB: tile (i, jp) of the inverse's right-hand side, jp <= k < i ----------
     // L X = I solved by the same elimination: B starts as the identity, step k finishes row block k,
@@ -1167,7 +1252,8 @@ __global__ __launch_bounds__(256) void inv_lastrow_kernel(T* __restrict__ linv, 
 //       whole trailing matrix (rank 64); at these sizes
 //       the matrix lives in the L2 / Infinity Cache and a step's bulk work is shorter than the
 //       diagonal chain it hides behind.  The off-diagonal blocks of L^-1 ride along in the same
-//       launches (role PB + one last-row launch), so no separate triangular inverse follows.
+//       launches (role PB + one last-row launch), so no separate triangular inverse follows; when
+//       the gradient is wanted K^-1 = L^-T L^-1 rides along as well (role KI + one tail launch).
 //   larger: two-level.  Steps update only the columns of the current outer panel plus ONE
 //       look-ahead tile column (so that the first diagonal block of the next panel never waits for
 //       the big update); everything right of that gets one rank-(panel) SYRK per outer panel, which
@@ -1179,8 +1265,8 @@ template <typename T>
 constexpr int64_t kSingleLevelMax = (sizeof(T) == 4) ? 3072 : 2048;
 
 template <typename T>
-bool launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, int64_t n, int64_t npad,
-                  double* diag64, int* info, int64_t single_max) {
+int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t n, int64_t npad,
+                 double* diag64, int* info, int64_t single_max) {
   const int ntile = (int)(npad / kFitBlock);
   const bool single = npad <= (single_max >= 0 ? single_max : kSingleLevelMax<T>);
   static bool attr_set = false;  // per instantiation; the step kernel needs more than 64 KB of LDS
@@ -1193,11 +1279,14 @@ bool launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, int64_t n, int6
   auto step = [&](int k, int jmax) {
     // grid.x = 1 (role D / idle) + rows below the diagonal of the tile column, grid.y = tile columns
     // with the inverse riding along (single level): blockIdx.z == 1 -> role PB, tile columns 0 .. k
-    const int ncol = (k < 0) ? 1 : std::max(single ? k + 1 : 1, jmax - k);
-    const int nrow = (k < 0) ? 0 : std::max(1, ntile - (k + 1));
+    // blockIdx.z == 2 -> role KI (K^-1 riding along when the gradient is wanted), tiles (i, j <= i < k)
+    const bool ki = single && kinv != nullptr && k >= 1;
+    const int ncol = (k < 0) ? 1 : std::max(std::max(single ? k + 1 : 1, jmax - k), ki ? k : 1);
+    const int nrow = (k < 0) ? 0 : std::max(std::max(1, ntile - (k + 1)), ki ? k : 1);
     hipLaunchKernelGGL((potrf_step_kernel<T>),
-                       dim3((unsigned)(1 + nrow), (unsigned)ncol, (single && k >= 0) ? 2u : 1u),
-                       dim3(256), lds_bytes, st, K, Lf, linv, npad, k, jmax, ntile, n, diag64, info, work);
+                       dim3((unsigned)(1 + nrow), (unsigned)ncol, !(single && k >= 0) ? 1u : ki ? 3u : 2u),
+                       dim3(256), lds_bytes, st, K, Lf, linv, npad, k, jmax, ntile, n, diag64, info, work,
+                       (single ? kinv : nullptr));
   };
   step(-1, -1);  // diagonal block 0
   int p_end = single ? ntile : std::min(ntile, (kOuterPanel - kFitBlock) / kFitBlock);  // tiles
@@ -1232,10 +1321,21 @@ bool launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, int64_t n, int6
     hipLaunchKernelGGL((inv_lastrow_kernel<T>), dim3((unsigned)(ntile - 1)), dim3(256),
                        2 * StepLds<T>::kTileBytes, st, linv, work, npad, ntile - 1);
   }
-  return single;  // true: linv already holds the complete inverse
+  if (single && kinv != nullptr) {
+    static bool attr3 = false;
+    if (!attr3) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kinv_rows_kernel<T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * StepLds<T>::kTileBytes);
+      attr3 = true;
+    }
+    hipLaunchKernelGGL((kinv_rows_kernel<T>), dim3((unsigned)ntile, (unsigned)ntile), dim3(256),
+                       2 * StepLds<T>::kTileBytes, st, linv, kinv, npad, std::max(0, ntile - 2), ntile);
+  }
+  // bit 0: linv already holds the complete inverse; bit 1: kinv already holds K^-1 (lower tiles)
+  return (single ? 1 : 0) | ((single && kinv != nullptr) ? 2 : 0);
 }
-template bool launch_potrf<float>(hipStream_t, float*, float*, float*, float*, int64_t, int64_t, double*, int*, int64_t);
-template bool launch_potrf<double>(hipStream_t, double*, double*, double*, double*, int64_t, int64_t, double*, int*, int64_t);
+template int launch_potrf<float>(hipStream_t, float*, float*, float*, float*, float*, int64_t, int64_t, double*, int*, int64_t);
+template int launch_potrf<double>(hipStream_t, double*, double*, double*, double*, double*, int64_t, int64_t, double*, int*, int64_t);
 
 // =============================================================================================
 // triangular inverse by level doubling
@@ -1522,16 +1622,18 @@ __global__ __launch_bounds__(256) void grad_final_kernel(const double* __restric
 template <typename T>
 void launch_gradient(hipStream_t st, const T* linv, const T* alpha, const T* xs, const T* xnorm,
                      int64_t n, int64_t npad, int d, int dp, int n_ls, const double* ls,
-                     const KernParams& kp, T* kinv, double* partial, double* grad_out) {
+                     const KernParams& kp, T* kinv, bool kinv_ready, double* partial, double* grad_out) {
   (void)d;
-  // Kinv = Linv^T Linv, lower tiles:  opA(i,k) = Linv[k][i],  opB(k,j) = Linv[k][j],  k >= 64 ti
-  GemmDesc g{};
-  g.A = linv; g.sai = 1; g.sak = npad;
-  g.B = linv; g.sbk = npad; g.sbj = 1;
-  g.C = kinv; g.ldc = npad;
-  g.m = (int)npad; g.n = (int)npad; g.k = (int)npad; g.m_last = (int)npad; g.nbatch = 1;
-  g.alpha = 1.0; g.beta = 0.0; g.lower_only = 1; g.kmode = 2;
-  launch_gemm<T>(st, g);
+  if (!kinv_ready) {
+    // Kinv = Linv^T Linv, lower tiles:  opA(i,k) = Linv[k][i],  opB(k,j) = Linv[k][j],  k >= 64 ti
+    GemmDesc g{};
+    g.A = linv; g.sai = 1; g.sak = npad;
+    g.B = linv; g.sbk = npad; g.sbj = 1;
+    g.C = kinv; g.ldc = npad;
+    g.m = (int)npad; g.n = (int)npad; g.k = (int)npad; g.m_last = (int)npad; g.nbatch = 1;
+    g.alpha = 1.0; g.beta = 0.0; g.lower_only = 1; g.kmode = 2;
+    launch_gemm<T>(st, g);
+  }
   const int nt = (int)(npad / 64);
   const size_t lds = (size_t)2 * 64 * dp * sizeof(T);
   hipLaunchKernelGGL((grad_tile_kernel<T>), dim3((unsigned)nt, (unsigned)nt), dim3(256), lds, st,
@@ -1539,8 +1641,8 @@ void launch_gradient(hipStream_t st, const T* linv, const T* alpha, const T* xs,
   hipLaunchKernelGGL((grad_final_kernel<T>), dim3(1), dim3(256), 0, st, partial,
                      (int64_t)nt * nt, n_ls, alpha, n, grad_out);
 }
-template void launch_gradient<float>(hipStream_t, const float*, const float*, const float*, const float*, int64_t, int64_t, int, int, int, const double*, const KernParams&, float*, double*, double*);
-template void launch_gradient<double>(hipStream_t, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int, int, const double*, const KernParams&, double*, double*, double*);
+template void launch_gradient<float>(hipStream_t, const float*, const float*, const float*, const float*, int64_t, int64_t, int, int, int, const double*, const KernParams&, float*, bool, double*, double*);
+template void launch_gradient<double>(hipStream_t, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int, int, const double*, const KernParams&, double*, bool, double*, double*);
 
 // =============================================================================================
 // conversions / interop

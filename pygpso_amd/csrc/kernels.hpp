@@ -52,11 +52,12 @@ void launch_gram(hipStream_t st, const T* xs, const T* xnorm, int64_t n, int64_t
 // blocked right-looking Cholesky, K (destroyed) -> Lf (lower); also writes the inverted 64x64 diagonal
 // blocks into linv, the unrounded diagonal of L to diag64[npad], and the first failing pivot (or
 // INT_MAX) to info
-// Returns true when linv already holds the COMPLETE inverse (small sizes: it is built beside the
-// factorisation, using work as scratch) and launch_trtri must be skipped.
+// Returns bit flags.  Bit 0: linv already holds the COMPLETE inverse (small sizes: it is built beside
+// the factorisation, using work as scratch) and launch_trtri must be skipped.  Bit 1: kinv (nullable:
+// only wanted with the gradient) already holds K^-1 = L^-T L^-1 (lower tiles).
 template <typename T>
-bool launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, int64_t n, int64_t npad,
-                  double* diag64, int* info, int64_t single_level_max /* < 0: default */);
+int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t n, int64_t npad,
+                 double* diag64, int* info, int64_t single_level_max /* < 0: default */);
 // L^-1 by level-doubling: needs the diagonal-block inverses already in linv; work = npad x npad scratch
 template <typename T>
 void launch_trtri(hipStream_t st, const T* L, T* linv, T* work, int64_t npad);
@@ -68,12 +69,12 @@ template <typename T>
 void launch_solve_alpha(hipStream_t st, const T* linv, const double* y64, int64_t n, int64_t npad,
                         double mean_c, const double* diag64, T* white, T* alpha,
                         double* alpha_part /* [ceil(npad/256) * npad] scratch */, double* nlml_out);
-// Kinv = L^-T L^-1 (lower tiles, mirrored), then the gradient reductions of SURVEY.md A.3;
+// Kinv = L^-T L^-1 (lower tiles; skipped when kinv_ready), then the gradient reductions of SURVEY.md A.3;
 // grad_out[n_ls + 3] = d nlml / d (ls..., variance, noise, c)
 template <typename T>
 void launch_gradient(hipStream_t st, const T* linv, const T* alpha, const T* xs, const T* xnorm,
                      int64_t n, int64_t npad, int d, int dp, int n_ls, const double* ls,
-                     const KernParams& kp, T* kinv, double* partial, double* grad_out);
+                     const KernParams& kp, T* kinv, bool kinv_ready, double* partial, double* grad_out);
 constexpr int kGradMaxLs = 64;
 
 // float64 host -> T device conversions and getters
