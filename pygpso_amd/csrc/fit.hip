@@ -1041,6 +1041,13 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
     T* TW = TI + kFitBlock * kTL;
     T* TX = TW + kFitBlock * kTL;
     const T* Xkk = linv + (k * T64) * ld + k * T64;
+    // this lane's entries of the tile it will update, in flight from the start
+    T* Cw = W + (jp * T64) * ld + i * T64 + (int64_t)(wave * 16) * ld + (lane & 15);
+    T c_old[4][4];
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c_old[tj][r] = (jp < k) ? Cw[(int64_t)M::crow(lane, r) * ld + 16 * tj] : (T)0;
     tile_to_lds<T>(K + (i * T64) * ld + k * T64, ld, TI, tid);
     tile_to_lds<T>(Xkk, ld, TX, tid);
     if (jp < k) tile_to_lds<T>(W + (jp * T64) * ld + k * T64, ld, TW, tid);
@@ -1064,14 +1071,10 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
     __syncthreads();
     if (i == k + 1 && jp < k) lds_t_to_tile<T>(TW, linv + (k * T64) * ld + jp * T64, ld, tid);
     mma_abt<T, false>(TW + wave * 16 * kTL, TI, lane, acc);
-    T* C = W + (jp * T64) * ld + i * T64;
 #pragma unroll
     for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        T* c = C + (int64_t)(wave * 16 + M::crow(lane, r)) * ld + 16 * tj + (lane & 15);
-        *c = (jp < k) ? *c - acc[tj][r] : -acc[tj][r];
-      }
+      for (int r = 0; r < 4; ++r) Cw[(int64_t)M::crow(lane, r) * ld + 16 * tj] = c_old[tj][r] - acc[tj][r];
     return;
   }
   if (blockIdx.x == 0 && blockIdx.y == 0) {
@@ -1177,6 +1180,15 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
   T* TI = reinterpret_cast<T*>(lds);
   T* TJ = TI + kFitBlock * kTL;
   T* TX = TJ + kFitBlock * kTL;
+  // this lane's entries of the tile it will update, in flight from the start
+  T* Cu = K + (i * T64) * ld + j * T64 + (int64_t)(wave * 16) * ld + (lane & 15);
+  T c_old[4][4];
+  if (!(diag_next && j == k + 1)) {
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c_old[tj][r] = Cu[(int64_t)M::crow(lane, r) * ld + 16 * tj];
+  }
   tile_to_lds<T>(K + (i * T64) * ld + k * T64, ld, TI, tid);
   if (i != j) tile_to_lds<T>(K + (j * T64) * ld + k * T64, ld, TJ, tid);
   tile_to_lds<T>(linv + (k * T64) * ld + k * T64, ld, TX, tid);
@@ -1206,14 +1218,10 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
   }
   __syncthreads();
   mma_abt<T, false>(TI + wave * 16 * kTL, (i != j) ? TJ : TI, lane, acc);
-  T* C = K + (i * T64) * ld + j * T64;
 #pragma unroll
   for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      T* c = C + (int64_t)(wave * 16 + M::crow(lane, r)) * ld + 16 * tj + (lane & 15);
-      *c -= acc[tj][r];
-    }
+    for (int r = 0; r < 4; ++r) Cu[(int64_t)M::crow(lane, r) * ld + 16 * tj] = c_old[tj][r] - acc[tj][r];
 }
 
 // last row block of the inverse (no rows below it, so no step launch finished it):
