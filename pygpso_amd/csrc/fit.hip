@@ -440,7 +440,7 @@ struct GemmDesc {
   int m_last;                      // rows of the LAST batch entry (multiple of 64, <= m)
   int nbatch;
   double alpha, beta;
-  int lower_only;  // skip tiles strictly above the diagonal (tj > ti)
+  int lower_only;  // only tiles with tj <= ti (needs m == n)
   int kmode;       // 0: all k | 1: k >= 64 tj | 2: k >= 64 ti | 3: k < 64 (ti + 1)
 };
 
@@ -570,10 +570,10 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmDesc g) {
 //   row (lane % 16) of a 16-row block; MFMA step e takes element e on both operands (the k order
 //   inside a block is a permutation shared by A and B).
 //   k-contiguous operand (KC): one 16-byte DMA per lane brings its own fragment (float; two for
-//   double): LDS [row block][slab][lane] x 16 B.
-//   row-contiguous operand (RC: consecutive rows adjacent in memory, k strided): a DMA instruction
-//   is tied to one e; a lane brings 4 (double: 2) consecutive rows at k = 4 g + e, and the lane
-//   order (row block, g, row quad) makes the LDS image [e][row block][lane] words.
+//   double): LDS [tile][slab][lane] x 16 B.
+//   row-contiguous operand (RC: consecutive rows adjacent in memory, k strided): a lane brings 4
+//   (double: 2) consecutive rows at one k; the LDS image is [k][strip rows] and, the tiles of a strip
+//   being interleaved, one 16-byte LDS read yields the same k for all four tiles.
 //   Per operand and k-block: float 8 DMA instructions / 8 KB, double 16 / 16 KB.  A k-step is two
 //   k-blocks for float and one for double: 16 DMA instructions and 16 KB per operand either way,
 //   64 KB of LDS for the two buffers of both operands (2 workgroups per CU).
@@ -587,66 +587,77 @@ __device__ __forceinline__ void gemm_glds16(const void* gsrc_lane, void* lds_wav
 template <typename T, int TS>
 struct G128 {
   static constexpr int kSlabs = sizeof(T) / 4;              // 16-byte DMAs per KC fragment
-  static constexpr int kBlocksPerStep = (sizeof(T) == 4) ? 2 : 1;
+  // k-blocks per step / ring depth: a step must be short enough for 4 buffers to fit 64 KB (the DMA then
+  // runs 3 steps ahead); only the 128-tile double kernel (32 KB per 16-k step) stays at 2 buffers
+  static constexpr int kBlocksPerStep = (sizeof(T) == 4 && TS == 64) ? 2 : 1;
   static constexpr int kStepK = 16 * kBlocksPerStep;
-  static constexpr int kRb = TS / 16;                        // 16-row blocks of an operand
-  static constexpr int kBlockBytes = TS * 16 * (int)sizeof(T);  // one operand, one k-block
+  static constexpr int kWE = TS / 2;                         // rows of a wave strip (2 x 2 waves)
+  static constexpr int kWT = kWE / 16;                       // MFMA tiles per strip
+  static constexpr int kStripBytes = kWE * 16 * (int)sizeof(T);  // one strip, one k-block
+  static constexpr int kBlockBytes = 2 * kStripBytes;        // one operand, one k-block
   static constexpr int kOperandBytes = kBlockBytes * kBlocksPerStep;
   static constexpr int kBufBytes = 2 * kOperandBytes;        // A + B of one step
-  static constexpr int kInstrPerBlock = kRb * kSlabs;
+  static constexpr int kInstrPerStrip = kWT * kSlabs;        // DMAs per strip and k-block (KC and RC alike)
+  static constexpr int kInstrPerBlock = 2 * kInstrPerStrip;
   static constexpr int kInstrPerStep = kInstrPerBlock * kBlocksPerStep;  // per operand: 16 | 8
-  static constexpr int kRowsPerLaneRC = 16 / (int)sizeof(T);           // 4 | 2
-  static constexpr int kRbPerInstrRC = kRowsPerLaneRC;                 // row blocks covered by one RC DMA
-  static constexpr int kWT = TS / 32;                        // MFMA tiles per side of a wave tile
-  static constexpr int kNbuf = (TS == 128) ? 2 : 4;          // LDS ring depth (64 KB either way)
+  static constexpr int kNbuf = (sizeof(T) == 8 && TS == 128) ? 2 : 4;  // LDS ring depth
 };
 
-// global element offset (row-stride s_row, k-stride s_k; one of them is 1) this lane's DMA number
-// `ins` of a k-block starts at, and the LDS byte offset (inside the operand's k-block image) of the
-// wave-wide destination
+// Rows (A) / columns (B) of a wave strip are dealt to its kWT MFMA tiles INTERLEAVED: tile x, lane
+// index i  <->  strip element kWT * i + x.  A lane then owns kWT consecutive columns of C (16-byte
+// accesses to C instead of 4-byte ones) and a row-contiguous operand can be read kWT tiles at a time.
+//
+// DMA number `ins` of a k-block: element offsets (row, k) this lane fetches 16 bytes from, and the LDS
+// byte offset (inside the operand's k-block image) of the wave-wide destination.
+//   KC: [tile x][slab][lane] x 16 B -- the lane's own fragment (k = 4 (lane/16) + e).
+//   RC: [k (16)][strip rows] elements; a lane brings 16 bytes = consecutive rows at one k, lanes ordered
+//       (k, row group) so the image is linear in the lane id.
 template <typename T, int TS, bool KC>
 __device__ __forceinline__ void g128_dma_coords(int ins, int lane, int& row, int& k, int& lds_off) {
   using G = G128<T, TS>;
+  const int s = ins / G::kInstrPerStrip, n = ins % G::kInstrPerStrip;
   if (KC) {
-    const int rb = ins / G::kSlabs, slab = ins % G::kSlabs;
-    row = rb * 16 + (lane & 15);
+    const int x = n / G::kSlabs, slab = n % G::kSlabs;
+    row = s * G::kWE + G::kWT * (lane & 15) + x;
     k = 4 * (lane >> 4) + slab * (4 / G::kSlabs);
-    lds_off = (rb * G::kSlabs + slab) * 1024;
   } else {
-    constexpr int RPL = G::kRowsPerLaneRC;       // rows per lane
-    constexpr int QN = 16 / RPL;                 // lanes per 16 rows
-    constexpr int NH = G::kRb / G::kRbPerInstrRC;  // DMAs per e
-    const int e = ins / NH, h = ins % NH;
-    const int q = lane % QN, g = (lane / QN) & 3, rbq = lane / (4 * QN);
-    row = (h * G::kRbPerInstrRC + rbq) * 16 + RPL * q;
-    k = 4 * g + e;
-    lds_off = (e * NH + h) * 1024;
+    constexpr int RPL = 16 / (int)sizeof(T);  // rows per lane
+    constexpr int LPK = G::kWE / RPL;         // lanes per k
+    constexpr int KPI = 64 / LPK;             // k values per DMA instruction
+    row = s * G::kWE + RPL * (lane % LPK);
+    k = n * KPI + lane / LPK;
   }
+  lds_off = s * G::kStripBytes + n * 1024;
 }
 
-// fragment (4 k values) of row block rb for this lane out of an operand's k-block image
+// fragments f[x][e] (tile x of strip s, MFMA step e: k = 4 (lane/16) + e) of this lane
 template <typename T, int TS, bool KC>
-__device__ __forceinline__ typename Mfma<T>::vec4 g128_frag(const unsigned char* blk, int rb, int lane) {
+__device__ __forceinline__ void g128_frags(const unsigned char* blk, int s, int lane,
+                                           typename Mfma<T>::vec4 (&f)[G128<T, TS>::kWT]) {
   using G = G128<T, TS>;
   using vec4 = typename Mfma<T>::vec4;
+  const unsigned char* st = blk + s * G::kStripBytes;
   if constexpr (KC) {
-    if constexpr (sizeof(T) == 4) {
-      return *reinterpret_cast<const vec4*>(blk + rb * 1024 + lane * 16);
-    } else {
-      typedef double f64x2 __attribute__((ext_vector_type(2)));
-      const f64x2 lo = *reinterpret_cast<const f64x2*>(blk + rb * 2048 + lane * 16);
-      const f64x2 hi = *reinterpret_cast<const f64x2*>(blk + rb * 2048 + 1024 + lane * 16);
-      return vec4{lo[0], lo[1], hi[0], hi[1]};
+#pragma unroll
+    for (int x = 0; x < G::kWT; ++x) {
+      if constexpr (sizeof(T) == 4) {
+        f[x] = *reinterpret_cast<const vec4*>(st + x * 1024 + lane * 16);
+      } else {
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        const f64x2 lo = *reinterpret_cast<const f64x2*>(st + x * 2048 + lane * 16);
+        const f64x2 hi = *reinterpret_cast<const f64x2*>(st + x * 2048 + 1024 + lane * 16);
+        f[x] = vec4{lo[0], lo[1], hi[0], hi[1]};
+      }
     }
   } else {
-    constexpr int NH = G::kRb / G::kRbPerInstrRC;
-    const int h = rb / G::kRbPerInstrRC, rbq = rb % G::kRbPerInstrRC;
-    vec4 v;
+    typedef T vecW __attribute__((ext_vector_type(G::kWT)));
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      v[e] = *reinterpret_cast<const T*>(blk + (e * NH + h) * 1024 + rbq * (1024 / G::kRbPerInstrRC) +
-                                         lane * (int)sizeof(T));
-    return v;
+    for (int e = 0; e < 4; ++e) {
+      const vecW v = *reinterpret_cast<const vecW*>(
+          st + ((4 * (lane >> 4) + e) * G::kWE + G::kWT * (lane & 15)) * (int)sizeof(T));
+#pragma unroll
+      for (int x = 0; x < G::kWT; ++x) f[x][e] = v[x];
+    }
   }
 }
 
@@ -659,13 +670,40 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmDesc g) {
   using M = Mfma<T>;
   using vec4 = typename M::vec4;
   using G = G128<T, TS>;
-  constexpr int WT = G::kWT, WE = TS / 2;  // wave tile: WT x WT MFMA tiles, WE rows / columns
+  constexpr int WT = G::kWT, WE = G::kWE;  // wave tile: WT x WT MFMA tiles, WE rows / columns
   constexpr int NBUF = G::kNbuf;
+  typedef T vecW __attribute__((ext_vector_type(WT)));
   extern __shared__ __align__(32) unsigned char lds[];  // [NBUF buffers][A | B][k-block] images
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ti = blockIdx.y, tj = blockIdx.x, bz = blockIdx.z;
-  if (g.lower_only && tj > ti) return;
+  // Tile of this workgroup.  The grid is 1-D over the ACTIVE tiles only and ordered so that (a) the
+  // hardware's round-robin of consecutive workgroups over the 8 XCDs deals every XCD the same amount
+  // of work -- tiles of equal k-length are neighbours -- and (b) the longest tiles start first:
+  //   lower_only      compact triangular enumeration, row-major (k-length depends on the row only)
+  //   kmode 1         column-major (k-length depends on tj)
+  //   kmode 3         row-major, last row first (k-length grows with ti)
+  //   otherwise       row-major
+  // (A 2-D grid whose upper-triangle workgroups exit at once ran the K^-1 product at 78 TFLOP/s
+  // against 141 for a full square: XCD 0 got up to 35 % more work than XCD 7.)
+  const int bz = blockIdx.z;
+  const int nti = g.m / TS, ntj = g.n / TS;
+  int ti, tj;
+  {
+    const int id = (int)blockIdx.x;
+    if (g.lower_only) {
+      ti = (int)((__builtin_sqrtf(8.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
+      while ((ti + 1) * (ti + 2) / 2 <= id) ++ti;
+      while (ti * (ti + 1) / 2 > id) --ti;
+      tj = id - ti * (ti + 1) / 2;
+    } else if (g.kmode == 1) {
+      tj = id / nti;
+      ti = id % nti;
+    } else {
+      ti = id / ntj;
+      tj = id % ntj;
+      if (g.kmode == 3) ti = nti - 1 - ti;
+    }
+  }
   const int m_here = (bz == g.nbatch - 1) ? g.m_last : g.m;
   if (ti * TS >= m_here) return;
   const T* A = static_cast<const T*>(g.A) + (int64_t)bz * g.batchA;
@@ -710,15 +748,19 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmDesc g) {
 #pragma unroll
   for (int d = 0; d < NBUF - 1; ++d)
     if (k_lo + d * G::kStepK < k_hi) issue(d);
+  // C element of (tile a, tile b, register r): row c_row(a, r), columns c_col .. c_col + WT - 1 (b)
+  T* c_base = C + (int64_t)(ti * TS + wr * WE) * g.ldc + tj * TS + wc * WE + WT * (lane & 15);
+  auto c_ptr = [&](int a, int r) { return c_base + (int64_t)(WT * M::crow(lane, r) + a) * g.ldc; };
   if (g.beta != 0.0) {  // all loads of the C tile in flight together, beside the first DMAs
     const T scale = (T)(g.beta / g.alpha);
-    const T* c0 = C + (int64_t)(ti * TS + wr * WE) * g.ldc + tj * TS + wc * WE + (lane & 15);
 #pragma unroll
     for (int a = 0; a < WT; ++a)
 #pragma unroll
-      for (int b = 0; b < WT; ++b)
+      for (int r = 0; r < 4; ++r) {
+        const vecW v = *reinterpret_cast<const vecW*>(c_ptr(a, r));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[a][b][r] = c0[(int64_t)(a * 16 + M::crow(lane, r)) * g.ldc + b * 16];
+        for (int b = 0; b < WT; ++b) acc[a][b][r] = v[b];
+      }
 #pragma unroll
     for (int a = 0; a < WT; ++a)
 #pragma unroll
@@ -749,11 +791,8 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmDesc g) {
 #pragma unroll
     for (int kb = 0; kb < G::kBlocksPerStep; ++kb) {
       vec4 a4[WT], b4[WT];
-#pragma unroll
-      for (int x = 0; x < WT; ++x) {
-        a4[x] = g128_frag<T, TS, A_KC>(cur + kb * G::kBlockBytes, wr * WT + x, lane);
-        b4[x] = g128_frag<T, TS, B_KC>(cur + G::kOperandBytes + kb * G::kBlockBytes, wc * WT + x, lane);
-      }
+      g128_frags<T, TS, A_KC>(cur + kb * G::kBlockBytes, wr, lane, a4);
+      g128_frags<T, TS, B_KC>(cur + G::kOperandBytes + kb * G::kBlockBytes, wc, lane, b4);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -767,13 +806,12 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmDesc g) {
 #pragma unroll
   for (int a = 0; a < WT; ++a)
 #pragma unroll
-    for (int b = 0; b < WT; ++b)
+    for (int r = 0; r < 4; ++r) {
+      vecW v;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t i = ti * TS + wr * WE + a * 16 + M::crow(lane, r);
-        const int64_t j = tj * TS + wc * WE + b * 16 + (lane & 15);
-        C[i * g.ldc + j] = alpha * acc[a][b][r];
-      }
+      for (int b = 0; b < WT; ++b) v[b] = alpha * acc[a][b][r];
+      *reinterpret_cast<vecW*>(c_ptr(a, r)) = v;
+    }
 }
 
 template <typename T, int TS, bool A_KC, bool B_KC>
@@ -785,7 +823,9 @@ static void launch_gemm128(hipStream_t st, const GemmDesc& g) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     attr_set = true;
   }
-  const dim3 grid((unsigned)(g.n / TS), (unsigned)(g.m / TS), (unsigned)g.nbatch);
+  const int64_t nti = g.m / TS, ntj = g.n / TS;
+  const int64_t ntiles = g.lower_only ? nti * (nti + 1) / 2 : nti * ntj;  // lower_only: m == n
+  const dim3 grid((unsigned)ntiles, 1, (unsigned)g.nbatch);
   hipLaunchKernelGGL((gemm128_kernel<T, TS, A_KC, B_KC>), grid, dim3(256), kLds, st, g);
 }
 
@@ -801,7 +841,8 @@ template <typename T>
 static void launch_gemm(hipStream_t st, const GemmDesc& g) {
   if (g.m <= 0 || g.n <= 0 || g.nbatch <= 0) return;
   const bool a_kc = (g.sak == 1), a_rc = (g.sai == 1), b_kc = (g.sbk == 1), b_rc = (g.sbj == 1);
-  const bool dma_ok = (a_kc || a_rc) && (b_kc || b_rc) && g.alpha != 0.0 && g.k % 64 == 0;
+  const bool dma_ok = (a_kc || a_rc) && (b_kc || b_rc) && g.alpha != 0.0 && g.k % 64 == 0 &&
+                      (!g.lower_only || g.m == g.n);
   // 128 x 128 tiles when every extent allows it and they still give every CU about two tiles
   // (lower_only launches compute only half of the grid); 64 x 64 tiles otherwise
   const bool div128 = (g.m % 128 == 0) && (g.n % 128 == 0) && (g.m_last % 128 == 0) && (g.k % 128 == 0);
