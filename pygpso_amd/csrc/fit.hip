@@ -1571,14 +1571,14 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(const T* __restrict__ ki
   T* xi = reinterpret_cast<T*>(lds_raw);  // [64][dp]
   T* xj = xi + 64 * dp;                   // [64][dp]
   __shared__ double red[4];
-  const int ti = blockIdx.y, tj = blockIdx.x;
-  const int nt = gridDim.x;
-  const int64_t blk = (int64_t)ti * nt + tj;
+  // 1-D grid over the lower tiles only (a 2-D grid with the upper half exiting at once leaves the 8
+  // XCDs unevenly loaded): blk -> (ti, tj <= ti), row-major
+  const int64_t blk = blockIdx.x;
+  int ti = (int)((__builtin_sqrtf(8.0f * (float)blk + 1.0f) - 1.0f) * 0.5f);
+  while ((int64_t)(ti + 1) * (ti + 2) / 2 <= blk) ++ti;
+  while ((int64_t)ti * (ti + 1) / 2 > blk) --ti;
+  const int tj = (int)(blk - (int64_t)ti * (ti + 1) / 2);
   const int H = n_ls + 2;
-  if (tj > ti) {
-    if ((int)threadIdx.x < H) partial[blk * H + threadIdx.x] = 0.0;
-    return;
-  }
   for (int e = threadIdx.x; e < 64 * dp; e += 256) {
     xi[e] = xs[(int64_t)ti * 64 * dp + e];
     xj[e] = xs[(int64_t)tj * 64 * dp + e];
@@ -1685,10 +1685,11 @@ void launch_gradient(hipStream_t st, const T* linv, const T* alpha, const T* xs,
   }
   const int nt = (int)(npad / 64);
   const size_t lds = (size_t)2 * 64 * dp * sizeof(T);
-  hipLaunchKernelGGL((grad_tile_kernel<T>), dim3((unsigned)nt, (unsigned)nt), dim3(256), lds, st,
+  const int64_t nblk = (int64_t)nt * (nt + 1) / 2;
+  hipLaunchKernelGGL((grad_tile_kernel<T>), dim3((unsigned)nblk), dim3(256), lds, st,
                      kinv, alpha, xs, xnorm, n, npad, dp, n_ls, ls, kp.kernel, kp.variance, partial);
-  hipLaunchKernelGGL((grad_final_kernel<T>), dim3(1), dim3(256), 0, st, partial,
-                     (int64_t)nt * nt, n_ls, alpha, n, grad_out);
+  hipLaunchKernelGGL((grad_final_kernel<T>), dim3(1), dim3(256), 0, st, partial, nblk, n_ls, alpha, n,
+                     grad_out);
 }
 template void launch_gradient<float>(hipStream_t, const float*, const float*, const float*, const float*, int64_t, int64_t, int, int, int, const double*, const KernParams&, float*, bool, double*, double*);
 template void launch_gradient<double>(hipStream_t, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int, int, const double*, const KernParams&, double*, bool, double*, double*);

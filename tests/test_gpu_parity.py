@@ -235,6 +235,31 @@ def test_two_level_cholesky_path_matches_oracle(dtype, n, d):
     assert np.max(np.abs(m1 - m2)) < ptol * max(1.0, np.max(np.abs(y))) and np.max(np.abs(v1 - v2)) < ptol
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_fit_and_gradient_at_4600_points(dtype):
+    """N = 4600 is past the single-level limit and large enough for the 128x128-tile instantiations of
+    the LDS-DMA GEMM (rank-256 SYRK, K^-1 = L^-T L^-1) in both element types: NLML, gradient and a few
+    predictions against the float64 oracle."""
+    n, d = 4600, 8
+    X, y, th = _problem(n, d, noise=1e-3 if dtype == "float64" else 1e-2)
+    f_ref, g_ref = gpr.nlml_and_grad(th, X, y)
+    post = gpr.posterior(th, X, y)
+    eng = _engine(dtype)
+    f, g = _fit(eng, X, y, th)
+    Xs = synthetic_leaves(500, d)
+    mean, var = eng.predict(Xs)
+    mean_ref, var_ref = gpr.predict_y(post, Xs)
+    if dtype == "float64":
+        assert abs(f - f_ref) <= 1e-9 * abs(f_ref)
+        assert np.max(np.abs(g - g_ref) / np.maximum(1.0, np.abs(g_ref))) < 1e-7
+        assert np.max(np.abs(mean - mean_ref)) < 1e-8 and np.max(np.abs(var - var_ref)) < 1e-8
+    else:
+        assert abs(f - f_ref) <= 5e-5 * abs(f_ref)
+        assert np.max(np.abs(g - g_ref) / np.maximum(1.0, np.abs(g_ref))) < 5e-2
+        assert np.max(np.abs(mean - mean_ref)) < 3e-3 * np.max(np.abs(y))
+        assert np.max(np.abs(var - var_ref)) < 3e-4 * th.variance
+
+
 def test_not_positive_definite_raises_linalgerror():
     # the reference lets TF's Cholesky failure escape run(); here: LinAlgError naming the pivot
     X = np.array([[0.1, 0.2], [0.1, 0.2], [0.4, 0.4], [0.7, 0.1]])
