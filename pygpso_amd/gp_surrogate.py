@@ -61,12 +61,18 @@ class GPListOfPoints(list):
     list.  ``append`` additionally RETURNS the index the point now lives at (first duplicate, or
     the new last position)."""
 
+    # bucket width of the index on the first coordinate: any two points closer than the duplicate
+    # tolerance (1e-12, L2) differ by at most that in coordinate 0, so a duplicate of x can only sit
+    # in the bucket of x[0] or one of its two neighbours
+    _BUCKET = 1.0e-6
+
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         assert all(isinstance(p, GPPoint) for p in self)
         self._coords = None
         self._n = 0
         self._dirty = True
+        self._buckets = {}
 
     # -- coordinate matrix kept in sync -----------------------------------------------------------
     def _matrix(self):
@@ -82,20 +88,41 @@ class GPListOfPoints(list):
                 self._coords = None
             self._n = n
             self._dirty = False
+            self._buckets = {}
+            for i in range(n):
+                self._buckets.setdefault(self._bucket_of(self._coords[i, 0]), []).append(i)
         return None if self._coords is None else self._coords[: self._n]
 
+    @classmethod
+    def _bucket_of(cls, c0):
+        return int(np.floor(float(c0) / cls._BUCKET))
+
     def _matches(self, coords):
+        """Indices (ascending) of the stored points within the duplicate tolerance of ``coords`` --
+        the reference's linear scan (gpso/gp_surrogate.py:68-101), answered from a hash on the first
+        coordinate: candidates come from three buckets, the exact distance test decides."""
         mat = self._matrix()
         if mat is None:
             return np.empty(0, dtype=np.int64)
-        diff = mat - np.asarray(coords, dtype=np.float64).reshape(1, -1)
+        c = np.asarray(coords, dtype=np.float64).reshape(-1)
+        b = self._bucket_of(c[0])
+        cand = self._buckets.get(b - 1, []) + self._buckets.get(b, []) + self._buckets.get(b + 1, [])
+        if not cand:
+            return np.empty(0, dtype=np.int64)
+        idx = np.array(sorted(cand), dtype=np.int64)
+        diff = mat[idx] - c.reshape(1, -1)
         dist = np.sqrt(np.einsum("ij,ij->i", diff, diff))
-        return np.flatnonzero(dist < DUPLICATE_TOLERANCE)
+        return idx[dist < DUPLICATE_TOLERANCE]
 
     def __setitem__(self, idx, value):
         super().__setitem__(idx, value)
         if isinstance(idx, int) and not self._dirty and self._coords is not None and -self._n <= idx < self._n:
-            self._coords[idx] = value.normed_coord
+            i = idx % self._n
+            old_b, new_b = self._bucket_of(self._coords[i, 0]), self._bucket_of(np.ravel(value.normed_coord)[0])
+            self._coords[i] = value.normed_coord
+            if old_b != new_b:
+                self._buckets[old_b].remove(i)
+                self._buckets.setdefault(new_b, []).append(i)
         else:
             self._dirty = True
 
@@ -118,6 +145,7 @@ class GPListOfPoints(list):
         self._coords[n] = point.normed_coord
         super().append(point)
         self._n = n + 1
+        self._buckets.setdefault(self._bucket_of(self._coords[n, 0]), []).append(n)
         return n
 
     def find_index_by_coords(self, coords):

@@ -339,3 +339,45 @@ def test_bad_arguments():
         GPSOptimiser(parameter_space="space")
     with pytest.raises(AssertionError):
         LeafNode(norm_bounds=[(0, 1), (1, 0)], scaler=_space().scaler, parameter_names=["a", "b"])
+
+
+def test_point_store_index_equals_the_linear_scan():
+    """The bucketed index must answer exactly what the reference's linear scan answers
+    (gpso/gp_surrogate.py:68-101): L2 distance < 1e-12, all matches in list order -- including pairs
+    that straddle a bucket boundary, in-place replacement and growth past the initial capacity."""
+    from pygpso_amd.gp_surrogate import DUPLICATE_TOLERANCE, GPListOfPoints
+
+    rng = np.random.default_rng(3)
+    width = GPListOfPoints._BUCKET
+    pts = GPListOfPoints()
+    ref = []  # plain list mirror
+
+    def scan(c):
+        return [i for i, q in enumerate(ref) if np.linalg.norm(np.asarray(q) - np.asarray(c)) < DUPLICATE_TOLERANCE]
+
+    def make(c, label=PointLabels.gp_based):
+        return GPPoint(normed_coord=np.array(c, dtype=np.float64), score_mu=0.0, score_sigma=0.0, score_ucb=0.0,
+                       label=label)
+
+    for step in range(400):
+        if step % 5 == 0 and ref:  # a near-duplicate of an existing point, sometimes across a bucket edge
+            base = np.array(ref[rng.integers(len(ref))])
+            c = base + rng.uniform(-4e-13, 4e-13, size=3)
+        elif step % 7 == 0:  # exactly on / next to a bucket boundary
+            c = np.array([rng.integers(0, 1000) * width + rng.choice([0.0, 3e-13, -3e-13]), rng.random(), rng.random()])
+        else:
+            c = rng.random(3)
+        want = scan(c)
+        got = pts._matches(c)
+        assert list(got) == want
+        assert pts.find_index_by_coords(c) == (want[0] if want else None)
+        idx = pts.append(make(c))
+        if want:
+            assert idx == want[0]
+            for i in want:
+                ref[i] = c.copy()  # not evaluated -> replaced, as in the reference
+        else:
+            assert idx == len(ref)
+            ref.append(c.copy())
+        assert len(pts) == len(ref)
+    assert all(np.array_equal(p.normed_coord, q) for p, q in zip(pts, ref))
