@@ -2,6 +2,7 @@
 // No torch, no BLAS/solver libraries: every kernel launched here is hand-written (predict.hip,
 // fit.hip, grow.hip).
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdarg>
@@ -67,6 +68,37 @@ struct gpso_ctx {
   double last_ms[3] = {0, 0, 0};
   std::string err;
   Engine* eng = nullptr;
+  hipEvent_t ev_wait = nullptr;  // completion marker of the call in flight
+  double* pinned = nullptr;      // pinned host scratch for the small result read-backs
+  size_t pinned_doubles = 0;
+
+  // Wait for everything queued on s.  hipStreamSynchronize parks the thread on an interrupt and costs
+  // tens of microseconds to wake up -- as much as the device work of a small fit.  The calling thread
+  // is blocked in this library anyway, so poll an event for up to kSpinMs and only then block.
+  hipError_t wait(hipStream_t s) {
+    constexpr double kSpinMs = 20.0;
+    hipError_t e = hipEventRecord(ev_wait, s);
+    if (e != hipSuccess) return e;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int it = 0;; ++it) {
+      e = hipEventQuery(ev_wait);
+      if (e != hipErrorNotReady) return e;
+      if ((it & 63) == 63 &&
+          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > kSpinMs)
+        return hipStreamSynchronize(s);
+    }
+  }
+  double* pinned_scratch(size_t doubles) {
+    if (doubles > pinned_doubles) {
+      if (pinned) (void)hipHostFree(pinned);
+      pinned = nullptr;
+      pinned_doubles = 0;
+      const size_t want = std::max<size_t>(doubles, 256);
+      if (hipHostMalloc(reinterpret_cast<void**>(&pinned), want * 8, hipHostMallocDefault) != hipSuccess) return nullptr;
+      pinned_doubles = want;
+    }
+    return pinned;
+  }
 
   int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -222,13 +254,18 @@ struct EngineT : Engine {
     kp.mean_c = mean_c;
     n_ls = n_ls_;
     ls_host.assign(ls, ls + n_ls_);
-    double h[kHyperHeader + kMaxD];
-    std::memset(h, 0, sizeof(h));
+    // staged in pinned memory (upper half of the scratch; the read-backs use the lower half): the copy
+    // is then a plain stream operation and needs no host synchronisation here
+    static_assert(128 + kHyperHeader + kMaxD <= 256, "pinned scratch layout");
+    double* scratch = ctx->pinned_scratch(256);
+    if (!scratch) return ctx->fail(GPSO_E_OOM, "pinned host scratch");
+    double* h = scratch + 128;
+    constexpr size_t kHyperBytes = (size_t)(kHyperHeader + kMaxD) * 8;
+    std::memset(h, 0, kHyperBytes);
     h[0] = (double)n; h[1] = (double)d; h[2] = (double)kernel; h[3] = (double)n_ls_;
     h[4] = variance; h[5] = noise; h[6] = mean_c;
     for (int k = 0; k < kMaxD; ++k) h[kHyperHeader + k] = ls[n_ls_ == 1 ? 0 : std::min(k, n_ls_ - 1)];
-    HIPCHECK(hipMemcpyAsync(hyper.p, h, sizeof(h), hipMemcpyHostToDevice, st()));
-    HIPCHECK(hipStreamSynchronize(st()));  // h is a stack buffer
+    HIPCHECK(hipMemcpyAsync(hyper.p, h, kHyperBytes, hipMemcpyHostToDevice, st()));
     return GPSO_OK;
   }
 
@@ -276,9 +313,11 @@ struct EngineT : Engine {
     if ((rc = pack_bf16())) return rc;
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipEventRecord(ctx->ev[5], s));
-    double host[8 + kGradMaxLs + 3];
-    HIPCHECK(hipMemcpyAsync(host, scal.p, sizeof(host), hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
+    constexpr size_t kHostDoubles = 8 + kGradMaxLs + 3;
+    double* host = ctx->pinned_scratch(kHostDoubles);
+    if (!host) return ctx->fail(GPSO_E_OOM, "pinned host scratch");
+    HIPCHECK(hipMemcpyAsync(host, scal.p, kHostDoubles * 8, hipMemcpyDeviceToHost, s));
+    HIPCHECK(ctx->wait(s));
     float ms = 0;
     if (hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->last_ms[2] = ms;
     int info;
@@ -437,7 +476,7 @@ struct EngineT : Engine {
       HIPCHECK(hipMemcpyAsync(var, vd, (size_t)m * 8, hipMemcpyDeviceToHost, s));
     }
     HIPCHECK(hipEventRecord(ctx->ev[3], s));
-    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(ctx->wait(s));
     collect_tile_ms();
     float ms = 0;
     if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ms[1] = ms;
@@ -474,10 +513,11 @@ struct EngineT : Engine {
       if ((rc = score_device_leaves(dev, xs_dtype, m, varsigma, true, as<double>(omean), as<double>(ovar), as<double>(oucb)))) return rc;
     launch_seg_argmax(s, as<double>(omean), as<double>(ovar), as<double>(oucb), as<int64_t>(segoff),
                       nseg, kArgmaxBlocks, best.p, as<double>(ovals));
-    std::vector<double> vals((size_t)nseg * 4);
-    HIPCHECK(hipMemcpyAsync(vals.data(), ovals.p, (size_t)nseg * 32, hipMemcpyDeviceToHost, s));
+    double* vals = ctx->pinned_scratch((size_t)nseg * 4);
+    if (!vals) return ctx->fail(GPSO_E_OOM, "pinned host scratch");
+    HIPCHECK(hipMemcpyAsync(vals, ovals.p, (size_t)nseg * 32, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipEventRecord(ctx->ev[3], s));
-    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(ctx->wait(s));
     HIPCHECK(hipGetLastError());
     collect_tile_ms();
     for (int i = 0; i < nseg; ++i) {
@@ -678,6 +718,11 @@ int gpso_create(gpso_ctx** out, int device, int dtype) {
     return GPSO_E_HIP;
   }
   ctx->stream = ctx->own_stream;
+  if ((e = hipEventCreateWithFlags(&ctx->ev_wait, hipEventDisableTiming)) != hipSuccess) {
+    g_create_error = std::string("hipEventCreate: ") + hipGetErrorString(e);
+    gpso_destroy(ctx);
+    return GPSO_E_HIP;
+  }
   for (auto& ev : ctx->ev)
     if ((e = hipEventCreate(&ev)) != hipSuccess) {
       g_create_error = std::string("hipEventCreate: ") + hipGetErrorString(e);
@@ -700,6 +745,8 @@ void gpso_destroy(gpso_ctx* ctx) {
   for (auto& ev : ctx->ev)
     if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : ctx->tile_ev) (void)hipEventDestroy(ev);
+  if (ctx->ev_wait) (void)hipEventDestroy(ctx->ev_wait);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
