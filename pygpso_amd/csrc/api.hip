@@ -302,7 +302,7 @@ struct EngineT : Engine {
     const int done = launch_potrf<T>(s, as<T>(K), as<T>(Lf), as<T>(linv), as<T>(work),
                                      grad ? as<T>(kinvb) : nullptr, n, npad, as<double>(logdet), info_dev,
                                      single_level_max);
-    if (!(done & 1)) launch_trtri<T>(s, as<T>(Lf), as<T>(linv), as<T>(work), npad);
+    if (!(done & 1)) launch_trtri<T>(s, as<T>(Lf), as<T>(linv), as<T>(work), npad, kFitOuterPanel);
     launch_solve_alpha<T>(s, as<T>(linv), as<double>(y64), n, npad, mean_c, as<double>(logdet),
                           as<T>(white), as<T>(alpha), as<double>(gpart),
                           as<double>(scal));
@@ -356,7 +356,7 @@ struct EngineT : Engine {
     launch_scale_x<T>(s, as<double>(x64), n, npad, d, dp, ls_dev(), as<T>(xs), as<T>(xnorm), as<T>(xs_p));
     (void)hipMemsetAsync(linv.p, 0, (size_t)npad * npad * sizeof(T), s);
     launch_install_chol<T>(s, tmp, n, npad, as<T>(Lf), as<T>(linv));
-    launch_trtri<T>(s, as<T>(Lf), as<T>(linv), as<T>(work), npad);
+    launch_trtri<T>(s, as<T>(Lf), as<T>(linv), as<T>(work), npad, kFitBlock);
     (void)hipMemsetAsync(alpha.p, 0, (size_t)npad * sizeof(T), s);
     launch_convert_in<T>(s, tmp + (size_t)n * n, as<T>(alpha), 1, n, npad);
     launch_pack_linv<T>(s, as<T>(linv), n, npad, as<T>(linv_p));

@@ -441,7 +441,7 @@ struct GemmDesc {
   int nbatch;
   double alpha, beta;
   int lower_only;  // only tiles with tj <= ti (needs m == n)
-  int kmode;       // 0: all k | 1: k >= 64 tj | 2: k >= 64 ti | 3: k < 64 (ti + 1)
+  int kmode;       // 0: all k | 1: k >= TS tj | 2: k >= TS ti | 3: k < TS (ti + 1) | 4: k < TS (tj + 1)
 };
 
 constexpr int kGK = 32;       // k-step staged in LDS
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmDesc g) {
   // hardware's round-robin of consecutive workgroups over the 8 XCDs deals every XCD the same amount
   // of work -- tiles of equal k-length are neighbours -- and (b) the longest tiles start first:
   //   lower_only      compact triangular enumeration, row-major (k-length depends on the row only)
-  //   kmode 1         column-major (k-length depends on tj)
+  //   kmode 1, 4      column-major (k-length depends on tj; 4: last column first)
   //   kmode 3         row-major, last row first (k-length grows with ti)
   //   otherwise       row-major
   // (A 2-D grid whose upper-triangle workgroups exit at once ran the K^-1 product at 78 TFLOP/s
@@ -695,9 +695,10 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmDesc g) {
       while ((ti + 1) * (ti + 2) / 2 <= id) ++ti;
       while (ti * (ti + 1) / 2 > id) --ti;
       tj = id - ti * (ti + 1) / 2;
-    } else if (g.kmode == 1) {
+    } else if (g.kmode == 1 || g.kmode == 4) {
       tj = id / nti;
       ti = id % nti;
+      if (g.kmode == 4) tj = ntj - 1 - tj;
     } else {
       ti = id / ntj;
       tj = id % ntj;
@@ -714,6 +715,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmDesc g) {
   if (g.kmode == 1) k_lo = TS * tj;
   if (g.kmode == 2) k_lo = TS * ti;
   if (g.kmode == 3) k_hi = min(g.k, TS * (ti + 1));
+  if (g.kmode == 4) k_hi = min(g.k, TS * (tj + 1));
 
   // this wave's DMA instructions: numbers wave, wave + 4, ... of the kInstrPerStep per operand
   constexpr int NI = G::kInstrPerStep / 4;  // per wave, operand and step
@@ -1051,7 +1053,7 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
                                                          int jmax, int ntile, int64_t n,
                                                          double* __restrict__ diag64,
                                                          int* __restrict__ info, T* __restrict__ W,
-                                                         T* __restrict__ kinv) {
+                                                         T* __restrict__ kinv, int64_t row_base) {
   using M = Mfma<T>;
   using vec4 = typename M::vec4;
   using Lay = StepLds<T>;
@@ -1203,9 +1205,11 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
     __syncthreads();
     const int64_t k0 = kd * T64;
     GPSO_STAMP(15);
-    chol64_lds<(sizeof(T) == 4) ? 1 : 2, T>(Ls, Xs, Lf + k0 * ld + k0, ld, k0, n, info);
+    // (row_base: global row of this sub-matrix's first row -- pivot indices, padding test and the
+    // diagonal go by global row; every tile address above is relative to the sub-matrix)
+    chol64_lds<(sizeof(T) == 4) ? 1 : 2, T>(Ls, Xs, Lf + k0 * ld + k0, ld, row_base + k0, n, info);
     // the unrounded diagonal: its logarithms are summed by nlml_kernel, off this chain
-    if (tid < kFitBlock) diag64[k0 + tid] = Ls[tid * kDS + tid];
+    if (tid < kFitBlock) diag64[row_base + k0 + tid] = Ls[tid * kDS + tid];
     GPSO_STAMP(7);
     trinv64_lds<true, T>(Ls, Xs, Ts, Lf + k0 * ld + k0, ld);
     lower_tile_to_global<T>(Xs, linv + k0 * ld + k0, ld, tid);
@@ -1303,86 +1307,87 @@ __global__ __launch_bounds__(256) void inv_lastrow_kernel(T* __restrict__ linv, 
 //       diagonal chain it hides behind.  The off-diagonal blocks of L^-1 ride along in the same
 //       launches (role PB + one last-row launch), so no separate triangular inverse follows; when
 //       the gradient is wanted K^-1 = L^-T L^-1 rides along as well (role KI + one tail launch).
-//   larger: two-level.  Steps update only the columns of the current outer panel plus ONE
-//       look-ahead tile column (so that the first diagonal block of the next panel never waits for
-//       the big update); everything right of that gets one rank-(panel) SYRK per outer panel, which
-//       streams the trailing matrix N/512 times instead of N/64 times.  Panel boundaries sit at
-//       448 + 512 p so that the SYRK region starts on a multiple of 128 (128x128 GEMM tiles).
-constexpr int kOuterPanel = 512;  // 256 / 512 / 1024 measured within 2 % of each other at N = 4096 .. 16384
+//   larger: two-level by kOuterPanel-wide diagonal blocks, see launch_potrf.
+constexpr int kOuterPanel = kFitOuterPanel;
 // measured crossovers: float 3072 (a tie there; at 3584 two-level is 15% faster), double 2048
 template <typename T>
 constexpr int64_t kSingleLevelMax = (sizeof(T) == 4) ? 3072 : 2048;
 
+// Single-level factorisation (+ inverse, + optionally K^-1) of the ntile x ntile tile sub-matrix whose
+// first row / column is global row row_base; all pointers address that sub-matrix, ld is the leading
+// dimension of the full matrices.
 template <typename T>
-int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t n, int64_t npad,
-                 double* diag64, int* info, int64_t single_max) {
-  const int ntile = (int)(npad / kFitBlock);
-  const bool single = npad <= (single_max >= 0 ? single_max : kSingleLevelMax<T>);
-  static bool attr_set = false;  // per instantiation; the step kernel needs more than 64 KB of LDS
+static void potrf_block(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t ld, int ntile,
+                        int64_t row_base, int64_t n, double* diag64, int* info) {
+  static bool attr_set = false;  // per instantiation; the kernels need more than 64 KB of LDS
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_step_kernel<T>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, StepLds<T>::kBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&inv_lastrow_kernel<T>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * StepLds<T>::kTileBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kinv_rows_kernel<T>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * StepLds<T>::kTileBytes);
     attr_set = true;
   }
   const int lds_bytes = StepLds<T>::kBytes;
-  auto step = [&](int k, int jmax) {
-    // grid.x = 1 (role D / idle) + rows below the diagonal of the tile column, grid.y = tile columns
-    // with the inverse riding along (single level): blockIdx.z == 1 -> role PB, tile columns 0 .. k
-    // blockIdx.z == 2 -> role KI (K^-1 riding along when the gradient is wanted), tiles (i, j <= i < k)
-    const bool ki = single && kinv != nullptr && k >= 1;
-    const int ncol = (k < 0) ? 1 : std::max(std::max(single ? k + 1 : 1, jmax - k), ki ? k : 1);
+  auto step = [&](int k) {
+    // grid.x = 1 (role D / idle) + rows below the diagonal of the tile column, grid.y = tile columns;
+    // blockIdx.z == 1 -> role PB (tile columns 0 .. k), == 2 -> role KI (tiles (i, j <= i < k))
+    const bool ki = kinv != nullptr && k >= 1;
+    const int ncol = (k < 0) ? 1 : std::max(std::max(k + 1, ntile - 1 - k), ki ? k : 1);
     const int nrow = (k < 0) ? 0 : std::max(std::max(1, ntile - (k + 1)), ki ? k : 1);
-    hipLaunchKernelGGL((potrf_step_kernel<T>),
-                       dim3((unsigned)(1 + nrow), (unsigned)ncol, !(single && k >= 0) ? 1u : ki ? 3u : 2u),
-                       dim3(256), lds_bytes, st, K, Lf, linv, npad, k, jmax, ntile, n, diag64, info, work,
-                       (single ? kinv : nullptr));
+    hipLaunchKernelGGL((potrf_step_kernel<T>), dim3((unsigned)(1 + nrow), (unsigned)ncol, k < 0 ? 1u : ki ? 3u : 2u),
+                       dim3(256), lds_bytes, st, K, Lf, linv, ld, k, ntile - 1, ntile, n, diag64, info, work,
+                       kinv, row_base);
   };
-  step(-1, -1);  // diagonal block 0
-  const int outer = kOuterPanel;
-  int p_end = single ? ntile : std::min(ntile, (outer - kFitBlock) / kFitBlock);  // tiles
-  int p_beg = 0;
-  for (int k = 0; k < ntile - 1; ++k) {
-    const int jmax = std::min(ntile - 1, p_end);  // p_end itself is the look-ahead column
-    step(k, jmax);
-    if (k + 1 == p_end) {  // last step of the outer panel [p_beg, p_end): deferred rank update
-      const int64_t r0 = (int64_t)(p_end + 1) * kFitBlock;
-      const int m2 = (int)(npad - r0);
-      if (m2 > 0) {
-        const T* Lp = Lf + r0 * npad + (int64_t)p_beg * kFitBlock;
-        GemmDesc s{};
-        s.A = Lp; s.sai = npad; s.sak = 1;
-        s.B = Lp; s.sbk = 1; s.sbj = npad;
-        s.C = K + r0 * npad + r0; s.ldc = npad;
-        s.m = m2; s.n = m2; s.k = (p_end - p_beg) * kFitBlock; s.m_last = m2; s.nbatch = 1;
-        s.alpha = -1.0; s.beta = 1.0; s.lower_only = 1;
-        launch_gemm<T>(st, s);
-      }
-      p_beg = p_end;
-      p_end = std::min(ntile, p_end + outer / kFitBlock);
-    }
-  }
-  if (single && ntile > 1) {
-    static bool attr2 = false;
-    if (!attr2) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&inv_lastrow_kernel<T>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * StepLds<T>::kTileBytes);
-      attr2 = true;
-    }
+  step(-1);  // diagonal block 0
+  for (int k = 0; k < ntile - 1; ++k) step(k);
+  if (ntile > 1)
     hipLaunchKernelGGL((inv_lastrow_kernel<T>), dim3((unsigned)(ntile - 1)), dim3(256),
-                       2 * StepLds<T>::kTileBytes, st, linv, work, npad, ntile - 1);
-  }
-  if (single && kinv != nullptr) {
-    static bool attr3 = false;
-    if (!attr3) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kinv_rows_kernel<T>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * StepLds<T>::kTileBytes);
-      attr3 = true;
-    }
+                       2 * StepLds<T>::kTileBytes, st, linv, work, ld, ntile - 1);
+  if (kinv != nullptr)
     hipLaunchKernelGGL((kinv_rows_kernel<T>), dim3((unsigned)ntile, (unsigned)ntile), dim3(256),
-                       2 * StepLds<T>::kTileBytes, st, linv, kinv, npad, std::max(0, ntile - 2), ntile);
+                       2 * StepLds<T>::kTileBytes, st, linv, kinv, ld, std::max(0, ntile - 2), ntile);
+}
+
+template <typename T>
+int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t n, int64_t npad,
+                 double* diag64, int* info, int64_t single_max) {
+  const bool single = npad <= (single_max >= 0 ? single_max : kSingleLevelMax<T>);
+  if (single) {
+    potrf_block<T>(st, K, Lf, linv, work, kinv, npad, (int)(npad / kFitBlock), 0, n, diag64, info);
+    return 1 | (kinv != nullptr ? 2 : 0);
   }
-  // bit 0: linv already holds the complete inverse; bit 1: kinv already holds K^-1 (lower tiles)
-  return (single ? 1 : 0) | ((single && kinv != nullptr) ? 2 : 0);
+  // two-level, by kOuterPanel-wide diagonal blocks:
+  //   1. the diagonal block is factored AND inverted by the single-level routine (a latency chain of
+  //      kOuterPanel / 64 steps with hardly any bulk work);
+  //   2. rows below:  L21 = A21 X11^T  -- a plain GEMM, X11 the block's lower-triangular inverse;
+  //   3. A22 -= L21 L21^T  (lower tiles).
+  // The level-doubling inverse then starts at level kOuterPanel (launch_trtri's first_level).
+  for (int64_t c0 = 0; c0 < npad; c0 += kOuterPanel) {
+    const int64_t wp = std::min<int64_t>(kOuterPanel, npad - c0);
+    const int64_t off = c0 * npad + c0;
+    potrf_block<T>(st, K + off, Lf + off, linv + off, work + off, nullptr, npad, (int)(wp / kFitBlock), c0, n,
+                   diag64, info);
+    const int64_t r1 = c0 + wp;
+    const int m2 = (int)(npad - r1);
+    if (m2 <= 0) break;
+    GemmDesc t{};  // L21 = A21 X11^T:  opB(k, j) = X11[j][k], zero for k > j
+    t.A = K + r1 * npad + c0; t.sai = npad; t.sak = 1;
+    t.B = linv + off; t.sbk = 1; t.sbj = npad;
+    t.C = Lf + r1 * npad + c0; t.ldc = npad;
+    t.m = m2; t.n = (int)wp; t.k = (int)wp; t.m_last = m2; t.nbatch = 1;
+    t.alpha = 1.0; t.beta = 0.0; t.kmode = 4;
+    launch_gemm<T>(st, t);
+    GemmDesc u{};  // A22 -= L21 L21^T
+    u.A = Lf + r1 * npad + c0; u.sai = npad; u.sak = 1;
+    u.B = u.A; u.sbk = 1; u.sbj = npad;
+    u.C = K + r1 * npad + r1; u.ldc = npad;
+    u.m = m2; u.n = m2; u.k = (int)wp; u.m_last = m2; u.nbatch = 1;
+    u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1;
+    launch_gemm<T>(st, u);
+  }
+  return 0;
 }
 template int launch_potrf<float>(hipStream_t, float*, float*, float*, float*, float*, int64_t, int64_t, double*, int*, int64_t);
 template int launch_potrf<double>(hipStream_t, double*, double*, double*, double*, double*, int64_t, int64_t, double*, int*, int64_t);
@@ -1394,8 +1399,8 @@ template int launch_potrf<double>(hipStream_t, double*, double*, double*, double
 //   W[B,A]    = L[B,A] * Linv[A,A]         (Linv[A,A] lower  -> k >= 64 tj)
 //   Linv[B,A] = -Linv[B,B] * W[B,A]        (Linv[B,B] lower  -> k <  64 (ti+1))
 template <typename T>
-void launch_trtri(hipStream_t st, const T* L, T* linv, T* work, int64_t npad) {
-  for (int64_t s = kFitBlock; s < npad; s *= 2) {
+void launch_trtri(hipStream_t st, const T* L, T* linv, T* work, int64_t npad, int64_t first_level) {
+  for (int64_t s = first_level; s < npad; s *= 2) {
     const int64_t span = 2 * s;
     const int nfull = (int)(npad / span);          // pairs with a full-size B
     const int64_t rem = npad - (int64_t)nfull * span;  // leftover columns
@@ -1425,8 +1430,8 @@ void launch_trtri(hipStream_t st, const T* L, T* linv, T* work, int64_t npad) {
     launch_gemm<T>(st, b);
   }
 }
-template void launch_trtri<float>(hipStream_t, const float*, float*, float*, int64_t);
-template void launch_trtri<double>(hipStream_t, const double*, double*, double*, int64_t);
+template void launch_trtri<float>(hipStream_t, const float*, float*, float*, int64_t, int64_t);
+template void launch_trtri<double>(hipStream_t, const double*, double*, double*, int64_t, int64_t);
 
 // =============================================================================================
 // pack L^-1 into MFMA fragment-major tiles (layout documented in predict.hip)

@@ -58,9 +58,11 @@ void launch_gram(hipStream_t st, const T* xs, const T* xnorm, int64_t n, int64_t
 template <typename T>
 int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t n, int64_t npad,
                  double* diag64, int* info, int64_t single_level_max /* < 0: default */);
-// L^-1 by level-doubling: needs the diagonal-block inverses already in linv; work = npad x npad scratch
+// L^-1 by level-doubling from level first_level (64 or the factorisation's outer panel width): needs the
+// inverses of the first_level-wide diagonal blocks already in linv; work = npad x npad scratch
+constexpr int kFitOuterPanel = 512;
 template <typename T>
-void launch_trtri(hipStream_t st, const T* L, T* linv, T* work, int64_t npad);
+void launch_trtri(hipStream_t st, const T* L, T* linv, T* work, int64_t npad, int64_t first_level);
 // zero rows/cols >= n and re-tile L^-1 into the MFMA fragment-major layout the predict kernel reads
 template <typename T>
 void launch_pack_linv(hipStream_t st, const T* linv, int64_t n, int64_t npad, T* linv_p);
