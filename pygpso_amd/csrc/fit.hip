@@ -931,24 +931,6 @@ __device__ __forceinline__ void mma_atb(const T* A, int a0, const T* B, int lane
   }
 }
 
-// one 16x16 tile: acc = A_rows[16 x 64] * B_rows[16 x 64]^T
-template <typename T>
-__device__ __forceinline__ typename Mfma<T>::vec4 mma_abt_tile(const T* A_rows, const T* B_rows, int lane) {
-  using M = Mfma<T>;
-  using vec4 = typename M::vec4;
-  vec4 acc{0, 0, 0, 0};
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    const int ko = 16 * kk + 4 * (lane >> 4);
-    const vec4 a4 = *reinterpret_cast<const vec4*>(A_rows + (lane & 15) * kTL + ko);
-    const vec4 b4 = *reinterpret_cast<const vec4*>(B_rows + (lane & 15) * kTL + ko);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc = M::mma(a4[e], b4[e], acc);
-  }
-  return acc;
-}
-
-
 // all 256 threads: 64x64 tile at src (row stride ld) -> LDS tile (stride kTL), 16-byte loads
 template <typename T>
 __device__ __forceinline__ void tile_to_lds(const T* __restrict__ src, int64_t ld, T* dst, int tid) {
@@ -1479,15 +1461,18 @@ __global__ __launch_bounds__(256) void white_kernel(const T* __restrict__ linv,
   const int64_t i = (int64_t)blockIdx.x * 4 + wave;
   if (i >= npad) return;
   double acc = 0.0;
-  if (i < n)
+  if (i < n) {
+#pragma unroll 4
     for (int64_t k = lane; k <= i; k += 64) acc += (double)linv[i * npad + k] * (y64[k] - mean_c);
+  }
   acc = wave_sum(acc);
   if (lane == 0) white[i] = (T)acc;
 }
 
-// alpha[j] = sum_{i>=j} Linv[i][j] white[i].  Stage 1: block (column block cb, row chunk rc of 256
-// rows) -> part[rc][j] (double); stage 2 sums the chunks in order (deterministic).
-constexpr int kAlphaChunk = 256;
+// alpha[j] = sum_{i>=j} Linv[i][j] white[i].  Stage 1: block (column block cb, row chunk rc of 64
+// rows) -> part[rc][j] (double); stage 2 sums the chunks in order (deterministic).  (Chunks of 256 rows
+// left a thread 64 dependent loads: 22 us at N = 2048 for 8 MB.)
+constexpr int kAlphaChunk = 64;
 template <typename T>
 __global__ __launch_bounds__(256) void alpha_part_kernel(const T* __restrict__ linv,
                                                          const T* __restrict__ white, int64_t n,

@@ -70,7 +70,7 @@ void launch_pack_linv(hipStream_t st, const T* linv, int64_t n, int64_t npad, T*
 template <typename T>
 void launch_solve_alpha(hipStream_t st, const T* linv, const double* y64, int64_t n, int64_t npad,
                         double mean_c, const double* diag64, T* white, T* alpha,
-                        double* alpha_part /* [ceil(npad/256) * npad] scratch */, double* nlml_out);
+                        double* alpha_part /* [ceil(npad/64) * npad] scratch */, double* nlml_out);
 // Kinv = L^-T L^-1 (lower tiles; skipped when kinv_ready), then the gradient reductions of SURVEY.md A.3;
 // grad_out[n_ls + 3] = d nlml / d (ls..., variance, noise, c)
 template <typename T>
