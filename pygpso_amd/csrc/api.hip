@@ -377,7 +377,10 @@ struct EngineT : Engine {
   // leaves already on the device as raw coordinates (dtype xs_dtype) -> mean/var(/ucb) device arrays
   int score_device_leaves(const void* xs_dev, int xs_dtype, int64_t m, double varsigma, bool want_ucb,
                           double* mean_dev, double* var_dev, double* ucb_dev) {
-    const int nbi = leaf_tiles_nbi<T>(npad);
+    // row blocks of L^-1 = partial sums per leaf: the split-bf16 kernel always works on 256-row blocks,
+    // the native kernels on the shape leaf_tiles_bm picks
+    const bool use_bf16 = bf16_usable() && linv_b_valid;
+    const int nbi = use_bf16 ? (int)(npad / 256) : leaf_tiles_nbi<T>(npad, dp / 4);
     const int64_t chunk = std::min<int64_t>(m, kLeafChunk);
     const int64_t cpad = (chunk + kLeafPad - 1) / kLeafPad * kLeafPad;
     int rc;
@@ -402,7 +405,7 @@ struct EngineT : Engine {
         ctx->tile_ev.push_back(e);
       }
       HIPCHECK(hipEventRecord(ctx->tile_ev[2 * ctx->tile_pairs], s));
-      if (bf16_usable() && linv_b_valid) {
+      if (use_bf16) {
         if constexpr (sizeof(T) == 4)
           launch_leaf_tiles_bf16(s, nsplit(), linv_b.p, as<float>(xs_p), as<float>(xnorm), as<float>(alpha),
                                  as<float>(leaves_s), as<float>(lnorm), as<float>(pvar), as<float>(pmean),

@@ -8,11 +8,11 @@ namespace gpso {
 // (chosen per launch: f32 uses 256 x 128 when N_pad is a multiple of 256, else 128 x 256; f64 64 x 128;
 //  always 32 (f32) / 8 (f64) accumulator tiles per wave)
 constexpr int kLeafPad = 256;  // leaf batches are padded to a multiple of this
-// rows of L^-1 per workgroup for a given padded N, and the resulting number of row blocks
+// rows of L^-1 per workgroup for a given padded N and D / 4, and the resulting number of row blocks
 template <typename T>
-int leaf_tiles_bm(int64_t npad);
+int leaf_tiles_bm(int64_t npad, int dp4);
 template <typename T>
-inline int leaf_tiles_nbi(int64_t npad) { return (int)(npad / leaf_tiles_bm<T>(npad)); }
+inline int leaf_tiles_nbi(int64_t npad, int dp4) { return (int)(npad / leaf_tiles_bm<T>(npad, dp4)); }
 
 // ---- predict.hip ----------------------------------------------------------------------------------
 template <typename T, typename TIN>

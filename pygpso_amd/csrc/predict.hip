@@ -892,13 +892,23 @@ template void launch_prep_leaves<double, float>(hipStream_t, const float*, int64
 template void launch_prep_leaves<double, double>(hipStream_t, const double*, int64_t, int64_t, int, int, const double*, double*, double*);
 
 template <>
-int leaf_tiles_bm<float>(int64_t npad) {
-  static const char* force = getenv("GPSO_LEAF_BM");  // experiment switch: 128 | 256
+int leaf_tiles_bm<float>(int64_t npad, int dp4) {
+  static const char* force = getenv("GPSO_LEAF_BM");  // experiment switch: 128 | 256 | 512
+  static const bool v1 = getenv("GPSO_LEAF_V1") != nullptr;
   if (force && atoi(force) == 128) return 128;
+  if (npad % 512 == 0 && !v1) {
+    if (force && atoi(force) == 512) return 512;
+    // 512 rows x 16 leaves per wave: every generated K* tile feeds 32 row tiles instead of 16, which
+    // halves the regeneration share (D / 4 generation MFMAs per 64 apply MFMAs and row block; 15 % of
+    // the matrix work at D = 40).  Pays once D and the number of row blocks are large (measured: C5
+    // +6.4 %, C4 +1.9 %, C3 -4 %).
+    if (!force && npad >= 4096 && dp4 >= 5) return 512;
+  }
   return (npad % 256 == 0) ? 256 : 128;
 }
 template <>
-int leaf_tiles_bm<double>(int64_t npad) {
+int leaf_tiles_bm<double>(int64_t npad, int dp4) {
+  (void)dp4;
   static const bool v1 = getenv("GPSO_LEAF_V1") != nullptr;
   if (v1) return 64;
   return (npad % 256 == 0) ? 256 : 128;
@@ -948,11 +958,13 @@ static void launch_leaf_tiles_shape(hipStream_t st, const T* linv_p, const T* xs
   static const bool v1 = getenv("GPSO_LEAF_V1") != nullptr;  // A/B switch (same results)
   if constexpr (sizeof(T) == 4) {
     if (!v1) {
-      if (leaf_tiles_bm<T>(npad) == 256)
+      if (leaf_tiles_bm<T>(npad, dp4) == 512)
+        launch_leaf_tiles_v2<T, 512, 1, KERNEL>(GPSO_ARGS);
+      else if (leaf_tiles_bm<T>(npad, dp4) == 256)
         launch_leaf_tiles_v2<T, 256, 2, KERNEL>(GPSO_ARGS);
       else
         launch_leaf_tiles_v2<T, 128, 4, KERNEL>(GPSO_ARGS);
-    } else if (leaf_tiles_bm<T>(npad) == 256) {
+    } else if (leaf_tiles_bm<T>(npad, dp4) == 256) {
       launch_leaf_tiles_k<T, 256, 2, KERNEL>(GPSO_ARGS);
     } else {
       launch_leaf_tiles_k<T, 128, 4, KERNEL>(GPSO_ARGS);
@@ -962,7 +974,7 @@ static void launch_leaf_tiles_shape(hipStream_t st, const T* linv_p, const T* xs
     // of generated entries per MFMA low (the f64 kernel map is VALU-expensive)
     if (v1)
       launch_leaf_tiles_k<T, 64, 2, KERNEL>(GPSO_ARGS);
-    else if (leaf_tiles_bm<T>(npad) == 256)
+    else if (leaf_tiles_bm<T>(npad, dp4) == 256)
       launch_leaf_tiles_v2<T, 256, 1, KERNEL>(GPSO_ARGS);
     else
       launch_leaf_tiles_v2<T, 128, 2, KERNEL>(GPSO_ARGS);

@@ -453,7 +453,10 @@ def test_config_C5_one_gpu_share_properties_fp32():
     eng.set_predict_math("bf16x3")
     m3, v3 = eng.predict(Xs)
     assert np.max(np.abs(v6 - var)) <= 5e-5 and np.max(np.abs(v3 - var)) <= 2e-4
-    assert np.array_equal(m6, mean) and np.array_equal(m3, mean)  # the mean never goes through the split
+    # the mean never goes through the split: identical in both split modes; against the native kernel only
+    # the grouping of the float32 partial sums differs (512- vs 256-row blocks at this size)
+    assert np.array_equal(m6, m3)
+    assert np.max(np.abs(m6 - mean)) <= 5e-4 * max(1.0, float(np.max(np.abs(y))))  # float32 parity is 2e-3 max|y|
 
 
 def test_config_C2_full_oracle():
