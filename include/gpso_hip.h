@@ -58,7 +58,7 @@ typedef struct gpso_ctx gpso_ctx;
 #define GPSO_MATH_BF16X3 3      /*   2-way bf16 split, 3 bf16 MFMAs per product: |d var| ~ 2e-5 sigma^2  */
 #define GPSO_MATH_BF16X6 6      /*   3-way bf16 split, 6 bf16 MFMAs per product: f32-class accuracy      */
 #define GPSO_OPT_FIT_SINGLE_LEVEL_MAX 2 /* tuning / test hook: largest padded N whose Cholesky runs single-level */
-                                        /* with L^-1 built beside it (default 3072, double 2048); 0 = always two-level +     */
+                                        /* with L^-1 built beside it (default 3584, double 2560); 0 = always two-level +     */
                                         /* level-doubling triangular inverse.  Results agree to rounding.       */
 
 /* which device-resident matrix / vector the debug getters copy out (as float64) */

@@ -1291,9 +1291,10 @@ __global__ __launch_bounds__(256) void inv_lastrow_kernel(T* __restrict__ linv, 
 //       the gradient is wanted K^-1 = L^-T L^-1 rides along as well (role KI + one tail launch).
 //   larger: two-level by kOuterPanel-wide diagonal blocks, see launch_potrf.
 constexpr int kOuterPanel = kFitOuterPanel;
-// measured crossovers: float 3072 (a tie there; at 3584 two-level is 15% faster), double 2048
+// measured crossovers (posterior fit, ms, single | two-level): float 3584: 1.38 | 1.44, 4096: 1.86 | 1.73;
+// double 2560: 1.24 | 1.36, 3072: 1.85 | 1.68
 template <typename T>
-constexpr int64_t kSingleLevelMax = (sizeof(T) == 4) ? 3072 : 2048;
+constexpr int64_t kSingleLevelMax = (sizeof(T) == 4) ? 3584 : 2560;
 
 // Single-level factorisation (+ inverse, + optionally K^-1) of the ntile x ntile tile sub-matrix whose
 // first row / column is global row row_base; all pointers address that sub-matrix, ld is the leading
