@@ -165,6 +165,31 @@ __device__ __forceinline__ double dkern_dr2(int kernel, double r2, double varian
   return -variance * 0.5 * exp(-r) / r;
 }
 
+// k and dk/d(r^2) together with the lean exp / sqrt (full double precision, no special-case handling:
+// every argument of exp is <= 0 and r^2 is clamped away from 0) -- the gradient kernel evaluates both
+// per matrix entry and the library calls were most of its time
+__device__ __forceinline__ void kern_and_dkern_lean(int kernel, double r2_k, double r2_dk, double variance,
+                                                    double& k, double& dk) {
+  if (kernel == 3) {
+    k = variance * exp_lean(-0.5 * r2_k);
+    dk = -0.5 * variance * exp_lean(-0.5 * r2_dk);
+    return;
+  }
+  const double rk = sqrt_lean(fmax(r2_k, 1e-36)), rd = sqrt_lean(fmax(r2_dk, 1e-36));
+  if (kernel == 0) {
+    const double s5 = 2.23606797749978969641;
+    k = variance * (1.0 + s5 * rk + (5.0 / 3.0) * (rk * rk)) * exp_lean(-s5 * rk);
+    dk = -variance * (5.0 / 6.0) * (1.0 + s5 * rd) * exp_lean(-s5 * rd);
+  } else if (kernel == 1) {
+    const double s3 = 1.73205080756887729353;
+    k = variance * (1.0 + s3 * rk) * exp_lean(-s3 * rk);
+    dk = -variance * 1.5 * exp_lean(-s3 * rd);
+  } else {
+    k = variance * exp_lean(-rk);
+    dk = -variance * 0.5 * exp_lean(-rd) / rd;
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

@@ -1596,11 +1596,11 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(const T* __restrict__ ki
     const double r2 = (double)(T(-2) * s + (xnorm[i] + xnorm[j]));  // GEMM form: the K the loss saw
     const double ai = (double)alpha[i], aj = (double)alpha[j];
     const double W = 0.5 * ((double)kinv[i * npad + j] - ai * aj);
-    const double kv = kern_from_r2(kernel, r2, variance);
     // the derivative is taken at the direct-difference distance: the Matern-1/2 factor 1/r would
     // otherwise amplify a GEMM-form r^2 that cancelled to ~0 (or to the 1e-36 clamp) between
     // near-coincident points in float32, while the per-dimension terms below use direct differences
-    const double dk = dkern_dr2(kernel, r2d, variance);
+    double kv, dk;
+    kern_and_dkern_lean(kernel, r2, r2d, variance, kv, dk);
     g_var += w * W * kv / variance;
     if (i == j) g_noise += W;
     base[p] = w * W * dk;
