@@ -901,8 +901,8 @@ int leaf_tiles_bm<float>(int64_t npad, int dp4) {
     // 512 rows x 16 leaves per wave: every generated K* tile feeds 32 row tiles instead of 16, which
     // halves the regeneration share (D / 4 generation MFMAs per 64 apply MFMAs and row block; 15 % of
     // the matrix work at D = 40).  Pays once D and the number of row blocks are large (measured: C5
-    // +6.4 %, C4 +1.9 %, C3 -4 %).
-    if (!force && npad >= 4096 && dp4 >= 5) return 512;
+    // +6.4 %, C4 +1.9 %, N = 4096 / D = 40 +4 %, N = 2048 / D = 40 +2 %; C3 -4 %, N = 2048 / D = 20 -2 %).
+    if (!force && ((npad >= 4096 && dp4 >= 5) || (npad >= 2048 && dp4 >= 9))) return 512;
   }
   return (npad % 256 == 0) ? 256 : 128;
 }
