@@ -37,11 +37,17 @@ typedef struct gpso_ctx gpso_ctx;
                           /* the reference lets TF's InvalidArgumentError escape here         */
 #define GPSO_E_OOM (-4)   /* device allocation failed                                         */
 #define GPSO_E_STATE (-5) /* call order: no training data / no posterior resident yet         */
-#define GPSO_E_RCCL (-6)  /* reserved for the multi-GPU group calls                           */
+#define GPSO_E_RCCL (-6)  /* an RCCL call of the multi-GPU group failed                        */
+#define GPSO_E_PRECISION (-7) /* float predict arithmetic cannot meet the stated tolerance on this */
+                          /* posterior (measured by the self-test, see gpso_precision_info): open a   */
+                          /* GPSO_MIXED or GPSO_F64 context instead                                   */
 
-/* arithmetic type of a context (what the kernels compute in) */
-#define GPSO_F64 0
-#define GPSO_F32 1
+/* arithmetic type of a context (what the kernels compute in).  Also the type tag of leaf buffers
+ * (xs_dtype: GPSO_F64 | GPSO_F32 only). */
+#define GPSO_F64 0   /* fit and predict in float64 (the reference's dtype: gpflow.default_float)      */
+#define GPSO_F32 1   /* fit (Gram, Cholesky, L^-1, alpha) and predict apply in float32                */
+#define GPSO_MIXED 2 /* fit in float64, predict apply in float32 (or split bf16): the hyper-parameter */
+                     /* path is bit-identical to GPSO_F64, only predictions carry float rounding      */
 
 /* stationary kernels, [gpflow.kernels]: the objects passed as gp_kernel at gpso/gp_surrogate.py:393-434 */
 #define GPSO_MATERN52 0 /* default, gpso/gp_surrogate.py:424 */
@@ -60,6 +66,18 @@ typedef struct gpso_ctx gpso_ctx;
 #define GPSO_OPT_FIT_SINGLE_LEVEL_MAX 2 /* tuning / test hook: largest padded N whose Cholesky runs single-level */
                                         /* with L^-1 built beside it (default 3584, double 2560); 0 = always two-level +     */
                                         /* level-doubling triangular inverse.  Results agree to rounding.       */
+#define GPSO_OPT_GENERATION 3   /* float-predict contexts: arithmetic of the cross-Gram x.x* contraction / r^2 */
+#define GPSO_GEN_F64 0          /*   double (default): r^2 free of float cancellation error                    */
+#define GPSO_GEN_F32 1          /*   float: GPflow's GEMM form evaluated in float (|d r^2| ~ 1e-5 at l ~ 0.1) */
+#define GPSO_OPT_PRECISION_CHECK 4 /* 1: the first predict after every fit runs the self-test and returns       */
+                                   /* GPSO_E_PRECISION when it fails (default in GPSO_F32 / GPSO_MIXED); 0: off  */
+                                   /* (default in GPSO_F64)                                                     */
+#define GPSO_OPT_FIT_FUSED_SMALL 5 /* 1 (default): N <= 128 is fitted by the single-launch, single-workgroup     */
+                                   /* kernel; 0: the general multi-launch path (test hook: results agree to     */
+                                   /* rounding)                                                                 */
+/* floating-point options (gpso_set_option_f64): tolerances of the self-test */
+#define GPSO_OPTF_TOL_VAR 100  /* max |d var| at the training inputs, relative to the kernel variance (default 1e-4; GPSO_F32: 1e-3) */
+#define GPSO_OPTF_TOL_MEAN 101 /* max |d mean| at the training inputs, relative to max |y - c|   (default 1e-4; GPSO_F32: 1e-3) */
 
 /* which device-resident matrix / vector the debug getters copy out (as float64) */
 #define GPSO_MAT_CHOL 0  /* L, lower Cholesky factor of K + noise*I (upper triangle returned as 0) */
@@ -85,6 +103,12 @@ int gpso_synchronize(gpso_ctx* ctx);
  * predict path multiplies by L^-1.  The split-bf16 modes need N padded to a multiple of 256
  * (otherwise the native kernel runs) and keep an extra nsplit * N^2 bf16 copy of L^-1. */
 int gpso_set_option(gpso_ctx* ctx, int option, int value);
+int gpso_set_option_f64(gpso_ctx* ctx, int option, double value);
+/* Order the context's stream behind everything already queued on producer_stream (a hipStream_t, e.g.
+ * torch.cuda.current_stream().cuda_stream; NULL = the legacy default stream): call it before handing
+ * the library device buffers that another stream is still writing (GPSO_MEM_DEVICE leaves / outputs).
+ * The library itself is synchronous at the boundary, so no ordering is needed after a call returns. */
+int gpso_wait_stream(gpso_ctx* ctx, void* producer_stream);
 
 /* ---- fit (GPSurrogate.gp_update -> GPRSurrogate._gp_train) --------------------------------- */
 
@@ -144,15 +168,29 @@ int64_t gpso_padded_n(const gpso_ctx* ctx);
 int gpso_get_matrix(gpso_ctx* ctx, int which, double* out /* [N*N] host */);
 int gpso_get_vector(gpso_ctx* ctx, int which, double* out /* [N] host */);
 
-/* Device pointers + byte sizes of everything a peer GPU needs to predict (packed L^-1, scaled X,
- * norms, alpha, hyper-parameter block), for an RCCL broadcast driven from Python
- * (torch.distributed): fills up to cap entries, returns the count (or a negative status). */
+/* Device pointers + byte sizes of everything a peer GPU needs to predict (packed lower tiles of
+ * L^-1, scaled X, norms, alpha, hyper-parameter block): fills up to cap entries, returns the count
+ * (or a negative status). */
 int gpso_posterior_buffers(gpso_ctx* ctx, void** ptrs, int64_t* nbytes, int cap);
 /* Allocate the same buffers for n, d on a receiving rank so they can be broadcast into. */
 int gpso_alloc_posterior(gpso_ctx* ctx, int64_t n, int d);
 /* After the buffers were filled by a broadcast: mark the posterior resident (reads the
  * hyper-parameter block back from the device). */
 int gpso_adopt_posterior(gpso_ctx* ctx);
+
+/* Precision self-test of the resident posterior (runs it if it has not run since the last fit; needs
+ * the training targets, i.e. a posterior produced by gpso_fit_eval on this context): the predict path
+ * is evaluated at the training inputs, where mean and variance have the closed form
+ * mean_i = y_i - noise alpha_i, var_i = 2 noise - noise^2 (K_y^-1)_ii.  out[10]:
+ *   [0] max |d mean|   [1] max |d var|   [2] max |y - c|   [3] min predicted var (incl. noise)
+ *   [4] max |alpha|    [5] kernel variance   [6] tolerance on [0] (absolute)   [7] tolerance on [1]
+ *   [8] amplification a: 1 for a float64 factor (GPSO_MIXED / GPSO_F64); for a float factor (GPSO_F32)
+ *       max(1, sqrt(sigma^2 max_i (K_y^-1)_ii)) -- the training inputs see the factor's backward error
+ *       unamplified, a general leaf amplified by the solve weights (calibrated heuristic)
+ *   [9] max_i (K_y^-1)_ii
+ * Returns GPSO_OK, GPSO_E_PRECISION when sqrt(a) [0] > [6] or a [1] > [7] (or a value is not finite), or
+ * GPSO_E_STATE when no fitted posterior with targets is resident. */
+int gpso_precision_info(gpso_ctx* ctx, double* out);
 
 /* last-call device timings in milliseconds measured with HIP events on the context's stream:
  * what = 0: dominant predict kernel (leaf tiles) of the last predict/best_ucb call,

@@ -17,14 +17,20 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPSO_HIP_LIB") or os.path.join(_HERE, "libgpso_hip.so")
 
 # status codes / enums (mirror include/gpso_hip.h)
-OK, E_ARG, E_HIP, E_NOTPD, E_OOM, E_STATE, E_RCCL = 0, -1, -2, -3, -4, -5, -6
-F64, F32 = 0, 1
+OK, E_ARG, E_HIP, E_NOTPD, E_OOM, E_STATE, E_RCCL, E_PRECISION = 0, -1, -2, -3, -4, -5, -6, -7
+F64, F32, MIXED = 0, 1, 2
 MATERN52, MATERN32, MATERN12, SQEXP = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
 MAT_CHOL, MAT_LINV, MAT_KINV, MAT_GRAM = 0, 1, 2, 3
 VEC_ALPHA, VEC_WHITE = 0, 1
 OPT_PREDICT_MATH = 1
 OPT_FIT_SINGLE_LEVEL_MAX = 2
+OPT_GENERATION = 3
+OPT_PRECISION_CHECK = 4
+OPTF_TOL_VAR, OPTF_TOL_MEAN = 100, 101
+GEN_F64, GEN_F32 = 0, 1
+GEN_IDS = {"float64": GEN_F64, "f64": GEN_F64, "float32": GEN_F32, "f32": GEN_F32}
+DTYPE_IDS = {"float64": F64, "fp64": F64, "f64": F64, "float32": F32, "fp32": F32, "f32": F32, "mixed": MIXED}
 MATH_NATIVE, MATH_BF16X3, MATH_BF16X6 = 0, 3, 6
 MATH_IDS = {"native": MATH_NATIVE, "f32": MATH_NATIVE, "bf16x3": MATH_BF16X3, "bf16x6": MATH_BF16X6}
 
@@ -48,6 +54,9 @@ SIGNATURES = {
     "gpso_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gpso_synchronize": (C.c_int, [C.c_void_p]),
     "gpso_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "gpso_set_option_f64": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    "gpso_wait_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gpso_precision_info": (C.c_int, [C.c_void_p, _c_double_p]),
     "gpso_set_data": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, C.c_int64, C.c_int]),
     "gpso_fit_eval": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, C.c_int, C.c_double, C.c_double,
                                 C.c_double, _c_double_p, _c_double_p]),
@@ -80,6 +89,11 @@ class GpsoHipError(RuntimeError):
     def __init__(self, code, message):
         super().__init__(f"libgpso_hip error {code}: {message}")
         self.code = code
+
+
+class GpsoPrecisionError(GpsoHipError):
+    """GPSO_E_PRECISION: the float predict arithmetic fails its self-test on the resident posterior
+    (the message carries the measured errors).  Callers open a "mixed" or "float64" engine instead."""
 
 
 def load():

@@ -8,7 +8,10 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <set>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/gpso_hip.h"
@@ -16,6 +19,39 @@
 #include "kernels.hpp"
 
 using namespace gpso;
+
+namespace gpso {
+
+namespace {
+thread_local std::string g_launch_error;
+std::mutex g_lds_mutex;
+std::set<std::pair<const void*, int>> g_lds_done;  // (kernel, device) pairs already opted in
+}  // namespace
+
+void note_launch_error(const char* msg) {
+  if (g_launch_error.empty()) g_launch_error = msg;
+}
+
+int ensure_dyn_lds(const void* fn, int bytes) {
+  if (bytes <= 64 * 1024) return 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    note_launch_error("hipGetDevice failed");
+    return GPSO_E_HIP;
+  }
+  std::lock_guard<std::mutex> lock(g_lds_mutex);
+  if (g_lds_done.count({fn, dev})) return 0;
+  // the attribute belongs to the DEVICE's function object: every device a context lives on opts in
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) {
+    note_launch_error((std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e)).c_str());
+    return GPSO_E_HIP;
+  }
+  g_lds_done.insert({fn, dev});
+  return 0;
+}
+
+}  // namespace gpso
 
 namespace {
 
@@ -53,9 +89,25 @@ struct Engine {
   virtual int adopt_posterior() = 0;
   virtual int64_t padded_n() const = 0;
   virtual int set_option(int option, int value) = 0;
+  virtual int set_option_f64(int option, double value) = 0;
+  virtual int precision_info(double* out) = 0;
 };
 
 }  // namespace
+
+// current-device guard: HIP calls act on the calling thread's current device
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = (prev == dev) || hipSetDevice(dev) == hipSuccess;
+    if (prev == dev) prev = -1;  // nothing to restore
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
 
 struct gpso_ctx {
   int device = 0;
@@ -71,6 +123,8 @@ struct gpso_ctx {
   hipEvent_t ev_wait = nullptr;  // completion marker of the call in flight
   double* pinned = nullptr;      // pinned host scratch for the small result read-backs
   size_t pinned_doubles = 0;
+  double* stage = nullptr;       // pinned staging of small host inputs (training data, bounds)
+  size_t stage_doubles = 0;
 
   // Wait for everything queued on s.  hipStreamSynchronize parks the thread on an interrupt and costs
   // tens of microseconds to wake up -- as much as the device work of a small fit.  The calling thread
@@ -100,8 +154,24 @@ struct gpso_ctx {
     return pinned;
   }
 
+  // staging buffer for host -> device copies that must not force a stream synchronisation.  It is
+  // reused by the next call, so wait for the copies of the previous one first (they are long done in
+  // practice: every entry point ends with a wait on the stream).
+  double* pinned_stage(size_t doubles) {
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (doubles > stage_doubles) {
+      if (stage) (void)hipHostFree(stage);
+      stage = nullptr;
+      stage_doubles = 0;
+      const size_t want = std::max<size_t>(doubles, 4096);
+      if (hipHostMalloc(reinterpret_cast<void**>(&stage), want * 8, hipHostMallocDefault) != hipSuccess) return nullptr;
+      stage_doubles = want;
+    }
+    return stage;
+  }
+
   int fail(int code, const char* fmt, ...) {
-    char buf[512];
+    char buf[768];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
@@ -121,10 +191,20 @@ struct gpso_ctx {
 
 namespace {
 
-template <typename T>
+// TF: fit type (Gram, Cholesky, L^-1, alpha);  TP: predict / apply type.
+//   GPSO_F64   -> EngineT<double, double>
+//   GPSO_F32   -> EngineT<float, float>
+//   GPSO_MIXED -> EngineT<double, float>
+template <typename TF, typename TP>
 struct EngineT : Engine {
   gpso_ctx* ctx;
-  explicit EngineT(gpso_ctx* c) : ctx(c) {}
+  explicit EngineT(gpso_ctx* c) : ctx(c) {
+    check = sizeof(TP) == 4;  // float predict arithmetic: self-test on by default
+    // default tolerances: a double factor with a float apply measures 1e-6 .. 3e-5 (bf16x3) -> 1e-4; an
+    // all-float engine is a 1e-4-class instrument already at noise 1e-3 -> 1e-3
+    tol_var = tol_mean = (sizeof(TF) == 4) ? 1.0e-3 : 1.0e-4;
+  }
+  static constexpr bool kFloatPredict = sizeof(TP) == 4;
 
   // problem
   int64_t n = 0, npad = 0;
@@ -134,58 +214,117 @@ struct EngineT : Engine {
   int n_ls = 1;
   std::vector<double> ls_host;
 
-  // device buffers
-  DevBuf x64, y64, hyper, xs, xnorm, xs_p, K, Lf, linv, work, kinvb, linv_p, white, alpha, logdet, scal, gpart;
-  // split-bf16 copy of L^-1 (float contexts with GPSO_OPT_PREDICT_MATH != native)
+  // device buffers.  Fit side: xs64 / xnorm64 (scaled inputs, always double), K, Lf, linv, work, kinvb,
+  // white, alpha_f in TF.  Predict side: linv_p, alpha in TP; xs_p64 (+ xnorm64) or xs_p32 / xnorm32
+  // in the generation type.
+  DevBuf x64, y64, hyper, xs64, xnorm64, xs_p64, xs32, xnorm32, xs_p32, K, Lf, linv, work, kinvb, linv_p,
+      white, alpha_f, alpha, logdet, scal, gpart, apart, kinv_diag, getter_tmp;
+  // split-bf16 copy of L^-1 (float predict with GPSO_OPT_PREDICT_MATH != native)
   DevBuf linv_b;
   int math = GPSO_MATH_NATIVE;
+  bool gen32 = false;  // GPSO_OPT_GENERATION == GPSO_GEN_F32 (float predict only)
   int64_t single_level_max = -1;  // < 0: library default
+  bool fused_small = true;        // GPSO_OPT_FIT_FUSED_SMALL
   bool linv_b_valid = false;
   std::vector<int64_t> segoff_cache;  // what the device copy of seg_off currently holds
   // predict workspace
   DevBuf leaves_raw, leaves_s, lnorm, pvar, pmean, omean, ovar, oucb, segoff, best, oidx, ovals;
+  // precision self-test
+  bool check = false, st_done = false, st_have = false;
+  double tol_var = 1.0e-4, tol_mean = 1.0e-4;
+  double st_vals[6] = {0, 0, 0, 0, 0, 0};
+  DevBuf st_mean, st_var, st_out;
 
   ~EngineT() override {
-    for (DevBuf* b : {&x64, &y64, &hyper, &xs, &xnorm, &xs_p, &K, &Lf, &linv, &work, &kinvb, &linv_p, &white,
-                      &alpha, &logdet, &scal, &gpart, &leaves_raw, &leaves_s, &lnorm, &pvar, &pmean,
-                      &omean, &ovar, &oucb, &segoff, &best, &oidx, &ovals, &linv_b})
+    for (DevBuf* b : {&x64, &y64, &hyper, &xs64, &xnorm64, &xs_p64, &xs32, &xnorm32, &xs_p32, &K, &Lf, &linv,
+                      &work, &kinvb, &linv_p, &white, &alpha_f, &alpha, &logdet, &scal, &gpart, &apart,
+                      &kinv_diag, &getter_tmp, &leaves_raw, &leaves_s, &lnorm, &pvar, &pmean, &omean, &ovar,
+                      &oucb, &segoff, &best, &oidx, &ovals, &linv_b, &st_mean, &st_var, &st_out})
       if (b->p) (void)hipFree(b->p);
   }
 
   int64_t padded_n() const override { return npad; }
 
+  // generation type actually used: double unless GPSO_GEN_F32 was asked for -- or the split-bf16 kernel
+  // with double leaf fragments would not fit the 160 KB of LDS (D > 24 for bf16x6, > 36 for bf16x3):
+  // those shapes generate in float, and the self-test measures what that costs on the posterior at hand
+  bool gen_double() const {
+    if (!kFloatPredict) return true;
+    if (gen32) return false;
+    if (bf16_usable() && leaf_bf16_lds_bytes(nsplit(), dp / 4, 8) > 160 * 1024) return false;
+    return true;
+  }
   int nsplit() const { return math == GPSO_MATH_BF16X6 ? 3 : 2; }
-  bool bf16_usable() const { return sizeof(T) == 4 && math != GPSO_MATH_NATIVE && npad > 0 && npad % 256 == 0; }
+  bool bf16_usable() const { return kFloatPredict && math != GPSO_MATH_NATIVE && npad > 0 && npad % 256 == 0; }
 
-  // (re)build the bf16 pieces of L^-1 from the f32 L^-1 resident in `linv`
+  // (re)build the bf16 pieces of L^-1 from the fit-type L^-1 resident in `linv`
   int pack_bf16() {
     linv_b_valid = false;
     if (!bf16_usable()) return GPSO_OK;
     int rc = ensure(linv_b, (size_t)nsplit() * npad * npad * 2);
     if (rc) return rc;
-    if constexpr (sizeof(T) == 4) launch_pack_linv_bf16(st(), nsplit(), as<float>(linv), n, npad, linv_b.p);
+    launch_pack_linv_bf16<TF>(st(), nsplit(), as<TF>(linv), n, npad, linv_b.p);
     HIPCHECK(hipGetLastError());
     linv_b_valid = true;
     return GPSO_OK;
   }
 
   int set_option(int option, int value) override {
-    if (option == GPSO_OPT_FIT_SINGLE_LEVEL_MAX) {
-      if (value < 0) return ctx->fail(GPSO_E_ARG, "single-level limit %d must be >= 0", value);
-      single_level_max = value;
-      return GPSO_OK;
+    switch (option) {
+      case GPSO_OPT_FIT_SINGLE_LEVEL_MAX:
+        if (value < 0) return ctx->fail(GPSO_E_ARG, "single-level limit %d must be >= 0", value);
+        single_level_max = value;
+        return GPSO_OK;
+      case GPSO_OPT_FIT_FUSED_SMALL:
+        if (value != 0 && value != 1) return ctx->fail(GPSO_E_ARG, "fused small fit must be 0 or 1");
+        fused_small = value != 0;
+        return GPSO_OK;
+      case GPSO_OPT_PRECISION_CHECK:
+        if (value != 0 && value != 1) return ctx->fail(GPSO_E_ARG, "precision check must be 0 or 1");
+        check = value != 0;
+        return GPSO_OK;
+      case GPSO_OPT_GENERATION:
+        if (value != GPSO_GEN_F64 && value != GPSO_GEN_F32) return ctx->fail(GPSO_E_ARG, "unknown generation mode %d", value);
+        if (!kFloatPredict) {
+          if (value == GPSO_GEN_F32) return ctx->fail(GPSO_E_ARG, "GPSO_GEN_F32 needs a float-predict context");
+          return GPSO_OK;
+        }
+        if ((value == GPSO_GEN_F32) != gen32) {
+          gen32 = value == GPSO_GEN_F32;
+          st_done = false;
+          if (have_post && have_data) return refresh_generation_inputs();
+          if (have_post) return ctx->fail(GPSO_E_STATE, "set GPSO_OPT_GENERATION before installing a posterior");
+        }
+        return GPSO_OK;
+      case GPSO_OPT_PREDICT_MATH:
+        break;
+      default:
+        return ctx->fail(GPSO_E_ARG, "unknown option %d", option);
     }
-    if (option != GPSO_OPT_PREDICT_MATH) return ctx->fail(GPSO_E_ARG, "unknown option %d", option);
     if (value != GPSO_MATH_NATIVE && value != GPSO_MATH_BF16X3 && value != GPSO_MATH_BF16X6)
       return ctx->fail(GPSO_E_ARG, "unknown predict math %d", value);
-    if (value != GPSO_MATH_NATIVE && sizeof(T) != 4)
-      return ctx->fail(GPSO_E_ARG, "split-bf16 predict math needs a GPSO_F32 context");
+    if (value != GPSO_MATH_NATIVE && !kFloatPredict)
+      return ctx->fail(GPSO_E_ARG, "split-bf16 predict math needs a GPSO_F32 or GPSO_MIXED context");
     if (value == math) return GPSO_OK;
     math = value;
     linv_b_valid = false;
-    if (chol_valid) return pack_bf16();  // L^-1 is resident: make the new mode usable right away
+    st_done = false;
+    if (chol_valid) {  // L^-1 is resident: make the new mode usable right away
+      int rc = pack_bf16();
+      if (rc) return rc;
+      if (have_data) return refresh_generation_inputs();
+    }
     return GPSO_OK;
   }
+
+  int set_option_f64(int option, double value) override {
+    if (!(value > 0.0)) return ctx->fail(GPSO_E_ARG, "tolerance %g must be positive", value);
+    if (option == GPSO_OPTF_TOL_VAR) tol_var = value;
+    else if (option == GPSO_OPTF_TOL_MEAN) tol_mean = value;
+    else return ctx->fail(GPSO_E_ARG, "unknown floating-point option %d", option);
+    return GPSO_OK;
+  }
+
   hipStream_t st() const { return ctx->stream; }
   double* ls_dev() const { return static_cast<double*>(hyper.p) + kHyperHeader; }
   template <typename U>
@@ -205,6 +344,17 @@ struct EngineT : Engine {
     return GPSO_OK;
   }
 
+  // launcher-side errors (hipFuncSetAttribute, unsupported GEMM shapes) + the HIP launch status
+  int launch_status() {
+    HIPCHECK(hipGetLastError());
+    if (!gpso::g_launch_error.empty()) {
+      const std::string msg = gpso::g_launch_error;
+      gpso::g_launch_error.clear();
+      return ctx->fail(GPSO_E_HIP, "%s", msg.c_str());
+    }
+    return GPSO_OK;
+  }
+
   int shape(int64_t n_, int d_) {
     if (n_ < 1) return ctx->fail(GPSO_E_ARG, "need at least one training point (n=%lld)", (long long)n_);
     if (d_ < 1 || d_ > kMaxD) return ctx->fail(GPSO_E_ARG, "input dimension %d outside [1, %d]", d_, kMaxD);
@@ -214,27 +364,34 @@ struct EngineT : Engine {
     npad = (n + kPadN - 1) / kPadN * kPadN;
     dp = (d + 3) / 4 * 4;
     int rc;
-    const size_t s = sizeof(T);
     if ((rc = ensure(x64, (size_t)n * d * 8))) return rc;
     if ((rc = ensure(y64, (size_t)n * 8))) return rc;
     if ((rc = ensure(hyper, (size_t)(kHyperHeader + kMaxD) * 8))) return rc;
-    if ((rc = ensure(xs, (size_t)npad * dp * s))) return rc;
-    if ((rc = ensure(xnorm, (size_t)npad * s))) return rc;
-    if ((rc = ensure(xs_p, (size_t)npad * dp * s))) return rc;
-    if ((rc = ensure(linv_p, (size_t)npad * npad * s))) return rc;
-    if ((rc = ensure(alpha, (size_t)npad * s))) return rc;
+    if ((rc = ensure(xs64, (size_t)npad * dp * 8))) return rc;
+    if ((rc = ensure(xnorm64, (size_t)npad * 8))) return rc;
+    if ((rc = ensure(xs_p64, (size_t)npad * dp * 8))) return rc;
+    if (kFloatPredict) {
+      if ((rc = ensure(xs32, (size_t)npad * dp * 4))) return rc;
+      if ((rc = ensure(xnorm32, (size_t)npad * 4))) return rc;
+      if ((rc = ensure(xs_p32, (size_t)npad * dp * 4))) return rc;
+    }
+    if ((rc = ensure(linv_p, packed_linv_elems(npad) * sizeof(TP)))) return rc;
+    if ((rc = ensure(alpha, (size_t)npad * sizeof(TP)))) return rc;
     return GPSO_OK;
   }
 
   int ensure_fit_buffers() {
     int rc;
-    const size_t s = sizeof(T);
+    const size_t s = sizeof(TF);
     if ((rc = ensure(K, (size_t)npad * npad * s))) return rc;
     if ((rc = ensure(Lf, (size_t)npad * npad * s))) return rc;
     if ((rc = ensure(linv, (size_t)npad * npad * s))) return rc;
     if ((rc = ensure(work, (size_t)npad * npad * s))) return rc;
     if ((rc = ensure(white, (size_t)npad * s))) return rc;
+    if ((rc = ensure(alpha_f, (size_t)npad * s))) return rc;
     if ((rc = ensure(logdet, (size_t)npad * 8))) return rc;
+    if ((rc = ensure(kinv_diag, (size_t)npad * 8))) return rc;
+    if ((rc = ensure(apart, alpha_part_doubles(npad) * 8))) return rc;
     if ((rc = ensure(scal, (size_t)(8 + kGradMaxLs + 3) * 8))) return rc;
     const size_t nt = (size_t)(npad / 64);
     if ((rc = ensure(gpart, nt * nt * (size_t)(kGradMaxLs + 2) * 8))) return rc;
@@ -269,16 +426,41 @@ struct EngineT : Engine {
     return GPSO_OK;
   }
 
+  // X / lengthscale for the fit (double) and, packed as MFMA fragments, for the predict generation
+  int scale_inputs() {
+    launch_scale_x<double>(st(), as<double>(x64), n, npad, d, dp, ls_dev(), as<double>(xs64), as<double>(xnorm64),
+                           as<double>(xs_p64));
+    return refresh_generation_inputs();
+  }
+  int refresh_generation_inputs() {
+    if (!gen_double())
+      launch_scale_x<float>(st(), as<double>(x64), n, npad, d, dp, ls_dev(), as<float>(xs32), as<float>(xnorm32),
+                            as<float>(xs_p32));
+    return GPSO_OK;
+  }
+
   // ------------------------------------------------------------------------------------------
   int set_data(const double* X, const double* y, int64_t n_, int d_) override {
     if (!X || !y) return ctx->fail(GPSO_E_ARG, "X / y must not be NULL");
     int rc = shape(n_, d_);
     if (rc) return rc;
-    HIPCHECK(hipMemcpyAsync(x64.p, X, (size_t)n * d * 8, hipMemcpyHostToDevice, st()));
-    HIPCHECK(hipMemcpyAsync(y64.p, y, (size_t)n * 8, hipMemcpyHostToDevice, st()));
-    HIPCHECK(hipStreamSynchronize(st()));
+    // small problems (the optimiser loop: N <= a few hundred) are staged through pinned memory so that
+    // the call needs no stream synchronisation; large ones copy straight from the caller's pages
+    const size_t doubles = (size_t)n * d + (size_t)n;
+    double* stage = doubles <= (1u << 17) ? ctx->pinned_stage(doubles) : nullptr;
+    if (stage) {
+      std::memcpy(stage, X, (size_t)n * d * 8);
+      std::memcpy(stage + (size_t)n * d, y, (size_t)n * 8);
+      HIPCHECK(hipMemcpyAsync(x64.p, stage, (size_t)n * d * 8, hipMemcpyHostToDevice, st()));
+      HIPCHECK(hipMemcpyAsync(y64.p, stage + (size_t)n * d, (size_t)n * 8, hipMemcpyHostToDevice, st()));
+    } else {
+      HIPCHECK(hipMemcpyAsync(x64.p, X, (size_t)n * d * 8, hipMemcpyHostToDevice, st()));
+      HIPCHECK(hipMemcpyAsync(y64.p, y, (size_t)n * 8, hipMemcpyHostToDevice, st()));
+      HIPCHECK(hipStreamSynchronize(st()));
+    }
     have_data = true;
     have_post = have_kinv = chol_valid = false;
+    st_done = st_have = false;
     return GPSO_OK;
   }
 
@@ -290,28 +472,45 @@ struct EngineT : Engine {
     if (rc) return rc;
     if ((rc = set_theta(kernel, ls, n_ls_, variance, noise, mean_c))) return rc;
     have_post = have_kinv = chol_valid = false;
+    st_done = st_have = false;
     hipStream_t s = st();
     HIPCHECK(hipEventRecord(ctx->ev[4], s));
-    launch_scale_x<T>(s, as<double>(x64), n, npad, d, dp, ls_dev(), as<T>(xs), as<T>(xnorm), as<T>(xs_p));
-    launch_gram<T>(s, as<T>(xs), as<T>(xnorm), n, npad, dp, kp, as<T>(K));
-    HIPCHECK(hipMemsetAsync(linv.p, 0, (size_t)npad * npad * sizeof(T), s));
-    const int imax = INT_MAX;
-    int* info_dev = reinterpret_cast<int*>(as<double>(scal) + 1);
-    HIPCHECK(hipMemcpyAsync(info_dev, &imax, sizeof(int), hipMemcpyHostToDevice, s));
-    if (grad && (rc = ensure(kinvb, (size_t)npad * npad * sizeof(T)))) return rc;
-    const int done = launch_potrf<T>(s, as<T>(K), as<T>(Lf), as<T>(linv), as<T>(work),
-                                     grad ? as<T>(kinvb) : nullptr, n, npad, as<double>(logdet), info_dev,
-                                     single_level_max);
-    if (!(done & 1)) launch_trtri<T>(s, as<T>(Lf), as<T>(linv), as<T>(work), npad, kFitOuterPanel);
-    launch_solve_alpha<T>(s, as<T>(linv), as<double>(y64), n, npad, mean_c, as<double>(logdet),
-                          as<T>(white), as<T>(alpha), as<double>(gpart),
-                          as<double>(scal));
-    if (grad)
-      launch_gradient<T>(s, as<T>(linv), as<T>(alpha), as<T>(xs), as<T>(xnorm), n, npad, d, dp, n_ls,
-                         ls_dev(), kp, as<T>(kinvb), (done & 2) != 0, as<double>(gpart), as<double>(scal) + 8);
-    launch_pack_linv<T>(s, as<T>(linv), n, npad, as<T>(linv_p));
+    if (grad && (rc = ensure(kinvb, (size_t)npad * npad * sizeof(TF)))) return rc;
+    if (fused_small && small_fit_eligible(n, dp)) {
+      // N <= 128: the whole evaluation in ONE launch (fit.hip: small_fit_kernel)
+      SmallFitArgs a{};
+      a.x64 = as<double>(x64); a.y64 = as<double>(y64); a.ls = ls_dev();
+      a.n = (int)n; a.d = d; a.dp = dp; a.kernel = kernel; a.n_ls = n_ls; a.want_grad = grad ? 1 : 0;
+      a.variance = variance; a.noise = noise; a.mean_c = mean_c;
+      a.xs64 = as<double>(xs64); a.xnorm64 = as<double>(xnorm64); a.xs_p64 = as<double>(xs_p64);
+      a.Lf = Lf.p; a.linv = linv.p; a.kinv = grad ? kinvb.p : nullptr;
+      a.white = white.p; a.alpha_f = alpha_f.p; a.alpha_p = alpha.p; a.linv_p = linv_p.p;
+      a.diag64 = as<double>(logdet); a.kinv_diag = as<double>(kinv_diag); a.scal = as<double>(scal);
+      if ((rc = launch_small_fit<TF, TP>(s, a))) return launch_status();
+      if ((rc = refresh_generation_inputs())) return rc;
+    } else {
+      if ((rc = scale_inputs())) return rc;
+      launch_gram<TF>(s, as<double>(xs64), as<double>(xnorm64), n, npad, dp, kp, as<TF>(K));
+      HIPCHECK(hipMemsetAsync(linv.p, 0, (size_t)npad * npad * sizeof(TF), s));
+      const int imax = INT_MAX;
+      int* info_dev = reinterpret_cast<int*>(as<double>(scal) + 1);
+      HIPCHECK(hipMemcpyAsync(info_dev, &imax, sizeof(int), hipMemcpyHostToDevice, s));
+      const int done = launch_potrf<TF>(s, as<TF>(K), as<TF>(Lf), as<TF>(linv), as<TF>(work),
+                                        grad ? as<TF>(kinvb) : nullptr, n, npad, as<double>(logdet), info_dev,
+                                        single_level_max);
+      if (!(done & 1)) launch_trtri<TF>(s, as<TF>(Lf), as<TF>(linv), as<TF>(work), npad, kFitOuterPanel);
+      launch_solve_alpha<TF>(s, as<TF>(linv), as<double>(y64), n, npad, mean_c, as<double>(logdet),
+                             as<TF>(white), as<TF>(alpha_f), as<double>(apart), as<double>(kinv_diag),
+                             as<double>(scal));
+      if (grad)
+        launch_gradient<TF>(s, as<TF>(linv), as<TF>(alpha_f), as<double>(xs64), as<double>(xnorm64), n, npad, d, dp,
+                            n_ls, ls_dev(), kp, as<TF>(kinvb), (done & 2) != 0, as<double>(gpart),
+                            as<double>(scal) + 8);
+      launch_pack_linv<TF, TP>(s, as<TF>(linv), n, npad, as<TP>(linv_p));
+      launch_convert_vec<TF, TP>(s, as<TF>(alpha_f), as<TP>(alpha), npad);
+    }
     if ((rc = pack_bf16())) return rc;
-    HIPCHECK(hipGetLastError());
+    if ((rc = launch_status())) return rc;
     HIPCHECK(hipEventRecord(ctx->ev[5], s));
     constexpr size_t kHostDoubles = 8 + kGradMaxLs + 3;
     double* host = ctx->pinned_scratch(kHostDoubles);
@@ -330,7 +529,7 @@ struct EngineT : Engine {
       for (int h = 0; h < n_ls + 3; ++h) grad[h] = host[8 + h];
       have_kinv = true;
     }
-    have_post = chol_valid = true;
+    have_post = chol_valid = st_have = true;
     return GPSO_OK;
   }
 
@@ -342,63 +541,67 @@ struct EngineT : Engine {
     if (rc) return rc;
     if ((rc = ensure_fit_buffers())) return rc;
     if ((rc = set_theta(kernel, ls, n_ls_, variance, noise, mean_c))) return rc;
+    if ((rc = ensure(getter_tmp, (size_t)n * n * 8 + (size_t)n * 8))) return rc;
     hipStream_t s = st();
+    double* tmp = as<double>(getter_tmp);
     HIPCHECK(hipMemcpyAsync(x64.p, X, (size_t)n * d * 8, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(tmp, L, (size_t)n * n * 8, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(tmp + (size_t)n * n, alpha64, (size_t)n * 8, hipMemcpyHostToDevice, s));
     have_data = false;  // y unknown: a later fit needs gpso_set_data
-    double* tmp = nullptr;
-    HIPCHECK(hipMalloc(reinterpret_cast<void**>(&tmp), (size_t)n * n * 8 + (size_t)n * 8));
-    hipError_t e1 = hipMemcpyAsync(tmp, L, (size_t)n * n * 8, hipMemcpyHostToDevice, s);
-    hipError_t e2 = hipMemcpyAsync(tmp + (size_t)n * n, alpha64, (size_t)n * 8, hipMemcpyHostToDevice, s);
-    if (e1 != hipSuccess || e2 != hipSuccess) {
-      (void)hipFree(tmp);
-      return ctx->fail(GPSO_E_HIP, "upload of L / alpha failed");
-    }
-    launch_scale_x<T>(s, as<double>(x64), n, npad, d, dp, ls_dev(), as<T>(xs), as<T>(xnorm), as<T>(xs_p));
-    (void)hipMemsetAsync(linv.p, 0, (size_t)npad * npad * sizeof(T), s);
-    launch_install_chol<T>(s, tmp, n, npad, as<T>(Lf), as<T>(linv));
-    launch_trtri<T>(s, as<T>(Lf), as<T>(linv), as<T>(work), npad, kFitBlock);
-    (void)hipMemsetAsync(alpha.p, 0, (size_t)npad * sizeof(T), s);
-    launch_convert_in<T>(s, tmp + (size_t)n * n, as<T>(alpha), 1, n, npad);
-    launch_pack_linv<T>(s, as<T>(linv), n, npad, as<T>(linv_p));
-    if ((rc = pack_bf16())) {
-      (void)hipFree(tmp);
-      return rc;
-    }
-    hipError_t e3 = hipStreamSynchronize(s);
-    (void)hipFree(tmp);
-    if (e3 != hipSuccess) return ctx->fail(GPSO_E_HIP, "set_posterior: %s", hipGetErrorString(e3));
-    HIPCHECK(hipGetLastError());
+    have_post = have_kinv = chol_valid = false;
+    st_done = st_have = false;
+    if ((rc = scale_inputs())) return rc;
+    HIPCHECK(hipMemsetAsync(linv.p, 0, (size_t)npad * npad * sizeof(TF), s));
+    launch_install_chol<TF>(s, tmp, n, npad, as<TF>(Lf), as<TF>(linv));
+    launch_trtri<TF>(s, as<TF>(Lf), as<TF>(linv), as<TF>(work), npad, kFitBlock);
+    HIPCHECK(hipMemsetAsync(alpha_f.p, 0, (size_t)npad * sizeof(TF), s));
+    launch_convert_in<TF>(s, tmp + (size_t)n * n, as<TF>(alpha_f), 1, n, npad);
+    launch_pack_linv<TF, TP>(s, as<TF>(linv), n, npad, as<TP>(linv_p));
+    launch_convert_vec<TF, TP>(s, as<TF>(alpha_f), as<TP>(alpha), npad);
+    if ((rc = pack_bf16())) return rc;
+    HIPCHECK(hipStreamSynchronize(s));  // the caller's host buffers are free again on return
+    if ((rc = launch_status())) return rc;
     have_post = chol_valid = true;
-    have_kinv = false;
     return GPSO_OK;
   }
 
   // ------------------------------------------------------------------------------------------
-  // leaves already on the device as raw coordinates (dtype xs_dtype) -> mean/var(/ucb) device arrays
-  int score_device_leaves(const void* xs_dev, int xs_dtype, int64_t m, double varsigma, bool want_ucb,
-                          double* mean_dev, double* var_dev, double* ucb_dev) {
+  // leaves already on the device as raw coordinates (dtype xs_dtype) -> mean/var(/ucb) device arrays.
+  // TG = generation type (double unless the context is float-predict with GPSO_GEN_F32).
+  template <typename TG>
+  int score_leaves_t(const void* xs_dev, int xs_dtype, int64_t m, double varsigma, bool want_ucb,
+                     double* mean_dev, double* var_dev, double* ucb_dev, const int64_t* m_live) {
     // row blocks of L^-1 = partial sums per leaf: the split-bf16 kernel always works on 256-row blocks,
     // the native kernels on the shape leaf_tiles_bm picks
     const bool use_bf16 = bf16_usable() && linv_b_valid;
-    const int nbi = use_bf16 ? (int)(npad / 256) : leaf_tiles_nbi<T>(npad, dp / 4);
+    const int nbi = use_bf16 ? (int)(npad / 256) : leaf_tiles_nbi<TP>(npad, dp / 4);
     const int64_t chunk = std::min<int64_t>(m, kLeafChunk);
     const int64_t cpad = (chunk + kLeafPad - 1) / kLeafPad * kLeafPad;
     int rc;
-    if ((rc = ensure(leaves_s, (size_t)cpad * dp * sizeof(T)))) return rc;
-    if ((rc = ensure(lnorm, (size_t)cpad * sizeof(T)))) return rc;
-    if ((rc = ensure(pvar, (size_t)nbi * cpad * sizeof(T)))) return rc;
-    if ((rc = ensure(pmean, (size_t)nbi * cpad * sizeof(T)))) return rc;
+    if ((rc = ensure(leaves_s, (size_t)cpad * dp * sizeof(TG)))) return rc;
+    if ((rc = ensure(lnorm, (size_t)cpad * sizeof(TG)))) return rc;
+    if ((rc = ensure(pvar, (size_t)nbi * cpad * 8))) return rc;
+    if ((rc = ensure(pmean, (size_t)nbi * cpad * 8))) return rc;
     hipStream_t s = st();
     ctx->tile_pairs = 0;
     const size_t in_elem = (xs_dtype == GPSO_F64) ? 8 : 4;
+    const TG* xsp = nullptr;
+    const TG* xnr = nullptr;
+    if constexpr (sizeof(TG) == 8) {
+      xsp = as<double>(xs_p64);
+      xnr = as<double>(xnorm64);
+    } else {
+      xsp = as<float>(xs_p32);
+      xnr = as<float>(xnorm32);
+    }
     for (int64_t off = 0; off < m; off += chunk) {
       const int64_t mc = std::min<int64_t>(chunk, m - off);
       const int64_t mp = (mc + kLeafPad - 1) / kLeafPad * kLeafPad;
       const char* src = static_cast<const char*>(xs_dev) + (size_t)off * d * in_elem;
       if (xs_dtype == GPSO_F64)
-        launch_prep_leaves<T, double>(s, reinterpret_cast<const double*>(src), mc, mp, d, dp, ls_dev(), as<T>(leaves_s), as<T>(lnorm));
+        launch_prep_leaves<TG, double>(s, reinterpret_cast<const double*>(src), mc, mp, d, dp, ls_dev(), m_live, as<TG>(leaves_s), as<TG>(lnorm));
       else
-        launch_prep_leaves<T, float>(s, reinterpret_cast<const float*>(src), mc, mp, d, dp, ls_dev(), as<T>(leaves_s), as<T>(lnorm));
+        launch_prep_leaves<TG, float>(s, reinterpret_cast<const float*>(src), mc, mp, d, dp, ls_dev(), m_live, as<TG>(leaves_s), as<TG>(lnorm));
       while ((int)ctx->tile_ev.size() < 2 * (ctx->tile_pairs + 1)) {
         hipEvent_t e;
         HIPCHECK(hipEventCreate(&e));
@@ -406,21 +609,30 @@ struct EngineT : Engine {
       }
       HIPCHECK(hipEventRecord(ctx->tile_ev[2 * ctx->tile_pairs], s));
       if (use_bf16) {
-        if constexpr (sizeof(T) == 4)
-          launch_leaf_tiles_bf16(s, nsplit(), linv_b.p, as<float>(xs_p), as<float>(xnorm), as<float>(alpha),
-                                 as<float>(leaves_s), as<float>(lnorm), as<float>(pvar), as<float>(pmean),
-                                 npad, dp / 4, mp, kp);
+        if constexpr (kFloatPredict)
+          rc = launch_leaf_tiles_bf16<TG>(s, nsplit(), linv_b.p, xsp, xnr, as<float>(alpha), as<TG>(leaves_s),
+                                          as<TG>(lnorm), as<double>(pvar), as<double>(pmean), npad, dp / 4, mp,
+                                          kp, m_live);
       } else {
-        launch_leaf_tiles<T>(s, as<T>(linv_p), as<T>(xs_p), as<T>(xnorm), as<T>(alpha), as<T>(leaves_s),
-                             as<T>(lnorm), as<T>(pvar), as<T>(pmean), npad, dp / 4, mp, kp);
+        rc = launch_leaf_tiles<TP, TG>(s, as<TP>(linv_p), xsp, xnr, as<TP>(alpha), as<TG>(leaves_s),
+                                       as<TG>(lnorm), as<double>(pvar), as<double>(pmean), npad, dp / 4, mp, kp,
+                                       m_live);
       }
+      if (rc) return launch_status();
       HIPCHECK(hipEventRecord(ctx->tile_ev[2 * ctx->tile_pairs + 1], s));
       ++ctx->tile_pairs;
-      launch_leaf_finalize<T>(s, as<T>(pvar), as<T>(pmean), nbi, mp, mc, kp, varsigma, mean_dev + off,
-                              var_dev + off, want_ucb ? ucb_dev + off : nullptr);
+      launch_leaf_finalize(s, as<double>(pvar), as<double>(pmean), nbi, mp, mc, kp, varsigma, mean_dev + off,
+                           var_dev + off, want_ucb ? ucb_dev + off : nullptr);
     }
-    HIPCHECK(hipGetLastError());
-    return GPSO_OK;  // (no host wait here: the kernel time is read after the call's final sync)
+    return launch_status();  // (no host wait here: the kernel time is read after the call's final sync)
+  }
+
+  int score_device_leaves(const void* xs_dev, int xs_dtype, int64_t m, double varsigma, bool want_ucb,
+                          double* mean_dev, double* var_dev, double* ucb_dev, const int64_t* m_live = nullptr) {
+    if constexpr (kFloatPredict) {
+      if (!gen_double()) return score_leaves_t<float>(xs_dev, xs_dtype, m, varsigma, want_ucb, mean_dev, var_dev, ucb_dev, m_live);
+    }
+    return score_leaves_t<double>(xs_dev, xs_dtype, m, varsigma, want_ucb, mean_dev, var_dev, ucb_dev, m_live);
   }
 
   // after the stream has been synchronised: total leaf-tile kernel time of the call
@@ -432,6 +644,72 @@ struct EngineT : Engine {
     }
     ctx->last_ms[0] = total;
     ctx->tile_pairs = 0;
+  }
+
+  // ---- precision self-test (see fit.hip: selftest_kernel) ---------------------------------------
+  double tol_var_abs() const { return tol_var * kp.variance; }
+  double tol_mean_abs() const { return tol_mean * std::max(st_vals[2], 1.0e-300); }
+  // A float FACTOR (GPSO_F32) carries a backward error E that the training inputs see unamplified (there
+  // the solve weights w = K_y^-1 k_i are ~ a unit vector) but a general leaf sees as w^T E w, i.e. times
+  // |w|_1^2 <= sigma^2 |K_y^-1| =: kappa.  The bound itself is far too pessimistic (measured |w|^2 at the
+  // leaves: 440 where kappa ~ 2.6e4); sqrt(kappa), with kappa estimated from max_i (K_y^-1)_ii, is a
+  // CALIBRATED HEURISTIC: it covers every float32 case of tools/fuzz_gpu.py and tools/precision_probe.py
+  // (profiles/r02*_precision*.jsonl).  GPSO_MIXED (double factor) needs no such factor and is exact.
+  double amplification() const {
+    return sizeof(TF) == 4 ? std::max(1.0, std::sqrt(kp.variance * st_vals[5])) : 1.0;
+  }
+  bool st_pass() const {
+    const bool finite = std::isfinite(st_vals[0]) && std::isfinite(st_vals[1]) && std::isfinite(st_vals[3]);
+    const double amp = amplification();  // var: w^T E w ~ |w|^2; mean: w^T E alpha ~ |w|
+    return finite && st_vals[0] * std::sqrt(amp) <= tol_mean_abs() && st_vals[1] * amp <= tol_var_abs();
+  }
+  int run_selftest() {
+    if (st_done) return GPSO_OK;
+    if (!st_have || !have_data) return ctx->fail(GPSO_E_STATE, "self-test needs a posterior fitted on this context (gpso_fit_eval)");
+    int rc;
+    if ((rc = ensure(st_mean, (size_t)n * 8))) return rc;
+    if ((rc = ensure(st_var, (size_t)n * 8))) return rc;
+    if ((rc = ensure(st_out, 8 * 8))) return rc;  // 6 used
+    if ((rc = score_device_leaves(x64.p, GPSO_F64, n, 0.0, false, as<double>(st_mean), as<double>(st_var), nullptr))) return rc;
+    launch_selftest<TF>(st(), as<double>(st_mean), as<double>(st_var), as<double>(y64), as<TF>(alpha_f),
+                        as<double>(kinv_diag), n, kp.noise, kp.mean_c, as<double>(st_out));
+    double* host = ctx->pinned_scratch(8);
+    if (!host) return ctx->fail(GPSO_E_OOM, "pinned host scratch");
+    HIPCHECK(hipMemcpyAsync(host, st_out.p, 6 * 8, hipMemcpyDeviceToHost, st()));
+    HIPCHECK(ctx->wait(st()));
+    if ((rc = launch_status())) return rc;
+    for (int i = 0; i < 6; ++i) st_vals[i] = host[i];
+    st_done = true;
+    return GPSO_OK;
+  }
+  // called at the top of every predict-type entry point
+  int precision_gate() {
+    if (!check || !st_have || !have_data) return GPSO_OK;  // posteriors installed from outside carry no targets
+    int rc = run_selftest();
+    if (rc) return rc;
+    if (!st_pass())
+      return ctx->fail(GPSO_E_PRECISION,
+                       "float predict arithmetic fails the self-test on this posterior: at the training inputs "
+                       "max |d mean| = %.3g (tolerance %.3g), max |d var| = %.3g (tolerance %.3g = %.1e sigma^2), "
+                       "amplification applied %.3g (float factor: sigma^2 max (K_y^-1)_ii), min predicted var %.3g "
+                       "at noise %.3g, max |alpha| %.3g; use a GPSO_MIXED or GPSO_F64 context",
+                       st_vals[0], tol_mean_abs(), st_vals[1], tol_var_abs(), tol_var, amplification(), st_vals[3],
+                       kp.noise, st_vals[4]);
+    return GPSO_OK;
+  }
+  int precision_info(double* out) override {
+    if (!have_post) return ctx->fail(GPSO_E_STATE, "no posterior resident");
+    int rc = run_selftest();
+    if (rc) return rc;
+    for (int i = 0; i < 5; ++i) out[i] = st_vals[i];
+    out[5] = kp.variance;
+    out[6] = tol_mean_abs();
+    out[7] = tol_var_abs();
+    out[8] = amplification();
+    out[9] = st_vals[5];
+    if (!st_pass()) return ctx->fail(GPSO_E_PRECISION, "self-test: max |d mean| %.3g (tol %.3g), max |d var| %.3g (tol %.3g), amplification %.3g",
+                                     st_vals[0], out[6], st_vals[1], out[7], out[8]);
+    return GPSO_OK;
   }
 
   int stage_leaves(const void* xs, int xs_dtype, int xs_mem, int64_t m, const void** dev_ptr) {
@@ -453,7 +731,7 @@ struct EngineT : Engine {
     if (m > 0 && !xs) return ctx->fail(GPSO_E_ARG, "xs must not be NULL");
     if (xs_dtype != GPSO_F64 && xs_dtype != GPSO_F32) return ctx->fail(GPSO_E_ARG, "bad xs_dtype %d", xs_dtype);
     if (xs_mem != GPSO_MEM_HOST && xs_mem != GPSO_MEM_DEVICE) return ctx->fail(GPSO_E_ARG, "bad xs_mem %d", xs_mem);
-    return GPSO_OK;
+    return precision_gate();
   }
 
   int predict(const void* xs, int xs_dtype, int xs_mem, int64_t m, double* mean, double* var,
@@ -521,7 +799,7 @@ struct EngineT : Engine {
     HIPCHECK(hipMemcpyAsync(vals, ovals.p, (size_t)nseg * 32, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipEventRecord(ctx->ev[3], s));
     HIPCHECK(ctx->wait(s));
-    HIPCHECK(hipGetLastError());
+    if ((rc = launch_status())) return rc;
     collect_tile_ms();
     for (int i = 0; i < nseg; ++i) {
       if (idx) std::memcpy(&idx[i], &vals[4 * i + 3], 8);
@@ -559,10 +837,12 @@ struct EngineT : Engine {
     // bounds live behind the generated rows in the same buffer
     if ((rc = ensure(leaves_raw, ob + bb))) return rc;
     double* bdev = reinterpret_cast<double*>(static_cast<char*>(leaves_raw.p) + ob);
-    HIPCHECK(hipMemcpyAsync(bdev, bounds, bb, hipMemcpyHostToDevice, st()));
+    double* stage = ctx->pinned_stage((size_t)nseg * d_ * 2);
+    if (!stage) return ctx->fail(GPSO_E_OOM, "pinned host staging");
+    std::memcpy(stage, bounds, bb);
+    HIPCHECK(hipMemcpyAsync(bdev, stage, bb, hipMemcpyHostToDevice, st()));
     launch_grow(st(), bdev, nseg, d_, depth, as<double>(leaves_raw));
-    HIPCHECK(hipGetLastError());
-    return GPSO_OK;
+    return launch_status();
   }
 
   int grow(const double* bounds, int nseg, int d_, int depth, double* out) override {
@@ -579,10 +859,11 @@ struct EngineT : Engine {
   int best_ucb_grow(const double* bounds, int nseg, int depth, double varsigma, int64_t* idx,
                     double* mean, double* var, double* ucb) override {
     if (!have_post) return ctx->fail(GPSO_E_STATE, "no posterior resident: call gpso_fit_eval / gpso_set_posterior first");
+    int rc = precision_gate();
+    if (rc) return rc;
     HIPCHECK(hipEventRecord(ctx->ev[2], st()));
     int64_t rows = 0;
-    int rc = grow_to_device(bounds, nseg, d, depth, &rows);
-    if (rc) return rc;
+    if ((rc = grow_to_device(bounds, nseg, d, depth, &rows))) return rc;
     std::vector<int64_t> so(nseg + 1);
     for (int i = 0; i <= nseg; ++i) so[i] = (int64_t)i * rows;
     return best_ucb_device(leaves_raw.p, GPSO_F64, (int64_t)nseg * rows, so.data(), nseg, varsigma,
@@ -592,58 +873,55 @@ struct EngineT : Engine {
   // ------------------------------------------------------------------------------------------
   int get_matrix(int which, double* out) override {
     if (!out) return ctx->fail(GPSO_E_ARG, "out must not be NULL");
-    const T* src = nullptr;
+    const TF* src = nullptr;
     int lower = 1;
     switch (which) {
       case GPSO_MAT_CHOL:
         if (!chol_valid) return ctx->fail(GPSO_E_STATE, "no factor resident");
-        src = as<T>(Lf);
+        src = as<TF>(Lf);
         break;
       case GPSO_MAT_LINV:
         if (!chol_valid) return ctx->fail(GPSO_E_STATE, "no factor resident");
-        src = as<T>(linv);
+        src = as<TF>(linv);
         break;
       case GPSO_MAT_KINV:
         if (!have_kinv) return ctx->fail(GPSO_E_STATE, "Kinv only exists after gpso_fit_eval with grad");
-        src = as<T>(kinvb);
+        src = as<TF>(kinvb);
         lower = 2;
         break;
       default:
         return ctx->fail(GPSO_E_ARG, "unknown matrix id %d", which);
     }
-    double* tmp = nullptr;
-    HIPCHECK(hipMalloc(reinterpret_cast<void**>(&tmp), (size_t)n * n * 8));
-    launch_convert_out<T>(st(), src, npad, tmp, n, n, lower);
-    hipError_t e = hipMemcpyAsync(out, tmp, (size_t)n * n * 8, hipMemcpyDeviceToHost, st());
-    if (e == hipSuccess) e = hipStreamSynchronize(st());
-    (void)hipFree(tmp);
-    if (e != hipSuccess) return ctx->fail(GPSO_E_HIP, "get_matrix: %s", hipGetErrorString(e));
+    int rc = ensure(getter_tmp, (size_t)n * n * 8);
+    if (rc) return rc;
+    launch_convert_out<TF>(st(), src, npad, as<double>(getter_tmp), n, n, lower);
+    HIPCHECK(hipMemcpyAsync(out, getter_tmp.p, (size_t)n * n * 8, hipMemcpyDeviceToHost, st()));
+    HIPCHECK(hipStreamSynchronize(st()));
     return GPSO_OK;
   }
 
   int get_vector(int which, double* out) override {
     if (!out) return ctx->fail(GPSO_E_ARG, "out must not be NULL");
-    if (!have_post) return ctx->fail(GPSO_E_STATE, "no posterior resident");
-    const T* src = (which == GPSO_VEC_ALPHA) ? as<T>(alpha) : (which == GPSO_VEC_WHITE) ? as<T>(white) : nullptr;
+    if (!have_post || !chol_valid) return ctx->fail(GPSO_E_STATE, "no fitted posterior resident");
+    const TF* src = (which == GPSO_VEC_ALPHA) ? as<TF>(alpha_f) : (which == GPSO_VEC_WHITE) ? as<TF>(white) : nullptr;
     if (!src) return ctx->fail(GPSO_E_ARG, "unknown vector id %d", which);
-    double* tmp = nullptr;
-    HIPCHECK(hipMalloc(reinterpret_cast<void**>(&tmp), (size_t)n * 8));
-    launch_convert_out<T>(st(), src, npad, tmp, 1, n, 0);
-    hipError_t e = hipMemcpyAsync(out, tmp, (size_t)n * 8, hipMemcpyDeviceToHost, st());
-    if (e == hipSuccess) e = hipStreamSynchronize(st());
-    (void)hipFree(tmp);
-    if (e != hipSuccess) return ctx->fail(GPSO_E_HIP, "get_vector: %s", hipGetErrorString(e));
+    int rc = ensure(getter_tmp, (size_t)n * 8);
+    if (rc) return rc;
+    launch_convert_out<TF>(st(), src, npad, as<double>(getter_tmp), 1, n, 0);
+    HIPCHECK(hipMemcpyAsync(out, getter_tmp.p, (size_t)n * 8, hipMemcpyDeviceToHost, st()));
+    HIPCHECK(hipStreamSynchronize(st()));
     return GPSO_OK;
   }
 
   int posterior_buffers(void** ptrs, int64_t* nbytes, int cap) override {
     if (npad == 0) return ctx->fail(GPSO_E_STATE, "no problem shape yet");
     if (cap < 5) return ctx->fail(GPSO_E_ARG, "need room for 5 buffers");
-    const size_t s = sizeof(T);
+    const size_t s = sizeof(TP);
+    const bool g64 = gen_double();
     ptrs[0] = hyper.p;  nbytes[0] = (int64_t)(kHyperHeader + kMaxD) * 8;
-    ptrs[1] = linv_p.p; nbytes[1] = (int64_t)(npad * npad * s);
-    ptrs[2] = xs_p.p;   nbytes[2] = (int64_t)(npad * dp * s);
-    ptrs[3] = xnorm.p;  nbytes[3] = (int64_t)(npad * s);
+    ptrs[1] = linv_p.p; nbytes[1] = (int64_t)(packed_linv_elems(npad) * s);
+    ptrs[2] = g64 ? xs_p64.p : xs_p32.p;   nbytes[2] = (int64_t)(npad * dp * (g64 ? 8 : 4));
+    ptrs[3] = g64 ? xnorm64.p : xnorm32.p; nbytes[3] = (int64_t)(npad * (g64 ? 8 : 4));
     ptrs[4] = alpha.p;  nbytes[4] = (int64_t)(npad * s);
     if (bf16_usable()) {
       if (cap < 6) return ctx->fail(GPSO_E_ARG, "need room for 6 buffers");
@@ -659,13 +937,15 @@ struct EngineT : Engine {
     int rc = shape(n_, d_);
     if (rc) return rc;
     have_data = have_post = have_kinv = chol_valid = false;
+    st_done = st_have = false;
     return GPSO_OK;
   }
 
   int adopt_posterior() override {
     if (npad == 0) return ctx->fail(GPSO_E_STATE, "gpso_alloc_posterior first");
-    double h[kHyperHeader + kMaxD];
-    HIPCHECK(hipMemcpyAsync(h, hyper.p, sizeof(h), hipMemcpyDeviceToHost, st()));
+    double* h = ctx->pinned_scratch(kHyperHeader + kMaxD);
+    if (!h) return ctx->fail(GPSO_E_OOM, "pinned host scratch");
+    HIPCHECK(hipMemcpyAsync(h, hyper.p, (size_t)(kHyperHeader + kMaxD) * 8, hipMemcpyDeviceToHost, st()));
     HIPCHECK(hipStreamSynchronize(st()));
     if ((int64_t)h[0] != n || (int)h[1] != d)
       return ctx->fail(GPSO_E_ARG, "received posterior is for n=%lld d=%d, buffers were sized for n=%lld d=%d",
@@ -678,6 +958,7 @@ struct EngineT : Engine {
     ls_host.assign(h + kHyperHeader, h + kHyperHeader + n_ls);
     have_post = true;
     chol_valid = have_kinv = false;
+    st_done = st_have = false;     // the fitting rank ran the self-test; no targets here
     linv_b_valid = bf16_usable();  // the bf16 pieces travel with the posterior when the mode is on
     return GPSO_OK;
   }
@@ -694,8 +975,8 @@ int gpso_create(gpso_ctx** out, int device, int dtype) {
     return GPSO_E_ARG;
   }
   *out = nullptr;
-  if (dtype != GPSO_F64 && dtype != GPSO_F32) {
-    g_create_error = "dtype must be GPSO_F64 or GPSO_F32";
+  if (dtype != GPSO_F64 && dtype != GPSO_F32 && dtype != GPSO_MIXED) {
+    g_create_error = "dtype must be GPSO_F64, GPSO_F32 or GPSO_MIXED";
     return GPSO_E_ARG;
   }
   int count = 0;
@@ -708,8 +989,9 @@ int gpso_create(gpso_ctx** out, int device, int dtype) {
     g_create_error = "device index out of range";
     return GPSO_E_ARG;
   }
-  if ((e = hipSetDevice(device)) != hipSuccess) {
-    g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+  DeviceGuard guard(device);  // the caller's current device is restored on return
+  if (!guard.ok) {
+    g_create_error = "hipSetDevice failed";
     return GPSO_E_HIP;
   }
   gpso_ctx* ctx = new gpso_ctx();
@@ -733,16 +1015,18 @@ int gpso_create(gpso_ctx** out, int device, int dtype) {
       return GPSO_E_HIP;
     }
   if (dtype == GPSO_F64)
-    ctx->eng = new EngineT<double>(ctx);
+    ctx->eng = new EngineT<double, double>(ctx);
+  else if (dtype == GPSO_F32)
+    ctx->eng = new EngineT<float, float>(ctx);
   else
-    ctx->eng = new EngineT<float>(ctx);
+    ctx->eng = new EngineT<double, float>(ctx);
   *out = ctx;
   return GPSO_OK;
 }
 
 void gpso_destroy(gpso_ctx* ctx) {
   if (!ctx) return;
-  (void)hipSetDevice(ctx->device);
+  DeviceGuard guard(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   delete ctx->eng;
   for (auto& ev : ctx->ev)
@@ -750,6 +1034,7 @@ void gpso_destroy(gpso_ctx* ctx) {
   for (auto& ev : ctx->tile_ev) (void)hipEventDestroy(ev);
   if (ctx->ev_wait) (void)hipEventDestroy(ctx->ev_wait);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->stage) (void)hipHostFree(ctx->stage);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -758,9 +1043,12 @@ const char* gpso_last_error(const gpso_ctx* ctx) {
   return ctx ? ctx->err.c_str() : g_create_error.c_str();
 }
 
-#define ENTER()                                         \
-  if (!ctx) return GPSO_E_ARG;                          \
-  if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail(GPSO_E_HIP, "hipSetDevice failed");
+// every entry point runs on the context's device and puts the caller's current device back on return
+#define ENTER()                                                              \
+  if (!ctx) return GPSO_E_ARG;                                               \
+  DeviceGuard guard_(ctx->device);                                           \
+  if (!guard_.ok) return ctx->fail(GPSO_E_HIP, "hipSetDevice(%d) failed", ctx->device); \
+  gpso::g_launch_error.clear();
 
 int gpso_set_stream(gpso_ctx* ctx, void* hip_stream) {
   ENTER();
@@ -778,6 +1066,26 @@ int gpso_synchronize(gpso_ctx* ctx) {
 int gpso_set_option(gpso_ctx* ctx, int option, int value) {
   ENTER();
   return ctx->eng->set_option(option, value);
+}
+
+int gpso_set_option_f64(gpso_ctx* ctx, int option, double value) {
+  ENTER();
+  return ctx->eng->set_option_f64(option, value);
+}
+
+int gpso_wait_stream(gpso_ctx* ctx, void* producer_stream) {
+  ENTER();
+  hipStream_t prod = static_cast<hipStream_t>(producer_stream);
+  if (prod == ctx->stream) return GPSO_OK;
+  HIPCHECK(hipEventRecord(ctx->ev_wait, prod));
+  HIPCHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_wait, 0));
+  return GPSO_OK;
+}
+
+int gpso_precision_info(gpso_ctx* ctx, double* out) {
+  ENTER();
+  if (!out) return ctx->fail(GPSO_E_ARG, "out must not be NULL");
+  return ctx->eng->precision_info(out);
 }
 
 int gpso_set_data(gpso_ctx* ctx, const double* X, const double* y, int64_t n, int d) {
@@ -867,6 +1175,6 @@ double gpso_last_ms(gpso_ctx* ctx, int what) {
   return ctx->last_ms[what];
 }
 
-const char* gpso_version(void) { return "gpso-hip 0.1.0 (gfx950)"; }
+const char* gpso_version(void) { return "gpso-hip 0.2.0 (gfx950)"; }
 
 }  // extern "C"

@@ -165,6 +165,29 @@ __device__ __forceinline__ double dkern_dr2(int kernel, double r2, double varian
   return -variance * 0.5 * exp(-r) / r;
 }
 
+// k(r^2) with a run-time kernel id: float as kern_from_r2; double with the lean exp / sqrt (the
+// library calls were most of the Gram kernel's time in double)
+__device__ __forceinline__ float kern_from_r2_lean(int kernel, float r2, float variance) {
+  return kern_from_r2(kernel, r2, variance);
+}
+__device__ __forceinline__ double kern_from_r2_lean(int kernel, double r2, double variance) {
+  if (kernel == 3) return variance * exp_lean(-0.5 * r2);
+  const double r = sqrt_lean(fmax(r2, 1e-36));
+  if (kernel == 0) {
+    const double s5 = 2.23606797749978969641;
+    return variance * (1.0 + s5 * r + (5.0 / 3.0) * (r * r)) * exp_lean(-s5 * r);
+  }
+  if (kernel == 1) {
+    const double s3 = 1.73205080756887729353;
+    return variance * (1.0 + s3 * r) * exp_lean(-s3 * r);
+  }
+  // (the negation is kept out of the optimiser's reach: with a run-time kernel id hipcc 7.2 -O3 folded
+  // it into the merged branches wrongly here -- exp(+r), and 1e220 on the diagonal; tools/micro/gram_check.hip)
+  double mr = -r;
+  asm volatile("" : "+v"(mr));
+  return variance * exp_lean(mr);
+}
+
 // k and dk/d(r^2) together with the lean exp / sqrt (full double precision, no special-case handling:
 // every argument of exp is <= 0 and r^2 is clamped away from 0) -- the gradient kernel evaluates both
 // per matrix entry and the library calls were most of its time

@@ -26,6 +26,8 @@ namespace gpso {
 // =============================================================================================
 // scale + pack inputs
 // =============================================================================================
+// xs / xnorm feed the Gram and gradient kernels (always double, see gram_kernel); xs_p is the
+// MFMA-fragment packing the predict kernels stream, in THEIR generation type T.
 template <typename T>
 __global__ __launch_bounds__(256) void scale_x_kernel(const double* __restrict__ x64, int64_t n,
                                                       int64_t npad, int d, int dp,
@@ -63,56 +65,84 @@ void launch_scale_x(hipStream_t st, const double* x64, int64_t n, int64_t npad, 
                     const double* ls, T* xs, T* xnorm, T* xs_p) {
   hipLaunchKernelGGL((scale_x_kernel<T>), dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, st,
                      x64, n, npad, d, dp, ls, xs, xnorm);
-  hipLaunchKernelGGL((pack_xs_kernel<T>), dim3((unsigned)((npad * dp + 255) / 256)), dim3(256), 0,
-                     st, xs, npad, dp, xs_p);
+  if (xs_p != nullptr)
+    hipLaunchKernelGGL((pack_xs_kernel<T>), dim3((unsigned)((npad * dp + 255) / 256)), dim3(256), 0,
+                       st, xs, npad, dp, xs_p);
 }
 template void launch_scale_x<float>(hipStream_t, const double*, int64_t, int64_t, int, int, const double*, float*, float*, float*);
 template void launch_scale_x<double>(hipStream_t, const double*, int64_t, int64_t, int, int, const double*, double*, double*, double*);
 
 // =============================================================================================
-// Gram matrix: one wave per 16x16 tile, x.x^T on MFMA, kernel map as epilogue
+// Gram matrix, lower 64x64 tiles only: x.x^T on the f64 MFMA, kernel map as epilogue
 // =============================================================================================
+// One workgroup per tile (ti >= tj; 1-D grid: a 2-D grid whose upper half exits at once leaves the 8
+// XCDs unevenly loaded), one wave per 16-row strip.  r^2 = |x|^2 + |x'|^2 - 2 x.x' is ALWAYS formed in
+// double from double inputs, whatever the matrix type T: in float that cancellation leaves ~1e-5 of
+// absolute error in r^2 at the reference's lengthscales, i.e. a relative perturbation of K that the
+// conditioning of K + sigma_n^2 I (1e6..1e7 at GPflow's noise floor) turns into a wrong posterior
+// (measured: NLML off by 1.5e-3, negative variances -- profiles/r02a_precision_before.jsonl).  The
+// contraction is D / 4 MFMAs per 16x16 tile and the kernel is bound by its N^2 / 2 * s bytes of stores.
+// The four column tiles of a strip are INTERLEAVED (tile x, lane index i <-> column 4 i + x) so that a
+// lane owns 4 consecutive columns: 16-byte (float) / 32-byte (double) stores, 256 / 512 contiguous
+// bytes per row and instruction.
 template <typename T>
-__global__ __launch_bounds__(256) void gram_kernel(const T* __restrict__ xs,
-                                                   const T* __restrict__ xnorm, int64_t n,
-                                                   int64_t npad, int dp, int kernel, T variance,
-                                                   T noise, T* __restrict__ K) {
-  using M = Mfma<T>;
-  using vec4 = typename M::vec4;
+__global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ xs,
+                                                   const double* __restrict__ xnorm, int64_t n,
+                                                   int64_t npad, int dp, int kernel, double variance,
+                                                   double noise, T* __restrict__ K) {
+  using vec4 = typename Mfma<T>::vec4;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t i0 = (int64_t)blockIdx.y * 16;
-  const int64_t j0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
-  vec4 s{0, 0, 0, 0};
+  const int64_t blk = blockIdx.x;
+  int ti = (int)((__builtin_sqrtf(8.0f * (float)blk + 1.0f) - 1.0f) * 0.5f);
+  while ((int64_t)(ti + 1) * (ti + 2) / 2 <= blk) ++ti;
+  while ((int64_t)ti * (ti + 1) / 2 > blk) --ti;
+  const int tj = (int)(blk - (int64_t)ti * (ti + 1) / 2);
+  const int64_t i0 = (int64_t)ti * 64 + wave * 16;
+  const int64_t j0 = (int64_t)tj * 64;
+  f64x4 s[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) s[x] = f64x4{0, 0, 0, 0};
   for (int c = 0; c < dp / 4; ++c) {
-    const T a = xs[(i0 + (lane & 15)) * dp + 4 * c + (lane >> 4)];
-    const T b = xs[(j0 + (lane & 15)) * dp + 4 * c + (lane >> 4)];
-    s = M::mma(a, b, s);
+    const double a = xs[(i0 + (lane & 15)) * dp + 4 * c + (lane >> 4)];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const double b = xs[(j0 + 4 * (lane & 15) + x) * dp + 4 * c + (lane >> 4)];
+      s[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, s[x], 0, 0, 0);
+    }
   }
-  const int64_t j = j0 + (lane & 15);
-  const T nbj = xnorm[j];
+  const int64_t jc = j0 + 4 * (lane & 15);  // first of this lane's 4 columns
+  double nbj[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) nbj[x] = xnorm[jc + x];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int64_t i = i0 + M::crow(lane, r);
-    T v;
-    if (i < n && j < n) {
-      const T r2 = T(-2) * s[r] + (xnorm[i] + nbj);
-      v = kern_from_r2(kernel, r2, variance);
-      if (i == j) v += noise;
-    } else {
-      v = (i == j) ? T(1) : T(0);
+    const int64_t i = i0 + (lane >> 4) + 4 * r;  // f64 accumulator layout
+    const double nai = xnorm[i];
+    vec4 v;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const int64_t j = jc + x;
+      if (i < n && j < n) {
+        const double r2 = fma(-2.0, s[x][r], nai + nbj[x]);
+        T kv = kern_from_r2_lean(kernel, (T)r2, (T)variance);
+        if (i == j) kv += (T)noise;
+        v[x] = kv;
+      } else {
+        v[x] = (i == j) ? T(1) : T(0);
+      }
     }
-    K[i * npad + j] = v;
+    *reinterpret_cast<vec4*>(K + i * npad + jc) = v;
   }
 }
 
 template <typename T>
-void launch_gram(hipStream_t st, const T* xs, const T* xnorm, int64_t n, int64_t npad, int dp,
+void launch_gram(hipStream_t st, const double* xs, const double* xnorm, int64_t n, int64_t npad, int dp,
                  const KernParams& kp, T* K) {
-  const dim3 grid((unsigned)(npad / 64), (unsigned)(npad / 16));
-  hipLaunchKernelGGL((gram_kernel<T>), grid, dim3(256), 0, st, xs, xnorm, n, npad, dp, kp.kernel,
-                     (T)kp.variance, (T)kp.noise, K);
+  const int64_t nt = npad / 64;
+  hipLaunchKernelGGL((gram_kernel<T>), dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, st, xs, xnorm, n,
+                     npad, dp, kp.kernel, kp.variance, kp.noise, K);
 }
-template void launch_gram<float>(hipStream_t, const float*, const float*, int64_t, int64_t, int, const KernParams&, float*);
+template void launch_gram<float>(hipStream_t, const double*, const double*, int64_t, int64_t, int, const KernParams&, float*);
 template void launch_gram<double>(hipStream_t, const double*, const double*, int64_t, int64_t, int, const KernParams&, double*);
 
 // =============================================================================================
@@ -426,7 +456,7 @@ __global__ __launch_bounds__(256) void trinv_diag_kernel(const T* __restrict__ L
 }
 
 // =============================================================================================
-// generic batched 64x64-tile GEMM on MFMA 16x16x4:  C = alpha * opA * opB + beta * C
+// batched tile GEMM descriptor:  C = alpha * opA * opB + beta * C
 // =============================================================================================
 struct GemmDesc {
   const void* A;
@@ -444,125 +474,11 @@ struct GemmDesc {
   int kmode;       // 0: all k | 1: k >= TS tj | 2: k >= TS ti | 3: k < TS (ti + 1) | 4: k < TS (tj + 1)
 };
 
-constexpr int kGK = 32;       // k-step staged in LDS
-constexpr int kGS = kGK + 4;  // LDS row stride (keeps vec4 alignment)
-
-// WT = wave tile edge in 16-element units: the workgroup (4 waves, 2 x 2) computes a TS x TS tile
-// with TS = 32 * WT (64 for WT = 2, 128 for WT = 4).  Staging: every thread moves TS/8 vec4 per
-// operand and k-step with 16-byte global loads along whichever index is contiguous, prefetched into
-// registers one k-step ahead of the MFMAs (the first version waited per scalar load: 14 us for a
-// 64^3 product).  kmode trims the k range of triangular operands at tile granularity.
-template <typename T, int WT>
-__global__ __launch_bounds__(256) void gemm_tile_kernel(GemmDesc g) {
-  using M = Mfma<T>;
-  using vec4 = typename M::vec4;
-  constexpr int TS = 32 * WT;
-  constexpr int NV = TS / 32;  // vec4 per thread, operand and k-step: TS * 32 / 4 / 256
-  __shared__ __align__(32) T As[TS * kGS];
-  __shared__ __align__(32) T Bs[TS * kGS];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int ti = blockIdx.y, tj = blockIdx.x, bz = blockIdx.z;
-  if (g.lower_only && tj > ti) return;
-  const int m_here = (bz == g.nbatch - 1) ? g.m_last : g.m;
-  if (ti * TS >= m_here) return;
-  const T* A = static_cast<const T*>(g.A) + (int64_t)bz * g.batchA;
-  const T* B = static_cast<const T*>(g.B) + (int64_t)bz * g.batchB;
-  T* C = static_cast<T*>(g.C) + (int64_t)bz * g.batchC;
-
-  int k_lo = 0, k_hi = g.k;
-  if (g.kmode == 1) k_lo = TS * tj;
-  if (g.kmode == 2) k_lo = TS * ti;
-  if (g.kmode == 3) k_hi = min(g.k, TS * (ti + 1));
-
-  const int wr = wave >> 1, wc = wave & 1;
-  vec4 acc[WT][WT];
-#pragma unroll
-  for (int a = 0; a < WT; ++a)
-#pragma unroll
-    for (int b = 0; b < WT; ++b) acc[a][b] = vec4{0, 0, 0, 0};
-
-  // staging coordinates of this thread's v-th vec4: (row, k) of the 4-element group and the
-  // direction it runs in (along k when the operand is k-contiguous, along the row index otherwise)
-  const bool a_kc = (g.sak == 1), b_kc = (g.sbk == 1);
-  vec4 av[NV], bv[NV];
-  auto load = [&](int k0) {
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int idx = tid + 256 * v;
-      // k-contiguous: 8 groups per row  -> row = idx / 8, k = 4 * (idx % 8)
-      // row-contiguous: TS/4 groups per k -> k = idx / (TS/4), row = 4 * (idx % (TS/4))
-      const int ar = a_kc ? (idx >> 3) : 4 * (idx % (TS / 4));
-      const int ak = a_kc ? 4 * (idx & 7) : idx / (TS / 4);
-      av[v] = *reinterpret_cast<const vec4*>(A + (int64_t)(ti * TS + ar) * g.sai + (int64_t)(k0 + ak) * g.sak);
-      const int br = b_kc ? (idx >> 3) : 4 * (idx % (TS / 4));
-      const int bk = b_kc ? 4 * (idx & 7) : idx / (TS / 4);
-      bv[v] = *reinterpret_cast<const vec4*>(B + (int64_t)(k0 + bk) * g.sbk + (int64_t)(tj * TS + br) * g.sbj);
-    }
-  };
-  auto store = [&]() {
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int idx = tid + 256 * v;
-      if (a_kc) {
-        *reinterpret_cast<vec4*>(&As[(idx >> 3) * kGS + 4 * (idx & 7)]) = av[v];
-      } else {
-        const int r0 = 4 * (idx % (TS / 4)), k = idx / (TS / 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) As[(r0 + e) * kGS + k] = av[v][e];
-      }
-      if (b_kc) {
-        *reinterpret_cast<vec4*>(&Bs[(idx >> 3) * kGS + 4 * (idx & 7)]) = bv[v];
-      } else {
-        const int r0 = 4 * (idx % (TS / 4)), k = idx / (TS / 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) Bs[(r0 + e) * kGS + k] = bv[v][e];
-      }
-    }
-  };
-
-  if (k_lo < k_hi) load(k_lo);
-  for (int k0 = k_lo; k0 < k_hi; k0 += kGK) {
-    store();
-    __syncthreads();
-    if (k0 + kGK < k_hi) load(k0 + kGK);  // in flight while the MFMAs below run
-#pragma unroll
-    for (int kk = 0; kk < kGK / 16; ++kk) {
-      vec4 a4[WT], b4[WT];
-#pragma unroll
-      for (int x = 0; x < WT; ++x) {
-        a4[x] = *reinterpret_cast<const vec4*>(&As[(wr * 16 * WT + x * 16 + (lane & 15)) * kGS + kk * 16 + 4 * (lane >> 4)]);
-        b4[x] = *reinterpret_cast<const vec4*>(&Bs[(wc * 16 * WT + x * 16 + (lane & 15)) * kGS + kk * 16 + 4 * (lane >> 4)]);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int a = 0; a < WT; ++a)
-#pragma unroll
-          for (int b = 0; b < WT; ++b) acc[a][b] = M::mma(a4[a][r], b4[b][r], acc[a][b]);
-    }
-    __syncthreads();
-  }
-  const T alpha = (T)g.alpha, beta = (T)g.beta;
-#pragma unroll
-  for (int a = 0; a < WT; ++a)
-#pragma unroll
-    for (int b = 0; b < WT; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t i = ti * TS + wr * 16 * WT + a * 16 + M::crow(lane, r);
-        const int64_t j = tj * TS + wc * 16 * WT + b * 16 + (lane & 15);
-        T* c = C + i * g.ldc + j;
-        T v = alpha * acc[a][b][r];
-        if (g.beta != 0.0) v += beta * (*c);
-        *c = v;
-      }
-}
-
 // =============================================================================================
-// tile GEMM through LDS-DMA (same contract as gemm_tile_kernel), 128x128 or 64x64 tiles
+// tile GEMM through LDS-DMA, 128x128 or 64x64 tiles
 // =============================================================================================
-// The register-staged kernel above spends most of a k-step waiting (a lone 128x128x256 tile took
-// 38 us against 14 us of MFMA time).  Here the A and B panels of a k-step go global -> LDS with
+// (A register-staged predecessor spent most of a k-step waiting: a lone 128x128x256 tile took 38 us
+// against 14 us of MFMA time.)  The A and B panels of a k-step go global -> LDS with
 // global_load_lds into fragment-major double buffers -- every 16-byte DMA lands exactly where the
 // lane that will feed it to the MFMA reads it, so fragment reads are conflict-free and linear in the
 // lane id -- with ONE barrier per k-step and the next step's DMA in flight under the MFMAs.
@@ -818,13 +734,8 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmDesc g) {
 
 template <typename T, int TS, bool A_KC, bool B_KC>
 static void launch_gemm128(hipStream_t st, const GemmDesc& g) {
-  static bool attr_set = false;
   constexpr int kLds = G128<T, TS>::kNbuf * G128<T, TS>::kBufBytes;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm128_kernel<T, TS, A_KC, B_KC>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-    attr_set = true;
-  }
+  if (ensure_dyn_lds(reinterpret_cast<const void*>(&gemm128_kernel<T, TS, A_KC, B_KC>), kLds)) return;
   const int64_t nti = g.m / TS, ntj = g.n / TS;
   const int64_t ntiles = g.lower_only ? nti * (nti + 1) / 2 : nti * ntj;  // lower_only: m == n
   const dim3 grid((unsigned)ntiles, 1, (unsigned)g.nbatch);
@@ -849,14 +760,14 @@ static void launch_gemm(hipStream_t st, const GemmDesc& g) {
   // (lower_only launches compute only half of the grid); 64 x 64 tiles otherwise
   const bool div128 = (g.m % 128 == 0) && (g.n % 128 == 0) && (g.m_last % 128 == 0) && (g.k % 128 == 0);
   const int64_t tiles128 = (int64_t)(g.m / 128) * (g.n / 128) * g.nbatch / (g.lower_only ? 2 : 1);
-  if (dma_ok && div128 && tiles128 >= 512) {
-    launch_gemm_dma<T, 128>(st, g, a_kc, b_kc);
-  } else if (dma_ok) {
-    launch_gemm_dma<T, 64>(st, g, a_kc, b_kc);
-  } else {
-    const dim3 grid((unsigned)(g.n / 64), (unsigned)(g.m / 64), (unsigned)g.nbatch);
-    hipLaunchKernelGGL((gemm_tile_kernel<T, 2>), grid, dim3(256), 0, st, g);
+  // every product of the fit has unit-stride operands, k a multiple of 64 and alpha != 0 (checked
+  // once here: anything else is a programming error, reported through the launch-error state)
+  if (!dma_ok) {
+    note_launch_error("launch_gemm: operand strides / sizes the LDS-DMA tile kernel cannot take");
+    return;
   }
+  if (div128 && tiles128 >= 512) launch_gemm_dma<T, 128>(st, g, a_kc, b_kc);
+  else launch_gemm_dma<T, 64>(st, g, a_kc, b_kc);
 }
 
 // =============================================================================================
@@ -1302,16 +1213,12 @@ constexpr int64_t kSingleLevelMax = (sizeof(T) == 4) ? 3584 : 2560;
 template <typename T>
 static void potrf_block(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t ld, int ntile,
                         int64_t row_base, int64_t n, double* diag64, int* info) {
-  static bool attr_set = false;  // per instantiation; the kernels need more than 64 KB of LDS
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_step_kernel<T>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, StepLds<T>::kBytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&inv_lastrow_kernel<T>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * StepLds<T>::kTileBytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kinv_rows_kernel<T>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * StepLds<T>::kTileBytes);
-    attr_set = true;
-  }
+  // the kernels need more than 64 KB of LDS: opt in, per device (the attribute belongs to the
+  // device's function object)
+  if (ensure_dyn_lds(reinterpret_cast<const void*>(&potrf_step_kernel<T>), StepLds<T>::kBytes) ||
+      ensure_dyn_lds(reinterpret_cast<const void*>(&inv_lastrow_kernel<T>), 2 * StepLds<T>::kTileBytes) ||
+      ensure_dyn_lds(reinterpret_cast<const void*>(&kinv_rows_kernel<T>), 2 * StepLds<T>::kTileBytes))
+    return;
   const int lds_bytes = StepLds<T>::kBytes;
   auto step = [&](int k) {
     // grid.x = 1 (role D / idle) + rows below the diagonal of the tile column, grid.y = tile columns;
@@ -1419,35 +1326,42 @@ template void launch_trtri<double>(hipStream_t, const double*, double*, double*,
 // =============================================================================================
 // pack L^-1 into MFMA fragment-major tiles (layout documented in predict.hip)
 // =============================================================================================
-template <typename T>
-__global__ __launch_bounds__(256) void pack_linv_kernel(const T* __restrict__ linv, int64_t n,
-                                                        int64_t npad, T* __restrict__ linv_p) {
-  using vec4 = typename Mfma<T>::vec4;
+// Only the lower 16x16 tiles are stored, row-major over the triangle: tile (rt, kt <= rt) at
+// (rt (rt + 1) / 2 + kt) * 256 elements.  (Round 1 also stored the all-zero upper tiles, which doubled
+// this buffer and the multi-GPU broadcast of it.)  TF = fit type, TP = predict type.
+template <typename TF, typename TP>
+__global__ __launch_bounds__(256) void pack_linv_kernel(const TF* __restrict__ linv, int64_t n,
+                                                        int64_t npad, TP* __restrict__ linv_p) {
+  using vec4 = typename Mfma<TP>::vec4;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (tile, lane)
   const int64_t npad16 = npad / 16;
-  if (idx >= npad16 * npad16 * 64) return;
+  if (idx >= npad16 * (npad16 + 1) / 2 * 64) return;
   const int lane = (int)(idx & 63);
   const int64_t tile = idx >> 6;
-  const int64_t rt = tile / npad16, kt = tile % npad16;
+  int64_t rt = (int64_t)((__builtin_sqrt(8.0 * (double)tile + 1.0) - 1.0) * 0.5);
+  while ((rt + 1) * (rt + 2) / 2 <= tile) ++rt;
+  while (rt * (rt + 1) / 2 > tile) --rt;
+  const int64_t kt = tile - rt * (rt + 1) / 2;
   const int64_t row = rt * 16 + (lane & 15);
   const int64_t col = kt * 16 + 4 * (lane >> 4);
   vec4 v{0, 0, 0, 0};
-  if (kt <= rt && row < n) {
+  if (row < n) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (col + r <= row && col + r < n) v[r] = linv[row * npad + col + r];
+      if (col + r <= row && col + r < n) v[r] = (TP)linv[row * npad + col + r];
   }
   reinterpret_cast<vec4*>(linv_p)[idx] = v;
 }
 
-template <typename T>
-void launch_pack_linv(hipStream_t st, const T* linv, int64_t n, int64_t npad, T* linv_p) {
-  const int64_t total = (npad / 16) * (npad / 16) * 64;
-  hipLaunchKernelGGL((pack_linv_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+template <typename TF, typename TP>
+void launch_pack_linv(hipStream_t st, const TF* linv, int64_t n, int64_t npad, TP* linv_p) {
+  const int64_t total = (npad / 16) * (npad / 16 + 1) / 2 * 64;
+  hipLaunchKernelGGL((pack_linv_kernel<TF, TP>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                      linv, n, npad, linv_p);
 }
-template void launch_pack_linv<float>(hipStream_t, const float*, int64_t, int64_t, float*);
-template void launch_pack_linv<double>(hipStream_t, const double*, int64_t, int64_t, double*);
+template void launch_pack_linv<float, float>(hipStream_t, const float*, int64_t, int64_t, float*);
+template void launch_pack_linv<double, double>(hipStream_t, const double*, int64_t, int64_t, double*);
+template void launch_pack_linv<double, float>(hipStream_t, const double*, int64_t, int64_t, float*);
 
 // =============================================================================================
 // single-RHS solves through L^-1 and the NLML
@@ -1473,35 +1387,51 @@ __global__ __launch_bounds__(256) void white_kernel(const T* __restrict__ linv,
 // alpha[j] = sum_{i>=j} Linv[i][j] white[i].  Stage 1: block (column block cb, row chunk rc of 64
 // rows) -> part[rc][j] (double); stage 2 sums the chunks in order (deterministic).  (Chunks of 256 rows
 // left a thread 64 dependent loads: 22 us at N = 2048 for 8 MB.)
-constexpr int kAlphaChunk = 64;
+// The same pass also sums Linv[i][j]^2 over i: the squared column norms of L^-1 are the diagonal of
+// (K + noise I)^-1, which the precision self-test needs (the loads are shared, the extra FMA is free).
 template <typename T>
 __global__ __launch_bounds__(256) void alpha_part_kernel(const T* __restrict__ linv,
                                                          const T* __restrict__ white, int64_t n,
-                                                         int64_t npad, double* __restrict__ part) {
-  __shared__ double sh[4][64];
+                                                         int64_t npad, double* __restrict__ part,
+                                                         double* __restrict__ part_sq) {
+  __shared__ double sh[2][4][64];
   const int g = threadIdx.x >> 6, c = threadIdx.x & 63;
   const int64_t j = (int64_t)blockIdx.x * 64 + c;
   const int64_t r0 = (int64_t)blockIdx.y * kAlphaChunk;
-  double acc = 0.0;
+  double acc = 0.0, sq = 0.0;
   if (r0 + kAlphaChunk > (int64_t)blockIdx.x * 64 && j < n) {  // chunk reaches below this column block
     const int64_t hi = min(n, r0 + kAlphaChunk);
 #pragma unroll 4
     for (int64_t i = r0 + g; i < hi; i += 4)
-      if (i >= j) acc = fma((double)linv[i * npad + j], (double)white[i], acc);
+      if (i >= j) {
+        const double l = (double)linv[i * npad + j];
+        acc = fma(l, (double)white[i], acc);
+        sq = fma(l, l, sq);
+      }
   }
-  sh[g][c] = acc;
+  sh[0][g][c] = acc;
+  sh[1][g][c] = sq;
   __syncthreads();
-  if (g == 0) part[(int64_t)blockIdx.y * npad + j] = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
+  if (g == 0) {
+    part[(int64_t)blockIdx.y * npad + j] = (sh[0][0][c] + sh[0][1][c]) + (sh[0][2][c] + sh[0][3][c]);
+    part_sq[(int64_t)blockIdx.y * npad + j] = (sh[1][0][c] + sh[1][1][c]) + (sh[1][2][c] + sh[1][3][c]);
+  }
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void alpha_sum_kernel(const double* __restrict__ part, int nchunk,
-                                                        int64_t npad, T* __restrict__ alpha) {
+__global__ __launch_bounds__(256) void alpha_sum_kernel(const double* __restrict__ part,
+                                                        const double* __restrict__ part_sq, int nchunk,
+                                                        int64_t npad, T* __restrict__ alpha,
+                                                        double* __restrict__ kinv_diag) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= npad) return;
-  double acc = 0.0;
-  for (int c = 0; c < nchunk; ++c) acc += part[(int64_t)c * npad + j];
+  double acc = 0.0, sq = 0.0;
+  for (int c = 0; c < nchunk; ++c) {
+    acc += part[(int64_t)c * npad + j];
+    sq += part_sq[(int64_t)c * npad + j];
+  }
   alpha[j] = (T)acc;
+  kinv_diag[j] = sq;
 }
 
 template <typename T>
@@ -1532,19 +1462,20 @@ __global__ __launch_bounds__(256) void nlml_kernel(const T* __restrict__ white, 
 template <typename T>
 void launch_solve_alpha(hipStream_t st, const T* linv, const double* y64, int64_t n, int64_t npad,
                         double mean_c, const double* diag64, T* white, T* alpha,
-                        double* alpha_part, double* nlml_out) {
+                        double* alpha_part, double* kinv_diag, double* nlml_out) {
   hipLaunchKernelGGL((white_kernel<T>), dim3((unsigned)(npad / 4)), dim3(256), 0, st, linv, y64, n,
                      npad, mean_c, white);
   const int nchunk = (int)((npad + kAlphaChunk - 1) / kAlphaChunk);
+  double* part_sq = alpha_part + (size_t)nchunk * npad;
   hipLaunchKernelGGL((alpha_part_kernel<T>), dim3((unsigned)(npad / 64), (unsigned)nchunk), dim3(256),
-                     0, st, linv, white, n, npad, alpha_part);
+                     0, st, linv, white, n, npad, alpha_part, part_sq);
   hipLaunchKernelGGL((alpha_sum_kernel<T>), dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, st,
-                     alpha_part, nchunk, npad, alpha);
+                     alpha_part, part_sq, nchunk, npad, alpha, kinv_diag);
   if (nlml_out)
     hipLaunchKernelGGL((nlml_kernel<T>), dim3(1), dim3(256), 0, st, white, n, diag64, nlml_out);
 }
-template void launch_solve_alpha<float>(hipStream_t, const float*, const double*, int64_t, int64_t, double, const double*, float*, float*, double*, double*);
-template void launch_solve_alpha<double>(hipStream_t, const double*, const double*, int64_t, int64_t, double, const double*, double*, double*, double*, double*);
+template void launch_solve_alpha<float>(hipStream_t, const float*, const double*, int64_t, int64_t, double, const double*, float*, float*, double*, double*, double*);
+template void launch_solve_alpha<double>(hipStream_t, const double*, const double*, int64_t, int64_t, double, const double*, double*, double*, double*, double*, double*);
 
 // =============================================================================================
 // analytic gradient of the NLML  
@@ -1553,15 +1484,15 @@ template void launch_solve_alpha<double>(hipStream_t, const double*, const doubl
 template <typename T>
 __global__ __launch_bounds__(256) void grad_tile_kernel(const T* __restrict__ kinv,
                                                         const T* __restrict__ alpha,
-                                                        const T* __restrict__ xs,
-                                                        const T* __restrict__ xnorm, int64_t n,
+                                                        const double* __restrict__ xs,
+                                                        const double* __restrict__ xnorm, int64_t n,
                                                         int64_t npad, int dp, int n_ls,
                                                         const double* __restrict__ ls, int kernel,
                                                         double variance,
                                                         double* __restrict__ partial) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  T* xi = reinterpret_cast<T*>(lds_raw);  // [64][dp]
-  T* xj = xi + 64 * dp;                   // [64][dp]
+  double* xi = reinterpret_cast<double*>(lds_raw);  // [64][dp]
+  double* xj = xi + 64 * dp;                        // [64][dp]
   __shared__ double red[4];
   // 1-D grid over the lower tiles only (a 2-D grid with the upper half exiting at once leaves the 8
   // XCDs unevenly loaded): blk -> (ti, tj <= ti), row-major
@@ -1586,14 +1517,14 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(const T* __restrict__ ki
     base[p] = 0.0;
     if (i >= n || j >= n || j > i) continue;
     const double w = (i == j) ? 1.0 : 2.0;
-    T s = 0;
+    double s = 0;
     double r2d = 0.0;  // squared distance from direct differences: >= 0 and free of cancellation
     for (int k = 0; k < dp; ++k) {
       s += xi[ii * dp + k] * xj[jj * dp + k];
-      const double df = (double)xi[ii * dp + k] - (double)xj[jj * dp + k];
+      const double df = xi[ii * dp + k] - xj[jj * dp + k];
       r2d = fma(df, df, r2d);
     }
-    const double r2 = (double)(T(-2) * s + (xnorm[i] + xnorm[j]));  // GEMM form: the K the loss saw
+    const double r2 = -2.0 * s + (xnorm[i] + xnorm[j]);  // GEMM form (in double, as gram_kernel): the K the loss saw
     const double ai = (double)alpha[i], aj = (double)alpha[j];
     const double W = 0.5 * ((double)kinv[i * npad + j] - ai * aj);
     // the derivative is taken at the direct-difference distance: the Matern-1/2 factor 1/r would
@@ -1625,7 +1556,7 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(const T* __restrict__ ki
       for (int p = 0; p < 16; ++p) {
         const int idx = threadIdx.x + 256 * p;
         const int ii = idx >> 6, jj = idx & 63;
-        const double df = (double)xi[ii * dp + d] - (double)xj[jj * dp + d];
+        const double df = xi[ii * dp + d] - xj[jj * dp + d];
         acc += base[p] * (-2.0 * df * df);
       }
       const double sd = block_sum(acc) / ls[d];
@@ -1661,7 +1592,7 @@ __global__ __launch_bounds__(256) void grad_final_kernel(const double* __restric
 }
 
 template <typename T>
-void launch_gradient(hipStream_t st, const T* linv, const T* alpha, const T* xs, const T* xnorm,
+void launch_gradient(hipStream_t st, const T* linv, const T* alpha, const double* xs, const double* xnorm,
                      int64_t n, int64_t npad, int d, int dp, int n_ls, const double* ls,
                      const KernParams& kp, T* kinv, bool kinv_ready, double* partial, double* grad_out) {
   (void)d;
@@ -1676,15 +1607,447 @@ void launch_gradient(hipStream_t st, const T* linv, const T* alpha, const T* xs,
     launch_gemm<T>(st, g);
   }
   const int nt = (int)(npad / 64);
-  const size_t lds = (size_t)2 * 64 * dp * sizeof(T);
+  const size_t lds = (size_t)2 * 64 * dp * sizeof(double);
   const int64_t nblk = (int64_t)nt * (nt + 1) / 2;
   hipLaunchKernelGGL((grad_tile_kernel<T>), dim3((unsigned)nblk), dim3(256), lds, st,
                      kinv, alpha, xs, xnorm, n, npad, dp, n_ls, ls, kp.kernel, kp.variance, partial);
   hipLaunchKernelGGL((grad_final_kernel<T>), dim3(1), dim3(256), 0, st, partial, nblk, n_ls, alpha, n,
                      grad_out);
 }
-template void launch_gradient<float>(hipStream_t, const float*, const float*, const float*, const float*, int64_t, int64_t, int, int, int, const double*, const KernParams&, float*, bool, double*, double*);
+template void launch_gradient<float>(hipStream_t, const float*, const float*, const double*, const double*, int64_t, int64_t, int, int, int, const double*, const KernParams&, float*, bool, double*, double*);
 template void launch_gradient<double>(hipStream_t, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int, int, const double*, const KernParams&, double*, bool, double*, double*);
+
+// =============================================================================================
+// fused fit for N <= 128: ONE launch, one workgroup, everything in LDS
+// =============================================================================================
+// The reference's real problem sizes are N = 5 .. ~100 (14 fits with N = 5 .. 52 in the
+// toy run, each 10 - 45 L-BFGS-B loss evaluations, gpso/gp_surrogate.py:496-503).  There the general
+// path is pure launch latency: 17 launches, 0.10 ms of device time, per evaluation.  This kernel does
+// the whole evaluation -- scale X, Gram, Cholesky, L^-1, alpha, NLML, K^-1 and the analytic gradient,
+// the tile packing the predict kernels read -- in a single workgroup with the matrices in LDS as
+// 64x64 double blocks (A, B, C, D4 below), whatever the context's matrix type T (the outputs are
+// rounded to T / TP on the way out).  Block algebra for 64 < N <= 128 (N <= 64: only the first line):
+//     K00 = L00 L00^T ;  X00 = L00^-1
+//     L10 = K10 X00^T ;  S = K11 - L10 L10^T = L11 L11^T ;  X11 = L11^-1 ;  X10 = -X11 (L10 X00)
+// The 64-pivot chains (chol64_lds / trinv64_lds, shared with the general path) are what is left on
+// the critical path: ~15 us each.
+constexpr int kSmallN = 128;
+constexpr int kBlk = kFitBlock * kDS;  // doubles per 64x64 LDS block
+constexpr int kSmallLdsDoubles = 4 * kBlk + kTsDoubles + 6 * kSmallN + 4 * (kGradMaxLs + 2) + 16;
+constexpr int kSmallLdsBytes = kSmallLdsDoubles * 8;
+
+// 64x64 Gram block (bi, bj) from the scaled inputs in LDS (xs[row][dp]) into blk (stride kDS): the
+// same MFMA sequence and epilogue as gram_kernel<double>, so the entries are bit-identical to it
+__device__ __forceinline__ void small_gram_block(const double* xs, const double* nrm, int dp, int bi, int bj,
+                                                 int n, int kernel, double variance, double noise,
+                                                 double* blk, int wave, int lane) {
+  f64x4 s[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) s[t] = f64x4{0, 0, 0, 0};
+  const int i0 = 64 * bi + 16 * wave, j0 = 64 * bj;
+  for (int c = 0; c < dp / 4; ++c) {
+    const double a = xs[(i0 + (lane & 15)) * dp + 4 * c + (lane >> 4)];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const double b = xs[(j0 + 16 * t + (lane & 15)) * dp + 4 * c + (lane >> 4)];
+      s[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, s[t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ii = 16 * wave + (lane >> 4) + 4 * r, jj = 16 * t + (lane & 15);
+      const int i = 64 * bi + ii, j = 64 * bj + jj;
+      double v;
+      if (i < n && j < n) {
+        const double r2 = fma(-2.0, s[t][r], nrm[i] + nrm[j]);
+        v = kern_from_r2_lean(kernel, r2, variance);
+        if (i == j) v += noise;
+      } else {
+        v = (i == j) ? 1.0 : 0.0;
+      }
+      blk[ii * kDS + jj] = v;
+    }
+}
+
+// this wave's 4 tiles (row strip `wave`, column tiles 0..3) of a 64x64x64 product of LDS blocks:
+// out[t] = sum_k A[16 wave + i][k] * Bop(k, 16 t + j);  Bop(k, j) = Bb[k * sbk + j * sbj]
+__device__ __forceinline__ void small_mm_strip(const double* Ab, const double* Bb, int sbk, int sbj, int wave,
+                                               int lane, f64x4 (&out)[4]) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    out[t] = mma16_lds<64>(Ab + 16 * wave * kDS, kDS, 1, Bb + 16 * t * sbj, sbk, sbj, lane);
+}
+__device__ __forceinline__ void small_store_strip(double* blk, int wave, int lane, const f64x4 (&v)[4], double sign) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) blk[(16 * wave + (lane >> 4) + 4 * r) * kDS + 16 * t + (lane & 15)] = sign * v[t][r];
+}
+
+template <typename T, typename TP>
+__global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs g) {
+  extern __shared__ __align__(32) unsigned char lds_raw[];
+  double* A = reinterpret_cast<double*>(lds_raw);
+  double* B = A + kBlk;
+  double* C = B + kBlk;
+  double* D4 = C + kBlk;
+  double* Ts = D4 + kBlk;
+  double* nrm = Ts + kTsDoubles;       // [128] squared norms of the scaled inputs
+  double* resid = nrm + kSmallN;       // [128] y - c
+  double* wht = resid + kSmallN;       // [128] a = L^-1 (y - c)
+  double* alp = wht + kSmallN;         // [128] alpha
+  double* dg = alp + kSmallN;          // [128] diagonal of L
+  double* kd = dg + kSmallN;           // [128] diag(K_y^-1)
+  double* gacc = kd + kSmallN;         // [4][kGradMaxLs + 2] per-wave gradient partials
+  double* red = gacc + 4 * (kGradMaxLs + 2);  // [16]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = g.n, dp = g.dp, nb = (n > 64) ? 2 : 1, rows = 64 * nb;
+  int* info = reinterpret_cast<int*>(g.scal + 1);
+  T* Lf = static_cast<T*>(g.Lf);
+  T* linv = static_cast<T*>(g.linv);
+  constexpr int64_t ld = kSmallN;
+
+  // ---- 0. scaled inputs: LDS (in B, free until X00 is formed) + the global copies the predict path reads
+  double* xs = B;
+  if (tid == 0) *info = INT_MAX;
+  for (int e = tid; e < kSmallN * dp; e += 256) {
+    const int i = e / dp, k = e % dp;
+    double v = 0.0;
+    if (i < n && k < g.d) v = g.x64[(int64_t)i * g.d + k] / g.ls[k];
+    if (i < rows) xs[e] = v;
+    g.xs64[e] = v;
+  }
+  __syncthreads();
+  if (tid < kSmallN) {
+    double acc = 0.0;
+    if (tid < rows)
+      for (int k = 0; k < dp; ++k) acc += xs[tid * dp + k] * xs[tid * dp + k];
+    nrm[tid] = acc;
+    g.xnorm64[tid] = acc;
+    resid[tid] = (tid < n) ? g.y64[tid] - g.mean_c : 0.0;
+  }
+  {  // MFMA A-fragment packing (pack_xs_kernel<double>)
+    const int dp4 = dp / 4;
+    for (int idx = tid; idx < kSmallN * dp; idx += 256) {
+      const int l = idx & 63, q = idx >> 6, c = q % dp4, kt = q / dp4;
+      const int row = kt * 16 + Mfma<double>::arow_for_k4(l & 15);
+      g.xs_p64[idx] = (row < rows) ? xs[row * dp + 4 * c + (l >> 4)] : 0.0;
+    }
+  }
+  __syncthreads();
+  // ---- 1. Gram blocks: K00 -> A, K10 -> C, K11 -> D4
+  small_gram_block(xs, nrm, dp, 0, 0, n, g.kernel, g.variance, g.noise, A, wave, lane);
+  if (nb == 2) {
+    small_gram_block(xs, nrm, dp, 1, 0, n, g.kernel, g.variance, g.noise, C, wave, lane);
+    small_gram_block(xs, nrm, dp, 1, 1, n, g.kernel, g.variance, g.noise, D4, wave, lane);
+  }
+  __syncthreads();
+  for (int e = tid; e < kBlk; e += 256) B[e] = 0.0;  // X00 is written on and below the diagonal only
+  __syncthreads();
+  // ---- 2. K00 = L00 L00^T, X00 = L00^-1 (B)
+  chol64_lds<2, T>(A, B, Lf, ld, 0, n, info);
+  if (tid < kFitBlock) dg[tid] = A[tid * kDS + tid];
+  trinv64_lds<true, T>(A, B, Ts, Lf, ld);
+  if (nb == 2) {
+    // ---- 3. L10 = K10 X00^T -> C (and Lf[1][0])
+    f64x4 v[4];
+    small_mm_strip(C, B, 1, kDS, wave, lane, v);  // Bop(k, j) = X00[j][k]
+    __syncthreads();
+    small_store_strip(C, wave, lane, v, 1.0);
+    for (int e = tid; e < kBlk; e += 256) A[e] = 0.0;  // L00 is dead: A becomes X11
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        Lf[(int64_t)(64 + 16 * wave + (lane >> 4) + 4 * r) * ld + 16 * t + (lane & 15)] = (T)v[t][r];
+    __syncthreads();
+    // ---- 4. S = K11 - L10 L10^T (lower 16x16 tiles) in place in D4
+    for (int t = wave; t < 10; t += 4) {
+      int ti = 0, tj = t;
+      while (tj > ti) {
+        tj -= ti + 1;
+        ++ti;
+      }
+      const f64x4 p = mma16_lds<64>(C + 16 * ti * kDS, kDS, 1, C + 16 * tj * kDS, 1, kDS, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) D4[(16 * ti + (lane >> 4) + 4 * r) * kDS + 16 * tj + (lane & 15)] -= p[r];
+    }
+    __syncthreads();
+    // ---- 5. S = L11 L11^T, X11 = L11^-1 (A)
+    chol64_lds<2, T>(D4, A, Lf + 64 * ld + 64, ld, 64, n, info);
+    if (tid < kFitBlock) dg[64 + tid] = D4[tid * kDS + tid];
+    trinv64_lds<true, T>(D4, A, Ts, Lf + 64 * ld + 64, ld);
+    // ---- 6. X10 = -X11 (L10 X00) -> C
+    small_mm_strip(C, B, kDS, 1, wave, lane, v);  // W = L10 X00
+    __syncthreads();
+    small_store_strip(D4, wave, lane, v, 1.0);    // L11 is dead: D4 holds W
+    __syncthreads();
+    small_mm_strip(A, D4, kDS, 1, wave, lane, v);  // X11 W
+    __syncthreads();
+    small_store_strip(C, wave, lane, v, -1.0);
+  } else if (tid < kFitBlock) {
+    dg[64 + tid] = 1.0;
+  }
+  __syncthreads();
+  // element (row, col) of X = L^-1 (zeros above the diagonal are real zeros in LDS)
+  auto Xat = [&](int row, int col) -> double {
+    if (row < 64) return (col < 64) ? B[row * kDS + col] : 0.0;
+    if (nb == 1) return (row == col) ? 1.0 : 0.0;
+    return (col < 64) ? C[(row - 64) * kDS + col] : A[(row - 64) * kDS + col - 64];
+  };
+  // ---- 7. L^-1 to global (full 128 x 128, identity on the padding) + the predict kernels' tile packing
+  for (int e = tid; e < kSmallN * kSmallN; e += 256) {
+    const int r = e >> 7, c = e & 127;
+    linv[e] = (T)((c <= r) ? Xat(r, c) : 0.0);
+  }
+  {
+    using vecP = typename Mfma<TP>::vec4;
+    vecP* out = static_cast<vecP*>(g.linv_p);
+    for (int idx = tid; idx < 36 * 64; idx += 256) {  // 8 * 9 / 2 lower tiles of 16 x 16
+      const int l = idx & 63, tile = idx >> 6;
+      int rt = 0, kt = tile;
+      while (kt > rt) {
+        kt -= rt + 1;
+        ++rt;
+      }
+      const int row = rt * 16 + (l & 15), col = kt * 16 + 4 * (l >> 4);
+      vecP v{0, 0, 0, 0};
+      if (row < n) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (col + r <= row && col + r < n) v[r] = (TP)Xat(row, col + r);
+      }
+      out[idx] = v;
+    }
+  }
+  // ---- 8. a = X (y - c), alpha = X^T a, diag(K_y^-1), NLML
+  {
+    const int i = tid >> 1, h = tid & 1;  // two threads per row
+    double acc = 0.0;
+    if (i < rows)
+      for (int k = 64 * h; k < 64 * h + 64 && k <= i; ++k) acc = fma(Xat(i, k), resid[k], acc);
+    acc += __shfl_xor(acc, 1);
+    if (h == 0) wht[i] = (i < n) ? acc : 0.0;
+  }
+  __syncthreads();
+  {
+    const int j = tid >> 1, h = tid & 1;  // two threads per column
+    double acc = 0.0, sq = 0.0;
+    if (j < n)
+      for (int i = max(j, 64 * h); i < min(n, 64 * h + 64); ++i) {
+        const double x = Xat(i, j);
+        acc = fma(x, wht[i], acc);
+        sq = fma(x, x, sq);
+      }
+    acc += __shfl_xor(acc, 1);
+    sq += __shfl_xor(sq, 1);
+    if (h == 0) {
+      alp[j] = acc;
+      kd[j] = sq;
+    }
+  }
+  __syncthreads();
+  if (tid < kSmallN) {
+    static_cast<T*>(g.white)[tid] = (T)wht[tid];
+    static_cast<T*>(g.alpha_f)[tid] = (T)alp[tid];
+    static_cast<TP*>(g.alpha_p)[tid] = (TP)alp[tid];
+    g.kinv_diag[tid] = kd[tid];
+    g.diag64[tid] = dg[tid];
+  }
+  {
+    double q = 0.0, lg = 0.0, sa = 0.0;
+    if (tid < n) {
+      q = wht[tid] * wht[tid];
+      lg = log(dg[tid]);
+      sa = alp[tid];
+    }
+    q = wave_sum(q);
+    lg = wave_sum(lg);
+    sa = wave_sum(sa);
+    if (lane == 0) {
+      red[wave] = q;
+      red[4 + wave] = lg;
+      red[8 + wave] = sa;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const double quad = (red[0] + red[1]) + (red[2] + red[3]);
+    const double ldet = (red[4] + red[5]) + (red[6] + red[7]);
+    g.scal[0] = 0.5 * quad + ldet + 0.5 * (double)n * 1.83787706640934548356;  // log(2 pi)
+    if (g.want_grad) g.scal[8 + g.n_ls + 2] = -((red[8] + red[9]) + (red[10] + red[11]));
+  }
+  if (!g.want_grad) return;
+  // ---- 9. K^-1 = X^T X tile by tile on the MFMA, consumed at once by the gradient reductions
+  //         (W = (K^-1 - alpha alpha^T) / 2; sums of W o dK/dtheta over the lower triangle)
+  double* xg = D4;  // scaled inputs again (D4 is dead)
+  for (int e = tid; e < rows * dp; e += 256) {
+    const int i = e / dp, k = e % dp;
+    xg[e] = (i < n && k < g.d) ? g.x64[(int64_t)i * g.d + k] / g.ls[k] : 0.0;
+  }
+  const int H = g.n_ls + 2;
+  for (int h = tid; h < 4 * (kGradMaxLs + 2); h += 256) gacc[h] = 0.0;
+  __syncthreads();
+  const int nt16 = (n + 15) / 16;
+  T* kinv = static_cast<T*>(g.kinv);
+  for (int t = wave; t < nt16 * (nt16 + 1) / 2; t += 4) {
+    int ti = 0, tj = t;
+    while (tj > ti) {
+      tj -= ti + 1;
+      ++ti;
+    }
+    // K^-1[ti][tj] = sum_{k >= 16 ti} X[k][16 ti + i] X[k][16 tj + j]
+    f64x4 acc{0, 0, 0, 0};
+    for (int k0 = 16 * ti; k0 < rows; k0 += 16) {
+      double a[4], b[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = k0 + 4 * q + (lane >> 4);
+        a[q] = Xat(k, 16 * ti + (lane & 15));
+        b[q] = Xat(k, 16 * tj + (lane & 15));
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
+    }
+    double g_var = 0.0, g_noise = 0.0, g_iso = 0.0, base[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * ti + (lane >> 4) + 4 * r, j = 16 * tj + (lane & 15);
+      base[r] = 0.0;
+      if (kinv != nullptr && i < kSmallN) kinv[(int64_t)i * ld + j] = (T)acc[r];
+      if (i >= n || j >= n || j > i) continue;
+      const double w = (i == j) ? 1.0 : 2.0;
+      double s = 0.0, r2d = 0.0;
+      for (int k = 0; k < dp; ++k) {
+        s += xg[i * dp + k] * xg[j * dp + k];
+        const double df = xg[i * dp + k] - xg[j * dp + k];
+        r2d = fma(df, df, r2d);
+      }
+      const double r2 = -2.0 * s + (nrm[i] + nrm[j]);
+      const double Wij = 0.5 * (acc[r] - alp[i] * alp[j]);
+      double kv, dk;
+      kern_and_dkern_lean(g.kernel, r2, r2d, g.variance, kv, dk);
+      g_var += w * Wij * kv / g.variance;
+      if (i == j) g_noise += Wij;
+      base[r] = w * Wij * dk;
+      g_iso += base[r] * (-2.0 * r2d);
+    }
+    g_var = wave_sum(g_var);
+    g_noise = wave_sum(g_noise);
+    if (lane == 0) {
+      gacc[wave * (kGradMaxLs + 2) + g.n_ls] += g_var;
+      gacc[wave * (kGradMaxLs + 2) + g.n_ls + 1] += g_noise;
+    }
+    if (g.n_ls == 1) {
+      g_iso = wave_sum(g_iso);
+      if (lane == 0) gacc[wave * (kGradMaxLs + 2)] += g_iso;
+    } else {
+      for (int dd = 0; dd < g.n_ls; ++dd) {
+        double a2 = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * ti + (lane >> 4) + 4 * r, j = 16 * tj + (lane & 15);
+          const double df = (i < rows && j < rows) ? xg[i * dp + dd] - xg[j * dp + dd] : 0.0;
+          a2 += base[r] * (-2.0 * df * df);
+        }
+        a2 = wave_sum(a2);
+        if (lane == 0) gacc[wave * (kGradMaxLs + 2) + dd] += a2;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < H) {
+    double v = (gacc[tid] + gacc[(kGradMaxLs + 2) + tid]) + (gacc[2 * (kGradMaxLs + 2) + tid] + gacc[3 * (kGradMaxLs + 2) + tid]);
+    if (tid < g.n_ls) v /= g.ls[g.n_ls == 1 ? 0 : tid];
+    g.scal[8 + tid] = v;
+  }
+}
+
+bool small_fit_eligible(int64_t n, int dp) { return n <= kSmallN && (n <= 64 || dp <= 32); }
+
+template <typename T, typename TP>
+int launch_small_fit(hipStream_t st, const SmallFitArgs& args) {
+  const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(&small_fit_kernel<T, TP>), kSmallLdsBytes);
+  if (rc) return rc;
+  hipLaunchKernelGGL((small_fit_kernel<T, TP>), dim3(1), dim3(256), kSmallLdsBytes, st, args);
+  return 0;
+}
+template int launch_small_fit<double, double>(hipStream_t, const SmallFitArgs&);
+template int launch_small_fit<double, float>(hipStream_t, const SmallFitArgs&);
+template int launch_small_fit<float, float>(hipStream_t, const SmallFitArgs&);
+
+// =============================================================================================
+// precision self-test (float-predict contexts): the predict path at the training inputs against the
+// closed form the fit implies
+// =============================================================================================
+// With K_y = K + noise I = L L^T, alpha = K_y^-1 (y - c) and k_i = K_y e_i - noise e_i:
+//     mean(x_i) = k_i . alpha + c                       = y_i - noise * alpha_i
+//     var_y(x_i) = sigma^2 - |L^-1 k_i|^2 + noise       = 2 noise - noise^2 * (K_y^-1)_ii
+// (K_y^-1)_ii = squared column norm of L^-1 (alpha_sum_kernel).  The predict kernels recompute k_i
+// from X, so the differences measure the whole chain: the rounding of the apply (the training inputs
+// are where var is smallest, i.e. where the cancellation sigma^2 - |A|^2 is worst) and, for a float
+// factorisation, its BACKWARD error (at x_i the solve weights K_y^-1 k_i are nearly a unit vector; at a
+// general leaf they amplify a factorisation error by up to |K_y^-1| sigma^2, which is why max_i
+// (K_y^-1)_ii is reported as well: the host multiplies the measured errors by it for float factors).
+// out: [0] max |d mean|, [1] max |d var|, [2] max |y - c|, [3] min predicted var, [4] max |alpha|,
+// [5] max_i (K_y^-1)_ii.
+template <typename T>
+__global__ __launch_bounds__(256) void selftest_kernel(const double* __restrict__ mean,
+                                                       const double* __restrict__ var,
+                                                       const double* __restrict__ y64,
+                                                       const T* __restrict__ alpha,
+                                                       const double* __restrict__ kinv_diag, int64_t n,
+                                                       double noise, double mean_c,
+                                                       double* __restrict__ out) {
+  __shared__ double sh[6][4];
+  double v[6] = {0.0, 0.0, 0.0, 1.0e300, 0.0, 0.0};
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const double a = (double)alpha[i];
+    const double m_ref = y64[i] - noise * a;
+    const double v_ref = 2.0 * noise - noise * noise * kinv_diag[i];
+    const double dm = fabs(mean[i] - m_ref), dv = fabs(var[i] - v_ref);
+    v[0] = (dm > v[0] || dm != dm) ? dm : v[0];  // NaN sticks
+    v[1] = (dv > v[1] || dv != dv) ? dv : v[1];
+    v[2] = fmax(v[2], fabs(y64[i] - mean_c));
+    v[3] = fmin(v[3], var[i]);
+    v[4] = fmax(v[4], fabs(a));
+    v[5] = fmax(v[5], kinv_diag[i]);
+  }
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    for (int off = 32; off > 0; off >>= 1) {
+      const double o = __shfl_xor(v[q], off);
+      if (q == 3) v[q] = fmin(v[q], o);
+      else v[q] = (o > v[q] || o != o) ? o : v[q];
+    }
+    if ((threadIdx.x & 63) == 0) sh[q][threadIdx.x >> 6] = v[q];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int q = 0; q < 6; ++q) {
+      double r = sh[q][0];
+      for (int w = 1; w < 4; ++w) {
+        const double o = sh[q][w];
+        if (q == 3) r = fmin(r, o);
+        else r = (o > r || o != o) ? o : r;
+      }
+      out[q] = r;
+    }
+  }
+}
+
+template <typename T>
+void launch_selftest(hipStream_t st, const double* mean, const double* var, const double* y64,
+                     const T* alpha, const double* kinv_diag, int64_t n, double noise, double mean_c,
+                     double* out) {
+  hipLaunchKernelGGL((selftest_kernel<T>), dim3(1), dim3(256), 0, st, mean, var, y64, alpha, kinv_diag, n,
+                     noise, mean_c, out);
+}
+template void launch_selftest<float>(hipStream_t, const double*, const double*, const double*, const float*, const double*, int64_t, double, double, double*);
+template void launch_selftest<double>(hipStream_t, const double*, const double*, const double*, const double*, const double*, int64_t, double, double, double*);
 
 // =============================================================================================
 // conversions / interop
@@ -1730,6 +2093,22 @@ void launch_convert_out(hipStream_t st, const T* src, int64_t ld_src, double* ds
 }
 template void launch_convert_out<float>(hipStream_t, const float*, int64_t, double*, int64_t, int64_t, int);
 template void launch_convert_out<double>(hipStream_t, const double*, int64_t, double*, int64_t, int64_t, int);
+
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void convert_vec_kernel(const TS* __restrict__ src, TD* __restrict__ dst,
+                                                          int64_t len) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < len) dst[i] = (TD)src[i];
+}
+template <typename TS, typename TD>
+void launch_convert_vec(hipStream_t st, const TS* src, TD* dst, int64_t len) {
+  if (len <= 0) return;
+  hipLaunchKernelGGL((convert_vec_kernel<TS, TD>), dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, src,
+                     dst, len);
+}
+template void launch_convert_vec<double, float>(hipStream_t, const double*, float*, int64_t);
+template void launch_convert_vec<float, float>(hipStream_t, const float*, float*, int64_t);
+template void launch_convert_vec<double, double>(hipStream_t, const double*, double*, int64_t);
 
 template <typename T>
 __global__ __launch_bounds__(256) void install_chol_kernel(const double* __restrict__ L64, int64_t n,

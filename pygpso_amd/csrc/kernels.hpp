@@ -1,12 +1,24 @@
 // Host-callable launchers of the gfx950 kernels (definitions in predict.hip / fit.hip / grow.hip).
+//
+// Type roles:  TF = fit type (Gram, Cholesky, L^-1, alpha: float | double)
+//              T / TP = predict ("apply") type (packed L^-1, alpha, accumulators: float | double)
+//              TG = generation type of the cross-Gram tile's x.x* contraction and r^2 (float | double;
+//                   double by default also in float contexts, see predict.hip)
 #pragma once
 #include "common.hpp"
 
 namespace gpso {
 
+// ---- runtime helpers (api.hip) ------------------------------------------------------------------
+// Opt a kernel into `bytes` of dynamic LDS (> 64 KB needs hipFuncAttributeMaxDynamicSharedMemorySize)
+// on the CURRENT device; remembered per (function, device), thread-safe.  Returns 0 or a negative
+// GPSO_E_* code (also recorded with note_launch_error).
+int ensure_dyn_lds(const void* fn, int bytes);
+// Remember the first launcher-side error of the call in flight (thread-local); the C-ABI entry
+// points turn it into GPSO_E_HIP with this message.
+void note_launch_error(const char* msg);
+
 // tile shape of the dominant predict kernel: BM rows of L^-1 x (4 waves * CT * 16) leaves per workgroup
-// (chosen per launch: f32 uses 256 x 128 when N_pad is a multiple of 256, else 128 x 256; f64 64 x 128;
-//  always 32 (f32) / 8 (f64) accumulator tiles per wave)
 constexpr int kLeafPad = 256;  // leaf batches are padded to a multiple of this
 // rows of L^-1 per workgroup for a given padded N and D / 4, and the resulting number of row blocks
 template <typename T>
@@ -15,23 +27,33 @@ template <typename T>
 inline int leaf_tiles_nbi(int64_t npad, int dp4) { return (int)(npad / leaf_tiles_bm<T>(npad, dp4)); }
 
 // ---- predict.hip ----------------------------------------------------------------------------------
-template <typename T, typename TIN>
+// m_live (nullable, device): number of live leaves; rows at or beyond it are padding
+template <typename TG, typename TIN>
 void launch_prep_leaves(hipStream_t st, const TIN* xs, int64_t m, int64_t mpad, int d, int dp,
-                        const double* ls, T* out, T* norm);
-template <typename T>
-void launch_leaf_tiles(hipStream_t st, const T* linv_p, const T* xs_p, const T* xnorm,
-                       const T* alpha, const T* leaves_s, const T* lnorm, T* part_var, T* part_mean,
-                       int64_t npad, int dp4, int64_t mpad, const KernParams& kp);
+                        const double* ls, const int64_t* m_live, TG* out, TG* norm);
+// partial sums per row block of L^-1: part_var / part_mean [nbi][mpad] double
+template <typename T, typename TG>
+int launch_leaf_tiles(hipStream_t st, const T* linv_p, const TG* xs_p, const TG* xnorm,
+                      const T* alpha, const TG* leaves_s, const TG* lnorm, double* part_var,
+                      double* part_mean, int64_t npad, int dp4, int64_t mpad, const KernParams& kp,
+                      const int64_t* m_live);
 // split-bf16 apply (float contexts): nsplit = 2 -> bf16x3, 3 -> bf16x6; needs npad % 256 == 0.
-// linv_b = nsplit * npad * npad bf16, produced by launch_pack_linv_bf16 from the f32 L^-1
-void launch_pack_linv_bf16(hipStream_t st, int nsplit, const float* linv, int64_t n, int64_t npad,
+// linv_b = nsplit * npad * npad bf16, produced by launch_pack_linv_bf16 from the fit-type L^-1
+template <typename TF>
+void launch_pack_linv_bf16(hipStream_t st, int nsplit, const TF* linv, int64_t n, int64_t npad,
                            void* linv_b);
-void launch_leaf_tiles_bf16(hipStream_t st, int nsplit, const void* linv_b, const float* xs_p,
-                            const float* xnorm, const float* alpha, const float* leaves_s,
-                            const float* lnorm, float* part_var, float* part_mean, int64_t npad,
-                            int dp4, int64_t mpad, const KernParams& kp);
-template <typename T>
-void launch_leaf_finalize(hipStream_t st, const T* part_var, const T* part_mean, int nbi,
+// dynamic LDS of the split-bf16 kernel: A pieces (2 buffers x nsplit x 16 KiB) + 2 X buffers + the 8 waves' leaf
+// fragments, for a generation type of tg_bytes
+inline size_t leaf_bf16_lds_bytes(int nsplit, int dp4, int tg_bytes) {
+  return (size_t)2 * nsplit * 16 * 64 * 16 + (size_t)2 * (2 * dp4 * 64 * tg_bytes + 64 * tg_bytes + 256) +
+         (size_t)8 * 2 * dp4 * 64 * tg_bytes;
+}
+template <typename TG>
+int launch_leaf_tiles_bf16(hipStream_t st, int nsplit, const void* linv_b, const TG* xs_p,
+                           const TG* xnorm, const float* alpha, const TG* leaves_s,
+                           const TG* lnorm, double* part_var, double* part_mean, int64_t npad,
+                           int dp4, int64_t mpad, const KernParams& kp, const int64_t* m_live);
+void launch_leaf_finalize(hipStream_t st, const double* part_var, const double* part_mean, int nbi,
                           int64_t mpad, int64_t m, const KernParams& kp, double varsigma,
                           double* mean, double* var, double* ucb);
 void launch_seg_argmax(hipStream_t st, const double* mean, const double* var, const double* ucb,
@@ -41,13 +63,14 @@ constexpr int kArgmaxBlocks = 64;      // stage-1 blocks per segment
 constexpr size_t kArgmaxPartialBytes = 16;  // sizeof(Best)
 
 // ---- fit.hip --------------------------------------------------------------------------------------
-// scaled inputs: xs[npad*dp] = X/ls (zero padded), xnorm[npad], xs_p = MFMA-fragment packing
+// scaled inputs: xs[npad*dp] = X/ls (zero padded), xnorm[npad], xs_p (nullable) = MFMA-fragment packing
 template <typename T>
 void launch_scale_x(hipStream_t st, const double* x64, int64_t n, int64_t npad, int d, int dp,
                     const double* ls, T* xs, T* xnorm, T* xs_p);
-// K = k(X, X) + noise * I on rows < n; identity on the padding
+// K = k(X, X) + noise * I on rows < n (lower 64x64 tiles only); identity on the padding.  r^2 is
+// always formed in double from the double scaled inputs.
 template <typename T>
-void launch_gram(hipStream_t st, const T* xs, const T* xnorm, int64_t n, int64_t npad, int dp,
+void launch_gram(hipStream_t st, const double* xs, const double* xnorm, int64_t n, int64_t npad, int dp,
                  const KernParams& kp, T* K);
 // blocked right-looking Cholesky, K (destroyed) -> Lf (lower); also writes the inverted 64x64 diagonal
 // blocks into linv, the unrounded diagonal of L to diag64[npad], and the first failing pivot (or
@@ -63,23 +86,65 @@ int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t
 constexpr int kFitOuterPanel = 512;
 template <typename T>
 void launch_trtri(hipStream_t st, const T* L, T* linv, T* work, int64_t npad, int64_t first_level);
-// zero rows/cols >= n and re-tile L^-1 into the MFMA fragment-major layout the predict kernel reads
-template <typename T>
-void launch_pack_linv(hipStream_t st, const T* linv, int64_t n, int64_t npad, T* linv_p);
-// a = L^-1 (y - c), alpha = L^-T a, nlml = 1/2 a.a + sum log diag64 + n/2 log 2pi  (double accumulators)
+// zero rows/cols >= n and re-tile the lower 16x16 tiles of L^-1 into the MFMA fragment-major layout
+// the predict kernel reads: npad16 (npad16 + 1) / 2 tiles of 256 elements
+template <typename TF, typename TP>
+void launch_pack_linv(hipStream_t st, const TF* linv, int64_t n, int64_t npad, TP* linv_p);
+inline size_t packed_linv_elems(int64_t npad) { return (size_t)(npad / 16) * (size_t)(npad / 16 + 1) / 2 * 256; }
+// a = L^-1 (y - c), alpha = L^-T a, nlml = 1/2 a.a + sum log diag64 + n/2 log 2pi  (double accumulators);
+// kinv_diag[npad] = squared column norms of L^-1 = diag((K + noise I)^-1)
+constexpr int kAlphaChunk = 64;
+inline size_t alpha_part_doubles(int64_t npad) { return (size_t)2 * ((npad + kAlphaChunk - 1) / kAlphaChunk) * npad; }
 template <typename T>
 void launch_solve_alpha(hipStream_t st, const T* linv, const double* y64, int64_t n, int64_t npad,
                         double mean_c, const double* diag64, T* white, T* alpha,
-                        double* alpha_part /* [ceil(npad/64) * npad] scratch */, double* nlml_out);
+                        double* alpha_part /* alpha_part_doubles(npad) scratch */, double* kinv_diag,
+                        double* nlml_out);
 // Kinv = L^-T L^-1 (lower tiles; skipped when kinv_ready), then the gradient reductions of SURVEY.md A.3;
 // grad_out[n_ls + 3] = d nlml / d (ls..., variance, noise, c)
 template <typename T>
-void launch_gradient(hipStream_t st, const T* linv, const T* alpha, const T* xs, const T* xnorm,
+void launch_gradient(hipStream_t st, const T* linv, const T* alpha, const double* xs, const double* xnorm,
                      int64_t n, int64_t npad, int d, int dp, int n_ls, const double* ls,
                      const KernParams& kp, T* kinv, bool kinv_ready, double* partial, double* grad_out);
 constexpr int kGradMaxLs = 64;
+// fused single-launch fit for N <= 128 (one workgroup, matrices in LDS): everything launch_scale_x<double>
+// .. launch_pack_linv / launch_convert_vec produce, in one kernel (definition + field docs: fit.hip)
+struct SmallFitArgs {
+  const double* x64;
+  const double* y64;
+  const double* ls;  // [dp] lengthscale per input dimension (device)
+  int n, d, dp, kernel, n_ls, want_grad;
+  double variance, noise, mean_c;
+  // outputs
+  double* xs64;    // [128 * dp] scaled inputs
+  double* xnorm64; // [128]
+  double* xs_p64;  // [128 * dp] MFMA A fragments (double layout)
+  void* Lf;        // [128 * 128] T
+  void* linv;      // [128 * 128] T
+  void* kinv;      // [128 * 128] T, nullable
+  void* white;     // [128] T
+  void* alpha_f;   // [128] T
+  void* alpha_p;   // [128] TP
+  void* linv_p;    // packed lower tiles, TP
+  double* diag64;  // [128]
+  double* kinv_diag;  // [128]
+  double* scal;    // [0] nlml, [1] info (int), [8 ..] gradient (ls..., variance, noise, c)
+};
 
-// float64 host -> T device conversions and getters
+bool small_fit_eligible(int64_t n, int dp);
+template <typename T, typename TP>
+int launch_small_fit(hipStream_t st, const SmallFitArgs& args);
+
+// precision self-test: predictions at the training inputs vs the closed form the fit implies;
+// out[6] = max |d mean|, max |d var|, max |y - c|, min predicted var, max |alpha|, max_i (K_y^-1)_ii
+template <typename T>
+void launch_selftest(hipStream_t st, const double* mean, const double* var, const double* y64,
+                     const T* alpha, const double* kinv_diag, int64_t n, double noise, double mean_c,
+                     double* out);
+
+// conversions and getters
+template <typename TS, typename TD>
+void launch_convert_vec(hipStream_t st, const TS* src, TD* dst, int64_t len);
 template <typename T>
 void launch_convert_in(hipStream_t st, const double* src, T* dst, int64_t rows, int64_t cols,
                        int64_t ld_dst);

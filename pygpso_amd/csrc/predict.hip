@@ -22,18 +22,22 @@
 
 namespace gpso {
 
+
 // ---------------------------------------------------------------------------------------------
-template <typename T, typename TIN>
+// raw leaf coordinates -> x* / lengthscale in the generation type TG, + squared norms
+template <typename TG, typename TIN>
 __global__ __launch_bounds__(256) void prep_leaves_kernel(const TIN* __restrict__ xs, int64_t m,
                                                           int64_t mpad, int d, int dp,
                                                           const double* __restrict__ ls /*[dp]*/,
-                                                          T* __restrict__ out, T* __restrict__ norm) {
+                                                          const int64_t* __restrict__ m_live,
+                                                          TG* __restrict__ out, TG* __restrict__ norm) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= mpad) return;
-  T acc = 0;
+  const bool live = j < m && (m_live == nullptr || j < *m_live);
+  TG acc = 0;
   for (int k = 0; k < dp; ++k) {
-    T v = 0;
-    if (j < m && k < d) v = (T)((double)xs[j * d + k] / ls[k]);
+    TG v = 0;
+    if (live && k < d) v = (TG)((double)xs[j * d + k] / ls[k]);
     out[j * dp + k] = v;
     acc += v * v;
   }
@@ -42,191 +46,26 @@ __global__ __launch_bounds__(256) void prep_leaves_kernel(const TIN* __restrict_
 
 // ---------------------------------------------------------------------------------------------
 // Packed operand layouts produced at fit time (fit.hip: pack_linv_kernel / scale_x_kernel):
-//   linv_p : 16x16 tiles of L^-1, tile (rt, kt) at ((rt * npad16 + kt) * 256), inside a tile
-//            element (row, k) sits at lane * 4 + (k & 3) with lane = (row & 15) + 16 * ((k & 15) >> 2)
+//   linv_p : 16x16 tiles of L^-1 (lower tiles only, row-major over the triangle: tile (rt, kt <= rt)
+//            at ((rt (rt + 1) / 2 + kt) * 256)); inside a tile element (row, k) sits at
+//            lane * 4 + (k & 3) with lane = (row & 15) + 16 * ((k & 15) >> 2)
 //            -> one wave reads a whole tile as 64 contiguous vec4 (1 KiB f32 / 2 KiB f64), and
 //            lane l gets L^-1[row l&15][k = 4 (l>>4) + 0..3]: the A operand of MFMA k-step r is
 //            element r.
-//   xs_p   : scaled training inputs as MFMA A fragments: ((kt * dp4 + c) * 64 + lane) holds
-//            x~[16 kt + arow_for_k4(lane & 15)][4 c + (lane >> 4)]
+//   xs_p   : scaled training inputs as MFMA A fragments IN THE GENERATION TYPE TG:
+//            ((kt * dp4 + c) * 64 + lane) holds x~[16 kt + arow_for_k4(lane & 15)][4 c + (lane >> 4)]
 // With those, accumulator register r of lane l of the generated tile S = x~ x~*^T corresponds to
 // training row 16 kt + 4 (l >> 4) + r and leaf column (l & 15) for BOTH the f32 and f64 MFMA,
 // which is exactly the B-operand shape (k = l >> 4 within k-step r) the second MFMA needs.
-// one k-tile (16 training rows) of work for a wave; DIAG = the k-tile lies in the diagonal block
-// of this row block (mean partial + skipping of the all-zero upper tiles of L^-1)
-// PF: the L^-1 fragments of k-tile kt arrive in `a` (loaded one step earlier) and the fragments of
-// kt + 1 are requested at the top of this step, a full step ahead of their use (register double
-// buffer; tiles above the diagonal are stored as zeros, so the prefetch never needs a guard other
-// than the end of the row block).
-template <typename T, int RT, int CT, int KERNEL, bool DIAG, bool PF>
-__device__ __forceinline__ void leaf_tile_step(
-    int kt, int kt_diag0, int lane, int dp4, int npad16, const T* __restrict__ xs_p,
-    const T* xb, const typename Mfma<T>::vec4* __restrict__ xn4,
-    const typename Mfma<T>::vec4* __restrict__ al4, const typename Mfma<T>::vec4* __restrict__ linv4,
-    const T (&nb)[CT], T variance, typename Mfma<T>::vec4 (&acc)[RT][CT], T (&macc)[CT],
-    typename Mfma<T>::vec4 (&a)[RT]) {
-  using M = Mfma<T>;
-  using vec4 = typename M::vec4;
-  vec4 an[RT];
-  if (PF) {
-    if (kt + 1 < kt_diag0 + RT) {
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-        an[rt] = linv4[((size_t)(kt_diag0 + rt) * npad16 + kt + 1) * 64 + lane];
-    }
-  } else {
-    // L^-1 fragments of this k-tile for all RT row tiles: issued first, consumed last
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      if (DIAG && kt > kt_diag0 + rt) {
-        a[rt] = vec4{0, 0, 0, 0};
-      } else {
-#if defined(GPSO_ABLATE) && (GPSO_ABLATE & 2)  // timing-only: no L^-1 traffic
-        a[rt] = vec4{(T)kt, (T)rt, (T)lane, 1};
-#else
-        a[rt] = linv4[((size_t)(kt_diag0 + rt) * npad16 + kt) * 64 + lane];
-#endif
-      }
-    }
-  }
-  // ---- generate the 16 x (CT*16) cross-Gram tile for training rows [16 kt, 16 kt + 16) ----
-  vec4 s[CT];
-#pragma unroll
-  for (int t = 0; t < CT; ++t) s[t] = vec4{0, 0, 0, 0};
-#if defined(GPSO_ABLATE) && (GPSO_ABLATE & 4)  // timing-only: no generation MFMAs
-  for (int t = 0; t < CT; ++t) s[t] = vec4{(T)kt, (T)t, (T)lane, 1};
-#else
-  for (int c = 0; c < dp4; ++c) {
-    const T xa = xs_p[((size_t)kt * dp4 + c) * 64 + lane];
-#pragma unroll
-    for (int t = 0; t < CT; ++t) s[t] = M::mma(xa, xb[(t * dp4 + c) * 64 + lane], s[t]);
-  }
-#endif
-  // u = C2 * r^2 with GPflow's GEMM form r^2 = -2 x.x* + (|x|^2 + |x*|^2); nb is pre-scaled by C2
-  constexpr T C2 = (T)KernScale<KERNEL>::C2;
-  const vec4 na = xn4[kt * 4 + (lane >> 4)] * C2;
-  vec4 p[CT];
-#pragma unroll
-  for (int t = 0; t < CT; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#if defined(GPSO_ABLATE) && (GPSO_ABLATE & 1)  // timing-only: skip the kernel map
-      p[t][r] = s[t][r] + na[r];
-#else
-      p[t][r] = kern_from_scaled<KERNEL>(fma_t((T)(T(-2) * C2), s[t][r], na[r] + nb[t]), variance);
-#endif
-  if (DIAG) {
-    const vec4 a4 = al4[kt * 4 + (lane >> 4)];
-#pragma unroll
-    for (int t = 0; t < CT; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) macc[t] = fma_t(p[t][r], a4[r], macc[t]);
-  }
-  // ---- apply the rows of L^-1: acc[rt][t] += Linv[rows, 16 kt ..] * tile --------------------
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    if (DIAG && kt > kt_diag0 + rt) continue;  // upper-triangular tile of the diagonal block: zeros
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int t = 0; t < CT; ++t) acc[rt][t] = M::mma(a[rt][r], p[t][r], acc[rt][t]);
-  }
-  if (PF) {
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) a[rt] = an[rt];
-  }
-}
-
-template <typename T, int BM, int CT, int KERNEL>
-__global__ __launch_bounds__(256, 2) void leaf_tiles_kernel(
-    const T* __restrict__ linv_p, const T* __restrict__ xs_p, const T* __restrict__ xnorm,
-    const T* __restrict__ alpha, const T* __restrict__ leaves_s, const T* __restrict__ lnorm,
-    T* __restrict__ part_var, T* __restrict__ part_mean, int npad16, int dp4, int64_t mpad, int nbi,
-    T variance) {
-  using M = Mfma<T>;
-  using vec4 = typename M::vec4;
-  constexpr int RT = BM / 16;  // row tiles per block
-  extern __shared__ __align__(16) unsigned char lds_raw[];
-  T* lds = reinterpret_cast<T*>(lds_raw);
-
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6;
-  const int lane = tid & 63;
-  const int bi = nbi - 1 - (int)blockIdx.y;  // heaviest row blocks are dispatched first
-  const int64_t col0 = ((int64_t)blockIdx.x * 4 + wave) * (CT * 16);
-  const int dp = dp4 * 4;
-
-  // this wave's leaf fragments (B operand of the generation MFMA), kept in LDS: [t][c][lane]
-  T* xb = lds + (size_t)wave * CT * dp4 * 64;
-  for (int t = 0; t < CT; ++t)
-    for (int c = 0; c < dp4; ++c)
-      xb[(t * dp4 + c) * 64 + lane] =
-          leaves_s[(col0 + t * 16 + (lane & 15)) * dp + 4 * c + (lane >> 4)];
-  T nb[CT];
-#pragma unroll
-  for (int t = 0; t < CT; ++t)
-    nb[t] = lnorm[col0 + t * 16 + (lane & 15)] * (T)KernScale<KERNEL>::C2;
-  // (each wave only reads back what it wrote itself: no workgroup barrier needed)
-
-  vec4 acc[RT][CT];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int t = 0; t < CT; ++t) acc[rt][t] = vec4{0, 0, 0, 0};
-  T macc[CT];
-#pragma unroll
-  for (int t = 0; t < CT; ++t) macc[t] = 0;
-
-  const int kt_diag0 = bi * RT;  // first k-tile of the diagonal block
-  const vec4* linv4 = reinterpret_cast<const vec4*>(linv_p);
-  const vec4* xn4 = reinterpret_cast<const vec4*>(xnorm);
-  const vec4* al4 = reinterpret_cast<const vec4*>(alpha);
-
-  constexpr bool PF = false;  // (register double-buffering the L^-1 fragments measured as no gain)
-  vec4 a[RT];
-  if (PF) {
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) a[rt] = linv4[((size_t)(kt_diag0 + rt) * npad16) * 64 + lane];
-  }
-  for (int kt = 0; kt < kt_diag0; ++kt)
-    leaf_tile_step<T, RT, CT, KERNEL, false, PF>(kt, kt_diag0, lane, dp4, npad16, xs_p, xb, xn4, al4,
-                                                 linv4, nb, variance, acc, macc, a);
-  for (int kt = kt_diag0; kt < kt_diag0 + RT; ++kt)
-    leaf_tile_step<T, RT, CT, KERNEL, true, PF>(kt, kt_diag0, lane, dp4, npad16, xs_p, xb, xn4, al4,
-                                                linv4, nb, variance, acc, macc, a);
-
-  // ---- epilogue: column sums of squares over the BM rows, and the mean partial ----------------
-#pragma unroll
-  for (int t = 0; t < CT; ++t) {
-    T sq = 0;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sq = fma_t(acc[rt][t][r], acc[rt][t][r], sq);
-    sq += __shfl_xor(sq, 16);
-    sq += __shfl_xor(sq, 32);
-    T mm = macc[t];
-    mm += __shfl_xor(mm, 16);
-    mm += __shfl_xor(mm, 32);
-    if (lane < 16) {
-      const int64_t col = col0 + t * 16 + lane;
-      part_var[(int64_t)bi * mpad + col] = sq;
-      part_mean[(int64_t)bi * mpad + col] = mm;
-    }
-  }
-}
-
-// =============================================================================================
-// leaf_tiles v2 (float): same arithmetic per leaf as leaf_tiles_kernel, restructured around the
-// two costs measured on MI355X (ablation builds): L^-1 fragment loads from
-// L1/L2 and the exposed generation phase.
-//   * the BM x 16 panel of L^-1 and the X fragments of the next k-tiles are brought into LDS by
-//     the whole workgroup with direct-to-LDS loads (global_load_lds: no VGPRs, one KiB per wave
-//     instruction, fragment-major source == linear LDS image), double buffered, one barrier per
-//     k-tile; every wave then reads its A operands from LDS just in time;
-//   * the cross-Gram tile of k-tile kt + 1 is generated WHILE the MFMAs of k-tile kt run: the
-//     generation MFMAs go first, the Matern/SE map is sliced into the issue shadow of the apply
-//     MFMAs (sched_group_barrier pipeline), so the matrix pipe no longer waits for the VALU.
+//
+// Generation type TG vs apply type T.  float contexts generate the cross-Gram tile with TG = double
+// by default ("accurate generation"): GPflow's GEMM-form r^2 = |x|^2 + |x*|^2 - 2 x.x* is a
+// cancellation of terms of size |x / l|^2 (~100 at the reference's lengthscales), which in float
+// leaves an absolute error ~1e-5 in r^2 -- and L^-1 (entries up to 1/sigma_n ~ 1e3 at the
+// reference's noise floor) amplifies that into a variance error of 1e-3 sigma^2 (measured,
+// profiles/r02a_precision_before.jsonl).  The x.x* contraction is D/4 MFMAs per 16x16 tile against
+// 64..128 for the apply, so running it on v_mfma_f64_16x16x4_f64 costs a few percent; r^2 is
+// combined in double and only then rounded to float for the Matern / SE map.
 // =============================================================================================
 __device__ __forceinline__ void glds16(const void* gsrc_lane, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
@@ -237,73 +76,66 @@ __device__ __forceinline__ void glds4(const void* gsrc_lane, void* lds_wave_base
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
 
-// timing-only ablation switches of the v2 kernel (never set in the shipped build)
-#if defined(GPSO_ABLATE2) && (GPSO_ABLATE2 & 2)
-#define GPSO_NOLOAD 1
-#else
-#define GPSO_NOLOAD 0
-#endif
-#if defined(GPSO_ABLATE2) && (GPSO_ABLATE2 & 16)
-#define GPSO_NOBAR 1
-#else
-#define GPSO_NOBAR 0
-#endif
-
-// LDS images written by global_load_lds are "slabs" of 64 lanes x 16 B (vec4 of double = two slabs)
-// resp. 64 lanes x 4 B (a double = two word planes): the DMA destination is wave-base + lane * size.
+// LDS images written by global_load_lds: A fragments are "slabs" of 64 lanes x 16 B (a vec4 of
+// double = two slabs); X fragments (one TG per lane) are the linear memory image, 64 x sizeof(TG)
+// bytes moved as 256-byte pieces.
 template <typename T>
 struct V2Lds;
 template <>
 struct V2Lds<float> {
-  static constexpr int SLABS = 1, WORDS = 1;
+  static constexpr int SLABS = 1;
   static __device__ __forceinline__ f32x4 frag(const unsigned char* base, int lane) {
     return *reinterpret_cast<const f32x4*>(base + lane * 16);
-  }
-  static __device__ __forceinline__ float word(const unsigned* base, int lane) {
-    return __builtin_bit_cast(float, base[lane]);
   }
 };
 template <>
 struct V2Lds<double> {
-  static constexpr int SLABS = 2, WORDS = 2;
+  static constexpr int SLABS = 2;
   typedef double f64x2 __attribute__((ext_vector_type(2)));
   static __device__ __forceinline__ f64x4 frag(const unsigned char* base, int lane) {
     const f64x2 lo = *reinterpret_cast<const f64x2*>(base + lane * 16);
     const f64x2 hi = *reinterpret_cast<const f64x2*>(base + 1024 + lane * 16);
     return f64x4{lo[0], lo[1], hi[0], hi[1]};
   }
-  static __device__ __forceinline__ double word(const unsigned* base, int lane) {
-    const unsigned long long b = (unsigned long long)base[lane] | ((unsigned long long)base[64 + lane] << 32);
-    return __builtin_bit_cast(double, b);
-  }
 };
+// one X fragment (64 x TG, contiguous in memory) -> LDS, 256 bytes per DMA instruction
+template <typename TG>
+__device__ __forceinline__ void glds_xfrag(const TG* src_frag, unsigned char* dst, int lane) {
+#pragma unroll
+  for (int w = 0; w < (int)sizeof(TG) / 4; ++w)
+    glds4(reinterpret_cast<const unsigned*>(src_frag) + w * 64 + lane, dst + w * 256);
+}
 
-template <typename T, int RT, int CT, int KERNEL, bool DIAG>
+// address of tile (rt, kt <= rt) of the triangle-packed L^-1, in vec4 units
+__device__ __forceinline__ size_t linv_tile(int rt, int kt) {
+  return ((size_t)rt * (size_t)(rt + 1) / 2 + (size_t)kt) * 64;
+}
+
+template <typename T, typename TG, int RT, int CT, int KERNEL, bool DIAG>
 __device__ __forceinline__ void leaf_v2_step(
     int kt, int kt_diag0, bool gen, bool gen_diag, int lane, int dp4,
-    const unsigned char* panel_b /* [RT][SLABS] KiB */, const unsigned* xs_b /* [dp4][WORDS][64] */,
-    const T* xb, const typename Mfma<T>::vec4& na, const typename Mfma<T>::vec4* __restrict__ al4,
-    const T (&nb)[CT], T variance, typename Mfma<T>::vec4 (&acc)[RT][CT], T (&macc)[CT],
+    const unsigned char* panel_b /* [RT][SLABS] KiB */, const unsigned char* xs_b /* [dp4] X fragments */,
+    const TG* xb, const typename Mfma<TG>::vec4& na, const typename Mfma<T>::vec4* __restrict__ al4,
+    const TG (&nb)[CT], T variance, typename Mfma<T>::vec4 (&acc)[RT][CT], T (&macc)[CT],
     typename Mfma<T>::vec4 (&p_cur)[CT]) {
   using M = Mfma<T>;
+  using MG = Mfma<TG>;
   using vec4 = typename M::vec4;
+  using vecG = typename MG::vec4;
   using L = V2Lds<T>;
   constexpr int E = CT * 4;
   constexpr int FB = L::SLABS * 1024;  // bytes of one A fragment in LDS
-  constexpr T C2 = (T)KernScale<KERNEL>::C2;
+  constexpr int XB = 64 * (int)sizeof(TG);
+  constexpr TG C2 = (TG)KernScale<KERNEL>::C2;
   // ---- generation MFMAs for k-tile kt + 1 (short dependent chains; issued ahead of the apply) --
-  vec4 s[CT];
+  vecG s[CT];
 #pragma unroll
-  for (int t = 0; t < CT; ++t) s[t] = vec4{0, 0, 0, 0};
-#if defined(GPSO_ABLATE2) && (GPSO_ABLATE2 & 4)
-  if (false) {
-#else
+  for (int t = 0; t < CT; ++t) s[t] = vecG{0, 0, 0, 0};
   if (gen) {
-#endif
     for (int c = 0; c < dp4; ++c) {
-      const T xa = L::word(xs_b + c * L::WORDS * 64, lane);
+      const TG xa = reinterpret_cast<const TG*>(xs_b + c * XB)[lane];
 #pragma unroll
-      for (int t = 0; t < CT; ++t) s[t] = M::mma(xa, xb[(t * dp4 + c) * 64 + lane], s[t]);
+      for (int t = 0; t < CT; ++t) s[t] = MG::mma(xa, xb[(t * dp4 + c) * 64 + lane], s[t]);
     }
   }
   vec4 p_nxt[CT];
@@ -316,11 +148,7 @@ __device__ __forceinline__ void leaf_v2_step(
   // ---- apply k-tile kt, with the map of k-tile kt + 1 sliced between the MFMAs -----------------
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
-#if defined(GPSO_ABLATE2) && (GPSO_ABLATE2 & 8)
-    if (rt + 2 < RT) a[(rt + 2) % 3] = vec4{(T)kt, (T)rt, (T)lane, 1};
-#else
     if (rt + 2 < RT) a[(rt + 2) % 3] = L::frag(panel_b + (rt + 2) * FB, lane);
-#endif
     __builtin_amdgcn_sched_barrier(0);
     if (!(DIAG && kt > kt_diag0 + rt)) {
 #pragma unroll
@@ -331,11 +159,9 @@ __device__ __forceinline__ void leaf_v2_step(
 #pragma unroll
     for (int e = rt * E / RT; e < (rt + 1) * E / RT; ++e) {
       const int t = e >> 2, r = e & 3;
-#if defined(GPSO_ABLATE2) && (GPSO_ABLATE2 & 1)
-      p_nxt[t][r] = s[t][r] + na[r];
-#else
-      p_nxt[t][r] = kern_from_scaled<KERNEL>(fma_t((T)(T(-2) * C2), s[t][r], na[r] + nb[t]), variance);
-#endif
+      // u = C2 * r^2, GPflow's GEMM form r^2 = -2 x.x* + (|x|^2 + |x*|^2) combined in TG (norms
+      // pre-scaled by C2), rounded to T for the map
+      p_nxt[t][r] = kern_from_scaled<KERNEL>((T)fma_t((TG)(TG(-2) * C2), s[t][r], na[r] + nb[t]), variance);
     }
   }
   if (gen && gen_diag) {  // k-tile kt + 1 lies in the diagonal block: its share of k*.alpha
@@ -349,54 +175,64 @@ __device__ __forceinline__ void leaf_v2_step(
   for (int t = 0; t < CT; ++t) p_cur[t] = p_nxt[t];
 }
 
-template <typename T, int CT, int DP4MAX>
-__host__ __device__ inline size_t leaf_v2_lds_bytes(int rt, int dp4) {
-  return (size_t)2 * rt * (sizeof(T) * 4 / 16) * 1024 + (size_t)2 * dp4 * (sizeof(T) / 4) * 256 +
-         (size_t)4 * CT * dp4 * 64 * sizeof(T);
+template <typename T, typename TG, int CT>
+inline size_t leaf_v2_lds_bytes(int rt, int dp4) {
+  return (size_t)2 * rt * (sizeof(T) * 4 / 16) * 1024 + (size_t)2 * dp4 * 64 * sizeof(TG) +
+         (size_t)4 * CT * dp4 * 64 * sizeof(TG);
 }
 
-template <typename T, int BM, int CT, int KERNEL>
+// =============================================================================================
+// leaf_tiles v2: the BM x 16 panel of L^-1 and the X fragments of the next k-tiles are brought
+// into LDS by the whole workgroup with direct-to-LDS loads (global_load_lds: no VGPRs, one KiB per
+// wave instruction, fragment-major source == linear LDS image), double buffered, one barrier per
+// k-tile; every wave reads its A operands from LDS just in time; the cross-Gram tile of k-tile
+// kt + 1 is generated WHILE the MFMAs of k-tile kt run (generation MFMAs first, the Matern / SE map
+// sliced into the issue shadow of the apply MFMAs).
+// m_live (nullable): device count of live leaves; workgroups whose first leaf is at or beyond it
+// exit at once (on-device growth sizes its launch for the worst case, see grow.hip).
+// =============================================================================================
+template <typename T, typename TG, int BM, int CT, int KERNEL>
 __global__ __launch_bounds__(256, 2) void leaf_tiles_v2_kernel(
-    const T* __restrict__ linv_p, const T* __restrict__ xs_p, const T* __restrict__ xnorm,
-    const T* __restrict__ alpha, const T* __restrict__ leaves_s, const T* __restrict__ lnorm,
-    T* __restrict__ part_var, T* __restrict__ part_mean, int npad16, int dp4, int64_t mpad, int nbi,
-    T variance) {
+    const T* __restrict__ linv_p, const TG* __restrict__ xs_p, const TG* __restrict__ xnorm,
+    const T* __restrict__ alpha, const TG* __restrict__ leaves_s, const TG* __restrict__ lnorm,
+    double* __restrict__ part_var, double* __restrict__ part_mean, int dp4, int64_t mpad, int nbi,
+    T variance, const int64_t* __restrict__ m_live) {
   using M = Mfma<T>;
   using vec4 = typename M::vec4;
+  using vecG = typename Mfma<TG>::vec4;
   using L = V2Lds<T>;
   constexpr int RT = BM / 16;
-  constexpr int FB = L::SLABS * 1024;     // bytes of one A fragment
-  constexpr int XB = L::WORDS * 64 * 4;   // bytes of one X fragment
-  constexpr T C2 = (T)KernScale<KERNEL>::C2;
+  constexpr int FB = L::SLABS * 1024;        // bytes of one A fragment
+  constexpr int XB = 64 * (int)sizeof(TG);   // bytes of one X fragment
+  constexpr TG C2 = (TG)KernScale<KERNEL>::C2;
   extern __shared__ __align__(16) unsigned char lds_raw[];
+  if (m_live != nullptr && (int64_t)blockIdx.x * (4 * CT * 16) >= *m_live) return;  // workgroup-uniform
   unsigned char* panel = lds_raw;                              // [2][RT] fragments of FB bytes
   unsigned char* xsl = panel + (size_t)2 * RT * FB;            // [2][dp4] fragments of XB bytes
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: loops over it stay uniform
-  T* xb = reinterpret_cast<T*>(xsl + (size_t)2 * dp4 * XB) + (size_t)wave * CT * dp4 * 64;
+  TG* xb = reinterpret_cast<TG*>(xsl + (size_t)2 * dp4 * XB) + (size_t)wave * CT * dp4 * 64;
 
-  const int bi = nbi - 1 - (int)blockIdx.y;
+  const int bi = nbi - 1 - (int)blockIdx.y;  // heaviest row blocks are dispatched first
   const int64_t col0 = ((int64_t)blockIdx.x * 4 + wave) * (CT * 16);
   const int dp = dp4 * 4;
   const int kt_diag0 = bi * RT, kt_end = kt_diag0 + RT;
   const vec4* linv4 = reinterpret_cast<const vec4*>(linv_p);
-  const vec4* xn4 = reinterpret_cast<const vec4*>(xnorm);
+  const vecG* xn4 = reinterpret_cast<const vecG*>(xnorm);
   const vec4* al4 = reinterpret_cast<const vec4*>(alpha);
 
   auto issue_panel = [&](int kt, int buf) {
     for (int f = wave; f < RT; f += 4) {
-      const unsigned char* src =
-          reinterpret_cast<const unsigned char*>(linv4 + ((size_t)(kt_diag0 + f) * npad16 + kt) * 64 + lane);
+      // tiles above the diagonal do not exist in the packed triangle; their slot is never read
+      if (kt > kt_diag0 + f) continue;
+      const unsigned char* src = reinterpret_cast<const unsigned char*>(linv4 + linv_tile(kt_diag0 + f, kt) + lane);
 #pragma unroll
       for (int h = 0; h < L::SLABS; ++h) glds16(src + 16 * h, panel + (size_t)(buf * RT + f) * FB + h * 1024);
     }
   };
   auto issue_xs = [&](int kt, int buf) {
-    for (int c = wave; c < dp4; c += 4) {
-      const unsigned* src = reinterpret_cast<const unsigned*>(xs_p + ((size_t)kt * dp4 + c) * 64 + lane);
-#pragma unroll
-      for (int w = 0; w < L::WORDS; ++w) glds4(src + w, xsl + (size_t)(buf * dp4 + c) * XB + w * 256);
-    }
+    for (int c = wave; c < dp4; c += 4)
+      glds_xfrag<TG>(xs_p + ((size_t)kt * dp4 + c) * 64, xsl + (size_t)(buf * dp4 + c) * XB, lane);
   };
 
   // prologue: panel(0) -> P[0], xs(0) -> X[1], xs(1) -> X[0]; this wave's leaf fragments -> xb
@@ -407,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void leaf_tiles_v2_kernel(
     for (int c = 0; c < dp4; ++c)
       xb[(t * dp4 + c) * 64 + lane] =
           leaves_s[(col0 + t * 16 + (lane & 15)) * dp + 4 * c + (lane >> 4)];
-  T nb[CT];
+  TG nb[CT];
 #pragma unroll
   for (int t = 0; t < CT; ++t) nb[t] = lnorm[col0 + t * 16 + (lane & 15)] * C2;
   vec4 acc[RT][CT];
@@ -418,26 +254,26 @@ __global__ __launch_bounds__(256, 2) void leaf_tiles_v2_kernel(
   T macc[CT];
 #pragma unroll
   for (int t = 0; t < CT; ++t) macc[t] = 0;
-  vec4 na = xn4[lane >> 4] * C2;  // norms of k-tile 0
+  vecG na = xn4[lane >> 4] * C2;  // norms of k-tile 0
   __syncthreads();                // (hipcc drains the LDS-DMA queue before the barrier)
 
   // G(0): not overlapped with anything
   vec4 p_cur[CT];
   {
-    vec4 s[CT];
+    vecG s[CT];
 #pragma unroll
-    for (int t = 0; t < CT; ++t) s[t] = vec4{0, 0, 0, 0};
-    const unsigned* x1 = reinterpret_cast<const unsigned*>(xsl + (size_t)1 * dp4 * XB);
+    for (int t = 0; t < CT; ++t) s[t] = vecG{0, 0, 0, 0};
+    const unsigned char* x1 = xsl + (size_t)1 * dp4 * XB;
     for (int c = 0; c < dp4; ++c) {
-      const T xa = L::word(x1 + c * L::WORDS * 64, lane);
+      const TG xa = reinterpret_cast<const TG*>(x1 + c * XB)[lane];
 #pragma unroll
-      for (int t = 0; t < CT; ++t) s[t] = M::mma(xa, xb[(t * dp4 + c) * 64 + lane], s[t]);
+      for (int t = 0; t < CT; ++t) s[t] = Mfma<TG>::mma(xa, xb[(t * dp4 + c) * 64 + lane], s[t]);
     }
 #pragma unroll
     for (int t = 0; t < CT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        p_cur[t][r] = kern_from_scaled<KERNEL>(fma_t((T)(T(-2) * C2), s[t][r], na[r] + nb[t]), variance);
+        p_cur[t][r] = kern_from_scaled<KERNEL>((T)fma_t((TG)(TG(-2) * C2), s[t][r], na[r] + nb[t]), variance);
     if (kt_diag0 == 0) {
       const vec4 a4 = al4[lane >> 4];
 #pragma unroll
@@ -453,33 +289,34 @@ __global__ __launch_bounds__(256, 2) void leaf_tiles_v2_kernel(
 #define GPSO_V2_STEP(DIAGF, GEN_DIAG)                                                              \
   {                                                                                                \
     const int b = kt & 1;                                                                          \
-    if (kt + 1 < kt_end && !GPSO_NOLOAD) issue_panel(kt + 1, b ^ 1);                               \
-    vec4 na_nxt = na;                                                                              \
-    if (kt + 2 < kt_end && !GPSO_NOLOAD) {                                                         \
+    if (kt + 1 < kt_end) issue_panel(kt + 1, b ^ 1);                                               \
+    vecG na_nxt = na;                                                                              \
+    if (kt + 2 < kt_end) {                                                                         \
       issue_xs(kt + 2, b ^ 1);                                                                     \
       na_nxt = xn4[(kt + 2) * 4 + (lane >> 4)] * C2;                                               \
     }                                                                                              \
-    leaf_v2_step<T, RT, CT, KERNEL, DIAGF>(                                                        \
+    leaf_v2_step<T, TG, RT, CT, KERNEL, DIAGF>(                                                    \
         kt, kt_diag0, kt + 1 < kt_end, GEN_DIAG, lane, dp4, panel + (size_t)b * RT * FB,           \
-        reinterpret_cast<const unsigned*>(xsl + (size_t)b * dp4 * XB), xb, na, al4, nb, variance,  \
-        acc, macc, p_cur);                                                                         \
+        xsl + (size_t)b * dp4 * XB, xb, na, al4, nb, variance, acc, macc, p_cur);                  \
     na = na_nxt;                                                                                   \
-    if (!GPSO_NOBAR) __syncthreads(); /* panel(kt+1) / xs(kt+2) landed; buffers b free */          \
+    __syncthreads(); /* panel(kt+1) / xs(kt+2) landed; buffers b free */                           \
   }
   for (int kt = 0; kt < kt_diag0; ++kt) GPSO_V2_STEP(false, kt + 1 >= kt_diag0)
   for (int kt = kt_diag0; kt < kt_end; ++kt) GPSO_V2_STEP(true, true)
 #undef GPSO_V2_STEP
 
+  // ---- epilogue: column sums of squares over the BM rows (double accumulation: the variance is
+  // sigma^2 minus this sum, a cancellation at the reference's noise floor) and the mean partial ----
 #pragma unroll
   for (int t = 0; t < CT; ++t) {
-    T sq = 0;
+    double sq = 0;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sq = fma_t(acc[rt][t][r], acc[rt][t][r], sq);
+      for (int r = 0; r < 4; ++r) sq = fma((double)acc[rt][t][r], (double)acc[rt][t][r], sq);
     sq += __shfl_xor(sq, 16);
     sq += __shfl_xor(sq, 32);
-    T mm = macc[t];
+    double mm = (double)macc[t];
     mm += __shfl_xor(mm, 16);
     mm += __shfl_xor(mm, 32);
     if (lane < 16) {
@@ -496,9 +333,8 @@ __global__ __launch_bounds__(256, 2) void leaf_tiles_v2_kernel(
 // The bf16 matrix cores run at 16x the rate of the f32 MFMA.  L^-1 (at fit time) and the generated
 // cross-Gram tile (here) are split into NS bf16 pieces x = h0 + h1 (+ h2), each piece the bf16
 // rounding of the remainder; the product is recovered from 3 (NS = 2: h0h0 + h0h1 + h1h0) or 6
-// (NS = 3: + h1h1 + h0h2 + h2h0) v_mfma_f32_16x16x32_bf16 with f32 accumulation.  Measured accuracy
-// of the variance at C3 vs float64: native f32 1e-6, bf16x6 7e-7, bf16x3 2e-5 (x sigma^2).
-// The x.x* contraction and the Matern map stay in f32 (r^2 is a cancellation).
+// (NS = 3: + h1h1 + h0h2 + h2h0) v_mfma_f32_16x16x32_bf16 with f32 accumulation.  The x.x*
+// contraction runs in TG (double by default, see above) and the Matern map in f32.
 //
 // Workgroup: 8 waves (one per CU, 2 per SIMD), 256 rows of L^-1 x 256 leaves; per k-step of 32
 // training points the NS x 16 A fragments (1 KiB each, 8 bf16 per lane) arrive in LDS by
@@ -521,8 +357,10 @@ __device__ __forceinline__ unsigned bf16_split_pair(float& a, float& b) {
   return u;
 }
 
-template <int NS>
-__global__ __launch_bounds__(256) void pack_linv_bf16_kernel(const float* __restrict__ linv, int64_t n,
+// bf16 pieces of L^-1 from the fit-type matrix (TF = float or double: the first piece rounds the
+// full-precision value)
+template <int NS, typename TF>
+__global__ __launch_bounds__(256) void pack_linv_bf16_kernel(const TF* __restrict__ linv, int64_t n,
                                                              int64_t npad, u32x4* __restrict__ out) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (rt, kq, lane)
   const int64_t npad16 = npad / 16, npad32 = npad / 32;
@@ -531,61 +369,78 @@ __global__ __launch_bounds__(256) void pack_linv_bf16_kernel(const float* __rest
   const int64_t kq = (idx >> 6) % npad32, rt = (idx >> 6) / npad32;
   const int64_t row = rt * 16 + (lane & 15);
   float v[8];
+  float lo[8];  // TF = double: the part of the value float cannot hold goes into the later pieces
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int64_t col = kq * 32 + (j >> 2) * 16 + 4 * (lane >> 4) + (j & 3);
-    v[j] = (row < n && col <= row) ? linv[row * npad + col] : 0.0f;
+    const TF x = (row < n && col <= row) ? linv[row * npad + col] : (TF)0;
+    v[j] = (float)x;
+    lo[j] = (float)(x - (TF)v[j]);
   }
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     u32x4 f;
 #pragma unroll
     for (int h = 0; h < 4; ++h) f[h] = bf16_split_pair(v[2 * h], v[2 * h + 1]);
+    if (s == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += lo[j];
+    }
     out[((int64_t)s * npad16 + rt) * npad32 * 64 + kq * 64 + lane] = f;
   }
 }
 
-template <int NS, int KERNEL, bool DIAG>
+template <typename TG>
+struct Bf16Lds {
+  // bytes of one X buffer: 2 k-tiles of fragments (TG), 32 norms (TG, padded to 64), 32 alphas (float, padded to 64)
+  static __host__ __device__ constexpr int xbytes(int dp4) { return 2 * dp4 * 64 * (int)sizeof(TG) + 64 * (int)sizeof(TG) + 256; }
+};
+
+template <int NS, typename TG, int KERNEL, bool DIAG>
 __device__ __forceinline__ void leaf_bf16_step(int q, int q_diag0, int lane, int dp4,
                                                const u32x4* panel_b /* [NS][16][64] */,
-                                               const float* xs_b /* [2][dp4][64] | norms[64] | alpha[64] */,
-                                               const float* xb, const float (&nb)[2], float variance,
+                                               const unsigned char* xs_b /* [2][dp4] X fragments | norms | alpha */,
+                                               const TG* xb, const TG (&nb)[2], float variance,
                                                f32x4 (&acc)[16][2], float (&macc)[2]) {
-  using M = Mfma<float>;
+  using MG = Mfma<TG>;
+  using vecG = typename MG::vec4;
   constexpr int RT = 16, CT = 2;
-  constexpr float C2 = (float)KernScale<KERNEL>::C2;
-  // ---- generate the two 16-point tiles of this k-step (f32) -------------------------------------
-  f32x4 s[2][CT];
+  constexpr int XB = 64 * (int)sizeof(TG);
+  constexpr TG C2 = (TG)KernScale<KERNEL>::C2;
+  // ---- generate the two 16-point tiles of this k-step (TG) --------------------------------------
+  vecG s[2][CT];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int t = 0; t < CT; ++t) s[h][t] = f32x4{0, 0, 0, 0};
+    for (int t = 0; t < CT; ++t) s[h][t] = vecG{0, 0, 0, 0};
   for (int c = 0; c < dp4; ++c) {
-    const float x0 = xs_b[c * 64 + lane], x1 = xs_b[(dp4 + c) * 64 + lane];
+    const TG x0 = reinterpret_cast<const TG*>(xs_b + c * XB)[lane];
+    const TG x1 = reinterpret_cast<const TG*>(xs_b + (dp4 + c) * XB)[lane];
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
-      const float l = xb[(t * dp4 + c) * 64 + lane];
-      s[0][t] = M::mma(x0, l, s[0][t]);
-      s[1][t] = M::mma(x1, l, s[1][t]);
+      const TG l = xb[(t * dp4 + c) * 64 + lane];
+      s[0][t] = MG::mma(x0, l, s[0][t]);
+      s[1][t] = MG::mma(x1, l, s[1][t]);
     }
   }
   float p[CT][8];
   // norms and alpha of the 32 points of this k-step arrived in LDS with the panel (no ordinary global
   // load inside the loop: one issued after the LDS-DMA makes hipcc drain the DMA queue at its use)
-  const float* nrm = xs_b + 2 * dp4 * 64;
+  const TG* nrm = reinterpret_cast<const TG*>(xs_b + 2 * dp4 * XB);
+  const float* alp = reinterpret_cast<const float*>(xs_b + 2 * dp4 * XB + 64 * sizeof(TG));
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const f32x4 na = *reinterpret_cast<const f32x4*>(nrm + 16 * h + 4 * (lane >> 4)) * C2;
+    const vecG na = *reinterpret_cast<const vecG*>(nrm + 16 * h + 4 * (lane >> 4)) * C2;
 #pragma unroll
     for (int t = 0; t < CT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        p[t][4 * h + r] = kern_from_scaled<KERNEL>(fma_t(-2.0f * C2, s[h][t][r], na[r] + nb[t]), variance);
+        p[t][4 * h + r] = kern_from_scaled<KERNEL>((float)fma_t((TG)(TG(-2) * C2), s[h][t][r], na[r] + nb[t]), variance);
   }
   if (DIAG) {  // this k-step lies in the diagonal block: its share of k*.alpha (f32, before the split)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const f32x4 a4 = *reinterpret_cast<const f32x4*>(nrm + 64 + 16 * h + 4 * (lane >> 4));
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(alp + 16 * h + 4 * (lane >> 4));
 #pragma unroll
       for (int t = 0; t < CT; ++t)
 #pragma unroll
@@ -634,21 +489,23 @@ __device__ __forceinline__ void leaf_bf16_step(int q, int q_diag0, int lane, int
   }
 }
 
-template <int NS, int KERNEL>
+template <int NS, typename TG, int KERNEL>
 __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
-    const u32x4* __restrict__ linv_b, const float* __restrict__ xs_p, const float* __restrict__ xnorm,
-    const float* __restrict__ alpha, const float* __restrict__ leaves_s,
-    const float* __restrict__ lnorm, float* __restrict__ part_var, float* __restrict__ part_mean,
-    int npad16, int dp4, int64_t mpad, int nbi, float variance) {
+    const u32x4* __restrict__ linv_b, const TG* __restrict__ xs_p, const TG* __restrict__ xnorm,
+    const float* __restrict__ alpha, const TG* __restrict__ leaves_s,
+    const TG* __restrict__ lnorm, double* __restrict__ part_var, double* __restrict__ part_mean,
+    int npad16, int dp4, int64_t mpad, int nbi, float variance, const int64_t* __restrict__ m_live) {
   constexpr int RT = 16, CT = 2, NW = 8;
-  constexpr float C2 = (float)KernScale<KERNEL>::C2;
+  constexpr int XB = 64 * (int)sizeof(TG);
+  constexpr TG C2 = (TG)KernScale<KERNEL>::C2;
   extern __shared__ __align__(16) unsigned char lds_raw[];
+  if (m_live != nullptr && (int64_t)blockIdx.x * (NW * CT * 16) >= *m_live) return;  // workgroup-uniform
   u32x4* panel = reinterpret_cast<u32x4*>(lds_raw);                 // [2][NS][RT][64]
-  float* xsl = reinterpret_cast<float*>(panel + 2 * NS * RT * 64);  // [2][2][dp4][64]
+  unsigned char* xsl = reinterpret_cast<unsigned char*>(panel + 2 * NS * RT * 64);  // [2] X buffers
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int xstride = 2 * dp4 * 64 + 128;  // floats per X buffer: 2 k-tiles of fragments, norms, alpha
-  float* xb = xsl + 2 * xstride + (size_t)wave * CT * dp4 * 64;  // [CT][dp4][64] per wave
+  const int xstride = Bf16Lds<TG>::xbytes(dp4);
+  TG* xb = reinterpret_cast<TG*>(xsl + 2 * xstride) + (size_t)wave * CT * dp4 * 64;  // [CT][dp4][64] per wave
 
   const int bi = nbi - 1 - (int)blockIdx.y;
   const int64_t col0 = ((int64_t)blockIdx.x * NW + wave) * (CT * 16);
@@ -662,13 +519,18 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
       glds16(linv_b + (((size_t)sp * npad16 + (bi * RT + rt)) * npad32 + q) * 64 + lane,
              panel + ((buf * NS + sp) * RT + rt) * 64);
     }
+    unsigned char* xd = xsl + buf * xstride;
     for (int i = wave; i < 2 * dp4; i += NW) {
       const int h = i / dp4, c = i % dp4;
-      glds4(xs_p + ((size_t)(2 * q + h) * dp4 + c) * 64 + lane, xsl + buf * xstride + (h * dp4 + c) * 64);
+      glds_xfrag<TG>(xs_p + ((size_t)(2 * q + h) * dp4 + c) * 64, xd + (h * dp4 + c) * XB, lane);
     }
-    // 32 norms / 32 alphas of the k-step (lanes 32-63 fetch duplicates into the unused half)
-    if (wave == NW - 1) glds4(xnorm + 32 * q + (lane & 31), xsl + buf * xstride + 2 * dp4 * 64);
-    if (wave == NW - 2) glds4(alpha + 32 * q + (lane & 31), xsl + buf * xstride + 2 * dp4 * 64 + 64);
+    // 32 norms (TG) / 32 alphas (float) of the k-step as linear images (float: lanes 32-63 fetch
+    // duplicates into the unused half)
+    if (wave == NW - 1) {
+      if (sizeof(TG) == 8) glds4(reinterpret_cast<const unsigned*>(xnorm + 32 * q) + lane, xd + 2 * dp4 * XB);
+      else glds4(reinterpret_cast<const unsigned*>(xnorm + 32 * q) + (lane & 31), xd + 2 * dp4 * XB);
+    }
+    if (wave == NW - 2) glds4(alpha + 32 * q + (lane & 31), xd + 2 * dp4 * XB + 64 * sizeof(TG));
   };
 
   issue(0, 0);
@@ -676,7 +538,7 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     for (int c = 0; c < dp4; ++c)
       xb[(t * dp4 + c) * 64 + lane] =
           leaves_s[(col0 + t * 16 + (lane & 15)) * dp + 4 * c + (lane >> 4)];
-  float nb[CT];
+  TG nb[CT];
 #pragma unroll
   for (int t = 0; t < CT; ++t) nb[t] = lnorm[col0 + t * 16 + (lane & 15)] * C2;
   f32x4 acc[RT][CT];
@@ -690,28 +552,28 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   for (int q = 0; q < q_diag0; ++q) {
     const int b = q & 1;
     issue(q + 1, b ^ 1);
-    leaf_bf16_step<NS, KERNEL, false>(q, q_diag0, lane, dp4, panel + b * NS * RT * 64,
-                                      xsl + b * xstride, xb, nb, variance, acc, macc);
+    leaf_bf16_step<NS, TG, KERNEL, false>(q, q_diag0, lane, dp4, panel + b * NS * RT * 64,
+                                          xsl + b * xstride, xb, nb, variance, acc, macc);
     __syncthreads();
   }
   for (int q = q_diag0; q < q_end; ++q) {
     const int b = q & 1;
     if (q + 1 < q_end) issue(q + 1, b ^ 1);
-    leaf_bf16_step<NS, KERNEL, true>(q, q_diag0, lane, dp4, panel + b * NS * RT * 64,
-                                     xsl + b * xstride, xb, nb, variance, acc, macc);
+    leaf_bf16_step<NS, TG, KERNEL, true>(q, q_diag0, lane, dp4, panel + b * NS * RT * 64,
+                                         xsl + b * xstride, xb, nb, variance, acc, macc);
     __syncthreads();
   }
 
 #pragma unroll
   for (int t = 0; t < CT; ++t) {
-    float sq = 0;
+    double sq = 0;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sq = fma_t(acc[rt][t][r], acc[rt][t][r], sq);
+      for (int r = 0; r < 4; ++r) sq = fma((double)acc[rt][t][r], (double)acc[rt][t][r], sq);
     sq += __shfl_xor(sq, 16);
     sq += __shfl_xor(sq, 32);
-    float mm = macc[t];
+    double mm = (double)macc[t];
     mm += __shfl_xor(mm, 16);
     mm += __shfl_xor(mm, 32);
     if (lane < 16) {
@@ -722,26 +584,24 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   }
 }
 
-template <int NS>
-static void launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const float* xs_p,
-                                      const float* xnorm, const float* alpha, const float* leaves_s,
-                                      const float* lnorm, float* part_var, float* part_mean,
-                                      int64_t npad, int dp4, int64_t mpad, const KernParams& kp) {
+template <int NS, typename TG>
+static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const TG* xs_p,
+                                     const TG* xnorm, const float* alpha, const TG* leaves_s,
+                                     const TG* lnorm, double* part_var, double* part_mean,
+                                     int64_t npad, int dp4, int64_t mpad, const KernParams& kp,
+                                     const int64_t* m_live) {
   const int nbi = (int)(npad / 256);
   const dim3 grid((unsigned)(mpad / 256), (unsigned)nbi);
-  const size_t lds = (size_t)2 * NS * 16 * 64 * 16 + (size_t)2 * (2 * dp4 * 64 + 128) * 4 + (size_t)8 * 2 * dp4 * 64 * 4;
-#define GPSO_L(K)                                                                                  \
-  hipLaunchKernelGGL((leaf_tiles_bf16_kernel<NS, K>), grid, dim3(512), lds, st,                    \
-                     static_cast<const u32x4*>(linv_b), xs_p, xnorm, alpha, leaves_s, lnorm,       \
-                     part_var, part_mean, (int)(npad / 16), dp4, mpad, nbi, (float)kp.variance)
-  static bool attr_set = false;
-  if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in attribute
-    (void)hipFuncSetAttribute((const void*)leaf_tiles_bf16_kernel<NS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)leaf_tiles_bf16_kernel<NS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)leaf_tiles_bf16_kernel<NS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)leaf_tiles_bf16_kernel<NS, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  const size_t lds = leaf_bf16_lds_bytes(NS, dp4, (int)sizeof(TG));
+#define GPSO_L(K)                                                                                   \
+  do {                                                                                              \
+    const int rc = ensure_dyn_lds((const void*)leaf_tiles_bf16_kernel<NS, TG, K>, (int)lds);        \
+    if (rc) return rc;                                                                              \
+    hipLaunchKernelGGL((leaf_tiles_bf16_kernel<NS, TG, K>), grid, dim3(512), lds, st,               \
+                       static_cast<const u32x4*>(linv_b), xs_p, xnorm, alpha, leaves_s, lnorm,      \
+                       part_var, part_mean, (int)(npad / 16), dp4, mpad, nbi, (float)kp.variance,   \
+                       m_live);                                                                     \
+  } while (0)
   switch (kp.kernel) {
     case 0: GPSO_L(0); break;
     case 1: GPSO_L(1); break;
@@ -749,32 +609,37 @@ static void launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const 
     default: GPSO_L(3); break;
   }
 #undef GPSO_L
+  return 0;
 }
 
-void launch_leaf_tiles_bf16(hipStream_t st, int nsplit, const void* linv_b, const float* xs_p,
-                            const float* xnorm, const float* alpha, const float* leaves_s,
-                            const float* lnorm, float* part_var, float* part_mean, int64_t npad,
-                            int dp4, int64_t mpad, const KernParams& kp) {
+template <typename TG>
+int launch_leaf_tiles_bf16(hipStream_t st, int nsplit, const void* linv_b, const TG* xs_p,
+                           const TG* xnorm, const float* alpha, const TG* leaves_s,
+                           const TG* lnorm, double* part_var, double* part_mean, int64_t npad,
+                           int dp4, int64_t mpad, const KernParams& kp, const int64_t* m_live) {
   if (nsplit == 3)
-    launch_leaf_tiles_bf16_ns<3>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp);
-  else
-    launch_leaf_tiles_bf16_ns<2>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp);
+    return launch_leaf_tiles_bf16_ns<3, TG>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live);
+  return launch_leaf_tiles_bf16_ns<2, TG>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live);
 }
+template int launch_leaf_tiles_bf16<float>(hipStream_t, int, const void*, const float*, const float*, const float*, const float*, const float*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*);
+template int launch_leaf_tiles_bf16<double>(hipStream_t, int, const void*, const double*, const double*, const float*, const double*, const double*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*);
 
-void launch_pack_linv_bf16(hipStream_t st, int nsplit, const float* linv, int64_t n, int64_t npad,
+template <typename TF>
+void launch_pack_linv_bf16(hipStream_t st, int nsplit, const TF* linv, int64_t n, int64_t npad,
                            void* linv_b) {
   const int64_t total = (npad / 16) * (npad / 32) * 64;
   const dim3 grid((unsigned)((total + 255) / 256));
   if (nsplit == 3)
-    hipLaunchKernelGGL((pack_linv_bf16_kernel<3>), grid, dim3(256), 0, st, linv, n, npad, static_cast<u32x4*>(linv_b));
+    hipLaunchKernelGGL((pack_linv_bf16_kernel<3, TF>), grid, dim3(256), 0, st, linv, n, npad, static_cast<u32x4*>(linv_b));
   else
-    hipLaunchKernelGGL((pack_linv_bf16_kernel<2>), grid, dim3(256), 0, st, linv, n, npad, static_cast<u32x4*>(linv_b));
+    hipLaunchKernelGGL((pack_linv_bf16_kernel<2, TF>), grid, dim3(256), 0, st, linv, n, npad, static_cast<u32x4*>(linv_b));
 }
+template void launch_pack_linv_bf16<float>(hipStream_t, int, const float*, int64_t, int64_t, void*);
+template void launch_pack_linv_bf16<double>(hipStream_t, int, const double*, int64_t, int64_t, void*);
 
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void leaf_finalize_kernel(const T* __restrict__ part_var,
-                                                            const T* __restrict__ part_mean,
+__global__ __launch_bounds__(256) void leaf_finalize_kernel(const double* __restrict__ part_var,
+                                                            const double* __restrict__ part_mean,
                                                             int nbi, int64_t mpad, int64_t m,
                                                             KernParams kp, double varsigma,
                                                             double* __restrict__ mean,
@@ -784,8 +649,8 @@ __global__ __launch_bounds__(256) void leaf_finalize_kernel(const T* __restrict_
   if (j >= m) return;
   double v = 0, mu = 0;
   for (int b = 0; b < nbi; ++b) {
-    v += (double)part_var[(int64_t)b * mpad + j];
-    mu += (double)part_mean[(int64_t)b * mpad + j];
+    v += part_var[(int64_t)b * mpad + j];
+    mu += part_mean[(int64_t)b * mpad + j];
   }
   // [gpflow base_conditional] fvar = k** - sum A^2 ; predict_y adds the noise variance
   const double vy = __dadd_rn(__dsub_rn(kp.variance, v), kp.noise);
@@ -877,136 +742,97 @@ __global__ __launch_bounds__(256) void seg_argmax_stage2(const Best* __restrict_
   }
 }
 
+
 // ---------------------------------------------------------------------------------------------
 // host-side launchers (declared in kernels.hpp)
-template <typename T, typename TIN>
+template <typename TG, typename TIN>
 void launch_prep_leaves(hipStream_t st, const TIN* xs, int64_t m, int64_t mpad, int d, int dp,
-                        const double* ls, T* out, T* norm) {
+                        const double* ls, const int64_t* m_live, TG* out, TG* norm) {
   const int64_t blocks = (mpad + 255) / 256;
-  hipLaunchKernelGGL((prep_leaves_kernel<T, TIN>), dim3((unsigned)blocks), dim3(256), 0, st, xs, m,
-                     mpad, d, dp, ls, out, norm);
+  hipLaunchKernelGGL((prep_leaves_kernel<TG, TIN>), dim3((unsigned)blocks), dim3(256), 0, st, xs, m,
+                     mpad, d, dp, ls, m_live, out, norm);
 }
-template void launch_prep_leaves<float, float>(hipStream_t, const float*, int64_t, int64_t, int, int, const double*, float*, float*);
-template void launch_prep_leaves<float, double>(hipStream_t, const double*, int64_t, int64_t, int, int, const double*, float*, float*);
-template void launch_prep_leaves<double, float>(hipStream_t, const float*, int64_t, int64_t, int, int, const double*, double*, double*);
-template void launch_prep_leaves<double, double>(hipStream_t, const double*, int64_t, int64_t, int, int, const double*, double*, double*);
+template void launch_prep_leaves<float, float>(hipStream_t, const float*, int64_t, int64_t, int, int, const double*, const int64_t*, float*, float*);
+template void launch_prep_leaves<float, double>(hipStream_t, const double*, int64_t, int64_t, int, int, const double*, const int64_t*, float*, float*);
+template void launch_prep_leaves<double, float>(hipStream_t, const float*, int64_t, int64_t, int, int, const double*, const int64_t*, double*, double*);
+template void launch_prep_leaves<double, double>(hipStream_t, const double*, int64_t, int64_t, int, int, const double*, const int64_t*, double*, double*);
 
+// rows of L^-1 per workgroup.  float: 256 rows x 32 leaves per wave, or -- once D and the number of
+// row blocks are large -- 512 rows x 16 leaves: every generated K* tile then feeds 32 row tiles
+// instead of 16, which halves the regeneration share (measured in round 1: C5 +6.4 %, C4 +1.9 %,
+// C3 -4 %).  double: 256 rows x 16 leaves.  128-row blocks when N_pad is an odd multiple of 128.
 template <>
 int leaf_tiles_bm<float>(int64_t npad, int dp4) {
-  static const char* force = getenv("GPSO_LEAF_BM");  // experiment switch: 128 | 256 | 512
-  static const bool v1 = getenv("GPSO_LEAF_V1") != nullptr;
-  if (force && atoi(force) == 128) return 128;
-  if (npad % 512 == 0 && !v1) {
-    if (force && atoi(force) == 512) return 512;
-    // 512 rows x 16 leaves per wave: every generated K* tile feeds 32 row tiles instead of 16, which
-    // halves the regeneration share (D / 4 generation MFMAs per 64 apply MFMAs and row block; 15 % of
-    // the matrix work at D = 40).  Pays once D and the number of row blocks are large (measured: C5
-    // +6.4 %, C4 +1.9 %, N = 4096 / D = 40 +4 %, N = 2048 / D = 40 +2 %; C3 -4 %, N = 2048 / D = 20 -2 %).
-    if (!force && ((npad >= 4096 && dp4 >= 5) || (npad >= 2048 && dp4 >= 9))) return 512;
-  }
+  if (npad % 512 == 0 && ((npad >= 4096 && dp4 >= 5) || (npad >= 2048 && dp4 >= 9))) return 512;
   return (npad % 256 == 0) ? 256 : 128;
 }
 template <>
 int leaf_tiles_bm<double>(int64_t npad, int dp4) {
   (void)dp4;
-  static const bool v1 = getenv("GPSO_LEAF_V1") != nullptr;
-  if (v1) return 64;
   return (npad % 256 == 0) ? 256 : 128;
 }
 
-template <typename T, int BM, int CT, int KERNEL>
-static void launch_leaf_tiles_k(hipStream_t st, const T* linv_p, const T* xs_p, const T* xnorm,
-                                const T* alpha, const T* leaves_s, const T* lnorm, T* part_var,
-                                T* part_mean, int64_t npad, int dp4, int64_t mpad,
-                                const KernParams& kp) {
-  const int nbi = (int)(npad / BM);
-  const dim3 grid((unsigned)(mpad / (4 * CT * 16)), (unsigned)nbi);
-  const size_t lds = (size_t)4 * CT * dp4 * 64 * sizeof(T);
-  hipLaunchKernelGGL((leaf_tiles_kernel<T, BM, CT, KERNEL>), grid, dim3(256), lds, st, linv_p, xs_p,
-                     xnorm, alpha, leaves_s, lnorm, part_var, part_mean, (int)(npad / 16), dp4, mpad,
-                     nbi, (T)kp.variance);
-}
-
-template <typename T, int BM, int CT, int KERNEL>
-static void launch_leaf_tiles_v2(hipStream_t st, const T* linv_p, const T* xs_p, const T* xnorm,
-                                 const T* alpha, const T* leaves_s, const T* lnorm, T* part_var,
-                                 T* part_mean, int64_t npad, int dp4, int64_t mpad,
-                                 const KernParams& kp) {
+template <typename T, typename TG, int BM, int CT, int KERNEL>
+static int launch_leaf_tiles_v2(hipStream_t st, const T* linv_p, const TG* xs_p, const TG* xnorm,
+                                const T* alpha, const TG* leaves_s, const TG* lnorm, double* part_var,
+                                double* part_mean, int64_t npad, int dp4, int64_t mpad,
+                                const KernParams& kp, const int64_t* m_live) {
   constexpr int RT = BM / 16;
   const int nbi = (int)(npad / BM);
   const dim3 grid((unsigned)(mpad / (4 * CT * 16)), (unsigned)nbi);
-  const size_t lds = leaf_v2_lds_bytes<T, CT, 0>(RT, dp4);
-  if (lds > 64 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)leaf_tiles_v2_kernel<T, BM, CT, KERNEL>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
-  }
-  hipLaunchKernelGGL((leaf_tiles_v2_kernel<T, BM, CT, KERNEL>), grid, dim3(256), lds, st, linv_p, xs_p,
-                     xnorm, alpha, leaves_s, lnorm, part_var, part_mean, (int)(npad / 16), dp4, mpad,
-                     nbi, (T)kp.variance);
+  const size_t lds = leaf_v2_lds_bytes<T, TG, CT>(RT, dp4);
+  const int rc = ensure_dyn_lds((const void*)leaf_tiles_v2_kernel<T, TG, BM, CT, KERNEL>, (int)lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL((leaf_tiles_v2_kernel<T, TG, BM, CT, KERNEL>), grid, dim3(256), lds, st, linv_p, xs_p,
+                     xnorm, alpha, leaves_s, lnorm, part_var, part_mean, dp4, mpad, nbi, (T)kp.variance,
+                     m_live);
+  return 0;
 }
 
-template <typename T, int KERNEL>
-static void launch_leaf_tiles_shape(hipStream_t st, const T* linv_p, const T* xs_p, const T* xnorm,
-                                    const T* alpha, const T* leaves_s, const T* lnorm, T* part_var,
-                                    T* part_mean, int64_t npad, int dp4, int64_t mpad,
-                                    const KernParams& kp) {
-#define GPSO_ARGS st, linv_p, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp
-  static const bool v1 = getenv("GPSO_LEAF_V1") != nullptr;  // A/B switch (same results)
+template <typename T, typename TG, int KERNEL>
+static int launch_leaf_tiles_shape(hipStream_t st, const T* linv_p, const TG* xs_p, const TG* xnorm,
+                                   const T* alpha, const TG* leaves_s, const TG* lnorm, double* part_var,
+                                   double* part_mean, int64_t npad, int dp4, int64_t mpad,
+                                   const KernParams& kp, const int64_t* m_live) {
+#define GPSO_ARGS st, linv_p, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live
+  const int bm = leaf_tiles_bm<T>(npad, dp4);
   if constexpr (sizeof(T) == 4) {
-    if (!v1) {
-      if (leaf_tiles_bm<T>(npad, dp4) == 512)
-        launch_leaf_tiles_v2<T, 512, 1, KERNEL>(GPSO_ARGS);
-      else if (leaf_tiles_bm<T>(npad, dp4) == 256)
-        launch_leaf_tiles_v2<T, 256, 2, KERNEL>(GPSO_ARGS);
-      else
-        launch_leaf_tiles_v2<T, 128, 4, KERNEL>(GPSO_ARGS);
-    } else if (leaf_tiles_bm<T>(npad, dp4) == 256) {
-      launch_leaf_tiles_k<T, 256, 2, KERNEL>(GPSO_ARGS);
-    } else {
-      launch_leaf_tiles_k<T, 128, 4, KERNEL>(GPSO_ARGS);
-    }
+    if (bm == 512) return launch_leaf_tiles_v2<T, TG, 512, 1, KERNEL>(GPSO_ARGS);
+    if (bm == 256) return launch_leaf_tiles_v2<T, TG, 256, 2, KERNEL>(GPSO_ARGS);
+    return launch_leaf_tiles_v2<T, TG, 128, 4, KERNEL>(GPSO_ARGS);
   } else {
     // float64: 16 accumulator tiles of 8 VGPRs; 256 (128) rows x 16 leaves per wave keeps the number
     // of generated entries per MFMA low (the f64 kernel map is VALU-expensive)
-    if (v1)
-      launch_leaf_tiles_k<T, 64, 2, KERNEL>(GPSO_ARGS);
-    else if (leaf_tiles_bm<T>(npad, dp4) == 256)
-      launch_leaf_tiles_v2<T, 256, 1, KERNEL>(GPSO_ARGS);
-    else
-      launch_leaf_tiles_v2<T, 128, 2, KERNEL>(GPSO_ARGS);
+    if (bm == 256) return launch_leaf_tiles_v2<T, TG, 256, 1, KERNEL>(GPSO_ARGS);
+    return launch_leaf_tiles_v2<T, TG, 128, 2, KERNEL>(GPSO_ARGS);
   }
 }
 
-template <typename T>
-void launch_leaf_tiles(hipStream_t st, const T* linv_p, const T* xs_p, const T* xnorm,
-                       const T* alpha, const T* leaves_s, const T* lnorm, T* part_var, T* part_mean,
-                       int64_t npad, int dp4, int64_t mpad, const KernParams& kp) {
+template <typename T, typename TG>
+int launch_leaf_tiles(hipStream_t st, const T* linv_p, const TG* xs_p, const TG* xnorm,
+                      const T* alpha, const TG* leaves_s, const TG* lnorm, double* part_var,
+                      double* part_mean, int64_t npad, int dp4, int64_t mpad, const KernParams& kp,
+                      const int64_t* m_live) {
   switch (kp.kernel) {
-    case 0: launch_leaf_tiles_shape<T, 0>(GPSO_ARGS); break;
-    case 1: launch_leaf_tiles_shape<T, 1>(GPSO_ARGS); break;
-    case 2: launch_leaf_tiles_shape<T, 2>(GPSO_ARGS); break;
-    default: launch_leaf_tiles_shape<T, 3>(GPSO_ARGS); break;
+    case 0: return launch_leaf_tiles_shape<T, TG, 0>(GPSO_ARGS);
+    case 1: return launch_leaf_tiles_shape<T, TG, 1>(GPSO_ARGS);
+    case 2: return launch_leaf_tiles_shape<T, TG, 2>(GPSO_ARGS);
+    default: return launch_leaf_tiles_shape<T, TG, 3>(GPSO_ARGS);
   }
 #undef GPSO_ARGS
 }
-template void launch_leaf_tiles<float>(hipStream_t, const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, int64_t, int, int64_t, const KernParams&);
-template void launch_leaf_tiles<double>(hipStream_t, const double*, const double*, const double*, const double*, const double*, const double*, double*, double*, int64_t, int, int64_t, const KernParams&);
+template int launch_leaf_tiles<float, float>(hipStream_t, const float*, const float*, const float*, const float*, const float*, const float*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*);
+template int launch_leaf_tiles<float, double>(hipStream_t, const float*, const double*, const double*, const float*, const double*, const double*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*);
+template int launch_leaf_tiles<double, double>(hipStream_t, const double*, const double*, const double*, const double*, const double*, const double*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*);
 
-template <typename T>
-void launch_leaf_finalize(hipStream_t st, const T* part_var, const T* part_mean, int nbi,
+void launch_leaf_finalize(hipStream_t st, const double* part_var, const double* part_mean, int nbi,
                           int64_t mpad, int64_t m, const KernParams& kp, double varsigma,
                           double* mean, double* var, double* ucb) {
   const int64_t blocks = (m + 255) / 256;
   if (blocks == 0) return;
-  hipLaunchKernelGGL((leaf_finalize_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, part_var,
+  hipLaunchKernelGGL(leaf_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part_var,
                      part_mean, nbi, mpad, m, kp, varsigma, mean, var, ucb);
 }
-template void launch_leaf_finalize<float>(hipStream_t, const float*, const float*, int, int64_t, int64_t, const KernParams&, double, double*, double*, double*);
-template void launch_leaf_finalize<double>(hipStream_t, const double*, const double*, int, int64_t, int64_t, const KernParams&, double, double*, double*, double*);
 
 void launch_seg_argmax(hipStream_t st, const double* mean, const double* var, const double* ucb,
                        const int64_t* seg_off_dev, int nseg, int nblk, void* partial_dev,

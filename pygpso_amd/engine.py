@@ -19,13 +19,38 @@ def _is_device_tensor(x):
     return hasattr(x, "data_ptr") and getattr(x, "is_cuda", False)
 
 
+def _producer_stream(x):
+    """hipStream_t (int) on which the framework that owns the device tensor ``x`` is currently
+    queueing work for x's device.  Only torch tensors are recognised -- through the module the CALLER
+    has already imported; this package never imports torch itself.  None: unknown (the C-ABI then
+    relies on its documented contract: device buffers must be ready before the call)."""
+    import sys
+
+    torch = sys.modules.get("torch")
+    if torch is None or not isinstance(x, torch.Tensor):
+        return None
+    return int(torch.cuda.current_stream(x.device).cuda_stream)
+
+
 class HipGPEngine:
-    def __init__(self, dtype="float64", device=0, predict_math="native"):
-        """``predict_math`` (float32 engines only): "native" f32 MFMA, or the split-bf16 modes
-        "bf16x6" (f32-class accuracy) / "bf16x3" (|d var| ~ 2e-5 sigma^2) on the bf16 matrix cores."""
+    def __init__(self, dtype="float64", device=0, predict_math="native", generation=None,
+                 precision_check=None, tol_var=None, tol_mean=None):
+        """``dtype``: "float64" (fit and predict in double: the reference's arithmetic), "float32" (fit
+        and predict apply in float) or "mixed" (fit in double, predict apply in float: the
+        hyper-parameter path is bit-identical to float64).
+        ``predict_math`` (float-predict engines only): "native" f32 MFMA, or the split-bf16 modes
+        "bf16x6" (f32-class accuracy) / "bf16x3" (|d var| ~ 2e-5 sigma^2) on the bf16 matrix cores.
+        ``generation`` (float-predict engines): "float64" (default; r^2 of the cross-Gram tile formed
+        in double) or "float32" (GPflow's GEMM form in float: faster, |d r^2| ~ 1e-5).
+        ``precision_check`` / ``tol_var`` / ``tol_mean``: the self-test that guards float predictions
+        (include/gpso_hip.h: gpso_precision_info); on by default for float-predict engines."""
         self._lib = L.load()
-        self.dtype = {"float64": L.F64, "fp64": L.F64, "f64": L.F64, np.float64: L.F64,
-                      "float32": L.F32, "fp32": L.F32, "f32": L.F32, np.float32: L.F32}[dtype]
+        if dtype is np.float64:
+            dtype = "float64"
+        elif dtype is np.float32:
+            dtype = "float32"
+        self.dtype_name = {L.F64: "float64", L.F32: "float32", L.MIXED: "mixed"}[L.DTYPE_IDS[dtype]]
+        self.dtype = L.DTYPE_IDS[dtype]
         self.device = int(device)
         handle = C.c_void_p()
         rc = self._lib.gpso_create(C.byref(handle), self.device, self.dtype)
@@ -36,6 +61,12 @@ class HipGPEngine:
         self.d = 0
         if predict_math not in (None, "native", "f32"):
             self.set_predict_math(predict_math)
+        if generation is not None:
+            self.set_generation(generation)
+        if precision_check is not None:
+            self.set_precision_check(precision_check)
+        if tol_var is not None or tol_mean is not None:
+            self.set_tolerances(tol_var, tol_mean)
 
     # -- plumbing ----------------------------------------------------------------------------
     def close(self):
@@ -56,11 +87,45 @@ class HipGPEngine:
                 raise np.linalg.LinAlgError(msg)
             if rc == L.E_ARG:
                 raise ValueError(msg)
+            if rc == L.E_PRECISION:
+                raise L.GpsoPrecisionError(rc, msg)
             raise L.GpsoHipError(rc, msg)
         return rc
 
     def set_predict_math(self, mode):
         self._check(self._lib.gpso_set_option(self._h, L.OPT_PREDICT_MATH, L.MATH_IDS[mode]))
+
+    def set_generation(self, mode):
+        """"float64" (default) | "float32": arithmetic of the cross-Gram x.x* contraction and r^2."""
+        self._check(self._lib.gpso_set_option(self._h, L.OPT_GENERATION, L.GEN_IDS[mode]))
+
+    def set_precision_check(self, on):
+        self._check(self._lib.gpso_set_option(self._h, L.OPT_PRECISION_CHECK, 1 if on else 0))
+
+    def set_tolerances(self, tol_var=None, tol_mean=None):
+        """Self-test tolerances: |d var| <= tol_var * sigma^2, |d mean| <= tol_mean * max|y - c|."""
+        if tol_var is not None:
+            self._check(self._lib.gpso_set_option_f64(self._h, L.OPTF_TOL_VAR, float(tol_var)))
+        if tol_mean is not None:
+            self._check(self._lib.gpso_set_option_f64(self._h, L.OPTF_TOL_MEAN, float(tol_mean)))
+
+    def precision_info(self, raise_on_fail=False):
+        """Self-test of the resident posterior (runs it if needed): measured errors of the predict path
+        at the training inputs against their closed form, and the tolerances they are held to."""
+        out = np.zeros(10, dtype=np.float64)
+        rc = self._lib.gpso_precision_info(self._h, L.dptr(out))
+        if rc not in (L.OK, L.E_PRECISION) or (rc == L.E_PRECISION and raise_on_fail):
+            self._check(rc)
+        keys = ("max_abs_err_mean", "max_abs_err_var", "max_abs_y_minus_c", "min_var", "max_abs_alpha",
+                "kernel_variance", "tol_mean_abs", "tol_var_abs", "amplification", "max_kinv_diag")
+        info = dict(zip(keys, (float(v) for v in out)))
+        info["passed"] = rc == L.OK
+        return info
+
+    def wait_stream(self, stream_ptr):
+        """Order this engine's stream behind the work queued on another hipStream_t (int pointer;
+        0 / None = the legacy default stream)."""
+        self._check(self._lib.gpso_wait_stream(self._h, C.c_void_p(stream_ptr or None)))
 
     def set_fit_single_level_max(self, npad_max):
         """Tuning / test hook (GPSO_OPT_FIT_SINGLE_LEVEL_MAX): 0 forces the two-level Cholesky path."""
@@ -130,6 +195,7 @@ class HipGPEngine:
                 raise ValueError(f"unsupported leaf dtype {xs.dtype}")
             if self.d and xs.shape[1] != self.d:
                 raise ValueError(f"leaves have D={xs.shape[1]}, model has D={self.d}")
+            self._order_after(xs)
             return C.c_void_p(xs.data_ptr()), dt, L.MEM_DEVICE, int(xs.shape[0]), xs
         a = np.asarray(xs)
         if a.ndim != 2:
@@ -144,12 +210,22 @@ class HipGPEngine:
             dt = L.F64
         return C.c_void_p(a.ctypes.data), dt, L.MEM_HOST, int(a.shape[0]), a
 
+    def _order_after(self, tensor):
+        """The engine runs on its own stream: queue it behind whatever the tensor's framework has
+        pending on its current stream (reads of leaves still being written / writes into outputs still
+        being read would otherwise race)."""
+        ps = _producer_stream(tensor)
+        if ps is not None:
+            self.wait_stream(ps)
+
     def predict(self, xs, out=None):
         """predict_y: (mean[M], var[M]) float64; var includes the noise variance.  ``out`` may be a
         pair of float64 CUDA tensors of length M to keep the results on the device."""
         ptr, dt, mem, m, keep = self._leaf_args(xs)
         if out is not None:
             mean_t, var_t = out
+            self._order_after(mean_t)
+            self._order_after(var_t)
             self._check(self._lib.gpso_predict(self._h, ptr, dt, mem, m, C.c_void_p(mean_t.data_ptr()),
                                                C.c_void_p(var_t.data_ptr()), L.MEM_DEVICE))
             return mean_t, var_t

@@ -213,7 +213,7 @@ class GPSurrogate:
         raise NotImplementedError
 
     def __init__(self, gp_kernel, gp_meanf=None, optimiser=None, varsigma=erfcinv(0.01), points=None,
-                 gpflow_model=None, dtype="float64", device=0):
+                 gpflow_model=None, dtype="float64", device=0, engine_options=None):
         """
         :param gp_kernel: kernel spec (``pygpso_amd.kernels.Matern52(...)`` etc.)
         :param gp_meanf: mean-function spec (``Constant(c)``) or None
@@ -221,8 +221,12 @@ class GPSurrogate:
         :param varsigma: UCB = mean + varsigma * VAR (gpso/gp_surrogate.py:150-155,326)
         :param points: initial list of ``GPPoint``
         :param gpflow_model: an initialised ``HipGPR`` (used when loading a saved surrogate)
-        :param dtype: arithmetic type of the device kernels, "float64" (parity) or "float32"
+        :param dtype: arithmetic of the device kernels: "float64" (the reference's; parity), "mixed"
+            (fit in float64, predictions in float32 / split bf16) or "float32" (everything in float32).
+            Float predictions are guarded by a self-test; a model whose posterior fails it moves to the
+            next more precise arithmetic on the device by itself (``HipGPR``).
         :param device: HIP device index
+        :param engine_options: extra ``HipGPEngine`` keyword arguments (predict_math, generation, ...)
         """
         self.gpflow_model = gpflow_model
         self.gp_varsigma = float(varsigma)
@@ -235,6 +239,7 @@ class GPSurrogate:
         self.optimiser = optimiser
         self.dtype = dtype
         self.device = device
+        self.engine_options = dict(engine_options or {})
         self.points = GPListOfPoints(points or list())
 
     # -- bookkeeping properties (gpso/gp_surrogate.py:174-257) -----------------------------------
@@ -332,18 +337,18 @@ class GPRSurrogate(GPSurrogate):
 
     def __init__(self, gp_kernel, gp_meanf=None, optimiser=None, varsigma=erfcinv(0.01),
                  gauss_likelihood_sigma=1.0e-3, points=None, gpflow_model=None, dtype="float64",
-                 device=0):
+                 device=0, engine_options=None):
         """
         :param gauss_likelihood_sigma: initial noise VARIANCE of the Gaussian likelihood (the
             reference passes it as ``noise_variance`` despite the name, gpso/gp_surrogate.py:494)
         """
         super().__init__(gp_kernel=gp_kernel, gp_meanf=gp_meanf, optimiser=optimiser,
                          varsigma=varsigma, points=points, gpflow_model=gpflow_model, dtype=dtype,
-                         device=device)
+                         device=device, engine_options=engine_options)
         self.gp_lik_sigma = gauss_likelihood_sigma
 
     @classmethod
-    def default(cls, dtype="float64", device=0):
+    def default(cls, dtype="float64", device=0, engine_options=None):
         """Matern-5/2 (l = 0.25, s2 = 1), constant mean 0, L-BFGS-B, noise 1e-3
         (gpso/gp_surrogate.py:418-434)."""
         return cls(
@@ -354,6 +359,7 @@ class GPRSurrogate(GPSurrogate):
             gauss_likelihood_sigma=1.0e-3,
             dtype=dtype,
             device=device,
+            engine_options=engine_options,
         )
 
     def _gp_train(self, x, y):
@@ -363,7 +369,8 @@ class GPRSurrogate(GPSurrogate):
             engine = self.engine_factory() if self.engine_factory is not None else None
             self.gpflow_model = HipGPR(data=(x, y), kernel=self.gp_kernel, mean_function=self.gp_meanf,
                                        noise_variance=self.gp_lik_sigma, dtype=self.dtype,
-                                       device=self.device, engine=engine)
+                                       device=self.device, engine=engine,
+                                       engine_options=self.engine_options)
         else:
             self.gpflow_model.data = (x, y)  # hyper-parameters warm-start from the last optimum
         self.optimiser.minimize(self.gpflow_model.training_loss, self.gpflow_model.trainable_variables)

@@ -9,14 +9,19 @@ lengthscales / kernel variance, 1e-6 + softplus for the likelihood variance, ide
 """
 from __future__ import annotations
 
+import logging
 import types
 
 import numpy as np
 
+from . import _lib as L
 from .engine import HipGPEngine
-from .kernels import Constant, Kernel, MeanFunction
+from .kernels import Constant, Kernel, MeanFunction, Zero
 
 NOISE_FLOOR = 1.0e-6  # gpflow.likelihoods.Gaussian DEFAULT_VARIANCE_LOWER_BOUND
+# what a model does when the device reports GPSO_E_PRECISION: reopen the posterior in the next more
+# precise arithmetic ON THE DEVICE (never on the CPU, never in the test oracle)
+PRECISION_ESCALATION = {"float32": "mixed", "mixed": "float64"}
 
 
 def _softplus(u):
@@ -45,16 +50,27 @@ def _as_result(a):
 
 class HipGPR:
     def __init__(self, data, kernel, mean_function=None, noise_variance=1.0e-3, dtype="float64",
-                 device=0, engine=None):
+                 device=0, engine=None, engine_options=None, escalate=True):
+        """``dtype``: "float64" | "mixed" | "float32" (see ``HipGPEngine``).  ``engine_options``: extra
+        keyword arguments of ``HipGPEngine`` (predict_math, generation, tolerances).  ``escalate``:
+        when the device reports that float predictions fail their self-test on the current posterior
+        (GPSO_E_PRECISION), reopen it as "mixed", then "float64", with a logged warning, instead of
+        raising."""
         if not isinstance(kernel, Kernel):
             raise TypeError("kernel must be a pygpso_amd.kernels.Kernel")
         if mean_function is not None and not isinstance(mean_function, MeanFunction):
             raise TypeError("mean_function must be a pygpso_amd.kernels.MeanFunction or None")
         self.kernel = kernel
-        self.mean_function = mean_function if mean_function is not None else Constant(0.0)
+        # [gpflow] GPR(mean_function=None) uses Zero(): a fixed mean, nothing to train
+        self.mean_function = mean_function if mean_function is not None else Zero()
         self._train_mean = isinstance(self.mean_function, Constant)
         self.likelihood = types.SimpleNamespace(variance=float(noise_variance))
-        self.engine = engine if engine is not None else HipGPEngine(dtype=dtype, device=device)
+        self._engine_options = dict(engine_options or {})
+        self._device = device
+        self._owns_engine = engine is None
+        self.escalate = bool(escalate)
+        self.engine = engine if engine is not None else HipGPEngine(dtype=dtype, device=device,
+                                                                    **self._engine_options)
         self._data = None
         self._resident = False  # posterior on the device matches (data, hyper-parameters)?
         self.num_loss_evals = 0
@@ -148,10 +164,36 @@ class HipGPR:
         return -self.training_loss()
 
     # -- predict ------------------------------------------------------------------------------
+    def _escalate(self, err):
+        """GPSO_E_PRECISION: move data + hyper-parameters to an engine of the next more precise
+        arithmetic (still on the device).  Returns False when there is nowhere left to go."""
+        nxt = PRECISION_ESCALATION.get(getattr(self.engine, "dtype_name", None))
+        if nxt is None or not self.escalate or not self._owns_engine:
+            return False
+        logging.warning(f"{err}; reopening the GP posterior as a {nxt!r} engine on device {self._device}")
+        old = self.engine
+        self.engine = HipGPEngine(dtype=nxt, device=self._device, **self._engine_options)
+        old.close()
+        x, y = self._data
+        self.engine.set_data(x, y[:, 0])
+        self._resident = False
+        return True
+
+    def _predicting(self, call):
+        """Run a predict-type engine call; a float engine that reports GPSO_E_PRECISION is replaced by
+        a more precise one and the call repeated."""
+        while True:
+            try:
+                self._ensure_resident()
+                return call()
+            except L.GpsoPrecisionError as err:
+                if not self._escalate(err):
+                    raise
+
     def predict_y(self, Xnew):
         """(mean [M,1], var [M,1]); the variance includes the likelihood (noise) variance."""
-        self._ensure_resident()
-        mean, var = self.engine.predict(np.asarray(Xnew))
+        Xnew = np.asarray(Xnew)
+        mean, var = self._predicting(lambda: self.engine.predict(Xnew))
         return _as_result(mean), _as_result(var)
 
     def predict_f(self, Xnew):
@@ -159,12 +201,10 @@ class HipGPR:
         return mean, _as_result(np.asarray(var) - self.likelihood.variance)
 
     def best_ucb(self, Xnew, varsigma, seg_off=None):
-        self._ensure_resident()
-        return self.engine.best_ucb(Xnew, varsigma, seg_off)
+        return self._predicting(lambda: self.engine.best_ucb(Xnew, varsigma, seg_off))
 
     def best_ucb_grow(self, bounds, depth, varsigma):
-        self._ensure_resident()
-        return self.engine.best_ucb_grow(bounds, depth, varsigma)
+        return self._predicting(lambda: self.engine.best_ucb_grow(bounds, depth, varsigma))
 
     # -- reporting ----------------------------------------------------------------------------
     def parameter_dict(self):

@@ -6,6 +6,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import gpr, tree
 from pygpso_amd import HipGPEngine
+from pygpso_amd._lib import GpsoPrecisionError
 from tests.helpers import synthetic_problem, synthetic_leaves
 
 rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1234")))
@@ -13,17 +14,19 @@ N_CASES = int(os.environ.get("FUZZ_CASES", "60"))
 KERNELS = ["Matern52", "Matern32", "Matern12", "SquaredExponential"]
 bad = 0
 t0 = time.time()
+refused = 0
 for case in range(N_CASES):
-    dtype = rng.choice(["float64", "float32"])
+    dtype = str(rng.choice(["float64", "float32", "mixed"]))
     n = int(rng.choice([1, 2, 7, 33, 64, 65, 127, 128, 129, 200, 255, 256, 257, 400, 512, 700, 1024]))
     d = int(rng.choice([1, 2, 3, 4, 5, 6, 9, 12, 17, 20, 33, 40, 48]))
     m = int(rng.choice([1, 2, 15, 16, 17, 100, 255, 256, 257, 1000, 4097]))
     kernel = str(rng.choice(KERNELS))
     ard = bool(rng.random() < 0.3) and d > 1
     math = "native"
-    if dtype == "float32":
+    if dtype != "float64":
         math = str(rng.choice(["native", "bf16x6", "bf16x3"]))
-    noise = float(rng.choice([1e-3, 1e-2, 1e-1])) if dtype == "float32" else float(rng.choice([1e-6, 1e-4, 1e-2]))
+    # float engines are exercised down to GPflow's noise floor (1e-6): there they must be right or refuse
+    noise = float(rng.choice([1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1])) if dtype != "float64" else float(rng.choice([1e-6, 1e-4, 1e-2]))
     X, y = synthetic_problem(n, d, seed=int(rng.integers(1 << 30)))
     Xs = synthetic_leaves(m, d, seed=int(rng.integers(1 << 30)))
     ls = 0.25 * np.sqrt(d) * (rng.uniform(0.7, 1.5, size=d) if ard else np.ones(1))
@@ -33,31 +36,42 @@ for case in range(N_CASES):
     except np.linalg.LinAlgError:
         continue
     f_ref, g_ref = gpr.nlml_and_grad(th, X, y)
-    eng = HipGPEngine(dtype, predict_math=math)
-    eng.set_data(X, y)
-    f, g = eng.fit_eval(kernel, ls, th.variance, th.noise, th.mean_c, want_grad=True)
-    mean, var = eng.predict(Xs)
-    mean_ref, var_ref = gpr.predict_y(post, Xs)
-    ys = max(1.0, float(np.max(np.abs(y))))
-    # tolerances scale with the conditioning of K + noise I: forward errors of a
-    # Cholesky-based solve are ~ cond * eps; well-conditioned cases keep the base tolerances of the
-    # parity tests (float64: 1e-9, Matern-1/2 1e-5; float32: |d mean| 3e-3 max|y|, |d var| 3e-4 s2)
     Ky = gpr.gram(kernel, X, None, ls, th.variance) + th.noise * np.eye(n)
     ev = np.linalg.eigvalsh(Ky)
     cond = float(ev[-1] / max(ev[0], 1e-300))
-    if dtype == "float64":
-        amp = max(1.0, cond * 2.2e-16 * 1e9)  # forward-error allowance 1.0 * cond * eps once that exceeds 1e-9
-        base = 1e-5 if kernel == "Matern12" else 1e-9
-        e_f, e_g, e_m, e_v = base * amp, 1e3 * base * amp, base * amp * ys, base * amp * th.variance
-    else:
-        amp = max(1.0, cond * 6e-8 * 100)
-        if kernel == "Matern12":
-            amp *= 30.0  # sqrt at small r amplifies the float32 rounding of the GEMM-form r^2
-        e_f, e_g, e_m, e_v = 5e-5 * amp, 2e-2 * amp, 3e-3 * amp * ys, 3e-4 * amp * th.variance
-        # NLML (relative to max(1, |f|)) and gradient: |a|^2 = |L^-1 (y - c)|^2 carries cond * eps
-        m12 = 30.0 if kernel == "Matern12" else 1.0
+    eng = HipGPEngine(dtype, predict_math=math)
+    eng.set_data(X, y)
+    tag = (f"{dtype:7s} {math:7s} {kernel:18s} n={n:5d} d={d:2d} m={m:5d} ard={int(ard)} noise={noise:g} cond={cond:.1e}")
+    try:
+        f, g = eng.fit_eval(kernel, ls, th.variance, th.noise, th.mean_c, want_grad=True)
+        mean, var = eng.predict(Xs)
+    except (GpsoPrecisionError, np.linalg.LinAlgError) as e:
+        # a loud refusal is a correct outcome for the float engines -- but only where the problem is
+        # genuinely ill-conditioned for their arithmetic: a float FACTOR from cond ~ 1e3 on (its gate is
+        # conservative by design), float applies on a double factor only at extreme conditioning
+        limit = 3e2 if dtype == "float32" else 1e7
+        ok = dtype != "float64" and cond >= limit
+        refused += 1
+        bad += (not ok)
+        print(f"{'ref' if ok else 'BAD'} {tag} refused: {type(e).__name__} {str(e)[60:330]}")
+        continue
+    mean_ref, var_ref = gpr.predict_y(post, Xs)
+    ys = max(1.0, float(np.max(np.abs(y - th.mean_c))))
+    # Tolerances.  float64 and the float64 fit of "mixed": forward errors of a Cholesky-based solve are
+    # ~ cond * eps (base 1e-9; Matern-1/2 1e-5).  Float PREDICTIONS that passed the self-test gate: FIXED
+    # bounds, 4x the gate's tolerances (1e-4 sigma^2, 1e-4 max|y - c|) -- no conditioning allowance.
+    m12 = 30.0 if kernel == "Matern12" else 1.0
+    if dtype == "float32":
         e_f = m12 * (5e-5 + cond * 6e-8 * 10.0)
         e_g = m12 * (2e-2 + cond * 6e-8 * 100.0)
+    else:
+        amp = max(1.0, cond * 2.2e-16 * 1e9)  # forward-error allowance 1.0 * cond * eps once that exceeds 1e-9
+        base = 1e-5 if kernel == "Matern12" else 1e-9
+        e_f, e_g = base * amp, 1e3 * base * amp
+    if dtype == "float64":
+        e_m, e_v = base * amp * ys, base * amp * th.variance
+    else:
+        e_m, e_v = 4e-4 * ys, 4e-4 * th.variance
     errs = dict(nlml=abs(f - f_ref) / max(1.0, abs(f_ref)), grad=float(np.max(np.abs(g - g_ref) / np.maximum(1.0, np.abs(g_ref)))),
                 mean=float(np.max(np.abs(mean - mean_ref))), var=float(np.max(np.abs(var - var_ref))))
     ok = errs["nlml"] <= e_f and errs["grad"] <= e_g and errs["mean"] <= e_m and errs["var"] <= e_v
@@ -82,7 +96,6 @@ for case in range(N_CASES):
         ok &= np.array_equal(eng.grow(np.array(b), depth), tree.grow(b, depth))
     status = "ok " if ok else "BAD"
     bad += (not ok)
-    print(f"{status} {dtype:7s} {math:7s} {kernel:18s} n={n:5d} d={d:2d} m={m:5d} ard={int(ard)} noise={noise:g} cond={cond:.1e} "
-          + " ".join(f"{k_}={v:.1e}" for k_, v in errs.items()))
-print(f"{N_CASES} cases, {bad} bad, {time.time() - t0:.1f} s")
+    print(f"{status} {tag} " + " ".join(f"{k_}={v:.1e}" for k_, v in errs.items()))
+print(f"{N_CASES} cases, {refused} refused, {bad} bad, {time.time() - t0:.1f} s")
 sys.exit(1 if bad else 0)

@@ -46,7 +46,10 @@ def problems():
 def main():
     from pygpso_amd import HipGPEngine
 
-    modes = [("float64", "native"), ("float32", "native"), ("float32", "bf16x6"), ("float32", "bf16x3")]
+    # dtype:predict_math:generation
+    modes = [("float64", "native", "float64"), ("mixed", "native", "float64"), ("mixed", "bf16x6", "float64"),
+             ("mixed", "bf16x3", "float64"), ("mixed", "native", "float32"), ("float32", "native", "float64"),
+             ("float32", "bf16x6", "float64"), ("float32", "native", "float32")]
     if len(sys.argv) > 1:
         modes = [tuple(m.split(":")) for m in sys.argv[1:]]
     for name, X, y, th, leaves in problems():
@@ -55,11 +58,13 @@ def main():
         ucb_ref = mean_ref + VS * var_ref
         i_ref = int(np.argmax(ucb_ref))
         f_ref, g_ref = gpr.nlml_and_grad(th, X, y)
-        for dtype, math in modes:
-            rec = {"problem": name, "dtype": dtype, "math": math, "cond_L": float(np.linalg.cond(post.L)),
+        for dtype, math, gen in modes:
+            rec = {"problem": name, "dtype": dtype, "math": math, "gen": gen, "cond_L": float(np.linalg.cond(post.L)),
                    "var_ref_min": float(var_ref.min())}
             try:
-                eng = HipGPEngine(dtype, predict_math=math)
+                # the self-test is reported, not enforced: this tool measures the raw errors
+                eng = HipGPEngine(dtype, predict_math=math, generation=gen if dtype != "float64" else None,
+                                  precision_check=False)
                 eng.set_data(X, y)
                 f, g = eng.fit_eval(th.kernel, th.lengthscales, th.variance, th.noise, th.mean_c, want_grad=True)
                 mean, var = eng.predict(leaves)
@@ -74,8 +79,7 @@ def main():
                     ucb_gap_at_winner=float(ucb_ref[i_ref] - ucb_ref[int(idx[0])]),
                     ducb=float(np.max(np.abs(mean + VS * var - ucb_ref))),
                 )
-                if hasattr(eng, "precision_info"):
-                    rec["self_test"] = eng.precision_info()
+                rec["self_test"] = eng.precision_info()
             except Exception as e:  # noqa: BLE001 - report, keep going
                 rec["error"] = f"{type(e).__name__}: {e}"
             print(json.dumps(rec), flush=True)
