@@ -155,7 +155,9 @@ int gpso_best_ucb(gpso_ctx* ctx, const void* xs, int xs_dtype, int xs_mem, int64
  * (3^depth - 1) / 2.  bounds[nseg*D*2] = (lo, hi) per dimension, host float64.
  * gpso_grow copies the centres out (host float64 [nseg*rows*D]);
  * gpso_best_ucb_grow scores them without leaving the device: one call = one exploration level
- * of GPSOptimiser._tree_explore (gpso/optimisation.py:366-403). */
+ * of GPSOptimiser._tree_explore (gpso/optimisation.py:366-403).  Rows that repeat an earlier row bit for
+ * bit are scored once; idx is the REFERENCE row index (first maximum over the full duplicated list), so
+ * the result equals gpso_best_ucb on the rows gpso_grow returns. */
 int64_t gpso_grow_rows(int depth);
 int gpso_grow(gpso_ctx* ctx, const double* bounds, int nseg, int d, int depth, double* out_coords);
 int gpso_best_ucb_grow(gpso_ctx* ctx, const double* bounds, int nseg, int depth, double varsigma,
@@ -196,6 +198,12 @@ int gpso_precision_info(gpso_ctx* ctx, double* out);
  * what = 0: dominant predict kernel (leaf tiles) of the last predict/best_ucb call,
  *        1: whole last predict/best_ucb call, 2: whole last gpso_fit_eval call. */
 double gpso_last_ms(gpso_ctx* ctx, int what);
+
+/* leaf counts of the last predict / best_ucb / best_ucb_grow call: what = 0: rows the predict kernels
+ * actually scored, 1: rows of the reference's list.  They differ for gpso_best_ucb_grow, which drops the
+ * rows of LeafNode.grow that repeat an earlier row bit for bit (a centre child's centre is its parent's,
+ * gpso/param_space.py:186-200: (3^depth - 1) / 2 rows per box, 3^(depth-1) distinct). */
+int64_t gpso_last_count(gpso_ctx* ctx, int what);
 
 const char* gpso_version(void);
 

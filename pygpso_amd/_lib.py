@@ -80,6 +80,7 @@ SIGNATURES = {
     "gpso_alloc_posterior": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
     "gpso_adopt_posterior": (C.c_int, [C.c_void_p]),
     "gpso_last_ms": (C.c_double, [C.c_void_p, C.c_int]),
+    "gpso_last_count": (C.c_int64, [C.c_void_p, C.c_int]),
     "gpso_version": (C.c_char_p, []),
 }
 

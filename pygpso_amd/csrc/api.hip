@@ -118,6 +118,7 @@ struct gpso_ctx {
   std::vector<hipEvent_t> tile_ev;  // start/stop pairs around the leaf-tile kernel, one per chunk
   int tile_pairs = 0;               // pairs recorded by the call in flight
   double last_ms[3] = {0, 0, 0};
+  int64_t last_count[2] = {0, 0};  // leaves scored / leaves asked for by the last predict-type call
   std::string err;
   Engine* eng = nullptr;
   hipEvent_t ev_wait = nullptr;  // completion marker of the call in flight
@@ -228,7 +229,8 @@ struct EngineT : Engine {
   bool linv_b_valid = false;
   std::vector<int64_t> segoff_cache;  // what the device copy of seg_off currently holds
   // predict workspace
-  DevBuf leaves_raw, leaves_s, lnorm, pvar, pmean, omean, ovar, oucb, segoff, best, oidx, ovals;
+  DevBuf leaves_raw, leaves_s, lnorm, pvar, pmean, omean, ovar, oucb, segoff, best, oidx, ovals, grow_key,
+      live_cnt, best_pos;
   // precision self-test
   bool check = false, st_done = false, st_have = false;
   double tol_var = 1.0e-4, tol_mean = 1.0e-4;
@@ -239,7 +241,8 @@ struct EngineT : Engine {
     for (DevBuf* b : {&x64, &y64, &hyper, &xs64, &xnorm64, &xs_p64, &xs32, &xnorm32, &xs_p32, &K, &Lf, &linv,
                       &work, &kinvb, &linv_p, &white, &alpha_f, &alpha, &logdet, &scal, &gpart, &apart,
                       &kinv_diag, &getter_tmp, &leaves_raw, &leaves_s, &lnorm, &pvar, &pmean, &omean, &ovar,
-                      &oucb, &segoff, &best, &oidx, &ovals, &linv_b, &st_mean, &st_var, &st_out})
+                      &oucb, &segoff, &best, &oidx, &ovals, &linv_b, &st_mean, &st_var, &st_out, &grow_key, &live_cnt,
+                      &best_pos})
       if (b->p) (void)hipFree(b->p);
   }
 
@@ -340,6 +343,21 @@ struct EngineT : Engine {
       b.bytes = 0;
     }
     HIPCHECK(hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return GPSO_OK;
+  }
+
+  // like ensure(), but the old contents survive a re-allocation
+  int ensure_keep(DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes) return GPSO_OK;
+    void* np_ = nullptr;
+    HIPCHECK(hipMalloc(&np_, bytes));
+    if (b.p) {
+      HIPCHECK(hipMemcpyAsync(np_, b.p, b.bytes, hipMemcpyDeviceToDevice, st()));
+      HIPCHECK(hipStreamSynchronize(st()));
+      HIPCHECK(hipFree(b.p));
+    }
+    b.p = np_;
     b.bytes = bytes;
     return GPSO_OK;
   }
@@ -594,14 +612,23 @@ struct EngineT : Engine {
       xsp = as<float>(xs_p32);
       xnr = as<float>(xnorm32);
     }
+    // m_live counts live rows of the WHOLE batch; a batch processed in several chunks needs the count
+    // per chunk (slots 1.. of live_cnt, filled on the device)
+    const int nchunk = (int)((m + chunk - 1) / chunk);
+    if (m_live != nullptr && nchunk > 1) {
+      if ((rc = ensure_keep(live_cnt, (size_t)(1 + nchunk) * 8))) return rc;
+      m_live = as<int64_t>(live_cnt);
+      launch_chunk_live(s, m_live, chunk, nchunk, as<int64_t>(live_cnt) + 1);
+    }
     for (int64_t off = 0; off < m; off += chunk) {
       const int64_t mc = std::min<int64_t>(chunk, m - off);
       const int64_t mp = (mc + kLeafPad - 1) / kLeafPad * kLeafPad;
+      const int64_t* m_live_c = (m_live != nullptr && nchunk > 1) ? as<int64_t>(live_cnt) + 1 + off / chunk : m_live;
       const char* src = static_cast<const char*>(xs_dev) + (size_t)off * d * in_elem;
       if (xs_dtype == GPSO_F64)
-        launch_prep_leaves<TG, double>(s, reinterpret_cast<const double*>(src), mc, mp, d, dp, ls_dev(), m_live, as<TG>(leaves_s), as<TG>(lnorm));
+        launch_prep_leaves<TG, double>(s, reinterpret_cast<const double*>(src), mc, mp, d, dp, ls_dev(), m_live_c, as<TG>(leaves_s), as<TG>(lnorm));
       else
-        launch_prep_leaves<TG, float>(s, reinterpret_cast<const float*>(src), mc, mp, d, dp, ls_dev(), m_live, as<TG>(leaves_s), as<TG>(lnorm));
+        launch_prep_leaves<TG, float>(s, reinterpret_cast<const float*>(src), mc, mp, d, dp, ls_dev(), m_live_c, as<TG>(leaves_s), as<TG>(lnorm));
       while ((int)ctx->tile_ev.size() < 2 * (ctx->tile_pairs + 1)) {
         hipEvent_t e;
         HIPCHECK(hipEventCreate(&e));
@@ -612,11 +639,11 @@ struct EngineT : Engine {
         if constexpr (kFloatPredict)
           rc = launch_leaf_tiles_bf16<TG>(s, nsplit(), linv_b.p, xsp, xnr, as<float>(alpha), as<TG>(leaves_s),
                                           as<TG>(lnorm), as<double>(pvar), as<double>(pmean), npad, dp / 4, mp,
-                                          kp, m_live);
+                                          kp, m_live_c);
       } else {
         rc = launch_leaf_tiles<TP, TG>(s, as<TP>(linv_p), xsp, xnr, as<TP>(alpha), as<TG>(leaves_s),
                                        as<TG>(lnorm), as<double>(pvar), as<double>(pmean), npad, dp / 4, mp, kp,
-                                       m_live);
+                                       m_live_c);
       }
       if (rc) return launch_status();
       HIPCHECK(hipEventRecord(ctx->tile_ev[2 * ctx->tile_pairs + 1], s));
@@ -759,6 +786,7 @@ struct EngineT : Engine {
     HIPCHECK(hipEventRecord(ctx->ev[3], s));
     HIPCHECK(ctx->wait(s));
     collect_tile_ms();
+    ctx->last_count[0] = ctx->last_count[1] = m;
     float ms = 0;
     if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ms[1] = ms;
     return GPSO_OK;
@@ -801,6 +829,7 @@ struct EngineT : Engine {
     HIPCHECK(ctx->wait(s));
     if ((rc = launch_status())) return rc;
     collect_tile_ms();
+    ctx->last_count[0] = ctx->last_count[1] = m;
     for (int i = 0; i < nseg; ++i) {
       if (idx) std::memcpy(&idx[i], &vals[4 * i + 3], 8);
       if (mean) mean[i] = vals[4 * i];
@@ -856,18 +885,66 @@ struct EngineT : Engine {
     return GPSO_OK;
   }
 
+  // One exploration level: the sub-tree centres of every box are generated on the device WITHOUT the rows
+  // that repeat an earlier row bit for bit (a centre child repeats its parent: 1/3 of the reference's
+  // list, gpso/param_space.py:186-200), scored, and the winner is reported by its REFERENCE row index --
+  // the result is what gp_eval_best_ucb(leaf.grow(depth)) returns (grow.hip: grow_unique_kernel).
   int best_ucb_grow(const double* bounds, int nseg, int depth, double varsigma, int64_t* idx,
                     double* mean, double* var, double* ucb) override {
     if (!have_post) return ctx->fail(GPSO_E_STATE, "no posterior resident: call gpso_fit_eval / gpso_set_posterior first");
     int rc = precision_gate();
     if (rc) return rc;
-    HIPCHECK(hipEventRecord(ctx->ev[2], st()));
-    int64_t rows = 0;
-    if ((rc = grow_to_device(bounds, nseg, d, depth, &rows))) return rc;
-    std::vector<int64_t> so(nseg + 1);
-    for (int i = 0; i <= nseg; ++i) so[i] = (int64_t)i * rows;
-    return best_ucb_device(leaves_raw.p, GPSO_F64, (int64_t)nseg * rows, so.data(), nseg, varsigma,
-                           idx, mean, var, ucb);
+    if (!bounds) return ctx->fail(GPSO_E_ARG, "bounds must not be NULL");
+    if (nseg < 1) return ctx->fail(GPSO_E_ARG, "nseg must be >= 1");
+    if (depth < 0 || depth > 16) return ctx->fail(GPSO_E_ARG, "depth %d outside [0, 16]", depth);
+    hipStream_t s = st();
+    HIPCHECK(hipEventRecord(ctx->ev[2], s));
+    const int64_t rows = gpso_grow_rows(depth), uniq = grow_unique_rows(depth);
+    const int64_t cap = (int64_t)nseg * rows;  // worst case: no centre child repeats its parent
+    const size_t bb = (size_t)nseg * d * 2 * 8;
+    const size_t ob = (size_t)cap * d * 8;
+    if ((rc = ensure(leaves_raw, ob + bb))) return rc;
+    if ((rc = ensure(grow_key, (size_t)std::max<int64_t>(cap, 1) * 8))) return rc;
+    if ((rc = ensure_keep(live_cnt, 64))) return rc;
+    if ((rc = ensure(omean, (size_t)cap * 8))) return rc;
+    if ((rc = ensure(ovar, (size_t)cap * 8))) return rc;
+    if ((rc = ensure(oucb, (size_t)cap * 8))) return rc;
+    if ((rc = ensure(best, (size_t)nseg * kArgmaxBlocks * kArgmaxPartialBytes))) return rc;
+    if ((rc = ensure(best_pos, (size_t)nseg * kArgmaxBlocks * 8))) return rc;
+    if ((rc = ensure(ovals, (size_t)(nseg * 4 + 1) * 8))) return rc;
+    double* bdev = reinterpret_cast<double*>(static_cast<char*>(leaves_raw.p) + ob);
+    double* stage = ctx->pinned_stage((size_t)nseg * d * 2 + 1);
+    if (!stage) return ctx->fail(GPSO_E_OOM, "pinned host staging");
+    std::memcpy(stage, bounds, bb);
+    const int64_t live0 = (int64_t)nseg * uniq;
+    std::memcpy(stage + (size_t)nseg * d * 2, &live0, 8);
+    HIPCHECK(hipMemcpyAsync(bdev, stage, bb, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(live_cnt.p, stage + (size_t)nseg * d * 2, 8, hipMemcpyHostToDevice, s));
+    launch_grow_unique(s, bdev, nseg, d, depth, as<double>(leaves_raw), as<int64_t>(grow_key), as<int64_t>(live_cnt));
+    if (cap > 0)
+      if ((rc = score_device_leaves(leaves_raw.p, GPSO_F64, cap, varsigma, true, as<double>(omean), as<double>(ovar),
+                                    as<double>(oucb), as<int64_t>(live_cnt))))
+        return rc;
+    launch_keyed_argmax(s, as<double>(omean), as<double>(ovar), as<double>(oucb), as<int64_t>(grow_key), rows, uniq,
+                        nseg, as<int64_t>(live_cnt), kArgmaxBlocks, best.p, as<int64_t>(best_pos), as<double>(ovals));
+    double* vals = ctx->pinned_scratch((size_t)nseg * 4 + 1);
+    if (!vals) return ctx->fail(GPSO_E_OOM, "pinned host scratch");
+    HIPCHECK(hipMemcpyAsync(vals, ovals.p, (size_t)(nseg * 4 + 1) * 8, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipEventRecord(ctx->ev[3], s));
+    HIPCHECK(ctx->wait(s));
+    if ((rc = launch_status())) return rc;
+    collect_tile_ms();
+    for (int i = 0; i < nseg; ++i) {
+      if (idx) std::memcpy(&idx[i], &vals[4 * i + 3], 8);
+      if (mean) mean[i] = vals[4 * i];
+      if (var) var[i] = vals[4 * i + 1];
+      if (ucb) ucb[i] = vals[4 * i + 2];
+    }
+    std::memcpy(&ctx->last_count[0], &vals[4 * nseg], 8);
+    ctx->last_count[1] = cap;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ms[1] = ms;
+    return GPSO_OK;
   }
 
   // ------------------------------------------------------------------------------------------
@@ -1173,6 +1250,11 @@ int gpso_adopt_posterior(gpso_ctx* ctx) {
 double gpso_last_ms(gpso_ctx* ctx, int what) {
   if (!ctx || what < 0 || what > 2) return -1.0;
   return ctx->last_ms[what];
+}
+
+int64_t gpso_last_count(gpso_ctx* ctx, int what) {
+  if (!ctx || what < 0 || what > 1) return -1;
+  return ctx->last_count[what];
 }
 
 const char* gpso_version(void) { return "gpso-hip 0.2.0 (gfx950)"; }

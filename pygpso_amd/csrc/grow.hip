@@ -15,63 +15,165 @@
 
 namespace gpso {
 
-constexpr int kGrowMaxD = 64;
+// Per-thread box state lives in LDS as [dimension][thread] (conflict-free, no scratch: a per-thread
+// double lo[64], hi[64] array spills): one wave per block, 2 * d * 64 doubles of dynamic LDS.
+constexpr int kGrowThreads = 64;
 
-__global__ __launch_bounds__(128) void grow_kernel(const double* __restrict__ bounds, int d,
-                                                   int depth, int64_t rows,
-                                                   double* __restrict__ out) {
-  const int seg = blockIdx.y;
-  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= rows) return;
-  // level j and position p of this row: rows of level j start at (3^j - 1) / 2
-  int level = 0;
-  int64_t start = 0, width = 1;  // width = 3^level
+// level j and position p of a row: rows of level j start at (3^j - 1) / 2
+__device__ __forceinline__ void grow_locate(int64_t row, int& level, int64_t& width, int64_t& p) {
+  level = 0;
+  int64_t start = 0;
+  width = 1;  // 3^level
   while (start + width <= row) {
     start += width;
     width *= 3;
     ++level;
   }
-  int64_t p = row - start;
-  double lo[kGrowMaxD], hi[kGrowMaxD];
+  p = row - start;
+}
+
+// one ternary split of the box held in (lo, hi)[k * kGrowThreads + t]: child 0 = l, 1 = c, 2 = r
+__device__ __forceinline__ void grow_split(double* lo, double* hi, int t, int d, int child) {
+  int kmax = 0;
+  double wmax = hi[t] - lo[t];
+  for (int k = 1; k < d; ++k) {
+    const double w = hi[k * kGrowThreads + t] - lo[k * kGrowThreads + t];
+    if (w > wmax) {  // first maximum wins, as np.argmax
+      wmax = w;
+      kmax = k;
+    }
+  }
+  const double delta = wmax / 3;
+  const double base = lo[kmax * kGrowThreads + t];
+  const double c0 = base + (double)child * delta;
+  const double c1 = base + (double)(child + 1) * delta;
+  lo[kmax * kGrowThreads + t] = c0;
+  hi[kmax * kGrowThreads + t] = c1;
+}
+
+__global__ __launch_bounds__(kGrowThreads) void grow_kernel(const double* __restrict__ bounds, int d,
+                                                            int depth, int64_t rows,
+                                                            double* __restrict__ out) {
+  extern __shared__ double grow_lds[];
+  double* lo = grow_lds;
+  double* hi = grow_lds + (size_t)d * kGrowThreads;
+  const int seg = blockIdx.y, t = threadIdx.x;
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + t;
+  if (row >= rows) return;
+  int level;
+  int64_t width, p;
+  grow_locate(row, level, width, p);
   const double* b = bounds + (int64_t)seg * d * 2;
   for (int k = 0; k < d; ++k) {
-    lo[k] = b[2 * k];
-    hi[k] = b[2 * k + 1];
+    lo[k * kGrowThreads + t] = b[2 * k];
+    hi[k * kGrowThreads + t] = b[2 * k + 1];
   }
   int64_t div = width;  // 3^level
-  for (int t = 0; t < level; ++t) {
+  for (int s = 0; s < level; ++s) {
     div /= 3;
-    const int child = (int)((p / div) % 3);  // 0 = l, 1 = c, 2 = r
+    grow_split(lo, hi, t, d, (int)((p / div) % 3));
+  }
+  double* o = out + ((int64_t)seg * rows + row) * d;
+  for (int k = 0; k < d; ++k) o[k] = (lo[k * kGrowThreads + t] + hi[k * kGrowThreads + t]) / 2;
+}
+
+// De-duplicated growth for the scoring path.  A centre child's centre is its parent's centre
+// (gpso/param_space.py:186-200 emits both), so only 3^(depth-1) of the (3^depth - 1) / 2 rows of a box
+// are distinct points: the root and, on every level j >= 1, the 2 * 3^(j-1) l / r children -- which
+// get the closed-form compact slots [3^(j-1), 3^j) of their box, slot = 3^(j-1) + 2 * (p / 3) + (p % 3 == 2).
+// "Is" holds in exact arithmetic; in float64 the two centres can differ in the last bit (they never do
+// for boxes cut from the unit cube, they do for about half of arbitrary boxes).  A centre child whose
+// centre is NOT bit-identical to its parent's is a different input to the predict kernels and is kept:
+// it is appended behind the nseg * U analytic slots through an atomic counter (*count starts at
+// nseg * U and ends as the number of live rows).  key[slot] = seg * rows + reference row index: the
+// arg-max runs on (ucb, key), so neither the compaction nor the order of the appended rows can change
+// the winner or its index -- a dropped row has the same bits, hence the same ucb, as an EARLIER row.
+__global__ __launch_bounds__(kGrowThreads) void grow_unique_kernel(const double* __restrict__ bounds, int d,
+                                                                   int depth, int64_t rows, int64_t uniq,
+                                                                   double* __restrict__ out,
+                                                                   int64_t* __restrict__ key,
+                                                                   unsigned long long* __restrict__ count) {
+  extern __shared__ double grow_lds[];
+  double* lo = grow_lds;
+  double* hi = grow_lds + (size_t)d * kGrowThreads;
+  const int seg = blockIdx.y, t = threadIdx.x;
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + t;
+  if (row >= rows) return;
+  int level;
+  int64_t width, p;
+  grow_locate(row, level, width, p);
+  const double* b = bounds + (int64_t)seg * d * 2;
+  for (int k = 0; k < d; ++k) {
+    lo[k * kGrowThreads + t] = b[2 * k];
+    hi[k * kGrowThreads + t] = b[2 * k + 1];
+  }
+  int64_t div = width;
+  for (int s = 0; s + 1 < level; ++s) {
+    div /= 3;
+    grow_split(lo, hi, t, d, (int)((p / div) % 3));
+  }
+  const int child = (level > 0) ? (int)(p % 3) : 0;
+  int64_t slot;
+  if (level == 0) {
+    slot = (int64_t)seg * uniq;
+  } else if (child != 1) {
+    grow_split(lo, hi, t, d, child);
+    slot = (int64_t)seg * uniq + width / 3 + 2 * (p / 3) + (child == 2 ? 1 : 0);
+  } else {
+    // centre child: compare its centre with the parent's, bit for bit, in the only dimension the split
+    // touches (the others hold the same lo / hi)
     int kmax = 0;
-    double wmax = hi[0] - lo[0];
+    double wmax = hi[t] - lo[t];
     for (int k = 1; k < d; ++k) {
-      const double w = hi[k] - lo[k];
-      if (w > wmax) {  // first maximum wins, as np.argmax
+      const double w = hi[k * kGrowThreads + t] - lo[k * kGrowThreads + t];
+      if (w > wmax) {
         wmax = w;
         kmax = k;
       }
     }
-    const double delta = wmax / 3;
-    const double base = lo[kmax];
-    const double c0 = base + (double)child * delta;
-    const double c1 = base + (double)(child + 1) * delta;
-    lo[kmax] = c0;
-    hi[kmax] = c1;
+    const double parent_c = (lo[kmax * kGrowThreads + t] + hi[kmax * kGrowThreads + t]) / 2;
+    grow_split(lo, hi, t, d, 1);
+    const double child_c = (lo[kmax * kGrowThreads + t] + hi[kmax * kGrowThreads + t]) / 2;
+    if (__builtin_bit_cast(long long, parent_c) == __builtin_bit_cast(long long, child_c)) return;
+    slot = (int64_t)atomicAdd(count, 1ull);
   }
-  double* o = out + ((int64_t)seg * rows + row) * d;
-  for (int k = 0; k < d; ++k) o[k] = (lo[k] + hi[k]) / 2;
+  key[slot] = (int64_t)seg * rows + row;
+  double* o = out + slot * d;
+  for (int k = 0; k < d; ++k) o[k] = (lo[k * kGrowThreads + t] + hi[k * kGrowThreads + t]) / 2;
 }
 
-void launch_grow(hipStream_t st, const double* bounds_dev, int nseg, int d, int depth,
-                 double* out_dev) {
+static int64_t grow_rows_of(int depth) {
   int64_t rows = 0, w = 1;
   for (int j = 0; j < depth; ++j) {
     rows += w;
     w *= 3;
   }
+  return rows;
+}
+
+void launch_grow(hipStream_t st, const double* bounds_dev, int nseg, int d, int depth,
+                 double* out_dev) {
+  const int64_t rows = grow_rows_of(depth);
   if (rows == 0 || nseg == 0) return;
-  const dim3 grid((unsigned)((rows + 127) / 128), (unsigned)nseg);
-  hipLaunchKernelGGL(grow_kernel, grid, dim3(128), 0, st, bounds_dev, d, depth, rows, out_dev);
+  const dim3 grid((unsigned)((rows + kGrowThreads - 1) / kGrowThreads), (unsigned)nseg);
+  hipLaunchKernelGGL(grow_kernel, grid, dim3(kGrowThreads), (size_t)2 * d * kGrowThreads * 8, st, bounds_dev, d,
+                     depth, rows, out_dev);
+}
+
+int64_t grow_unique_rows(int depth) {
+  int64_t u = (depth >= 1) ? 1 : 0;
+  for (int j = 1; j < depth; ++j) u *= 3;
+  return u;
+}
+
+void launch_grow_unique(hipStream_t st, const double* bounds_dev, int nseg, int d, int depth,
+                        double* out_dev, int64_t* key_dev, int64_t* count_dev) {
+  const int64_t rows = grow_rows_of(depth);
+  if (rows == 0 || nseg == 0) return;
+  const dim3 grid((unsigned)((rows + kGrowThreads - 1) / kGrowThreads), (unsigned)nseg);
+  hipLaunchKernelGGL(grow_unique_kernel, grid, dim3(kGrowThreads), (size_t)2 * d * kGrowThreads * 8, st,
+                     bounds_dev, d, depth, rows, grow_unique_rows(depth), out_dev, key_dev,
+                     reinterpret_cast<unsigned long long*>(count_dev));
 }
 
 }  // namespace gpso

@@ -59,6 +59,13 @@ void launch_leaf_finalize(hipStream_t st, const double* part_var, const double* 
 void launch_seg_argmax(hipStream_t st, const double* mean, const double* var, const double* ucb,
                        const int64_t* seg_off_dev, int nseg, int nblk, void* partial_dev,
                        double* out_vals_dev /* [nseg*4]: mean, var, ucb, bit-cast int64 index */);
+// arg-max over a de-duplicated, keyed leaf list (grow.hip: launch_grow_unique); out_vals_dev[nseg*4 + 1]:
+// per segment mean, var, ucb, bit-cast reference row index; then the bit-cast live row count
+void launch_keyed_argmax(hipStream_t st, const double* mean, const double* var, const double* ucb,
+                         const int64_t* key_dev, int64_t rows, int64_t uniq, int nseg, const int64_t* live_dev,
+                         int nblk, void* partial_dev, int64_t* pos_dev, double* out_vals_dev);
+// out_dev[c] = number of live leaves inside chunk c of a batch whose total live count is *live_dev
+void launch_chunk_live(hipStream_t st, const int64_t* live_dev, int64_t chunk, int nchunk, int64_t* out_dev);
 constexpr int kArgmaxBlocks = 64;      // stage-1 blocks per segment
 constexpr size_t kArgmaxPartialBytes = 16;  // sizeof(Best)
 
@@ -159,5 +166,12 @@ void launch_install_chol(hipStream_t st, const double* L64, int64_t n, int64_t n
 // centres of the ternary subtree (levels 0..depth-1) under each box; out[nseg*rows*d] float64
 void launch_grow(hipStream_t st, const double* bounds_dev, int nseg, int d, int depth,
                  double* out_dev);
+// the same centres WITHOUT the rows that repeat an earlier row bit for bit (a centre child repeats its
+// parent): grow_unique_rows(depth) = 3^(depth-1) analytic slots per box, then the centre children whose
+// centre differs from the parent's in the last bit; key_dev[slot] = seg * rows + reference row index;
+// *count_dev must hold nseg * grow_unique_rows(depth) on entry and holds the live row count on exit
+int64_t grow_unique_rows(int depth);
+void launch_grow_unique(hipStream_t st, const double* bounds_dev, int nseg, int d, int depth,
+                        double* out_dev, int64_t* key_dev, int64_t* count_dev);
 
 }  // namespace gpso

@@ -743,6 +743,111 @@ __global__ __launch_bounds__(256) void seg_argmax_stage2(const Best* __restrict_
 }
 
 
+// Keyed variant for de-duplicated on-device growth (grow.hip: grow_unique_kernel): row j of the compact
+// list carries key[j] = seg * rows + reference row index.  Segment seg owns the compact range
+// [seg * uniq, (seg + 1) * uniq) plus those rows of the appended tail [nseg * uniq, *live) whose key
+// falls into it.  The order is np.argmax's on (ucb, reference row index), so the winner and its index
+// are what scoring the full duplicated list would give.
+__global__ __launch_bounds__(256) void keyed_argmax_stage1(const double* __restrict__ ucb,
+                                                           const int64_t* __restrict__ key, int64_t rows,
+                                                           int64_t uniq, int nseg,
+                                                           const int64_t* __restrict__ live,
+                                                           Best* __restrict__ partial,
+                                                           int64_t* __restrict__ pos /* compact row of each partial */) {
+  __shared__ Best sh[4];
+  __shared__ int64_t shp[4];
+  const int seg = blockIdx.y;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  Best mine{0.0, -1};
+  int64_t mypos = -1;
+  for (int64_t j = (int64_t)seg * uniq + t0; j < (int64_t)(seg + 1) * uniq; j += stride) {
+    Best c{ucb[j], key[j]};
+    if (better(c, mine)) {
+      mine = c;
+      mypos = j;
+    }
+  }
+  const int64_t lv = *live;
+  for (int64_t j = (int64_t)nseg * uniq + t0; j < lv; j += stride) {
+    const int64_t kj = key[j];
+    if (kj / rows != seg) continue;
+    Best c{ucb[j], kj};
+    if (better(c, mine)) {
+      mine = c;
+      mypos = j;
+    }
+  }
+  // block reduction carrying the compact position along
+  for (int off = 32; off > 0; off >>= 1) {
+    Best o;
+    o.u = __shfl_xor(mine.u, off);
+    o.i = __shfl_xor(mine.i, off);
+    const int64_t op = __shfl_xor(mypos, off);
+    if (better(o, mine)) {
+      mine = o;
+      mypos = op;
+    }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+    sh[wave] = mine;
+    shp[wave] = mypos;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (better(sh[w], mine)) {
+        mine = sh[w];
+        mypos = shp[w];
+      }
+    partial[(int64_t)seg * gridDim.x + blockIdx.x] = mine;
+    pos[(int64_t)seg * gridDim.x + blockIdx.x] = mypos;
+  }
+}
+
+__global__ __launch_bounds__(256) void keyed_argmax_stage2(const Best* __restrict__ partial,
+                                                           const int64_t* __restrict__ pos, int nblk,
+                                                           int64_t rows, const double* __restrict__ mean,
+                                                           const double* __restrict__ var,
+                                                           const double* __restrict__ ucb,
+                                                           const int64_t* __restrict__ live, int nseg,
+                                                           double* __restrict__ out_vals /*[nseg*4 + 1]*/) {
+  __shared__ Best sh[4];
+  const int seg = blockIdx.x;
+  Best mine{0.0, -1};
+  for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
+    Best c = partial[(int64_t)seg * nblk + b];
+    if (better(c, mine)) mine = c;
+  }
+  mine = block_best(mine, sh);
+  if (threadIdx.x == 0) {
+    if (mine.i < 0) {
+      out_vals[seg * 4 + 0] = out_vals[seg * 4 + 1] = out_vals[seg * 4 + 2] = __builtin_nan("");
+      out_vals[seg * 4 + 3] = __builtin_bit_cast(double, (int64_t)-1);
+    } else {
+      int64_t at = -1;  // keys are unique: the partial that holds the winner's key holds its position
+      for (int b = 0; b < nblk; ++b)
+        if (partial[(int64_t)seg * nblk + b].i == mine.i) at = pos[(int64_t)seg * nblk + b];
+      out_vals[seg * 4 + 0] = mean[at];
+      out_vals[seg * 4 + 1] = var[at];
+      out_vals[seg * 4 + 2] = ucb[at];
+      out_vals[seg * 4 + 3] = __builtin_bit_cast(double, (int64_t)(mine.i - (int64_t)seg * rows));
+    }
+    if (seg == 0) out_vals[nseg * 4] = __builtin_bit_cast(double, *live);
+  }
+}
+
+// per-chunk live count of a leaf batch processed in chunks: out[c] = clamp(*live - c * chunk, 0, chunk)
+__global__ void chunk_live_kernel(const int64_t* __restrict__ live, int64_t chunk, int nchunk,
+                                  int64_t* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nchunk) return;
+  const int64_t v = *live - (int64_t)c * chunk;
+  out[c] = v < 0 ? 0 : (v > chunk ? chunk : v);
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // host-side launchers (declared in kernels.hpp)
 template <typename TG, typename TIN>
@@ -842,6 +947,21 @@ void launch_seg_argmax(hipStream_t st, const double* mean, const double* var, co
   hipLaunchKernelGGL(seg_argmax_stage2, dim3((unsigned)nseg), dim3(256), 0, st,
                      reinterpret_cast<const Best*>(partial_dev), nblk, seg_off_dev, mean, var, ucb,
                      out_vals_dev);
+}
+
+void launch_keyed_argmax(hipStream_t st, const double* mean, const double* var, const double* ucb,
+                         const int64_t* key_dev, int64_t rows, int64_t uniq, int nseg, const int64_t* live_dev,
+                         int nblk, void* partial_dev, int64_t* pos_dev, double* out_vals_dev) {
+  hipLaunchKernelGGL(keyed_argmax_stage1, dim3((unsigned)nblk, (unsigned)nseg), dim3(256), 0, st, ucb, key_dev,
+                     rows, uniq, nseg, live_dev, reinterpret_cast<Best*>(partial_dev), pos_dev);
+  hipLaunchKernelGGL(keyed_argmax_stage2, dim3((unsigned)nseg), dim3(256), 0, st,
+                     reinterpret_cast<const Best*>(partial_dev), pos_dev, nblk, rows, mean, var, ucb, live_dev,
+                     nseg, out_vals_dev);
+}
+
+void launch_chunk_live(hipStream_t st, const int64_t* live_dev, int64_t chunk, int nchunk, int64_t* out_dev) {
+  hipLaunchKernelGGL(chunk_live_kernel, dim3((unsigned)((nchunk + 63) / 64)), dim3(64), 0, st, live_dev, chunk,
+                     nchunk, out_dev);
 }
 
 }  // namespace gpso

@@ -141,6 +141,10 @@ class HipGPEngine:
     def last_ms(self, what=0):
         return float(self._lib.gpso_last_ms(self._h, int(what)))
 
+    def last_count(self, what=0):
+        """0: leaves the kernels scored in the last predict-type call, 1: leaves of the reference's list."""
+        return int(self._lib.gpso_last_count(self._h, int(what)))
+
     @property
     def padded_n(self):
         return int(self._lib.gpso_padded_n(self._h))

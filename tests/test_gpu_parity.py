@@ -373,6 +373,67 @@ def test_best_ucb_grow_equals_scoring_host_grown_leaves():
         assert (int(one[0][0]), one[1][0], one[2][0], one[3][0]) == (int(idx[s]), mu[s], vv[s], ucb[s])
 
 
+def test_best_ucb_grow_scores_each_distinct_centre_once():
+    """A centre child's centre is its parent's (reference: gpso/param_space.py:186-200 emits both), so
+    only 3^(depth-1) of the (3^depth - 1)/2 rows are distinct.  Boxes cut from the unit cube repeat bit
+    for bit: exactly 1/3 of the rows is dropped, the reported index is still the reference's."""
+    X, y, th = _problem(60, 2)
+    eng = _engine()
+    _fit(eng, X, y, th, grad=False)
+    kids = tree.split_bounds([(0.0, 1.0), (0.0, 1.0)])
+    boxes = np.array([kids[0], kids[2]])
+    for depth, rows, uniq in ((1, 1, 1), (2, 4, 3), (5, 121, 81), (8, 3280, 2187)):
+        idx, mu, vv, ucb = eng.best_ucb_grow(boxes, depth, VS)
+        assert eng.last_count(1) == 2 * rows and eng.last_count(0) == 2 * uniq
+        for s, b in enumerate((kids[0], kids[2])):
+            one = eng.best_ucb(tree.grow(b, depth), VS)
+            assert (int(one[0][0]), one[1][0], one[2][0], one[3][0]) == (int(idx[s]), mu[s], vv[s], ucb[s])
+
+
+@pytest.mark.parametrize("d,depth,nbox", [(1, 6, 3), (2, 6, 5), (3, 7, 4), (5, 5, 7)])
+def test_best_ucb_grow_on_arbitrary_boxes_keeps_near_duplicates(d, depth, nbox):
+    """For arbitrary boxes a centre child's centre can differ from its parent's in the last bit: such a
+    row is a different input and must still be scored (the appended tail of the compact list).  The
+    result is bit-identical to scoring the host-grown list, box by box."""
+    rng = np.random.default_rng(100 * d + depth)
+    X, y, th = _problem(80, d)
+    eng = _engine()
+    _fit(eng, X, y, th, grad=False)
+    lo = rng.uniform(0.0, 0.6, (nbox, d))
+    boxes = np.stack([lo, lo + rng.uniform(0.05, 0.4, (nbox, d))], axis=2)
+    idx, mu, vv, ucb = eng.best_ucb_grow(boxes, depth, VS)
+    scored, asked = eng.last_count(0), eng.last_count(1)
+    rows, uniq = tree.grow_count(depth), 3 ** (depth - 1)
+    distinct = 0
+    for s in range(nbox):
+        coords = tree.grow([tuple(b) for b in boxes[s]], depth)
+        distinct += len(np.unique(coords.view(np.dtype((np.void, 8 * d)))))
+        one = eng.best_ucb(coords, VS)
+        assert (int(one[0][0]), one[1][0], one[2][0], one[3][0]) == (int(idx[s]), mu[s], vv[s], ucb[s])
+    assert asked == nbox * rows
+    # every bit-distinct row is scored; rows equal to their PARENT are dropped (rows that merely coincide
+    # with some other row are not looked for)
+    assert distinct <= scored <= nbox * rows
+    assert scored > nbox * uniq or distinct == nbox * uniq
+
+
+def test_best_ucb_grow_in_several_chunks():
+    """depth 13 x 2 boxes = 1.6 M reference rows (1.06 M distinct): more than one 1 Mi-leaf pass of the
+    tile kernel, so the live count is split per chunk on the device."""
+    X, y, th = _problem(64, 3)
+    eng = _engine("float32")
+    _fit(eng, X, y, th, grad=False)
+    kids = tree.split_bounds([(0.0, 1.0)] * 3)
+    boxes = np.array([kids[0], kids[2]])
+    depth = 13
+    idx, mu, vv, ucb = eng.best_ucb_grow(boxes, depth, VS)
+    assert eng.last_count(1) == 2 * tree.grow_count(depth) and eng.last_count(0) == 2 * 3 ** (depth - 1)
+    full = eng.grow(boxes, depth)
+    for s in range(2):
+        one = eng.best_ucb(full[s], VS)
+        assert (int(one[0][0]), one[1][0], one[2][0], one[3][0]) == (int(idx[s]), mu[s], vv[s], ucb[s])
+
+
 # ---- BASELINE.json sizes: oracle on a subsample + size-independent properties ----------------------
 def _properties(eng, X, y, th, Xs, post, n_check):
     m = Xs.shape[0]
