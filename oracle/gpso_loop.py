@@ -171,7 +171,11 @@ def tree_explore(state: LoopState, levels, seed=None):
                 if state.method == "tree":
                     coords = tree.grow(child["bounds"], state.max_depth)
                 else:
+                    # the reference pops "seed" from its kwargs at the first use
+                    # (gpso/optimisation.py:361-364): only the first fresh child of a pass is seeded,
+                    # the later ones re-seed numpy from OS entropy (np.random.seed(None))
                     coords = tree.sample_uniformly(child["bounds"], state.max_depth, seed)
+                    seed = None
                 mean, var = predict(state, coords)
                 ucb = mean + state.varsigma * var
                 i = int(np.argmax(ucb))

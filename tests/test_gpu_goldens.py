@@ -135,3 +135,72 @@ def test_G6_G7_notebook_trace_and_hyperparameters():
     for got, exp in zip(thetas, G["G7"]["theta_after_each_update"]):
         for key in ("mean_c", "variance", "lengthscale", "noise"):
             assert abs(got[key] - exp[key]) <= 6e-6 * abs(exp[key]), (key, got[key], exp[key])
+
+
+# ---- a8: the "sample" exploration method (gpso/optimisation.py:361-364, param_space.py:157-173) ------
+@pytest.mark.parametrize("dtype", ["float64", "mixed"])
+def test_sample_method_matches_the_oracle_loop(dtype, monkeypatch):
+    """exploration_method="sample": every fresh child is scored on depth * D^2 uniform samples of its
+    box (np.random.seed(seed) for the first child of a pass only -- the reference's quirk).  The HIP
+    engine behind the drop-in classes against the CPU restatement of the reference loop, same seed:
+    the evaluation trace is identical (float64: bit for bit; "mixed": float64 fit, float32 predict)."""
+    from oracle import gpso_loop
+    from pygpso_amd import GPRSurrogate, GPSOptimiser, ParameterSpace
+
+    # np.random.seed(None) -- what every child after the first of a pass gets -- draws OS entropy; make
+    # it a reproducible sequence for the two runs being compared
+    real_seed = np.random.seed
+
+    def seeding():
+        fallback = iter(range(1000, 100000))
+        return lambda s=None: real_seed(next(fallback) if s is None else s)
+
+    bounds, depth, budget, seed = G["G4"]["bounds"], 4, 40, 42
+    monkeypatch.setattr(np.random, "seed", seeding())
+    space = ParameterSpace(parameter_names=["x", "y"], parameter_bounds=bounds)
+    opt = GPSOptimiser(parameter_space=space, gp_surrogate=GPRSurrogate.default(dtype=dtype),
+                       exploration_method="sample", exploration_depth=depth, budget=budget)
+    best = opt.run(rotated_peaks, seed=seed)
+    assert opt.max_depth == depth * 2 ** 2
+    monkeypatch.setattr(np.random, "seed", seeding())
+    st = gpso_loop.LoopState(bounds, depth=depth, budget=budget, method="sample")
+    best_ref = gpso_loop.run(st, rotated_peaks, seed=seed)
+    assert [t[0] for t in opt.trace] == [t[0] for t in st.trace]
+    assert [t[1] for t in opt.trace] == [t[1] for t in st.trace]  # objective values: same points evaluated
+    tol = 1e-8 if dtype == "float64" else 1e-4
+    assert max(abs(a[2] - b[2]) for a, b in zip(opt.trace, st.trace)) < tol
+    np.testing.assert_array_equal(best.normed_coord, best_ref["coord"])
+    assert best.score_mu == best_ref["mu"]
+
+
+# ---- n3: conditional-surrogate grids (gpso/plotting.py:257-381) --------------------------------------
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-9), ("mixed", 5e-6)])
+def test_conditional_surrogate_grids_against_per_pair_oracle_predictions(dtype, tol):
+    """D = 4, granularity 50: the six 50 x 50 slices through the best point, scored by the HIP predict
+    kernel as ONE batch of 15 000 rows, against per-pair oracle predict_y calls (what the reference's
+    plot_conditional_surrogate_distributions evaluates pair by pair)."""
+    from oracle import gpr
+    from pygpso_amd import GPRSurrogate, GPSOptimiser, ParameterSpace, conditional_surrogate_grids
+
+    d, g = 4, 50
+    space = ParameterSpace(parameter_names=list("abcd"), parameter_bounds=[[-1, 1]] * d)
+    opt = GPSOptimiser(parameter_space=space, gp_surrogate=GPRSurrogate.default(dtype=dtype),
+                       exploration_depth=4, budget=30)
+    opt.run(lambda p: float(np.exp(-np.sum((np.asarray(p) - 0.2) ** 2)) + 0.1 * np.cos(3 * np.sum(p))))
+    grids = conditional_surrogate_grids(opt.gp_surr, granularity=g)
+    assert sorted(grids) == [(i, j) for i in range(d) for j in range(i + 1, d)]
+    model = opt.gp_surr.gpflow_model
+    x, y = opt.gp_surr.current_training_data
+    th = gpr.Theta(model.kernel.name, np.atleast_1d(model.kernel.lengthscales), model.kernel.variance,
+                   model.likelihood.variance, float(model.mean_function.c))
+    post = gpr.posterior(th, x, y)
+    best = opt.gp_surr.highest_score.normed_coord
+    ax = np.linspace(0, 1, g)
+    xg, yg = np.meshgrid(ax, ax)
+    scale = max(1.0, float(np.max(np.abs(y))))
+    for (i, j), (mean, var) in grids.items():
+        at = np.vstack([best] * g * g)
+        at[:, i], at[:, j] = xg.flatten(), yg.flatten()
+        m_ref, v_ref = gpr.predict_y(post, at)
+        assert np.max(np.abs(mean - m_ref.reshape(g, g))) <= tol * scale, (i, j)
+        assert np.max(np.abs(var - v_ref.reshape(g, g))) <= tol * th.variance, (i, j)
