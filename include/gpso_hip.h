@@ -37,7 +37,7 @@ typedef struct gpso_ctx gpso_ctx;
                           /* the reference lets TF's InvalidArgumentError escape here         */
 #define GPSO_E_OOM (-4)   /* device allocation failed                                         */
 #define GPSO_E_STATE (-5) /* call order: no training data / no posterior resident yet         */
-#define GPSO_E_RCCL (-6)  /* an RCCL call of the multi-GPU group failed                        */
+#define GPSO_E_RCCL (-6)  /* an RCCL call of the multi-GPU group failed (or librccl could not be loaded) */
 #define GPSO_E_PRECISION (-7) /* float predict arithmetic cannot meet the stated tolerance on this */
                           /* posterior (measured by the self-test, see gpso_precision_info): open a   */
                           /* GPSO_MIXED or GPSO_F64 context instead                                   */
@@ -163,10 +163,48 @@ int gpso_grow(gpso_ctx* ctx, const double* bounds, int nseg, int d, int depth, d
 int gpso_best_ucb_grow(gpso_ctx* ctx, const double* bounds, int nseg, int depth, double varsigma,
                        int64_t* idx, double* mean, double* var, double* ucb);
 
+/* ---- multi-GPU group (no counterpart in the reference: it has no distributed path) --------------- */
+
+/* One context per GPU -- in one process per GPU (torchrun / MPI style) or on several threads of one
+ * process -- joined into a group through RCCL.  The predict path shards (leaves are independent given
+ * the posterior): the GP is fitted on ONE rank, its predict-ready state is broadcast over xGMI, every
+ * rank scores a contiguous share of the leaves with no data-path collective, and the per-segment
+ * winners (4 doubles each) are all-gathered and folded on the device with np.argmax's order on
+ * (ucb, global index) -- so every rank returns the same result, bit-identical to the single-GPU call.
+ * librccl is loaded (dlopen) by the first of these calls; failures return GPSO_E_RCCL.
+ * Every rank of a group must make the same sequence of group calls with the same arguments (as for any
+ * collective); the arithmetic options (dtype, predict math, generation) must match across the group. */
+#define GPSO_UNIQUE_ID_BYTES 128
+/* rank 0 creates the group id (ncclGetUniqueId) and hands the 128 bytes to every rank by any means
+ * (the launcher's rendezvous, MPI, a file); ctx-less: the message of a failure is gpso_last_error(NULL) */
+int gpso_comm_unique_id(void* out_id /* [GPSO_UNIQUE_ID_BYTES] */);
+/* collective over the group: ncclCommInitRank on the context's device */
+int gpso_comm_init(gpso_ctx* ctx, int rank, int world, const void* unique_id);
+int gpso_comm_destroy(gpso_ctx* ctx);
+/* returns 1 when the context belongs to a group, 0 otherwise; rank / world are filled either way */
+int gpso_comm_info(const gpso_ctx* ctx, int* rank, int* world);
+/* the contiguous share [lo, hi) of m leaves (or reference rows) that `rank` of `world` handles */
+void gpso_shard_range(int64_t m, int rank, int world, int64_t* lo, int64_t* hi);
+/* collective: the posterior resident on `root` (after gpso_fit_eval / gpso_set_posterior) becomes
+ * resident on every rank -- one RCCL broadcast per buffer of gpso_posterior_buffers, device to device */
+int gpso_broadcast_posterior(gpso_ctx* ctx, int root);
+/* collective gpso_best_ucb: xs holds THIS rank's rows gpso_shard_range(m_global, rank, world) of the
+ * batch (m_local of them); seg_off[nseg+1] (host, NULL = one segment) is in GLOBAL rows; idx is relative
+ * to the global segment start.  Outputs are identical on every rank. */
+int gpso_best_ucb_sharded(gpso_ctx* ctx, const void* xs, int xs_dtype, int xs_mem, int64_t m_local,
+                          int64_t m_global, const int64_t* seg_off, int nseg, double varsigma,
+                          int64_t* idx, double* mean, double* var, double* ucb);
+/* collective gpso_best_ucb_grow: every rank generates and scores the reference rows
+ * gpso_shard_range(gpso_grow_rows(depth), rank, world) of every box on its own device (O(D) bytes in) */
+int gpso_best_ucb_grow_sharded(gpso_ctx* ctx, const double* bounds, int nseg, int depth, double varsigma,
+                               int64_t* idx, double* mean, double* var, double* ucb);
+
 /* ---- introspection ------------------------------------------------------------------------- */
 
 /* padded problem size the device works with (multiple of 128), 0 before gpso_set_data */
 int64_t gpso_padded_n(const gpso_ctx* ctx);
+/* N and D of the problem the context currently holds (0, 0 before any data / posterior arrived) */
+int gpso_problem_shape(const gpso_ctx* ctx, int64_t* n, int* d);
 int gpso_get_matrix(gpso_ctx* ctx, int which, double* out /* [N*N] host */);
 int gpso_get_vector(gpso_ctx* ctx, int which, double* out /* [N] host */);
 

@@ -21,6 +21,7 @@ OK, E_ARG, E_HIP, E_NOTPD, E_OOM, E_STATE, E_RCCL, E_PRECISION = 0, -1, -2, -3, 
 F64, F32, MIXED = 0, 1, 2
 MATERN52, MATERN32, MATERN12, SQEXP = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
+UNIQUE_ID_BYTES = 128
 MAT_CHOL, MAT_LINV, MAT_KINV, MAT_GRAM = 0, 1, 2, 3
 VEC_ALPHA, VEC_WHITE = 0, 1
 OPT_PREDICT_MATH = 1
@@ -74,11 +75,23 @@ SIGNATURES = {
     "gpso_best_ucb_grow": (C.c_int, [C.c_void_p, _c_double_p, C.c_int, C.c_int, C.c_double,
                                      _c_int64_p, _c_double_p, _c_double_p, _c_double_p]),
     "gpso_padded_n": (C.c_int64, [C.c_void_p]),
+    "gpso_problem_shape": (C.c_int, [C.c_void_p, _c_int64_p, C.POINTER(C.c_int)]),
     "gpso_get_matrix": (C.c_int, [C.c_void_p, C.c_int, _c_double_p]),
     "gpso_get_vector": (C.c_int, [C.c_void_p, C.c_int, _c_double_p]),
     "gpso_posterior_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), _c_int64_p, C.c_int]),
     "gpso_alloc_posterior": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
     "gpso_adopt_posterior": (C.c_int, [C.c_void_p]),
+    "gpso_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "gpso_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "gpso_comm_destroy": (C.c_int, [C.c_void_p]),
+    "gpso_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gpso_shard_range": (None, [C.c_int64, C.c_int, C.c_int, _c_int64_p, _c_int64_p]),
+    "gpso_broadcast_posterior": (C.c_int, [C.c_void_p, C.c_int]),
+    "gpso_best_ucb_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                        _c_int64_p, C.c_int, C.c_double, _c_int64_p, _c_double_p,
+                                        _c_double_p, _c_double_p]),
+    "gpso_best_ucb_grow_sharded": (C.c_int, [C.c_void_p, _c_double_p, C.c_int, C.c_int, C.c_double,
+                                             _c_int64_p, _c_double_p, _c_double_p, _c_double_p]),
     "gpso_last_ms": (C.c_double, [C.c_void_p, C.c_int]),
     "gpso_last_count": (C.c_int64, [C.c_void_p, C.c_int]),
     "gpso_version": (C.c_char_p, []),

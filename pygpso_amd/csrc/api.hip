@@ -17,6 +17,7 @@
 #include "../../include/gpso_hip.h"
 #include "common.hpp"
 #include "kernels.hpp"
+#include "rccl_api.hpp"
 
 using namespace gpso;
 
@@ -88,10 +89,24 @@ struct Engine {
   virtual int alloc_posterior(int64_t n, int d) = 0;
   virtual int adopt_posterior() = 0;
   virtual int64_t padded_n() const = 0;
+  virtual void problem_shape(int64_t* n_out, int* d_out) const = 0;
   virtual int set_option(int option, int value) = 0;
   virtual int set_option_f64(int option, double value) = 0;
   virtual int precision_info(double* out) = 0;
+  virtual int broadcast_posterior(int root) = 0;
+  virtual int best_ucb_sharded(const void* xs, int xs_dtype, int xs_mem, int64_t m_local, int64_t m_global,
+                               const int64_t* seg_off, int nseg, double varsigma, int64_t* idx, double* mean,
+                               double* var, double* ucb) = 0;
+  virtual int best_ucb_grow_sharded(const double* bounds, int nseg, int depth, double varsigma, int64_t* idx,
+                                    double* mean, double* var, double* ucb) = 0;
 };
+
+// contiguous share [lo, hi) of m items for `rank` of `world`: global order is preserved across ranks
+inline void shard_range(int64_t m, int rank, int world, int64_t* lo, int64_t* hi) {
+  const int64_t base = m / world, extra = m % world;
+  *lo = rank * base + std::min<int64_t>(rank, extra);
+  *hi = *lo + base + (rank < extra ? 1 : 0);
+}
 
 }  // namespace
 
@@ -118,6 +133,9 @@ struct gpso_ctx {
   std::vector<hipEvent_t> tile_ev;  // start/stop pairs around the leaf-tile kernel, one per chunk
   int tile_pairs = 0;               // pairs recorded by the call in flight
   double last_ms[3] = {0, 0, 0};
+  // multi-GPU group (gpso_comm_init): one RCCL communicator per context, collectives on ctx->stream
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
   int64_t last_count[2] = {0, 0};  // leaves scored / leaves asked for by the last predict-type call
   std::string err;
   Engine* eng = nullptr;
@@ -190,6 +208,13 @@ struct gpso_ctx {
                        #call, hipGetErrorString(e_));                                      \
   } while (0)
 
+#define RCCLCHECK(call)                                                                              \
+  do {                                                                                               \
+    ncclResult_t r_ = (call);                                                                        \
+    if (r_ != ncclSuccess)                                                                           \
+      return ctx->fail(GPSO_E_RCCL, "%s failed: %s", #call, RcclApi::get().GetErrorString(r_));      \
+  } while (0)
+
 namespace {
 
 // TF: fit type (Gram, Cholesky, L^-1, alpha);  TP: predict / apply type.
@@ -230,7 +255,7 @@ struct EngineT : Engine {
   std::vector<int64_t> segoff_cache;  // what the device copy of seg_off currently holds
   // predict workspace
   DevBuf leaves_raw, leaves_s, lnorm, pvar, pmean, omean, ovar, oucb, segoff, best, oidx, ovals, grow_key,
-      live_cnt, best_pos;
+      live_cnt, best_pos, gath, wbase, ovals2, bhdr;
   // precision self-test
   bool check = false, st_done = false, st_have = false;
   double tol_var = 1.0e-4, tol_mean = 1.0e-4;
@@ -242,11 +267,15 @@ struct EngineT : Engine {
                       &work, &kinvb, &linv_p, &white, &alpha_f, &alpha, &logdet, &scal, &gpart, &apart,
                       &kinv_diag, &getter_tmp, &leaves_raw, &leaves_s, &lnorm, &pvar, &pmean, &omean, &ovar,
                       &oucb, &segoff, &best, &oidx, &ovals, &linv_b, &st_mean, &st_var, &st_out, &grow_key, &live_cnt,
-                      &best_pos})
+                      &best_pos, &gath, &wbase, &ovals2, &bhdr})
       if (b->p) (void)hipFree(b->p);
   }
 
   int64_t padded_n() const override { return npad; }
+  void problem_shape(int64_t* n_out, int* d_out) const override {
+    *n_out = n;
+    *d_out = d;
+  }
 
   // generation type actually used: double unless GPSO_GEN_F32 was asked for -- or the split-bf16 kernel
   // with double leaf fragments would not fit the 160 KB of LDS (D > 24 for bf16x6, > 36 for bf16x3):
@@ -792,8 +821,12 @@ struct EngineT : Engine {
     return GPSO_OK;
   }
 
-  int best_ucb_device(const void* dev, int xs_dtype, int64_t m, const int64_t* seg_off, int nseg,
-                      double varsigma, int64_t* idx, double* mean, double* var, double* ucb) {
+  // ---- best-UCB sequencing: enqueue the local work (winners stay on the device, no host wait) ->
+  //      [multi-GPU: all-gather + fold] -> one read-back ------------------------------------------------
+  // per segment (mean, var, ucb, bit-cast index relative to the segment start) -> ovals; seg_off: host,
+  // nseg + 1 entries over [0, m]
+  int enqueue_best_leaves(const void* dev, int xs_dtype, int64_t m, const int64_t* seg_off, int nseg,
+                          double varsigma) {
     int rc;
     hipStream_t s = st();
     if ((rc = ensure(omean, (size_t)m * 8))) return rc;
@@ -801,7 +834,7 @@ struct EngineT : Engine {
     if ((rc = ensure(oucb, (size_t)m * 8))) return rc;
     if ((rc = ensure(segoff, (size_t)(nseg + 1) * 8))) return rc;
     if ((rc = ensure(best, (size_t)nseg * kArgmaxBlocks * kArgmaxPartialBytes))) return rc;
-    if ((rc = ensure(ovals, (size_t)nseg * 4 * 8))) return rc;
+    if ((rc = ensure(ovals, (size_t)(nseg * 4 + 1) * 8))) return rc;
     std::vector<int64_t> so(nseg + 1);
     if (seg_off) {
       for (int i = 0; i <= nseg; ++i) so[i] = seg_off[i];
@@ -822,20 +855,98 @@ struct EngineT : Engine {
       if ((rc = score_device_leaves(dev, xs_dtype, m, varsigma, true, as<double>(omean), as<double>(ovar), as<double>(oucb)))) return rc;
     launch_seg_argmax(s, as<double>(omean), as<double>(ovar), as<double>(oucb), as<int64_t>(segoff),
                       nseg, kArgmaxBlocks, best.p, as<double>(ovals));
-    double* vals = ctx->pinned_scratch((size_t)nseg * 4);
+    ctx->last_count[0] = ctx->last_count[1] = m;
+    return launch_status();
+  }
+
+  // the reference rows [row_lo, row_hi) of the sub-tree under every box, de-duplicated (grow.hip), scored;
+  // per segment (mean, var, ucb, bit-cast REFERENCE row index) -> ovals, live row count -> ovals[nseg*4]
+  int enqueue_best_grow(const double* bounds, int nseg, int depth, int64_t row_lo, int64_t row_hi,
+                        double varsigma) {
+    if (!bounds) return ctx->fail(GPSO_E_ARG, "bounds must not be NULL");
+    if (nseg < 1) return ctx->fail(GPSO_E_ARG, "nseg must be >= 1");
+    if (depth < 0 || depth > 16) return ctx->fail(GPSO_E_ARG, "depth %d outside [0, 16]", depth);
+    int rc;
+    hipStream_t s = st();
+    const int64_t rows = gpso_grow_rows(depth);
+    const int64_t uniq = grow_unique_before(row_hi) - grow_unique_before(row_lo);
+    const int64_t cap = (int64_t)nseg * (row_hi - row_lo);  // worst case: no centre child repeats its parent
+    const size_t bb = (size_t)nseg * d * 2 * 8;
+    const size_t ob = (size_t)cap * d * 8;
+    if ((rc = ensure(leaves_raw, ob + bb))) return rc;
+    if ((rc = ensure(grow_key, (size_t)std::max<int64_t>(cap, 1) * 8))) return rc;
+    if ((rc = ensure_keep(live_cnt, 64))) return rc;
+    if ((rc = ensure(omean, (size_t)cap * 8))) return rc;
+    if ((rc = ensure(ovar, (size_t)cap * 8))) return rc;
+    if ((rc = ensure(oucb, (size_t)cap * 8))) return rc;
+    if ((rc = ensure(best, (size_t)nseg * kArgmaxBlocks * kArgmaxPartialBytes))) return rc;
+    if ((rc = ensure(best_pos, (size_t)nseg * kArgmaxBlocks * 8))) return rc;
+    if ((rc = ensure(ovals, (size_t)(nseg * 4 + 1) * 8))) return rc;
+    double* bdev = reinterpret_cast<double*>(static_cast<char*>(leaves_raw.p) + ob);
+    double* stage = ctx->pinned_stage((size_t)nseg * d * 2 + 1);
+    if (!stage) return ctx->fail(GPSO_E_OOM, "pinned host staging");
+    std::memcpy(stage, bounds, bb);
+    const int64_t live0 = (int64_t)nseg * uniq;
+    std::memcpy(stage + (size_t)nseg * d * 2, &live0, 8);
+    HIPCHECK(hipMemcpyAsync(bdev, stage, bb, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(live_cnt.p, stage + (size_t)nseg * d * 2, 8, hipMemcpyHostToDevice, s));
+    launch_grow_unique(s, bdev, nseg, d, depth, row_lo, row_hi, as<double>(leaves_raw), as<int64_t>(grow_key),
+                       as<int64_t>(live_cnt));
+    if (cap > 0)
+      if ((rc = score_device_leaves(leaves_raw.p, GPSO_F64, cap, varsigma, true, as<double>(omean), as<double>(ovar),
+                                    as<double>(oucb), as<int64_t>(live_cnt))))
+        return rc;
+    launch_keyed_argmax(s, as<double>(omean), as<double>(ovar), as<double>(oucb), as<int64_t>(grow_key), rows, uniq,
+                        nseg, as<int64_t>(live_cnt), kArgmaxBlocks, best.p, as<int64_t>(best_pos), as<double>(ovals));
+    ctx->last_count[1] = cap;
+    return launch_status();
+  }
+
+  // multi-GPU: all-gather every rank's ovals and fold them with the arg-max rule on (ucb, global index);
+  // base (host, [world][nseg], nullable) is added to a rank's indices first.  Result -> ovals2.
+  // (upload_base, called BEFORE the local work is queued, puts base into wbase through the pinned stage)
+  int upload_base(const std::vector<int64_t>& base) {
+    int rc = ensure(wbase, base.size() * 8);
+    if (rc) return rc;
+    double* stage = ctx->pinned_stage(base.size());
+    if (!stage) return ctx->fail(GPSO_E_OOM, "pinned host staging");
+    std::memcpy(stage, base.data(), base.size() * 8);
+    HIPCHECK(hipMemcpyAsync(wbase.p, stage, base.size() * 8, hipMemcpyHostToDevice, st()));
+    return GPSO_OK;
+  }
+  int exchange_winners(int nseg, bool with_base) {
+    RcclApi& R = RcclApi::get();
+    int rc;
+    hipStream_t s = st();
+    const int world = ctx->world;
+    if ((rc = ensure(gath, (size_t)world * nseg * 4 * 8))) return rc;
+    if ((rc = ensure(ovals2, (size_t)(nseg * 4 + 1) * 8))) return rc;
+    const int64_t* base_dev = with_base ? as<int64_t>(wbase) : nullptr;
+    RCCLCHECK(R.AllGather(ovals.p, gath.p, (size_t)nseg * 4, ncclDouble, ctx->comm, s));
+    launch_reduce_winners(s, as<double>(gath), base_dev, world, nseg, as<double>(ovals2));
+    return launch_status();
+  }
+
+  // one read-back of nseg x (mean, var, ucb, index) [+ the live row count], then the host wait
+  int finish_best(const DevBuf& src, int nseg, bool with_count, int64_t* idx, double* mean, double* var,
+                  double* ucb) {
+    hipStream_t s = st();
+    const size_t doubles = (size_t)nseg * 4 + (with_count ? 1 : 0);
+    double* vals = ctx->pinned_scratch(doubles);
     if (!vals) return ctx->fail(GPSO_E_OOM, "pinned host scratch");
-    HIPCHECK(hipMemcpyAsync(vals, ovals.p, (size_t)nseg * 32, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(vals, src.p, doubles * 8, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipEventRecord(ctx->ev[3], s));
     HIPCHECK(ctx->wait(s));
+    int rc;
     if ((rc = launch_status())) return rc;
     collect_tile_ms();
-    ctx->last_count[0] = ctx->last_count[1] = m;
     for (int i = 0; i < nseg; ++i) {
       if (idx) std::memcpy(&idx[i], &vals[4 * i + 3], 8);
       if (mean) mean[i] = vals[4 * i];
       if (var) var[i] = vals[4 * i + 1];
       if (ucb) ucb[i] = vals[4 * i + 2];
     }
+    if (with_count) std::memcpy(&ctx->last_count[0], &vals[4 * nseg], 8);
     float ms = 0;
     if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ms[1] = ms;
     return GPSO_OK;
@@ -849,7 +960,57 @@ struct EngineT : Engine {
     HIPCHECK(hipEventRecord(ctx->ev[2], st()));
     const void* dev = nullptr;
     if (m > 0 && (rc = stage_leaves(xs, xs_dtype, xs_mem, m, &dev))) return rc;
-    return best_ucb_device(dev, xs_dtype, m, seg_off, nseg, varsigma, idx, mean, var, ucb);
+    if ((rc = enqueue_best_leaves(dev, xs_dtype, m, seg_off, nseg, varsigma))) return rc;
+    return finish_best(ovals, nseg, false, idx, mean, var, ucb);
+  }
+
+  int need_comm() {
+    if (ctx->comm == nullptr) return ctx->fail(GPSO_E_STATE, "this context is not part of a group: call gpso_comm_init first");
+    return GPSO_OK;
+  }
+
+  // This rank's contiguous share of a batch of m_global leaves (rows shard_range(m_global, rank, world) of
+  // it) -> the GLOBAL per-segment winners, identical on every rank and identical to gpso_best_ucb on the
+  // whole batch.  seg_off (host, nseg + 1 entries over [0, m_global], NULL: one segment) is global.
+  int best_ucb_sharded(const void* xs, int xs_dtype, int xs_mem, int64_t m_local, int64_t m_global,
+                       const int64_t* seg_off, int nseg, double varsigma, int64_t* idx, double* mean,
+                       double* var, double* ucb) override {
+    int rc = need_comm();
+    if (rc) return rc;
+    if ((rc = check_predict_args(xs, xs_dtype, xs_mem, m_local))) return rc;
+    if (nseg < 1) return ctx->fail(GPSO_E_ARG, "nseg must be >= 1");
+    int64_t lo, hi;
+    shard_range(m_global, ctx->rank, ctx->world, &lo, &hi);
+    if (m_local != hi - lo)
+      return ctx->fail(GPSO_E_ARG, "rank %d of %d must pass rows [%lld, %lld) of the %lld leaves (gpso_shard_range), got %lld rows",
+                       ctx->rank, ctx->world, (long long)lo, (long long)hi, (long long)m_global, (long long)m_local);
+    std::vector<int64_t> so(nseg + 1);
+    if (seg_off) {
+      for (int i = 0; i <= nseg; ++i) so[i] = seg_off[i];
+      if (so[0] != 0 || so[nseg] != m_global) return ctx->fail(GPSO_E_ARG, "seg_off must start at 0 and end at the global M");
+      for (int i = 0; i < nseg; ++i)
+        if (so[i + 1] < so[i]) return ctx->fail(GPSO_E_ARG, "seg_off must be non-decreasing");
+    } else {
+      if (nseg != 1) return ctx->fail(GPSO_E_ARG, "seg_off == NULL requires nseg == 1");
+      so[0] = 0;
+      so[1] = m_global;
+    }
+    // local segmentation: the part of every global segment inside [lo, hi); and for EVERY rank r the
+    // offset of its local piece of segment s inside the global segment (added to its winner's index)
+    std::vector<int64_t> sl(nseg + 1), base((size_t)ctx->world * nseg);
+    for (int i = 0; i <= nseg; ++i) sl[i] = std::min(std::max(so[i], lo), hi) - lo;
+    for (int r = 0; r < ctx->world; ++r) {
+      int64_t rlo, rhi;
+      shard_range(m_global, r, ctx->world, &rlo, &rhi);
+      for (int i = 0; i < nseg; ++i) base[(size_t)r * nseg + i] = std::min(std::max(so[i], rlo), rhi) - so[i];
+    }
+    HIPCHECK(hipEventRecord(ctx->ev[2], st()));
+    if ((rc = upload_base(base))) return rc;
+    const void* dev = nullptr;
+    if (m_local > 0 && (rc = stage_leaves(xs, xs_dtype, xs_mem, m_local, &dev))) return rc;
+    if ((rc = enqueue_best_leaves(dev, xs_dtype, m_local, sl.data(), nseg, varsigma))) return rc;
+    if ((rc = exchange_winners(nseg, true))) return rc;
+    return finish_best(ovals2, nseg, false, idx, mean, var, ucb);
   }
 
   // ------------------------------------------------------------------------------------------
@@ -894,56 +1055,79 @@ struct EngineT : Engine {
     if (!have_post) return ctx->fail(GPSO_E_STATE, "no posterior resident: call gpso_fit_eval / gpso_set_posterior first");
     int rc = precision_gate();
     if (rc) return rc;
-    if (!bounds) return ctx->fail(GPSO_E_ARG, "bounds must not be NULL");
-    if (nseg < 1) return ctx->fail(GPSO_E_ARG, "nseg must be >= 1");
-    if (depth < 0 || depth > 16) return ctx->fail(GPSO_E_ARG, "depth %d outside [0, 16]", depth);
+    HIPCHECK(hipEventRecord(ctx->ev[2], st()));
+    if ((rc = enqueue_best_grow(bounds, nseg, depth, 0, gpso_grow_rows(depth), varsigma))) return rc;
+    return finish_best(ovals, nseg, true, idx, mean, var, ucb);
+  }
+
+  // The same on a group: every rank generates and scores the reference rows shard_range(rows, rank, world)
+  // of every box (no leaf crosses a link: O(D) bytes in); the winners are all-gathered and folded on the
+  // (ucb, reference row index) order.  Identical result on every rank, identical to gpso_best_ucb_grow.
+  int best_ucb_grow_sharded(const double* bounds, int nseg, int depth, double varsigma, int64_t* idx,
+                            double* mean, double* var, double* ucb) override {
+    int rc = need_comm();
+    if (rc) return rc;
+    if (!have_post) return ctx->fail(GPSO_E_STATE, "no posterior resident: call gpso_broadcast_posterior first");
+    if ((rc = precision_gate())) return rc;
+    HIPCHECK(hipEventRecord(ctx->ev[2], st()));
+    int64_t lo, hi;
+    shard_range(gpso_grow_rows(depth), ctx->rank, ctx->world, &lo, &hi);
+    if ((rc = enqueue_best_grow(bounds, nseg, depth, lo, hi, varsigma))) return rc;
+    if ((rc = exchange_winners(nseg, false))) return rc;
+    if ((rc = finish_best(ovals2, nseg, false, idx, mean, var, ucb))) return rc;
+    ctx->last_count[0] = -1;  // (the local live count stays on the device: no second read-back)
+    return GPSO_OK;
+  }
+
+  // Make the posterior resident on `root` resident on every rank of the group: a 32-byte header (shape
+  // and arithmetic options, checked on every rank and agreed with an all-reduce so that either all ranks
+  // go on or all return), then one RCCL broadcast per predict buffer (gpso_posterior_buffers) straight
+  // out of / into the library's device memory, on the context's stream.
+  int broadcast_posterior(int root) override {
+    int rc = need_comm();
+    if (rc) return rc;
+    RcclApi& R = RcclApi::get();
+    if (root < 0 || root >= ctx->world) return ctx->fail(GPSO_E_ARG, "root %d outside the group of %d", root, ctx->world);
     hipStream_t s = st();
-    HIPCHECK(hipEventRecord(ctx->ev[2], s));
-    const int64_t rows = gpso_grow_rows(depth), uniq = grow_unique_rows(depth);
-    const int64_t cap = (int64_t)nseg * rows;  // worst case: no centre child repeats its parent
-    const size_t bb = (size_t)nseg * d * 2 * 8;
-    const size_t ob = (size_t)cap * d * 8;
-    if ((rc = ensure(leaves_raw, ob + bb))) return rc;
-    if ((rc = ensure(grow_key, (size_t)std::max<int64_t>(cap, 1) * 8))) return rc;
-    if ((rc = ensure_keep(live_cnt, 64))) return rc;
-    if ((rc = ensure(omean, (size_t)cap * 8))) return rc;
-    if ((rc = ensure(ovar, (size_t)cap * 8))) return rc;
-    if ((rc = ensure(oucb, (size_t)cap * 8))) return rc;
-    if ((rc = ensure(best, (size_t)nseg * kArgmaxBlocks * kArgmaxPartialBytes))) return rc;
-    if ((rc = ensure(best_pos, (size_t)nseg * kArgmaxBlocks * 8))) return rc;
-    if ((rc = ensure(ovals, (size_t)(nseg * 4 + 1) * 8))) return rc;
-    double* bdev = reinterpret_cast<double*>(static_cast<char*>(leaves_raw.p) + ob);
-    double* stage = ctx->pinned_stage((size_t)nseg * d * 2 + 1);
-    if (!stage) return ctx->fail(GPSO_E_OOM, "pinned host staging");
-    std::memcpy(stage, bounds, bb);
-    const int64_t live0 = (int64_t)nseg * uniq;
-    std::memcpy(stage + (size_t)nseg * d * 2, &live0, 8);
-    HIPCHECK(hipMemcpyAsync(bdev, stage, bb, hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemcpyAsync(live_cnt.p, stage + (size_t)nseg * d * 2, 8, hipMemcpyHostToDevice, s));
-    launch_grow_unique(s, bdev, nseg, d, depth, as<double>(leaves_raw), as<int64_t>(grow_key), as<int64_t>(live_cnt));
-    if (cap > 0)
-      if ((rc = score_device_leaves(leaves_raw.p, GPSO_F64, cap, varsigma, true, as<double>(omean), as<double>(ovar),
-                                    as<double>(oucb), as<int64_t>(live_cnt))))
-        return rc;
-    launch_keyed_argmax(s, as<double>(omean), as<double>(ovar), as<double>(oucb), as<int64_t>(grow_key), rows, uniq,
-                        nseg, as<int64_t>(live_cnt), kArgmaxBlocks, best.p, as<int64_t>(best_pos), as<double>(ovals));
-    double* vals = ctx->pinned_scratch((size_t)nseg * 4 + 1);
-    if (!vals) return ctx->fail(GPSO_E_OOM, "pinned host scratch");
-    HIPCHECK(hipMemcpyAsync(vals, ovals.p, (size_t)(nseg * 4 + 1) * 8, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipEventRecord(ctx->ev[3], s));
-    HIPCHECK(ctx->wait(s));
-    if ((rc = launch_status())) return rc;
-    collect_tile_ms();
-    for (int i = 0; i < nseg; ++i) {
-      if (idx) std::memcpy(&idx[i], &vals[4 * i + 3], 8);
-      if (mean) mean[i] = vals[4 * i];
-      if (var) var[i] = vals[4 * i + 1];
-      if (ucb) ucb[i] = vals[4 * i + 2];
+    const bool is_root = ctx->rank == root;
+    if ((rc = ensure(bhdr, 64))) return rc;
+    int64_t* hd = as<int64_t>(bhdr);
+    int64_t* host = reinterpret_cast<int64_t*>(ctx->pinned_scratch(8));
+    if (!host) return ctx->fail(GPSO_E_OOM, "pinned host scratch");
+    const int64_t my_opts = (int64_t)math | ((int64_t)(gen32 ? 1 : 0) << 8) | ((int64_t)ctx->dtype << 16);
+    int64_t ok = 1;
+    if (is_root) {
+      if (!have_post) ok = 0;  // still take part in the collectives below: every rank must leave together
+      host[0] = n; host[1] = d; host[2] = my_opts; host[3] = ok;
+      HIPCHECK(hipMemcpyAsync(hd, host, 32, hipMemcpyHostToDevice, s));
     }
-    std::memcpy(&ctx->last_count[0], &vals[4 * nseg], 8);
-    ctx->last_count[1] = cap;
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ms[1] = ms;
+    RCCLCHECK(R.Broadcast(hd, hd, 32, ncclChar, root, ctx->comm, s));
+    HIPCHECK(hipMemcpyAsync(host, hd, 32, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    const int64_t rn = host[0], rd = host[1], ropts = host[2];
+    ok = host[3];
+    const char* why = ok ? nullptr : "the root has no posterior resident";
+    if (ok && ropts != my_opts) {
+      ok = 0;
+      why = "dtype / predict math / generation options differ from the root's";
+    }
+    // agree: min over the ranks of `ok` (slot 4 of the header block)
+    host[4] = ok;
+    HIPCHECK(hipMemcpyAsync(hd + 4, host + 4, 8, hipMemcpyHostToDevice, s));
+    RCCLCHECK(R.AllReduce(hd + 4, hd + 4, 1, ncclInt64, ncclMin, ctx->comm, s));
+    HIPCHECK(hipMemcpyAsync(host + 4, hd + 4, 8, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    if (host[4] == 0)
+      return ctx->fail(why && !is_root ? GPSO_E_ARG : GPSO_E_STATE, "gpso_broadcast_posterior: %s",
+                       why ? why : "another rank of the group cannot take the root's posterior");
+    if (!is_root && (rc = alloc_posterior(rn, (int)rd))) return rc;
+    void* ptrs[8];
+    int64_t nb[8];
+    const int cnt = posterior_buffers(ptrs, nb, 8);
+    if (cnt < 0) return cnt;
+    for (int i = 0; i < cnt; ++i) RCCLCHECK(R.Broadcast(ptrs[i], ptrs[i], (size_t)nb[i], ncclChar, root, ctx->comm, s));
+    if (!is_root) return adopt_posterior();  // (synchronises the stream)
+    HIPCHECK(ctx->wait(s));
     return GPSO_OK;
   }
 
@@ -1105,6 +1289,7 @@ void gpso_destroy(gpso_ctx* ctx) {
   if (!ctx) return;
   DeviceGuard guard(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->comm) (void)RcclApi::get().CommDestroy(ctx->comm);
   delete ctx->eng;
   for (auto& ev : ctx->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -1221,6 +1406,16 @@ int64_t gpso_padded_n(const gpso_ctx* ctx) {
   return ctx ? ctx->eng->padded_n() : 0;
 }
 
+int gpso_problem_shape(const gpso_ctx* ctx, int64_t* n, int* d) {
+  if (!ctx) return GPSO_E_ARG;
+  int64_t nn = 0;
+  int dd = 0;
+  ctx->eng->problem_shape(&nn, &dd);
+  if (n) *n = nn;
+  if (d) *d = dd;
+  return GPSO_OK;
+}
+
 int gpso_get_matrix(gpso_ctx* ctx, int which, double* out) {
   ENTER();
   return ctx->eng->get_matrix(which, out);
@@ -1250,6 +1445,85 @@ int gpso_adopt_posterior(gpso_ctx* ctx) {
 double gpso_last_ms(gpso_ctx* ctx, int what) {
   if (!ctx || what < 0 || what > 2) return -1.0;
   return ctx->last_ms[what];
+}
+
+// ---- multi-GPU group --------------------------------------------------------------------------
+int gpso_comm_unique_id(void* out) {
+  if (!out) return GPSO_E_ARG;
+  RcclApi& R = RcclApi::get();
+  if (!R.ok) {
+    g_create_error = R.load_error;
+    return GPSO_E_RCCL;
+  }
+  ncclUniqueId id;
+  const ncclResult_t r = R.GetUniqueId(&id);
+  if (r != ncclSuccess) {
+    g_create_error = std::string("ncclGetUniqueId: ") + R.GetErrorString(r);
+    return GPSO_E_RCCL;
+  }
+  static_assert(sizeof(id) == GPSO_UNIQUE_ID_BYTES, "unique id size");
+  std::memcpy(out, &id, sizeof(id));
+  return GPSO_OK;
+}
+
+int gpso_comm_init(gpso_ctx* ctx, int rank, int world, const void* unique_id) {
+  ENTER();
+  if (!unique_id) return ctx->fail(GPSO_E_ARG, "unique_id must not be NULL");
+  if (world < 1 || rank < 0 || rank >= world) return ctx->fail(GPSO_E_ARG, "rank %d / world %d", rank, world);
+  if (ctx->comm) return ctx->fail(GPSO_E_STATE, "the context already belongs to a group (gpso_comm_destroy first)");
+  RcclApi& R = RcclApi::get();
+  if (!R.ok) return ctx->fail(GPSO_E_RCCL, "%s", R.load_error.c_str());
+  ncclUniqueId id;
+  std::memcpy(&id, unique_id, sizeof(id));
+  RCCLCHECK(R.CommInitRank(&ctx->comm, world, id, rank));
+  ctx->rank = rank;
+  ctx->world = world;
+  return GPSO_OK;
+}
+
+int gpso_comm_destroy(gpso_ctx* ctx) {
+  ENTER();
+  if (ctx->comm) {
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    RCCLCHECK(RcclApi::get().CommDestroy(ctx->comm));
+  }
+  ctx->comm = nullptr;
+  ctx->rank = 0;
+  ctx->world = 1;
+  return GPSO_OK;
+}
+
+int gpso_comm_info(const gpso_ctx* ctx, int* rank, int* world) {
+  if (!ctx) return GPSO_E_ARG;
+  if (rank) *rank = ctx->rank;
+  if (world) *world = ctx->world;
+  return ctx->comm ? 1 : 0;
+}
+
+void gpso_shard_range(int64_t m, int rank, int world, int64_t* lo, int64_t* hi) {
+  int64_t a = 0, b = 0;
+  if (world >= 1 && rank >= 0 && rank < world && m >= 0) shard_range(m, rank, world, &a, &b);
+  if (lo) *lo = a;
+  if (hi) *hi = b;
+}
+
+int gpso_broadcast_posterior(gpso_ctx* ctx, int root) {
+  ENTER();
+  return ctx->eng->broadcast_posterior(root);
+}
+
+int gpso_best_ucb_sharded(gpso_ctx* ctx, const void* xs, int xs_dtype, int xs_mem, int64_t m_local,
+                          int64_t m_global, const int64_t* seg_off, int nseg, double varsigma, int64_t* idx,
+                          double* mean, double* var, double* ucb) {
+  ENTER();
+  return ctx->eng->best_ucb_sharded(xs, xs_dtype, xs_mem, m_local, m_global, seg_off, nseg, varsigma, idx, mean,
+                                    var, ucb);
+}
+
+int gpso_best_ucb_grow_sharded(gpso_ctx* ctx, const double* bounds, int nseg, int depth, double varsigma,
+                               int64_t* idx, double* mean, double* var, double* ucb) {
+  ENTER();
+  return ctx->eng->best_ucb_grow_sharded(bounds, nseg, depth, varsigma, idx, mean, var, ucb);
 }
 
 int64_t gpso_last_count(gpso_ctx* ctx, int what) {

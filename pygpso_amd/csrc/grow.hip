@@ -88,17 +88,21 @@ __global__ __launch_bounds__(kGrowThreads) void grow_kernel(const double* __rest
 // nseg * U and ends as the number of live rows).  key[slot] = seg * rows + reference row index: the
 // arg-max runs on (ucb, key), so neither the compaction nor the order of the appended rows can change
 // the winner or its index -- a dropped row has the same bits, hence the same ucb, as an EARLIER row.
+// Multi-GPU: a rank generates the reference rows [row_lo, row_hi) of every box only; uniq is then the
+// number of analytic slots inside that range and slot_base the analytic slot of its first row
+// (grow_unique_before), so the compact list of a rank is dense.  Keys stay global reference indices.
 __global__ __launch_bounds__(kGrowThreads) void grow_unique_kernel(const double* __restrict__ bounds, int d,
-                                                                   int depth, int64_t rows, int64_t uniq,
-                                                                   double* __restrict__ out,
+                                                                   int depth, int64_t rows, int64_t row_lo,
+                                                                   int64_t row_hi, int64_t uniq,
+                                                                   int64_t slot_base, double* __restrict__ out,
                                                                    int64_t* __restrict__ key,
                                                                    unsigned long long* __restrict__ count) {
   extern __shared__ double grow_lds[];
   double* lo = grow_lds;
   double* hi = grow_lds + (size_t)d * kGrowThreads;
   const int seg = blockIdx.y, t = threadIdx.x;
-  const int64_t row = (int64_t)blockIdx.x * blockDim.x + t;
-  if (row >= rows) return;
+  const int64_t row = row_lo + (int64_t)blockIdx.x * blockDim.x + t;
+  if (row >= row_hi) return;
   int level;
   int64_t width, p;
   grow_locate(row, level, width, p);
@@ -115,10 +119,10 @@ __global__ __launch_bounds__(kGrowThreads) void grow_unique_kernel(const double*
   const int child = (level > 0) ? (int)(p % 3) : 0;
   int64_t slot;
   if (level == 0) {
-    slot = (int64_t)seg * uniq;
+    slot = (int64_t)seg * uniq - slot_base;
   } else if (child != 1) {
     grow_split(lo, hi, t, d, child);
-    slot = (int64_t)seg * uniq + width / 3 + 2 * (p / 3) + (child == 2 ? 1 : 0);
+    slot = (int64_t)seg * uniq + (width / 3 + 2 * (p / 3) + (child == 2 ? 1 : 0) - slot_base);
   } else {
     // centre child: compare its centre with the parent's, bit for bit, in the only dimension the split
     // touches (the others hold the same lo / hi)
@@ -166,13 +170,27 @@ int64_t grow_unique_rows(int depth) {
   return u;
 }
 
-void launch_grow_unique(hipStream_t st, const double* bounds_dev, int nseg, int d, int depth,
-                        double* out_dev, int64_t* key_dev, int64_t* count_dev) {
+// number of analytic slots (root + l / r children) among the reference rows [0, row)
+int64_t grow_unique_before(int64_t row) {
+  if (row <= 0) return 0;
+  int64_t start = 0, width = 1;  // width = 3^level of the level that holds `row`
+  while (start + width <= row) {
+    start += width;
+    width *= 3;
+  }
+  const int64_t p = row - start;  // position inside that level (level >= 1 here)
+  return width / 3 + 2 * (p / 3) + (p % 3 >= 1 ? 1 : 0);
+}
+
+void launch_grow_unique(hipStream_t st, const double* bounds_dev, int nseg, int d, int depth, int64_t row_lo,
+                        int64_t row_hi, double* out_dev, int64_t* key_dev, int64_t* count_dev) {
   const int64_t rows = grow_rows_of(depth);
-  if (rows == 0 || nseg == 0) return;
-  const dim3 grid((unsigned)((rows + kGrowThreads - 1) / kGrowThreads), (unsigned)nseg);
+  if (row_hi <= row_lo || nseg == 0) return;
+  const int64_t slot_base = grow_unique_before(row_lo);
+  const int64_t uniq = grow_unique_before(row_hi) - slot_base;
+  const dim3 grid((unsigned)((row_hi - row_lo + kGrowThreads - 1) / kGrowThreads), (unsigned)nseg);
   hipLaunchKernelGGL(grow_unique_kernel, grid, dim3(kGrowThreads), (size_t)2 * d * kGrowThreads * 8, st,
-                     bounds_dev, d, depth, rows, grow_unique_rows(depth), out_dev, key_dev,
+                     bounds_dev, d, depth, rows, row_lo, row_hi, uniq, slot_base, out_dev, key_dev,
                      reinterpret_cast<unsigned long long*>(count_dev));
 }
 

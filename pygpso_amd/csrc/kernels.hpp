@@ -170,8 +170,16 @@ void launch_grow(hipStream_t st, const double* bounds_dev, int nseg, int d, int 
 // parent): grow_unique_rows(depth) = 3^(depth-1) analytic slots per box, then the centre children whose
 // centre differs from the parent's in the last bit; key_dev[slot] = seg * rows + reference row index;
 // *count_dev must hold nseg * grow_unique_rows(depth) on entry and holds the live row count on exit
+// Only the reference rows [row_lo, row_hi) of every box (a rank's share of a sharded call; the whole list
+// is [0, rows)): analytic slots per box = grow_unique_before(row_hi) - grow_unique_before(row_lo).
 int64_t grow_unique_rows(int depth);
-void launch_grow_unique(hipStream_t st, const double* bounds_dev, int nseg, int d, int depth,
-                        double* out_dev, int64_t* key_dev, int64_t* count_dev);
+int64_t grow_unique_before(int64_t row);
+void launch_grow_unique(hipStream_t st, const double* bounds_dev, int nseg, int d, int depth, int64_t row_lo,
+                        int64_t row_hi, double* out_dev, int64_t* key_dev, int64_t* count_dev);
+// winners of several ranks -> the global winner per segment, np.argmax order on (ucb, global index):
+// gathered[world][nseg][4] = (mean, var, ucb, bit-cast index), base[world][nseg] (nullable) is added to a
+// rank's indices first; out[nseg][4]
+void launch_reduce_winners(hipStream_t st, const double* gathered, const int64_t* base, int world, int nseg,
+                           double* out);
 
 }  // namespace gpso

@@ -838,6 +838,36 @@ __global__ __launch_bounds__(256) void keyed_argmax_stage2(const Best* __restric
   }
 }
 
+// multi-GPU: one thread per segment folds the ranks' winners in rank order with the same rule
+__global__ void reduce_winners_kernel(const double* __restrict__ gathered, const int64_t* __restrict__ base,
+                                      int world, int nseg, double* __restrict__ out) {
+  const int seg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (seg >= nseg) return;
+  Best best{0.0, -1};
+  int from = -1;
+  for (int r = 0; r < world; ++r) {
+    const double* row = gathered + ((int64_t)r * nseg + seg) * 4;
+    int64_t i = __builtin_bit_cast(int64_t, row[3]);
+    if (i >= 0 && base != nullptr) i += base[(int64_t)r * nseg + seg];
+    const Best c{row[2], i};
+    if (better(c, best)) {
+      best = c;
+      from = r;
+    }
+  }
+  double* o = out + (int64_t)seg * 4;
+  if (from < 0) {
+    o[0] = o[1] = o[2] = __builtin_nan("");
+    o[3] = __builtin_bit_cast(double, (int64_t)-1);
+  } else {
+    const double* row = gathered + ((int64_t)from * nseg + seg) * 4;
+    o[0] = row[0];
+    o[1] = row[1];
+    o[2] = row[2];
+    o[3] = __builtin_bit_cast(double, best.i);
+  }
+}
+
 // per-chunk live count of a leaf batch processed in chunks: out[c] = clamp(*live - c * chunk, 0, chunk)
 __global__ void chunk_live_kernel(const int64_t* __restrict__ live, int64_t chunk, int nchunk,
                                   int64_t* __restrict__ out) {
@@ -957,6 +987,12 @@ void launch_keyed_argmax(hipStream_t st, const double* mean, const double* var, 
   hipLaunchKernelGGL(keyed_argmax_stage2, dim3((unsigned)nseg), dim3(256), 0, st,
                      reinterpret_cast<const Best*>(partial_dev), pos_dev, nblk, rows, mean, var, ucb, live_dev,
                      nseg, out_vals_dev);
+}
+
+void launch_reduce_winners(hipStream_t st, const double* gathered, const int64_t* base, int world, int nseg,
+                           double* out) {
+  hipLaunchKernelGGL(reduce_winners_kernel, dim3((unsigned)((nseg + 63) / 64)), dim3(64), 0, st, gathered, base,
+                     world, nseg, out);
 }
 
 void launch_chunk_live(hipStream_t st, const int64_t* live_dev, int64_t chunk, int nchunk, int64_t* out_dev) {

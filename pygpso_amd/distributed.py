@@ -1,96 +1,109 @@
 """
-Multi-GPU leaf-UCB: one process per GPU, ``torch.distributed`` over RCCL/xGMI ("nccl" backend).
+Multi-GPU leaf-UCB: one ``HipGPEngine`` per MI355X, joined into a group through RCCL **behind the
+C-ABI** (``gpso_comm_init`` / ``gpso_broadcast_posterior`` / ``gpso_best_ucb_sharded`` /
+``gpso_best_ucb_grow_sharded``, include/gpso_hip.h).  This module holds no torch and no collective of
+its own: it bootstraps the group id, computes the shard ranges and calls the library.
 
-The predict path shards naturally: leaves are independent given the
-posterior.  So
-  * the GP is fitted on ONE rank and its predict-ready state (tile-packed L^-1, scaled inputs,
-    norms, alpha, hyper-parameter block -- ``gpso_posterior_buffers``) is BROADCAST to the peers:
-    the only bulk collective, once per fit; a 1 -> 7 broadcast drives all 7 xGMI links of the root;
-  * every rank scores its own contiguous range of the leaf batch with no data-path collective;
-  * the per-rank winners (4 doubles each) are all-gathered and reduced with the same first-max
-    rule ``np.argmax`` applies to the unsharded batch, so the sharded result is bit-identical to
-    the single-GPU one.
+The predict path shards naturally: leaves are independent given the posterior.
+  * the GP is fitted on ONE rank and its predict-ready state (triangle-packed L^-1, scaled inputs,
+    norms, alpha, hyper-parameter block) is BROADCAST to the peers over xGMI: the only bulk collective,
+    once per fit;
+  * every rank scores its own contiguous share of the leaf batch -- or, for on-device growth, generates
+    and scores its share of the reference rows of every box -- with no data-path collective;
+  * the per-segment winners (4 doubles each) are all-gathered and folded on the device with the same
+    first-max rule ``np.argmax`` applies to the unsharded batch, so the sharded result is bit-identical
+    to the single-GPU one and identical on every rank.
 Nothing is all-reduced.  The reference has no distributed path at all.
+
+Two ways to form a group:
+  * one process per GPU (``torchrun`` / MPI style): every process creates its engine, rank 0 calls
+    ``unique_id()`` and ships the 128 bytes to the others by the launcher's rendezvous
+    (``exchange_unique_id``: a TCP exchange on MASTER_ADDR / MASTER_PORT, no framework needed), then all
+    call ``engine.comm_init(rank, world, uid)``;
+  * ONE process, several GPUs (``GPRSurrogate(devices=[...])``): ``HipGPEngineGroup`` drives one engine
+    per device from its own thread (ctypes releases the GIL; RCCL supports one communicator per thread).
+
+Engines without a native communicator (the CPU test double of tests/) go through ``HostGroup``, the
+same sharding and the same winner rule over a caller-supplied all-gather -- that is what the
+world-size-2 ``gloo`` tests exercise on CPU.
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
+import socket
+import struct
+import time
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
-import torch
-import torch.distributed as dist
+
+from . import _lib as L
 
 
-class _DeviceBytes:
-    """Expose a raw device allocation to torch through ``__cuda_array_interface__``."""
-
-    def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {
-            "shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2,
-            "strides": None,
-        }
-
-
-def device_bytes_as_tensor(ptr, nbytes, device):
-    """uint8 view (no copy) of ``nbytes`` of device memory at ``ptr`` on ``cuda:device``."""
-    return torch.as_tensor(_DeviceBytes(ptr, nbytes), device=torch.device("cuda", device))
+# -- group bootstrap ------------------------------------------------------------------------------
+def unique_id():
+    """128-byte RCCL group id (``ncclGetUniqueId`` through the C-ABI); call on ONE rank."""
+    lib = L.load()
+    buf = C.create_string_buffer(L.UNIQUE_ID_BYTES)
+    rc = lib.gpso_comm_unique_id(buf)
+    if rc != L.OK:
+        raise L.GpsoHipError(rc, lib.gpso_last_error(None).decode())
+    return bytes(buf.raw)
 
 
-def engine_posterior_tensors(engine):
-    """The predict-ready state of ``engine`` as a list of flat tensors that can be broadcast."""
-    if hasattr(engine, "posterior_tensors"):  # engines that keep their state in torch tensors already
-        return engine.posterior_tensors()
-    return [device_bytes_as_tensor(p, nb, engine.device) for p, nb in engine.posterior_buffers()]
+def exchange_unique_id(rank, world, addr=None, port=None, timeout=120.0, make_id=None):
+    """Rank 0 creates the id and serves it to the other ranks over TCP on (addr, port) -- by default
+    MASTER_ADDR and MASTER_PORT + 1 of the launcher's environment (the port itself belongs to the
+    launcher's own store)."""
+    make_id = make_id or unique_id
+    if world == 1:
+        return make_id()
+    addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(port if port is not None else int(os.environ.get("MASTER_PORT", "29500")) + 1)
+    if rank == 0:
+        uid = make_id()
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            for _ in range(world - 1):
+                conn, _peer = srv.accept()
+                with conn:
+                    conn.sendall(struct.pack("<I", len(uid)) + uid)
+        return uid
+    deadline = time.monotonic() + timeout
+    while True:
+        try:
+            with socket.create_connection((addr, port), timeout=5.0) as conn:
+                head = _recv_exact(conn, 4)
+                return _recv_exact(conn, struct.unpack("<I", head)[0])
+        except (ConnectionRefusedError, socket.timeout, OSError):
+            if time.monotonic() > deadline:
+                raise
+            time.sleep(0.05)
+
+
+def _recv_exact(conn, n):
+    out = b""
+    while len(out) < n:
+        chunk = conn.recv(n - len(out))
+        if not chunk:
+            raise ConnectionError("peer closed the connection while sending the group id")
+        out += chunk
+    return out
 
 
 def shard_range(m, rank, world):
-    """Contiguous leaf range [lo, hi) of ``rank``: global row order is preserved across ranks."""
+    """Contiguous range [lo, hi) of ``rank``: global row order is preserved across ranks (the same
+    rule as ``gpso_shard_range``)."""
     base, extra = divmod(int(m), int(world))
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def can_view_engine_memory(engine, group=None):
-    """True on every rank iff EVERY rank can hand the engine's device buffers to torch (agreed with
-    a MIN all-reduce on a torch-allocated tensor, so a rank that cannot does not leave the others
-    waiting inside a broadcast).  Callers that get False re-fit on each rank instead."""
-    ok = 1
-    try:
-        if hasattr(engine, "posterior_tensors"):
-            pass  # the engine already keeps its state in torch tensors
-        elif engine.n > 0:
-            for t in engine_posterior_tensors(engine):
-                _ = t.numel()
-        else:
-            probe = device_bytes_as_tensor(torch.zeros(16, dtype=torch.uint8, device=torch.device(
-                "cuda", engine.device)).data_ptr(), 16, engine.device)
-            _ = probe.numel()
-    except Exception:  # noqa: BLE001 - any failure means "do not broadcast"
-        ok = 0
-    flag = torch.tensor([ok], dtype=torch.int32)
-    if dist.get_backend(group) == "nccl":
-        flag = flag.cuda(engine.device)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    return bool(int(flag.item()))
-
-
-def broadcast_posterior(engine, src=0, group=None):
-    """Make the posterior resident on rank ``src`` resident on every rank of ``group``."""
-    rank = dist.get_rank(group)
-    shape = torch.tensor([engine.n, engine.d] if rank == src else [0, 0], dtype=torch.int64)
-    backend = dist.get_backend(group)
-    if backend == "nccl":
-        shape = shape.cuda(engine.device)
-    dist.broadcast(shape, src=src, group=group)
-    n, d = (int(v) for v in shape.cpu())
-    if rank != src:
-        engine.alloc_posterior(n, d)
-    for t in engine_posterior_tensors(engine):
-        dist.broadcast(t, src=src, group=group)
-    if backend == "nccl":
-        torch.cuda.synchronize(engine.device)
-    if rank != src:
-        engine.adopt_posterior()
-
-
+# -- winner rule (host mirror of predict.hip: reduce_winners_kernel) ---------------------------------
 def _better(a, b):
     """np.argmax order on (ucb, global index): NaN is the maximum, ties go to the lower index."""
     (ua, ia), (ub, ib) = a, b
@@ -115,48 +128,164 @@ def reduce_winners(rows):
     return best
 
 
-class _WinnerExchange:
-    """Preallocated buffers for the per-predict all-gather of (ucb, global idx, mean, var): pinned
-    host staging + device tensors, one collective and ONE stream synchronisation per step."""
-
-    def __init__(self, engine, group):
-        self.world = dist.get_world_size(group)
-        self.nccl = dist.get_backend(group) == "nccl"
-        if self.nccl:
-            dev = torch.device("cuda", engine.device)
-            self.mine_host = torch.empty(4, dtype=torch.float64).pin_memory()
-            self.rows_host = torch.empty(self.world * 4, dtype=torch.float64).pin_memory()
-            self.mine_dev = torch.empty(4, dtype=torch.float64, device=dev)
-            self.rows_dev = torch.empty(self.world * 4, dtype=torch.float64, device=dev)
-        else:
-            self.mine_host = torch.empty(4, dtype=torch.float64)
-            self.rows_host = torch.empty(self.world * 4, dtype=torch.float64)
-
-    def exchange(self, ucb, gidx, mean, var, group):
-        m = self.mine_host
-        m[0], m[1], m[2], m[3] = ucb, gidx, mean, var
-        if self.nccl:
-            self.mine_dev.copy_(m, non_blocking=True)
-            dist.all_gather_into_tensor(self.rows_dev, self.mine_dev, group=group)
-            self.rows_host.copy_(self.rows_dev, non_blocking=True)
-            torch.cuda.current_stream(self.mine_dev.device).synchronize()
-        else:
-            dist.all_gather_into_tensor(self.rows_host, m, group=group)
-        return self.rows_host.numpy().reshape(self.world, 4)
+# -- collective calls: native for HIP engines ---------------------------------------------------------
+def broadcast_posterior(engine, src=0):
+    """Make the posterior resident on rank ``src`` resident on every rank of the engine's group."""
+    engine.broadcast_posterior(src)
 
 
-_exchanges = {}
+def best_ucb_sharded(engine, local_leaves, m_global, varsigma, seg_off=None):
+    """Score this rank's leaf shard (rows ``shard_range(m_global, rank, world)`` of the batch) and agree
+    on the global winner of every segment.  Returns (idx, mean, var, ucb) arrays of length nseg --
+    identical on every rank, and identical to ``engine.best_ucb(all_leaves, varsigma, seg_off)``."""
+    return engine.best_ucb_sharded(local_leaves, m_global, varsigma, seg_off)
 
 
-def best_ucb_sharded(engine, local_leaves, offset, varsigma, group=None):
-    """Score this rank's leaf shard (rows ``offset ..`` of the global batch) and agree on the global
-    winner.  Returns (global_idx, mean, var, ucb) -- identical on every rank, and identical to
-    ``engine.best_ucb(all_leaves)`` on one GPU."""
-    idx, mean, var, ucb = engine.best_ucb(local_leaves, varsigma)
-    gidx = float(idx[0] + offset) if idx[0] >= 0 else -1.0  # < 2^53: exact in float64
-    key = (id(engine), id(group))
-    ex = _exchanges.get(key)
-    if ex is None:
-        ex = _exchanges[key] = _WinnerExchange(engine, group)
-    w = reduce_winners(ex.exchange(float(ucb[0]), gidx, float(mean[0]), float(var[0]), group))
-    return int(w[1]), float(w[2]), float(w[3]), float(w[0])
+def best_ucb_grow_sharded(engine, bounds, depth, varsigma):
+    return engine.best_ucb_grow_sharded(bounds, depth, varsigma)
+
+
+# -- the same protocol over a caller-supplied transport (engines without a native communicator) -------
+class HostGroup:
+    """Sharding + winner rule on the host for an engine object that has no RCCL communicator of its
+    own (the oracle-backed test double).  ``allgather(a)``: float64 array -> [world, *a.shape] stacked
+    in rank order; ``bcast(obj, src)``: python object from ``src`` to all."""
+
+    def __init__(self, engine, rank, world, allgather, bcast):
+        self.engine, self.rank, self.world = engine, int(rank), int(world)
+        self._allgather, self._bcast = allgather, bcast
+
+    def broadcast_posterior(self, src=0):
+        state = self.engine.export_posterior() if self.rank == src else None
+        state = self._bcast(state, src)
+        if self.rank != src:
+            self.engine.import_posterior(state)
+
+    def _fold(self, mine):
+        """mine [nseg, 4] = (ucb, global idx or -1, mean, var) -> winners [nseg, 4]"""
+        rows = np.asarray(self._allgather(np.ascontiguousarray(mine, dtype=np.float64)))
+        return np.stack([reduce_winners(rows[:, s, :]) for s in range(mine.shape[0])])
+
+    def best_ucb_sharded(self, local_leaves, m_global, varsigma, seg_off=None):
+        lo, hi = shard_range(m_global, self.rank, self.world)
+        assert local_leaves.shape[0] == hi - lo
+        so = np.array([0, m_global], dtype=np.int64) if seg_off is None else np.asarray(seg_off, dtype=np.int64)
+        local = np.clip(so, lo, hi) - lo
+        idx, mean, var, ucb = self.engine.best_ucb(local_leaves, varsigma, local)
+        # index relative to the GLOBAL segment start
+        gidx = np.where(idx >= 0, idx + (np.clip(so[:-1], lo, hi) - so[:-1]), -1).astype(np.float64)
+        w = self._fold(np.stack([ucb, gidx, mean, var], axis=1))
+        return w[:, 1].astype(np.int64), w[:, 2], w[:, 3], w[:, 0]
+
+    def best_ucb_grow_sharded(self, bounds, depth, varsigma):
+        b = np.asarray(bounds, dtype=np.float64)
+        if b.ndim == 2:
+            b = b[None]
+        rows = self.engine.grow_rows(depth)
+        lo, hi = shard_range(rows, self.rank, self.world)
+        grown = self.engine.grow(b, depth)[:, lo:hi, :]  # this rank's reference rows of every box
+        nseg = b.shape[0]
+        flat = grown.reshape(nseg * (hi - lo), b.shape[1])
+        idx, mean, var, ucb = self.engine.best_ucb(flat, varsigma, np.arange(nseg + 1) * (hi - lo))
+        gidx = np.where(idx >= 0, idx + lo, -1).astype(np.float64)
+        w = self._fold(np.stack([ucb, gidx, mean, var], axis=1))
+        return w[:, 1].astype(np.int64), w[:, 2], w[:, 3], w[:, 0]
+
+
+# -- ONE process, several GPUs --------------------------------------------------------------------------
+class HipGPEngineGroup:
+    """``HipGPEngine`` interface over several devices of one process: the fit runs on the first device,
+    every predict-type call is sharded over all of them.  Each engine is driven by its own thread (the
+    C-ABI calls release the GIL; the RCCL collectives inside them need all ranks in flight at once)."""
+
+    def __init__(self, dtype="float64", devices=(0,), **engine_options):
+        from .engine import HipGPEngine
+
+        self.devices = [int(dev) for dev in devices]
+        if not self.devices:
+            raise ValueError("devices must name at least one GPU")
+        self.world = len(self.devices)
+        self.engines = [HipGPEngine(dtype, device=dev, **engine_options) for dev in self.devices]
+        self.dtype_name, self.dtype = self.engines[0].dtype_name, self.engines[0].dtype
+        self.device = self.devices[0]
+        self._pool = ThreadPoolExecutor(self.world)
+        uid = unique_id()
+        self._all(lambda r, e: e.comm_init(r, self.world, uid))
+        self._stale = False  # peers lag behind the root's posterior?
+        self.n = self.d = 0
+
+    def _all(self, fn):
+        """fn(rank, engine) on every engine, each on its own thread; returns the results in rank order
+        (the first exception, if any, is raised after all threads are back)."""
+        futs = [self._pool.submit(fn, r, e) for r, e in enumerate(self.engines)]
+        out, err = [], None
+        for f in futs:
+            try:
+                out.append(f.result())
+            except Exception as exc:  # noqa: BLE001 - re-raised below
+                err = err or exc
+                out.append(None)
+        if err is not None:
+            raise err
+        return out
+
+    def close(self):
+        for e in getattr(self, "engines", []):
+            e.close()
+        if getattr(self, "_pool", None) is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # fit: first device only
+    def set_data(self, X, y):
+        self.engines[0].set_data(X, y)
+        self.n, self.d = self.engines[0].n, self.engines[0].d
+        self._stale = True
+
+    def fit_eval(self, *a, **kw):
+        self._stale = True
+        return self.engines[0].fit_eval(*a, **kw)
+
+    def set_posterior(self, *a, **kw):
+        self.engines[0].set_posterior(*a, **kw)
+        self.n, self.d = self.engines[0].n, self.engines[0].d
+        self._stale = True
+
+    def _sync_posterior(self):
+        if self._stale and self.world > 1:
+            self._all(lambda r, e: e.broadcast_posterior(0))
+        self._stale = False
+
+    # predict-type calls: sharded
+    def predict(self, xs, out=None):
+        if out is not None:
+            raise ValueError("device outputs are per-engine: use the engines of the group directly")
+        self._sync_posterior()
+        xs = np.asarray(xs)
+        m = xs.shape[0]
+        parts = self._all(lambda r, e: e.predict(xs[slice(*shard_range(m, r, self.world))]))
+        return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+
+    def best_ucb(self, xs, varsigma, seg_off=None):
+        self._sync_posterior()
+        xs = np.asarray(xs)
+        m = xs.shape[0]
+        res = self._all(lambda r, e: e.best_ucb_sharded(xs[slice(*shard_range(m, r, self.world))], m, varsigma,
+                                                        seg_off))
+        return res[0]
+
+    def best_ucb_grow(self, bounds, depth, varsigma):
+        self._sync_posterior()
+        return self._all(lambda r, e: e.best_ucb_grow_sharded(bounds, depth, varsigma))[0]
+
+    # everything else: the first engine
+    def __getattr__(self, name):
+        if name in ("engines", "_pool"):
+            raise AttributeError(name)
+        return getattr(self.engines[0], name)

@@ -59,6 +59,7 @@ class HipGPEngine:
         self._h = handle
         self.n = 0
         self.d = 0
+        self.rank, self.world = 0, 1
         if predict_math not in (None, "native", "f32"):
             self.set_predict_math(predict_math)
         if generation is not None:
@@ -285,6 +286,60 @@ class HipGPEngine:
         ucb = np.empty(nseg, dtype=np.float64)
         self._check(self._lib.gpso_best_ucb_grow(self._h, L.dptr(b), nseg, int(depth), float(varsigma),
                                                  L.i64ptr(idx), L.dptr(mean), L.dptr(var), L.dptr(ucb)))
+        return idx, mean, var, ucb
+
+    # -- multi-GPU group (RCCL behind the C-ABI; see pygpso_amd/distributed.py) ------------------
+    def comm_init(self, rank, world, unique_id):
+        """Join a group (collective: every rank calls it with the same 128-byte id of
+        ``distributed.unique_id()``)."""
+        buf = C.create_string_buffer(bytes(unique_id), L.UNIQUE_ID_BYTES)
+        self._check(self._lib.gpso_comm_init(self._h, int(rank), int(world), buf))
+        self.rank, self.world = int(rank), int(world)
+
+    def comm_destroy(self):
+        self._check(self._lib.gpso_comm_destroy(self._h))
+        self.rank, self.world = 0, 1
+
+    def broadcast_posterior(self, root=0):
+        """Collective: the posterior resident on ``root`` becomes resident here (RCCL broadcast)."""
+        self._check(self._lib.gpso_broadcast_posterior(self._h, int(root)))
+        n, d = C.c_int64(), C.c_int()
+        self._check(self._lib.gpso_problem_shape(self._h, C.byref(n), C.byref(d)))
+        self.n, self.d = int(n.value), int(d.value)
+
+    def best_ucb_sharded(self, local_leaves, m_global, varsigma, seg_off=None):
+        """Collective ``best_ucb``: ``local_leaves`` are this rank's rows
+        ``distributed.shard_range(m_global, rank, world)`` of the batch; ``seg_off`` is global.
+        Returns the global (idx, mean, var, ucb) per segment, identical on every rank."""
+        ptr, dt, mem, m, keep = self._leaf_args(local_leaves)
+        if seg_off is None:
+            nseg, so_ptr = 1, None
+        else:
+            so = np.ascontiguousarray(seg_off, dtype=np.int64)
+            nseg, so_ptr = int(so.shape[0] - 1), L.i64ptr(so)
+        idx = np.empty(nseg, dtype=np.int64)
+        mean = np.empty(nseg, dtype=np.float64)
+        var = np.empty(nseg, dtype=np.float64)
+        ucb = np.empty(nseg, dtype=np.float64)
+        self._check(self._lib.gpso_best_ucb_sharded(self._h, ptr, dt, mem, m, int(m_global), so_ptr, nseg,
+                                                    float(varsigma), L.i64ptr(idx), L.dptr(mean), L.dptr(var),
+                                                    L.dptr(ucb)))
+        return idx, mean, var, ucb
+
+    def best_ucb_grow_sharded(self, bounds, depth, varsigma):
+        """Collective ``best_ucb_grow``: every rank grows and scores its share of the reference rows."""
+        b = L.as_f64(bounds)
+        if b.ndim == 2:
+            b = b[None]
+        nseg, d, _ = b.shape
+        if d != self.d:
+            raise ValueError(f"bounds have D={d}, model has D={self.d}")
+        idx = np.empty(nseg, dtype=np.int64)
+        mean = np.empty(nseg, dtype=np.float64)
+        var = np.empty(nseg, dtype=np.float64)
+        ucb = np.empty(nseg, dtype=np.float64)
+        self._check(self._lib.gpso_best_ucb_grow_sharded(self._h, L.dptr(b), nseg, int(depth), float(varsigma),
+                                                         L.i64ptr(idx), L.dptr(mean), L.dptr(var), L.dptr(ucb)))
         return idx, mean, var, ucb
 
     # -- introspection -----------------------------------------------------------------------

@@ -213,7 +213,7 @@ class GPSurrogate:
         raise NotImplementedError
 
     def __init__(self, gp_kernel, gp_meanf=None, optimiser=None, varsigma=erfcinv(0.01), points=None,
-                 gpflow_model=None, dtype="float64", device=0, engine_options=None):
+                 gpflow_model=None, dtype="float64", device=0, engine_options=None, devices=None):
         """
         :param gp_kernel: kernel spec (``pygpso_amd.kernels.Matern52(...)`` etc.)
         :param gp_meanf: mean-function spec (``Constant(c)``) or None
@@ -226,6 +226,9 @@ class GPSurrogate:
             Float predictions are guarded by a self-test; a model whose posterior fails it moves to the
             next more precise arithmetic on the device by itself (``HipGPR``).
         :param device: HIP device index
+        :param devices: several HIP device indices: the fit runs on the first, every leaf-UCB / predict
+            call is sharded over all of them (RCCL behind the C-ABI, ``HipGPEngineGroup``); results are
+            bit-identical to a single device's
         :param engine_options: extra ``HipGPEngine`` keyword arguments (predict_math, generation, ...)
         """
         self.gpflow_model = gpflow_model
@@ -238,7 +241,8 @@ class GPSurrogate:
         assert hasattr(optimiser, "minimize")
         self.optimiser = optimiser
         self.dtype = dtype
-        self.device = device
+        self.devices = [int(v) for v in devices] if devices is not None else None
+        self.device = self.devices[0] if self.devices else device
         self.engine_options = dict(engine_options or {})
         self.points = GPListOfPoints(points or list())
 
@@ -337,18 +341,18 @@ class GPRSurrogate(GPSurrogate):
 
     def __init__(self, gp_kernel, gp_meanf=None, optimiser=None, varsigma=erfcinv(0.01),
                  gauss_likelihood_sigma=1.0e-3, points=None, gpflow_model=None, dtype="float64",
-                 device=0, engine_options=None):
+                 device=0, engine_options=None, devices=None):
         """
         :param gauss_likelihood_sigma: initial noise VARIANCE of the Gaussian likelihood (the
             reference passes it as ``noise_variance`` despite the name, gpso/gp_surrogate.py:494)
         """
         super().__init__(gp_kernel=gp_kernel, gp_meanf=gp_meanf, optimiser=optimiser,
                          varsigma=varsigma, points=points, gpflow_model=gpflow_model, dtype=dtype,
-                         device=device, engine_options=engine_options)
+                         device=device, engine_options=engine_options, devices=devices)
         self.gp_lik_sigma = gauss_likelihood_sigma
 
     @classmethod
-    def default(cls, dtype="float64", device=0, engine_options=None):
+    def default(cls, dtype="float64", device=0, engine_options=None, devices=None):
         """Matern-5/2 (l = 0.25, s2 = 1), constant mean 0, L-BFGS-B, noise 1e-3
         (gpso/gp_surrogate.py:418-434)."""
         return cls(
@@ -360,6 +364,7 @@ class GPRSurrogate(GPSurrogate):
             dtype=dtype,
             device=device,
             engine_options=engine_options,
+            devices=devices,
         )
 
     def _gp_train(self, x, y):
@@ -370,7 +375,7 @@ class GPRSurrogate(GPSurrogate):
             self.gpflow_model = HipGPR(data=(x, y), kernel=self.gp_kernel, mean_function=self.gp_meanf,
                                        noise_variance=self.gp_lik_sigma, dtype=self.dtype,
                                        device=self.device, engine=engine,
-                                       engine_options=self.engine_options)
+                                       engine_options=self.engine_options, devices=self.devices)
         else:
             self.gpflow_model.data = (x, y)  # hyper-parameters warm-start from the last optimum
         self.optimiser.minimize(self.gpflow_model.training_loss, self.gpflow_model.trainable_variables)
@@ -397,7 +402,7 @@ class GPRSurrogate(GPSurrogate):
             fh.write(json.dumps(info))
 
     @classmethod
-    def from_saved(cls, folder, device=0):
+    def from_saved(cls, folder, device=0, devices=None):
         points = GPListOfPoints.from_file(os.path.join(folder, cls.POINTS_FILE))
         ev = [p for p in points if p.label == PointLabels.evaluated]
         x = np.array([p.normed_coord for p in ev])
@@ -414,7 +419,8 @@ class GPRSurrogate(GPSurrogate):
         engine = cls.engine_factory() if cls.engine_factory is not None else None
         model = HipGPR(data=(x, y), kernel=kernel, mean_function=meanf,
                        noise_variance=params[".likelihood.variance"], dtype=info.get("dtype", "float64"),
-                       device=device, engine=engine)
+                       device=device, engine=engine, devices=devices)
         return cls(gp_kernel=kernel, gp_meanf=meanf, optimiser=Scipy(),
                    gauss_likelihood_sigma=info["gp_likelihood"], varsigma=info["gp_varsigma"],
-                   points=points, gpflow_model=model, dtype=info.get("dtype", "float64"), device=device)
+                   points=points, gpflow_model=model, dtype=info.get("dtype", "float64"), device=device,
+                   devices=devices)

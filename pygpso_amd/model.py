@@ -50,7 +50,7 @@ def _as_result(a):
 
 class HipGPR:
     def __init__(self, data, kernel, mean_function=None, noise_variance=1.0e-3, dtype="float64",
-                 device=0, engine=None, engine_options=None, escalate=True):
+                 device=0, engine=None, engine_options=None, escalate=True, devices=None):
         """``dtype``: "float64" | "mixed" | "float32" (see ``HipGPEngine``).  ``engine_options``: extra
         keyword arguments of ``HipGPEngine`` (predict_math, generation, tolerances).  ``escalate``:
         when the device reports that float predictions fail their self-test on the current posterior
@@ -67,14 +67,23 @@ class HipGPR:
         self.likelihood = types.SimpleNamespace(variance=float(noise_variance))
         self._engine_options = dict(engine_options or {})
         self._device = device
+        self._devices = list(devices) if devices is not None else None
         self._owns_engine = engine is None
         self.escalate = bool(escalate)
-        self.engine = engine if engine is not None else HipGPEngine(dtype=dtype, device=device,
-                                                                    **self._engine_options)
+        self.engine = engine if engine is not None else self._open_engine(dtype)
         self._data = None
         self._resident = False  # posterior on the device matches (data, hyper-parameters)?
         self.num_loss_evals = 0
         self.data = data
+
+    def _open_engine(self, dtype):
+        """One engine on ``device``, or -- ``devices=[...]`` -- a group that shards every predict-type
+        call over several GPUs of this process (pygpso_amd/distributed.py)."""
+        if self._devices is not None and len(self._devices) > 1:
+            from .distributed import HipGPEngineGroup
+
+            return HipGPEngineGroup(dtype=dtype, devices=self._devices, **self._engine_options)
+        return HipGPEngine(dtype=dtype, device=self._device, **self._engine_options)
 
     # -- data ---------------------------------------------------------------------------------
     @property
@@ -172,7 +181,7 @@ class HipGPR:
             return False
         logging.warning(f"{err}; reopening the GP posterior as a {nxt!r} engine on device {self._device}")
         old = self.engine
-        self.engine = HipGPEngine(dtype=nxt, device=self._device, **self._engine_options)
+        self.engine = self._open_engine(nxt)
         old.close()
         x, y = self._data
         self.engine.set_data(x, y[:, 0])

@@ -69,31 +69,16 @@ class OracleEngine:
     def last_ms(self, what=0):
         return self._ms
 
-    # -- the broadcast protocol of pygpso_amd.distributed, over host memory -----------------------
-    _HYPER = 8 + 48
+    # -- posterior hand-off of pygpso_amd.distributed.HostGroup (host memory) ------------------------
+    def export_posterior(self):
+        th = self.post.theta
+        return dict(kernel=th.kernel, lengthscales=np.array(th.lengthscales), variance=th.variance,
+                    noise=th.noise, mean_c=th.mean_c, X=self.post.X.copy(), L=self.post.L.copy(),
+                    alpha=self.post.alpha.copy(), y=self.post.y.copy())
 
-    def alloc_posterior(self, n, d):
-        self.n, self.d = int(n), int(d)
-        self._state = [np.zeros(self._HYPER), np.zeros((self.n, self.d)), np.zeros((self.n, self.n)),
-                       np.zeros(self.n), np.zeros(self.n)]
-
-    def posterior_tensors(self):
-        import torch
-
-        if self.post is not None:
-            th = self.post.theta
-            h = np.zeros(self._HYPER)
-            h[:7] = [self.n, self.d, gpr.KERNELS.index(th.kernel), th.lengthscales.shape[0],
-                     th.variance, th.noise, th.mean_c]
-            h[8:8 + th.lengthscales.shape[0]] = th.lengthscales
-            self._state = [h, self.post.X.copy(), self.post.L.copy(), self.post.alpha.copy(),
-                           self.post.y.copy()]
-        return [torch.from_numpy(a.reshape(-1)) for a in self._state]
-
-    def adopt_posterior(self):
-        h, X, Lc, alpha, y = self._state
-        n_ls = int(h[3])
+    def import_posterior(self, st):
         post = gpr.Posterior()
-        post.theta = gpr.Theta(gpr.KERNELS[int(h[2])], h[8:8 + n_ls], h[4], h[5], h[6])
-        post.X, post.L, post.alpha, post.y, post.nlml = X, Lc, alpha, y, float("nan")
+        post.theta = gpr.Theta(st["kernel"], st["lengthscales"], st["variance"], st["noise"], st["mean_c"])
+        post.X, post.L, post.alpha, post.y, post.nlml = st["X"], st["L"], st["alpha"], st["y"], float("nan")
         self.post = post
+        self.n, self.d = post.X.shape

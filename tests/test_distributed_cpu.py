@@ -1,6 +1,9 @@
 """
-World-size-2 ``gloo`` tests of the multi-GPU path (leaf sharding, posterior broadcast protocol,
-winner reduction) on CPU, with the oracle-backed test double as the per-rank engine.
+World-size-2 ``gloo`` tests of the multi-GPU path (leaf sharding, posterior hand-off, on-device-growth
+row sharding, multi-segment batches, winner folding) on CPU: ``pygpso_amd.distributed.HostGroup`` --
+the host mirror of what the C-ABI group calls do with RCCL -- over torch.distributed's gloo backend,
+with the oracle-backed test double as the per-rank engine.  (torch lives in the TEST: the package
+itself imports no torch.)
 """
 import os
 import socket
@@ -19,54 +22,84 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, m, dup, out):
+def _gloo_transport(dist):
+    import torch
+
+    def allgather(a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        out = [torch.empty(a.shape, dtype=torch.float64) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, torch.from_numpy(a))
+        return np.stack([t.numpy() for t in out])
+
+    def bcast(obj, src):
+        box = [obj]
+        dist.broadcast_object_list(box, src=src)
+        return box[0]
+
+    return allgather, bcast
+
+
+def _worker(rank, world, port, case, m, out):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
 
-    from oracle import gpr
+    from oracle import gpr, tree
     from pygpso_amd import distributed as D
     from tests.helpers import synthetic_leaves, synthetic_problem
     from tests.oracle_engine import OracleEngine
 
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
+        VS = gpr.VARSIGMA_DEFAULT
         X, y = synthetic_problem(80, 3, seed=0)
-        leaves = synthetic_leaves(m, 3, seed=1)
-        if dup:  # the global winner also appears, later, in the other rank's shard
-            eng0 = OracleEngine()
-            eng0.set_data(X, y)
-            eng0.fit_eval("Matern52", [0.4], 1.0, 1e-3, 0.0, want_grad=False)
-            i0 = int(eng0.best_ucb(leaves, gpr.VARSIGMA_DEFAULT)[0][0])
-            leaves[(i0 + m // 2) % m] = leaves[i0]
+        ref = OracleEngine()  # single-process answer
+        ref.set_data(X, y)
+        ref.fit_eval("Matern52", [0.4], 1.0, 1e-3, 0.0, want_grad=False)
         eng = OracleEngine()
         if rank == 0:  # only the root fits
             eng.set_data(X, y)
             eng.fit_eval("Matern52", [0.4], 1.0, 1e-3, 0.0, want_grad=False)
-        assert D.can_view_engine_memory(eng) is True  # agreed across ranks before any bulk collective
-        D.broadcast_posterior(eng, src=0)
-        lo, hi = D.shard_range(m, rank, world)
-        got = D.best_ucb_sharded(eng, leaves[lo:hi], lo, gpr.VARSIGMA_DEFAULT)
-        # single-process answer on the whole batch
-        ref = OracleEngine()
-        ref.set_data(X, y)
-        ref.fit_eval("Matern52", [0.4], 1.0, 1e-3, 0.0, want_grad=False)
-        i, mu, vv, uu = ref.best_ucb(leaves, gpr.VARSIGMA_DEFAULT)
-        out[rank] = (got, (int(i[0]), float(mu[0]), float(vv[0]), float(uu[0])))
+        grp = D.HostGroup(eng, rank, world, *_gloo_transport(dist))
+        grp.broadcast_posterior(src=0)
+        if case in ("plain", "dup", "segments"):
+            leaves = synthetic_leaves(m, 3, seed=1)
+            if case == "dup":  # the global winner also appears, later, in the other rank's shard
+                i0 = int(ref.best_ucb(leaves, VS)[0][0])
+                leaves[(i0 + m // 2) % m] = leaves[i0]
+            seg = None
+            if case == "segments":  # uneven segments, one empty, several straddling the shard boundary
+                seg = np.array([0, m // 7, m // 7, m // 2 - 3, m // 2 + 5, m - 1, m], dtype=np.int64)
+            lo, hi = D.shard_range(m, rank, world)
+            got = grp.best_ucb_sharded(leaves[lo:hi], m, VS, seg)
+            exp = ref.best_ucb(leaves, VS, seg)
+        else:  # "grow": every rank grows and scores its share of the reference rows of every box
+            kids = tree.split_bounds([(0.0, 1.0)] * 3)
+            boxes = np.array([kids[0], kids[2], tree.split_bounds(kids[1])[0]])
+            got = grp.best_ucb_grow_sharded(boxes, m, VS)
+            exp = ref.best_ucb_grow(boxes, m, VS)
+        out[rank] = ([np.asarray(g).tolist() for g in got], [np.asarray(e).tolist() for e in exp])
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("m,dup", [(1001, False), (640, True), (3, False)])
-def test_two_ranks_agree_with_single_process(m, dup):
+@pytest.mark.parametrize("case,m", [("plain", 1001), ("dup", 640), ("plain", 3), ("segments", 900),
+                                    ("grow", 5), ("grow", 1)])
+def test_two_ranks_agree_with_single_process(case, m):
     world = 2
     with mp.Manager() as mgr:
         out = mgr.dict()
-        mp.spawn(_worker, args=(world, _free_port(), m, dup, out), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), case, m, out), nprocs=world, join=True)
         res = dict(out)
     assert sorted(res) == [0, 1]
-    assert res[0][0] == res[1][0]  # every rank holds the same winner
+    assert repr(res[0][0]) == repr(res[1][0])  # every rank holds the same winners (NaN-safe comparison)
     for got, ref in res.values():
-        assert got == ref  # bit-identical to the unsharded result, first-max tie rule included
+        # same winner (first-max tie rule included).  The values agree to the last bits only: the test
+        # double's BLAS rounds a leaf differently in batches of different shapes -- the HIP kernels do
+        # not (tests/test_gpu_parity.py::test_leaf_order_does_not_change_a_leafs_result), which is why
+        # the GPU group test below this level asserts bit-identity
+        assert got[0] == ref[0]
+        np.testing.assert_allclose(np.array(got[1:], dtype=float), np.array(ref[1:], dtype=float),
+                                   rtol=1e-12, atol=1e-13, equal_nan=True)
 
 
 def test_shard_ranges_partition_the_batch():
@@ -81,6 +114,21 @@ def test_shard_ranges_partition_the_batch():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_shard_range_of_the_library_matches_the_host_rule():
+    import ctypes as C
+
+    from pygpso_amd import _lib
+    from pygpso_amd.distributed import shard_range
+
+    lib = _lib.load()
+    for m in (0, 1, 7, 121, 65536, 1000003):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                lo, hi = C.c_int64(), C.c_int64()
+                lib.gpso_shard_range(m, r, world, C.byref(lo), C.byref(hi))
+                assert (lo.value, hi.value) == shard_range(m, r, world)
+
+
 def test_reduce_winners_first_max_and_nan_rules():
     from pygpso_amd.distributed import reduce_winners
 
@@ -90,3 +138,30 @@ def test_reduce_winners_first_max_and_nan_rules():
     assert int(reduce_winners(rows)[1]) == 40  # NaN counts as the maximum, first one wins
     rows = np.array([[np.nan, -1, 0, 0], [0.1, 5, 0, 0]])
     assert int(reduce_winners(rows)[1]) == 5  # an empty shard never wins
+
+
+def _id_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    from pygpso_amd import distributed as D
+
+    out[rank] = D.exchange_unique_id(rank, world, addr="127.0.0.1", port=port,
+                                     make_id=lambda: bytes(range(128)))
+
+
+def test_group_id_exchange_over_tcp():
+    """The framework-free bootstrap of the RCCL group id (rank 0 serves the 128 bytes on the launcher's
+    address); the id itself comes from a stand-in here -- ncclGetUniqueId needs the GPU box."""
+    world = 3
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_id_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        res = dict(out)
+    assert [res[r] for r in range(world)] == [bytes(range(128))] * world
+
+
+def test_package_imports_no_torch():
+    import subprocess
+
+    code = ("import sys; import pygpso_amd, pygpso_amd.distributed; "
+            "assert 'torch' not in sys.modules, 'pygpso_amd pulled in torch'")
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
