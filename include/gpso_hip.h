@@ -67,8 +67,11 @@ typedef struct gpso_ctx gpso_ctx;
                                         /* with L^-1 built beside it (default 3584, double 2560); 0 = always two-level +     */
                                         /* level-doubling triangular inverse.  Results agree to rounding.       */
 #define GPSO_OPT_GENERATION 3   /* float-predict contexts: arithmetic of the cross-Gram x.x* contraction / r^2 */
-#define GPSO_GEN_F64 0          /*   double (default): r^2 free of float cancellation error                    */
+#define GPSO_GEN_F64 0          /*   double: r^2 free of float cancellation error                              */
 #define GPSO_GEN_F32 1          /*   float: GPflow's GEMM form evaluated in float (|d r^2| ~ 1e-5 at l ~ 0.1) */
+#define GPSO_GEN_AUTO 2         /*   (default) float when the precision self-test of the posterior at hand     */
+                                /*   passes with it by a margin of 8x, double otherwise; double when no self-test can run and    */
+                                /*   for Matern-1/2 (its sqrt at r -> 0 is blind to the test)                  */
 #define GPSO_OPT_PRECISION_CHECK 4 /* 1: the first predict after every fit runs the self-test and returns       */
                                    /* GPSO_E_PRECISION when it fails (default in GPSO_F32 / GPSO_MIXED); 0: off  */
                                    /* (default in GPSO_F64)                                                     */
@@ -208,9 +211,11 @@ int gpso_problem_shape(const gpso_ctx* ctx, int64_t* n, int* d);
 int gpso_get_matrix(gpso_ctx* ctx, int which, double* out /* [N*N] host */);
 int gpso_get_vector(gpso_ctx* ctx, int which, double* out /* [N] host */);
 
-/* Device pointers + byte sizes of everything a peer GPU needs to predict (packed lower tiles of
- * L^-1, scaled X, norms, alpha, hyper-parameter block): fills up to cap entries, returns the count
- * (or a negative status). */
+/* Device pointers + byte sizes of everything a peer GPU needs to predict: hyper-parameter block, packed
+ * lower tiles of L^-1, scaled X (double: plain, as MFMA fragments, norms), alpha [, the bf16 pieces of
+ * L^-1 when a split-bf16 predict math is on]: fills up to cap (>= 7) entries, returns the count (or a
+ * negative status).  On a context that holds a posterior the call first lets GPSO_GEN_AUTO rule (it may
+ * run the self-test) and records the choice in the hyper block, so that the receiver generates alike. */
 int gpso_posterior_buffers(gpso_ctx* ctx, void** ptrs, int64_t* nbytes, int cap);
 /* Allocate the same buffers for n, d on a receiving rank so they can be broadcast into. */
 int gpso_alloc_posterior(gpso_ctx* ctx, int64_t n, int d);
@@ -221,13 +226,14 @@ int gpso_adopt_posterior(gpso_ctx* ctx);
 /* Precision self-test of the resident posterior (runs it if it has not run since the last fit; needs
  * the training targets, i.e. a posterior produced by gpso_fit_eval on this context): the predict path
  * is evaluated at the training inputs, where mean and variance have the closed form
- * mean_i = y_i - noise alpha_i, var_i = 2 noise - noise^2 (K_y^-1)_ii.  out[10]:
+ * mean_i = y_i - noise alpha_i, var_i = 2 noise - noise^2 (K_y^-1)_ii.  out[11]:
  *   [0] max |d mean|   [1] max |d var|   [2] max |y - c|   [3] min predicted var (incl. noise)
  *   [4] max |alpha|    [5] kernel variance   [6] tolerance on [0] (absolute)   [7] tolerance on [1]
  *   [8] amplification a: 1 for a float64 factor (GPSO_MIXED / GPSO_F64); for a float factor (GPSO_F32)
  *       max(1, sqrt(sigma^2 max_i (K_y^-1)_ii)) -- the training inputs see the factor's backward error
  *       unamplified, a general leaf amplified by the solve weights (calibrated heuristic)
  *   [9] max_i (K_y^-1)_ii
+ *   [10] generation arithmetic in use on this posterior: 0 double, 1 float (GPSO_GEN_AUTO's choice)
  * Returns GPSO_OK, GPSO_E_PRECISION when sqrt(a) [0] > [6] or a [1] > [7] (or a value is not finite), or
  * GPSO_E_STATE when no fitted posterior with targets is resident. */
 int gpso_precision_info(gpso_ctx* ctx, double* out);

@@ -248,7 +248,14 @@ struct EngineT : Engine {
   // split-bf16 copy of L^-1 (float predict with GPSO_OPT_PREDICT_MATH != native)
   DevBuf linv_b;
   int math = GPSO_MATH_NATIVE;
-  bool gen32 = false;  // GPSO_OPT_GENERATION == GPSO_GEN_F32 (float predict only)
+  // generation of the cross-Gram tile in float-predict contexts: the OPTION (gen_mode) and what the
+  // resident posterior actually uses (gen_eff32).  GPSO_GEN_AUTO starts every posterior in float -- the
+  // fast form -- and lets the precision self-test decide: if the float form misses the tolerances the
+  // posterior moves to double generation and is tested again (decide_generation).
+  int gen_mode = GPSO_GEN_AUTO;
+  bool gen_eff32 = true;
+  bool gen_decided = false;     // AUTO: has the self-test ruled on this posterior?
+  bool gen32_inputs_ok = false; // xs32 / xnorm32 / xs_p32 match the resident posterior
   int64_t single_level_max = -1;  // < 0: library default
   bool fused_small = true;        // GPSO_OPT_FIT_FUSED_SMALL
   bool linv_b_valid = false;
@@ -277,15 +284,12 @@ struct EngineT : Engine {
     *d_out = d;
   }
 
-  // generation type actually used: double unless GPSO_GEN_F32 was asked for -- or the split-bf16 kernel
-  // with double leaf fragments would not fit the 160 KB of LDS (D > 24 for bf16x6, > 36 for bf16x3):
-  // those shapes generate in float, and the self-test measures what that costs on the posterior at hand
-  bool gen_double() const {
-    if (!kFloatPredict) return true;
-    if (gen32) return false;
-    if (bf16_usable() && leaf_bf16_lds_bytes(nsplit(), dp / 4, 8) > 160 * 1024) return false;
-    return true;
-  }
+  // generation type actually used by the resident posterior
+  bool gen_double() const { return !kFloatPredict || !gen_eff32; }
+  // the split-bf16 kernel keeps its leaf fragments in LDS: with double generation they do not fit the
+  // 160 KB for D > 24 (bf16x6) / D > 36 (bf16x3) -- those calls run the native f32 kernel instead (accuracy
+  // decides the generation type, the kernel follows)
+  bool bf16_fits(bool gen64) const { return leaf_bf16_lds_bytes(nsplit(), dp / 4, gen64 ? 8 : 4) <= 160 * 1024; }
   int nsplit() const { return math == GPSO_MATH_BF16X6 ? 3 : 2; }
   bool bf16_usable() const { return kFloatPredict && math != GPSO_MATH_NATIVE && npad > 0 && npad % 256 == 0; }
 
@@ -316,16 +320,17 @@ struct EngineT : Engine {
         check = value != 0;
         return GPSO_OK;
       case GPSO_OPT_GENERATION:
-        if (value != GPSO_GEN_F64 && value != GPSO_GEN_F32) return ctx->fail(GPSO_E_ARG, "unknown generation mode %d", value);
+        if (value != GPSO_GEN_F64 && value != GPSO_GEN_F32 && value != GPSO_GEN_AUTO)
+          return ctx->fail(GPSO_E_ARG, "unknown generation mode %d", value);
         if (!kFloatPredict) {
           if (value == GPSO_GEN_F32) return ctx->fail(GPSO_E_ARG, "GPSO_GEN_F32 needs a float-predict context");
           return GPSO_OK;
         }
-        if ((value == GPSO_GEN_F32) != gen32) {
-          gen32 = value == GPSO_GEN_F32;
-          st_done = false;
-          if (have_post && have_data) return refresh_generation_inputs();
-          if (have_post) return ctx->fail(GPSO_E_STATE, "set GPSO_OPT_GENERATION before installing a posterior");
+        if (value != gen_mode) {
+          if (have_post && !have_data && value != GPSO_GEN_F64)
+            return ctx->fail(GPSO_E_STATE, "set GPSO_OPT_GENERATION before installing a posterior");
+          gen_mode = value;
+          reset_generation();
         }
         return GPSO_OK;
       case GPSO_OPT_PREDICT_MATH:
@@ -341,10 +346,10 @@ struct EngineT : Engine {
     math = value;
     linv_b_valid = false;
     st_done = false;
+    reset_generation();
     if (chol_valid) {  // L^-1 is resident: make the new mode usable right away
       int rc = pack_bf16();
       if (rc) return rc;
-      if (have_data) return refresh_generation_inputs();
     }
     return GPSO_OK;
   }
@@ -477,12 +482,22 @@ struct EngineT : Engine {
   int scale_inputs() {
     launch_scale_x<double>(st(), as<double>(x64), n, npad, d, dp, ls_dev(), as<double>(xs64), as<double>(xnorm64),
                            as<double>(xs_p64));
-    return refresh_generation_inputs();
+    return GPSO_OK;
   }
-  int refresh_generation_inputs() {
-    if (!gen_double())
-      launch_scale_x<float>(st(), as<double>(x64), n, npad, d, dp, ls_dev(), as<float>(xs32), as<float>(xnorm32),
-                            as<float>(xs_p32));
+  // a new posterior (or new options): generation starts over -- float unless double was asked for -- and the
+  // self-test has to rule again
+  void reset_generation() {
+    gen_eff32 = kFloatPredict && gen_mode != GPSO_GEN_F64;
+    gen_decided = false;
+    gen32_inputs_ok = false;
+    st_done = false;
+  }
+  // float copies of the scaled inputs, made when a float-generation predict first needs them, from the
+  // double ones (resident after a fit AND after a hand-off): two short launches, not two per loss evaluation
+  int ensure_generation_inputs() {
+    if (gen_double() || gen32_inputs_ok) return GPSO_OK;
+    launch_gen_inputs_f32(st(), as<double>(xs64), npad, dp, as<float>(xs32), as<float>(xnorm32), as<float>(xs_p32));
+    gen32_inputs_ok = true;
     return GPSO_OK;
   }
 
@@ -520,6 +535,7 @@ struct EngineT : Engine {
     if ((rc = set_theta(kernel, ls, n_ls_, variance, noise, mean_c))) return rc;
     have_post = have_kinv = chol_valid = false;
     st_done = st_have = false;
+    reset_generation();
     hipStream_t s = st();
     HIPCHECK(hipEventRecord(ctx->ev[4], s));
     if (grad && (rc = ensure(kinvb, (size_t)npad * npad * sizeof(TF)))) return rc;
@@ -534,7 +550,6 @@ struct EngineT : Engine {
       a.white = white.p; a.alpha_f = alpha_f.p; a.alpha_p = alpha.p; a.linv_p = linv_p.p;
       a.diag64 = as<double>(logdet); a.kinv_diag = as<double>(kinv_diag); a.scal = as<double>(scal);
       if ((rc = launch_small_fit<TF, TP>(s, a))) return launch_status();
-      if ((rc = refresh_generation_inputs())) return rc;
     } else {
       if ((rc = scale_inputs())) return rc;
       launch_gram<TF>(s, as<double>(xs64), as<double>(xnorm64), n, npad, dp, kp, as<TF>(K));
@@ -597,6 +612,7 @@ struct EngineT : Engine {
     have_data = false;  // y unknown: a later fit needs gpso_set_data
     have_post = have_kinv = chol_valid = false;
     st_done = st_have = false;
+    reset_generation();
     if ((rc = scale_inputs())) return rc;
     HIPCHECK(hipMemsetAsync(linv.p, 0, (size_t)npad * npad * sizeof(TF), s));
     launch_install_chol<TF>(s, tmp, n, npad, as<TF>(Lf), as<TF>(linv));
@@ -620,7 +636,7 @@ struct EngineT : Engine {
                      double* mean_dev, double* var_dev, double* ucb_dev, const int64_t* m_live) {
     // row blocks of L^-1 = partial sums per leaf: the split-bf16 kernel always works on 256-row blocks,
     // the native kernels on the shape leaf_tiles_bm picks
-    const bool use_bf16 = bf16_usable() && linv_b_valid;
+    const bool use_bf16 = bf16_usable() && linv_b_valid && bf16_fits(sizeof(TG) == 8);
     const int nbi = use_bf16 ? (int)(npad / 256) : leaf_tiles_nbi<TP>(npad, dp / 4);
     const int64_t chunk = std::min<int64_t>(m, kLeafChunk);
     const int64_t cpad = (chunk + kLeafPad - 1) / kLeafPad * kLeafPad;
@@ -686,7 +702,11 @@ struct EngineT : Engine {
   int score_device_leaves(const void* xs_dev, int xs_dtype, int64_t m, double varsigma, bool want_ucb,
                           double* mean_dev, double* var_dev, double* ucb_dev, const int64_t* m_live = nullptr) {
     if constexpr (kFloatPredict) {
-      if (!gen_double()) return score_leaves_t<float>(xs_dev, xs_dtype, m, varsigma, want_ucb, mean_dev, var_dev, ucb_dev, m_live);
+      if (!gen_double()) {
+        int rc = ensure_generation_inputs();
+        if (rc) return rc;
+        return score_leaves_t<float>(xs_dev, xs_dtype, m, varsigma, want_ucb, mean_dev, var_dev, ucb_dev, m_live);
+      }
     }
     return score_leaves_t<double>(xs_dev, xs_dtype, m, varsigma, want_ucb, mean_dev, var_dev, ucb_dev, m_live);
   }
@@ -714,11 +734,16 @@ struct EngineT : Engine {
   double amplification() const {
     return sizeof(TF) == 4 ? std::max(1.0, std::sqrt(kp.variance * st_vals[5])) : 1.0;
   }
-  bool st_pass() const {
+  // margin > 1: the readings must sit that far INSIDE the tolerances
+  bool st_pass(double margin = 1.0) const {
     const bool finite = std::isfinite(st_vals[0]) && std::isfinite(st_vals[1]) && std::isfinite(st_vals[3]);
     const double amp = amplification();  // var: w^T E w ~ |w|^2; mean: w^T E alpha ~ |w|
-    return finite && st_vals[0] * std::sqrt(amp) <= tol_mean_abs() && st_vals[1] * amp <= tol_var_abs();
+    return finite && margin * st_vals[0] * std::sqrt(amp) <= tol_mean_abs() && margin * st_vals[1] * amp <= tol_var_abs();
   }
+  // GPSO_GEN_AUTO keeps float generation only when it is comfortably inside the tolerances: double
+  // generation is typically 1e-6-class, and a posterior that float generation brings within a factor of
+  // a few of the gate is better served by it
+  static constexpr double kAutoMargin = 8.0;
   int run_selftest() {
     if (st_done) return GPSO_OK;
     if (!st_have || !have_data) return ctx->fail(GPSO_E_STATE, "self-test needs a posterior fitted on this context (gpso_fit_eval)");
@@ -738,11 +763,59 @@ struct EngineT : Engine {
     st_done = true;
     return GPSO_OK;
   }
-  // called at the top of every predict-type entry point
-  int precision_gate() {
-    if (!check || !st_have || !have_data) return GPSO_OK;  // posteriors installed from outside carry no targets
+  // GPSO_GEN_AUTO: let the self-test choose the generation arithmetic of this posterior.  Without a
+  // self-test (switched off, or a posterior installed from outside: no targets) the choice is double.
+  int decide_generation() {
+    if (!kFloatPredict || gen_decided) return GPSO_OK;
+    if (gen_mode != GPSO_GEN_AUTO) {
+      gen_decided = true;
+      return GPSO_OK;
+    }
+    // Matern-1/2 is exp(-sqrt(r^2)): near r = 0 the square root turns the 1e-6-class error of a float r^2
+    // into 1e-3 of k -- for leaves CLOSE to a training input, while AT the training inputs (where the
+    // self-test looks) the float form cancels exactly.  The test cannot see it, so this kernel generates
+    // in double.
+    const bool can_test = check && st_have && have_data && kp.kernel != GPSO_MATERN12;
+    if (!can_test) {
+      gen_eff32 = false;
+      st_done = false;
+      gen_decided = true;
+      return GPSO_OK;
+    }
     int rc = run_selftest();
     if (rc) return rc;
+    if (!st_pass(kAutoMargin) && gen_eff32) {
+      // not comfortably inside with float generation: measure double generation as well
+      double r32[6];
+      std::copy(st_vals, st_vals + 6, r32);
+      const bool pass32 = st_pass();
+      if (pass32 && bf16_usable() && linv_b_valid && !bf16_fits(true)) {
+        // the split-bf16 kernel the caller opted into cannot hold double fragments at this D: double
+        // generation would also mean the (slower) native kernel.  Inside the tolerances: stay.
+        gen_decided = true;
+        return GPSO_OK;
+      }
+      gen_eff32 = false;
+      st_done = false;
+      if ((rc = run_selftest())) return rc;
+      // the float form of r^2 is what fails at small lengthscales / noise -- then double is clearly
+      // better and stays.  Where the readings are the same within 1.5x the error is not the generation's
+      // (a float factor's, the apply's): float generation is as good and is kept.
+      const bool finite64 = std::isfinite(st_vals[0]) && std::isfinite(st_vals[1]);
+      if (pass32 && finite64 && r32[0] <= 1.5 * st_vals[0] && r32[1] <= 1.5 * st_vals[1]) {
+        gen_eff32 = true;
+        std::copy(r32, r32 + 6, st_vals);
+      }
+    }
+    gen_decided = true;
+    return GPSO_OK;
+  }
+  // called at the top of every predict-type entry point
+  int precision_gate() {
+    int rc = decide_generation();
+    if (rc) return rc;
+    if (!check || !st_have || !have_data) return GPSO_OK;  // posteriors installed from outside carry no targets
+    if ((rc = run_selftest())) return rc;
     if (!st_pass())
       return ctx->fail(GPSO_E_PRECISION,
                        "float predict arithmetic fails the self-test on this posterior: at the training inputs "
@@ -755,14 +828,16 @@ struct EngineT : Engine {
   }
   int precision_info(double* out) override {
     if (!have_post) return ctx->fail(GPSO_E_STATE, "no posterior resident");
-    int rc = run_selftest();
+    int rc = decide_generation();
     if (rc) return rc;
+    if ((rc = run_selftest())) return rc;
     for (int i = 0; i < 5; ++i) out[i] = st_vals[i];
     out[5] = kp.variance;
     out[6] = tol_mean_abs();
     out[7] = tol_var_abs();
     out[8] = amplification();
     out[9] = st_vals[5];
+    out[10] = gen_double() ? 0.0 : 1.0;
     if (!st_pass()) return ctx->fail(GPSO_E_PRECISION, "self-test: max |d mean| %.3g (tol %.3g), max |d var| %.3g (tol %.3g), amplification %.3g",
                                      st_vals[0], out[6], st_vals[1], out[7], out[8]);
     return GPSO_OK;
@@ -1094,22 +1169,23 @@ struct EngineT : Engine {
     int64_t* hd = as<int64_t>(bhdr);
     int64_t* host = reinterpret_cast<int64_t*>(ctx->pinned_scratch(8));
     if (!host) return ctx->fail(GPSO_E_OOM, "pinned host scratch");
-    const int64_t my_opts = (int64_t)math | ((int64_t)(gen32 ? 1 : 0) << 8) | ((int64_t)ctx->dtype << 16);
+    const int64_t my_opts = (int64_t)math | ((int64_t)ctx->dtype << 16);
     int64_t ok = 1;
     if (is_root) {
-      if (!have_post) ok = 0;  // still take part in the collectives below: every rank must leave together
+      // still take part in the collectives below when something is wrong: every rank must leave together
+      if (!have_post || decide_generation() != GPSO_OK) ok = 0;
       host[0] = n; host[1] = d; host[2] = my_opts; host[3] = ok;
-      HIPCHECK(hipMemcpyAsync(hd, host, 32, hipMemcpyHostToDevice, s));
+      HIPCHECK(hipMemcpyAsync(hd, host, 48, hipMemcpyHostToDevice, s));
     }
-    RCCLCHECK(R.Broadcast(hd, hd, 32, ncclChar, root, ctx->comm, s));
-    HIPCHECK(hipMemcpyAsync(host, hd, 32, hipMemcpyDeviceToHost, s));
+    RCCLCHECK(R.Broadcast(hd, hd, 48, ncclChar, root, ctx->comm, s));
+    HIPCHECK(hipMemcpyAsync(host, hd, 48, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
     const int64_t rn = host[0], rd = host[1], ropts = host[2];
     ok = host[3];
-    const char* why = ok ? nullptr : "the root has no posterior resident";
+    const char* why = ok ? nullptr : "the root has no usable posterior resident";
     if (ok && ropts != my_opts) {
       ok = 0;
-      why = "dtype / predict math / generation options differ from the root's";
+      why = "dtype / predict math options differ from the root's";
     }
     // agree: min over the ranks of `ok` (slot 4 of the header block)
     host[4] = ok;
@@ -1174,24 +1250,34 @@ struct EngineT : Engine {
     return GPSO_OK;
   }
 
+  // hyper | packed L^-1 | scaled inputs (double: plain, MFMA fragments, norms) | alpha [| bf16 pieces].
+  // The generation inputs always travel in double; a receiver derives the float copies itself when the
+  // sender's choice (slot 7 of the hyper block, written here) is float generation.
   int posterior_buffers(void** ptrs, int64_t* nbytes, int cap) override {
     if (npad == 0) return ctx->fail(GPSO_E_STATE, "no problem shape yet");
-    if (cap < 5) return ctx->fail(GPSO_E_ARG, "need room for 5 buffers");
+    if (cap < 7) return ctx->fail(GPSO_E_ARG, "need room for 7 buffers");
+    if (have_post) {
+      int rc = decide_generation();
+      if (rc) return rc;
+      double* flag = ctx->pinned_scratch(256) + 120;  // (a slot neither the read-backs nor set_theta use)
+      *flag = gen_double() ? 0.0 : 1.0;
+      HIPCHECK(hipMemcpyAsync(as<double>(hyper) + 7, flag, 8, hipMemcpyHostToDevice, st()));
+      HIPCHECK(hipStreamSynchronize(st()));  // callers copy these buffers on streams of their own
+    }
     const size_t s = sizeof(TP);
-    const bool g64 = gen_double();
-    ptrs[0] = hyper.p;  nbytes[0] = (int64_t)(kHyperHeader + kMaxD) * 8;
-    ptrs[1] = linv_p.p; nbytes[1] = (int64_t)(packed_linv_elems(npad) * s);
-    ptrs[2] = g64 ? xs_p64.p : xs_p32.p;   nbytes[2] = (int64_t)(npad * dp * (g64 ? 8 : 4));
-    ptrs[3] = g64 ? xnorm64.p : xnorm32.p; nbytes[3] = (int64_t)(npad * (g64 ? 8 : 4));
-    ptrs[4] = alpha.p;  nbytes[4] = (int64_t)(npad * s);
+    int k = 0;
+    ptrs[k] = hyper.p;   nbytes[k++] = (int64_t)(kHyperHeader + kMaxD) * 8;
+    ptrs[k] = linv_p.p;  nbytes[k++] = (int64_t)(packed_linv_elems(npad) * s);
+    ptrs[k] = xs64.p;    nbytes[k++] = (int64_t)(npad * dp * 8);
+    ptrs[k] = xs_p64.p;  nbytes[k++] = (int64_t)(npad * dp * 8);
+    ptrs[k] = xnorm64.p; nbytes[k++] = (int64_t)(npad * 8);
+    ptrs[k] = alpha.p;   nbytes[k++] = (int64_t)(npad * s);
     if (bf16_usable()) {
-      if (cap < 6) return ctx->fail(GPSO_E_ARG, "need room for 6 buffers");
       int rc = ensure(linv_b, (size_t)nsplit() * npad * npad * 2);
       if (rc) return rc;
-      ptrs[5] = linv_b.p; nbytes[5] = (int64_t)nsplit() * npad * npad * 2;
-      return 6;
+      ptrs[k] = linv_b.p; nbytes[k++] = (int64_t)nsplit() * npad * npad * 2;
     }
-    return 5;
+    return k;
   }
 
   int alloc_posterior(int64_t n_, int d_) override {
@@ -1221,6 +1307,10 @@ struct EngineT : Engine {
     chol_valid = have_kinv = false;
     st_done = st_have = false;     // the fitting rank ran the self-test; no targets here
     linv_b_valid = bf16_usable();  // the bf16 pieces travel with the posterior when the mode is on
+    // generation arithmetic: the sender's choice (its self-test ruled), unless this context insists
+    gen_eff32 = kFloatPredict && (gen_mode == GPSO_GEN_F32 || (gen_mode == GPSO_GEN_AUTO && h[7] == 1.0));
+    gen_decided = true;
+    gen32_inputs_ok = false;
     return GPSO_OK;
   }
 };

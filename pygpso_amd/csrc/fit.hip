@@ -69,6 +69,31 @@ void launch_scale_x(hipStream_t st, const double* x64, int64_t n, int64_t npad, 
     hipLaunchKernelGGL((pack_xs_kernel<T>), dim3((unsigned)((npad * dp + 255) / 256)), dim3(256), 0,
                        st, xs, npad, dp, xs_p);
 }
+// float copies of the (double) scaled inputs for float generation of the cross-Gram tile: exactly what
+// scale_x_kernel<float> computes from the raw inputs -- (float)(x / l) is the rounding of the double
+// quotient xs64 holds, the norm is accumulated in float in the same order -- without needing the raw
+// inputs (a rank that RECEIVED the posterior only has the scaled ones)
+__global__ __launch_bounds__(256) void gen_inputs_f32_kernel(const double* __restrict__ xs64, int64_t npad,
+                                                             int dp, float* __restrict__ xs,
+                                                             float* __restrict__ xnorm) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npad) return;
+  float acc = 0;
+  for (int k = 0; k < dp; ++k) {
+    const float v = (float)xs64[i * dp + k];
+    xs[i * dp + k] = v;
+    acc += v * v;
+  }
+  xnorm[i] = acc;
+}
+
+void launch_gen_inputs_f32(hipStream_t st, const double* xs64, int64_t npad, int dp, float* xs, float* xnorm,
+                           float* xs_p) {
+  hipLaunchKernelGGL(gen_inputs_f32_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, st, xs64, npad,
+                     dp, xs, xnorm);
+  hipLaunchKernelGGL((pack_xs_kernel<float>), dim3((unsigned)((npad * dp + 255) / 256)), dim3(256), 0, st, xs,
+                     npad, dp, xs_p);
+}
 template void launch_scale_x<float>(hipStream_t, const double*, int64_t, int64_t, int, int, const double*, float*, float*, float*);
 template void launch_scale_x<double>(hipStream_t, const double*, int64_t, int64_t, int, int, const double*, double*, double*, double*);
 

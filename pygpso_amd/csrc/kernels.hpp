@@ -74,6 +74,9 @@ constexpr size_t kArgmaxPartialBytes = 16;  // sizeof(Best)
 template <typename T>
 void launch_scale_x(hipStream_t st, const double* x64, int64_t n, int64_t npad, int d, int dp,
                     const double* ls, T* xs, T* xnorm, T* xs_p);
+// float generation inputs (xs, xnorm, fragment packing) derived from the double scaled inputs
+void launch_gen_inputs_f32(hipStream_t st, const double* xs64, int64_t npad, int dp, float* xs, float* xnorm,
+                           float* xs_p);
 // K = k(X, X) + noise * I on rows < n (lower 64x64 tiles only); identity on the padding.  r^2 is
 // always formed in double from the double scaled inputs.
 template <typename T>

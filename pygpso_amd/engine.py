@@ -40,8 +40,9 @@ class HipGPEngine:
         hyper-parameter path is bit-identical to float64).
         ``predict_math`` (float-predict engines only): "native" f32 MFMA, or the split-bf16 modes
         "bf16x6" (f32-class accuracy) / "bf16x3" (|d var| ~ 2e-5 sigma^2) on the bf16 matrix cores.
-        ``generation`` (float-predict engines): "float64" (default; r^2 of the cross-Gram tile formed
-        in double) or "float32" (GPflow's GEMM form in float: faster, |d r^2| ~ 1e-5).
+        ``generation`` (float-predict engines): "auto" (default: float when the posterior's self-test
+        passes with it, else double), "float64" (r^2 of the cross-Gram tile formed in double) or
+        "float32" (GPflow's GEMM form in float: faster, |d r^2| ~ 1e-5).
         ``precision_check`` / ``tol_var`` / ``tol_mean``: the self-test that guards float predictions
         (include/gpso_hip.h: gpso_precision_info); on by default for float-predict engines."""
         self._lib = L.load()
@@ -97,7 +98,7 @@ class HipGPEngine:
         self._check(self._lib.gpso_set_option(self._h, L.OPT_PREDICT_MATH, L.MATH_IDS[mode]))
 
     def set_generation(self, mode):
-        """"float64" (default) | "float32": arithmetic of the cross-Gram x.x* contraction and r^2."""
+        """"auto" (default) | "float64" | "float32": arithmetic of the cross-Gram x.x* contraction and r^2."""
         self._check(self._lib.gpso_set_option(self._h, L.OPT_GENERATION, L.GEN_IDS[mode]))
 
     def set_precision_check(self, on):
@@ -113,13 +114,14 @@ class HipGPEngine:
     def precision_info(self, raise_on_fail=False):
         """Self-test of the resident posterior (runs it if needed): measured errors of the predict path
         at the training inputs against their closed form, and the tolerances they are held to."""
-        out = np.zeros(10, dtype=np.float64)
+        out = np.zeros(11, dtype=np.float64)
         rc = self._lib.gpso_precision_info(self._h, L.dptr(out))
         if rc not in (L.OK, L.E_PRECISION) or (rc == L.E_PRECISION and raise_on_fail):
             self._check(rc)
         keys = ("max_abs_err_mean", "max_abs_err_var", "max_abs_y_minus_c", "min_var", "max_abs_alpha",
                 "kernel_variance", "tol_mean_abs", "tol_var_abs", "amplification", "max_kinv_diag")
         info = dict(zip(keys, (float(v) for v in out)))
+        info["generation"] = "float32" if out[10] else "float64"
         info["passed"] = rc == L.OK
         return info
 

@@ -57,7 +57,7 @@ def test_posterior_handoff_carries_the_bf16_pieces():
 
     src = _fitted("float32", n=512, predict_math="bf16x6")
     dst = HipGPEngine("float32", predict_math="bf16x6")
-    assert _handoff(src, dst) == 6
+    assert _handoff(src, dst) == 7
     Xs = synthetic_leaves(1500, 5)
     assert all(np.array_equal(p, q) for p, q in zip(src.predict(Xs), dst.predict(Xs)))
 
@@ -69,7 +69,7 @@ def test_posterior_handoff_between_two_contexts(dtype):
 
     src = _fitted(dtype)
     dst = HipGPEngine(dtype)
-    assert _handoff(src, dst) == 5
+    assert _handoff(src, dst) == 6
     Xs = synthetic_leaves(2000, 5)
     m1, v1 = src.predict(Xs)
     m2, v2 = dst.predict(Xs)
@@ -81,7 +81,7 @@ def test_the_packed_posterior_holds_lower_tiles_only():
     """L^-1 travels as its lower 16x16 tiles (N_pad/16 (N_pad/16 + 1) / 2 of them): about half of the
     square round 1 broadcast."""
     eng = _fitted("float32", n=2048)
-    sizes = dict(zip(("hyper", "linv_p", "xs_p", "xnorm", "alpha"), (nb for _, nb in eng.posterior_buffers())))
+    sizes = dict(zip(("hyper", "linv_p", "xs", "xs_p", "xnorm", "alpha"), (nb for _, nb in eng.posterior_buffers())))
     t = eng.padded_n // 16
     assert sizes["linv_p"] == t * (t + 1) // 2 * 256 * 4 < 0.51 * eng.padded_n ** 2 * 4 + 16 * eng.padded_n * 4
 
