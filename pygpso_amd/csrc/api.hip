@@ -258,6 +258,7 @@ struct EngineT : Engine {
   bool gen32_inputs_ok = false; // xs32 / xnorm32 / xs_p32 match the resident posterior
   int64_t single_level_max = -1;  // < 0: library default
   bool fused_small = true;        // GPSO_OPT_FIT_FUSED_SMALL
+  int small_tile_rows = 8;        // tile rows of the 128-padded linv_p that may be non-zero (8: all / unknown)
   bool linv_b_valid = false;
   std::vector<int64_t> segoff_cache;  // what the device copy of seg_off currently holds
   // predict workspace
@@ -427,6 +428,7 @@ struct EngineT : Engine {
       if ((rc = ensure(xnorm32, (size_t)npad * 4))) return rc;
       if ((rc = ensure(xs_p32, (size_t)npad * dp * 4))) return rc;
     }
+    if (linv_p.bytes < packed_linv_elems(npad) * sizeof(TP)) small_tile_rows = 8;  // fresh memory
     if ((rc = ensure(linv_p, packed_linv_elems(npad) * sizeof(TP)))) return rc;
     if ((rc = ensure(alpha, (size_t)npad * sizeof(TP)))) return rc;
     return GPSO_OK;
@@ -544,6 +546,8 @@ struct EngineT : Engine {
       SmallFitArgs a{};
       a.x64 = as<double>(x64); a.y64 = as<double>(y64); a.ls = ls_dev();
       a.n = (int)n; a.d = d; a.dp = dp; a.kernel = kernel; a.n_ls = n_ls; a.want_grad = grad ? 1 : 0;
+      a.zero_tile_rows = small_tile_rows;  // (tile rows of linv_p beyond this fit's that may hold old data)
+      small_tile_rows = (int)((n + 15) / 16);
       a.variance = variance; a.noise = noise; a.mean_c = mean_c;
       a.xs64 = as<double>(xs64); a.xnorm64 = as<double>(xnorm64); a.xs_p64 = as<double>(xs_p64);
       a.Lf = Lf.p; a.linv = linv.p; a.kinv = grad ? kinvb.p : nullptr;
@@ -570,6 +574,7 @@ struct EngineT : Engine {
                             as<double>(scal) + 8);
       launch_pack_linv<TF, TP>(s, as<TF>(linv), n, npad, as<TP>(linv_p));
       launch_convert_vec<TF, TP>(s, as<TF>(alpha_f), as<TP>(alpha), npad);
+      small_tile_rows = 8;
     }
     if ((rc = pack_bf16())) return rc;
     if ((rc = launch_status())) return rc;
@@ -621,6 +626,7 @@ struct EngineT : Engine {
     launch_convert_in<TF>(s, tmp + (size_t)n * n, as<TF>(alpha_f), 1, n, npad);
     launch_pack_linv<TF, TP>(s, as<TF>(linv), n, npad, as<TP>(linv_p));
     launch_convert_vec<TF, TP>(s, as<TF>(alpha_f), as<TP>(alpha), npad);
+    small_tile_rows = 8;
     if ((rc = pack_bf16())) return rc;
     HIPCHECK(hipStreamSynchronize(s));  // the caller's host buffers are free again on return
     if ((rc = launch_status())) return rc;
@@ -1305,6 +1311,7 @@ struct EngineT : Engine {
     ls_host.assign(h + kHyperHeader, h + kHyperHeader + n_ls);
     have_post = true;
     chol_valid = have_kinv = false;
+    small_tile_rows = 8;           // linv_p came from elsewhere
     st_done = st_have = false;     // the fitting rank ran the self-test; no targets here
     linv_b_valid = bf16_usable();  // the bf16 pieces travel with the posterior when the mode is on
     // generation arithmetic: the sender's choice (its self-test ruled), unless this context insists

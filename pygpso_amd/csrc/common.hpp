@@ -213,6 +213,36 @@ __device__ __forceinline__ void kern_and_dkern_lean(int kernel, double r2_k, dou
   }
 }
 
+// k and dk/d(r^2) at ONE squared distance (one sqrt, one exp): for callers whose r^2 is free of
+// cancellation (direct differences), where evaluating k at the GEMM-form r^2 instead would change it by
+// ~1e-15 relative at most
+__device__ __forceinline__ void kern_and_dkern_same(int kernel, double r2, double variance, double& k, double& dk) {
+  if (kernel == 3) {
+    const double e = variance * exp_lean(-0.5 * r2);
+    k = e;
+    dk = -0.5 * e;
+    return;
+  }
+  const double r = sqrt_lean(fmax(r2, 1e-36));
+  if (kernel == 0) {
+    const double s5 = 2.23606797749978969641;
+    const double e = variance * exp_lean(-s5 * r);
+    k = (1.0 + s5 * r + (5.0 / 3.0) * (r * r)) * e;
+    dk = -(5.0 / 6.0) * (1.0 + s5 * r) * e;
+  } else if (kernel == 1) {
+    const double s3 = 1.73205080756887729353;
+    const double e = variance * exp_lean(-s3 * r);
+    k = (1.0 + s3 * r) * e;
+    dk = -1.5 * e;
+  } else {
+    double mr = -r;
+    asm volatile("" : "+v"(mr));  // (see kern_from_r2_lean: keeps the negation out of a mis-folding merge)
+    const double e = variance * exp_lean(mr);
+    k = e;
+    dk = -0.5 * e / r;
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

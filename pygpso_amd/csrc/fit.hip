@@ -218,6 +218,21 @@ __device__ __forceinline__ f64x4 mma16_lds(const double* Ab, int sai, int sak, c
   return acc;
 }
 
+// the same, accumulated onto acc
+template <int K>
+__device__ __forceinline__ f64x4 mma16_lds_acc(f64x4 acc, const double* Ab, int sai, int sak, const double* Bb,
+                                               int sbk, int sbj, int lane) {
+  double a[K / 4], b[K / 4];
+#pragma unroll
+  for (int s = 0; s < K / 4; ++s) {
+    a[s] = Ab[(lane & 15) * sai + (4 * s + (lane >> 4)) * sak];
+    b[s] = Bb[(4 * s + (lane >> 4)) * sbk + (lane & 15) * sbj];
+  }
+#pragma unroll
+  for (int s = 0; s < K / 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
+  return acc;
+}
+
 // value of lane (16 * (lane / 16) + N) for every lane: 64-bit DPP row_newbcast, one v_mov_b64_dpp
 template <int N>
 __device__ __forceinline__ double row_bcast_f64(double x) {
@@ -1656,6 +1671,9 @@ template void launch_gradient<double>(hipStream_t, const double*, const double*,
 //     L10 = K10 X00^T ;  S = K11 - L10 L10^T = L11 L11^T ;  X11 = L11^-1 ;  X10 = -X11 (L10 X00)
 // The 64-pivot chains (chol64_lds / trinv64_lds, shared with the general path) are what is left on
 // the critical path: ~15 us each.
+#ifndef GPSO_SSTAMP
+#define GPSO_SSTAMP(i)  // tools/micro/small_phases.hip defines this to record s_memtime stamps
+#endif
 constexpr int kSmallN = 128;
 constexpr int kBlk = kFitBlock * kDS;  // doubles per 64x64 LDS block
 constexpr int kSmallLdsDoubles = 4 * kBlk + kTsDoubles + 6 * kSmallN + 4 * (kGradMaxLs + 2) + 16;
@@ -1666,6 +1684,8 @@ constexpr int kSmallLdsBytes = kSmallLdsDoubles * 8;
 __device__ __forceinline__ void small_gram_block(const double* xs, const double* nrm, int dp, int bi, int bj,
                                                  int n, int kernel, double variance, double noise,
                                                  double* blk, int wave, int lane) {
+  // (a diagonal block is only read on and below its diagonal: column tiles t <= wave)
+  const int tmax = (bi == bj) ? wave : 3;
   f64x4 s[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) s[t] = f64x4{0, 0, 0, 0};
@@ -1674,6 +1694,7 @@ __device__ __forceinline__ void small_gram_block(const double* xs, const double*
     const double a = xs[(i0 + (lane & 15)) * dp + 4 * c + (lane >> 4)];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
+      if (t > tmax) continue;
       const double b = xs[(j0 + 16 * t + (lane & 15)) * dp + 4 * c + (lane >> 4)];
       s[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, s[t], 0, 0, 0);
     }
@@ -1682,6 +1703,7 @@ __device__ __forceinline__ void small_gram_block(const double* xs, const double*
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+      if (t > tmax) continue;
       const int ii = 16 * wave + (lane >> 4) + 4 * r, jj = 16 * t + (lane & 15);
       const int i = 64 * bi + ii, j = 64 * bj + jj;
       double v;
@@ -1735,6 +1757,7 @@ __global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs g) {
   T* linv = static_cast<T*>(g.linv);
   constexpr int64_t ld = kSmallN;
 
+  GPSO_SSTAMP(0);
   // ---- 0. scaled inputs: LDS (in B, free until X00 is formed) + the global copies the predict path reads
   double* xs = B;
   if (tid == 0) *info = INT_MAX;
@@ -1763,6 +1786,7 @@ __global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs g) {
     }
   }
   __syncthreads();
+  GPSO_SSTAMP(1);
   // ---- 1. Gram blocks: K00 -> A, K10 -> C, K11 -> D4
   small_gram_block(xs, nrm, dp, 0, 0, n, g.kernel, g.variance, g.noise, A, wave, lane);
   if (nb == 2) {
@@ -1773,9 +1797,12 @@ __global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs g) {
   for (int e = tid; e < kBlk; e += 256) B[e] = 0.0;  // X00 is written on and below the diagonal only
   __syncthreads();
   // ---- 2. K00 = L00 L00^T, X00 = L00^-1 (B)
+  GPSO_SSTAMP(2);
   chol64_lds<2, T>(A, B, Lf, ld, 0, n, info);
   if (tid < kFitBlock) dg[tid] = A[tid * kDS + tid];
+  GPSO_SSTAMP(3);
   trinv64_lds<true, T>(A, B, Ts, Lf, ld);
+  GPSO_SSTAMP(4);
   if (nb == 2) {
     // ---- 3. L10 = K10 X00^T -> C (and Lf[1][0])
     f64x4 v[4];
@@ -1802,9 +1829,12 @@ __global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs g) {
     }
     __syncthreads();
     // ---- 5. S = L11 L11^T, X11 = L11^-1 (A)
+    GPSO_SSTAMP(5);
     chol64_lds<2, T>(D4, A, Lf + 64 * ld + 64, ld, 64, n, info);
     if (tid < kFitBlock) dg[64 + tid] = D4[tid * kDS + tid];
+    GPSO_SSTAMP(6);
     trinv64_lds<true, T>(D4, A, Ts, Lf + 64 * ld + 64, ld);
+    GPSO_SSTAMP(7);
     // ---- 6. X10 = -X11 (L10 X00) -> C
     small_mm_strip(C, B, kDS, 1, wave, lane, v);  // W = L10 X00
     __syncthreads();
@@ -1817,21 +1847,31 @@ __global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs g) {
     dg[64 + tid] = 1.0;
   }
   __syncthreads();
-  // element (row, col) of X = L^-1 (zeros above the diagonal are real zeros in LDS)
-  auto Xat = [&](int row, int col) -> double {
-    if (row < 64) return (col < 64) ? B[row * kDS + col] : 0.0;
-    if (nb == 1) return (row == col) ? 1.0 : 0.0;
-    return (col < 64) ? C[(row - 64) * kDS + col] : A[(row - 64) * kDS + col - 64];
-  };
-  // ---- 7. L^-1 to global (full 128 x 128, identity on the padding) + the predict kernels' tile packing
-  for (int e = tid; e < kSmallN * kSmallN; e += 256) {
-    const int r = e >> 7, c = e & 127;
-    linv[e] = (T)((c <= r) ? Xat(r, c) : 0.0);
+  GPSO_SSTAMP(8);
+  // X = L^-1 lives in LDS as 64x64 blocks (zeros above the diagonal are real zeros): X00 = B, and for
+  // nb == 2 X10 = C, X11 = A.  Block (rb, cb) of X, or nullptr for the zero block (0, 1):
+  auto Xblk = [&](int rb, int cb) -> const double* { return rb == 0 ? (cb == 0 ? B : nullptr) : (cb == 0 ? C : A); };
+  // ---- 7. L^-1 to global: the lower triangle of rows < 64 nb (all any later reader looks at: the bf16
+  //         packing and the debug getters read on / below the diagonal, rows < n) + the predict
+  //         kernels' tile packing (every tile row of the 128-padded problem: rows >= n are zero)
+  lower_tile_to_global<T>(B, linv, ld, tid);
+  if (nb == 2) {
+    lower_tile_to_global<T>(A, linv + 64 * ld + 64, ld, tid);
+    for (int e = tid; e < 64 * 16; e += 256) {  // X10: the full block, 16-byte stores
+      using vec4 = typename Mfma<T>::vec4;
+      const int r = e >> 4, c = 4 * (e & 15);
+      vec4 v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = (T)C[r * kDS + c + q];
+      *reinterpret_cast<vec4*>(linv + (int64_t)(64 + r) * ld + c) = v;
+    }
   }
   {
     using vecP = typename Mfma<TP>::vec4;
     vecP* out = static_cast<vecP*>(g.linv_p);
-    for (int idx = tid; idx < 36 * 64; idx += 256) {  // 8 * 9 / 2 lower tiles of 16 x 16
+    const int nrt = (n + 15) / 16;                       // tile rows that hold data
+    const int nzt = max(nrt, min(g.zero_tile_rows, 8));  // ... and those a previous fit may have left non-zero
+    for (int idx = tid; idx < nzt * (nzt + 1) / 2 * 64; idx += 256) {
       const int l = idx & 63, tile = idx >> 6;
       int rt = 0, kt = tile;
       while (kt > rt) {
@@ -1840,46 +1880,57 @@ __global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs g) {
       }
       const int row = rt * 16 + (l & 15), col = kt * 16 + 4 * (l >> 4);
       vecP v{0, 0, 0, 0};
-      if (row < n) {
+      const double* blk = (row < rows) ? Xblk(row >> 6, col >> 6) : nullptr;
+      if (row < n && blk != nullptr) {
+        const double* src = blk + (row & 63) * kDS + (col & 63);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (col + r <= row && col + r < n) v[r] = (TP)Xat(row, col + r);
+          if (col + r <= row && col + r < n) v[r] = (TP)src[r];
       }
       out[idx] = v;
     }
   }
-  // ---- 8. a = X (y - c), alpha = X^T a, diag(K_y^-1), NLML
-  {
-    const int i = tid >> 1, h = tid & 1;  // two threads per row
-    double acc = 0.0;
-    if (i < rows)
-      for (int k = 64 * h; k < 64 * h + 64 && k <= i; ++k) acc = fma(Xat(i, k), resid[k], acc);
-    acc += __shfl_xor(acc, 1);
-    if (h == 0) wht[i] = (i < n) ? acc : 0.0;
-  }
-  __syncthreads();
-  {
-    const int j = tid >> 1, h = tid & 1;  // two threads per column
-    double acc = 0.0, sq = 0.0;
-    if (j < n)
-      for (int i = max(j, 64 * h); i < min(n, 64 * h + 64); ++i) {
-        const double x = Xat(i, j);
-        acc = fma(x, wht[i], acc);
-        sq = fma(x, x, sq);
-      }
-    acc += __shfl_xor(acc, 1);
-    sq += __shfl_xor(sq, 1);
-    if (h == 0) {
-      alp[j] = acc;
-      kd[j] = sq;
+  GPSO_SSTAMP(9);
+  // ---- 8. a = X (y - c), alpha = X^T a, diag(K_y^-1) = column norms of X, NLML -- on the MFMA: a vector
+  //         is fed as a B operand whose 16 columns are all that vector (column stride 0), the result is read
+  //         from column 0; X^T is X read with swapped strides.  (Rows >= n of X are unit rows and the
+  //         residual is zero there, so the padding drops out by itself.)
+  for (int b = 0; b < nb; ++b) {  // a[64 b + 16 wave + .]
+    f64x4 acc{0, 0, 0, 0};
+    for (int cb = 0; cb <= b; ++cb)
+      acc = mma16_lds_acc<64>(acc, Xblk(b, cb) + 16 * wave * kDS, kDS, 1, resid + 64 * cb, 1, 0, lane);
+    if ((lane & 15) == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wht[64 * b + 16 * wave + (lane >> 4) + 4 * r] = acc[r];
     }
+  }
+  if (nb == 1 && tid < 64) wht[64 + tid] = 0.0;
+  __syncthreads();
+  for (int b = 0; b < nb; ++b) {  // alpha[64 b + 16 wave + .] = sum over row blocks rb >= b of X[rb][b]^T a[rb]
+    f64x4 acc{0, 0, 0, 0}, sq{0, 0, 0, 0};
+    for (int rb = b; rb < nb; ++rb) {
+      const double* xb = Xblk(rb, b) + 16 * wave;  // column strip of the block
+      acc = mma16_lds_acc<64>(acc, xb, 1, kDS, wht + 64 * rb, 1, 0, lane);
+      sq = mma16_lds_acc<64>(sq, xb, 1, kDS, xb, kDS, 1, lane);  // 16x16 diagonal tile of X^T X
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = (lane >> 4) + 4 * r;
+      if ((lane & 15) == 0) alp[64 * b + 16 * wave + i] = acc[r];
+      if ((lane & 15) == i) kd[64 * b + 16 * wave + i] = sq[r];
+    }
+  }
+  if (nb == 1 && tid < 64) {
+    alp[64 + tid] = 0.0;
+    kd[64 + tid] = 1.0;
   }
   __syncthreads();
   if (tid < kSmallN) {
-    static_cast<T*>(g.white)[tid] = (T)wht[tid];
-    static_cast<T*>(g.alpha_f)[tid] = (T)alp[tid];
-    static_cast<TP*>(g.alpha_p)[tid] = (TP)alp[tid];
-    g.kinv_diag[tid] = kd[tid];
+    const bool live = tid < n;  // (padding rows: unit rows of X -- zero them like the general path does)
+    static_cast<T*>(g.white)[tid] = (T)(live ? wht[tid] : 0.0);
+    static_cast<T*>(g.alpha_f)[tid] = (T)(live ? alp[tid] : 0.0);
+    static_cast<TP*>(g.alpha_p)[tid] = (TP)(live ? alp[tid] : 0.0);
+    g.kinv_diag[tid] = live ? kd[tid] : 0.0;
     g.diag64[tid] = dg[tid];
   }
   {
@@ -1905,6 +1956,7 @@ __global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs g) {
     g.scal[0] = 0.5 * quad + ldet + 0.5 * (double)n * 1.83787706640934548356;  // log(2 pi)
     if (g.want_grad) g.scal[8 + g.n_ls + 2] = -((red[8] + red[9]) + (red[10] + red[11]));
   }
+  GPSO_SSTAMP(10);
   if (!g.want_grad) return;
   // ---- 9. K^-1 = X^T X tile by tile on the MFMA, consumed at once by the gradient reductions
   //         (W = (K^-1 - alpha alpha^T) / 2; sums of W o dK/dtheta over the lower triangle)
@@ -1918,64 +1970,62 @@ __global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs g) {
   __syncthreads();
   const int nt16 = (n + 15) / 16;
   T* kinv = static_cast<T*>(g.kinv);
+  double g_var = 0.0, g_noise = 0.0, g_iso = 0.0;  // per lane, over all tiles of this wave
   for (int t = wave; t < nt16 * (nt16 + 1) / 2; t += 4) {
     int ti = 0, tj = t;
     while (tj > ti) {
       tj -= ti + 1;
       ++ti;
     }
-    // K^-1[ti][tj] = sum_{k >= 16 ti} X[k][16 ti + i] X[k][16 tj + j]
+    // K^-1[ti][tj] = sum_{k >= 16 ti} X[k][16 ti + i] X[k][16 tj + j]: the part of the sum inside the row
+    // block of tile ti (k-steps of 16 from the tile's own rows on), then the whole row block below it
     f64x4 acc{0, 0, 0, 0};
-    for (int k0 = 16 * ti; k0 < rows; k0 += 16) {
-      double a[4], b[4];
+    {
+      const int bi = ti >> 2, bj = tj >> 2;  // column blocks of the two tiles (bj <= bi)
+      const double* xi = Xblk(bi, bi) + 16 * (ti & 3);
+      const double* xj = Xblk(bi, bj) + 16 * (tj & 3);
+      for (int kq = (ti & 3); kq < 4; ++kq)
+        acc = mma16_lds_acc<16>(acc, xi + 16 * kq * kDS, 1, kDS, xj + 16 * kq * kDS, kDS, 1, lane);
+      if (nb == 2 && bi == 0)
+        acc = mma16_lds_acc<64>(acc, C + 16 * (ti & 3), 1, kDS, C + 16 * (tj & 3), kDS, 1, lane);
+    }
+    // squared distances of this lane's four entries (rows i_r, column j) from direct differences: the
+    // column point is read once per dimension and shared by the four rows
+    double base[4], r2d[4] = {0.0, 0.0, 0.0, 0.0};
+    const int jcol = 16 * tj + (lane & 15), irow0 = 16 * ti + (lane >> 4);
+    for (int c = 0; c < dp; c += 4) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int k = k0 + 4 * q + (lane >> 4);
-        a[q] = Xat(k, 16 * ti + (lane & 15));
-        b[q] = Xat(k, 16 * tj + (lane & 15));
-      }
+        const double xj = xg[jcol * dp + c + q];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
+        for (int r = 0; r < 4; ++r) {
+          const double df = xg[(irow0 + 4 * r) * dp + c + q] - xj;
+          r2d[r] = fma(df, df, r2d[r]);
+        }
+      }
     }
-    double g_var = 0.0, g_noise = 0.0, g_iso = 0.0, base[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int i = 16 * ti + (lane >> 4) + 4 * r, j = 16 * tj + (lane & 15);
+      const int i = irow0 + 4 * r, j = jcol;
       base[r] = 0.0;
       if (kinv != nullptr && i < kSmallN) kinv[(int64_t)i * ld + j] = (T)acc[r];
       if (i >= n || j >= n || j > i) continue;
       const double w = (i == j) ? 1.0 : 2.0;
-      double s = 0.0, r2d = 0.0;
-      for (int k = 0; k < dp; ++k) {
-        s += xg[i * dp + k] * xg[j * dp + k];
-        const double df = xg[i * dp + k] - xg[j * dp + k];
-        r2d = fma(df, df, r2d);
-      }
-      const double r2 = -2.0 * s + (nrm[i] + nrm[j]);
       const double Wij = 0.5 * (acc[r] - alp[i] * alp[j]);
       double kv, dk;
-      kern_and_dkern_lean(g.kernel, r2, r2d, g.variance, kv, dk);
+      kern_and_dkern_same(g.kernel, r2d[r], g.variance, kv, dk);
       g_var += w * Wij * kv / g.variance;
       if (i == j) g_noise += Wij;
       base[r] = w * Wij * dk;
-      g_iso += base[r] * (-2.0 * r2d);
+      g_iso += base[r] * (-2.0 * r2d[r]);
     }
-    g_var = wave_sum(g_var);
-    g_noise = wave_sum(g_noise);
-    if (lane == 0) {
-      gacc[wave * (kGradMaxLs + 2) + g.n_ls] += g_var;
-      gacc[wave * (kGradMaxLs + 2) + g.n_ls + 1] += g_noise;
-    }
-    if (g.n_ls == 1) {
-      g_iso = wave_sum(g_iso);
-      if (lane == 0) gacc[wave * (kGradMaxLs + 2)] += g_iso;
-    } else {
+    if (g.n_ls > 1) {
       for (int dd = 0; dd < g.n_ls; ++dd) {
         double a2 = 0.0;
+        const double xj = xg[jcol * dp + dd];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int i = 16 * ti + (lane >> 4) + 4 * r, j = 16 * tj + (lane & 15);
-          const double df = (i < rows && j < rows) ? xg[i * dp + dd] - xg[j * dp + dd] : 0.0;
+          const double df = xg[(irow0 + 4 * r) * dp + dd] - xj;
           a2 += base[r] * (-2.0 * df * df);
         }
         a2 = wave_sum(a2);
@@ -1983,12 +2033,22 @@ __global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs g) {
       }
     }
   }
+  // the sums every kernel needs: one reduction per wave, after its last tile
+  g_var = wave_sum(g_var);
+  g_noise = wave_sum(g_noise);
+  g_iso = wave_sum(g_iso);
+  if (lane == 0) {
+    gacc[wave * (kGradMaxLs + 2) + g.n_ls] = g_var;
+    gacc[wave * (kGradMaxLs + 2) + g.n_ls + 1] = g_noise;
+    if (g.n_ls == 1) gacc[wave * (kGradMaxLs + 2)] = g_iso;
+  }
   __syncthreads();
   if (tid < H) {
     double v = (gacc[tid] + gacc[(kGradMaxLs + 2) + tid]) + (gacc[2 * (kGradMaxLs + 2) + tid] + gacc[3 * (kGradMaxLs + 2) + tid]);
     if (tid < g.n_ls) v /= g.ls[g.n_ls == 1 ? 0 : tid];
     g.scal[8 + tid] = v;
   }
+  GPSO_SSTAMP(11);
 }
 
 bool small_fit_eligible(int64_t n, int dp) { return n <= kSmallN && (n <= 64 || dp <= 32); }

@@ -124,6 +124,7 @@ struct SmallFitArgs {
   const double* y64;
   const double* ls;  // [dp] lengthscale per input dimension (device)
   int n, d, dp, kernel, n_ls, want_grad;
+  int zero_tile_rows;  // 16-row tile rows of linv_p an earlier fit may have left non-zero (8 = unknown)
   double variance, noise, mean_c;
   // outputs
   double* xs64;    // [128 * dp] scaled inputs
