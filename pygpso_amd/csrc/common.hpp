@@ -150,6 +150,44 @@ __device__ __forceinline__ double kern_from_scaled(double u, double variance) {
   return variance * e;
 }
 
+// The same map in three stages -- t = sqrt part, e = exponential, k = polynomial * e -- so that a hot loop
+// can place them apart (the wave issues in order: a dependent transcendental right behind its producer
+// stalls everything behind it, MFMAs included).  kern_stage3(t, kern_stage2(t), v) with t = kern_stage1(u)
+// is kern_from_scaled(u, v) operation for operation.
+template <int KERNEL>
+__device__ __forceinline__ float kern_stage1(float u) {
+  if (KERNEL == 3) return u;
+  return __builtin_amdgcn_sqrtf(fmaxf(u, (float)(KernScale<KERNEL>::C2 * 1e-36)));
+}
+template <int KERNEL>
+__device__ __forceinline__ float kern_stage2(float t) {
+  constexpr float kNegLog2e = -1.4426950408889634f;
+  if (KERNEL == 3) return __builtin_amdgcn_exp2f(t * (0.5f * kNegLog2e));
+  return __builtin_amdgcn_exp2f(t * kNegLog2e);
+}
+template <int KERNEL>
+__device__ __forceinline__ float kern_stage3(float t, float e, float variance) {
+  if (KERNEL == 0) return (variance * fmaf(t, fmaf(t, 1.0f / 3.0f, 1.0f), 1.0f)) * e;
+  if (KERNEL == 1) return (variance * (1.0f + t)) * e;
+  return variance * e;
+}
+template <int KERNEL>
+__device__ __forceinline__ double kern_stage1(double u) {
+  if (KERNEL == 3) return u;
+  return sqrt_lean(fmax(u, KernScale<KERNEL>::C2 * 1e-36));
+}
+template <int KERNEL>
+__device__ __forceinline__ double kern_stage2(double t) {
+  if (KERNEL == 3) return exp_lean(-0.5 * t);
+  return exp_lean(-t);
+}
+template <int KERNEL>
+__device__ __forceinline__ double kern_stage3(double t, double e, double variance) {
+  if (KERNEL == 0) return (variance * fma(t, fma(t, 1.0 / 3.0, 1.0), 1.0)) * e;
+  if (KERNEL == 1) return variance * (1.0 + t) * e;
+  return variance * e;
+}
+
 // d k / d(r^2) * variance-scaled, used by the gradient reductions
 __device__ __forceinline__ double dkern_dr2(int kernel, double r2, double variance) {
   if (kernel == 3) return -0.5 * variance * exp(-0.5 * r2);

@@ -146,6 +146,13 @@ __device__ __forceinline__ void leaf_v2_step(
   a[0] = L::frag(panel_b, lane);
   if (RT > 1) a[1] = L::frag(panel_b + FB, lane);
   // ---- apply k-tile kt, with the map of k-tile kt + 1 sliced between the MFMAs -----------------
+  // The map runs in three stages per entry (sqrt | exp | polynomial, common.hpp), the 3 E stage-ops dealt
+  // over the row tiles 1 .. RT-1 in stage-major order: an entry's stages are then E ops -- at least a row
+  // tile's MFMAs -- apart, and no transcendental waits on the instruction right in front of it (the wave
+  // issues in order: such a wait would hold back the MFMAs behind it as well).  Row tile 0 carries none:
+  // the generation MFMAs that produce s are still in flight there.
+  T mt[CT][4], me[CT][4];
+  constexpr int OPS = 3 * E;
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     if (rt + 2 < RT) a[(rt + 2) % 3] = L::frag(panel_b + (rt + 2) * FB, lane);
@@ -156,12 +163,22 @@ __device__ __forceinline__ void leaf_v2_step(
 #pragma unroll
         for (int t = 0; t < CT; ++t) acc[rt][t] = M::mma(a[rt % 3][r], p_cur[t][r], acc[rt][t]);
     }
+    constexpr int RS = (RT > 1) ? RT - 1 : 1;  // row tiles that carry stage-ops
+    const int slot = (RT > 1) ? rt - 1 : 0;
+    if (slot >= 0) {
 #pragma unroll
-    for (int e = rt * E / RT; e < (rt + 1) * E / RT; ++e) {
-      const int t = e >> 2, r = e & 3;
-      // u = C2 * r^2, GPflow's GEMM form r^2 = -2 x.x* + (|x|^2 + |x*|^2) combined in TG (norms
-      // pre-scaled by C2), rounded to T for the map
-      p_nxt[t][r] = kern_from_scaled<KERNEL>((T)fma_t((TG)(TG(-2) * C2), s[t][r], na[r] + nb[t]), variance);
+      for (int o = slot * OPS / RS; o < (slot + 1) * OPS / RS; ++o) {
+        const int stage = o / E, e = o % E, t = e >> 2, r = e & 3;
+        if (stage == 0) {
+          // u = C2 * r^2, GPflow's GEMM form r^2 = -2 x.x* + (|x|^2 + |x*|^2) combined in TG (norms
+          // pre-scaled by C2), rounded to T for the map
+          mt[t][r] = kern_stage1<KERNEL>((T)fma_t((TG)(TG(-2) * C2), s[t][r], na[r] + nb[t]));
+        } else if (stage == 1) {
+          me[t][r] = kern_stage2<KERNEL>(mt[t][r]);
+        } else {
+          p_nxt[t][r] = kern_stage3<KERNEL>(mt[t][r], me[t][r], variance);
+        }
+      }
     }
   }
   if (gen && gen_diag) {  // k-tile kt + 1 lies in the diagonal block: its share of k*.alpha
