@@ -124,16 +124,28 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ xs
   const int tj = (int)(blk - (int64_t)ti * (ti + 1) / 2);
   const int64_t i0 = (int64_t)ti * 64 + wave * 16;
   const int64_t j0 = (int64_t)tj * 64;
+  // the two 64-row panels of scaled inputs go through LDS (coalesced copy, odd row stride): fetched
+  // straight from global as MFMA fragments they are 8-byte accesses 8 dp bytes apart, five dependent
+  // loads per k-step -- at D = 40 that, not the stores, was the kernel's time
+  extern __shared__ __align__(16) double gram_lds[];
+  const int st = dp + 1;
+  double* pi = gram_lds;
+  double* pj = (ti == tj) ? pi : gram_lds + 64 * st;
+  for (int e = threadIdx.x; e < 64 * dp; e += 256) {
+    const int r = e / dp, k = e - r * dp;
+    pi[r * st + k] = xs[(int64_t)ti * 64 * dp + e];
+    if (ti != tj) pj[r * st + k] = xs[(int64_t)tj * 64 * dp + e];
+  }
+  __syncthreads();
   f64x4 s[4];
 #pragma unroll
   for (int x = 0; x < 4; ++x) s[x] = f64x4{0, 0, 0, 0};
+  const double* pa = pi + (wave * 16 + (lane & 15)) * st + (lane >> 4);
+  const double* pb = pj + (4 * (lane & 15)) * st + (lane >> 4);
   for (int c = 0; c < dp / 4; ++c) {
-    const double a = xs[(i0 + (lane & 15)) * dp + 4 * c + (lane >> 4)];
+    const double a = pa[4 * c];
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      const double b = xs[(j0 + 4 * (lane & 15) + x) * dp + 4 * c + (lane >> 4)];
-      s[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, s[x], 0, 0, 0);
-    }
+    for (int x = 0; x < 4; ++x) s[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, pb[x * st + 4 * c], s[x], 0, 0, 0);
   }
   const int64_t jc = j0 + 4 * (lane & 15);  // first of this lane's 4 columns
   double nbj[4];
@@ -164,8 +176,9 @@ template <typename T>
 void launch_gram(hipStream_t st, const double* xs, const double* xnorm, int64_t n, int64_t npad, int dp,
                  const KernParams& kp, T* K) {
   const int64_t nt = npad / 64;
-  hipLaunchKernelGGL((gram_kernel<T>), dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, st, xs, xnorm, n,
-                     npad, dp, kp.kernel, kp.variance, kp.noise, K);
+  hipLaunchKernelGGL((gram_kernel<T>), dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256),
+                     (size_t)2 * 64 * (dp + 1) * sizeof(double), st, xs, xnorm, n, npad, dp, kp.kernel, kp.variance,
+                     kp.noise, K);
 }
 template void launch_gram<float>(hipStream_t, const double*, const double*, int64_t, int64_t, int, const KernParams&, float*);
 template void launch_gram<double>(hipStream_t, const double*, const double*, int64_t, int64_t, int, const KernParams&, double*);
