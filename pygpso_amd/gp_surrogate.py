@@ -22,6 +22,8 @@ import logging
 import os
 from collections import namedtuple
 
+import math
+
 import numpy as np
 from scipy.special import erfcinv
 
@@ -52,14 +54,16 @@ class GPPoint(namedtuple("GPPoint", ["normed_coord", "score_mu", "score_sigma", 
     __hash__ = None
 
 
+_NONE = []
+
+
 class GPListOfPoints(list):
     """List of ``GPPoint`` whose ``append`` de-duplicates by coordinates.
 
     Same observable behaviour as the reference: a new point within 1e-12 (L2) of stored points
     replaces every such point that is not ``evaluated`` and is not appended; the constructor does
-    not de-duplicate.  The distance test runs vectorised over a coordinate matrix kept beside the
-    list.  ``append`` additionally RETURNS the index the point now lives at (first duplicate, or
-    the new last position)."""
+    not de-duplicate.  ``append`` additionally RETURNS the index the point now lives at (first
+    duplicate, or the new last position)."""
 
     # bucket width of the index on the first coordinate: any two points closer than the duplicate
     # tolerance (1e-12, L2) differ by at most that in coordinate 0, so a duplicate of x can only sit
@@ -69,88 +73,86 @@ class GPListOfPoints(list):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         assert all(isinstance(p, GPPoint) for p in self)
-        self._coords = None
-        self._n = 0
+        self._rows = []      # coordinates of self[i] as a tuple of Python floats
         self._dirty = True
-        self._buckets = {}
+        self._buckets = {}   # bucket of coordinate 0 -> indices (ascending)
 
-    # -- coordinate matrix kept in sync -----------------------------------------------------------
-    def _matrix(self):
-        if self._dirty or self._coords is None or self._n != len(self):
-            n = len(self)
-            if n:
-                d = int(np.size(self[0].normed_coord))
-                cap = max(64, 2 * n)
-                self._coords = np.empty((cap, d), dtype=np.float64)
-                for i, p in enumerate(self):
-                    self._coords[i] = p.normed_coord
-            else:
-                self._coords = None
-            self._n = n
-            self._dirty = False
+    # -- index kept in sync ------------------------------------------------------------------------
+    # (plain Python floats on purpose: a look-up touches one or two candidate rows of D numbers, and the
+    # fixed cost of any numpy call is larger than that whole computation)
+    def _index(self):
+        if self._dirty or len(self._rows) != len(self):
+            self._rows = [tuple(np.asarray(p.normed_coord, dtype=np.float64).reshape(-1).tolist()) for p in self]
             self._buckets = {}
-            for i in range(n):
-                self._buckets.setdefault(self._bucket_of(self._coords[i, 0]), []).append(i)
-        return None if self._coords is None else self._coords[: self._n]
+            for i, r in enumerate(self._rows):
+                self._buckets.setdefault(self._bucket_of(r[0]), []).append(i)
+            self._dirty = False
 
     @classmethod
     def _bucket_of(cls, c0):
-        return int(np.floor(float(c0) / cls._BUCKET))
+        return int(math.floor(float(c0) / cls._BUCKET))
 
     def _matches(self, coords):
         """Indices (ascending) of the stored points within the duplicate tolerance of ``coords`` --
         the reference's linear scan (gpso/gp_surrogate.py:68-101), answered from a hash on the first
         coordinate: candidates come from three buckets, the exact distance test decides."""
-        mat = self._matrix()
-        if mat is None:
-            return np.empty(0, dtype=np.int64)
-        c = np.asarray(coords, dtype=np.float64).reshape(-1)
+        self._index()
+        if not self._rows:
+            return []
+        c = np.asarray(coords, dtype=np.float64).reshape(-1).tolist()
         b = self._bucket_of(c[0])
-        cand = self._buckets.get(b - 1, []) + self._buckets.get(b, []) + self._buckets.get(b + 1, [])
+        get = self._buckets.get
+        cand = get(b - 1, _NONE) + get(b, _NONE) + get(b + 1, _NONE)
         if not cand:
-            return np.empty(0, dtype=np.int64)
-        idx = np.array(sorted(cand), dtype=np.int64)
-        diff = mat[idx] - c.reshape(1, -1)
-        dist = np.sqrt(np.einsum("ij,ij->i", diff, diff))
-        return idx[dist < DUPLICATE_TOLERANCE]
+            return []
+        if len(cand) > 1:
+            cand = sorted(cand)
+        rows, hits = self._rows, []
+        for i in cand:
+            d2 = 0.0
+            for a, x in zip(rows[i], c):
+                t = a - x
+                d2 += t * t
+            if math.sqrt(d2) < DUPLICATE_TOLERANCE:
+                hits.append(i)
+        return hits
 
     def __setitem__(self, idx, value):
         super().__setitem__(idx, value)
-        if isinstance(idx, int) and not self._dirty and self._coords is not None and -self._n <= idx < self._n:
-            i = idx % self._n
-            old_b, new_b = self._bucket_of(self._coords[i, 0]), self._bucket_of(np.ravel(value.normed_coord)[0])
-            self._coords[i] = value.normed_coord
+        n = len(self._rows)
+        if isinstance(idx, int) and not self._dirty and n == len(self) and -n <= idx < n:
+            i = idx % n
+            row = tuple(np.asarray(value.normed_coord, dtype=np.float64).reshape(-1).tolist())
+            old_b, new_b = self._bucket_of(self._rows[i][0]), self._bucket_of(row[0])
+            self._rows[i] = row
             if old_b != new_b:
                 self._buckets[old_b].remove(i)
                 self._buckets.setdefault(new_b, []).append(i)
         else:
             self._dirty = True
 
-
     # -- reference API ----------------------------------------------------------------------------
     def append(self, point):
         assert isinstance(point, GPPoint)
         hits = self._matches(point.normed_coord)
-        if hits.size:
+        if hits:
             for i in hits:
-                if self[int(i)].label != PointLabels.evaluated:
-                    self[int(i)] = point
-            return int(hits[0])
-        self._matrix()
+                if self[i].label != PointLabels.evaluated:
+                    self[i] = point
+            return hits[0]
         n = len(self)
-        if self._coords is None or n >= self._coords.shape[0] or self._coords.shape[1] != np.size(point.normed_coord):
-            super().append(point)
-            self._dirty = True
-            return n
-        self._coords[n] = point.normed_coord
         super().append(point)
-        self._n = n + 1
-        self._buckets.setdefault(self._bucket_of(self._coords[n, 0]), []).append(n)
+        if not self._dirty and len(self._rows) == n:
+            row = tuple(np.asarray(point.normed_coord, dtype=np.float64).reshape(-1).tolist())
+            self._rows.append(row)
+            self._buckets.setdefault(self._bucket_of(row[0]), []).append(n)
+        else:
+            self._dirty = True
         return n
 
     def find_index_by_coords(self, coords):
         hits = self._matches(coords)
-        return int(hits[0]) if hits.size else None
+        return hits[0] if hits else None
 
     def find_by_coords(self, coords):
         i = self.find_index_by_coords(coords)

@@ -74,16 +74,80 @@ class Zero(MeanFunction):
 
 
 class Scipy:
-    """L-BFGS-B through ``scipy.optimize.minimize`` with SciPy defaults -- what
+    """L-BFGS-B through SciPy with SciPy's defaults -- what
     ``gpflow.optimizers.Scipy().minimize(model.training_loss, model.trainable_variables)`` does
     (gpso/gp_surrogate.py:500-503).  ``closure`` must be the bound ``training_loss`` of a model that
-    offers ``_loss_and_grad(u)`` / ``_pack()`` / ``_assign(u)`` (pygpso_amd.model.HipGPR)."""
+    offers ``_loss_and_grad(u)`` / ``_pack()`` / ``_assign(u)`` (pygpso_amd.model.HipGPR).
+
+    With the defaults the L-BFGS-B routine itself (``scipy.optimize._lbfgsb.setulb``, the code
+    ``scipy.optimize.minimize`` drives) is called in the same reverse-communication loop
+    ``scipy.optimize._lbfgsb_py._minimize_lbfgsb`` runs, minus the per-evaluation wrappers of
+    ``minimize`` (``ScalarFunction``, ``OptimizeResult`` per iteration): same routine, same inputs, same
+    iterates bit for bit -- at N <= 100 those wrappers cost as much as the device evaluation.  Any option,
+    another method, or a SciPy whose private routine has another signature goes through
+    ``scipy.optimize.minimize``."""
+
+    _SETULB_DOC = "setulb(m,x,l,u,nbd,f,g,factr,pgtol,wa,iwa,task,lsave,isave,dsave,maxls,ln_task)"
 
     def minimize(self, closure, variables=None, method="L-BFGS-B", **scipy_kwargs):
         model = getattr(closure, "__self__", None)
         if model is None or not hasattr(model, "_loss_and_grad"):
             raise TypeError("Scipy.minimize expects the bound training_loss of a HipGPR model")
-        res = scipy.optimize.minimize(model._loss_and_grad, model._pack(), jac=True, method=method,
-                                      **scipy_kwargs)
+        res = None
+        if method == "L-BFGS-B" and not scipy_kwargs:
+            res = self._lbfgsb_direct(model._loss_and_grad, model._pack())
+        if res is None:
+            res = scipy.optimize.minimize(model._loss_and_grad, model._pack(), jac=True, method=method,
+                                          **scipy_kwargs)
         model._assign(res.x)
         return res
+
+    @classmethod
+    def _lbfgsb_direct(cls, fun_and_grad, x0):
+        """The loop of scipy.optimize._lbfgsb_py._minimize_lbfgsb (SciPy 1.15) for an unbounded problem
+        with an exact gradient and default options; None when the private routine is not the expected one."""
+        try:
+            from scipy.optimize import _lbfgsb
+        except ImportError:
+            return None
+        if (getattr(_lbfgsb.setulb, "__doc__", None) or "").strip() != cls._SETULB_DOC:
+            return None
+        m, maxls, maxfun, maxiter = 10, 20, 15000, 15000
+        factr = 2.2204460492503131e-09 / np.finfo(float).eps
+        pgtol = 1e-5
+        x = np.array(np.asarray(x0).ravel(), dtype=np.float64)
+        n = x.shape[0]
+        nbd = np.zeros(n, np.int32)
+        low_bnd = np.zeros(n, np.float64)
+        upper_bnd = np.zeros(n, np.float64)
+        f = np.array(0.0, dtype=np.int32)
+        g = np.zeros((n,), dtype=np.int32)
+        wa = np.zeros(2 * m * n + 5 * n + 11 * m * m + 8 * m, np.float64)
+        iwa = np.zeros(3 * n, dtype=np.int32)
+        task = np.zeros(2, dtype=np.int32)
+        ln_task = np.zeros(2, dtype=np.int32)
+        lsave = np.zeros(4, dtype=np.int32)
+        isave = np.zeros(44, dtype=np.int32)
+        dsave = np.zeros(29, dtype=np.float64)
+        nfev = nit = 0
+        while True:
+            g = g.astype(np.float64)
+            _lbfgsb.setulb(m, x, low_bnd, upper_bnd, nbd, f, g, factr, pgtol, wa, iwa, task, lsave, isave,
+                           dsave, maxls, ln_task)
+            if task[0] == 3:  # the routine wants f and g at the current x
+                f, g = fun_and_grad(np.copy(x))
+                f = float(f)
+                g = np.array(g, dtype=np.float64).ravel()
+                nfev += 1
+            elif task[0] == 1:  # new iteration
+                nit += 1
+                if nit >= maxiter:
+                    task[0], task[1] = 5, 504
+                elif nfev > maxfun:
+                    task[0], task[1] = 5, 502
+            else:
+                break
+        status = 0 if task[0] == 4 else (1 if (nfev > maxfun or nit >= maxiter) else 2)
+        return scipy.optimize.OptimizeResult(fun=f, jac=g, nfev=nfev, njev=nfev, nit=nit, status=status,
+                                             x=x, success=(status == 0),
+                                             message=f"L-BFGS-B task {int(task[0])}/{int(task[1])}")

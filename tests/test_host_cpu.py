@@ -381,3 +381,33 @@ def test_point_store_index_equals_the_linear_scan():
             ref.append(c.copy())
         assert len(pts) == len(ref)
     assert all(np.array_equal(p.normed_coord, q) for p, q in zip(pts, ref))
+
+
+def test_direct_lbfgsb_driver_is_scipy_minimize_bit_for_bit():
+    """kernels.Scipy drives scipy's own L-BFGS-B routine without the wrappers of scipy.optimize.minimize:
+    same iterates, same evaluation count, bit for bit -- on a test function and on a GP loss."""
+    import scipy.optimize
+
+    from pygpso_amd.kernels import Scipy
+
+    def rosen(u):
+        return scipy.optimize.rosen(u), scipy.optimize.rosen_der(u)
+
+    x0 = np.array([-1.2, 1.0, 0.7, -0.3])
+    a = Scipy._lbfgsb_direct(rosen, x0)
+    assert a is not None, "scipy.optimize._lbfgsb.setulb changed its signature: the fallback path is in use"
+    b = scipy.optimize.minimize(rosen, x0, jac=True, method="L-BFGS-B")
+    assert np.array_equal(a.x, b.x) and a.fun == b.fun and (a.nfev, a.nit, a.status) == (b.nfev, b.nit, b.status)
+
+    import types
+
+    s = _fixture_surrogate()
+    x, y = s.current_training_data
+    s._gp_train(x=x, y=y[:, np.newaxis])  # through Scipy.minimize -> the direct driver
+    theta_direct = s.gpflow_model._pack()
+    s2 = _fixture_surrogate()
+    s2.optimiser = types.SimpleNamespace(minimize=lambda closure, variables=None: closure.__self__._assign(
+        scipy.optimize.minimize(closure.__self__._loss_and_grad, closure.__self__._pack(), jac=True,
+                                method="L-BFGS-B").x))
+    s2._gp_train(x=x, y=y[:, np.newaxis])
+    assert np.array_equal(theta_direct, s2.gpflow_model._pack())
