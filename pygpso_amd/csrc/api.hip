@@ -564,7 +564,7 @@ struct EngineT : Engine {
       const int done = launch_potrf<TF>(s, as<TF>(K), as<TF>(Lf), as<TF>(linv), as<TF>(work),
                                         grad ? as<TF>(kinvb) : nullptr, n, npad, as<double>(logdet), info_dev,
                                         single_level_max);
-      if (!(done & 1)) launch_trtri<TF>(s, as<TF>(Lf), as<TF>(linv), as<TF>(work), npad, kFitOuterPanel);
+      if (!(done & 1)) launch_trtri<TF>(s, as<TF>(Lf), as<TF>(linv), as<TF>(work), npad, fit_outer_panel(npad));
       launch_solve_alpha<TF>(s, as<TF>(linv), as<double>(y64), n, npad, mean_c, as<double>(logdet),
                              as<TF>(white), as<TF>(alpha_f), as<double>(apart), as<double>(kinv_diag),
                              as<double>(scal));

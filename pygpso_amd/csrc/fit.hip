@@ -1253,8 +1253,7 @@ __global__ __launch_bounds__(256) void inv_lastrow_kernel(T* __restrict__ linv, 
 //       diagonal chain it hides behind.  The off-diagonal blocks of L^-1 ride along in the same
 //       launches (role PB + one last-row launch), so no separate triangular inverse follows; when
 //       the gradient is wanted K^-1 = L^-T L^-1 rides along as well (role KI + one tail launch).
-//   larger: two-level by kOuterPanel-wide diagonal blocks, see launch_potrf.
-constexpr int kOuterPanel = kFitOuterPanel;
+//   larger: two-level by fit_outer_panel(npad)-wide diagonal blocks, see launch_potrf.
 // measured crossovers (posterior fit, ms, single | two-level): float 3584: 1.38 | 1.44, 4096: 1.86 | 1.73;
 // double 2560: 1.24 | 1.36, 3072: 1.85 | 1.68
 template <typename T>
@@ -1301,7 +1300,8 @@ int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t
     potrf_block<T>(st, K, Lf, linv, work, kinv, npad, (int)(npad / kFitBlock), 0, n, diag64, info);
     return 1 | (kinv != nullptr ? 2 : 0);
   }
-  // two-level, by kOuterPanel-wide diagonal blocks:
+  // two-level, by kOuterPanel = fit_outer_panel(npad)-wide diagonal blocks:
+  const int64_t kOuterPanel = fit_outer_panel(npad);
   //   1. the diagonal block is factored AND inverted by the single-level routine (a latency chain of
   //      kOuterPanel / 64 steps with hardly any bulk work);
   //   2. rows below:  L21 = A21 X11^T  -- a plain GEMM, X11 the block's lower-triangular inverse;

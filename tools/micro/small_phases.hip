@@ -41,7 +41,8 @@ int main(int argc, char** argv) {
   a.xs64 = xs64; a.xnorm64 = xn; a.xs_p64 = xsp; a.Lf = Lf; a.linv = linv; a.kinv = kinv; a.white = white;
   a.alpha_f = alf; a.alpha_p = alp; a.linv_p = linvp; a.diag64 = dg; a.kinv_diag = kd; a.scal = scal;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  const char* names[] = {"scale", "gram", "zero", "chol00", "trinv00", "L10+S", "chol11", "trinv11", "X10", "store+pack", "alpha+nlml", "kinv+grad"};
+  // stamp i is taken at the END of phase names[i - 1] (stamps 5..7 only exist for N > 64)
+  const char* names[] = {"scale", "gram+zero", "chol00", "trinv00", "L10+S", "chol11", "trinv11", "X10", "store+pack", "alpha+nlml", "kinv+grad"};
   for (int rep = 0; rep < 4; ++rep) {
     hipEventRecord(e0, 0);
     launch_small_fit<double, double>(0, a);
@@ -52,10 +53,11 @@ int main(int argc, char** argv) {
     double h[16]; hipMemcpy(h, scal, 16 * 8, hipMemcpyDeviceToHost);
     printf("n=%d d=%d: %.1f us (nlml %.6f) | clocks:", n, d, ms * 1e3, h[0]);
     const bool two = n > 64;
+    int prev = 0;
     for (int i = 1; i < 12; ++i) {
-      if (!two && (i >= 5 && i <= 7)) continue;
-      const int prev = (!two && i == 8) ? 4 : i - 1;
-      printf(" %s %lld", names[i - 1 + (i > 4 && !two ? 0 : 0)], g[i] - g[prev]);
+      if (!two && i >= 5 && i <= 7) continue;
+      printf(" %s %lld", names[i - 1], g[i] - g[prev]);
+      prev = i;
     }
     printf(" | total %lld\n", g[11] - g[0]);
   }
