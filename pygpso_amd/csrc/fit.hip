@@ -1009,23 +1009,58 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t T64 = kFitBlock;
 
-  if (blockIdx.z == 2) {
+  // 1-D grid over the ACTIVE workgroups only: [0] role D | role PU tiles | role PB tiles | role KI tiles.
+  // (A 3-D grid whose idle workgroups exit at once is harmless on an empty chip, but every workgroup of
+  // this launch reserves ~75 KB of LDS: beside a bulk GEMM on another stream -- the two-level path --
+  // the idle ones queue for the few free slots and the step takes twice as long.)
+  const int nT = (k < 0) ? 0 : ntile - (k + 1);           // trailing tile rows / columns
+  const int nPU = nT * (nT + 1) / 2;                      // tiles (i >= j >= k + 1)
+  const int nPB = (k < 0) ? 0 : nT * (k + 1);             // tiles (i > k, jp <= k)
+  int role = 0, bx = 0, by = 0;                           // decoded into the old (x, y) coordinates
+  {
+    int id = (int)blockIdx.x;
+    if (id == 0) {
+      role = 0;
+    } else if ((id -= 1) < nPU) {
+      // triangle, row-major over r = i - (k + 1) >= c = j - (k + 1): old by = c, old bx = r - c + 1
+      int r = (int)((__builtin_sqrtf(8.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
+      while ((r + 1) * (r + 2) / 2 <= id) ++r;
+      while (r * (r + 1) / 2 > id) --r;
+      const int c = id - r * (r + 1) / 2;
+      role = 3;
+      by = c;
+      bx = r - c + 1;
+    } else if ((id -= nPU) < nPB) {
+      role = 1;
+      by = id / nT;       // jp
+      bx = id % nT + 1;   // i - k
+    } else {
+      id -= nPB;          // role KI: triangle over i <= k - 1, j <= i
+      int r = (int)((__builtin_sqrtf(8.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
+      while ((r + 1) * (r + 2) / 2 <= id) ++r;
+      while (r * (r + 1) / 2 > id) --r;
+      role = 2;
+      bx = r + 1;
+      by = id - r * (r + 1) / 2;
+    }
+  }
+  if (role == 2) {
     // ---------------- role KI: row block k - 1 of X = L^-1 (complete since the previous launch) into
     // K^-1 = X^T X, tile (i, j), j <= i <= k - 1
-    const int i = (int)blockIdx.x - 1, j = (int)blockIdx.y;
-    if (kinv == nullptr || blockIdx.x == 0 || k < 1 || i > k - 1 || j > i) return;
+    const int i = bx - 1, j = by;
+    if (kinv == nullptr || k < 1 || i > k - 1 || j > i) return;
     kinv_accum_tile<T>(linv, kinv, ld, i, j, k - 1, k, lds, tid, lane, wave);
     return;
   }
-  if (blockIdx.z == 1) {
+  if (role == 1) {
     // ---------------- role PB: tile (i, jp) of the inverse's right-hand side, jp <= k < i ----------
     // L X = I solved by the same elimination: B starts as the identity, step k finishes row block k,
     // X[k,jp] = X_kk B[k,jp], and updates the rows below, B[i,jp] -= L[i,k] X[k,jp].  B is kept
     // TRANSPOSED in the scratch matrix, W[jp,i] = B[i,jp]^T, so that every product is the A B^T form
     // of mma_abt:  Xkj^T = W[jp,k] X_kk^T,  W[jp,i] -= Xkj^T Li^T.  (jp == k: B[k,k] = I, Xkj = X_kk,
     // and the first contribution overwrites W.)  The i == k+1 tiles also store X[k,jp] -> linv.
-    const int jp = (int)blockIdx.y, i = k + (int)blockIdx.x;
-    if (blockIdx.x == 0 || k < 0 || jp > k || i >= ntile) return;
+    const int jp = by, i = k + bx;
+    if (k < 0 || jp > k || i >= ntile) return;
     T* TI = reinterpret_cast<T*>(lds);
     T* TW = TI + kFitBlock * kTL;
     T* TX = TW + kFitBlock * kTL;
@@ -1066,7 +1101,7 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
       for (int r = 0; r < 4; ++r) Cw[(int64_t)M::crow(lane, r) * ld + 16 * tj] = c_old[tj][r] - acc[tj][r];
     return;
   }
-  if (blockIdx.x == 0 && blockIdx.y == 0) {
+  if (role == 0) {
     // ---------------- role D: diagonal block kd = k + 1 ----------------------------------------
     const int kd = k + 1;
     if (kd >= ntile) return;
@@ -1163,9 +1198,9 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
     return;
   }
   // ---------------- role PU: tile (i, j) of the trailing update -----------------------------------
-  if (blockIdx.x == 0 || k < 0) return;
-  const int j = k + 1 + (int)blockIdx.y;
-  const int i = j + (int)blockIdx.x - 1;
+  if (k < 0) return;
+  const int j = k + 1 + by;
+  const int i = j + bx - 1;
   if (j > jmax || i >= ntile) return;
   const bool diag_next = (i == k + 1);  // tile (k+1,k+1): role D updates it; only L10 is stored here
   T* TI = reinterpret_cast<T*>(lds);
@@ -1273,14 +1308,13 @@ static void potrf_block(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, 
     return;
   const int lds_bytes = StepLds<T>::kBytes;
   auto step = [&](int k) {
-    // grid.x = 1 (role D / idle) + rows below the diagonal of the tile column, grid.y = tile columns;
-    // blockIdx.z == 1 -> role PB (tile columns 0 .. k), == 2 -> role KI (tiles (i, j <= i < k))
-    const bool ki = kinv != nullptr && k >= 1;
-    const int ncol = (k < 0) ? 1 : std::max(std::max(k + 1, ntile - 1 - k), ki ? k : 1);
-    const int nrow = (k < 0) ? 0 : std::max(std::max(1, ntile - (k + 1)), ki ? k : 1);
-    hipLaunchKernelGGL((potrf_step_kernel<T>), dim3((unsigned)(1 + nrow), (unsigned)ncol, k < 0 ? 1u : ki ? 3u : 2u),
-                       dim3(256), lds_bytes, st, K, Lf, linv, ld, k, ntile - 1, ntile, n, diag64, info, work,
-                       kinv, row_base);
+    // one workgroup per ACTIVE role instance (decoded in the kernel): D, the trailing tiles (PU), the tiles
+    // of the inverse's right-hand side (PB), and -- when K^-1 is wanted -- the tiles of its finished part (KI)
+    const int nT = (k < 0) ? 0 : ntile - (k + 1);
+    const int nPU = nT * (nT + 1) / 2, nPB = (k < 0) ? 0 : nT * (k + 1);
+    const int nKI = (kinv != nullptr && k >= 1) ? k * (k + 1) / 2 : 0;
+    hipLaunchKernelGGL((potrf_step_kernel<T>), dim3((unsigned)(1 + nPU + nPB + nKI)), dim3(256), lds_bytes, st, K, Lf,
+                       linv, ld, k, ntile - 1, ntile, n, diag64, info, work, kinv, row_base);
   };
   step(-1);  // diagonal block 0
   for (int k = 0; k < ntile - 1; ++k) step(k);
