@@ -452,7 +452,9 @@ struct EngineT : Engine {
     return GPSO_OK;
   }
 
-  int set_theta(int kernel, const double* ls, int n_ls_, double variance, double noise, double mean_c) {
+  // upload = false: the caller's kernel writes the device copy of the block itself (fused small fit)
+  int set_theta(int kernel, const double* ls, int n_ls_, double variance, double noise, double mean_c,
+                bool upload = true) {
     if (kernel < 0 || kernel > 3) return ctx->fail(GPSO_E_ARG, "unknown kernel id %d", kernel);
     if (!(n_ls_ == 1 || n_ls_ == d)) return ctx->fail(GPSO_E_ARG, "n_ls=%d must be 1 or D=%d", n_ls_, d);
     if (n_ls_ > kGradMaxLs) return ctx->fail(GPSO_E_ARG, "too many lengthscales");
@@ -465,6 +467,7 @@ struct EngineT : Engine {
     kp.mean_c = mean_c;
     n_ls = n_ls_;
     ls_host.assign(ls, ls + n_ls_);
+    if (!upload) return GPSO_OK;
     // staged in pinned memory (upper half of the scratch; the read-backs use the lower half): the copy
     // is then a plain stream operation and needs no host synchronisation here
     static_assert(128 + kHyperHeader + kMaxD <= 256, "pinned scratch layout");
@@ -534,17 +537,19 @@ struct EngineT : Engine {
     if (!ls) return ctx->fail(GPSO_E_ARG, "lengthscales must not be NULL");
     int rc = ensure_fit_buffers();
     if (rc) return rc;
-    if ((rc = set_theta(kernel, ls, n_ls_, variance, noise, mean_c))) return rc;
+    const bool small = fused_small && small_fit_eligible(n, dp);
+    if ((rc = set_theta(kernel, ls, n_ls_, variance, noise, mean_c, !small))) return rc;
     have_post = have_kinv = chol_valid = false;
     st_done = st_have = false;
     reset_generation();
     hipStream_t s = st();
     HIPCHECK(hipEventRecord(ctx->ev[4], s));
     if (grad && (rc = ensure(kinvb, (size_t)npad * npad * sizeof(TF)))) return rc;
-    if (fused_small && small_fit_eligible(n, dp)) {
+    if (small) {
       // N <= 128: the whole evaluation in ONE launch (fit.hip: small_fit_kernel)
       SmallFitArgs a{};
-      a.x64 = as<double>(x64); a.y64 = as<double>(y64); a.ls = ls_dev();
+      a.x64 = as<double>(x64); a.y64 = as<double>(y64); a.hyper = as<double>(hyper);
+      for (int k = 0; k < kMaxD; ++k) a.ls[k] = ls[n_ls_ == 1 ? 0 : std::min(k, n_ls_ - 1)];
       a.n = (int)n; a.d = d; a.dp = dp; a.kernel = kernel; a.n_ls = n_ls; a.want_grad = grad ? 1 : 0;
       a.zero_tile_rows = small_tile_rows;  // (tile rows of linv_p beyond this fit's that may hold old data)
       small_tile_rows = (int)((n + 15) / 16);

@@ -1808,6 +1808,18 @@ __global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs g) {
   // ---- 0. scaled inputs: LDS (in B, free until X00 is formed) + the global copies the predict path reads
   double* xs = B;
   if (tid == 0) *info = INT_MAX;
+  if (tid < 8 + 48) {  // the hyper-parameter block (layout: api.hip set_theta)
+    double h = 0.0;
+    if (tid == 0) h = (double)n;
+    else if (tid == 1) h = (double)g.d;
+    else if (tid == 2) h = (double)g.kernel;
+    else if (tid == 3) h = (double)g.n_ls;
+    else if (tid == 4) h = g.variance;
+    else if (tid == 5) h = g.noise;
+    else if (tid == 6) h = g.mean_c;
+    else if (tid >= 8) h = g.ls[tid - 8];
+    g.hyper[tid] = h;
+  }
   for (int e = tid; e < kSmallN * dp; e += 256) {
     const int i = e / dp, k = e % dp;
     double v = 0.0;

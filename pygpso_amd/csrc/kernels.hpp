@@ -126,7 +126,10 @@ constexpr int kGradMaxLs = 64;
 struct SmallFitArgs {
   const double* x64;
   const double* y64;
-  const double* ls;  // [dp] lengthscale per input dimension (device)
+  double ls[48];     // lengthscale per input dimension (isotropic: repeated), by value: the kernel also
+                     // writes the hyper-parameter block the predict path reads, so the evaluation needs no
+                     // host-to-device copy of its own
+  double* hyper;     // [8 + 48] hyper-parameter block (device, output)
   int n, d, dp, kernel, n_ls, want_grad;
   int zero_tile_rows;  // 16-row tile rows of linv_p an earlier fit may have left non-zero (8 = unknown)
   double variance, noise, mean_c;

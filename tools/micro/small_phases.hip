@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
   hipMemcpy(y64, y.data(), n * 8, hipMemcpyHostToDevice);
   hipMemcpy(lsd, ls.data(), 48 * 8, hipMemcpyHostToDevice);
   SmallFitArgs a{};
-  a.x64 = x64; a.y64 = y64; a.ls = lsd; a.n = n; a.d = d; a.dp = dp; a.kernel = 0; a.n_ls = 1; a.want_grad = 1;
+  a.x64 = x64; a.y64 = y64; a.hyper = scal + 64; for (int k = 0; k < 48; ++k) a.ls[k] = ls[k]; a.n = n; a.d = d; a.dp = dp; a.kernel = 0; a.n_ls = 1; a.want_grad = 1;
   a.variance = 1.0; a.noise = 1e-3; a.mean_c = 0.1;
   a.xs64 = xs64; a.xnorm64 = xn; a.xs_p64 = xsp; a.Lf = Lf; a.linv = linv; a.kinv = kinv; a.white = white;
   a.alpha_f = alf; a.alpha_p = alp; a.linv_p = linvp; a.diag64 = dg; a.kinv_diag = kd; a.scal = scal;
