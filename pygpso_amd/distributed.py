@@ -198,18 +198,21 @@ class HipGPEngineGroup:
     every predict-type call is sharded over all of them.  Each engine is driven by its own thread (the
     C-ABI calls release the GIL; the RCCL collectives inside them need all ranks in flight at once)."""
 
-    def __init__(self, dtype="float64", devices=(0,), **engine_options):
-        from .engine import HipGPEngine
+    def __init__(self, dtype="float64", devices=(0,), engine_cls=None, make_id=None, **engine_options):
+        """``engine_cls`` / ``make_id``: test hooks (the per-device engine class, default ``HipGPEngine``, and
+        the source of the group id, default ``unique_id``)."""
+        if engine_cls is None:
+            from .engine import HipGPEngine as engine_cls
 
         self.devices = [int(dev) for dev in devices]
         if not self.devices:
             raise ValueError("devices must name at least one GPU")
         self.world = len(self.devices)
-        self.engines = [HipGPEngine(dtype, device=dev, **engine_options) for dev in self.devices]
+        self.engines = [engine_cls(dtype, device=dev, **engine_options) for dev in self.devices]
         self.dtype_name, self.dtype = self.engines[0].dtype_name, self.engines[0].dtype
         self.device = self.devices[0]
         self._pool = ThreadPoolExecutor(self.world)
-        uid = unique_id()
+        uid = (make_id or unique_id)()
         self._all(lambda r, e: e.comm_init(r, self.world, uid))
         self._stale = False  # peers lag behind the root's posterior?
         self.n = self.d = 0

@@ -165,3 +165,87 @@ def test_package_imports_no_torch():
     code = ("import sys; import pygpso_amd, pygpso_amd.distributed; "
             "assert 'torch' not in sys.modules, 'pygpso_amd pulled in torch'")
     subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
+
+
+def test_engine_group_threads_with_two_fake_devices():
+    """``HipGPEngineGroup`` (what ``GPRSurrogate(devices=[...])`` builds) with TWO ranks on CPU: the engines are
+    oracle-backed doubles whose group calls meet at an in-process rendezvous (a barrier + shared slots --
+    standing in for RCCL, which needs the GPUs), so the per-device threads, the fit-on-rank-0 / broadcast /
+    sharded-call choreography and the result selection run exactly as they do on two GPUs."""
+    import threading
+
+    from oracle import gpr, tree
+    from pygpso_amd import distributed as D
+    from tests.helpers import synthetic_leaves, synthetic_problem
+    from tests.oracle_engine import OracleEngine
+
+    world = 2
+    barrier = threading.Barrier(world)
+    slots = {}
+
+    class FakeDeviceEngine(OracleEngine):
+        dtype_name, dtype = "float64", 0
+
+        def __init__(self, dtype="float64", device=0, **_):
+            super().__init__()
+            self.device = device
+            self.rank, self.world = 0, 1
+
+        def close(self):
+            pass
+
+        def comm_init(self, rank, nranks, uid):
+            assert uid == b"id" * 64
+            self.rank, self.world = rank, nranks
+            self._grp = D.HostGroup(self, rank, nranks, self._allgather, self._bcast)
+
+        def _allgather(self, a):
+            slots[("g", self.rank)] = np.array(a)
+            barrier.wait()
+            out = np.stack([slots[("g", r)] for r in range(self.world)])
+            barrier.wait()
+            return out
+
+        def _bcast(self, obj, src):
+            if self.rank == src:
+                slots["b"] = obj
+            barrier.wait()
+            out = slots["b"]
+            barrier.wait()
+            return out
+
+        def broadcast_posterior(self, root=0):
+            self._grp.broadcast_posterior(root)
+
+        def best_ucb_sharded(self, local, m_global, varsigma, seg_off=None):
+            return self._grp.best_ucb_sharded(np.asarray(local), m_global, varsigma, seg_off)
+
+        def best_ucb_grow_sharded(self, bounds, depth, varsigma):
+            return self._grp.best_ucb_grow_sharded(bounds, depth, varsigma)
+
+    grp = D.HipGPEngineGroup("float64", devices=[0, 1], engine_cls=FakeDeviceEngine, make_id=lambda: b"id" * 64)
+    X, y = synthetic_problem(70, 3, seed=0)
+    grp.set_data(X, y)
+    grp.fit_eval("Matern52", [0.4], 1.0, 1e-3, 0.0, want_grad=False)
+    ref = OracleEngine()
+    ref.set_data(X, y)
+    ref.fit_eval("Matern52", [0.4], 1.0, 1e-3, 0.0, want_grad=False)
+    VS = gpr.VARSIGMA_DEFAULT
+    Xs = synthetic_leaves(501, 3, seed=1)
+    seg = np.array([0, 100, 100, 333, 501], dtype=np.int64)
+    got, exp = grp.best_ucb(Xs, VS, seg), ref.best_ucb(Xs, VS, seg)
+    assert np.array_equal(got[0], exp[0])
+    np.testing.assert_allclose(np.array(got[1:]), np.array(exp[1:]), rtol=1e-12, atol=1e-13, equal_nan=True)
+    kids = tree.split_bounds([(0.0, 1.0)] * 3)
+    boxes = np.array([kids[0], kids[2]])
+    got, exp = grp.best_ucb_grow(boxes, 4, VS), ref.best_ucb_grow(boxes, 4, VS)
+    assert np.array_equal(got[0], exp[0])
+    m, v = grp.predict(Xs)
+    m_ref, v_ref = ref.predict(Xs)
+    np.testing.assert_allclose(m, m_ref, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(v, v_ref, rtol=1e-12, atol=1e-13)
+    # a second fit makes the peers stale again: the next call re-broadcasts
+    grp.fit_eval("Matern52", [0.5], 1.2, 1e-3, 0.1, want_grad=False)
+    ref.fit_eval("Matern52", [0.5], 1.2, 1e-3, 0.1, want_grad=False)
+    assert np.array_equal(grp.best_ucb(Xs, VS)[0], ref.best_ucb(Xs, VS)[0])
+    grp.close()
