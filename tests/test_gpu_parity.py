@@ -417,6 +417,33 @@ def test_best_ucb_grow_on_arbitrary_boxes_keeps_near_duplicates(d, depth, nbox):
     assert scored > nbox * uniq or distinct == nbox * uniq
 
 
+def test_best_ucb_grow_edge_cases():
+    """depth 0 (no rows: every box reports the empty-segment record), depth 1 (the box centre only) and many
+    boxes in one call."""
+    X, y, th = _problem(40, 3)
+    eng = _engine()
+    _fit(eng, X, y, th, grad=False)
+    rng = np.random.default_rng(3)
+    boxes = []
+    for _ in range(37):
+        b = [(0.0, 1.0)] * 3
+        for _ in range(int(rng.integers(1, 6))):
+            b = tree.split_bounds(b)[int(rng.integers(3))]
+        boxes.append(b)
+    boxes = np.array(boxes)
+    idx, mu, vv, ucb = eng.best_ucb_grow(boxes, 0, VS)
+    assert np.all(idx == -1) and np.all(np.isnan(ucb)) and eng.last_count(1) == 0
+    idx, mu, vv, ucb = eng.best_ucb_grow(boxes, 1, VS)
+    centres = np.array([[(lo + hi) / 2 for lo, hi in b] for b in boxes])
+    m1, v1 = eng.predict(centres)
+    assert np.all(idx == 0) and np.array_equal(mu, m1) and np.array_equal(vv, v1)
+    idx, mu, vv, ucb = eng.best_ucb_grow(boxes, 4, VS)
+    assert eng.last_count(0) == 37 * 27 and eng.last_count(1) == 37 * 40
+    for s in (0, 11, 36):
+        one = eng.best_ucb(tree.grow([tuple(r) for r in boxes[s]], 4), VS)
+        assert (int(one[0][0]), one[1][0], one[2][0], one[3][0]) == (int(idx[s]), mu[s], vv[s], ucb[s])
+
+
 def test_best_ucb_grow_in_several_chunks():
     """depth 13 x 2 boxes = 1.6 M reference rows (1.06 M distinct): more than one 1 Mi-leaf pass of the
     tile kernel, so the live count is split per chunk on the device."""

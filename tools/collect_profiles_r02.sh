@@ -12,7 +12,7 @@ cp $(ls $O/prof/*/*kernel_stats.csv | head -1) $O/bench_c3_kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE TCC_HIT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc1 -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1; echo "pmc1 rc $?"
 rocprofv3 --pmc WRITE_SIZE TCC_MISS TCC_REQ --kernel-trace --output-format csv -d $O/pmc2 -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1; echo "pmc2 rc $?"
 rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pmc3 -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1; echo "pmc3 rc $?"
-for pat in leaf_tiles_v2 potrf_step gram_kernel; do echo "## $pat"; for p in pmc1 pmc2 pmc3; do python3 $R/tools/pmc_summary.py $O/$p $pat; done; done > $O/pmc_summary.txt 2>&1
+for pat in leaf_tiles_v2 potrf_step gram_kernel; do echo "## $pat (largest-grid dispatches only)"; for p in pmc1 pmc2 pmc3; do python3 $R/tools/pmc_summary.py $O/$p $pat; done; done > $O/pmc_summary.txt 2>&1
 rm -rf $O/prof $O/pmc1 $O/pmc2 $O/pmc3
 echo "bench profile done"
 for cfg in "2048 12 c3" "8192 20 c4" "16384 40 c5"; do
@@ -26,4 +26,8 @@ python3 $R/tools/host_overhead.py 52 2 2>/dev/null | head -1 > $O/host_overhead.
 python3 $R/tools/host_overhead.py 100 6 2>/dev/null | head -1 >> $O/host_overhead.txt
 if [ -x $R/tools/micro/small_phases.bin ]; then for a in "12 2" "52 2" "100 6"; do $R/tools/micro/small_phases.bin $a | tail -1; done > $O/small_fit_phases.txt; fi
 python3 $R/tools/gen_probe.py > $O/gen_probe.jsonl 2>/dev/null
+python3 $R/tools/explore_overhead.py > $O/explore_overhead.txt 2>/dev/null
+for s in 11 12 13; do FUZZ_CASES=80 FUZZ_SEED=$s python3 $R/tools/fuzz_gpu.py > $O/fuzz_seed$s.log 2>&1; tail -1 $O/fuzz_seed$s.log; done
+if [ -x $R/tools/micro/overlap_probe.bin ]; then timeout -k 5 120 $R/tools/micro/overlap_probe.bin 1024 6144 > $O/overlap_probe.txt 2>&1; fi
+bash $R/tools/pmc_sq.sh > $O/pmc_sq_leaf_tiles.txt 2>&1
 ls -la $O
