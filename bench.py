@@ -42,7 +42,7 @@ WORKLOADS = {
 PEAK_TFLOPS = {"float32": 157.3, "float64": 78.6}  # dense MFMA peaks, MI355X_MICROARCH.md
 # HBM bytes per launch of the dominant kernel come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
 # cannot be read from inside the process); the committed record of the latest collection:
-PMC_TRAFFIC = {"c3": "profiles/r02e_pmc_leaf_tiles_c3.json"}
+PMC_TRAFFIC = {"c3": "profiles/r02f_pmc_leaf_tiles_c3.json"}
 
 
 def pmc_traffic(workload):

@@ -54,7 +54,8 @@ for case in range(N_CASES):
         # ... or where the float rounding of the terms k_i alpha_i of the MEAN alone uses up the tolerance
         # (|alpha| grows with the conditioning; the mean is a cancelling sum of such terms)
         ys_ = max(1.0, float(np.max(np.abs(y - th.mean_c))))
-        ok = ok or (dtype != "float64" and 3 * 6e-8 * float(np.max(np.abs(post.alpha))) * th.variance >= 1e-4 * ys_)
+        # (a float k* . alpha carries ~eps_float * sum_i |k_i alpha_i| <= eps_float * sigma^2 * sum |alpha_i| of rounding)
+        ok = ok or (dtype != "float64" and 6e-8 * float(np.sum(np.abs(post.alpha))) * th.variance >= 0.5e-4 * ys_)
         refused += 1
         bad += (not ok)
         print(f"{'ref' if ok else 'BAD'} {tag} refused: {type(e).__name__} {str(e)[60:330]}")
