@@ -111,6 +111,9 @@ __device__ __forceinline__ size_t linv_tile(int rt, int kt) {
   return ((size_t)rt * (size_t)(rt + 1) / 2 + (size_t)kt) * 64;
 }
 
+#ifndef GPSO_PSTAMP
+#define GPSO_PSTAMP(kt, i)  // tools/micro/leaf_phases.hip defines this to record s_memtime stamps
+#endif
 template <typename T, typename TG, int RT, int CT, int KERNEL, bool DIAG>
 __device__ __forceinline__ void leaf_v2_step(
     int kt, int kt_diag0, bool gen, bool gen_diag, int lane, int dp4,
@@ -138,6 +141,7 @@ __device__ __forceinline__ void leaf_v2_step(
       for (int t = 0; t < CT; ++t) s[t] = MG::mma(xa, xb[(t * dp4 + c) * 64 + lane], s[t]);
     }
   }
+  GPSO_PSTAMP(kt, 2);
   vec4 p_nxt[CT];
   // A operands from LDS, two row tiles ahead of their use: the reads are pinned in front of the
   // previous tile's MFMAs (sched_barrier), otherwise the scheduler sinks them to just before their
@@ -181,6 +185,7 @@ __device__ __forceinline__ void leaf_v2_step(
       }
     }
   }
+  GPSO_PSTAMP(kt, 3);
   if (gen && gen_diag) {  // k-tile kt + 1 lies in the diagonal block: its share of k*.alpha
     const vec4 a4 = al4[(kt + 1) * 4 + (lane >> 4)];
 #pragma unroll
@@ -306,17 +311,21 @@ __global__ __launch_bounds__(256, 2) void leaf_tiles_v2_kernel(
 #define GPSO_V2_STEP(DIAGF, GEN_DIAG)                                                              \
   {                                                                                                \
     const int b = kt & 1;                                                                          \
+    GPSO_PSTAMP(kt, 0);                                                                            \
     if (kt + 1 < kt_end) issue_panel(kt + 1, b ^ 1);                                               \
     vecG na_nxt = na;                                                                              \
     if (kt + 2 < kt_end) {                                                                         \
       issue_xs(kt + 2, b ^ 1);                                                                     \
       na_nxt = xn4[(kt + 2) * 4 + (lane >> 4)] * C2;                                               \
     }                                                                                              \
+    GPSO_PSTAMP(kt, 1);                                                                            \
     leaf_v2_step<T, TG, RT, CT, KERNEL, DIAGF>(                                                    \
         kt, kt_diag0, kt + 1 < kt_end, GEN_DIAG, lane, dp4, panel + (size_t)b * RT * FB,           \
         xsl + (size_t)b * dp4 * XB, xb, na, al4, nb, variance, acc, macc, p_cur);                  \
     na = na_nxt;                                                                                   \
+    GPSO_PSTAMP(kt, 4);                                                                            \
     __syncthreads(); /* panel(kt+1) / xs(kt+2) landed; buffers b free */                           \
+    GPSO_PSTAMP(kt, 5);                                                                            \
   }
   for (int kt = 0; kt < kt_diag0; ++kt) GPSO_V2_STEP(false, kt + 1 >= kt_diag0)
   for (int kt = kt_diag0; kt < kt_end; ++kt) GPSO_V2_STEP(true, true)
