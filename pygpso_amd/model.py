@@ -99,6 +99,7 @@ class HipGPR:
         self._data = (x, y)
         self.engine.set_data(x, y[:, 0])
         self._resident = False
+        self._device_theta = None  # hyper-parameters of the posterior on the device (None: none / unknown)
 
     # -- hyper-parameters ---------------------------------------------------------------------
     @property
@@ -147,7 +148,10 @@ class HipGPR:
     def _loss_and_grad(self, u):
         """f(u), df/du for L-BFGS-B: one device evaluation (Gram -> Cholesky -> ... -> gradient)."""
         ls, var, noise, c = self._unpack(u)
+        self._device_theta = None
         f, g = self.engine.fit_eval(self.kernel.name, ls, var, noise, c, want_grad=True)
+        self._device_theta = self._theta_key(self.kernel.name, ls, var, noise, c)
+        self._last_nlml = f
         self.num_loss_evals += 1
         self._resident = False  # resident for u, not necessarily for the stored hyper-parameters
         k = self.n_ls
@@ -157,10 +161,19 @@ class HipGPR:
             gu[k + 2] = g[k + 2]
         return f, gu
 
+    @staticmethod
+    def _theta_key(name, ls, var, noise, c):
+        return (name, np.asarray(ls, dtype=np.float64).tobytes(), float(var), float(noise), float(c))
+
     def _ensure_resident(self):
         if not self._resident:
             name, ls, var, noise, c = self._theta()
-            self._last_nlml, _ = self.engine.fit_eval(name, ls, var, noise, c, want_grad=False)
+            # L-BFGS-B's last loss evaluation is, as a rule, at the point it returns: the posterior that
+            # evaluation left on the device is then the one asked for (an evaluation with the gradient builds
+            # the same factor, L^-1 and alpha, bit for bit) and no further fit is needed
+            if self._device_theta != self._theta_key(name, ls, var, noise, c):
+                self._last_nlml, _ = self.engine.fit_eval(name, ls, var, noise, c, want_grad=False)
+                self._device_theta = self._theta_key(name, ls, var, noise, c)
             self._resident = True
 
     def training_loss(self):
@@ -186,6 +199,7 @@ class HipGPR:
         x, y = self._data
         self.engine.set_data(x, y[:, 0])
         self._resident = False
+        self._device_theta = None
         return True
 
     def _predicting(self, call):
