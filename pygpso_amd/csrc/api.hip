@@ -247,6 +247,8 @@ struct EngineT : Engine {
       white, alpha_f, alpha, logdet, scal, gpart, apart, kinv_diag, getter_tmp;
   // split-bf16 copy of L^-1 (float predict with GPSO_OPT_PREDICT_MATH != native)
   DevBuf linv_b;
+  DevBuf lsplit;          // bf16 planes of one panel of the two-level float factorisation
+  bool bf16_fit = true;   // GPSO_OPT_FIT_BF16_SYRK
   int math = GPSO_MATH_NATIVE;
   // generation of the cross-Gram tile in float-predict contexts: the OPTION (gen_mode) and what the
   // resident posterior actually uses (gen_eff32).  GPSO_GEN_AUTO starts every posterior in float -- the
@@ -275,7 +277,7 @@ struct EngineT : Engine {
                       &work, &kinvb, &linv_p, &white, &alpha_f, &alpha, &logdet, &scal, &gpart, &apart,
                       &kinv_diag, &getter_tmp, &leaves_raw, &leaves_s, &lnorm, &pvar, &pmean, &omean, &ovar,
                       &oucb, &segoff, &best, &oidx, &ovals, &linv_b, &st_mean, &st_var, &st_out, &grow_key, &live_cnt,
-                      &best_pos, &gath, &wbase, &ovals2, &bhdr})
+                      &best_pos, &gath, &wbase, &ovals2, &bhdr, &lsplit})
       if (b->p) (void)hipFree(b->p);
   }
 
@@ -311,6 +313,10 @@ struct EngineT : Engine {
       case GPSO_OPT_FIT_SINGLE_LEVEL_MAX:
         if (value < 0) return ctx->fail(GPSO_E_ARG, "single-level limit %d must be >= 0", value);
         single_level_max = value;
+        return GPSO_OK;
+      case GPSO_OPT_FIT_BF16_SYRK:
+        if (value != 0 && value != 1) return ctx->fail(GPSO_E_ARG, "bf16 SYRK must be 0 or 1");
+        bf16_fit = value != 0;
         return GPSO_OK;
       case GPSO_OPT_FIT_FUSED_SMALL:
         if (value != 0 && value != 1) return ctx->fail(GPSO_E_ARG, "fused small fit must be 0 or 1");
@@ -566,9 +572,14 @@ struct EngineT : Engine {
       const int imax = INT_MAX;
       int* info_dev = reinterpret_cast<int*>(as<double>(scal) + 1);
       HIPCHECK(hipMemcpyAsync(info_dev, &imax, sizeof(int), hipMemcpyHostToDevice, s));
+      unsigned short* planes = nullptr;
+      if (sizeof(TF) == 4 && bf16_fit && npad > (single_level_max >= 0 ? single_level_max : 3584)) {
+        if ((rc = ensure(lsplit, fit_split_elems(npad) * 2))) return rc;
+        planes = static_cast<unsigned short*>(lsplit.p);
+      }
       const int done = launch_potrf<TF>(s, as<TF>(K), as<TF>(Lf), as<TF>(linv), as<TF>(work),
                                         grad ? as<TF>(kinvb) : nullptr, n, npad, as<double>(logdet), info_dev,
-                                        single_level_max);
+                                        single_level_max, planes);
       if (!(done & 1)) launch_trtri<TF>(s, as<TF>(Lf), as<TF>(linv), as<TF>(work), npad, fit_outer_panel(npad));
       launch_solve_alpha<TF>(s, as<TF>(linv), as<double>(y64), n, npad, mean_c, as<double>(logdet),
                              as<TF>(white), as<TF>(alpha_f), as<double>(apart), as<double>(kinv_diag),

@@ -281,6 +281,22 @@ __device__ __forceinline__ void kern_and_dkern_same(int kernel, double r2, doubl
   }
 }
 
+// ---- split-bf16 helpers (predict.hip: leaf_tiles_bf16_kernel; fit.hip: syrk_bf16_kernel) ----------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// (a, b) -> packed bf16 pair (round to nearest even); a, b are replaced by the remainders
+__device__ __forceinline__ unsigned bf16_split_pair(float& a, float& b) {
+  const f32x2 v = {a, b};
+  const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  a -= __builtin_bit_cast(float, u << 16);
+  b -= __builtin_bit_cast(float, u & 0xffff0000u);
+  return u;
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

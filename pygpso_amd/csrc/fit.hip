@@ -511,6 +511,9 @@ __global__ __launch_bounds__(256) void trinv_diag_kernel(const T* __restrict__ L
 // =============================================================================================
 // batched tile GEMM descriptor:  C = alpha * opA * opB + beta * C
 // =============================================================================================
+// (layout of the split-bf16 planes a GEMM may emit beside C: see SyrkBf16Desc below)
+__host__ __device__ __forceinline__ int64_t syrk_plane_offset(int64_t row, int k, int nkb);
+
 struct GemmDesc {
   const void* A;
   int64_t sai, sak;  // opA(i,k) = A[i*sai + k*sak]
@@ -525,6 +528,11 @@ struct GemmDesc {
   double alpha, beta;
   int lower_only;  // only tiles with tj <= ti (needs m == n)
   int kmode;       // 0: all k | 1: k >= TS tj | 2: k >= TS ti | 3: k < TS (ti + 1) | 4: k < TS (tj + 1)
+  // float only, nullable: also write C (rows / columns relative to C) as three bf16 planes in the layout
+  // syrk_bf16_kernel reads (the TRSM of the two-level Cholesky hands its panel to the SYRK this way)
+  unsigned short* split;
+  int64_t split_stride;  // bf16 elements between planes
+  int split_nkb;         // 32-column blocks per row of the plane layout (= n / 32)
 };
 
 // =============================================================================================
@@ -782,6 +790,19 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmDesc g) {
 #pragma unroll
       for (int b = 0; b < WT; ++b) v[b] = alpha * acc[a][b][r];
       *reinterpret_cast<vecW*>(c_ptr(a, r)) = v;
+      if constexpr (sizeof(T) == 4) {
+        if (g.split != nullptr) {  // the same WT values as bf16 pieces (x = h0 + h1 + h2), pairs of columns
+          const int64_t row = (int64_t)ti * TS + wr * WE + WT * M::crow(lane, r) + a;
+          const int col = tj * TS + wc * WE + WT * (lane & 15);
+#pragma unroll
+          for (int b = 0; b < WT; b += 2) {
+            float x0 = v[b], x1 = v[b + 1];
+            unsigned short* dst = g.split + syrk_plane_offset(row, col + b, g.split_nkb);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(dst + p * g.split_stride) = bf16_split_pair(x0, x1);
+          }
+        }
+      }
     }
 }
 
@@ -821,6 +842,160 @@ static void launch_gemm(hipStream_t st, const GemmDesc& g) {
   }
   if (div128 && tiles128 >= 512) launch_gemm_dma<T, 128>(st, g, a_kc, b_kc);
   else launch_gemm_dma<T, 64>(st, g, a_kc, b_kc);
+}
+
+// =============================================================================================
+// rank-W update of the trailing matrix on the bf16 matrix cores (float fits, two-level path)
+// =============================================================================================
+// C (lower 128x128 tiles of an m x m block) -= A A^T, A = the panel L21 (m x W) just produced by the
+// TRSM GEMM -- whose epilogue also wrote it as THREE bf16 planes (x = h0 + h1 + h2, each piece the bf16
+// rounding of the remainder: 3 x 8 mantissa bits hold a float exactly).  The product is recovered from six
+// v_mfma_f32_16x16x32_bf16 per tile pair (h0h0 + h0h1 + h1h0 + h1h1 + h0h2 + h2h0, small terms first, f32
+// accumulation: the dropped h1h2 / h2h1 / h2h2 are <= 2^-24 relative) -- the bf16 pipe runs at 16x the
+// f32 MFMA rate, so the six cost 3/8 of the eight f32 MFMAs they replace.  Both operands are rows of
+// the same k-contiguous planes, so no value is split inside this kernel: fragments (8 consecutive k of one
+// row = 16 bytes per lane) go global -> LDS by global_load_lds into a 3-deep ring of 48 KB steps (K = 32
+// per step: 2 operands x 3 pieces x 8 row tiles x 1 KB), one workgroup of four waves per CU, each wave a
+// 64 x 64 corner (4 x 4 MFMA tiles, strip rows dealt to the tiles interleaved so that a lane owns four
+// consecutive columns of C: 16-byte accesses, as in gemm128_kernel).
+// Plane layout (private to the TRSM epilogue that writes it and this kernel): the planes are stored as the
+// 1 KB fragments this kernel's MFMAs consume, so every LDS-DMA instruction reads 1 KB of contiguous memory:
+// fragment (T, kb) of a plane = rows of MFMA tile T x the 32 k of block kb, lane l = (i, kg) holding
+// k = 32 kb + 8 kg .. + 7 of the tile's row i; tile T = 4 (row / 64) + row % 4 with i = (row % 64) / 4
+// (the four tiles of a 64-row strip are dealt its rows interleaved, so that a lane owns four consecutive
+// columns of C).  Element (row, k) of plane p: p * plane_stride + syrk_plane_offset(row, k, nkb).
+__host__ __device__ __forceinline__ int64_t syrk_plane_offset(int64_t row, int k, int nkb) {
+  const int64_t T = 4 * (row >> 6) + (row & 3);
+  const int i = (int)((row & 63) >> 2);
+  return ((T * nkb + (k >> 5)) * 64 + (((k & 31) >> 3) * 16 + i)) * 8 + (k & 7);
+}
+struct SyrkBf16Desc {
+  const unsigned short* planes;
+  int64_t plane_stride;  // bf16 elements between planes
+  int nkb;               // 32-k blocks per row of the planes' layout (panel width / 32)
+  float* C;
+  int64_t ldc;
+  int m, k;  // multiples of 128 / 32
+};
+constexpr int kSyrkBf16MinRows = 3072;  // below: too few 128-tiles for one workgroup per CU to pay (measured)
+constexpr int kSyrkNbuf = 3;
+constexpr int kSyrkStepBytes = 2 * 3 * 8 * 1024;  // [operand][piece][row tile] x 1 KB
+constexpr int kSyrkLdsBytes = kSyrkNbuf * kSyrkStepBytes;
+
+__global__ __launch_bounds__(256, 1) void syrk_bf16_kernel(SyrkBf16Desc g) {
+  typedef float vecW __attribute__((ext_vector_type(4)));
+  extern __shared__ __align__(16) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // lower tiles, row-major over the triangle (k-length is the same for all: any order balances the XCDs)
+  const int id = (int)blockIdx.x;
+  int ti = (int)((__builtin_sqrtf(8.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
+  while ((ti + 1) * (ti + 2) / 2 <= id) ++ti;
+  while (ti * (ti + 1) / 2 > id) --ti;
+  const int tj = id - ti * (ti + 1) / 2;
+
+  // this wave's DMA pieces: numbers wave, wave + 4, ... of the 48 per step; piece q = (operand, p, tile):
+  // lane l fetches 16 bytes = k0 + 8 (l >> 4) .. + 7 of row  tile0 + 64 (tile / 4) + 4 (l & 15) + tile % 4
+  // (strip rows dealt to the four MFMA tiles of a 64-row strip interleaved)
+  const unsigned short* src[12];
+  int dst[12];
+#pragma unroll
+  for (int s = 0; s < 12; ++s) {
+    const int q = wave + 4 * s, op = q / 24, p = (q % 24) / 8, tile = q % 8;
+    const int64_t T = (int64_t)(op == 0 ? ti : tj) * 8 + tile;  // (tile = 4 (strip of the 128 rows) + x)
+    src[s] = g.planes + (int64_t)p * g.plane_stride + (T * g.nkb * 64 + lane) * 8;
+    dst[s] = q * 1024;
+  }
+  auto issue = [&](int buf) {
+#pragma unroll
+    for (int s = 0; s < 12; ++s) {
+      gemm_glds16(src[s], lds + buf * kSyrkStepBytes + dst[s]);
+      src[s] += 512;  // next 32-k block of the same tile
+    }
+  };
+  const int wr = wave >> 1, wc = wave & 1;
+  const int nsteps = g.k / 32;
+  for (int d = 0; d < kSyrkNbuf - 1; ++d)
+    if (d < nsteps) issue(d);
+  // C tile of this wave into the accumulators (negated: acc = -C, so that acc += A A^T and C = -acc)
+  f32x4 acc[4][4];
+  float* c_base = g.C + (int64_t)(ti * 128 + wr * 64) * g.ldc + tj * 128 + wc * 64 + 4 * (lane & 15);
+  auto c_ptr = [&](int a, int r) { return c_base + (int64_t)(4 * (4 * (lane >> 4) + r) + a) * g.ldc; };
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const vecW v = *reinterpret_cast<const vecW*>(c_ptr(a, r));
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b][r] = -v[b];
+    }
+  int buf = 0;
+  for (int st = 0; st < nsteps; ++st) {
+    // everything but the newest step's 12 DMAs of this wave has landed (tail: everything)
+    if (st + 1 < nsteps) __builtin_amdgcn_s_waitcnt(0x0f70 | (12 & 0xf) | ((12 >> 4) << 14));
+    else __builtin_amdgcn_s_waitcnt(0x0f70);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (st + kSyrkNbuf - 1 < nsteps) issue((buf + kSyrkNbuf - 1) % kSyrkNbuf);
+    const unsigned char* cur = lds + buf * kSyrkStepBytes;
+    u32x4 fa[4][3], fb[4][3];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        fa[x][p] = *reinterpret_cast<const u32x4*>(cur + ((0 * 3 + p) * 8 + wr * 4 + x) * 1024 + lane * 16);
+        fb[x][p] = *reinterpret_cast<const u32x4*>(cur + ((1 * 3 + p) * 8 + wc * 4 + x) * 1024 + lane * 16);
+      }
+#define GPSO_SY(PA, PB) \
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[a][PA]), __builtin_bit_cast(bf16x8, fb[b][PB]), c, 0, 0, 0)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        f32x4 c = acc[a][b];
+        GPSO_SY(2, 0);
+        GPSO_SY(0, 2);
+        GPSO_SY(1, 1);
+        GPSO_SY(1, 0);
+        GPSO_SY(0, 1);
+        GPSO_SY(0, 0);
+        acc[a][b] = c;
+      }
+#undef GPSO_SY
+    buf = (buf + 1 == kSyrkNbuf) ? 0 : buf + 1;
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      vecW v;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) v[b] = -acc[a][b][r];
+      *reinterpret_cast<vecW*>(c_ptr(a, r)) = v;
+    }
+}
+
+static void launch_syrk_bf16(hipStream_t st, const SyrkBf16Desc& g) {
+  if (ensure_dyn_lds(reinterpret_cast<const void*>(&syrk_bf16_kernel), kSyrkLdsBytes)) return;
+  const int64_t nt = g.m / 128;
+  hipLaunchKernelGGL(syrk_bf16_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), kSyrkLdsBytes, st, g);
+}
+
+// float matrix -> its three bf16 planes (test / tool helper; in the fit the TRSM epilogue writes them)
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int64_t ld, int64_t rows,
+                                                           int64_t cols, unsigned short* __restrict__ planes,
+                                                           int64_t plane_stride) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // pair index
+  const int64_t per_row = cols / 2;
+  if (idx >= rows * per_row) return;
+  const int64_t r = idx / per_row, c = 2 * (idx % per_row);
+  float a = src[r * ld + c], b = src[r * ld + c + 1];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    const unsigned u = bf16_split_pair(a, b);
+    *reinterpret_cast<unsigned*>(planes + p * plane_stride + syrk_plane_offset(r, (int)c, (int)(cols / 32))) = u;
+  }
 }
 
 // =============================================================================================
@@ -1328,7 +1503,7 @@ static void potrf_block(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, 
 
 template <typename T>
 int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t n, int64_t npad,
-                 double* diag64, int* info, int64_t single_max) {
+                 double* diag64, int* info, int64_t single_max, unsigned short* lsplit) {
   const bool single = npad <= (single_max >= 0 ? single_max : kSingleLevelMax<T>);
   if (single) {
     potrf_block<T>(st, K, Lf, linv, work, kinv, npad, (int)(npad / kFitBlock), 0, n, diag64, info);
@@ -1355,7 +1530,22 @@ int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t
     t.C = Lf + r1 * npad + c0; t.ldc = npad;
     t.m = m2; t.n = (int)wp; t.k = (int)wp; t.m_last = m2; t.nbatch = 1;
     t.alpha = 1.0; t.beta = 0.0; t.kmode = 4;
+    // float fits: the rank-wp update runs on the bf16 matrix cores (syrk_bf16_kernel) while the trailing
+    // matrix is large enough to fill the chip with its 128-tiles; the TRSM then also emits L21 as bf16 planes
+    const bool bf16_syrk = sizeof(T) == 4 && lsplit != nullptr && m2 >= kSyrkBf16MinRows && wp % 32 == 0;
+    if (bf16_syrk) {
+      t.split = lsplit;
+      t.split_stride = (int64_t)npad * fit_outer_panel(npad);
+      t.split_nkb = (int)(wp / 32);
+    }
     launch_gemm<T>(st, t);
+    if (bf16_syrk) {
+      if constexpr (sizeof(T) == 4) {
+        SyrkBf16Desc sy{lsplit, t.split_stride, t.split_nkb, reinterpret_cast<float*>(K + r1 * npad + r1), npad, m2, (int)wp};
+        launch_syrk_bf16(st, sy);
+      }
+      continue;
+    }
     GemmDesc u{};  // A22 -= L21 L21^T
     u.A = Lf + r1 * npad + c0; u.sai = npad; u.sak = 1;
     u.B = u.A; u.sbk = 1; u.sbj = npad;
@@ -1366,8 +1556,8 @@ int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t
   }
   return 0;
 }
-template int launch_potrf<float>(hipStream_t, float*, float*, float*, float*, float*, int64_t, int64_t, double*, int*, int64_t);
-template int launch_potrf<double>(hipStream_t, double*, double*, double*, double*, double*, int64_t, int64_t, double*, int*, int64_t);
+template int launch_potrf<float>(hipStream_t, float*, float*, float*, float*, float*, int64_t, int64_t, double*, int*, int64_t, unsigned short*);
+template int launch_potrf<double>(hipStream_t, double*, double*, double*, double*, double*, int64_t, int64_t, double*, int*, int64_t, unsigned short*);
 
 // =============================================================================================
 // triangular inverse by level doubling

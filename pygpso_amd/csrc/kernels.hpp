@@ -88,9 +88,11 @@ void launch_gram(hipStream_t st, const double* xs, const double* xnorm, int64_t 
 // Returns bit flags.  Bit 0: linv already holds the COMPLETE inverse (small sizes: it is built beside
 // the factorisation, using work as scratch) and launch_trtri must be skipped.  Bit 1: kinv (nullable:
 // only wanted with the gradient) already holds K^-1 = L^-T L^-1 (lower tiles).
+// lsplit (float fits, nullable): scratch for the bf16 planes of one panel, fit_split_elems(npad) bf16 -- with it
+// the two-level path runs its rank-W trailing updates on the bf16 matrix cores (split-bf16 x6 products)
 template <typename T>
 int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t n, int64_t npad,
-                 double* diag64, int* info, int64_t single_level_max /* < 0: default */);
+                 double* diag64, int* info, int64_t single_level_max /* < 0: default */, unsigned short* lsplit);
 // L^-1 by level-doubling from level first_level (64 or the factorisation's outer panel width): needs the
 // inverses of the first_level-wide diagonal blocks already in linv; work = npad x npad scratch
 // width of the diagonal blocks of the two-level factorisation (and first level of the level-doubling
@@ -98,6 +100,7 @@ int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t
 // 16384 29.95 | 30.18 -- the wider panel halves the passes over the trailing matrix, which pays while
 // the SYRKs are short.
 inline int fit_outer_panel(int64_t npad) { return (npad >= 4096 && npad <= 8192) ? 1024 : 512; }
+inline size_t fit_split_elems(int64_t npad) { return (size_t)3 * (size_t)npad * (size_t)fit_outer_panel(npad); }
 template <typename T>
 void launch_trtri(hipStream_t st, const T* L, T* linv, T* work, int64_t npad, int64_t first_level);
 // zero rows/cols >= n and re-tile the lower 16x16 tiles of L^-1 into the MFMA fragment-major layout

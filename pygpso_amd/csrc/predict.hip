@@ -369,19 +369,6 @@ __global__ __launch_bounds__(256, 2) void leaf_tiles_v2_kernel(
 // <-> point 32 q + 16 + 4 (l >> 4) + (j - 4): the two generated 16-point tiles of the step drop
 // into the B operand without any lane movement.
 // =============================================================================================
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// (a, b) -> packed bf16 pair (round to nearest even); a, b are replaced by the remainders
-__device__ __forceinline__ unsigned bf16_split_pair(float& a, float& b) {
-  const f32x2 v = {a, b};
-  const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-  a -= __builtin_bit_cast(float, u << 16);
-  b -= __builtin_bit_cast(float, u & 0xffff0000u);
-  return u;
-}
 
 // bf16 pieces of L^-1 from the fit-type matrix (TF = float or double: the first piece rounds the
 // full-precision value)
