@@ -78,10 +78,10 @@ typedef struct gpso_ctx gpso_ctx;
 #define GPSO_OPT_FIT_FUSED_SMALL 5 /* 1 (default): N <= 128 is fitted by the single-launch, single-workgroup     */
                                    /* kernel; 0: the general multi-launch path (test hook: results agree to     */
                                    /* rounding)                                                                 */
-#define GPSO_OPT_FIT_BF16_SYRK 6   /* GPSO_F32 contexts, N above the single-level limit: 1 (default) the rank-W      */
-                                   /* trailing updates of the Cholesky run on the bf16 matrix cores as 3-way split  */
-                                   /* products (6 bf16 MFMAs per product, f32 accumulation: f32-class accuracy);    */
-                                   /* 0: plain f32 MFMA                                                             */
+#define GPSO_OPT_FIT_BF16_SYRK 6   /* GPSO_F32 contexts, N above the single-level limit: 1 (default) the large products */
+                                   /* of the fit (rank-W trailing updates, level-doubling inverse) run on the bf16    */
+                                   /* matrix cores as 3-way split products (6 bf16 MFMAs per product, f32             */
+                                   /* accumulation: f32-class accuracy; 4 x 6 N^2 bytes of bf16 planes); 0: f32 MFMA   */
 /* floating-point options (gpso_set_option_f64): tolerances of the self-test */
 #define GPSO_OPTF_TOL_VAR 100  /* max |d var| at the training inputs, relative to the kernel variance (default 1e-4; GPSO_F32: 1e-3) */
 #define GPSO_OPTF_TOL_MEAN 101 /* max |d mean| at the training inputs, relative to max |y - c|   (default 1e-4; GPSO_F32: 1e-3) */

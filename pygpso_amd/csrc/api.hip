@@ -247,8 +247,8 @@ struct EngineT : Engine {
       white, alpha_f, alpha, logdet, scal, gpart, apart, kinv_diag, getter_tmp;
   // split-bf16 copy of L^-1 (float predict with GPSO_OPT_PREDICT_MATH != native)
   DevBuf linv_b;
-  DevBuf lsplit;          // bf16 planes of one panel of the two-level float factorisation
-  bool bf16_fit = true;   // GPSO_OPT_FIT_BF16_SYRK
+  DevBuf pl_L, pl_X, pl_XT, pl_WT;  // bf16 plane sets of the two-level float fit (kernels.hpp: FitPlanes)
+  bool bf16_fit = true;             // GPSO_OPT_FIT_BF16_SYRK
   int math = GPSO_MATH_NATIVE;
   // generation of the cross-Gram tile in float-predict contexts: the OPTION (gen_mode) and what the
   // resident posterior actually uses (gen_eff32).  GPSO_GEN_AUTO starts every posterior in float -- the
@@ -277,7 +277,7 @@ struct EngineT : Engine {
                       &work, &kinvb, &linv_p, &white, &alpha_f, &alpha, &logdet, &scal, &gpart, &apart,
                       &kinv_diag, &getter_tmp, &leaves_raw, &leaves_s, &lnorm, &pvar, &pmean, &omean, &ovar,
                       &oucb, &segoff, &best, &oidx, &ovals, &linv_b, &st_mean, &st_var, &st_out, &grow_key, &live_cnt,
-                      &best_pos, &gath, &wbase, &ovals2, &bhdr, &lsplit})
+                      &best_pos, &gath, &wbase, &ovals2, &bhdr, &pl_L, &pl_X, &pl_XT, &pl_WT})
       if (b->p) (void)hipFree(b->p);
   }
 
@@ -572,15 +572,29 @@ struct EngineT : Engine {
       const int imax = INT_MAX;
       int* info_dev = reinterpret_cast<int*>(as<double>(scal) + 1);
       HIPCHECK(hipMemcpyAsync(info_dev, &imax, sizeof(int), hipMemcpyHostToDevice, s));
-      unsigned short* planes = nullptr;
-      if (sizeof(TF) == 4 && bf16_fit && npad > (single_level_max >= 0 ? single_level_max : 3584)) {
-        if ((rc = ensure(lsplit, fit_split_elems(npad) * 2))) return rc;
-        planes = static_cast<unsigned short*>(lsplit.p);
+      FitPlanes planes{};
+      const FitPlanes* pl = nullptr;
+      if constexpr (sizeof(TF) == 4) {
+        if (bf16_fit && npad > (single_level_max >= 0 ? single_level_max : 3584)) {
+          for (DevBuf* b : {&pl_L, &pl_X, &pl_XT, &pl_WT})
+            if ((rc = ensure(*b, fit_plane_set_bytes(npad)))) return rc;
+          planes = FitPlanes{static_cast<unsigned short*>(pl_L.p), static_cast<unsigned short*>(pl_X.p),
+                             static_cast<unsigned short*>(pl_XT.p), static_cast<unsigned short*>(pl_WT.p),
+                             (int64_t)npad * npad, (int)(npad / 32)};
+          pl = &planes;
+        }
       }
       const int done = launch_potrf<TF>(s, as<TF>(K), as<TF>(Lf), as<TF>(linv), as<TF>(work),
                                         grad ? as<TF>(kinvb) : nullptr, n, npad, as<double>(logdet), info_dev,
-                                        single_level_max, planes);
-      if (!(done & 1)) launch_trtri<TF>(s, as<TF>(Lf), as<TF>(linv), as<TF>(work), npad, fit_outer_panel(npad));
+                                        single_level_max, pl);
+      bool inv_done = (done & 1) != 0;
+      if constexpr (sizeof(TF) == 4) {
+        if (!inv_done && pl != nullptr && trtri_bf16_applies(npad, fit_outer_panel(npad))) {
+          launch_trtri_bf16(s, as<float>(linv), planes, npad, fit_outer_panel(npad));
+          inv_done = true;
+        }
+      }
+      if (!inv_done) launch_trtri<TF>(s, as<TF>(Lf), as<TF>(linv), as<TF>(work), npad, fit_outer_panel(npad));
       launch_solve_alpha<TF>(s, as<TF>(linv), as<double>(y64), n, npad, mean_c, as<double>(logdet),
                              as<TF>(white), as<TF>(alpha_f), as<double>(apart), as<double>(kinv_diag),
                              as<double>(scal));

@@ -532,7 +532,8 @@ struct GemmDesc {
   // syrk_bf16_kernel reads (the TRSM of the two-level Cholesky hands its panel to the SYRK this way)
   unsigned short* split;
   int64_t split_stride;  // bf16 elements between planes
-  int split_nkb;         // 32-column blocks per row of the plane layout (= n / 32)
+  int split_nkb;         // 32-column blocks per row of the plane layout
+  int64_t split_row0, split_col0;  // position of C's (0, 0) in the planes
 };
 
 // =============================================================================================
@@ -797,7 +798,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmDesc g) {
 #pragma unroll
           for (int b = 0; b < WT; b += 2) {
             float x0 = v[b], x1 = v[b + 1];
-            unsigned short* dst = g.split + syrk_plane_offset(row, col + b, g.split_nkb);
+            unsigned short* dst = g.split + syrk_plane_offset(g.split_row0 + row, (int)g.split_col0 + col + b, g.split_nkb);
 #pragma unroll
             for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(dst + p * g.split_stride) = bf16_split_pair(x0, x1);
           }
@@ -869,41 +870,73 @@ __host__ __device__ __forceinline__ int64_t syrk_plane_offset(int64_t row, int k
   const int i = (int)((row & 63) >> 2);
   return ((T * nkb + (k >> 5)) * 64 + (((k & 31) >> 3) * 16 + i)) * 8 + (k & 7);
 }
-struct SyrkBf16Desc {
-  const unsigned short* planes;
-  int64_t plane_stride;  // bf16 elements between planes
-  int nkb;               // 32-k blocks per row of the planes' layout (panel width / 32)
+// A float matrix as three bf16 planes in that layout (nkb = 32-column blocks per row of the layout).
+struct Bf16Planes {
+  unsigned short* p;  // plane 0 (nullptr: absent)
+  int64_t stride;     // bf16 elements between planes
+  int nkb;
+};
+// C (m x n) = alpha * Aop Bop^T + beta * C with Aop = rows a_row0.. / columns a_col0.. of the matrix in planes A
+// (m x k) and Bop likewise (n x k): both operands k-contiguous rows, so a transposed factor is simply the
+// planes of the transposed matrix.  Row offsets are multiples of 64, column offsets of 32; m, n multiples of
+// 128, k of 32.  The result goes to C (float, nullable) and / or to planes: `out` at (o_row0, o_col0), `out_t`
+// -- the TRANSPOSE of the result -- at (ot_row0, ot_col0).  Batch entry z (blockIdx.z) shifts every row and
+// column offset by z * batch_shift and C along its diagonal.
+struct GemmBf16Desc {
+  Bf16Planes A, B;
+  int64_t a_row0, a_col0, b_row0, b_col0;
   float* C;
   int64_t ldc;
-  int m, k;  // multiples of 128 / 32
+  int m, n, k;
+  float alpha;
+  int beta;        // 0 | 1
+  int lower_only;  // only tiles tj <= ti (m == n)
+  int kmode;       // 0: all k | 2: k >= 128 ti | 3: k < 128 (ti + 1)
+  int nbatch;
+  int64_t batch_shift;
+  Bf16Planes out, out_t;
+  int64_t o_row0, o_col0, ot_row0, ot_col0;
 };
 constexpr int kSyrkBf16MinRows = 3072;  // below: too few 128-tiles for one workgroup per CU to pay (measured)
 constexpr int kSyrkNbuf = 3;
 constexpr int kSyrkStepBytes = 2 * 3 * 8 * 1024;  // [operand][piece][row tile] x 1 KB
 constexpr int kSyrkLdsBytes = kSyrkNbuf * kSyrkStepBytes;
 
-__global__ __launch_bounds__(256, 1) void syrk_bf16_kernel(SyrkBf16Desc g) {
+__global__ __launch_bounds__(256, 1) void gemm_bf16_kernel(GemmBf16Desc g) {
   typedef float vecW __attribute__((ext_vector_type(4)));
   extern __shared__ __align__(16) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // lower tiles, row-major over the triangle (k-length is the same for all: any order balances the XCDs)
   const int id = (int)blockIdx.x;
-  int ti = (int)((__builtin_sqrtf(8.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
-  while ((ti + 1) * (ti + 2) / 2 <= id) ++ti;
-  while (ti * (ti + 1) / 2 > id) --ti;
-  const int tj = id - ti * (ti + 1) / 2;
+  int ti, tj;
+  if (g.lower_only) {  // compact triangular enumeration, row-major
+    ti = (int)((__builtin_sqrtf(8.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= id) ++ti;
+    while (ti * (ti + 1) / 2 > id) --ti;
+    tj = id - ti * (ti + 1) / 2;
+  } else {  // row-major; the longest k-ranges first (kmode 2: small ti, kmode 3: large ti)
+    const int ntj = g.n / 128, nti = g.m / 128;
+    ti = id / ntj;
+    tj = id % ntj;
+    if (g.kmode == 3) ti = nti - 1 - ti;
+  }
+  const int64_t zs = (int64_t)blockIdx.z * g.batch_shift;
+  int k_lo = 0, k_hi = g.k;
+  if (g.kmode == 2) k_lo = 128 * ti;
+  if (g.kmode == 3) k_hi = min(g.k, 128 * (ti + 1));
 
-  // this wave's DMA pieces: numbers wave, wave + 4, ... of the 48 per step; piece q = (operand, p, tile):
-  // lane l fetches 16 bytes = k0 + 8 (l >> 4) .. + 7 of row  tile0 + 64 (tile / 4) + 4 (l & 15) + tile % 4
-  // (strip rows dealt to the four MFMA tiles of a 64-row strip interleaved)
+  // this wave's DMA pieces: numbers wave, wave + 4, ... of the 48 per step; piece q = (operand, plane, tile),
+  // tile = 4 (64-row strip of the 128 rows) + x: 1 KB of contiguous memory each
   const unsigned short* src[12];
   int dst[12];
 #pragma unroll
   for (int s = 0; s < 12; ++s) {
     const int q = wave + 4 * s, op = q / 24, p = (q % 24) / 8, tile = q % 8;
-    const int64_t T = (int64_t)(op == 0 ? ti : tj) * 8 + tile;  // (tile = 4 (strip of the 128 rows) + x)
-    src[s] = g.planes + (int64_t)p * g.plane_stride + (T * g.nkb * 64 + lane) * 8;
+    const Bf16Planes& P = (op == 0) ? g.A : g.B;
+    const int64_t row0 = (op == 0 ? g.a_row0 + (int64_t)ti * 128 : g.b_row0 + (int64_t)tj * 128) + zs;
+    const int64_t col0 = (op == 0 ? g.a_col0 : g.b_col0) + zs + k_lo;
+    const int64_t T = 4 * (row0 >> 6) + tile;
+    src[s] = P.p + (int64_t)p * P.stride + ((T * P.nkb + (col0 >> 5)) * 64 + lane) * 8;
     dst[s] = q * 1024;
   }
   auto issue = [&](int buf) {
@@ -914,21 +947,30 @@ __global__ __launch_bounds__(256, 1) void syrk_bf16_kernel(SyrkBf16Desc g) {
     }
   };
   const int wr = wave >> 1, wc = wave & 1;
-  const int nsteps = g.k / 32;
+  const int nsteps = (k_hi - k_lo) / 32;
   for (int d = 0; d < kSyrkNbuf - 1; ++d)
     if (d < nsteps) issue(d);
-  // C tile of this wave into the accumulators (negated: acc = -C, so that acc += A A^T and C = -acc)
+  // acc = (beta / alpha) * C, so that the loop adds A B^T and the epilogue scales by alpha
   f32x4 acc[4][4];
-  float* c_base = g.C + (int64_t)(ti * 128 + wr * 64) * g.ldc + tj * 128 + wc * 64 + 4 * (lane & 15);
+  const int row_w = ti * 128 + wr * 64, col_w = tj * 128 + wc * 64 + 4 * (lane & 15);  // this lane's rows / columns in C
+  float* c_base = (g.C != nullptr) ? g.C + zs * g.ldc + zs + (int64_t)row_w * g.ldc + col_w : nullptr;
   auto c_ptr = [&](int a, int r) { return c_base + (int64_t)(4 * (4 * (lane >> 4) + r) + a) * g.ldc; };
+  if (g.beta != 0 && c_base != nullptr) {
+    const float sc = 1.0f / g.alpha;
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const vecW v = *reinterpret_cast<const vecW*>(c_ptr(a, r));
+      for (int r = 0; r < 4; ++r) {
+        const vecW v = *reinterpret_cast<const vecW*>(c_ptr(a, r));
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b][r] = -v[b];
-    }
+        for (int b = 0; b < 4; ++b) acc[a][b][r] = sc * v[b];
+      }
+  } else {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0, 0, 0, 0};
+  }
   int buf = 0;
   for (int st = 0; st < nsteps; ++st) {
     // everything but the newest step's 12 DMAs of this wave has landed (tail: everything)
@@ -971,18 +1013,69 @@ __global__ __launch_bounds__(256, 1) void syrk_bf16_kernel(SyrkBf16Desc g) {
     for (int r = 0; r < 4; ++r) {
       vecW v;
 #pragma unroll
-      for (int b = 0; b < 4; ++b) v[b] = -acc[a][b][r];
-      *reinterpret_cast<vecW*>(c_ptr(a, r)) = v;
+      for (int b = 0; b < 4; ++b) v[b] = g.alpha * acc[a][b][r];
+      if (c_base != nullptr) *reinterpret_cast<vecW*>(c_ptr(a, r)) = v;
+      const int64_t row = row_w + 4 * (4 * (lane >> 4) + r) + a;  // (row, col_w .. col_w + 3) of the result
+      if (g.out.p != nullptr) {
+#pragma unroll
+        for (int b = 0; b < 4; b += 2) {
+          float x0 = v[b], x1 = v[b + 1];
+          unsigned short* d = g.out.p + syrk_plane_offset(g.o_row0 + zs + row, (int)(g.o_col0 + zs) + col_w + b, g.out.nkb);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(d + p * g.out.stride) = bf16_split_pair(x0, x1);
+        }
+      }
+      if (g.out_t.p != nullptr) {  // element (row, col) of the result is element (col, row) of the transpose
+#pragma unroll
+        for (int b = 0; b < 4; b += 2) {
+          float x0 = v[b], x1 = v[b + 1];
+          unsigned short* d0 = g.out_t.p + syrk_plane_offset(g.ot_row0 + zs + col_w + b, (int)(g.ot_col0 + zs + row), g.out_t.nkb);
+          unsigned short* d1 = g.out_t.p + syrk_plane_offset(g.ot_row0 + zs + col_w + b + 1, (int)(g.ot_col0 + zs + row), g.out_t.nkb);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            const unsigned u = bf16_split_pair(x0, x1);
+            d0[p * g.out_t.stride] = (unsigned short)(u & 0xffffu);
+            d1[p * g.out_t.stride] = (unsigned short)(u >> 16);
+          }
+        }
+      }
     }
 }
 
-static void launch_syrk_bf16(hipStream_t st, const SyrkBf16Desc& g) {
-  if (ensure_dyn_lds(reinterpret_cast<const void*>(&syrk_bf16_kernel), kSyrkLdsBytes)) return;
-  const int64_t nt = g.m / 128;
-  hipLaunchKernelGGL(syrk_bf16_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), kSyrkLdsBytes, st, g);
+static void launch_gemm_bf16(hipStream_t st, const GemmBf16Desc& g) {
+  if (ensure_dyn_lds(reinterpret_cast<const void*>(&gemm_bf16_kernel), kSyrkLdsBytes)) return;
+  const int64_t nti = g.m / 128, ntj = g.n / 128;
+  const int64_t ntiles = g.lower_only ? nti * (nti + 1) / 2 : nti * ntj;
+  hipLaunchKernelGGL(gemm_bf16_kernel, dim3((unsigned)ntiles, 1, (unsigned)g.nbatch), dim3(256), kSyrkLdsBytes, st, g);
 }
 
-// float matrix -> its three bf16 planes (test / tool helper; in the fit the TRSM epilogue writes them)
+// a float block (rows x cols at src, leading dimension ld) -> planes at (row0, col0) and / or its transpose at
+// (trow0, tcol0): the diagonal blocks of L^-1, which the step kernels produce in float
+__global__ __launch_bounds__(256) void block_to_planes_kernel(const float* __restrict__ src, int64_t ld, int rows,
+                                                              int cols, int64_t batch_src, int64_t batch_shift,
+                                                              Bf16Planes out, int64_t row0, int64_t col0,
+                                                              Bf16Planes out_t, int64_t trow0, int64_t tcol0) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // pair index inside a block
+  const int per_row = cols / 2;
+  if (idx >= (int64_t)rows * per_row) return;
+  const int64_t zs = (int64_t)blockIdx.y * batch_shift;
+  const int64_t r = idx / per_row;
+  const int c = 2 * (int)(idx % per_row);
+  const float* s = src + (int64_t)blockIdx.y * batch_src + r * ld + c;
+  float a = s[0], b = s[1];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    const unsigned u = bf16_split_pair(a, b);
+    if (out.p != nullptr)
+      *reinterpret_cast<unsigned*>(out.p + p * out.stride + syrk_plane_offset(row0 + zs + r, (int)(col0 + zs) + c, out.nkb)) = u;
+    if (out_t.p != nullptr) {
+      out_t.p[p * out_t.stride + syrk_plane_offset(trow0 + zs + c, (int)(tcol0 + zs + r), out_t.nkb)] = (unsigned short)(u & 0xffffu);
+      out_t.p[p * out_t.stride + syrk_plane_offset(trow0 + zs + c + 1, (int)(tcol0 + zs + r), out_t.nkb)] = (unsigned short)(u >> 16);
+    }
+  }
+}
+
+// float matrix (rows x cols, leading dimension ld) -> planes of its own (tools/micro/syrk_bench.hip)
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int64_t ld, int64_t rows,
                                                            int64_t cols, unsigned short* __restrict__ planes,
                                                            int64_t plane_stride) {
@@ -1503,7 +1596,7 @@ static void potrf_block(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, 
 
 template <typename T>
 int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t n, int64_t npad,
-                 double* diag64, int* info, int64_t single_max, unsigned short* lsplit) {
+                 double* diag64, int* info, int64_t single_max, const FitPlanes* planes) {
   const bool single = npad <= (single_max >= 0 ? single_max : kSingleLevelMax<T>);
   if (single) {
     potrf_block<T>(st, K, Lf, linv, work, kinv, npad, (int)(npad / kFitBlock), 0, n, diag64, info);
@@ -1530,19 +1623,33 @@ int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t
     t.C = Lf + r1 * npad + c0; t.ldc = npad;
     t.m = m2; t.n = (int)wp; t.k = (int)wp; t.m_last = m2; t.nbatch = 1;
     t.alpha = 1.0; t.beta = 0.0; t.kmode = 4;
-    // float fits: the rank-wp update runs on the bf16 matrix cores (syrk_bf16_kernel) while the trailing
-    // matrix is large enough to fill the chip with its 128-tiles; the TRSM then also emits L21 as bf16 planes
-    const bool bf16_syrk = sizeof(T) == 4 && lsplit != nullptr && m2 >= kSyrkBf16MinRows && wp % 32 == 0;
-    if (bf16_syrk) {
-      t.split = lsplit;
-      t.split_stride = (int64_t)npad * fit_outer_panel(npad);
-      t.split_nkb = (int)(wp / 32);
+    // float fits with bf16 planes: the TRSM also emits L21 into the planes of L (the level-doubling inverse
+    // and the rank-wp update read it from there), and the update runs on the bf16 matrix cores
+    // (gemm_bf16_kernel) while the trailing matrix is large enough to fill the chip with 128-tiles
+    const bool have_planes = sizeof(T) == 4 && planes != nullptr && planes->L != nullptr;
+    if (have_planes) {
+      t.split = planes->L;
+      t.split_stride = planes->stride;
+      t.split_nkb = planes->nkb;
+      t.split_row0 = r1;
+      t.split_col0 = c0;
     }
     launch_gemm<T>(st, t);
-    if (bf16_syrk) {
+    if (have_planes && m2 >= kSyrkBf16MinRows) {
       if constexpr (sizeof(T) == 4) {
-        SyrkBf16Desc sy{lsplit, t.split_stride, t.split_nkb, reinterpret_cast<float*>(K + r1 * npad + r1), npad, m2, (int)wp};
-        launch_syrk_bf16(st, sy);
+        GemmBf16Desc sy{};
+        sy.A = sy.B = Bf16Planes{planes->L, planes->stride, planes->nkb};
+        sy.a_row0 = sy.b_row0 = r1;
+        sy.a_col0 = sy.b_col0 = c0;
+        sy.C = reinterpret_cast<float*>(K + r1 * npad + r1);
+        sy.ldc = npad;
+        sy.m = sy.n = m2;
+        sy.k = (int)wp;
+        sy.alpha = -1.0f;
+        sy.beta = 1;
+        sy.lower_only = 1;
+        sy.nbatch = 1;
+        launch_gemm_bf16(st, sy);
       }
       continue;
     }
@@ -1556,8 +1663,8 @@ int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t
   }
   return 0;
 }
-template int launch_potrf<float>(hipStream_t, float*, float*, float*, float*, float*, int64_t, int64_t, double*, int*, int64_t, unsigned short*);
-template int launch_potrf<double>(hipStream_t, double*, double*, double*, double*, double*, int64_t, int64_t, double*, int*, int64_t, unsigned short*);
+template int launch_potrf<float>(hipStream_t, float*, float*, float*, float*, float*, int64_t, int64_t, double*, int*, int64_t, const FitPlanes*);
+template int launch_potrf<double>(hipStream_t, double*, double*, double*, double*, double*, int64_t, int64_t, double*, int*, int64_t, const FitPlanes*);
 
 // =============================================================================================
 // triangular inverse by level doubling
@@ -1597,6 +1704,53 @@ void launch_trtri(hipStream_t st, const T* L, T* linv, T* work, int64_t npad, in
     launch_gemm<T>(st, b);
   }
 }
+// The same level doubling on the bf16 matrix cores (float fits; N_pad / first_level a power of two).  All
+// operands are read as k-contiguous rows of plane sets: L (written by the TRSM epilogues), X = L^-1, XT = its
+// transpose, WT = scratch.  Level with half-size s, pair [A | B]:
+//   WT[A,B]   = XT[A,A] L[B,A]^T            (= (L[B,A] Linv[A,A])^T;  XT[A,A][j][r] = 0 for r < j  -> k >= 128 ti)
+//   Linv[B,A] = -X[B,B] (WT[A,B])^T         (X[B,B][i][k] = 0 for k > i                         -> k < 128 (ti + 1))
+// the second product writes the float result into linv and its pieces into X and -- transposed -- into XT, which
+// is what the next level reads.  The diagonal blocks of L^-1 (float, from the step kernels) enter X / XT first.
+void launch_trtri_bf16(hipStream_t st, float* linv, const FitPlanes& pl, int64_t npad, int64_t first_level) {
+  const Bf16Planes L{pl.L, pl.stride, pl.nkb}, X{pl.X, pl.stride, pl.nkb}, XT{pl.XT, pl.stride, pl.nkb},
+      WT{pl.WT, pl.stride, pl.nkb}, none{nullptr, 0, 0};
+  {
+    const int fl = (int)first_level, nb = (int)(npad / first_level);
+    const int64_t pairs = (int64_t)fl * fl / 2;
+    hipLaunchKernelGGL(block_to_planes_kernel, dim3((unsigned)((pairs + 255) / 256), (unsigned)nb), dim3(256), 0, st, linv,
+                       npad, fl, fl, (int64_t)fl * npad + fl, (int64_t)fl, X, (int64_t)0, (int64_t)0, XT, (int64_t)0,
+                       (int64_t)0);
+  }
+  for (int64_t s = first_level; s < npad; s *= 2) {
+    const int nb = (int)(npad / (2 * s));
+    GemmBf16Desc a{};  // WT[A,B]
+    a.A = XT; a.a_row0 = 0; a.a_col0 = 0;
+    a.B = L; a.b_row0 = s; a.b_col0 = 0;
+    a.C = nullptr; a.ldc = npad;
+    a.m = a.n = a.k = (int)s;
+    a.alpha = 1.0f; a.beta = 0; a.kmode = 2;
+    a.nbatch = nb; a.batch_shift = 2 * s;
+    a.out = WT; a.o_row0 = 0; a.o_col0 = s;
+    a.out_t = none;
+    launch_gemm_bf16(st, a);
+    GemmBf16Desc b{};  // Linv[B,A]
+    b.A = X; b.a_row0 = s; b.a_col0 = s;
+    b.B = WT; b.b_row0 = 0; b.b_col0 = s;
+    b.C = linv + s * npad; b.ldc = npad;
+    b.m = b.n = b.k = (int)s;
+    b.alpha = -1.0f; b.beta = 0; b.kmode = 3;
+    b.nbatch = nb; b.batch_shift = 2 * s;
+    b.out = X; b.o_row0 = s; b.o_col0 = 0;
+    b.out_t = XT; b.ot_row0 = 0; b.ot_col0 = s;
+    if (2 * s >= npad) b.out = b.out_t = none;  // last level: nobody reads the planes afterwards
+    launch_gemm_bf16(st, b);
+  }
+}
+bool trtri_bf16_applies(int64_t npad, int64_t first_level) {
+  const int64_t q = npad / first_level;
+  return npad % first_level == 0 && q >= 2 && (q & (q - 1)) == 0;
+}
+
 template void launch_trtri<float>(hipStream_t, const float*, float*, float*, int64_t, int64_t);
 template void launch_trtri<double>(hipStream_t, const double*, double*, double*, int64_t, int64_t);
 

@@ -88,11 +88,23 @@ void launch_gram(hipStream_t st, const double* xs, const double* xnorm, int64_t 
 // Returns bit flags.  Bit 0: linv already holds the COMPLETE inverse (small sizes: it is built beside
 // the factorisation, using work as scratch) and launch_trtri must be skipped.  Bit 1: kinv (nullable:
 // only wanted with the gradient) already holds K^-1 = L^-T L^-1 (lower tiles).
-// lsplit (float fits, nullable): scratch for the bf16 planes of one panel, fit_split_elems(npad) bf16 -- with it
-// the two-level path runs its rank-W trailing updates on the bf16 matrix cores (split-bf16 x6 products)
+// Float fits above the single-level limit can run their large products on the bf16 matrix cores (3-way split,
+// six bf16 MFMAs per product: float-class accuracy).  The operands then live as bf16 planes of N_pad x N_pad
+// matrices (fit_plane_set_bytes(npad) each): L, X = L^-1, XT = X^T, WT = scratch (fit.hip: gemm_bf16_kernel).
+struct FitPlanes {
+  unsigned short *L, *X, *XT, *WT;
+  int64_t stride;  // bf16 elements between the three planes of a set
+  int nkb;         // npad / 32
+};
+inline size_t fit_plane_set_bytes(int64_t npad) { return (size_t)3 * (size_t)npad * (size_t)npad * 2; }
+// planes (float fits, nullable): with them the TRSM GEMMs also emit L into planes->L and the rank-W trailing
+// updates run on the bf16 matrix cores
 template <typename T>
 int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t n, int64_t npad,
-                 double* diag64, int* info, int64_t single_level_max /* < 0: default */, unsigned short* lsplit);
+                 double* diag64, int* info, int64_t single_level_max /* < 0: default */, const FitPlanes* planes);
+// the level-doubling inverse on the bf16 matrix cores (after a launch_potrf with the same planes)
+void launch_trtri_bf16(hipStream_t st, float* linv, const FitPlanes& planes, int64_t npad, int64_t first_level);
+bool trtri_bf16_applies(int64_t npad, int64_t first_level);
 // L^-1 by level-doubling from level first_level (64 or the factorisation's outer panel width): needs the
 // inverses of the first_level-wide diagonal blocks already in linv; work = npad x npad scratch
 // width of the diagonal blocks of the two-level factorisation (and first level of the level-doubling
@@ -100,7 +112,6 @@ int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t
 // 16384 29.95 | 30.18 -- the wider panel halves the passes over the trailing matrix, which pays while
 // the SYRKs are short.
 inline int fit_outer_panel(int64_t npad) { return (npad >= 4096 && npad <= 8192) ? 1024 : 512; }
-inline size_t fit_split_elems(int64_t npad) { return (size_t)3 * (size_t)npad * (size_t)fit_outer_panel(npad); }
 template <typename T>
 void launch_trtri(hipStream_t st, const T* L, T* linv, T* work, int64_t npad, int64_t first_level);
 // zero rows/cols >= n and re-tile the lower 16x16 tiles of L^-1 into the MFMA fragment-major layout

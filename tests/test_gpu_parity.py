@@ -599,3 +599,30 @@ def _c4_posterior(th, X, y):
     if "post" not in _c4_cache:  # one CPU factorisation at N = 8192 for the three math modes
         _c4_cache["post"] = gpr.posterior(th, X, y)
     return _c4_cache["post"]
+
+
+def test_float_fit_on_the_bf16_matrix_cores_agrees_with_the_f32_path():
+    """Float fits above the single-level limit run their large products (rank-W trailing updates, level-doubling
+    inverse) as 3-way split bf16 products by default (GPSO_OPT_FIT_BF16_SYRK): float-class accuracy.  N = 4096
+    (N_pad / panel a power of two: both the update and the inverse take the bf16 path) against the same fit on
+    the f32 MFMA, and against the float64 oracle."""
+    from pygpso_amd import HipGPEngine, _lib as L
+
+    n, d = 4096, 6
+    X, y, th = _problem(n, d, variance=1.0, noise=1e-2)
+    post = gpr.posterior(th, X, y)
+    res = {}
+    for flag in (1, 0):
+        eng = HipGPEngine("float32")
+        eng._check(eng._lib.gpso_set_option(eng._h, L.OPT_FIT_BF16_SYRK, flag))
+        f, _ = _fit(eng, X, y, th, grad=False)
+        res[flag] = (f, eng.get_matrix(L.MAT_LINV), eng.get_vector(L.VEC_ALPHA), eng.get_matrix(L.MAT_CHOL))
+    for flag in (1, 0):  # each path against the oracle, float tolerances
+        f, linv, alpha, chol = res[flag]
+        assert abs(f - post.nlml) <= 2e-5 * abs(post.nlml), flag
+        assert np.max(np.abs(chol - post.L)) <= 2e-4 * np.max(np.abs(post.L)), flag
+        assert np.max(np.abs(alpha - post.alpha)) <= 2e-3 * np.max(np.abs(post.alpha)), flag
+    # and against each other: the split products are float-class
+    scale = np.max(np.abs(res[0][1]))
+    assert np.max(np.abs(res[1][1] - res[0][1])) <= 2e-4 * scale
+    assert np.max(np.abs(res[1][3] - res[0][3])) <= 1e-5 * np.max(np.abs(res[0][3]))

@@ -24,7 +24,7 @@ int main(int argc, char** argv) {
     hipMemset(X, 0, h.size() * 4);
     int imax = 2147483647; hipMemcpy(info, &imax, 4, hipMemcpyHostToDevice);
     hipEventRecord(e0, 0);
-    if (!(1 & launch_potrf<float>(0, K, Lf, X, Wk, (float*)nullptr, n, n, dg, info, (argc > 2) ? atoll(argv[2]) : -1, nullptr))) launch_trtri<float>(0, Lf, X, Wk, n, fit_outer_panel(n));
+    if (!(1 & launch_potrf<float>(0, K, Lf, X, Wk, (float*)nullptr, n, n, dg, info, (argc > 2) ? atoll(argv[2]) : -1, (const FitPlanes*)nullptr))) launch_trtri<float>(0, Lf, X, Wk, n, fit_outer_panel(n));
     hipEventRecord(e1, 0);
     hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);

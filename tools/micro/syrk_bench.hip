@@ -27,7 +27,7 @@ int main(int argc, char** argv) {
   GemmDesc u{};
   u.A = A; u.sai = ld; u.sak = 1; u.B = A; u.sbk = 1; u.sbj = ld; u.ldc = ld;
   u.m = (int)m; u.n = (int)m; u.k = (int)k; u.m_last = (int)m; u.nbatch = 1; u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1;
-  SyrkBf16Desc b{P, (int64_t)hA.size(), (int)(k / 32), C2, ld, (int)m, (int)k};
+  GemmBf16Desc b{}; b.A = b.B = Bf16Planes{P, (int64_t)hA.size(), (int)(k / 32)}; b.C = C2; b.ldc = ld; b.m = b.n = (int)m; b.k = (int)k; b.alpha = -1.0f; b.beta = 1; b.lower_only = 1; b.nbatch = 1;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const double gf = (double)m * m * k / 1e9;
   for (int rep = 0; rep < 3; ++rep) {
@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
     float t1, t2;
     u.C = C1;
     hipEventRecord(e0, 0); launch_gemm<float>(0, u); hipEventRecord(e1, 0); hipDeviceSynchronize(); hipEventElapsedTime(&t1, e0, e1);
-    hipEventRecord(e0, 0); launch_syrk_bf16(0, b); hipEventRecord(e1, 0); hipDeviceSynchronize(); hipEventElapsedTime(&t2, e0, e1);
+    hipEventRecord(e0, 0); launch_gemm_bf16(0, b); hipEventRecord(e1, 0); hipDeviceSynchronize(); hipEventElapsedTime(&t2, e0, e1);
     std::vector<float> r1(hC.size()), r2(hC.size());
     hipMemcpy(r1.data(), C1, r1.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(r2.data(), C2, r2.size() * 4, hipMemcpyDeviceToHost);
     double maxd = 0, maxv = 0;
