@@ -902,33 +902,87 @@ constexpr int kSyrkNbuf = 3;
 constexpr int kSyrkStepBytes = 2 * 3 * 8 * 1024;  // [operand][piece][row tile] x 1 KB
 constexpr int kSyrkLdsBytes = kSyrkNbuf * kSyrkStepBytes;
 
+#ifndef GPSO_GSTAMP
+#define GPSO_GSTAMP(st, i)  // tools/micro/syrk_bench.hip defines this to record s_memtime stamps per k-step
+#endif
+// super-tile: tile rows x tile columns that one XCD works on at a time (square for the triangular enumeration)
+struct BfTiling {
+  int nti, ntj, sr, sc, nsi, nsj, per_super, nsuper;
+};
+__host__ __device__ __forceinline__ BfTiling bf16_tiling(const GemmBf16Desc& g) {
+  BfTiling tl;
+  tl.nti = g.m / 128;
+  tl.ntj = g.n / 128;
+  tl.sr = min(4, tl.nti);
+  tl.sc = min(g.lower_only ? 4 : 8, tl.ntj);
+  tl.nsi = (tl.nti + tl.sr - 1) / tl.sr;
+  tl.nsj = (tl.ntj + tl.sc - 1) / tl.sc;
+  tl.per_super = tl.sr * tl.sc;
+  tl.nsuper = g.lower_only ? tl.nsi * (tl.nsi + 1) / 2 : tl.nsi * tl.nsj;
+  return tl;
+}
+
 __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel(GemmBf16Desc g) {
   typedef float vecW __attribute__((ext_vector_type(4)));
   extern __shared__ __align__(16) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int id = (int)blockIdx.x;
-  int ti, tj;
-  if (g.lower_only) {  // compact triangular enumeration, row-major
-    ti = (int)((__builtin_sqrtf(8.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
-    while ((ti + 1) * (ti + 2) / 2 <= id) ++ti;
-    while (ti * (ti + 1) / 2 > id) --ti;
-    tj = id - ti * (ti + 1) / 2;
-  } else {  // row-major; the longest k-ranges first (kmode 2: small ti, kmode 3: large ti)
-    const int ntj = g.n / 128, nti = g.m / 128;
-    ti = id / ntj;
-    tj = id % ntj;
-    if (g.kmode == 3) ti = nti - 1 - ti;
+  // Tile of this workgroup.  The grid is 1-D over super-tiles (4 x 8 tiles, 4 x 4 in the triangular case), and
+  // super-tile s of the sequence runs on XCD s % 8 (the hardware deals consecutive workgroups to the XCDs
+  // round-robin): the 32 workgroups an XCD holds at a time then read 12-16 operand tiles between them instead of
+  // up to 64, so that most of the LDS-DMA traffic is served by that XCD's L2 (a 128 x 128 tile of six-MFMA
+  // products needs 48 KB per 0.65 us of MFMA work).  No loops or tables in the decode: it is on every tile's
+  // critical path (a per-row scan cost 8k clocks of a ~70k-clock tile).
+  GPSO_GSTAMP(38, 0);
+  int ti, tj, bz;
+  {
+    const BfTiling tl = bf16_tiling(g);
+    const int id = (int)blockIdx.x, x = id & 7, j = id >> 3;
+    const int sg = (j / tl.per_super) * 8 + x, t = j % tl.per_super;
+    if (sg >= tl.nsuper * g.nbatch) return;
+    bz = sg % g.nbatch;
+    int sl = sg / g.nbatch, I, J;
+    if (g.lower_only) {  // compact triangular enumeration of the super-tiles, row-major
+      I = (int)((__builtin_sqrtf(8.0f * (float)sl + 1.0f) - 1.0f) * 0.5f);
+      while ((I + 1) * (I + 2) / 2 <= sl) ++I;
+      while (I * (I + 1) / 2 > sl) --I;
+      J = sl - I * (I + 1) / 2;
+    } else {
+      I = sl / tl.nsj;
+      J = sl % tl.nsj;
+      if (g.kmode == 3) I = tl.nsi - 1 - I;  // the longest k-ranges first (kmode 2: small ti, kmode 3: large ti)
+    }
+    ti = I * tl.sr + t / tl.sc;
+    tj = J * tl.sc + t % tl.sc;
+    if (ti >= tl.nti || tj >= tl.ntj || (g.lower_only && tj > ti)) return;
   }
-  const int64_t zs = (int64_t)blockIdx.z * g.batch_shift;
+  GPSO_GSTAMP(39, 0);
+  const int64_t zs = (int64_t)bz * g.batch_shift;
   int k_lo = 0, k_hi = g.k;
   if (g.kmode == 2) k_lo = 128 * ti;
   if (g.kmode == 3) k_hi = min(g.k, 128 * (ti + 1));
 
+  // C first: its loads are the longest latency of the prologue, the DMA issue that follows overlaps it
+  const int wr = wave >> 1, wc = wave & 1;
+  f32x4 acc[4][4];
+  const int row_w = ti * 128 + wr * 64, col_w = tj * 128 + wc * 64 + 4 * (lane & 15);  // this lane's rows / columns in C
+  float* c_base = (g.C != nullptr) ? g.C + zs * g.ldc + zs + (int64_t)row_w * g.ldc + col_w : nullptr;
+  auto c_ptr = [&](int a, int r) { return c_base + (int64_t)(4 * (4 * (lane >> 4) + r) + a) * g.ldc; };
+  const bool with_c = g.beta != 0 && c_base != nullptr;
+  vecW cin[4][4];
+  if (with_c) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cin[a][r] = *reinterpret_cast<const vecW*>(c_ptr(a, r));
+  }
+  GPSO_GSTAMP(39, 1);
   // this wave's DMA pieces: numbers wave, wave + 4, ... of the 48 per step; piece q = (operand, plane, tile),
   // tile = 4 (64-row strip of the 128 rows) + x: 1 KB of contiguous memory each
-  const unsigned short* src[12];
+  // (wave-uniform bases in SGPRs + one per-lane byte offset: the k-loop advances them on the scalar unit)
+  const unsigned char* src[12];
   int dst[12];
+  const unsigned lane_off = (unsigned)lane * 16u;
 #pragma unroll
   for (int s = 0; s < 12; ++s) {
     const int q = wave + 4 * s, op = q / 24, p = (q % 24) / 8, tile = q % 8;
@@ -936,77 +990,129 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel(GemmBf16Desc g) {
     const int64_t row0 = (op == 0 ? g.a_row0 + (int64_t)ti * 128 : g.b_row0 + (int64_t)tj * 128) + zs;
     const int64_t col0 = (op == 0 ? g.a_col0 : g.b_col0) + zs + k_lo;
     const int64_t T = 4 * (row0 >> 6) + tile;
-    src[s] = P.p + (int64_t)p * P.stride + ((T * P.nkb + (col0 >> 5)) * 64 + lane) * 8;
+    const uint64_t b = reinterpret_cast<uint64_t>(P.p + (int64_t)p * P.stride + (T * P.nkb + (col0 >> 5)) * 512);
+    const unsigned b_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)), b_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    src[s] = reinterpret_cast<const unsigned char*>(((uint64_t)b_hi << 32) | (uint64_t)b_lo);
     dst[s] = q * 1024;
   }
   auto issue = [&](int buf) {
 #pragma unroll
     for (int s = 0; s < 12; ++s) {
-      gemm_glds16(src[s], lds + buf * kSyrkStepBytes + dst[s]);
-      src[s] += 512;  // next 32-k block of the same tile
+      gemm_glds16(src[s] + lane_off, lds + buf * kSyrkStepBytes + dst[s]);
+      src[s] += 1024;  // next 32-k block of the same tile
     }
   };
-  const int wr = wave >> 1, wc = wave & 1;
   const int nsteps = (k_hi - k_lo) / 32;
-  for (int d = 0; d < kSyrkNbuf - 1; ++d)
+  for (int d = 0; d < kSyrkNbuf; ++d)
     if (d < nsteps) issue(d);
+  GPSO_GSTAMP(39, 2);
   // acc = (beta / alpha) * C, so that the loop adds A B^T and the epilogue scales by alpha
-  f32x4 acc[4][4];
-  const int row_w = ti * 128 + wr * 64, col_w = tj * 128 + wc * 64 + 4 * (lane & 15);  // this lane's rows / columns in C
-  float* c_base = (g.C != nullptr) ? g.C + zs * g.ldc + zs + (int64_t)row_w * g.ldc + col_w : nullptr;
-  auto c_ptr = [&](int a, int r) { return c_base + (int64_t)(4 * (4 * (lane >> 4) + r) + a) * g.ldc; };
-  if (g.beta != 0 && c_base != nullptr) {
+  if (with_c) {
     const float sc = 1.0f / g.alpha;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const vecW v = *reinterpret_cast<const vecW*>(c_ptr(a, r));
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b][r] = sc * v[b];
-      }
+        for (int b = 0; b < 4; ++b) acc[a][b][r] = sc * cin[a][r][b];
   } else {
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0, 0, 0, 0};
   }
-  int buf = 0;
-  for (int st = 0; st < nsteps; ++st) {
-    // everything but the newest step's 12 DMAs of this wave has landed (tail: everything)
-    if (st + 1 < nsteps) __builtin_amdgcn_s_waitcnt(0x0f70 | (12 & 0xf) | ((12 >> 4) << 14));
-    else __builtin_amdgcn_s_waitcnt(0x0f70);
+  // The k-loop is software-pipelined by hand: one wave per SIMD has nobody to hide behind, and the 12 LDS-DMA
+  // instructions of a step occupy the CU's address path for ~770 clocks (64 B / clk) -- issued in one burst
+  // they stalled the wave for ~600 of the ~1540 clocks its 96 MFMAs take (s_memtime stamps).  So while the
+  // MFMAs of step st run on the fragments in one register set, the wave (a) reads the fragments of step st + 1
+  // from LDS into the other set and (b) issues the DMAs of step st + 3 into the buffer step st was read from,
+  // two reads and one DMA behind every group of six MFMAs (sched_barrier pins that order).
+  u32x4 F[2][2][4][3];  // [set][operand][tile][piece]
+  auto frag_ptr = [&](int buf, int r) {  // read r of a step: operand r / 12, tile (r % 12) / 3, piece r % 3
+    const int op = r / 12, x = (r % 12) / 3, p = r % 3;
+    return reinterpret_cast<const u32x4*>(lds + buf * kSyrkStepBytes + ((op * 3 + p) * 8 + (op == 0 ? wr : wc) * 4 + x) * 1024 + lane * 16);
+  };
+  auto wait_landed = [&](int newer_groups) {  // all but this wave's newest 12 * newer_groups DMAs, and every LDS read
+    if (newer_groups >= 2) __builtin_amdgcn_s_waitcnt(0x0070 | (24 & 0xf) | ((24 >> 4) << 14));
+    else if (newer_groups == 1) __builtin_amdgcn_s_waitcnt(0x0070 | (12 & 0xf) | ((12 >> 4) << 14));
+    else __builtin_amdgcn_s_waitcnt(0x0070);
     asm volatile("" ::: "memory");
+  };
+  // kSteady: steps st + 3 < nsteps, where the reads and the DMAs are unconditional and the body is branch-free
+  auto step_body = [&](auto setc, auto steadyc, int st, int buf) {
+    constexpr int S = decltype(setc)::value;
+    constexpr bool kSteady = decltype(steadyc)::value;
+    GPSO_GSTAMP(st, 0);
+    // step st + 1 has landed (the reads below need it); the fragments of this step, read during the last one,
+    // are in registers on every wave once all have passed the barrier, so its buffer may be overwritten
+    if (kSteady) wait_landed(1);
+    else wait_landed(min(nsteps, st + 3) - min(nsteps, st + 2));
+    GPSO_GSTAMP(st, 1);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (st + kSyrkNbuf - 1 < nsteps) issue((buf + kSyrkNbuf - 1) % kSyrkNbuf);
-    const unsigned char* cur = lds + buf * kSyrkStepBytes;
-    u32x4 fa[4][3], fb[4][3];
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        fa[x][p] = *reinterpret_cast<const u32x4*>(cur + ((0 * 3 + p) * 8 + wr * 4 + x) * 1024 + lane * 16);
-        fb[x][p] = *reinterpret_cast<const u32x4*>(cur + ((1 * 3 + p) * 8 + wc * 4 + x) * 1024 + lane * 16);
-      }
+    GPSO_GSTAMP(st, 2);
+    const bool do_rd = kSteady || st + 1 < nsteps, do_dma = kSteady || st + 3 < nsteps;
+    const int buf_rd = (buf + 1 == kSyrkNbuf) ? 0 : buf + 1;
+    unsigned char* const dma_base = lds + buf * kSyrkStepBytes;
+    auto read_frag = [&](int r) {
+      if (do_rd) F[1 - S][r / 12][(r % 12) / 3][r % 3] = *frag_ptr(buf_rd, r);
+    };
 #define GPSO_SY(PA, PB) \
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[a][PA]), __builtin_bit_cast(bf16x8, fb[b][PB]), c, 0, 0, 0)
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, F[S][0][a][PA]), __builtin_bit_cast(bf16x8, F[S][1][b][PB]), c, 0, 0, 0)
+#define GPSO_SLOT __builtin_amdgcn_sched_barrier(0)
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        f32x4 c = acc[a][b];
-        GPSO_SY(2, 0);
-        GPSO_SY(0, 2);
-        GPSO_SY(1, 1);
-        GPSO_SY(1, 0);
-        GPSO_SY(0, 1);
-        GPSO_SY(0, 0);
-        acc[a][b] = c;
-      }
+    for (int ch = 0; ch < 16; ++ch) {  // one MFMA, then at most one other instruction: nothing else ever queues up
+      const int a = ch / 4, b = ch % 4;
+      f32x4 c = acc[a][b];
+      GPSO_SY(2, 0);
+      if (ch < 12 && do_dma) gemm_glds16(src[ch] + lane_off, dma_base + dst[ch]);
+      GPSO_SLOT;
+      GPSO_SY(0, 2);
+      if (ch < 12 && do_dma) src[ch] += 1024;
+      GPSO_SLOT;
+      GPSO_SY(1, 1);
+      GPSO_SLOT;
+      GPSO_SY(1, 0);
+      read_frag(ch);  // reads 0..15, one per group
+      GPSO_SLOT;
+      GPSO_SY(0, 1);
+      GPSO_SLOT;
+      GPSO_SY(0, 0);
+      if (ch < 8) read_frag(16 + ch);  // reads 16..23
+      GPSO_SLOT;
+      acc[a][b] = c;
+      if (ch == 11) GPSO_GSTAMP(st, 3);
+    }
+#undef GPSO_SLOT
 #undef GPSO_SY
+  };
+  if (nsteps > 0) {
+    wait_landed(min(nsteps, kSyrkNbuf) - 1);
+    GPSO_GSTAMP(39, 3);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < 24; ++r) F[0][r / 12][(r % 12) / 3][r % 3] = *frag_ptr(0, r);
+  }
+  GPSO_GSTAMP(38, 1);
+  int buf = 0, st = 0;
+  const std::integral_constant<int, 0> set0;
+  const std::integral_constant<int, 1> set1;
+  for (; st + 4 < nsteps; st += 2) {
+    step_body(set0, std::true_type{}, st, buf);
+    buf = (buf + 1 == kSyrkNbuf) ? 0 : buf + 1;
+    step_body(set1, std::true_type{}, st + 1, buf);
     buf = (buf + 1 == kSyrkNbuf) ? 0 : buf + 1;
   }
+  for (; st < nsteps; st += 2) {  // the last three or four steps: no more DMAs, then no more reads
+    step_body(set0, std::false_type{}, st, buf);
+    buf = (buf + 1 == kSyrkNbuf) ? 0 : buf + 1;
+    if (st + 1 < nsteps) {
+      step_body(set1, std::false_type{}, st + 1, buf);
+      buf = (buf + 1 == kSyrkNbuf) ? 0 : buf + 1;
+    }
+  }
+  GPSO_GSTAMP(38, 2);
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -1040,13 +1146,14 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel(GemmBf16Desc g) {
         }
       }
     }
+  GPSO_GSTAMP(38, 3);
 }
 
 static void launch_gemm_bf16(hipStream_t st, const GemmBf16Desc& g) {
   if (ensure_dyn_lds(reinterpret_cast<const void*>(&gemm_bf16_kernel), kSyrkLdsBytes)) return;
-  const int64_t nti = g.m / 128, ntj = g.n / 128;
-  const int64_t ntiles = g.lower_only ? nti * (nti + 1) / 2 : nti * ntj;
-  hipLaunchKernelGGL(gemm_bf16_kernel, dim3((unsigned)ntiles, 1, (unsigned)g.nbatch), dim3(256), kSyrkLdsBytes, st, g);
+  const BfTiling tl = bf16_tiling(g);
+  const int64_t ntiles = ((int64_t)tl.nsuper * g.nbatch + 7) / 8 * 8 * tl.per_super;
+  hipLaunchKernelGGL(gemm_bf16_kernel, dim3((unsigned)ntiles), dim3(256), kSyrkLdsBytes, st, g);
 }
 
 // a float block (rows x cols at src, leading dimension ld) -> planes at (row0, col0) and / or its transpose at

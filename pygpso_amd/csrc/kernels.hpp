@@ -111,7 +111,7 @@ bool trtri_bf16_applies(int64_t npad, int64_t first_level);
 // inverse).  Measured (posterior fit, float, ms, 512 | 1024): N 4096 1.78 | 1.66, 8192 6.16 | 5.91,
 // 16384 29.95 | 30.18 -- the wider panel halves the passes over the trailing matrix, which pays while
 // the SYRKs are short.
-inline int fit_outer_panel(int64_t npad) { return (npad >= 4096 && npad <= 8192) ? 1024 : 512; }
+inline int fit_outer_panel(int64_t npad) { return (npad >= 4096) ? 1024 : 512; }
 template <typename T>
 void launch_trtri(hipStream_t st, const T* L, T* linv, T* work, int64_t npad, int64_t first_level);
 // zero rows/cols >= n and re-tile the lower 16x16 tiles of L^-1 into the MFMA fragment-major layout

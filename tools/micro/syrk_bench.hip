@@ -1,6 +1,11 @@
 // split-bf16 SYRK (fit.hip: syrk_bf16_kernel) against the f32 tile GEMM on the trailing-update shape of the
 // two-level Cholesky: C (m x m, lower 128-tiles) -= A A^T, A = m x k.  Checks the result and times both.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I pygpso_amd/csrc tools/micro/syrk_bench.hip -o tools/micro/syrk_bench.bin
+__device__ long long g_gst[4 * 40 * 4];
+__device__ int g_sel[2];
+#ifdef GPSO_BENCH_STAMPS
+#define GPSO_GSTAMP(st, i) do { if ((threadIdx.x & 63) == 0 && ((int)blockIdx.x == g_sel[0] || (int)blockIdx.x == g_sel[1]) && st < 40) g_gst[(((int)blockIdx.x == g_sel[1]) * 2 + (threadIdx.x >> 7)) * 160 + st * 4 + i] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
 #include "../../pygpso_amd/csrc/fit.hip"
 #include <cstdio>
 #include <cmath>
@@ -28,6 +33,17 @@ int main(int argc, char** argv) {
   u.A = A; u.sai = ld; u.sak = 1; u.B = A; u.sbk = 1; u.sbj = ld; u.ldc = ld;
   u.m = (int)m; u.n = (int)m; u.k = (int)k; u.m_last = (int)m; u.nbatch = 1; u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1;
   GemmBf16Desc b{}; b.A = b.B = Bf16Planes{P, (int64_t)hA.size(), (int)(k / 32)}; b.C = C2; b.ldc = ld; b.m = b.n = (int)m; b.k = (int)k; b.alpha = -1.0f; b.beta = 1; b.lower_only = 1; b.nbatch = 1;
+  int sel[2] = {-1, -1};
+#ifdef GPSO_BENCH_STAMPS
+  {  // two tiles in the middle and near the end of the triangular grid (4 x 4 super-tiles, see gemm_bf16_kernel)
+    const int nt = (int)(m / 128), tis[2] = {nt / 2, nt - 3}, tjs[2] = {nt / 6, nt / 2 - 1};
+    for (int q = 0; q < 2; ++q) {
+      const int I = tis[q] / 4, J = tjs[q] / 4, sg = I * (I + 1) / 2 + J, t = (tis[q] % 4) * 4 + tjs[q] % 4;
+      sel[q] = (((sg / 8) * 16 + t) * 8) + sg % 8;
+    }
+    hipMemcpyToSymbol(HIP_SYMBOL(g_sel), sel, sizeof(sel));
+  }
+#endif
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const double gf = (double)m * m * k / 1e9;
   for (int rep = 0; rep < 3; ++rep) {
@@ -47,5 +63,17 @@ int main(int argc, char** argv) {
     printf("m %lld k %lld: f32 gemm %.0f us (%.0f TF/s) | split-bf16 syrk %.0f us (%.0f TF/s f32-equivalent) | max |diff| %.3g of max |C| %.3g\n",
            (long long)m, (long long)k, t1 * 1e3, gf / t1, t2 * 1e3, gf / t2, maxd, maxv);
   }
+#ifdef GPSO_BENCH_STAMPS
+  long long gs[641] = {0}; hipMemcpyFromSymbol(gs, HIP_SYMBOL(g_gst), 640 * 8);
+  for (int w = 0; w < 4; ++w) {
+    printf("block %d wave %d: per step [wait | barrier | groups 0-11 (+dma, reads) | groups 12-15]:", w < 2 ? sel[0] : sel[1], (w & 1) * 2);
+    for (int st = 0; st + 1 < (int)(k / 32) && st < 12; ++st) {
+      const long long* a = gs + w * 160 + st * 4;
+      printf(" %lld|%lld|%lld|%lld", a[1] - a[0], a[2] - a[1], a[3] - a[2], a[4] - a[3]);
+    }
+    { const long long* q = gs + w * 160; printf("\n   prologue: decode %lld | C issue %lld | addresses + DMA issue %lld | C arrives + wait landed %lld | barrier + fragment reads %lld", q[156] - q[152], q[157] - q[156], q[158] - q[157], q[159] - q[158], q[153] - q[159]); }
+    printf("\n   whole tile: decode+prologue %lld | k-loop %lld | epilogue %lld\n", gs[w * 160 + 38 * 4 + 1] - gs[w * 160 + 38 * 4], gs[w * 160 + 38 * 4 + 2] - gs[w * 160 + 38 * 4 + 1], gs[w * 160 + 38 * 4 + 3] - gs[w * 160 + 38 * 4 + 2]);
+  }
+#endif
   return 0;
 }
