@@ -140,6 +140,8 @@ struct gpso_ctx {
   std::string err;
   Engine* eng = nullptr;
   hipEvent_t ev_wait = nullptr;  // completion marker of the call in flight
+  hipStream_t side_stream = nullptr;  // look-ahead of the two-level float fit (kernels.hpp: FitPlanes)
+  hipEvent_t ev_col = nullptr, ev_chain = nullptr;
   double* pinned = nullptr;      // pinned host scratch for the small result read-backs
   size_t pinned_doubles = 0;
   double* stage = nullptr;       // pinned staging of small host inputs (training data, bounds)
@@ -581,6 +583,14 @@ struct EngineT : Engine {
           planes = FitPlanes{static_cast<unsigned short*>(pl_L.p), static_cast<unsigned short*>(pl_X.p),
                              static_cast<unsigned short*>(pl_XT.p), static_cast<unsigned short*>(pl_WT.p),
                              (int64_t)npad * npad, (int)(npad / 32)};
+          if (ctx->side_stream == nullptr) {
+            HIPCHECK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+            HIPCHECK(hipEventCreateWithFlags(&ctx->ev_col, hipEventDisableTiming));
+            HIPCHECK(hipEventCreateWithFlags(&ctx->ev_chain, hipEventDisableTiming));
+          }
+          planes.side = ctx->side_stream;
+          planes.ev_col = ctx->ev_col;
+          planes.ev_chain = ctx->ev_chain;
           pl = &planes;
         }
       }
@@ -1422,6 +1432,10 @@ void gpso_destroy(gpso_ctx* ctx) {
     if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : ctx->tile_ev) (void)hipEventDestroy(ev);
   if (ctx->ev_wait) (void)hipEventDestroy(ctx->ev_wait);
+  if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
+  if (ctx->ev_col) (void)hipEventDestroy(ctx->ev_col);
+  if (ctx->ev_chain) (void)hipEventDestroy(ctx->ev_chain);
+  if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->stage) (void)hipHostFree(ctx->stage);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

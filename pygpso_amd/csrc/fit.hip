@@ -876,12 +876,18 @@ struct Bf16Planes {
   int64_t stride;     // bf16 elements between planes
   int nkb;
 };
+// super-tile: tile rows x tile columns that one XCD works on at a time (square for the triangular enumeration);
+// filled by launch_gemm_bf16.  mg_*: q = n / d as __umulhi(n, mg) (exact for n < 2^20, 1 < d <= 4096).
+struct BfTiling {
+  int nti, ntj, sr, sc, nsi, nsj, per_super, nsuper, total_slots;
+  unsigned mg_per_super, mg_nbatch, mg_nsj, mg_sc;
+};
 // C (m x n) = alpha * Aop Bop^T + beta * C with Aop = rows a_row0.. / columns a_col0.. of the matrix in planes A
 // (m x k) and Bop likewise (n x k): both operands k-contiguous rows, so a transposed factor is simply the
 // planes of the transposed matrix.  Row offsets are multiples of 64, column offsets of 32; m, n multiples of
-// 128, k of 32.  The result goes to C (float, nullable) and / or to planes: `out` at (o_row0, o_col0), `out_t`
-// -- the TRANSPOSE of the result -- at (ot_row0, ot_col0).  Batch entry z (blockIdx.z) shifts every row and
-// column offset by z * batch_shift and C along its diagonal.
+// 128, k of 64 and every tile's k-range a multiple of 64, at least 128.  The result goes to C (float, nullable) and / or to planes:
+// `out` at (o_row0, o_col0), `out_t` -- the TRANSPOSE of the result -- at (ot_row0, ot_col0).  Batch entry z
+// shifts every row and column offset by z * batch_shift and C along its diagonal.
 struct GemmBf16Desc {
   Bf16Planes A, B;
   int64_t a_row0, a_col0, b_row0, b_col0;
@@ -896,164 +902,217 @@ struct GemmBf16Desc {
   int64_t batch_shift;
   Bf16Planes out, out_t;
   int64_t o_row0, o_col0, ot_row0, ot_col0;
+  BfTiling tl;
 };
 constexpr int kSyrkBf16MinRows = 3072;  // below: too few 128-tiles for one workgroup per CU to pay (measured)
 constexpr int kSyrkNbuf = 3;
 constexpr int kSyrkStepBytes = 2 * 3 * 8 * 1024;  // [operand][piece][row tile] x 1 KB
-constexpr int kSyrkLdsBytes = kSyrkNbuf * kSyrkStepBytes;
+constexpr int kSyrkLdsBytes = kSyrkNbuf * kSyrkStepBytes + 4 * 1024;  // + a spare KB per wave (C prefetch target)
 
 #ifndef GPSO_GSTAMP
-#define GPSO_GSTAMP(st, i)  // tools/micro/syrk_bench.hip defines this to record s_memtime stamps per k-step
+#define GPSO_GSTAMP(tile, i)  // tools/micro/syrk_bench.hip defines this to record s_memtime stamps per tile
 #endif
-// super-tile: tile rows x tile columns that one XCD works on at a time (square for the triangular enumeration)
-struct BfTiling {
-  int nti, ntj, sr, sc, nsi, nsj, per_super, nsuper;
-};
-__host__ __device__ __forceinline__ BfTiling bf16_tiling(const GemmBf16Desc& g) {
+static unsigned bf16_magic(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); }
+static BfTiling bf16_tiling(const GemmBf16Desc& g) {
   BfTiling tl;
   tl.nti = g.m / 128;
   tl.ntj = g.n / 128;
-  tl.sr = min(4, tl.nti);
-  tl.sc = min(g.lower_only ? 4 : 8, tl.ntj);
+  tl.sr = std::min(4, tl.nti);
+  tl.sc = std::min(g.lower_only ? 4 : 8, tl.ntj);
   tl.nsi = (tl.nti + tl.sr - 1) / tl.sr;
   tl.nsj = (tl.ntj + tl.sc - 1) / tl.sc;
   tl.per_super = tl.sr * tl.sc;
   tl.nsuper = g.lower_only ? tl.nsi * (tl.nsi + 1) / 2 : tl.nsi * tl.nsj;
+  tl.total_slots = (tl.nsuper * g.nbatch + 7) / 8 * 8 * tl.per_super;
+  tl.mg_per_super = bf16_magic(tl.per_super);
+  tl.mg_nbatch = bf16_magic(g.nbatch);
+  tl.mg_nsj = bf16_magic(tl.nsj);
+  tl.mg_sc = bf16_magic(tl.sc);
   return tl;
 }
+struct BfTile {
+  int ti, tj, bz, k_lo, nsteps;
+};
 
+// s_waitcnt vmcnt(N) lgkmcnt(0), N a multiple of 12 (DMA groups of one wave), 63 = no vector-memory wait
+template <int N>
+__device__ __forceinline__ void bf16_wait() {
+  __builtin_amdgcn_s_waitcnt(0x0070 | (N & 0xf) | ((N >> 4) << 14));
+  asm volatile("" ::: "memory");
+}
+
+// The kernel is PERSISTENT: one workgroup of four waves per CU walks slots blockIdx.x, + gridDim.x, ... of a 1-D
+// sequence of tile slots, and its k-loop is ONE software pipeline across all of its tiles (s_memtime stamps of the
+// one-tile-per-workgroup form: 14k of a tile's ~68k clocks were decode, address set-up, the first DMA round trip
+// and the C loads, with nothing else resident on the CU to hide them).
+//  * slots: super-tiles of 4 x 8 tiles (4 x 4 in the triangular case); super-tile s runs on XCD s % 8 (the
+//    hardware deals consecutive workgroups to the XCDs round-robin and gridDim.x is a multiple of 8), so the 32
+//    workgroups of an XCD read 12-16 operand tiles between them at a time and most LDS-DMA traffic is served by
+//    that XCD's L2.  The decode has no loops, tables or divisions.
+//  * pipeline: item e = (tile, k-step).  While the 96 MFMAs of item e run on the fragments in one register set,
+//    the wave reads the fragments of item e + 1 from LDS into the other set and issues the DMAs of item e + 3
+//    into the buffer item e was read from -- one DMA or LDS read behind each MFMA (sched_barrier pins that: the
+//    12 DMA instructions of a step occupy the CU's address path for ~770 clocks, and issued in one burst they
+//    stalled the wave for ~600 of the ~1540 clocks of its MFMAs).  Items e + 1 .. e + 3 may belong to the NEXT
+//    tile: its first three steps are in flight while this tile's accumulators are stored.
 __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel(GemmBf16Desc g) {
   typedef float vecW __attribute__((ext_vector_type(4)));
   extern __shared__ __align__(16) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // Tile of this workgroup.  The grid is 1-D over super-tiles (4 x 8 tiles, 4 x 4 in the triangular case), and
-  // super-tile s of the sequence runs on XCD s % 8 (the hardware deals consecutive workgroups to the XCDs
-  // round-robin): the 32 workgroups an XCD holds at a time then read 12-16 operand tiles between them instead of
-  // up to 64, so that most of the LDS-DMA traffic is served by that XCD's L2 (a 128 x 128 tile of six-MFMA
-  // products needs 48 KB per 0.65 us of MFMA work).  No loops or tables in the decode: it is on every tile's
-  // critical path (a per-row scan cost 8k clocks of a ~70k-clock tile).
-  GPSO_GSTAMP(38, 0);
-  int ti, tj, bz;
-  {
-    const BfTiling tl = bf16_tiling(g);
-    const int id = (int)blockIdx.x, x = id & 7, j = id >> 3;
-    const int sg = (j / tl.per_super) * 8 + x, t = j % tl.per_super;
-    if (sg >= tl.nsuper * g.nbatch) return;
-    bz = sg % g.nbatch;
-    int sl = sg / g.nbatch, I, J;
+  const int wr = wave >> 1, wc = wave & 1;
+  const BfTiling& tl = g.tl;
+  auto fdiv = [](unsigned n, int d, unsigned mg) { return d == 1 ? n : __umulhi(n, mg); };
+  auto decode = [&](int id, BfTile& t) -> bool {
+    const unsigned x = (unsigned)id & 7u, j = (unsigned)id >> 3;
+    const unsigned js = fdiv(j, tl.per_super, tl.mg_per_super), tt = j - js * tl.per_super;
+    const unsigned sg = js * 8 + x;
+    if (sg >= (unsigned)(tl.nsuper * g.nbatch)) return false;
+    const unsigned sl = fdiv(sg, g.nbatch, tl.mg_nbatch);
+    t.bz = (int)(sg - sl * g.nbatch);
+    int I, J;
     if (g.lower_only) {  // compact triangular enumeration of the super-tiles, row-major
       I = (int)((__builtin_sqrtf(8.0f * (float)sl + 1.0f) - 1.0f) * 0.5f);
-      while ((I + 1) * (I + 2) / 2 <= sl) ++I;
-      while (I * (I + 1) / 2 > sl) --I;
-      J = sl - I * (I + 1) / 2;
+      while ((I + 1) * (I + 2) / 2 <= (int)sl) ++I;
+      while (I * (I + 1) / 2 > (int)sl) --I;
+      J = (int)sl - I * (I + 1) / 2;
     } else {
-      I = sl / tl.nsj;
-      J = sl % tl.nsj;
+      I = (int)fdiv(sl, tl.nsj, tl.mg_nsj);
+      J = (int)sl - I * tl.nsj;
       if (g.kmode == 3) I = tl.nsi - 1 - I;  // the longest k-ranges first (kmode 2: small ti, kmode 3: large ti)
     }
-    ti = I * tl.sr + t / tl.sc;
-    tj = J * tl.sc + t % tl.sc;
-    if (ti >= tl.nti || tj >= tl.ntj || (g.lower_only && tj > ti)) return;
-  }
-  GPSO_GSTAMP(39, 0);
-  const int64_t zs = (int64_t)bz * g.batch_shift;
-  int k_lo = 0, k_hi = g.k;
-  if (g.kmode == 2) k_lo = 128 * ti;
-  if (g.kmode == 3) k_hi = min(g.k, 128 * (ti + 1));
+    const unsigned tr = fdiv(tt, tl.sc, tl.mg_sc);
+    t.ti = I * tl.sr + (int)tr;
+    t.tj = J * tl.sc + (int)(tt - tr * tl.sc);
+    if (t.ti >= tl.nti || t.tj >= tl.ntj || (g.lower_only && t.tj > t.ti)) return false;
+    int k_lo = 0, k_hi = g.k;
+    if (g.kmode == 2) k_lo = 128 * t.ti;
+    if (g.kmode == 3) k_hi = min(g.k, 128 * (t.ti + 1));
+    t.k_lo = k_lo;
+    t.nsteps = (k_hi - k_lo) / 32;
+    return true;
+  };
+  int slot = (int)blockIdx.x - (int)gridDim.x;
+  auto next_tile = [&](BfTile& t) -> bool {
+    for (slot += (int)gridDim.x; slot < tl.total_slots; slot += (int)gridDim.x)
+      if (decode(slot, t)) return true;
+    return false;
+  };
 
-  // C first: its loads are the longest latency of the prologue, the DMA issue that follows overlaps it
-  const int wr = wave >> 1, wc = wave & 1;
-  f32x4 acc[4][4];
-  const int row_w = ti * 128 + wr * 64, col_w = tj * 128 + wc * 64 + 4 * (lane & 15);  // this lane's rows / columns in C
-  float* c_base = (g.C != nullptr) ? g.C + zs * g.ldc + zs + (int64_t)row_w * g.ldc + col_w : nullptr;
-  auto c_ptr = [&](int a, int r) { return c_base + (int64_t)(4 * (4 * (lane >> 4) + r) + a) * g.ldc; };
-  const bool with_c = g.beta != 0 && c_base != nullptr;
-  vecW cin[4][4];
-  if (with_c) {
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) cin[a][r] = *reinterpret_cast<const vecW*>(c_ptr(a, r));
-  }
-  GPSO_GSTAMP(39, 1);
   // this wave's DMA pieces: numbers wave, wave + 4, ... of the 48 per step; piece q = (operand, plane, tile),
-  // tile = 4 (64-row strip of the 128 rows) + x: 1 KB of contiguous memory each
-  // (wave-uniform bases in SGPRs + one per-lane byte offset: the k-loop advances them on the scalar unit)
-  const unsigned char* src[12];
+  // tile = 4 (64-row strip of the 128 rows) + x: 1 KB of contiguous memory each.  Source of piece s = the
+  // cursor's per-operand base (a scalar register pair that advances 1 KB per step) + voff[s], a per-lane
+  // 32-bit offset that never changes (plane, tile and lane; three planes of a 16384^2 matrix span 1.5 GB).
+  unsigned voff[12];
   int dst[12];
-  const unsigned lane_off = (unsigned)lane * 16u;
 #pragma unroll
   for (int s = 0; s < 12; ++s) {
     const int q = wave + 4 * s, op = q / 24, p = (q % 24) / 8, tile = q % 8;
     const Bf16Planes& P = (op == 0) ? g.A : g.B;
-    const int64_t row0 = (op == 0 ? g.a_row0 + (int64_t)ti * 128 : g.b_row0 + (int64_t)tj * 128) + zs;
-    const int64_t col0 = (op == 0 ? g.a_col0 : g.b_col0) + zs + k_lo;
-    const int64_t T = 4 * (row0 >> 6) + tile;
-    const uint64_t b = reinterpret_cast<uint64_t>(P.p + (int64_t)p * P.stride + (T * P.nkb + (col0 >> 5)) * 512);
-    const unsigned b_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)), b_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
-    src[s] = reinterpret_cast<const unsigned char*>(((uint64_t)b_hi << 32) | (uint64_t)b_lo);
+    voff[s] = (unsigned)(((int64_t)p * P.stride + (int64_t)tile * P.nkb * 512) * 2) + (unsigned)lane * 16u;
     dst[s] = q * 1024;
   }
-  auto issue = [&](int buf) {
+  uint64_t src[2];  // the DMA cursor: next 32-k block, per operand
+  auto set_src = [&](const BfTile& t) {
+    const int64_t zs = (int64_t)t.bz * g.batch_shift;
 #pragma unroll
-    for (int s = 0; s < 12; ++s) {
-      gemm_glds16(src[s] + lane_off, lds + buf * kSyrkStepBytes + dst[s]);
-      src[s] += 1024;  // next 32-k block of the same tile
+    for (int op = 0; op < 2; ++op) {
+      const Bf16Planes& P = (op == 0) ? g.A : g.B;
+      const int64_t row0 = (op == 0 ? g.a_row0 + (int64_t)t.ti * 128 : g.b_row0 + (int64_t)t.tj * 128) + zs;
+      const int64_t col0 = (op == 0 ? g.a_col0 : g.b_col0) + zs + t.k_lo;
+      src[op] = reinterpret_cast<uint64_t>(P.p) + (uint64_t)(((4 * (row0 >> 6)) * P.nkb + (col0 >> 5)) * 1024);
     }
   };
-  const int nsteps = (k_hi - k_lo) / 32;
-  for (int d = 0; d < kSyrkNbuf; ++d)
-    if (d < nsteps) issue(d);
-  GPSO_GSTAMP(39, 2);
-  // acc = (beta / alpha) * C, so that the loop adds A B^T and the epilogue scales by alpha
-  if (with_c) {
-    const float sc = 1.0f / g.alpha;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b][r] = sc * cin[a][r][b];
-  } else {
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0, 0, 0, 0};
-  }
-  // The k-loop is software-pipelined by hand: one wave per SIMD has nobody to hide behind, and the 12 LDS-DMA
-  // instructions of a step occupy the CU's address path for ~770 clocks (64 B / clk) -- issued in one burst
-  // they stalled the wave for ~600 of the ~1540 clocks its 96 MFMAs take (s_memtime stamps).  So while the
-  // MFMAs of step st run on the fragments in one register set, the wave (a) reads the fragments of step st + 1
-  // from LDS into the other set and (b) issues the DMAs of step st + 3 into the buffer step st was read from,
-  // two reads and one DMA behind every group of six MFMAs (sched_barrier pins that order).
-  u32x4 F[2][2][4][3];  // [set][operand][tile][piece]
+  // The DMA is issued as two instructions in two different MFMA gaps -- M0 (the LDS destination), then the load
+  // with the scalar base + per-lane offset form -- because each gap hides ~8 clocks of other instructions and the
+  // compiler's form of this (per-lane 64-bit addresses: s_mov, 64-bit add, M0, load in one gap) made a group of
+  // six MFMAs take ~133 clocks instead of 96.
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  auto dma_m0 = [&](int s, int buf) {
+    const unsigned a = lds0 + (unsigned)(buf * kSyrkStepBytes + dst[s]);
+    asm volatile("s_mov_b32 m0, %0" ::"s"(a) : "memory");
+  };
+  auto dma_go = [&](int s) {
+    asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(voff[s]), "s"(src[s / 6]) : "memory");
+  };
+
+  u32x4 F[2][2][4][3];  // fragments: [set][operand][tile][piece]
   auto frag_ptr = [&](int buf, int r) {  // read r of a step: operand r / 12, tile (r % 12) / 3, piece r % 3
     const int op = r / 12, x = (r % 12) / 3, p = r % 3;
     return reinterpret_cast<const u32x4*>(lds + buf * kSyrkStepBytes + ((op * 3 + p) * 8 + (op == 0 ? wr : wc) * 4 + x) * 1024 + lane * 16);
   };
-  auto wait_landed = [&](int newer_groups) {  // all but this wave's newest 12 * newer_groups DMAs, and every LDS read
-    if (newer_groups >= 2) __builtin_amdgcn_s_waitcnt(0x0070 | (24 & 0xf) | ((24 >> 4) << 14));
-    else if (newer_groups == 1) __builtin_amdgcn_s_waitcnt(0x0070 | (12 & 0xf) | ((12 >> 4) << 14));
-    else __builtin_amdgcn_s_waitcnt(0x0070);
-    asm volatile("" ::: "memory");
+  auto wait_groups = [&](int newer) {  // every DMA group of this wave but the newest `newer`, and every LDS read
+    if (newer >= 2) bf16_wait<24>();
+    else if (newer == 1) bf16_wait<12>();
+    else bf16_wait<0>();
   };
-  // kSteady: steps st + 3 < nsteps, where the reads and the DMAs are unconditional and the body is branch-free
-  auto step_body = [&](auto setc, auto steadyc, int st, int buf) {
+
+  BfTile cur, nxt;
+  if (!next_tile(cur)) return;
+  bool have_next = false, switched = false;
+  int rem;        // DMA groups the cursor has left in its tile
+  int ahead = 2;  // DMA groups issued beyond the current item
+  int buf = 0;
+  set_src(cur);
+  rem = cur.nsteps - kSyrkNbuf;
+#pragma unroll
+  for (int d = 0; d < kSyrkNbuf; ++d)
+#pragma unroll
+    for (int s = 0; s < 12; ++s) {
+      dma_m0(s, d);
+      asm volatile("s_nop 0");
+      dma_go(s);
+      if (s == 11) src[0] += 1024, src[1] += 1024;
+    }
+  wait_groups(2);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int r = 0; r < 24; ++r) F[0][r / 12][(r % 12) / 3][r % 3] = *frag_ptr(0, r);
+
+  f32x4 acc[4][4];
+  float* c_base = nullptr;
+  int64_t c_row0 = 0;  // element offset of this wave's 64 x 64 corner of C
+  bool with_c = false, first_tile = true;
+  auto c_ptr = [&](int a, int r) { return c_base + (int64_t)(4 * (4 * (lane >> 4) + r) + a) * g.ldc; };
+
+  // kSteady: neither among a tile's first two nor its last three steps -- reads and DMAs unconditional, no branches
+  auto step_body = [&](auto setc, auto steadyc, int st) {
     constexpr int S = decltype(setc)::value;
     constexpr bool kSteady = decltype(steadyc)::value;
-    GPSO_GSTAMP(st, 0);
-    // step st + 1 has landed (the reads below need it); the fragments of this step, read during the last one,
-    // are in registers on every wave once all have passed the barrier, so its buffer may be overwritten
-    if (kSteady) wait_landed(1);
-    else wait_landed(min(nsteps, st + 3) - min(nsteps, st + 2));
-    GPSO_GSTAMP(st, 1);
+    if (!kSteady && rem == 0 && have_next && !switched) {  // the cursor moves on to the next tile
+      set_src(nxt);
+      rem = nxt.nsteps;
+      switched = true;
+    }
+#ifdef GPSO_EXP_NODMA
+    const bool do_dma = false;
+#else
+    const bool do_dma = kSteady || rem > 0;
+#endif
+#ifdef GPSO_EXP_NORD
+    const bool do_rd = false;
+#else
+    const bool do_rd = kSteady || st + 1 < cur.nsteps || have_next;
+#endif
+    // item e + 1 has landed (the reads below need it); the fragments of this item, read during the last one, are
+    // in registers on every wave once all have passed the barrier, so its buffer may be overwritten.  (Step 0 of
+    // a later tile: that wait was made before the stores of the previous tile's epilogue, see below.)
+    if (kSteady) bf16_wait<12>();
+    else if (st == 0 && !first_tile) bf16_wait<63>();
+    else wait_groups(ahead - 1);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    GPSO_GSTAMP(st, 2);
-    const bool do_rd = kSteady || st + 1 < nsteps, do_dma = kSteady || st + 3 < nsteps;
+    if (!kSteady && with_c && st == cur.nsteps - 1) {
+      // touch this wave's 64 rows x 2 lines of C (results discarded): the epilogue's loads then hit the L2 instead
+      // of paying an HBM round trip with nothing to hide it.  Issued before this step's DMAs: the counted waits
+      // look at the newest instructions only.
+      // (as LDS-DMA into a spare kilobyte of LDS per wave: no register receives data the compiler knows nothing of)
+      const float* row = g.C + c_row0 + (int64_t)lane * g.ldc;
+      const unsigned spare = lds0 + (unsigned)(kSyrkNbuf * kSyrkStepBytes + wave * 1024);
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\tglobal_load_lds_dword %1, off offset:128" ::"s"(spare), "v"(row) : "memory");
+    }
     const int buf_rd = (buf + 1 == kSyrkNbuf) ? 0 : buf + 1;
-    unsigned char* const dma_base = lds + buf * kSyrkStepBytes;
     auto read_frag = [&](int r) {
       if (do_rd) F[1 - S][r / 12][(r % 12) / 3][r % 3] = *frag_ptr(buf_rd, r);
     };
@@ -1065,95 +1124,134 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel(GemmBf16Desc g) {
       const int a = ch / 4, b = ch % 4;
       f32x4 c = acc[a][b];
       GPSO_SY(2, 0);
-      if (ch < 12 && do_dma) gemm_glds16(src[ch] + lane_off, dma_base + dst[ch]);
+      GPSO_SLOT;
+      if (ch < 12 && do_dma) dma_m0(ch, buf);
       GPSO_SLOT;
       GPSO_SY(0, 2);
-      if (ch < 12 && do_dma) src[ch] += 1024;
+      GPSO_SLOT;
+      if (ch < 12 && do_dma) dma_go(ch);
       GPSO_SLOT;
       GPSO_SY(1, 1);
       GPSO_SLOT;
-      GPSO_SY(1, 0);
       read_frag(ch);  // reads 0..15, one per group
+      GPSO_SLOT;
+      GPSO_SY(1, 0);
+      GPSO_SLOT;
+      if (ch < 8) read_frag(16 + ch);  // reads 16..23
       GPSO_SLOT;
       GPSO_SY(0, 1);
       GPSO_SLOT;
       GPSO_SY(0, 0);
-      if (ch < 8) read_frag(16 + ch);  // reads 16..23
       GPSO_SLOT;
       acc[a][b] = c;
-      if (ch == 11) GPSO_GSTAMP(st, 3);
     }
 #undef GPSO_SLOT
 #undef GPSO_SY
+    if (do_dma) --rem, src[0] += 1024, src[1] += 1024;
+    else --ahead;
+    buf = buf_rd;
   };
-  if (nsteps > 0) {
-    wait_landed(min(nsteps, kSyrkNbuf) - 1);
-    GPSO_GSTAMP(39, 3);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int r = 0; r < 24; ++r) F[0][r / 12][(r % 12) / 3][r % 3] = *frag_ptr(0, r);
-  }
-  GPSO_GSTAMP(38, 1);
-  int buf = 0, st = 0;
   const std::integral_constant<int, 0> set0;
   const std::integral_constant<int, 1> set1;
-  for (; st + 4 < nsteps; st += 2) {
-    step_body(set0, std::true_type{}, st, buf);
-    buf = (buf + 1 == kSyrkNbuf) ? 0 : buf + 1;
-    step_body(set1, std::true_type{}, st + 1, buf);
-    buf = (buf + 1 == kSyrkNbuf) ? 0 : buf + 1;
-  }
-  for (; st < nsteps; st += 2) {  // the last three or four steps: no more DMAs, then no more reads
-    step_body(set0, std::false_type{}, st, buf);
-    buf = (buf + 1 == kSyrkNbuf) ? 0 : buf + 1;
-    if (st + 1 < nsteps) {
-      step_body(set1, std::false_type{}, st + 1, buf);
-      buf = (buf + 1 == kSyrkNbuf) ? 0 : buf + 1;
+
+  int tile_no = 0;
+  for (;; ++tile_no) {
+    GPSO_GSTAMP(tile_no, 0);
+    have_next = next_tile(nxt);
+    switched = false;
+    const int64_t zs = (int64_t)cur.bz * g.batch_shift;
+    const int row_w = cur.ti * 128 + wr * 64, col_w = cur.tj * 128 + wc * 64 + 4 * (lane & 15);  // this lane's rows / columns in C
+    c_row0 = zs * g.ldc + zs + (int64_t)row_w * g.ldc + cur.tj * 128 + wc * 64;
+    c_base = (g.C != nullptr) ? g.C + zs * g.ldc + zs + (int64_t)row_w * g.ldc + col_w : nullptr;
+    with_c = g.beta != 0 && c_base != nullptr;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0, 0, 0, 0};
+    // (every k-range is a multiple of 64, so a tile starts on register set 0 and its last step leaves the next
+    // tile's first fragments there: at the tile boundary only that set is live)
+    int st = 0;
+    step_body(set0, std::false_type{}, st);
+    step_body(set1, std::false_type{}, st + 1);
+    for (st = 2; st + 4 < cur.nsteps; st += 2) {
+      step_body(set0, std::true_type{}, st);
+      step_body(set1, std::true_type{}, st + 1);
     }
-  }
-  GPSO_GSTAMP(38, 2);
+    for (; st < cur.nsteps; st += 2) {
+      step_body(set0, std::false_type{}, st);
+      step_body(set1, std::false_type{}, st + 1);
+    }
+    GPSO_GSTAMP(tile_no, 1);
+    // Step 0 of the next tile reads item e + 1 = its step 1: wait for that group HERE, before this tile's stores
+    // enter the queue (only DMAs are newer, so the count is exact whatever order loads and stores retire in).
+    if (have_next) wait_groups(ahead - 1);
+    vecW cin[4][4];  // (the register set whose fragments this tile's last step consumed is free now)
+    if (with_c) {
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      vecW v;
+        for (int r = 0; r < 4; ++r) cin[a][r] = *reinterpret_cast<const vecW*>(c_ptr(a, r));
+    }
 #pragma unroll
-      for (int b = 0; b < 4; ++b) v[b] = g.alpha * acc[a][b][r];
-      if (c_base != nullptr) *reinterpret_cast<vecW*>(c_ptr(a, r)) = v;
-      const int64_t row = row_w + 4 * (4 * (lane >> 4) + r) + a;  // (row, col_w .. col_w + 3) of the result
-      if (g.out.p != nullptr) {
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; b += 2) {
-          float x0 = v[b], x1 = v[b + 1];
-          unsigned short* d = g.out.p + syrk_plane_offset(g.o_row0 + zs + row, (int)(g.o_col0 + zs) + col_w + b, g.out.nkb);
+      for (int r = 0; r < 4; ++r) {
+        vecW v;
 #pragma unroll
-          for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(d + p * g.out.stride) = bf16_split_pair(x0, x1);
+        for (int b = 0; b < 4; ++b) v[b] = g.alpha * acc[a][b][r] + (with_c ? cin[a][r][b] : 0.0f);
+        if (c_base != nullptr) *reinterpret_cast<vecW*>(c_ptr(a, r)) = v;
+        const int64_t row = row_w + 4 * (4 * (lane >> 4) + r) + a;  // (row, col_w .. col_w + 3) of the result
+        if (g.out.p != nullptr) {
+#pragma unroll
+          for (int b = 0; b < 4; b += 2) {
+            float x0 = v[b], x1 = v[b + 1];
+            unsigned short* d = g.out.p + syrk_plane_offset(g.o_row0 + zs + row, (int)(g.o_col0 + zs) + col_w + b, g.out.nkb);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(d + p * g.out.stride) = bf16_split_pair(x0, x1);
+          }
         }
-      }
-      if (g.out_t.p != nullptr) {  // element (row, col) of the result is element (col, row) of the transpose
+        if (g.out_t.p != nullptr) {  // element (row, col) of the result is element (col, row) of the transpose
 #pragma unroll
-        for (int b = 0; b < 4; b += 2) {
-          float x0 = v[b], x1 = v[b + 1];
-          unsigned short* d0 = g.out_t.p + syrk_plane_offset(g.ot_row0 + zs + col_w + b, (int)(g.ot_col0 + zs + row), g.out_t.nkb);
-          unsigned short* d1 = g.out_t.p + syrk_plane_offset(g.ot_row0 + zs + col_w + b + 1, (int)(g.ot_col0 + zs + row), g.out_t.nkb);
+          for (int b = 0; b < 4; b += 2) {
+            float x0 = v[b], x1 = v[b + 1];
+            unsigned short* d0 = g.out_t.p + syrk_plane_offset(g.ot_row0 + zs + col_w + b, (int)(g.ot_col0 + zs + row), g.out_t.nkb);
+            unsigned short* d1 = g.out_t.p + syrk_plane_offset(g.ot_row0 + zs + col_w + b + 1, (int)(g.ot_col0 + zs + row), g.out_t.nkb);
 #pragma unroll
-          for (int p = 0; p < 3; ++p) {
-            const unsigned u = bf16_split_pair(x0, x1);
-            d0[p * g.out_t.stride] = (unsigned short)(u & 0xffffu);
-            d1[p * g.out_t.stride] = (unsigned short)(u >> 16);
+            for (int p = 0; p < 3; ++p) {
+              const unsigned u = bf16_split_pair(x0, x1);
+              d0[p * g.out_t.stride] = (unsigned short)(u & 0xffffu);
+              d1[p * g.out_t.stride] = (unsigned short)(u >> 16);
+            }
           }
         }
       }
-    }
-  GPSO_GSTAMP(38, 3);
+    GPSO_GSTAMP(tile_no, 2);
+    if (!have_next) break;
+    cur = nxt;
+    first_tile = false;
+  }
 }
 
-static void launch_gemm_bf16(hipStream_t st, const GemmBf16Desc& g) {
+static int bf16_gemm_grid(int total_slots) {
+  static int cus[64] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n / 8 * 8 > 0 ? n / 8 * 8 : 8;  // a multiple of the 8 XCDs
+  }
+  return std::min(total_slots, cus[dev]);
+}
+// reserve_cus: compute units left to another stream (a workgroup of this kernel fills a CU's LDS, so that many
+// CUs stay free for whatever else is in flight)
+static void launch_gemm_bf16(hipStream_t st, GemmBf16Desc g, int reserve_cus = 0) {
   if (ensure_dyn_lds(reinterpret_cast<const void*>(&gemm_bf16_kernel), kSyrkLdsBytes)) return;
-  const BfTiling tl = bf16_tiling(g);
-  const int64_t ntiles = ((int64_t)tl.nsuper * g.nbatch + 7) / 8 * 8 * tl.per_super;
-  hipLaunchKernelGGL(gemm_bf16_kernel, dim3((unsigned)ntiles), dim3(256), kSyrkLdsBytes, st, g);
+  g.tl = bf16_tiling(g);
+  int grid = bf16_gemm_grid(g.tl.total_slots);
+  if (reserve_cus > 0) grid = std::max(8, std::min(grid, (bf16_gemm_grid(INT_MAX) - reserve_cus) / 8 * 8));
+  hipLaunchKernelGGL(gemm_bf16_kernel, dim3((unsigned)grid), dim3(256), kSyrkLdsBytes, st, g);
 }
 
 // a float block (rows x cols at src, leading dimension ld) -> planes at (row0, col0) and / or its transpose at
@@ -1716,11 +1814,24 @@ int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t
   //   2. rows below:  L21 = A21 X11^T  -- a plain GEMM, X11 the block's lower-triangular inverse;
   //   3. A22 -= L21 L21^T  (lower tiles).
   // The level-doubling inverse then starts at level kOuterPanel (launch_trtri's first_level).
+  // Look-ahead (float fits with planes and a side stream): the diagonal block is a ~15 us x wp / 64 chain of
+  // launches that leaves the chip idle, so block p + 1 is factored on the side stream as soon as the update of
+  // panel p has produced its block column, while the rest of that update (a persistent kernel that leaves
+  // kLookaheadCus compute units to the chain) runs here.  (tools/micro/lookahead_probe.hip: beside a GEMM on all
+  // CUs the chain takes 416 us instead of 263, with 32 CUs left to it 307.)
+  constexpr int kLookaheadCus = 48;  // measured: 8-16 leave the chain's ~100-workgroup launches crawling; 32-64 within 2 %
+  const bool can_look = sizeof(T) == 4 && planes != nullptr && planes->L != nullptr && planes->side != nullptr;
+  bool chain_on_side = false;  // the diagonal block of this iteration was launched on the side stream
   for (int64_t c0 = 0; c0 < npad; c0 += kOuterPanel) {
     const int64_t wp = std::min<int64_t>(kOuterPanel, npad - c0);
     const int64_t off = c0 * npad + c0;
-    potrf_block<T>(st, K + off, Lf + off, linv + off, work + off, nullptr, npad, (int)(wp / kFitBlock), c0, n,
-                   diag64, info);
+    if (chain_on_side) {
+      (void)hipStreamWaitEvent(st, planes->ev_chain, 0);
+      chain_on_side = false;
+    } else {
+      potrf_block<T>(st, K + off, Lf + off, linv + off, work + off, nullptr, npad, (int)(wp / kFitBlock), c0, n,
+                     diag64, info);
+    }
     const int64_t r1 = c0 + wp;
     const int m2 = (int)(npad - r1);
     if (m2 <= 0) break;
@@ -1756,7 +1867,27 @@ int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t
         sy.beta = 1;
         sy.lower_only = 1;
         sy.nbatch = 1;
-        launch_gemm_bf16(st, sy);
+        const int64_t wn = std::min<int64_t>(kOuterPanel, npad - r1);  // the next panel
+        if (can_look && m2 - wn >= kSyrkBf16MinRows) {
+          GemmBf16Desc col = sy;  // its block column first: rows r1.., columns r1 .. r1 + wn
+          col.n = (int)wn;
+          col.lower_only = 0;
+          launch_gemm_bf16(st, col);
+          (void)hipEventRecord(planes->ev_col, st);
+          GemmBf16Desc rest = sy;  // then everything to the right of it (enqueued before the chain's 17 launches:
+          rest.a_row0 = rest.b_row0 = r1 + wn;  // the host needs ~100 us for those)
+          rest.C = reinterpret_cast<float*>(K + (r1 + wn) * npad + (r1 + wn));
+          rest.m = rest.n = (int)(m2 - wn);
+          launch_gemm_bf16(st, rest, kLookaheadCus);
+          (void)hipStreamWaitEvent(planes->side, planes->ev_col, 0);
+          const int64_t off1 = r1 * npad + r1;
+          potrf_block<T>(planes->side, K + off1, Lf + off1, linv + off1, work + off1, nullptr, npad,
+                         (int)(wn / kFitBlock), r1, n, diag64, info);
+          (void)hipEventRecord(planes->ev_chain, planes->side);
+          chain_on_side = true;
+        } else {
+          launch_gemm_bf16(st, sy);
+        }
       }
       continue;
     }

@@ -95,6 +95,10 @@ struct FitPlanes {
   unsigned short *L, *X, *XT, *WT;
   int64_t stride;  // bf16 elements between the three planes of a set
   int nkb;         // npad / 32
+  // look-ahead (all three set, or none): the next diagonal block is factored on `side` while the rest of the
+  // current rank-W update runs on the caller's stream; ev_col / ev_chain order the two streams
+  hipStream_t side = nullptr;
+  hipEvent_t ev_col = nullptr, ev_chain = nullptr;
 };
 inline size_t fit_plane_set_bytes(int64_t npad) { return (size_t)3 * (size_t)npad * (size_t)npad * 2; }
 // planes (float fits, nullable): with them the TRSM GEMMs also emit L into planes->L and the rank-W trailing

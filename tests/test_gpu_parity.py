@@ -625,4 +625,4 @@ def test_float_fit_on_the_bf16_matrix_cores_agrees_with_the_f32_path():
     # and against each other: the split products are float-class
     scale = np.max(np.abs(res[0][1]))
     assert np.max(np.abs(res[1][1] - res[0][1])) <= 2e-4 * scale
-    assert np.max(np.abs(res[1][3] - res[0][3])) <= 1e-5 * np.max(np.abs(res[0][3]))
+    assert np.max(np.abs(res[1][3] - res[0][3])) <= 5e-5 * np.max(np.abs(res[0][3]))

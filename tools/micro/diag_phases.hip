@@ -7,6 +7,13 @@ __device__ long long g_stamps[24];
 #include <cstdio>
 #include <cmath>
 #include <vector>
+namespace gpso {
+int ensure_dyn_lds(const void* fn, int bytes) {
+  if (bytes > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  return 0;
+}
+void note_launch_error(const char* m) { fprintf(stderr, "launch error: %s\n", m); }
+}  // namespace gpso
 using namespace gpso;
 
 int main(int argc, char** argv) {

@@ -4,7 +4,7 @@
 __device__ long long g_gst[4 * 40 * 4];
 __device__ int g_sel[2];
 #ifdef GPSO_BENCH_STAMPS
-#define GPSO_GSTAMP(st, i) do { if ((threadIdx.x & 63) == 0 && ((int)blockIdx.x == g_sel[0] || (int)blockIdx.x == g_sel[1]) && st < 40) g_gst[(((int)blockIdx.x == g_sel[1]) * 2 + (threadIdx.x >> 7)) * 160 + st * 4 + i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define GPSO_GSTAMP(st, i) do { if ((threadIdx.x & 63) == 0 && ((int)blockIdx.x == g_sel[0] || (int)blockIdx.x == g_sel[1]) && st < 40 && i < 3) g_gst[(((int)blockIdx.x == g_sel[1]) * 2 + (threadIdx.x >> 7)) * 160 + st * 4 + i] = __builtin_amdgcn_s_memtime(); } while (0)
 #endif
 #include "../../pygpso_amd/csrc/fit.hip"
 #include <cstdio>
@@ -33,25 +33,20 @@ int main(int argc, char** argv) {
   u.A = A; u.sai = ld; u.sak = 1; u.B = A; u.sbk = 1; u.sbj = ld; u.ldc = ld;
   u.m = (int)m; u.n = (int)m; u.k = (int)k; u.m_last = (int)m; u.nbatch = 1; u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1;
   GemmBf16Desc b{}; b.A = b.B = Bf16Planes{P, (int64_t)hA.size(), (int)(k / 32)}; b.C = C2; b.ldc = ld; b.m = b.n = (int)m; b.k = (int)k; b.alpha = -1.0f; b.beta = 1; b.lower_only = 1; b.nbatch = 1;
-  int sel[2] = {-1, -1};
+  int sel[2] = {17, 100};  // two of the persistent workgroups
 #ifdef GPSO_BENCH_STAMPS
-  {  // two tiles in the middle and near the end of the triangular grid (4 x 4 super-tiles, see gemm_bf16_kernel)
-    const int nt = (int)(m / 128), tis[2] = {nt / 2, nt - 3}, tjs[2] = {nt / 6, nt / 2 - 1};
-    for (int q = 0; q < 2; ++q) {
-      const int I = tis[q] / 4, J = tjs[q] / 4, sg = I * (I + 1) / 2 + J, t = (tis[q] % 4) * 4 + tjs[q] % 4;
-      sel[q] = (((sg / 8) * 16 + t) * 8) + sg % 8;
-    }
-    hipMemcpyToSymbol(HIP_SYMBOL(g_sel), sel, sizeof(sel));
-  }
+  hipMemcpyToSymbol(HIP_SYMBOL(g_sel), sel, sizeof(sel));
 #endif
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const double gf = (double)m * m * k / 1e9;
+  double last_us = 0;
   for (int rep = 0; rep < 3; ++rep) {
     hipMemcpy(C1, hC.data(), hC.size() * 4, hipMemcpyHostToDevice); hipMemcpy(C2, hC.data(), hC.size() * 4, hipMemcpyHostToDevice);
     float t1, t2;
     u.C = C1;
     hipEventRecord(e0, 0); launch_gemm<float>(0, u); hipEventRecord(e1, 0); hipDeviceSynchronize(); hipEventElapsedTime(&t1, e0, e1);
     hipEventRecord(e0, 0); launch_gemm_bf16(0, b); hipEventRecord(e1, 0); hipDeviceSynchronize(); hipEventElapsedTime(&t2, e0, e1);
+    last_us = t2 * 1e3;
     std::vector<float> r1(hC.size()), r2(hC.size());
     hipMemcpy(r1.data(), C1, r1.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(r2.data(), C2, r2.size() * 4, hipMemcpyDeviceToHost);
     double maxd = 0, maxv = 0;
@@ -66,13 +61,11 @@ int main(int argc, char** argv) {
 #ifdef GPSO_BENCH_STAMPS
   long long gs[641] = {0}; hipMemcpyFromSymbol(gs, HIP_SYMBOL(g_gst), 640 * 8);
   for (int w = 0; w < 4; ++w) {
-    printf("block %d wave %d: per step [wait | barrier | groups 0-11 (+dma, reads) | groups 12-15]:", w < 2 ? sel[0] : sel[1], (w & 1) * 2);
-    for (int st = 0; st + 1 < (int)(k / 32) && st < 12; ++st) {
-      const long long* a = gs + w * 160 + st * 4;
-      printf(" %lld|%lld|%lld|%lld", a[1] - a[0], a[2] - a[1], a[3] - a[2], a[4] - a[3]);
-    }
-    { const long long* q = gs + w * 160; printf("\n   prologue: decode %lld | C issue %lld | addresses + DMA issue %lld | C arrives + wait landed %lld | barrier + fragment reads %lld", q[156] - q[152], q[157] - q[156], q[158] - q[157], q[159] - q[158], q[153] - q[159]); }
-    printf("\n   whole tile: decode+prologue %lld | k-loop %lld | epilogue %lld\n", gs[w * 160 + 38 * 4 + 1] - gs[w * 160 + 38 * 4], gs[w * 160 + 38 * 4 + 2] - gs[w * 160 + 38 * 4 + 1], gs[w * 160 + 38 * 4 + 3] - gs[w * 160 + 38 * 4 + 2]);
+    printf("workgroup %d wave %d, per tile [decode + first two steps .. k-loop | wait + C + stores]:", w < 2 ? sel[0] : sel[1], (w & 1) * 2);
+    const long long* q = gs + w * 160;
+    int nt = 0;
+    for (int t = 0; t < 39 && q[4 * t + 2] != 0; ++t, ++nt) printf(" %lld|%lld", q[4 * t + 1] - q[4 * t], q[4 * t + 2] - q[4 * t + 1]);
+    if (nt > 0) printf("\n   %d tiles in %lld clocks (kernel %.0f us)\n", nt, q[4 * (nt - 1) + 2] - q[0], last_us);
   }
 #endif
   return 0;
