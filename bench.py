@@ -40,13 +40,15 @@ WORKLOADS = {
     "c5": (40, 16384, 131072, "float32", "C5 (one GPU's share): D=40 N_train=16384 leaves=131072/GPU fp32 Matern52"),
 }
 PEAK_TFLOPS = {"float32": 157.3, "float64": 78.6}  # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak; a split product costs 6 (bf16x6) or 3 (bf16x3) bf16 MFMAs
 # HBM bytes per launch of the dominant kernel come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
 # cannot be read from inside the process); the committed record of the latest collection:
-PMC_TRAFFIC = {"c3": "profiles/r02f_pmc_leaf_tiles_c3.json"}
+PMC_TRAFFIC = {("c3", "native"): "profiles/r02f_pmc_leaf_tiles_c3.json",
+               ("c3", "bf16x6"): "profiles/r02g_pmc_leaf_tiles_bf16x6_c3.json"}
 
 
-def pmc_traffic(workload):
-    path = os.path.join(ROOT, PMC_TRAFFIC.get(workload, ""))
+def pmc_traffic(workload, math_mode):
+    path = os.path.join(ROOT, PMC_TRAFFIC.get((workload, math_mode), ""))
     if not os.path.isfile(path):
         return None, None
     with open(path) as fh:
@@ -137,7 +139,8 @@ def split_bf16_report(eng, leaves_dev, leaves_all, varsigma, m_total, flops_per_
     product) and measure the error of each mode -- and of native f32 -- against the float64 oracle."""
     from oracle import gpr
 
-    rep = {"note": "opt-in gpso_set_option(GPSO_OPT_PREDICT_MATH); the headline value above is native f32"}
+    rep = {"note": "gpso_set_option(GPSO_OPT_PREDICT_MATH): every predict math on the same leaves in the same run; "
+                   "the headline value above is the default (GPSO_MATH_AUTO)"}
     sample = leaves_all[:2048]
     ref = gpr.predict_y(post, sample) if post is not None else None
     time.sleep(0.5)  # let the BLAS worker threads of the CPU-baseline leg stop spinning
@@ -158,7 +161,7 @@ def split_bf16_report(eng, leaves_dev, leaves_all, varsigma, m_total, flops_per_
             entry["max_abs_err_mean_vs_f64_oracle"] = float(np.max(np.abs(mean - ref[0])))
             entry["max_abs_err_var_vs_f64_oracle"] = float(np.max(np.abs(var - ref[1])))
         rep[mode] = entry
-    eng.set_predict_math("native")
+    eng.set_predict_math("auto")
     return rep
 
 
@@ -170,8 +173,9 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--noise", type=float, default=1.0e-3, help="noise variance of the synthetic posterior")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--math", default="native", choices=["native", "bf16x3", "bf16x6"],
-                    help="predict math of float32 workloads (split-bf16 modes are opt-in)")
+    ap.add_argument("--math", default="auto", choices=["auto", "native", "bf16x3", "bf16x6"],
+                    help="predict math of float32 workloads (auto = the library default: bf16x6 where the "
+                         "posterior's self-test passes with it, else native f32)")
     args = ap.parse_args()
 
     import torch
@@ -203,8 +207,8 @@ def main():
     X, y, leaves_all = synthetic(n, d, m_total)
     theta = ("Matern52", 0.25 * math.sqrt(d), 1.0, args.noise, float(y.mean()))
 
-    math_mode = args.math if dtype == "float32" else "native"
-    eng = HipGPEngine(dtype, device=local_rank, predict_math=math_mode)
+    math_opt = args.math if dtype == "float32" else "native"
+    eng = HipGPEngine(dtype, device=local_rank, predict_math=math_opt)
     # ---- fit on rank 0 (timed separately), broadcast the predict-ready posterior ----------------
     fit_ms = {}
 
@@ -219,8 +223,11 @@ def main():
                 fit_ms[name] = float(np.median(ts))
         eng.fit_eval(*theta, want_grad=False)
 
+    math_mode = "native"
     if rank == 0:
         fit_here(timed=True)
+        if dtype == "float32":  # what GPSO_MATH_AUTO settled on for this posterior (its self-test ran here)
+            math_mode = eng.precision_info()["predict_math"]
     bcast_ms = None
     posterior_bytes = None
     distribution = "single GPU"
@@ -275,7 +282,8 @@ def main():
         kern_ms = float(np.mean(tile_ms))
         flops_per_leaf = n * n + 2 * n * d + 20 * n
         achieved = flops_per_leaf * (hi - lo) / (kern_ms * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic(args.workload)
+        traffic, traffic_src = pmc_traffic(args.workload, math_mode)
+        peak = PEAK_TFLOPS[dtype] if math_mode == "native" else PEAK_BF16_TFLOPS / int(math_mode[-1])
         out = {
             "metric": "leaf_ucb_predictions_per_sec",
             "value": m_total * args.steps / elapsed,
@@ -293,7 +301,7 @@ def main():
                 "workload": label, "D": d, "N_train": n, "leaves_per_gpu": m_per_gpu,
                 "leaves_total": m_total, "kernel": "Matern52", "lengthscale": theta[1],
                 "noise_variance": theta[3], "parallelism": f"leaf-shard x{world}",
-                "leaves_resident_in_hbm": True, "predict_math": math_mode,
+                "leaves_resident_in_hbm": True, "predict_math": math_mode, "predict_math_option": math_opt,
             },
             "fit_ms": fit_ms,
             "roofline_fit": roofline_fit(n, d, dtype, fit_ms),
@@ -304,11 +312,10 @@ def main():
             "winner": {"index": winner[0], "ucb": winner[3]},
             "roofline": {
                 "kernel": "leaf_tiles_kernel" if math_mode == "native" else f"leaf_tiles_bf16_kernel({math_mode})",
-                "bound": "mfma", "achieved": achieved,
-                "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[dtype],
-                "peak_note": None if math_mode == "native" else
-                "algorithmic f32-equivalent FLOPs against the f32 MFMA peak; the kernel issues "
-                f"{math_mode[-1]} bf16 MFMAs per f32 product on the 2.5 PFLOP/s bf16 pipe",
+                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "peak_note": "dense f32 / f64 MFMA peak" if math_mode == "native" else
+                f"algorithmic (f32-equivalent) FLOPs; the kernel forms every f32 product from {math_mode[-1]} bf16 MFMAs "
+                f"with f32 accumulation, so the bound is the dense bf16 peak / {math_mode[-1]} = {peak:.0f} TFLOP/s",
                 "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC, gfx950-corrected)",
                 "traffic_source": traffic_src,
                 "algorithmic_bytes": int((hi - lo) * (d + 3) * (4 if dtype == "float32" else 8)
@@ -328,9 +335,9 @@ def main():
             ucb_ref = mean_ref + varsigma * var_ref
             if winner[0] < n_s:
                 out["winner"]["oracle_ucb_at_index"] = float(ucb_ref[winner[0]])
-        if world == 1 and dtype == "float32" and math_mode == "native":
-            # opt-in split-bf16 predict math, same leaves, same run: throughput + accuracy vs the oracle
-            out["split_bf16"] = split_bf16_report(eng, leaves_dev, leaves_all, varsigma, m_total,
+        if world == 1 and dtype == "float32" and math_opt == "auto":
+            # every predict math on the same leaves in the same run: throughput + accuracy vs the oracle
+            out["predict_math_modes"] = split_bf16_report(eng, leaves_dev, leaves_all, varsigma, m_total,
                                                   flops_per_leaf, post, max(3, args.steps // 2))
         print(json.dumps(out))
     if use_dist:

@@ -251,7 +251,10 @@ struct EngineT : Engine {
   DevBuf linv_b;
   DevBuf pl_L, pl_X, pl_XT, pl_WT;  // bf16 plane sets of the two-level float fit (kernels.hpp: FitPlanes)
   bool bf16_fit = true;             // GPSO_OPT_FIT_BF16_SYRK
-  int math = GPSO_MATH_NATIVE;
+  // predict math: the OPTION (math_auto: GPSO_MATH_AUTO) and what the resident posterior uses (math, and
+  // math_native_fallback when the self-test preferred the f32 MFMA kernel for it)
+  int math = kFloatPredict ? GPSO_MATH_BF16X6 : GPSO_MATH_NATIVE;
+  bool math_auto = kFloatPredict, math_native_fallback = false;
   // generation of the cross-Gram tile in float-predict contexts: the OPTION (gen_mode) and what the
   // resident posterior actually uses (gen_eff32).  GPSO_GEN_AUTO starts every posterior in float -- the
   // fast form -- and lets the precision self-test decide: if the float form misses the tolerances the
@@ -296,7 +299,7 @@ struct EngineT : Engine {
   // decides the generation type, the kernel follows)
   bool bf16_fits(bool gen64) const { return leaf_bf16_lds_bytes(nsplit(), dp / 4, gen64 ? 8 : 4) <= 160 * 1024; }
   int nsplit() const { return math == GPSO_MATH_BF16X6 ? 3 : 2; }
-  bool bf16_usable() const { return kFloatPredict && math != GPSO_MATH_NATIVE && npad > 0 && npad % 256 == 0; }
+  bool bf16_usable() const { return kFloatPredict && math != GPSO_MATH_NATIVE && !math_native_fallback && npad > 0 && npad % 256 == 0; }
 
   // (re)build the bf16 pieces of L^-1 from the fit-type L^-1 resident in `linv`
   int pack_bf16() {
@@ -347,12 +350,16 @@ struct EngineT : Engine {
       default:
         return ctx->fail(GPSO_E_ARG, "unknown option %d", option);
     }
-    if (value != GPSO_MATH_NATIVE && value != GPSO_MATH_BF16X3 && value != GPSO_MATH_BF16X6)
+    if (value != GPSO_MATH_NATIVE && value != GPSO_MATH_BF16X3 && value != GPSO_MATH_BF16X6 && value != GPSO_MATH_AUTO)
       return ctx->fail(GPSO_E_ARG, "unknown predict math %d", value);
-    if (value != GPSO_MATH_NATIVE && !kFloatPredict)
+    if (value != GPSO_MATH_NATIVE && value != GPSO_MATH_AUTO && !kFloatPredict)
       return ctx->fail(GPSO_E_ARG, "split-bf16 predict math needs a GPSO_F32 or GPSO_MIXED context");
-    if (value == math) return GPSO_OK;
+    const bool want_auto = value == GPSO_MATH_AUTO;
+    if (want_auto) value = kFloatPredict ? GPSO_MATH_BF16X6 : GPSO_MATH_NATIVE;
+    if (value == math && want_auto == math_auto && !math_native_fallback) return GPSO_OK;
     math = value;
+    math_auto = want_auto;
+    math_native_fallback = false;
     linv_b_valid = false;
     st_done = false;
     reset_generation();
@@ -500,6 +507,7 @@ struct EngineT : Engine {
   // a new posterior (or new options): generation starts over -- float unless double was asked for -- and the
   // self-test has to rule again
   void reset_generation() {
+    math_native_fallback = false;
     gen_eff32 = kFloatPredict && gen_mode != GPSO_GEN_F64;
     gen_decided = false;
     gen32_inputs_ok = false;
@@ -856,12 +864,27 @@ struct EngineT : Engine {
     gen_decided = true;
     return GPSO_OK;
   }
+  // the self-test, and under GPSO_MATH_AUTO a second look with the f32 MFMA kernel where the split-bf16 apply
+  // misses the tolerances on this posterior
+  int selftest_with_fallback() {
+    int rc = run_selftest();
+    if (rc) return rc;
+    if (!st_pass() && math_auto && bf16_usable() && linv_b_valid) {
+      math_native_fallback = true;
+      st_done = false;
+      rc = run_selftest();
+    }
+    return rc;
+  }
+  int math_in_use() const {
+    return (bf16_usable() && linv_b_valid && bf16_fits(gen_double())) ? math : GPSO_MATH_NATIVE;
+  }
   // called at the top of every predict-type entry point
   int precision_gate() {
     int rc = decide_generation();
     if (rc) return rc;
     if (!check || !st_have || !have_data) return GPSO_OK;  // posteriors installed from outside carry no targets
-    if ((rc = run_selftest())) return rc;
+    if ((rc = selftest_with_fallback())) return rc;
     if (!st_pass())
       return ctx->fail(GPSO_E_PRECISION,
                        "float predict arithmetic fails the self-test on this posterior: at the training inputs "
@@ -876,7 +899,7 @@ struct EngineT : Engine {
     if (!have_post) return ctx->fail(GPSO_E_STATE, "no posterior resident");
     int rc = decide_generation();
     if (rc) return rc;
-    if ((rc = run_selftest())) return rc;
+    if ((rc = selftest_with_fallback())) return rc;
     for (int i = 0; i < 5; ++i) out[i] = st_vals[i];
     out[5] = kp.variance;
     out[6] = tol_mean_abs();
@@ -884,6 +907,7 @@ struct EngineT : Engine {
     out[8] = amplification();
     out[9] = st_vals[5];
     out[10] = gen_double() ? 0.0 : 1.0;
+    out[11] = (double)math_in_use();
     if (!st_pass()) return ctx->fail(GPSO_E_PRECISION, "self-test: max |d mean| %.3g (tol %.3g), max |d var| %.3g (tol %.3g), amplification %.3g",
                                      st_vals[0], out[6], st_vals[1], out[7], out[8]);
     return GPSO_OK;
@@ -1215,11 +1239,15 @@ struct EngineT : Engine {
     int64_t* hd = as<int64_t>(bhdr);
     int64_t* host = reinterpret_cast<int64_t*>(ctx->pinned_scratch(8));
     if (!host) return ctx->fail(GPSO_E_OOM, "pinned host scratch");
-    const int64_t my_opts = (int64_t)math | ((int64_t)ctx->dtype << 16);
     int64_t ok = 1;
     if (is_root) {
       // still take part in the collectives below when something is wrong: every rank must leave together
       if (!have_post || decide_generation() != GPSO_OK) ok = 0;
+      else if (check && st_have && have_data && selftest_with_fallback() != GPSO_OK) ok = 0;  // settles GPSO_MATH_AUTO
+    }
+    // the predict math the posterior travels with (under GPSO_MATH_AUTO the root's self-test has chosen)
+    const int64_t my_opts = (int64_t)(math_native_fallback ? GPSO_MATH_NATIVE : math) | ((int64_t)ctx->dtype << 16);
+    if (is_root) {
       host[0] = n; host[1] = d; host[2] = my_opts; host[3] = ok;
       HIPCHECK(hipMemcpyAsync(hd, host, 48, hipMemcpyHostToDevice, s));
     }
@@ -1229,9 +1257,14 @@ struct EngineT : Engine {
     const int64_t rn = host[0], rd = host[1], ropts = host[2];
     ok = host[3];
     const char* why = ok ? nullptr : "the root has no usable posterior resident";
-    if (ok && ropts != my_opts) {
-      ok = 0;
-      why = "dtype / predict math options differ from the root's";
+    if (ok && !is_root) {
+      const int64_t rmath = ropts & 0xffff, rdtype = ropts >> 16;
+      if (rdtype == (int64_t)ctx->dtype && math_auto && (rmath == math || rmath == GPSO_MATH_NATIVE)) {
+        math_native_fallback = rmath == GPSO_MATH_NATIVE && math != GPSO_MATH_NATIVE;  // the root's choice
+      } else if (rdtype != (int64_t)ctx->dtype || rmath != math) {
+        ok = 0;
+        why = "dtype / predict math options differ from the root's";
+      }
     }
     // agree: min over the ranks of `ok` (slot 4 of the header block)
     host[4] = ok;
@@ -1298,15 +1331,17 @@ struct EngineT : Engine {
 
   // hyper | packed L^-1 | scaled inputs (double: plain, MFMA fragments, norms) | alpha [| bf16 pieces].
   // The generation inputs always travel in double; a receiver derives the float copies itself when the
-  // sender's choice (slot 7 of the hyper block, written here) is float generation.
+  // sender's choice (slot 7 of the hyper block, written here: 1 = float generation, + 2 = GPSO_MATH_AUTO
+  // settled on the f32 MFMA kernel for this posterior) is float generation.
   int posterior_buffers(void** ptrs, int64_t* nbytes, int cap) override {
     if (npad == 0) return ctx->fail(GPSO_E_STATE, "no problem shape yet");
     if (cap < 7) return ctx->fail(GPSO_E_ARG, "need room for 7 buffers");
     if (have_post) {
       int rc = decide_generation();
       if (rc) return rc;
+      if (check && st_have && have_data && (rc = selftest_with_fallback())) return rc;  // settles GPSO_MATH_AUTO
       double* flag = ctx->pinned_scratch(256) + 120;  // (a slot neither the read-backs nor set_theta use)
-      *flag = gen_double() ? 0.0 : 1.0;
+      *flag = (gen_double() ? 0.0 : 1.0) + (math_native_fallback ? 2.0 : 0.0);
       HIPCHECK(hipMemcpyAsync(as<double>(hyper) + 7, flag, 8, hipMemcpyHostToDevice, st()));
       HIPCHECK(hipStreamSynchronize(st()));  // callers copy these buffers on streams of their own
     }
@@ -1355,7 +1390,10 @@ struct EngineT : Engine {
     st_done = st_have = false;     // the fitting rank ran the self-test; no targets here
     linv_b_valid = bf16_usable();  // the bf16 pieces travel with the posterior when the mode is on
     // generation arithmetic: the sender's choice (its self-test ruled), unless this context insists
-    gen_eff32 = kFloatPredict && (gen_mode == GPSO_GEN_F32 || (gen_mode == GPSO_GEN_AUTO && h[7] == 1.0));
+    const int sender = (int)h[7];
+    math_native_fallback = math_auto && (sender & 2) != 0;
+    linv_b_valid = bf16_usable();
+    gen_eff32 = kFloatPredict && (gen_mode == GPSO_GEN_F32 || (gen_mode == GPSO_GEN_AUTO && (sender & 1) != 0));
     gen_decided = true;
     gen32_inputs_ok = false;
     return GPSO_OK;

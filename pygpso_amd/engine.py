@@ -33,13 +33,15 @@ def _producer_stream(x):
 
 
 class HipGPEngine:
-    def __init__(self, dtype="float64", device=0, predict_math="native", generation=None,
+    def __init__(self, dtype="float64", device=0, predict_math=None, generation=None,
                  precision_check=None, tol_var=None, tol_mean=None):
         """``dtype``: "float64" (fit and predict in double: the reference's arithmetic), "float32" (fit
         and predict apply in float) or "mixed" (fit in double, predict apply in float: the
         hyper-parameter path is bit-identical to float64).
-        ``predict_math`` (float-predict engines only): "native" f32 MFMA, or the split-bf16 modes
-        "bf16x6" (f32-class accuracy) / "bf16x3" (|d var| ~ 2e-5 sigma^2) on the bf16 matrix cores.
+        ``predict_math`` (float-predict engines only): "auto" (default: "bf16x6" where the posterior's
+        shape allows it and its self-test passes with it, else "native"), "native" f32 MFMA, or the
+        split-bf16 modes "bf16x6" (six bf16 MFMAs per f32 product, f32 accumulation: f32-class
+        accuracy) / "bf16x3" (|d var| ~ 2e-5 sigma^2) on the bf16 matrix cores.
         ``generation`` (float-predict engines): "auto" (default: float when the posterior's self-test
         passes with it, else double), "float64" (r^2 of the cross-Gram tile formed in double) or
         "float32" (GPflow's GEMM form in float: faster, |d r^2| ~ 1e-5).
@@ -61,7 +63,7 @@ class HipGPEngine:
         self.n = 0
         self.d = 0
         self.rank, self.world = 0, 1
-        if predict_math not in (None, "native", "f32"):
+        if predict_math is not None and not (predict_math in ("native", "f32") and self.dtype == L.F64):
             self.set_predict_math(predict_math)
         if generation is not None:
             self.set_generation(generation)
@@ -114,7 +116,7 @@ class HipGPEngine:
     def precision_info(self, raise_on_fail=False):
         """Self-test of the resident posterior (runs it if needed): measured errors of the predict path
         at the training inputs against their closed form, and the tolerances they are held to."""
-        out = np.zeros(11, dtype=np.float64)
+        out = np.zeros(12, dtype=np.float64)
         rc = self._lib.gpso_precision_info(self._h, L.dptr(out))
         if rc not in (L.OK, L.E_PRECISION) or (rc == L.E_PRECISION and raise_on_fail):
             self._check(rc)
@@ -122,6 +124,7 @@ class HipGPEngine:
                 "kernel_variance", "tol_mean_abs", "tol_var_abs", "amplification", "max_kinv_diag")
         info = dict(zip(keys, (float(v) for v in out)))
         info["generation"] = "float32" if out[10] else "float64"
+        info["predict_math"] = {L.MATH_NATIVE: "native", L.MATH_BF16X3: "bf16x3", L.MATH_BF16X6: "bf16x6"}[int(out[11])]
         info["passed"] = rc == L.OK
         return info
 

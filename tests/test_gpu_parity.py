@@ -147,13 +147,27 @@ def test_predict_math_option_rules():
     Xs = synthetic_leaves(700, 4)
     eng = HipGPEngine("float32")
     _fit(eng, X, y, th, grad=False)
+    d = eng.predict(Xs)  # the default, GPSO_MATH_AUTO: bf16x6 here (padded N a multiple of 256, self-test passes)
+    assert eng.precision_info()["predict_math"] == "bf16x6"
+    eng.set_predict_math("native")  # switching after the fit takes effect on the spot
     a = eng.predict(Xs)
-    eng.set_predict_math("bf16x6")  # switching after the fit repacks L^-1 on the spot
+    assert eng.precision_info()["predict_math"] == "native"
+    eng.set_predict_math("bf16x6")  # ... and repacks L^-1
     b = eng.predict(Xs)
     eng.set_predict_math("native")
     c = eng.predict(Xs)
     assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+    assert np.array_equal(d[0], b[0]) and np.array_equal(d[1], b[1])
     assert np.max(np.abs(a[1] - b[1])) < 1e-4 and not np.array_equal(a[1], b[1])
+    eng.set_predict_math("auto")
+    e = eng.predict(Xs)
+    assert np.array_equal(d[1], e[1])
+    # shapes the split kernel does not take (padded N not a multiple of 256) run the f32 MFMA kernel
+    X2, y2, th2 = _problem(100, 4)
+    eng2 = HipGPEngine("float32")
+    _fit(eng2, X2, y2, th2, grad=False)
+    eng2.predict(Xs)
+    assert eng2.precision_info()["predict_math"] == "native"
 
 
 def test_segments_ragged_empty_and_first_max_ties():
