@@ -42,10 +42,10 @@ int launch_leaf_tiles(hipStream_t st, const T* linv_p, const TG* xs_p, const TG*
 template <typename TF>
 void launch_pack_linv_bf16(hipStream_t st, int nsplit, const TF* linv, int64_t n, int64_t npad,
                            void* linv_b);
-// dynamic LDS of the split-bf16 kernel: A pieces (2 buffers x nsplit x 16 KiB) + 2 X buffers + the 8 waves' leaf
+// dynamic LDS of the split-bf16 kernel: A pieces (2 buffers x nsplit x 16 KiB) + 3 X buffers + the 8 waves' leaf
 // fragments, for a generation type of tg_bytes
 inline size_t leaf_bf16_lds_bytes(int nsplit, int dp4, int tg_bytes) {
-  return (size_t)2 * nsplit * 16 * 64 * 16 + (size_t)2 * (2 * dp4 * 64 * tg_bytes + 64 * tg_bytes + 256) +
+  return (size_t)2 * nsplit * 16 * 64 * 16 + (size_t)3 * (2 * dp4 * 64 * tg_bytes + 64 * tg_bytes + 256) +
          (size_t)8 * 2 * dp4 * 64 * tg_bytes;
 }
 template <typename TG>

@@ -111,6 +111,9 @@ __device__ __forceinline__ size_t linv_tile(int rt, int kt) {
   return ((size_t)rt * (size_t)(rt + 1) / 2 + (size_t)kt) * 64;
 }
 
+#ifndef GPSO_BSTAMP
+#define GPSO_BSTAMP(q, i)  // tools/micro/leaf_bf16_phases.hip defines this to record s_memtime stamps
+#endif
 #ifndef GPSO_PSTAMP
 #define GPSO_PSTAMP(kt, i)  // tools/micro/leaf_phases.hip defines this to record s_memtime stamps
 #endif
@@ -409,15 +412,21 @@ struct Bf16Lds {
   static __host__ __device__ constexpr int xbytes(int dp4) { return 2 * dp4 * 64 * (int)sizeof(TG) + 64 * (int)sizeof(TG) + 256; }
 };
 
-template <int NS, typename TG, int KERNEL, bool DIAG>
-__device__ __forceinline__ void leaf_bf16_step(int q, int q_diag0, int lane, int dp4,
-                                               const u32x4* panel_b /* [NS][16][64] */,
-                                               const unsigned char* xs_b /* [2][dp4] X fragments | norms | alpha */,
-                                               const TG* xb, const TG (&nb)[2], float variance,
-                                               f32x4 (&acc)[16][2], float (&macc)[2]) {
+// One k-step (32 training points) of the split-bf16 leaf tile is two stretches of very different kind: the
+// GENERATION of this wave's 32 x 32 cross-Gram values (x.x* contraction, kernel map, split into bf16 pieces:
+// vector ALU work) and the APPLY (192 bf16 MFMAs: 3072 clocks of the matrix pipe).  Two waves share a SIMD, and a
+// workgroup barrier per step starts them together: run in the same order they fight for the vector ALU, then
+// queue for the matrix pipe.  So the waves of a SIMD run the two stretches in OPPOSITE order (waves 0-3 generate
+// step q, then apply it; waves 4-7 apply step q with the pieces they generated during step q - 1, then generate
+// step q + 1): one wave's vector work runs under the other's MFMAs.
+template <int NS, typename TG, int KERNEL>
+__device__ __forceinline__ void leaf_bf16_gen(bool diag, int lane, int dp4,
+                                              const unsigned char* xs_b /* [2][dp4] X fragments | norms | alpha */,
+                                              const TG* xb, const TG (&nb)[2], float variance,
+                                              bf16x8 (&bfrag)[NS][2], float (&macc)[2]) {
   using MG = Mfma<TG>;
   using vecG = typename MG::vec4;
-  constexpr int RT = 16, CT = 2;
+  constexpr int CT = 2;
   constexpr int XB = 64 * (int)sizeof(TG);
   constexpr TG C2 = (TG)KernScale<KERNEL>::C2;
   // ---- generate the two 16-point tiles of this k-step (TG) --------------------------------------
@@ -450,7 +459,7 @@ __device__ __forceinline__ void leaf_bf16_step(int q, int q_diag0, int lane, int
       for (int r = 0; r < 4; ++r)
         p[t][4 * h + r] = kern_from_scaled<KERNEL>((float)fma_t((TG)(TG(-2) * C2), s[h][t][r], na[r] + nb[t]), variance);
   }
-  if (DIAG) {  // this k-step lies in the diagonal block: its share of k*.alpha (f32, before the split)
+  if (diag) {  // this k-step lies in the diagonal block (wave-uniform): its share of k*.alpha (f32, before the split)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const f32x4 a4 = *reinterpret_cast<const f32x4*>(alp + 16 * h + 4 * (lane >> 4));
@@ -461,7 +470,6 @@ __device__ __forceinline__ void leaf_bf16_step(int q, int q_diag0, int lane, int
     }
   }
   // ---- split into bf16 pieces: B operands ---------------------------------------------------------
-  bf16x8 bfrag[NS][CT];
 #pragma unroll
   for (int t = 0; t < CT; ++t)
 #pragma unroll
@@ -471,7 +479,13 @@ __device__ __forceinline__ void leaf_bf16_step(int q, int q_diag0, int lane, int
       for (int h = 0; h < 4; ++h) f[h] = bf16_split_pair(p[t][2 * h], p[t][2 * h + 1]);
       bfrag[sp][t] = __builtin_bit_cast(bf16x8, f);
     }
-  // ---- apply: acc[rt][t] += sum over the kept piece products, small terms first -------------------
+}
+
+// apply: acc[rt][t] += sum over the kept piece products, small terms first
+template <int NS>
+__device__ __forceinline__ void leaf_bf16_apply(int q, int q_diag0, int lane, const u32x4* panel_b /* [NS][16][64] */,
+                                                const bf16x8 (&bfrag)[NS][2], f32x4 (&acc)[16][2]) {
+  constexpr int RT = 16, CT = 2;
   u32x4 a[2][NS];
 #pragma unroll
   for (int sp = 0; sp < NS; ++sp) a[0][sp] = panel_b[(sp * RT + 0) * 64 + lane];
@@ -482,7 +496,7 @@ __device__ __forceinline__ void leaf_bf16_step(int q, int q_diag0, int lane, int
       for (int sp = 0; sp < NS; ++sp) a[(rt + 1) & 1][sp] = panel_b[(sp * RT + rt + 1) * 64 + lane];
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (DIAG && 2 * (q - q_diag0) > rt) continue;  // all-zero tiles above the diagonal
+    if (2 * (q - q_diag0) > rt) continue;  // diagonal block: all-zero tiles above the diagonal (never true before it)
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
       f32x4 c = acc[rt][t];
@@ -514,11 +528,11 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   extern __shared__ __align__(16) unsigned char lds_raw[];
   if (m_live != nullptr && (int64_t)blockIdx.x * (NW * CT * 16) >= *m_live) return;  // workgroup-uniform
   u32x4* panel = reinterpret_cast<u32x4*>(lds_raw);                 // [2][NS][RT][64]
-  unsigned char* xsl = reinterpret_cast<unsigned char*>(panel + 2 * NS * RT * 64);  // [2] X buffers
+  unsigned char* xsl = reinterpret_cast<unsigned char*>(panel + 2 * NS * RT * 64);  // [3] X buffers
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int xstride = Bf16Lds<TG>::xbytes(dp4);
-  TG* xb = reinterpret_cast<TG*>(xsl + 2 * xstride) + (size_t)wave * CT * dp4 * 64;  // [CT][dp4][64] per wave
+  TG* xb = reinterpret_cast<TG*>(xsl + 3 * xstride) + (size_t)wave * CT * dp4 * 64;  // [CT][dp4][64] per wave
 
   const int bi = nbi - 1 - (int)blockIdx.y;
   const int64_t col0 = ((int64_t)blockIdx.x * NW + wave) * (CT * 16);
@@ -526,13 +540,18 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   const int npad32 = npad16 / 2;
   const int q_diag0 = bi * (RT / 2), q_end = q_diag0 + RT / 2;
 
-  auto issue = [&](int q, int buf) {
+  // the L^-1 pieces of a k-step: two buffers (step q + 1 lands while step q is applied)
+  auto issue_panel = [&](int q, int buf) {
     for (int f = wave; f < NS * RT; f += NW) {
       const int sp = f / RT, rt = f % RT;
       glds16(linv_b + (((size_t)sp * npad16 + (bi * RT + rt)) * npad32 + q) * 64 + lane,
              panel + ((buf * NS + sp) * RT + rt) * 64);
     }
-    unsigned char* xd = xsl + buf * xstride;
+  };
+  // the inputs of a k-step (X fragments, norms, alpha): a ring of three buffers -- waves 4-7 generate step q + 1
+  // during step q
+  auto issue_x = [&](int q) {
+    unsigned char* xd = xsl + (q % 3) * xstride;
     for (int i = wave; i < 2 * dp4; i += NW) {
       const int h = i / dp4, c = i % dp4;
       glds_xfrag<TG>(xs_p + ((size_t)(2 * q + h) * dp4 + c) * 64, xd + (h * dp4 + c) * XB, lane);
@@ -546,7 +565,9 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     if (wave == NW - 2) glds4(alpha + 32 * q + (lane & 31), xd + 2 * dp4 * XB + 64 * sizeof(TG));
   };
 
-  issue(0, 0);
+  issue_panel(0, 0);
+  issue_x(0);
+  if (1 < q_end) issue_x(1);
   for (int t = 0; t < CT; ++t)
     for (int c = 0; c < dp4; ++c)
       xb[(t * dp4 + c) * 64 + lane] =
@@ -560,22 +581,34 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
 #pragma unroll
     for (int t = 0; t < CT; ++t) acc[rt][t] = f32x4{0, 0, 0, 0};
   float macc[CT] = {0, 0};
+  bf16x8 bfrag[NS][CT];
   __syncthreads();
 
-  for (int q = 0; q < q_diag0; ++q) {
-    const int b = q & 1;
-    issue(q + 1, b ^ 1);
-    leaf_bf16_step<NS, TG, KERNEL, false>(q, q_diag0, lane, dp4, panel + b * NS * RT * 64,
-                                          xsl + b * xstride, xb, nb, variance, acc, macc);
-    __syncthreads();
+  // Interval k (between workgroup barriers k - 1 and k): waves 0-3 generate and apply step k; waves 4-7 apply step
+  // k and generate step k + 1.  One copy of the code: every wave runs gen(q), apply(q) for q = 0, 1, ...; only the
+  // place of the barrier differs -- after apply(q) for waves 0-3, after gen(q) (q >= 1) for waves 4-7, which
+  // therefore meet one last barrier after the loop.  DMA issued in interval k (L^-1 pieces of step k + 1 into the
+  // buffer step k - 1 was applied from; inputs of step k + 2 into the ring of three) has landed at barrier k.
+  const bool ahead = wave >= NW / 2;
+  auto issue_for = [&](int k) {
+    if (k + 1 < q_end) issue_panel(k + 1, (k + 1) & 1);
+    if (k + 2 < q_end) issue_x(k + 2);
+  };
+  for (int q = 0; q < q_end; ++q) {
+    GPSO_BSTAMP(q, 0);
+    if (!ahead || q == 0) issue_for(q);
+    else if (q >= 2) issue_for(q - 1);  // (this wave's iteration q starts in interval q - 1)
+    GPSO_BSTAMP(q, 1);
+    leaf_bf16_gen<NS, TG, KERNEL>(q >= q_diag0, lane, dp4, xsl + (q % 3) * xstride, xb, nb, variance, bfrag, macc);
+    GPSO_BSTAMP(q, 2);
+    if (ahead && q > 0) __syncthreads();
+    GPSO_BSTAMP(q, 3);
+    leaf_bf16_apply<NS>(q, q_diag0, lane, panel + (q & 1) * NS * RT * 64, bfrag, acc);
+    GPSO_BSTAMP(q, 4);
+    if (!ahead) __syncthreads();
+    GPSO_BSTAMP(q, 5);
   }
-  for (int q = q_diag0; q < q_end; ++q) {
-    const int b = q & 1;
-    if (q + 1 < q_end) issue(q + 1, b ^ 1);
-    leaf_bf16_step<NS, TG, KERNEL, true>(q, q_diag0, lane, dp4, panel + b * NS * RT * 64,
-                                         xsl + b * xstride, xb, nb, variance, acc, macc);
-    __syncthreads();
-  }
+  if (ahead) __syncthreads();
 
 #pragma unroll
   for (int t = 0; t < CT; ++t) {
