@@ -605,11 +605,12 @@ struct EngineT : Engine {
       const int done = launch_potrf<TF>(s, as<TF>(K), as<TF>(Lf), as<TF>(linv), as<TF>(work),
                                         grad ? as<TF>(kinvb) : nullptr, n, npad, as<double>(logdet), info_dev,
                                         single_level_max, pl);
-      bool inv_done = (done & 1) != 0;
+      bool inv_done = (done & 1) != 0, xt_ready = false;
       if constexpr (sizeof(TF) == 4) {
         if (!inv_done && pl != nullptr && trtri_bf16_applies(npad, fit_outer_panel(npad))) {
-          launch_trtri_bf16(s, as<float>(linv), planes, npad, fit_outer_panel(npad));
+          launch_trtri_bf16(s, as<float>(linv), planes, npad, fit_outer_panel(npad), grad);
           inv_done = true;
+          xt_ready = true;
         }
       }
       if (!inv_done) launch_trtri<TF>(s, as<TF>(Lf), as<TF>(linv), as<TF>(work), npad, fit_outer_panel(npad));
@@ -619,7 +620,7 @@ struct EngineT : Engine {
       if (grad)
         launch_gradient<TF>(s, as<TF>(linv), as<TF>(alpha_f), as<double>(xs64), as<double>(xnorm64), n, npad, d, dp,
                             n_ls, ls_dev(), kp, as<TF>(kinvb), (done & 2) != 0, as<double>(gpart),
-                            as<double>(scal) + 8);
+                            as<double>(scal) + 8, xt_ready ? &planes : nullptr);
       launch_pack_linv<TF, TP>(s, as<TF>(linv), n, npad, as<TP>(linv_p));
       launch_convert_vec<TF, TP>(s, as<TF>(alpha_f), as<TP>(alpha), npad);
       small_tile_rows = 8;

@@ -1949,7 +1949,8 @@ void launch_trtri(hipStream_t st, const T* L, T* linv, T* work, int64_t npad, in
 //   Linv[B,A] = -X[B,B] (WT[A,B])^T         (X[B,B][i][k] = 0 for k > i                         -> k < 128 (ti + 1))
 // the second product writes the float result into linv and its pieces into X and -- transposed -- into XT, which
 // is what the next level reads.  The diagonal blocks of L^-1 (float, from the step kernels) enter X / XT first.
-void launch_trtri_bf16(hipStream_t st, float* linv, const FitPlanes& pl, int64_t npad, int64_t first_level) {
+void launch_trtri_bf16(hipStream_t st, float* linv, const FitPlanes& pl, int64_t npad, int64_t first_level,
+                       bool keep_xt) {
   const Bf16Planes L{pl.L, pl.stride, pl.nkb}, X{pl.X, pl.stride, pl.nkb}, XT{pl.XT, pl.stride, pl.nkb},
       WT{pl.WT, pl.stride, pl.nkb}, none{nullptr, 0, 0};
   {
@@ -1980,7 +1981,10 @@ void launch_trtri_bf16(hipStream_t st, float* linv, const FitPlanes& pl, int64_t
     b.nbatch = nb; b.batch_shift = 2 * s;
     b.out = X; b.o_row0 = s; b.o_col0 = 0;
     b.out_t = XT; b.ot_row0 = 0; b.ot_col0 = s;
-    if (2 * s >= npad) b.out = b.out_t = none;  // last level: nobody reads the planes afterwards
+    if (2 * s >= npad) {  // last level: nobody reads X afterwards; XT only feeds K^-1 = XT XT^T (gradient)
+      b.out = none;
+      if (!keep_xt) b.out_t = none;
+    }
     launch_gemm_bf16(st, b);
   }
 }
@@ -2263,9 +2267,26 @@ __global__ __launch_bounds__(256) void grad_final_kernel(const double* __restric
 template <typename T>
 void launch_gradient(hipStream_t st, const T* linv, const T* alpha, const double* xs, const double* xnorm,
                      int64_t n, int64_t npad, int d, int dp, int n_ls, const double* ls,
-                     const KernParams& kp, T* kinv, bool kinv_ready, double* partial, double* grad_out) {
+                     const KernParams& kp, T* kinv, bool kinv_ready, double* partial, double* grad_out,
+                     const FitPlanes* xt_planes) {
   (void)d;
-  if (!kinv_ready) {
+  if (!kinv_ready && sizeof(T) == 4 && xt_planes != nullptr && xt_planes->XT != nullptr) {
+    // float fit whose inverse was built on the bf16 matrix cores: the planes of L^-T are resident, and
+    // Kinv = L^-T (L^-T)^T is a product of k-contiguous rows of them (lower tiles, k >= 128 ti)
+    if constexpr (sizeof(T) == 4) {
+      GemmBf16Desc g{};
+      g.A = g.B = Bf16Planes{xt_planes->XT, xt_planes->stride, xt_planes->nkb};
+      g.C = reinterpret_cast<float*>(kinv);
+      g.ldc = npad;
+      g.m = g.n = g.k = (int)npad;
+      g.alpha = 1.0f;
+      g.beta = 0;
+      g.lower_only = 1;
+      g.kmode = 2;
+      g.nbatch = 1;
+      launch_gemm_bf16(st, g);
+    }
+  } else if (!kinv_ready) {
     // Kinv = Linv^T Linv, lower tiles:  opA(i,k) = Linv[k][i],  opB(k,j) = Linv[k][j],  k >= 64 ti
     GemmDesc g{};
     g.A = linv; g.sai = 1; g.sak = npad;
@@ -2283,8 +2304,8 @@ void launch_gradient(hipStream_t st, const T* linv, const T* alpha, const double
   hipLaunchKernelGGL((grad_final_kernel<T>), dim3(1), dim3(256), 0, st, partial, nblk, n_ls, alpha, n,
                      grad_out);
 }
-template void launch_gradient<float>(hipStream_t, const float*, const float*, const double*, const double*, int64_t, int64_t, int, int, int, const double*, const KernParams&, float*, bool, double*, double*);
-template void launch_gradient<double>(hipStream_t, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int, int, const double*, const KernParams&, double*, bool, double*, double*);
+template void launch_gradient<float>(hipStream_t, const float*, const float*, const double*, const double*, int64_t, int64_t, int, int, int, const double*, const KernParams&, float*, bool, double*, double*, const FitPlanes*);
+template void launch_gradient<double>(hipStream_t, const double*, const double*, const double*, const double*, int64_t, int64_t, int, int, int, const double*, const KernParams&, double*, bool, double*, double*, const FitPlanes*);
 
 // =============================================================================================
 // fused fit for N <= 128: ONE launch, one workgroup, everything in LDS

@@ -107,7 +107,8 @@ template <typename T>
 int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t n, int64_t npad,
                  double* diag64, int* info, int64_t single_level_max /* < 0: default */, const FitPlanes* planes);
 // the level-doubling inverse on the bf16 matrix cores (after a launch_potrf with the same planes)
-void launch_trtri_bf16(hipStream_t st, float* linv, const FitPlanes& planes, int64_t npad, int64_t first_level);
+void launch_trtri_bf16(hipStream_t st, float* linv, const FitPlanes& planes, int64_t npad, int64_t first_level,
+                       bool keep_xt /* also emit the planes of L^-T at the last level (K^-1 for the gradient) */);
 bool trtri_bf16_applies(int64_t npad, int64_t first_level);
 // L^-1 by level-doubling from level first_level (64 or the factorisation's outer panel width): needs the
 // inverses of the first_level-wide diagonal blocks already in linv; work = npad x npad scratch
@@ -137,7 +138,8 @@ void launch_solve_alpha(hipStream_t st, const T* linv, const double* y64, int64_
 template <typename T>
 void launch_gradient(hipStream_t st, const T* linv, const T* alpha, const double* xs, const double* xnorm,
                      int64_t n, int64_t npad, int d, int dp, int n_ls, const double* ls,
-                     const KernParams& kp, T* kinv, bool kinv_ready, double* partial, double* grad_out);
+                     const KernParams& kp, T* kinv, bool kinv_ready, double* partial, double* grad_out,
+                     const FitPlanes* xt_planes = nullptr /* float: planes of L^-T left by launch_trtri_bf16(keep_xt) */);
 constexpr int kGradMaxLs = 64;
 // fused single-launch fit for N <= 128 (one workgroup, matrices in LDS): everything launch_scale_x<double>
 // .. launch_pack_linv / launch_convert_vec produce, in one kernel (definition + field docs: fit.hip)

@@ -629,14 +629,19 @@ def test_float_fit_on_the_bf16_matrix_cores_agrees_with_the_f32_path():
     for flag in (1, 0):
         eng = HipGPEngine("float32")
         eng._check(eng._lib.gpso_set_option(eng._h, L.OPT_FIT_BF16_SYRK, flag))
-        f, _ = _fit(eng, X, y, th, grad=False)
-        res[flag] = (f, eng.get_matrix(L.MAT_LINV), eng.get_vector(L.VEC_ALPHA), eng.get_matrix(L.MAT_CHOL))
+        f, g = _fit(eng, X, y, th, grad=True)  # (with the gradient: K^-1 = L^-T L^-1 is a split product as well)
+        res[flag] = (f, eng.get_matrix(L.MAT_LINV), eng.get_vector(L.VEC_ALPHA), eng.get_matrix(L.MAT_CHOL),
+                     g, eng.get_matrix(L.MAT_KINV))
+    _, g_ref = gpr.nlml_and_grad(th, X, y)
     for flag in (1, 0):  # each path against the oracle, float tolerances
-        f, linv, alpha, chol = res[flag]
+        f, linv, alpha, chol, g, kinv = res[flag]
         assert abs(f - post.nlml) <= 2e-5 * abs(post.nlml), flag
+        assert np.max(np.abs(g - g_ref) / np.maximum(1.0, np.abs(g_ref))) < 2e-2, flag
         assert np.max(np.abs(chol - post.L)) <= 2e-4 * np.max(np.abs(post.L)), flag
         assert np.max(np.abs(alpha - post.alpha)) <= 2e-3 * np.max(np.abs(post.alpha)), flag
     # and against each other: the split products are float-class
     scale = np.max(np.abs(res[0][1]))
     assert np.max(np.abs(res[1][1] - res[0][1])) <= 2e-4 * scale
     assert np.max(np.abs(res[1][3] - res[0][3])) <= 5e-5 * np.max(np.abs(res[0][3]))
+    assert np.max(np.abs(res[1][5] - res[0][5])) <= 2e-4 * np.max(np.abs(res[0][5]))
+    assert np.max(np.abs(res[1][4] - res[0][4]) / np.maximum(1.0, np.abs(res[0][4]))) < 2e-2
