@@ -366,22 +366,34 @@ __device__ __forceinline__ void chol64_lds(double* Ls, double* Xs, T* __restrict
       // and finished columns are broadcast with v_readlane (uniform lane index): the 16-pivot chain
       // of a panel runs without a single LDS round trip, without branches and without selects;
       // the column updates are independent work that fills the latency of that chain.
-      double li[kPB];
+      double li[kPB], m[kPB];
 #pragma unroll
       for (int k = 0; k < kPB; ++k) li[k] = Ls[lane * kDS + c0 + k];
-#pragma unroll
-      for (int jj = 0; jj < kPB; ++jj) {
-        // right-looking: column jj is final here.  On the pivot chain: readlane -> rsqrt -> scale ->
-        // update of column jj+1 (multiplier by v_readlane).  Off the chain: the finished column goes
-        // straight to its final place in LDS and the multipliers of the later columns come back as
-        // wave-uniform LDS reads (one instruction per multiplier instead of two v_readlane).
+      double lprev = 0.0;
+      // right-looking: column jj is final at step jj.  On the pivot chain: readlane -> rsqrt -> scale ->
+      // update of column jj+1 (multiplier by v_readlane).  Off the chain: the finished column goes
+      // straight to its final place in LDS and the multipliers of the columns from jj+3 on come back as
+      // wave-uniform LDS reads (one instruction per multiplier instead of two v_readlane) -- but a
+      // write -> read round trip through LDS is ~150 clocks and the wave issues in order, so those
+      // reads are consumed ONE STEP LATER (software pipeline: step jj applies column jj-1 to the
+      // columns >= jj+2), and column jj+2, which the next step's chain needs, takes its multiplier by
+      // v_readlane as well.  Every entry still receives its column updates in the order 0, 1, 2, ...:
+      // same bits as the plain loop.
+      static_for<0, kPB>([&](auto jj_) {
+        constexpr int jj = decltype(jj_)::value;
         const double rinv = rsqrt_newton<NEWTON>(readlane_f64(li[jj], c0 + jj));
         const double l = li[jj] * rinv;
         Ls[lane * kDS + c0 + jj] = l;
-        if (jj + 1 < kPB) li[jj + 1] = fma(-l, readlane_f64(l, c0 + jj + 1), li[jj + 1]);
+        if constexpr (jj + 1 < kPB) li[jj + 1] = fma(-l, readlane_f64(l, c0 + jj + 1), li[jj + 1]);
+        if constexpr (jj >= 1) {
 #pragma unroll
-        for (int kk = jj + 2; kk < kPB; ++kk) li[kk] = fma(-l, Ls[(c0 + kk) * kDS + c0 + jj], li[kk]);
-      }
+          for (int kk = jj + 2; kk < kPB; ++kk) li[kk] = fma(-lprev, m[kk], li[kk]);
+        }
+        if constexpr (jj + 2 < kPB) li[jj + 2] = fma(-l, readlane_f64(l, c0 + jj + 2), li[jj + 2]);
+#pragma unroll
+        for (int kk = jj + 3; kk < kPB; ++kk) m[kk] = Ls[(c0 + kk) * kDS + c0 + jj];
+        lprev = l;
+      });
     } else if (wave == 1 && c0 > 0) {
       for (int cb = 0; cb < kPB; cb += 4) diag_inv16(Ls, Xs, c0 - kPB, cb, lane);
     } else if (wave == 2 && c0 > 0) {

@@ -2,7 +2,9 @@
 # (run on the GPU box: bash tools/collect_profiles_r02g.sh [TAG]).  Outputs under gpurun_out/TAG; the files to
 # keep are copied into profiles/ by hand (see profiles/README.md).
 TAG=${1:-r02g}
+PART=${2:-all}   # a = bench lines + kernel stats + PMC, b = fit timelines, loop bench, micro tools, fuzz
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+if [ $PART != b ]; then
 python3 $R/bench.py > $O/bench_c3.json 2> $O/bench_c3.err
 for w in c2 c4 c5 c3f64; do python3 $R/bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2>/dev/null; done
 python3 $R/bench.py --math native --no-cpu-baseline > $O/bench_c3_native.json 2>/dev/null
@@ -15,6 +17,8 @@ rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYC
 for pat in "leaf_tiles_bf16_kernel<3" leaf_tiles_v2 potrf_step gram_kernel; do echo "## $pat (largest-grid dispatches only)"; for p in pmc1 pmc2 pmc3; do python3 $R/tools/pmc_summary.py $O/$p "$pat"; done; done > $O/pmc_summary.txt 2>&1
 rm -rf $O/prof $O/pmc1 $O/pmc2 $O/pmc3
 echo "bench profile done"
+fi
+if [ $PART = a ]; then exit 0; fi
 for cfg in "2048 12 c3" "8192 20 c4" "16384 40 c5"; do
   set -- $cfg
   bash $R/tools/collect_fit_timeline.sh $TAG/fit_$3_posterior $1 $2 > /dev/null 2>&1
