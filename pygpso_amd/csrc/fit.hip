@@ -354,46 +354,73 @@ __device__ __forceinline__ void diag_inv16(const double* Ls, double* Xs, int b0,
 // the pivot chain); the last diagonal block is left to trinv64_lds.
 // Wave 2 stores the 16 finished columns of panel p-1 to Lout (global) at the same time; the last 16
 // columns are left to the caller.
-template <int NEWTON, typename T>
+// F32CHAIN (float fits of the general path): the panel lives in float registers, the pivot's 1/sqrt is
+// one v_rsq_f32 (1 ulp, no Newton step) and the multipliers come back from a float copy of the finished
+// columns (Fs[jj][row], 4 KB borrowed from the inverse's scratch, free until trinv64_lds).  The factor
+// is stored as float anyway and every trailing update of a float fit already rounds the block to
+// float; what changes is the rounding of the <= 63 updates inside the block (float instead of double).
+__device__ __forceinline__ float readlane_t(float x, int src_lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src_lane));
+}
+__device__ __forceinline__ double readlane_t(double x, int src_lane) { return readlane_f64(x, src_lane); }
+template <int NEWTON>
+__device__ __forceinline__ float rsqrt_t(float x) { return __builtin_amdgcn_rsqf(x); }
+template <int NEWTON>
+__device__ __forceinline__ double rsqrt_t(double x) { return rsqrt_newton<NEWTON>(x); }
+
+
+
+// One wave, panel columns c0 .. c0+15 of the 64x64 block in Ls; lane = row, the 16 panel entries of the
+// row in registers (type F): the 16-pivot chain of a panel runs without branches and without selects.
+// Right-looking: column jj is final at step jj.  On the pivot chain: readlane -> rsqrt -> scale ->
+// update of column jj+1 (multiplier by v_readlane).  Off the chain: the finished column goes straight
+// to its final place in LDS and the multipliers of the columns from jj+3 on come back as wave-uniform
+// LDS reads (one instruction per multiplier instead of two v_readlane) -- but a write -> read round
+// trip through LDS is ~150 clocks and the wave issues in order, so those reads are consumed ONE STEP
+// LATER (software pipeline: step jj applies column jj-1 to the columns >= jj+2), and column jj+2,
+// which the next step's chain needs, takes its multiplier by v_readlane as well.  Every entry still
+// receives its column updates in the order 0, 1, 2, ...: same bits as the plain loop.
+// (Measured and not kept, tools/micro/diag_phases: the chain freed of v_readlane by repeating the
+// operations of lanes jj+1 / jj+2 on wave-uniform copies fetched a step ahead, with and without the
+// delayed updates pinned under the rsqrt, LDS multipliers two steps late: 2850 - 2990 clocks per float
+// panel against 2730 for this loop -- ~180 clocks per pivot whatever sits on the dependent chain.)
+template <typename F, int NEWTON>
+__device__ __forceinline__ void chol_panel16(double* Ls, float* Fs, int c0, int lane) {
+  constexpr bool kF32 = sizeof(F) == 4;
+  F li[kPB], m[kPB], lprev = 0;
+#pragma unroll
+  for (int k = 0; k < kPB; ++k) li[k] = (F)Ls[lane * kDS + c0 + k];
+  static_for<0, kPB>([&](auto jj_) {
+    constexpr int jj = decltype(jj_)::value;
+    const F rinv = rsqrt_t<NEWTON>(readlane_t(li[jj], c0 + jj));
+    const F l = li[jj] * rinv;
+    Ls[lane * kDS + c0 + jj] = (double)l;
+    if constexpr (kF32) Fs[jj * kFitBlock + lane] = l;
+    if constexpr (jj + 1 < kPB) li[jj + 1] = fma_t(-l, readlane_t(l, c0 + jj + 1), li[jj + 1]);
+    if constexpr (jj >= 1) {
+#pragma unroll
+      for (int kk = jj + 2; kk < kPB; ++kk) li[kk] = fma_t(-lprev, m[kk], li[kk]);
+    }
+    if constexpr (jj + 2 < kPB) li[jj + 2] = fma_t(-l, readlane_t(l, c0 + jj + 2), li[jj + 2]);
+#pragma unroll
+    for (int kk = jj + 3; kk < kPB; ++kk) {
+      if constexpr (kF32) m[kk] = Fs[jj * kFitBlock + c0 + kk];
+      else m[kk] = (F)Ls[(c0 + kk) * kDS + c0 + jj];
+    }
+    lprev = l;
+  });
+}
+
+template <int NEWTON, typename T, bool F32CHAIN = false>
 __device__ __forceinline__ void chol64_lds(double* Ls, double* Xs, T* __restrict__ Lout, int64_t ld,
-                                           int64_t k0, int64_t n, int* info) {
+                                           int64_t k0, int64_t n, int* info, float* Fs = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int c0 = 0; c0 < kFitBlock; c0 += kPB) {
     GPSO_STAMP(2 * (c0 / kPB));
     if (wave == 0) {
-      // panel columns c0 .. c0+15; lane = row.  The 16 panel entries of the row live in registers
-      // and finished columns are broadcast with v_readlane (uniform lane index): the 16-pivot chain
-      // of a panel runs without a single LDS round trip, without branches and without selects;
-      // the column updates are independent work that fills the latency of that chain.
-      double li[kPB], m[kPB];
-#pragma unroll
-      for (int k = 0; k < kPB; ++k) li[k] = Ls[lane * kDS + c0 + k];
-      double lprev = 0.0;
-      // right-looking: column jj is final at step jj.  On the pivot chain: readlane -> rsqrt -> scale ->
-      // update of column jj+1 (multiplier by v_readlane).  Off the chain: the finished column goes
-      // straight to its final place in LDS and the multipliers of the columns from jj+3 on come back as
-      // wave-uniform LDS reads (one instruction per multiplier instead of two v_readlane) -- but a
-      // write -> read round trip through LDS is ~150 clocks and the wave issues in order, so those
-      // reads are consumed ONE STEP LATER (software pipeline: step jj applies column jj-1 to the
-      // columns >= jj+2), and column jj+2, which the next step's chain needs, takes its multiplier by
-      // v_readlane as well.  Every entry still receives its column updates in the order 0, 1, 2, ...:
-      // same bits as the plain loop.
-      static_for<0, kPB>([&](auto jj_) {
-        constexpr int jj = decltype(jj_)::value;
-        const double rinv = rsqrt_newton<NEWTON>(readlane_f64(li[jj], c0 + jj));
-        const double l = li[jj] * rinv;
-        Ls[lane * kDS + c0 + jj] = l;
-        if constexpr (jj + 1 < kPB) li[jj + 1] = fma(-l, readlane_f64(l, c0 + jj + 1), li[jj + 1]);
-        if constexpr (jj >= 1) {
-#pragma unroll
-          for (int kk = jj + 2; kk < kPB; ++kk) li[kk] = fma(-lprev, m[kk], li[kk]);
-        }
-        if constexpr (jj + 2 < kPB) li[jj + 2] = fma(-l, readlane_f64(l, c0 + jj + 2), li[jj + 2]);
-#pragma unroll
-        for (int kk = jj + 3; kk < kPB; ++kk) m[kk] = Ls[(c0 + kk) * kDS + c0 + jj];
-        lprev = l;
-      });
+      if constexpr (F32CHAIN) chol_panel16<float, NEWTON>(Ls, Fs, c0, lane);
+      else chol_panel16<double, NEWTON>(Ls, nullptr, c0, lane);
     } else if (wave == 1 && c0 > 0) {
       for (int cb = 0; cb < kPB; cb += 4) diag_inv16(Ls, Xs, c0 - kPB, cb, lane);
     } else if (wave == 2 && c0 > 0) {
@@ -1646,19 +1673,31 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
             fb[t][kk] = *reinterpret_cast<const vec4*>(TA + (16 * stj[t] + (lane & 15)) * kTL + ko);
           }
         }
+      // the (up to) three tiles of a wave accumulate interleaved: three independent MFMA chains of 16
+      // instead of one of 48 (a dependent MFMA waits for the previous one's passes); the last wave's
+      // missing tiles cost nothing (wave-uniform skip of whole k-sweeps)
+      vec4 a3[3] = {vec4{0, 0, 0, 0}, vec4{0, 0, 0, 0}, vec4{0, 0, 0, 0}};
+      if (sti[1] >= 0) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) a3[t] = M::mma(fa[t][kk][e], fb[t][kk][e], a3[t]);
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a3[0] = M::mma(fa[0][kk][e], fb[0][kk][e], a3[0]);
+      }
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
         const int ti = sti[t], tj = stj[t];
         if (ti < 0) break;
-        vec4 a{0, 0, 0, 0};
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) a = M::mma(fa[t][kk][e], fb[t][kk][e], a);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * ti + M::crow(lane, r), col = 16 * tj + (lane & 15);
-          const T upd = akk[t][r] - a[r];
+          const T upd = akk[t][r] - a3[t][r];
           Ls[row * kDS + col] = (col <= row) ? (double)upd : 0.0;
         }
       }
@@ -1673,7 +1712,8 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
     GPSO_STAMP(15);
     // (row_base: global row of this sub-matrix's first row -- pivot indices, padding test and the
     // diagonal go by global row; every tile address above is relative to the sub-matrix)
-    chol64_lds<(sizeof(T) == 4) ? 1 : 2, T>(Ls, Xs, Lf + k0 * ld + k0, ld, row_base + k0, n, info);
+    chol64_lds<(sizeof(T) == 4) ? 1 : 2, T, sizeof(T) == 4>(Ls, Xs, Lf + k0 * ld + k0, ld, row_base + k0, n, info,
+                                                          reinterpret_cast<float*>(Ts));
     // the unrounded diagonal: its logarithms are summed by nlml_kernel, off this chain
     if (tid < kFitBlock) diag64[row_base + k0 + tid] = Ls[tid * kDS + tid];
     GPSO_STAMP(7);
