@@ -411,6 +411,57 @@ __device__ __forceinline__ void chol_panel16(double* Ls, float* Fs, int c0, int 
   });
 }
 
+// The float panel again, with the instruction count cut (tools/micro/lat_probe: a wave alone on its SIMD
+// issues one instruction per ~5.6 ticks whatever its kind, so the ~28 instructions per pivot ARE the
+// 170 ticks per pivot): the delayed updates run two columns per v_pk_fma_f32 on multipliers read as
+// pairs, and ONE s_waitcnt covers the reads of a step (placed before the step's own LDS stores, so it
+// only waits for loads that have had the whole chain part of the step to arrive).  Same operations on
+// the same operands in the same order as chol_panel16<float>: same bits.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void chol_panel16_f32(double* Ls, float* Fs, int c0, int lane) {
+  f32x2 lp[kPB / 2], m2[2][kPB / 2];
+#pragma unroll
+  for (int k = 0; k < kPB / 2; ++k) {
+    lp[k].x = (float)Ls[lane * kDS + c0 + 2 * k];
+    lp[k].y = (float)Ls[lane * kDS + c0 + 2 * k + 1];
+  }
+  float lprev = 0.0f;
+  static_for<0, kPB>([&](auto jj_) {
+    constexpr int jj = decltype(jj_)::value;
+    constexpr int b = jj & 1;  // m2[b]: filled with column jj's multipliers here, consumed by step jj+1
+    const float cur = (jj & 1) ? lp[jj >> 1].y : lp[jj >> 1].x;
+    const float l = cur * __builtin_amdgcn_rsqf(readlane_t(cur, c0 + jj));
+    Fs[jj * kFitBlock + lane] = l;
+    Ls[lane * kDS + c0 + jj] = (double)l;
+    // multiplier pairs of column jj for the columns >= jj+3 (the first pair may start one column early),
+    // issued lowest pair first: the delayed update of the NEXT step uses the last one first, so that one
+    // counted s_waitcnt covers them all
+#pragma unroll
+    for (int P = (jj + 3) >> 1; P < kPB / 2; ++P)
+      m2[b][P] = *reinterpret_cast<const f32x2*>(Fs + jj * kFitBlock + c0 + 2 * P);
+    if constexpr (jj + 1 < kPB) {
+      const float mu = readlane_t(l, c0 + jj + 1);
+      if constexpr ((jj + 1) & 1) lp[(jj + 1) >> 1].y = fmaf(-l, mu, lp[(jj + 1) >> 1].y);
+      else lp[(jj + 1) >> 1].x = fmaf(-l, mu, lp[(jj + 1) >> 1].x);
+    }
+    if constexpr (jj >= 1 && jj + 2 < kPB) {
+      constexpr int k0 = jj + 2;  // first column of the delayed update (column jj-1 applied)
+      const f32x2 nl = {-lprev, -lprev};
+      static_for<0, kPB / 2 - ((k0 + 1) >> 1)>([&](auto q_) {
+        constexpr int P = kPB / 2 - 1 - decltype(q_)::value;
+        lp[P] = __builtin_elementwise_fma(nl, m2[b ^ 1][P], lp[P]);
+      });
+      if constexpr (k0 & 1) lp[k0 >> 1].y = fmaf(-lprev, m2[b ^ 1][k0 >> 1].y, lp[k0 >> 1].y);
+    }
+    if constexpr (jj + 2 < kPB) {
+      const float mu2 = readlane_t(l, c0 + jj + 2);
+      if constexpr ((jj + 2) & 1) lp[(jj + 2) >> 1].y = fmaf(-l, mu2, lp[(jj + 2) >> 1].y);
+      else lp[(jj + 2) >> 1].x = fmaf(-l, mu2, lp[(jj + 2) >> 1].x);
+    }
+    lprev = l;
+  });
+}
+
 template <int NEWTON, typename T, bool F32CHAIN = false>
 __device__ __forceinline__ void chol64_lds(double* Ls, double* Xs, T* __restrict__ Lout, int64_t ld,
                                            int64_t k0, int64_t n, int* info, float* Fs = nullptr) {
@@ -419,7 +470,7 @@ __device__ __forceinline__ void chol64_lds(double* Ls, double* Xs, T* __restrict
   for (int c0 = 0; c0 < kFitBlock; c0 += kPB) {
     GPSO_STAMP(2 * (c0 / kPB));
     if (wave == 0) {
-      if constexpr (F32CHAIN) chol_panel16<float, NEWTON>(Ls, Fs, c0, lane);
+      if constexpr (F32CHAIN) chol_panel16_f32(Ls, Fs, c0, lane);
       else chol_panel16<double, NEWTON>(Ls, nullptr, c0, lane);
     } else if (wave == 1 && c0 > 0) {
       for (int cb = 0; cb < kPB; cb += 4) diag_inv16(Ls, Xs, c0 - kPB, cb, lane);
