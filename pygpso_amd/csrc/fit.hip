@@ -371,107 +371,79 @@ __device__ __forceinline__ double rsqrt_t(double x) { return rsqrt_newton<NEWTON
 
 
 // One wave, panel columns c0 .. c0+15 of the 64x64 block in Ls; lane = row, the 16 panel entries of the
-// row in registers (type F): the 16-pivot chain of a panel runs without branches and without selects.
-// Right-looking: column jj is final at step jj.  On the pivot chain: readlane -> rsqrt -> scale ->
-// update of column jj+1 (multiplier by v_readlane).  Off the chain: the finished column goes straight
-// to its final place in LDS and the multipliers of the columns from jj+3 on come back as wave-uniform
-// LDS reads (one instruction per multiplier instead of two v_readlane) -- but a write -> read round
-// trip through LDS is ~150 clocks and the wave issues in order, so those reads are consumed ONE STEP
-// LATER (software pipeline: step jj applies column jj-1 to the columns >= jj+2), and column jj+2,
-// which the next step's chain needs, takes its multiplier by v_readlane as well.  Every entry still
-// receives its column updates in the order 0, 1, 2, ...: same bits as the plain loop.
+// row in registers (type F, as pairs): the 16-pivot chain of a panel runs without branches and without
+// selects.  Right-looking: column jj is final at step jj.  On the pivot chain: readlane -> rsqrt -> scale
+// -> update of column jj+1 (multiplier by v_readlane).  Off the chain: the finished column goes to its
+// final place in Ls and to a column-major copy Cs[jj][row] (type F, 4 / 8 KB borrowed from the inverse's
+// scratch, free until trinv64_lds), from which the multipliers of the columns from jj+3 on come back as
+// wave-uniform reads, two per instruction.  What shapes the loop (tools/micro/lat_probe.hip): a wave
+// alone on its SIMD issues one instruction per ~5.6 clocks WHATEVER its kind (s_waitcnt included), and
+// an LDS write -> read round trip is ~70 clocks.  So
+//  * the reads of column jj are issued right behind its store and consumed ONE STEP LATER (software
+//    pipeline: step jj applies column jj-1 to the columns >= jj+2; column jj+2, which the next step's
+//    chain needs, takes its multiplier by v_readlane as well), into double-buffered registers;
+//  * the delayed update walks the pairs from the last one issued down, so one counted s_waitcnt covers
+//    all of them;
+//  * float panels update two columns per v_pk_fma_f32.
+// Every entry receives its column updates in the order 0, 1, 2, ...: same bits as the plain loop.
 // (Measured and not kept, tools/micro/diag_phases: the chain freed of v_readlane by repeating the
 // operations of lanes jj+1 / jj+2 on wave-uniform copies fetched a step ahead, with and without the
-// delayed updates pinned under the rsqrt, LDS multipliers two steps late: 2850 - 2990 clocks per float
-// panel against 2730 for this loop -- ~180 clocks per pivot whatever sits on the dependent chain.)
+// delayed updates pinned under the rsqrt, LDS multipliers two steps late: no faster.)
 template <typename F, int NEWTON>
-__device__ __forceinline__ void chol_panel16(double* Ls, float* Fs, int c0, int lane) {
-  constexpr bool kF32 = sizeof(F) == 4;
-  F li[kPB], m[kPB], lprev = 0;
-#pragma unroll
-  for (int k = 0; k < kPB; ++k) li[k] = (F)Ls[lane * kDS + c0 + k];
-  static_for<0, kPB>([&](auto jj_) {
-    constexpr int jj = decltype(jj_)::value;
-    const F rinv = rsqrt_t<NEWTON>(readlane_t(li[jj], c0 + jj));
-    const F l = li[jj] * rinv;
-    Ls[lane * kDS + c0 + jj] = (double)l;
-    if constexpr (kF32) Fs[jj * kFitBlock + lane] = l;
-    if constexpr (jj + 1 < kPB) li[jj + 1] = fma_t(-l, readlane_t(l, c0 + jj + 1), li[jj + 1]);
-    if constexpr (jj >= 1) {
-#pragma unroll
-      for (int kk = jj + 2; kk < kPB; ++kk) li[kk] = fma_t(-lprev, m[kk], li[kk]);
-    }
-    if constexpr (jj + 2 < kPB) li[jj + 2] = fma_t(-l, readlane_t(l, c0 + jj + 2), li[jj + 2]);
-#pragma unroll
-    for (int kk = jj + 3; kk < kPB; ++kk) {
-      if constexpr (kF32) m[kk] = Fs[jj * kFitBlock + c0 + kk];
-      else m[kk] = (F)Ls[(c0 + kk) * kDS + c0 + jj];
-    }
-    lprev = l;
-  });
-}
-
-// The float panel again, with the instruction count cut (tools/micro/lat_probe: a wave alone on its SIMD
-// issues one instruction per ~5.6 ticks whatever its kind, so the ~28 instructions per pivot ARE the
-// 170 ticks per pivot): the delayed updates run two columns per v_pk_fma_f32 on multipliers read as
-// pairs, and ONE s_waitcnt covers the reads of a step (placed before the step's own LDS stores, so it
-// only waits for loads that have had the whole chain part of the step to arrive).  Same operations on
-// the same operands in the same order as chol_panel16<float>: same bits.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void chol_panel16_f32(double* Ls, float* Fs, int c0, int lane) {
-  f32x2 lp[kPB / 2], m2[2][kPB / 2];
+__device__ __forceinline__ void chol_panel16(double* Ls, F* Cs, int c0, int lane) {
+  typedef F F2 __attribute__((ext_vector_type(2)));
+  F2 lp[kPB / 2], m2[2][kPB / 2];
 #pragma unroll
   for (int k = 0; k < kPB / 2; ++k) {
-    lp[k].x = (float)Ls[lane * kDS + c0 + 2 * k];
-    lp[k].y = (float)Ls[lane * kDS + c0 + 2 * k + 1];
+    lp[k].x = (F)Ls[lane * kDS + c0 + 2 * k];
+    lp[k].y = (F)Ls[lane * kDS + c0 + 2 * k + 1];
   }
-  float lprev = 0.0f;
+  F lprev = 0;
   static_for<0, kPB>([&](auto jj_) {
     constexpr int jj = decltype(jj_)::value;
     constexpr int b = jj & 1;  // m2[b]: filled with column jj's multipliers here, consumed by step jj+1
-    const float cur = (jj & 1) ? lp[jj >> 1].y : lp[jj >> 1].x;
-    const float l = cur * __builtin_amdgcn_rsqf(readlane_t(cur, c0 + jj));
-    Fs[jj * kFitBlock + lane] = l;
+    const F cur = (jj & 1) ? lp[jj >> 1].y : lp[jj >> 1].x;
+    const F l = cur * rsqrt_t<NEWTON>(readlane_t(cur, c0 + jj));
+    Cs[jj * kFitBlock + lane] = l;
     Ls[lane * kDS + c0 + jj] = (double)l;
-    // multiplier pairs of column jj for the columns >= jj+3 (the first pair may start one column early),
-    // issued lowest pair first: the delayed update of the NEXT step uses the last one first, so that one
-    // counted s_waitcnt covers them all
+    // multiplier pairs of column jj for the columns >= jj+3 (the first pair may start one column early)
 #pragma unroll
     for (int P = (jj + 3) >> 1; P < kPB / 2; ++P)
-      m2[b][P] = *reinterpret_cast<const f32x2*>(Fs + jj * kFitBlock + c0 + 2 * P);
+      m2[b][P] = *reinterpret_cast<const F2*>(Cs + jj * kFitBlock + c0 + 2 * P);
     if constexpr (jj + 1 < kPB) {
-      const float mu = readlane_t(l, c0 + jj + 1);
-      if constexpr ((jj + 1) & 1) lp[(jj + 1) >> 1].y = fmaf(-l, mu, lp[(jj + 1) >> 1].y);
-      else lp[(jj + 1) >> 1].x = fmaf(-l, mu, lp[(jj + 1) >> 1].x);
+      const F mu = readlane_t(l, c0 + jj + 1);
+      if constexpr ((jj + 1) & 1) lp[(jj + 1) >> 1].y = fma_t(-l, mu, lp[(jj + 1) >> 1].y);
+      else lp[(jj + 1) >> 1].x = fma_t(-l, mu, lp[(jj + 1) >> 1].x);
     }
     if constexpr (jj >= 1 && jj + 2 < kPB) {
       constexpr int k0 = jj + 2;  // first column of the delayed update (column jj-1 applied)
-      const f32x2 nl = {-lprev, -lprev};
+      const F2 nl = {-lprev, -lprev};
       static_for<0, kPB / 2 - ((k0 + 1) >> 1)>([&](auto q_) {
         constexpr int P = kPB / 2 - 1 - decltype(q_)::value;
         lp[P] = __builtin_elementwise_fma(nl, m2[b ^ 1][P], lp[P]);
       });
-      if constexpr (k0 & 1) lp[k0 >> 1].y = fmaf(-lprev, m2[b ^ 1][k0 >> 1].y, lp[k0 >> 1].y);
+      if constexpr (k0 & 1) lp[k0 >> 1].y = fma_t(-lprev, m2[b ^ 1][k0 >> 1].y, lp[k0 >> 1].y);
     }
     if constexpr (jj + 2 < kPB) {
-      const float mu2 = readlane_t(l, c0 + jj + 2);
-      if constexpr ((jj + 2) & 1) lp[(jj + 2) >> 1].y = fmaf(-l, mu2, lp[(jj + 2) >> 1].y);
-      else lp[(jj + 2) >> 1].x = fmaf(-l, mu2, lp[(jj + 2) >> 1].x);
+      const F mu2 = readlane_t(l, c0 + jj + 2);
+      if constexpr ((jj + 2) & 1) lp[(jj + 2) >> 1].y = fma_t(-l, mu2, lp[(jj + 2) >> 1].y);
+      else lp[(jj + 2) >> 1].x = fma_t(-l, mu2, lp[(jj + 2) >> 1].x);
     }
     lprev = l;
   });
 }
 
+// (scratch: 8 KB that nothing else uses until trinv64_lds -- its Ts)
 template <int NEWTON, typename T, bool F32CHAIN = false>
 __device__ __forceinline__ void chol64_lds(double* Ls, double* Xs, T* __restrict__ Lout, int64_t ld,
-                                           int64_t k0, int64_t n, int* info, float* Fs = nullptr) {
+                                           int64_t k0, int64_t n, int* info, double* scratch) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int c0 = 0; c0 < kFitBlock; c0 += kPB) {
     GPSO_STAMP(2 * (c0 / kPB));
     if (wave == 0) {
-      if constexpr (F32CHAIN) chol_panel16_f32(Ls, Fs, c0, lane);
-      else chol_panel16<double, NEWTON>(Ls, nullptr, c0, lane);
+      if constexpr (F32CHAIN) chol_panel16<float, NEWTON>(Ls, reinterpret_cast<float*>(scratch), c0, lane);
+      else chol_panel16<double, NEWTON>(Ls, scratch, c0, lane);
     } else if (wave == 1 && c0 > 0) {
       for (int cb = 0; cb < kPB; cb += 4) diag_inv16(Ls, Xs, c0 - kPB, cb, lane);
     } else if (wave == 2 && c0 > 0) {
@@ -1763,8 +1735,7 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
     GPSO_STAMP(15);
     // (row_base: global row of this sub-matrix's first row -- pivot indices, padding test and the
     // diagonal go by global row; every tile address above is relative to the sub-matrix)
-    chol64_lds<(sizeof(T) == 4) ? 1 : 2, T, sizeof(T) == 4>(Ls, Xs, Lf + k0 * ld + k0, ld, row_base + k0, n, info,
-                                                          reinterpret_cast<float*>(Ts));
+    chol64_lds<(sizeof(T) == 4) ? 1 : 2, T, sizeof(T) == 4>(Ls, Xs, Lf + k0 * ld + k0, ld, row_base + k0, n, info, Ts);
     // the unrounded diagonal: its logarithms are summed by nlml_kernel, off this chain
     if (tid < kFitBlock) diag64[row_base + k0 + tid] = Ls[tid * kDS + tid];
     GPSO_STAMP(7);
@@ -2563,7 +2534,7 @@ __global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs g) {
   __syncthreads();
   // ---- 2. K00 = L00 L00^T, X00 = L00^-1 (B)
   GPSO_SSTAMP(2);
-  chol64_lds<2, T>(A, B, Lf, ld, 0, n, info);
+  chol64_lds<2, T>(A, B, Lf, ld, 0, n, info, Ts);
   if (tid < kFitBlock) dg[tid] = A[tid * kDS + tid];
   GPSO_SSTAMP(3);
   trinv64_lds<true, T>(A, B, Ts, Lf, ld);
@@ -2595,7 +2566,7 @@ __global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs g) {
     __syncthreads();
     // ---- 5. S = L11 L11^T, X11 = L11^-1 (A)
     GPSO_SSTAMP(5);
-    chol64_lds<2, T>(D4, A, Lf + 64 * ld + 64, ld, 64, n, info);
+    chol64_lds<2, T>(D4, A, Lf + 64 * ld + 64, ld, 64, n, info, Ts);
     if (tid < kFitBlock) dg[64 + tid] = D4[tid * kDS + tid];
     GPSO_SSTAMP(6);
     trinv64_lds<true, T>(D4, A, Ts, Lf + 64 * ld + 64, ld);
