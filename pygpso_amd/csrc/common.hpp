@@ -104,6 +104,14 @@ __device__ __forceinline__ float kern_from_scaled(float u, float variance) {
   if (KERNEL == 1) return (variance * (1.0f + t)) * e;
   return variance * e;
 }
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, I1)
+template <int I, int I1, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < I1) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, I1>(f);
+  }
+}
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return fmaf(a, b, c); }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return fma(a, b, c); }
 

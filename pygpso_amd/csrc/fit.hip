@@ -252,14 +252,6 @@ __device__ __forceinline__ double row_bcast_f64(double x) {
   return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + N, 0xf, 0xf, false);
 }
 
-// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, I1)
-template <int I, int I1, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < I1) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, I1>(f);
-  }
-}
 
 __device__ __forceinline__ double readlane_f64(double x, int src_lane /* wave-uniform */) {
   const long long b = __builtin_bit_cast(long long, x);

@@ -71,6 +71,19 @@ __device__ __forceinline__ void glds16(const void* gsrc_lane, void* lds_wave_bas
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// the same with the instruction's immediate offset (added to the global AND the LDS address)
+template <int OFF>
+__device__ __forceinline__ void glds16_off(const void* gsrc_lane, void* lds_wave_base) {
+  static_assert(OFF >= -4096 && OFF < 4096, "13-bit signed immediate");
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, OFF, 0);
+}
+template <int OFF>
+__device__ __forceinline__ void glds4_off(const void* gsrc_lane, void* lds_wave_base) {
+  static_assert(OFF >= -4096 && OFF < 4096, "13-bit signed immediate");
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 4, OFF, 0);
+}
 __device__ __forceinline__ void glds4(const void* gsrc_lane, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
@@ -540,34 +553,74 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   const int npad32 = npad16 / 2;
   const int q_diag0 = bi * (RT / 2), q_end = q_diag0 + RT / 2;
 
-  // the L^-1 pieces of a k-step: two buffers (step q + 1 lands while step q is applied)
-  auto issue_panel = [&](int q, int buf) {
-    for (int f = wave; f < NS * RT; f += NW) {
-      const int sp = f / RT, rt = f % RT;
-      glds16(linv_b + (((size_t)sp * npad16 + (bi * RT + rt)) * npad32 + q) * 64 + lane,
-             panel + ((buf * NS + sp) * RT + rt) * 64);
-    }
+  // ---- LDS-DMA duties: ONE LDS window (one M0 value) per wave between two workgroup barriers ----------------
+  // Measured (tools/fuzz_gpu.py FUZZ_REPEAT_CASE, profiles/r02h_dma_m0_hazard.txt): a global_load_lds whose M0 is
+  // rewritten for the next DMA shortly after it issued can land at the NEW address when the wave already has
+  // several DMAs queued -- 25 of 300 runs of a D = 3 posterior returned a wrong mean (the last L^-1 fragment of
+  // wave 6 landed on the alpha block whose DMA followed ~100 clocks later); with ~200 clocks of s_nop between
+  // them 0 of 300.  Distances are not a contract, so the kernel does not rely on them: every DMA a wave issues
+  // in an interval goes to ONE window addressed as M0 + the instruction's immediate offset (13 bits, signed,
+  // applied to the global and the LDS address alike -- the global base is pre-biased by the same amount), and M0
+  // is written again only after the barrier that ends the interval, behind the wave's own s_waitcnt vmcnt(0).
+  //   waves 0 .. NS*RT/8 - 1: eight consecutive 1 KB fragments of the L^-1 pieces (fragment f = piece f / RT, row
+  //                           tile f % RT), window centre at +4 KB;
+  //   wave 6:                 the X fragments of a step, a linear image of 256-byte pieces, window centre at +4 KB;
+  //   wave 7:                 the 32 norms and the 32 alphas of the step (two DMAs, one window).
+  constexpr int NPW = NS * RT / 8;  // 6 (bf16 x6) or 4 (bf16 x3)
+  static_assert(NPW <= NW - 2 && RT == 16, "panel waves and input waves are different waves");
+  const int lane16 = lane * 16, lane4 = lane * 4;
+  const unsigned char* pgb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int sp = wave >> 1, rt = 8 * (wave & 1) + j;  // fragment 8 wave + j
+    pgb[j] = reinterpret_cast<const unsigned char*>(linv_b + ((size_t)sp * npad16 + (bi * RT + rt)) * npad32 * 64) -
+             (j - 4) * 1024;
+  }
+  // (the empty asm keeps a wave-uniform address in scalar registers: left alone, the compiler hoists
+  // base + lane offset out of the loop as per-lane 64-bit pointers and spills them)
+  auto uniform = [](const unsigned char* p) {
+    const unsigned long long g = (unsigned long long)p;
+    unsigned lo = (unsigned)g, hi = (unsigned)(g >> 32);
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return reinterpret_cast<const unsigned char*>(((unsigned long long)hi << 32) | lo);
   };
-  // the inputs of a k-step (X fragments, norms, alpha): a ring of three buffers -- waves 4-7 generate step q + 1
-  // during step q
+  auto issue_panel = [&](int q, int buf) {
+    if (wave >= NPW) return;
+    unsigned char* centre = reinterpret_cast<unsigned char*>(panel) + buf * (NS * RT * 1024) + wave * 8192 + 4096;
+    static_for<0, 8>([&](auto j_) {
+      constexpr int j = decltype(j_)::value;
+      glds16_off<(j - 4) * 1024>(uniform(pgb[j] + (size_t)q * 1024) + lane16, centre);
+    });
+  };
+  // the inputs of a k-step: a ring of three buffers -- waves 4-7 generate step q + 1 during step q.  Piece p of
+  // the X fragments is bytes [256 p, 256 p + 256) of the step's contiguous source block and of the buffer alike
+  // (<= 32 pieces: D <= 48 in float, <= 32 in double -- checked at launch): wave 6, window centre at +4 KB; wave 7 moves the 32 norms
+  // (TG, as 64 dwords; float: lanes 32-63 fetch duplicates into the unused half) and, 64 TG further, the 32 alphas
+  const int xpieces = 2 * dp4 * ((int)sizeof(TG) / 4);
+  const unsigned char* xs_bytes = reinterpret_cast<const unsigned char*>(xs_p);
+  const size_t xstep = (size_t)2 * dp4 * 64 * sizeof(TG);
   auto issue_x = [&](int q) {
     unsigned char* xd = xsl + (q % 3) * xstride;
-    for (int i = wave; i < 2 * dp4; i += NW) {
-      const int h = i / dp4, c = i % dp4;
-      glds_xfrag<TG>(xs_p + ((size_t)(2 * q + h) * dp4 + c) * 64, xd + (h * dp4 + c) * XB, lane);
+    if (wave == NW - 2) {
+      const unsigned char* src = uniform(xs_bytes + (size_t)q * xstep + 4096);
+      static_for<0, 32>([&](auto r_) {
+        constexpr int r = decltype(r_)::value;
+        if (r < xpieces) glds4_off<(r - 16) * 256>(src + lane4, xd + 4096);
+      });
+    } else if (wave == NW - 1) {
+      unsigned char* nd = xd + (size_t)xpieces * 256;
+      const int nlane = (sizeof(TG) == 8) ? lane4 : (lane & 31) * 4;
+      glds4_off<0>(uniform(reinterpret_cast<const unsigned char*>(xnorm + 32 * q)) + nlane, nd);
+      glds4_off<64 * (int)sizeof(TG)>(uniform(reinterpret_cast<const unsigned char*>(alpha + 32 * q) - 64 * sizeof(TG)) + (lane & 31) * 4, nd);
     }
-    // 32 norms (TG) / 32 alphas (float) of the k-step as linear images (float: lanes 32-63 fetch
-    // duplicates into the unused half)
-    if (wave == NW - 1) {
-      if (sizeof(TG) == 8) glds4(reinterpret_cast<const unsigned*>(xnorm + 32 * q) + lane, xd + 2 * dp4 * XB);
-      else glds4(reinterpret_cast<const unsigned*>(xnorm + 32 * q) + (lane & 31), xd + 2 * dp4 * XB);
-    }
-    if (wave == NW - 2) glds4(alpha + 32 * q + (lane & 31), xd + 2 * dp4 * XB + 64 * sizeof(TG));
   };
 
   issue_panel(0, 0);
   issue_x(0);
-  if (1 < q_end) issue_x(1);
+  if (1 < q_end) {
+    if (wave >= NW - 2) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): a second window for the same wave (once per workgroup)
+    issue_x(1);
+  }
   for (int t = 0; t < CT; ++t)
     for (int c = 0; c < dp4; ++c)
       xb[(t * dp4 + c) * 64 + lane] =
@@ -639,6 +692,10 @@ static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const T
   const int nbi = (int)(npad / 256);
   const dim3 grid((unsigned)(mpad / 256), (unsigned)nbi);
   const size_t lds = leaf_bf16_lds_bytes(NS, dp4, (int)sizeof(TG));
+  if (2 * dp4 * (int)(sizeof(TG) / 4) > 32) {  // the X fragments of a k-step are one DMA window of 32 pieces
+    note_launch_error("launch_leaf_tiles_bf16: more than 32 X pieces per k-step");
+    return 1;
+  }
 #define GPSO_L(K)                                                                                   \
   do {                                                                                              \
     const int rc = ensure_dyn_lds((const void*)leaf_tiles_bf16_kernel<NS, TG, K>, (int)lds);        \

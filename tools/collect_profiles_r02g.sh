@@ -1,4 +1,5 @@
-# Round-2 (late) evidence bundle, after the split-bf16 fit path, the look-ahead and GPSO_MATH_AUTO
+# Round-2 (late) evidence bundle, after the split-bf16 fit path, the look-ahead and GPSO_MATH_AUTO (r02g), and again
+# on the final code of the round (r02h: float pivot chain, pipelined panels)
 # (run on the GPU box: bash tools/collect_profiles_r02g.sh [TAG]).  Outputs under gpurun_out/TAG; the files to
 # keep are copied into profiles/ by hand (see profiles/README.md).
 TAG=${1:-r02g}
@@ -35,5 +36,8 @@ timeout -k 5 60 $R/tools/micro/syrk_bench_stamps.bin 14336 1024 | tail -8 > $O/s
 timeout -k 5 120 $R/tools/micro/lookahead_probe.bin > $O/lookahead_probe.txt 2>&1
 timeout -k 5 100 $R/tools/micro/leaf_bf16_phases.bin | tail -3 > $O/leaf_bf16_phases.txt 2>&1
 timeout -k 5 100 $R/tools/micro/diag_phases.bin 1024 | tail -1 > $O/diag_phases.txt 2>&1
+timeout -k 5 60 $R/tools/micro/lat_probe.bin > $O/lat_probe.txt 2>&1
+{ timeout -k 5 60 $R/tools/micro/small_phases.bin 52 2 | tail -1; timeout -k 5 60 $R/tools/micro/small_phases.bin 100 2 | tail -1; } > $O/small_fit_phases.txt 2>&1
+python3 $R/tools/host_overhead.py 2>/dev/null | grep -E "wall|device" > $O/host_overhead.txt
 for s in 21 22 23; do FUZZ_CASES=80 FUZZ_SEED=$s python3 $R/tools/fuzz_gpu.py > $O/fuzz_seed$s.log 2>&1; tail -1 $O/fuzz_seed$s.log; done
 ls -la $O
