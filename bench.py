@@ -44,7 +44,7 @@ PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak; a split product costs 6 (bf16
 # HBM bytes per launch of the dominant kernel come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
 # cannot be read from inside the process); the committed record of the latest collection:
 PMC_TRAFFIC = {("c3", "native"): "profiles/r02f_pmc_leaf_tiles_c3.json",
-               ("c3", "bf16x6"): "profiles/r02g_pmc_leaf_tiles_bf16x6_c3.json"}
+               ("c3", "bf16x6"): "profiles/r02h_pmc_leaf_tiles_bf16x6_c3.json"}
 
 
 def pmc_traffic(workload, math_mode):
@@ -125,7 +125,13 @@ def roofline_fit(n, d, dtype, fit_ms):
     out = {"bound": "mfma", "peak": peak, "unit": "TFLOP/s",
            "dominant_kernel": ("small_fit_kernel (one launch)" if n <= 128 else
                                "potrf_step_kernel (one launch per 64 columns: diagonal-block chain + trailing update)"
-                               if single else "gemm128_kernel (SYRK / TRSM / level-doubling inverse) + potrf_step_kernel chain"),
+                               if single else
+                               "gemm_bf16_kernel (split-bf16 rank-1024 updates / level-doubling inverse / K^-1) + potrf_step_kernel "
+                               "chain of the diagonal blocks, looked ahead on a side stream" if dtype == "float32" else
+                               "gemm128_kernel (SYRK / TRSM / level-doubling inverse) + potrf_step_kernel chain"),
+           "peak_note": ("dense f32 MFMA peak; the large products of a two-level float fit run as 6 bf16 MFMAs per f32 product "
+                         "(bound 2500 / 6 = 417 TFLOP/s f32-equivalent), so frac may approach or pass 1 there"
+                         if dtype == "float32" and not single else "dense MFMA peak of the fit's arithmetic type"),
            "flops_posterior": f_post, "flops_nlml_grad": f_grad}
     for key, fl in (("posterior", f_post), ("nlml_grad", f_grad)):
         if key in fit_ms:

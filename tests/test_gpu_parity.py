@@ -645,3 +645,35 @@ def test_float_fit_on_the_bf16_matrix_cores_agrees_with_the_f32_path():
     assert np.max(np.abs(res[1][3] - res[0][3])) <= 5e-5 * np.max(np.abs(res[0][3]))
     assert np.max(np.abs(res[1][5] - res[0][5])) <= 2e-4 * np.max(np.abs(res[0][5]))
     assert np.max(np.abs(res[1][4] - res[0][4]) / np.maximum(1.0, np.abs(res[0][4]))) < 2e-2
+
+
+@pytest.mark.parametrize("dtype,math", [("float32", "bf16x6"), ("float32", "bf16x3"), ("float32", "native"),
+                                        ("mixed", "bf16x6"), ("float64", "native")])
+@pytest.mark.parametrize("n,d", [(200, 3), (512, 1), (1024, 12)])
+def test_run_to_run_determinism(dtype, math, n, d):
+    """No kernel of the path sums with atomics: the same posterior and leaves give the same BITS every time.  A
+    result that changes between runs is a race -- the LDS-DMA / M0 hazard of the split-bf16 kernel (a queued
+    global_load_lds landing at the address M0 was rewritten to for the next one; profiles/r02h_dma_m0_hazard.txt)
+    showed as a wrong mean in 8 % of the runs of the (200, 3) case.  tools/race_probe.py is the long version."""
+    from pygpso_amd import HipGPEngine
+    from pygpso_amd._lib import GpsoPrecisionError
+
+    X, y = synthetic_problem(n, d, seed=7 * n + d)
+    Xs = synthetic_leaves(257, d, seed=11 * n + d)
+    ls = 0.25 * np.sqrt(d) * np.ones(1)
+    ref = None
+    for _ in range(25):
+        eng = HipGPEngine(dtype, predict_math=math)
+        eng.set_data(X, y)
+        try:
+            f, g = eng.fit_eval("Matern32", ls, 1.3, 1e-3, float(y.mean()), want_grad=True)
+            mean, var = eng.predict(Xs)
+        except GpsoPrecisionError:
+            pytest.skip("refused by the precision self-test")
+        cur = (np.float64(f).tobytes(), np.asarray(g).tobytes(), mean.tobytes(), var.tobytes())
+        if ref is None:
+            ref = cur
+            post = gpr.posterior(gpr.Theta("Matern32", ls, 1.3, 1e-3, float(y.mean())), X, y)
+            mean_ref, _ = gpr.predict_y(post, Xs)
+            assert np.max(np.abs(mean - mean_ref)) <= (1e-9 if dtype == "float64" else 4e-4) * max(1.0, np.max(np.abs(y)))
+        assert cur == ref
