@@ -207,7 +207,10 @@ __device__ __forceinline__ void leaf_v2_step(
 #pragma unroll
     for (int t = 0; t < CT; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) macc[t] = fma_t(p_nxt[t][r], a4[r], macc[t]);
+      for (int r = 0; r < 4; ++r) {
+        macc[t] = fma_t(p_nxt[t][r], a4[r], macc[t]);
+        if constexpr (sizeof(T) == 4) asm volatile("" : "+v"(macc[t]));  // no packed accumulation (see leaf_bf16_gen)
+      }
   }
 #pragma unroll
   for (int t = 0; t < CT; ++t) p_cur[t] = p_nxt[t];
@@ -259,24 +262,65 @@ __global__ __launch_bounds__(256, 2) void leaf_tiles_v2_kernel(
   const vecG* xn4 = reinterpret_cast<const vecG*>(xnorm);
   const vec4* al4 = reinterpret_cast<const vec4*>(alpha);
 
-  auto issue_panel = [&](int kt, int buf) {
-    for (int f = wave; f < RT; f += 4) {
-      // tiles above the diagonal do not exist in the packed triangle; their slot is never read
-      if (kt > kt_diag0 + f) continue;
-      const unsigned char* src = reinterpret_cast<const unsigned char*>(linv4 + linv_tile(kt_diag0 + f, kt) + lane);
+  // LDS-DMA duty: ONE LDS window (one M0 value) per wave between two workgroup barriers, as in
+  // leaf_tiles_bf16_kernel: wave w moves the RT / 4 consecutive fragments w RT / 4 .. of the panel (4 or 8 KB),
+  // addressed as M0 + the instruction's immediate offset, which the hardware adds to the global address as well
+  // (the per-fragment global base is pre-biased).  The X fragments of a k-tile (dp4 x 64 values: at most three
+  // per thread) travel through registers instead: loaded at the top of the step, written to LDS in front of
+  // the barrier that ends it.
+  constexpr int NFW = RT / 4, WBYTES = NFW * FB;
+  static_assert(WBYTES <= 8192, "a wave's fragments must fit the 13-bit signed immediate around the window centre");
+  const int lane_b = lane * (int)sizeof(vec4);
+  const unsigned char* pgb[NFW];
 #pragma unroll
-      for (int h = 0; h < L::SLABS; ++h) glds16(src + 16 * h, panel + (size_t)(buf * RT + f) * FB + h * 1024);
-    }
+  for (int j = 0; j < NFW; ++j) {
+    const size_t r = (size_t)(kt_diag0 + wave * NFW + j);
+    pgb[j] = reinterpret_cast<const unsigned char*>(linv4 + r * (r + 1) / 2 * 64) - (j * FB - WBYTES / 2);
+  }
+  auto uniform = [](const unsigned char* p) {  // keeps a wave-uniform address in scalar registers (no per-lane hoisting)
+    const unsigned long long g = (unsigned long long)p;
+    unsigned lo = (unsigned)g, hi = (unsigned)(g >> 32);
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return reinterpret_cast<const unsigned char*>(((unsigned long long)hi << 32) | lo);
   };
-  auto issue_xs = [&](int kt, int buf) {
-    for (int c = wave; c < dp4; c += 4)
-      glds_xfrag<TG>(xs_p + ((size_t)kt * dp4 + c) * 64, xsl + (size_t)(buf * dp4 + c) * XB, lane);
+  auto issue_panel = [&](int kt, int buf) {
+    unsigned char* centre = panel + (size_t)buf * RT * FB + (size_t)wave * WBYTES + WBYTES / 2;
+    static_for<0, NFW>([&](auto j_) {
+      constexpr int j = decltype(j_)::value;
+      // tiles above the diagonal do not exist in the packed triangle; their slot is never read
+      if (kt <= kt_diag0 + wave * NFW + j) {
+        const unsigned char* src = uniform(pgb[j] + (size_t)kt * 64 * sizeof(vec4)) + lane_b;
+        static_for<0, L::SLABS>([&](auto h_) {
+          constexpr int h = decltype(h_)::value;
+          // slab h: bytes 16 h .. of every lane's vec4 -> LDS slab h of the fragment (the immediate also moves the
+          // global address: the slab's +16 there is what is left after the -1024 h that undoes it)
+          glds16_off<j * FB + h * 1024 - WBYTES / 2>(src + 16 * h - h * 1024, centre);
+        });
+      }
+    });
+  };
+  constexpr int XL = 3;  // X values per thread and k-tile (dp4 <= 12)
+  TG xr[XL];
+  auto load_xs = [&](int kt) {
+#pragma unroll
+    for (int u = 0; u < XL; ++u)
+      if (tid + 256 * u < dp4 * 64) xr[u] = xs_p[(size_t)kt * dp4 * 64 + tid + 256 * u];
+  };
+  auto store_xs = [&](int buf) {
+    TG* xd = reinterpret_cast<TG*>(xsl + (size_t)buf * dp4 * XB);
+#pragma unroll
+    for (int u = 0; u < XL; ++u)
+      if (tid + 256 * u < dp4 * 64) xd[tid + 256 * u] = xr[u];
   };
 
   // prologue: panel(0) -> P[0], xs(0) -> X[1], xs(1) -> X[0]; this wave's leaf fragments -> xb
   issue_panel(0, 0);
-  issue_xs(0, 1);
-  if (kt_end > 1) issue_xs(1, 0);
+  load_xs(0);
+  store_xs(1);
+  if (kt_end > 1) {
+    load_xs(1);
+    store_xs(0);
+  }
   for (int t = 0; t < CT; ++t)
     for (int c = 0; c < dp4; ++c)
       xb[(t * dp4 + c) * 64 + lane] =
@@ -317,7 +361,10 @@ __global__ __launch_bounds__(256, 2) void leaf_tiles_v2_kernel(
 #pragma unroll
       for (int t = 0; t < CT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) macc[t] = fma_t(p_cur[t][r], a4[r], macc[t]);
+        for (int r = 0; r < 4; ++r) {
+          macc[t] = fma_t(p_cur[t][r], a4[r], macc[t]);
+          if constexpr (sizeof(T) == 4) asm volatile("" : "+v"(macc[t]));  // no packed accumulation (see leaf_bf16_gen)
+        }
     }
   }
   na = (kt_end > 1) ? xn4[4 + (lane >> 4)] * C2 : na;  // norms of k-tile 1
@@ -331,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void leaf_tiles_v2_kernel(
     if (kt + 1 < kt_end) issue_panel(kt + 1, b ^ 1);                                               \
     vecG na_nxt = na;                                                                              \
     if (kt + 2 < kt_end) {                                                                         \
-      issue_xs(kt + 2, b ^ 1);                                                                     \
+      load_xs(kt + 2);                                                                             \
       na_nxt = xn4[(kt + 2) * 4 + (lane >> 4)] * C2;                                               \
     }                                                                                              \
     GPSO_PSTAMP(kt, 1);                                                                            \
@@ -339,6 +386,7 @@ __global__ __launch_bounds__(256, 2) void leaf_tiles_v2_kernel(
         kt, kt_diag0, kt + 1 < kt_end, GEN_DIAG, lane, dp4, panel + (size_t)b * RT * FB,           \
         xsl + (size_t)b * dp4 * XB, xb, na, al4, nb, variance, acc, macc, p_cur);                  \
     na = na_nxt;                                                                                   \
+    if (kt + 2 < kt_end) store_xs(b ^ 1);                                                          \
     GPSO_PSTAMP(kt, 4);                                                                            \
     __syncthreads(); /* panel(kt+1) / xs(kt+2) landed; buffers b free */                           \
     GPSO_PSTAMP(kt, 5);                                                                            \
@@ -479,7 +527,14 @@ __device__ __forceinline__ void leaf_bf16_gen(bool diag, int lane, int dp4,
 #pragma unroll
       for (int t = 0; t < CT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) macc[t] = fma_t(p[t][4 * h + r], a4[r], macc[t]);
+        for (int r = 0; r < 4; ++r) {
+          macc[t] = fma_t(p[t][4 * h + r], a4[r], macc[t]);
+          // keeps the two tiles' means in separate registers: packed by the SLP vectoriser into one register pair
+          // and a chain of dependent v_pk_fma_f32, the high half (t = 1) came back wrong now and then in waves
+          // 4-7 -- 33 of 400 runs of a D = 3 posterior, 27 of 150 of a C3 posterior in the bf16x3 kernel; 0 with
+          // this line (profiles/r02h_packed_mean_bug.txt; predict.hip is also built with -fno-slp-vectorize)
+          asm volatile("" : "+v"(macc[t]));
+        }
     }
   }
   // ---- split into bf16 pieces: B operands ---------------------------------------------------------
@@ -554,14 +609,13 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   const int q_diag0 = bi * (RT / 2), q_end = q_diag0 + RT / 2;
 
   // ---- LDS-DMA duties: ONE LDS window (one M0 value) per wave between two workgroup barriers ----------------
-  // Measured (tools/fuzz_gpu.py FUZZ_REPEAT_CASE, profiles/r02h_dma_m0_hazard.txt): a global_load_lds whose M0 is
-  // rewritten for the next DMA shortly after it issued can land at the NEW address when the wave already has
-  // several DMAs queued -- 25 of 300 runs of a D = 3 posterior returned a wrong mean (the last L^-1 fragment of
-  // wave 6 landed on the alpha block whose DMA followed ~100 clocks later); with ~200 clocks of s_nop between
-  // them 0 of 300.  Distances are not a contract, so the kernel does not rely on them: every DMA a wave issues
-  // in an interval goes to ONE window addressed as M0 + the instruction's immediate offset (13 bits, signed,
-  // applied to the global and the LDS address alike -- the global base is pre-biased by the same amount), and M0
-  // is written again only after the barrier that ends the interval, behind the wave's own s_waitcnt vmcnt(0).
+  // Every DMA a wave issues in an interval goes to one window addressed as M0 + the instruction's immediate
+  // offset (13 bits, signed, applied to the global and the LDS address alike -- the global base is pre-biased by
+  // the same amount): one M0 write and one scalar add per fragment instead of ~25 scalar instructions of address
+  // arithmetic (the DMA issue phase of a k-step 1 430 - 1 550 -> 730 - 810 clocks).  M0 is written again only
+  // after the barrier that ends the interval.  (Introduced while hunting an intermittent wrong mean that turned
+  // out to be the packed accumulation in leaf_bf16_gen -- profiles/r02h_packed_mean_bug.txt; there is no evidence
+  // of an M0 hazard, the windows are kept for what they save.)
   //   waves 0 .. NS*RT/8 - 1: eight consecutive 1 KB fragments of the L^-1 pieces (fragment f = piece f / RT, row
   //                           tile f % RT), window centre at +4 KB;
   //   wave 6:                 the X fragments of a step, a linear image of 256-byte pieces, window centre at +4 KB;

@@ -652,9 +652,9 @@ def test_float_fit_on_the_bf16_matrix_cores_agrees_with_the_f32_path():
 @pytest.mark.parametrize("n,d", [(200, 3), (512, 1), (1024, 12)])
 def test_run_to_run_determinism(dtype, math, n, d):
     """No kernel of the path sums with atomics: the same posterior and leaves give the same BITS every time.  A
-    result that changes between runs is a race -- the LDS-DMA / M0 hazard of the split-bf16 kernel (a queued
-    global_load_lds landing at the address M0 was rewritten to for the next one; profiles/r02h_dma_m0_hazard.txt)
-    showed as a wrong mean in 8 % of the runs of the (200, 3) case.  tools/race_probe.py is the long version."""
+    result that changes between runs is a race or a hazard -- the packed accumulation of the two column tiles'
+    means in the split-bf16 kernel (profiles/r02h_packed_mean_bug.txt) showed as a wrong mean in 8 % of the runs
+    of the (200, 3) case.  tools/race_probe.py is the long version."""
     from pygpso_amd import HipGPEngine
     from pygpso_amd._lib import GpsoPrecisionError
 

@@ -52,6 +52,11 @@ for case in range(N_CASES):
         # genuinely ill-conditioned for their arithmetic: a float FACTOR from cond ~ 1e3 on (its gate is
         # conservative by design), float applies on a double factor only at extreme conditioning
         limit = 3e2 if dtype == "float32" else 1e7
+        # ... and the three-product split (bf16x3, an explicit request: never the default) keeps 2^-16 per product,
+        # which the variance's cancellation amplifies: its gate may close from cond ~ 1e4 on (seed 55: 1.4e5,
+        # measured variance error 2.1e-4 sigma^2 against the gate's 1.5e-4 -- refused, as it should)
+        if math == "bf16x3":
+            limit = min(limit, 1e4)
         ok = dtype != "float64" and cond >= limit
         # ... or where the float rounding of the terms k_i alpha_i of the MEAN alone uses up the tolerance
         # (|alpha| grows with the conditioning; the mean is a cancelling sum of such terms)

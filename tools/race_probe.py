@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Run-to-run determinism probe (run on the GPU box).  Every kernel of the path is deterministic by
 construction (no atomics in the sums), so the SAME posterior and leaves must give the SAME bits every time:
-a result that changes between runs is a race (this is how the LDS-DMA / M0 hazard of the split-bf16 predict
-kernel showed up: fuzz seed 22, D = 3).  Small D and short workgroups are the sensitive corner -- the DMAs of
-a k-step follow each other most closely there.
+a result that changes between runs is a race or a hazard (the packed accumulation of the means in the split-bf16
+predict kernel, profiles/r02h_packed_mean_bug.txt, showed up this way: fuzz seed 22, D = 3).  Small D and short
+workgroups are the sensitive corner.
 
   python tools/race_probe.py [REPEATS]
 """
