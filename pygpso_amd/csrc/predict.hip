@@ -506,6 +506,9 @@ __device__ __forceinline__ void leaf_bf16_gen(bool diag, int lane, int dp4,
       s[1][t] = MG::mma(x1, l, s[1][t]);
     }
   }
+#ifdef GPSO_PROBE_NOPS_A  // tools/micro/packed_mean_probe.hip: wait states behind the contraction MFMAs
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15");
+#endif
   float p[CT][8];
   // norms and alpha of the 32 points of this k-step arrived in LDS with the panel (no ordinary global
   // load inside the loop: one issued after the LDS-DMA makes hipcc drain the DMA queue at its use)
@@ -520,6 +523,9 @@ __device__ __forceinline__ void leaf_bf16_gen(bool diag, int lane, int dp4,
       for (int r = 0; r < 4; ++r)
         p[t][4 * h + r] = kern_from_scaled<KERNEL>((float)fma_t((TG)(TG(-2) * C2), s[h][t][r], na[r] + nb[t]), variance);
   }
+#ifdef GPSO_PROBE_NOPS_B  // ... and in front of the mean updates
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15");
+#endif
   if (diag) {  // this k-step lies in the diagonal block (wave-uniform): its share of k*.alpha (f32, before the split)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -533,7 +539,9 @@ __device__ __forceinline__ void leaf_bf16_gen(bool diag, int lane, int dp4,
           // and a chain of dependent v_pk_fma_f32, the high half (t = 1) came back wrong now and then in waves
           // 4-7 -- 33 of 400 runs of a D = 3 posterior, 27 of 150 of a C3 posterior in the bf16x3 kernel; 0 with
           // this line (profiles/r02h_packed_mean_bug.txt; predict.hip is also built with -fno-slp-vectorize)
+#ifndef GPSO_PROBE_PACKED_MEAN  // tools/micro/packed_mean_probe.hip builds the kernel without it
           asm volatile("" : "+v"(macc[t]));
+#endif
         }
     }
   }

@@ -1,0 +1,92 @@
+// Self-contained reproducer of the packed-mean failure of leaf_tiles_bf16_kernel (profiles/r02h_packed_mean_bug.txt):
+// the real kernel on synthetic data, R launches on the same inputs, every launch's mean / variance partials compared
+// bit by bit with the first one's.  Two builds:
+//   as shipped   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -I pygpso_amd/csrc
+//                  tools/micro/packed_mean_probe.hip -o tools/micro/packed_mean_probe.bin
+//   packed       hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DGPSO_PROBE_PACKED_MEAN -I pygpso_amd/csrc
+//                  tools/micro/packed_mean_probe.hip -o tools/micro/packed_mean_probe_packed.bin
+// (packed: SLP vectorisation on and the empty asm behind the mean updates left out, so the two column tiles' means
+// are accumulated as one chain of dependent v_pk_fma_f32)
+#include "../../pygpso_amd/csrc/predict.hip"
+#include <cstdio>
+#include <cmath>
+#include <cstring>
+#include <vector>
+namespace gpso {
+int ensure_dyn_lds(const void* fn, int bytes) {
+  if (bytes > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  return 0;
+}
+void note_launch_error(const char* m) { fprintf(stderr, "launch error: %s\n", m); }
+}  // namespace gpso
+using namespace gpso;
+
+template <typename TG>
+static void run(int64_t npad, int d, int ns, int64_t m, int reps) {
+  const int dp4 = (d + 3) / 4, dp = dp4 * 4, nbi = (int)(npad / 256);
+  std::vector<float> linv((size_t)npad * npad, 0.f), al(npad);
+  std::vector<TG> xsp((size_t)npad * dp, (TG)0), xn(npad), lv((size_t)m * dp, (TG)0), ln(m);
+  unsigned s = 1; auto rnd = [&] { s = s * 1664525u + 1013904223u; return (float)(s >> 8) / (1 << 24); };
+  for (int64_t i = 0; i < npad; ++i)
+    for (int64_t j = 0; j <= i; ++j) linv[i * npad + j] = 0.01f * (rnd() - 0.5f);
+  for (auto& v : xsp) v = (TG)rnd();
+  for (auto& v : xn) v = (TG)(3.0f + rnd());
+  for (auto& v : al) v = 40.0f * (rnd() - 0.5f);
+  for (auto& v : lv) v = (TG)rnd();
+  for (auto& v : ln) v = (TG)(3.0f + rnd());
+  float *dl, *da; TG *dx, *dn, *dlv, *dln; double *pv, *pm; void* lb;
+  hipMalloc(&dl, linv.size() * 4); hipMalloc(&dx, xsp.size() * sizeof(TG)); hipMalloc(&dn, npad * sizeof(TG)); hipMalloc(&da, npad * 4);
+  hipMalloc(&dlv, lv.size() * sizeof(TG)); hipMalloc(&dln, m * sizeof(TG)); hipMalloc(&pv, (size_t)nbi * m * 8); hipMalloc(&pm, (size_t)nbi * m * 8);
+  hipMalloc(&lb, (size_t)ns * npad * npad * 2);
+  hipMemcpy(dl, linv.data(), linv.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dx, xsp.data(), xsp.size() * sizeof(TG), hipMemcpyHostToDevice);
+  hipMemcpy(dn, xn.data(), npad * sizeof(TG), hipMemcpyHostToDevice); hipMemcpy(da, al.data(), npad * 4, hipMemcpyHostToDevice);
+  hipMemcpy(dlv, lv.data(), lv.size() * sizeof(TG), hipMemcpyHostToDevice); hipMemcpy(dln, ln.data(), m * sizeof(TG), hipMemcpyHostToDevice);
+  launch_pack_linv_bf16<float>(0, ns, dl, npad, npad, lb);
+  KernParams kp{0, 1.0, 1e-3, 0.0};
+  std::vector<double> m0((size_t)nbi * m), v0((size_t)nbi * m), m1(m0.size()), v1(m0.size());
+  int bad_mean = 0, bad_var = 0; int64_t first_col = -1;
+  // the reference is a WARM launch (the third); before every compared launch the other instantiation of the kernel
+  // runs, so the compared one starts with a cold instruction cache -- the failing launches are the cold ones
+  void* lb2; hipMalloc(&lb2, (size_t)3 * npad * npad * 2);
+  launch_pack_linv_bf16<float>(0, 5 - ns, dl, npad, npad, lb2);
+  std::vector<double> mfirst(m0.size());
+  launch_leaf_tiles_bf16<TG>(0, ns, lb, dx, dn, da, dlv, dln, pv, pm, npad, dp4, m, kp, nullptr);  // the instantiation's first launch
+  hipDeviceSynchronize();
+  hipMemcpy(mfirst.data(), pm, mfirst.size() * 8, hipMemcpyDeviceToHost);
+  for (int w = 0; w < 2; ++w) launch_leaf_tiles_bf16<TG>(0, ns, lb, dx, dn, da, dlv, dln, pv, pm, npad, dp4, m, kp, nullptr);
+  hipDeviceSynchronize();
+  for (int rep = 0; rep < reps; ++rep) {
+    if (rep > 0) launch_leaf_tiles_bf16<TG>(0, 5 - ns, lb2, dx, dn, da, dlv, dln, pv, pm, npad, dp4, m, kp, nullptr);
+    hipMemset(pm, 0xff, m0.size() * 8); hipMemset(pv, 0xff, m0.size() * 8);
+    launch_leaf_tiles_bf16<TG>(0, ns, lb, dx, dn, da, dlv, dln, pv, pm, npad, dp4, m, kp, nullptr);
+    hipDeviceSynchronize();
+    hipMemcpy(m1.data(), pm, m1.size() * 8, hipMemcpyDeviceToHost); hipMemcpy(v1.data(), pv, v1.size() * 8, hipMemcpyDeviceToHost);
+    if (rep == 0) { m0 = m1; v0 = v1; continue; }
+    const bool bm = memcmp(m0.data(), m1.data(), m0.size() * 8) != 0, bv = memcmp(v0.data(), v1.data(), v0.size() * 8) != 0;
+    if (bm && first_col < 0)
+      for (size_t i = 0; i < m0.size(); ++i)
+        if (memcmp(&m0[i], &m1[i], 8)) { first_col = (int64_t)(i % m); break; }
+    bad_mean += bm; bad_var += bv;
+  }
+  int first_bad = 0;
+  for (size_t i = 0; i < m0.size(); ++i) first_bad += memcmp(&m0[i], &mfirst[i], 8) != 0;
+  printf("N %5lld D %2d bf16x%d generation %s, %lld leaves: first launch %s; %d of %d launches with a mean partial that differs from a warm launch's, %d with a variance partial",
+         (long long)npad, d, ns == 3 ? 6 : 3, sizeof(TG) == 8 ? "double" : "float ", (long long)m,
+         first_bad ? "DIFFERS from the warm ones in its mean partials" : "ok", bad_mean, reps - 1, bad_var);
+  if (first_bad) printf(" [%d partials of the first launch differ]", first_bad);
+  if (first_col >= 0) printf(" (first differing leaf %lld: wave %lld of its workgroup, column tile %lld)", (long long)first_col, (long long)((first_col % 256) / 32), (long long)((first_col % 32) / 16));
+  printf("\n");
+  hipFree(dl); hipFree(da); hipFree(dx); hipFree(dn); hipFree(dlv); hipFree(dln); hipFree(pv); hipFree(pm); hipFree(lb); hipFree(lb2);
+}
+
+int main(int argc, char** argv) {
+  const int reps = (argc > 1) ? atoi(argv[1]) : 200;
+  for (int ns = 2; ns <= 3; ++ns) {
+    run<float>(2048, 12, ns, 4096, reps);
+    run<double>(2048, 12, ns, 4096, reps);
+    run<float>(256, 3, ns, 512, reps);
+    run<double>(256, 3, ns, 512, reps);
+    run<double>(256, 6, ns, 4096, reps);
+  }
+  return 0;
+}
