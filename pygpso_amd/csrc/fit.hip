@@ -412,6 +412,10 @@ __device__ __forceinline__ void chol_panel16(double* Ls, F* Cs, int c0, int lane
       const F2 nl = {-lprev, -lprev};
       static_for<0, kPB / 2 - ((k0 + 1) >> 1)>([&](auto q_) {
         constexpr int P = kPB / 2 - 1 - decltype(q_)::value;
+        // (the one packed FMA left in the library -- the toolchain has shown a wait-state hazard in front of a
+        // chain of packed FMAs fed straight from LDS reads, profiles/r02h_packed_mean_bug.txt, cured by ~128 clocks
+        // of distance: here the multiplier pairs were read a whole step, >= 150 clocks, before this use, and the
+        // panel has been bit-identical over 27 000 probe runs; two scalar FMAs instead cost 7 % of a panel)
         lp[P] = __builtin_elementwise_fma(nl, m2[b ^ 1][P], lp[P]);
       });
       if constexpr (k0 & 1) lp[k0 >> 1].y = fma_t(-lprev, m2[b ^ 1][k0 >> 1].y, lp[k0 >> 1].y);
