@@ -526,6 +526,10 @@ __device__ __forceinline__ void leaf_bf16_gen(bool diag, int lane, int dp4,
 #ifdef GPSO_PROBE_NOPS_B  // ... and in front of the mean updates
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15");
 #endif
+#ifdef GPSO_PROBE_NOPS_N  // ... the same place, GPSO_PROBE_NOPS_N x 16 clocks
+#pragma unroll
+  for (int i = 0; i < GPSO_PROBE_NOPS_N; ++i) asm volatile("s_nop 15");
+#endif
   if (diag) {  // this k-step lies in the diagonal block (wave-uniform): its share of k*.alpha (f32, before the split)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
