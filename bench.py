@@ -27,6 +27,27 @@ import time
 
 import numpy as np
 
+# rank 0 prints ONE JSON line on stdout.  RCCL writes its version banner (NCCL_DEBUG=VERSION, as set on the GPU boxes)
+# straight to file descriptor 1: under the launcher, descriptor 1 is pointed at stderr for the duration of the run and
+# handed back for the one line
+_STDOUT_FD = None
+
+
+def _stdout_to_stderr():
+    global _STDOUT_FD
+    sys.stdout.flush()
+    _STDOUT_FD = os.dup(1)
+    os.dup2(2, 1)
+
+
+def _stdout_back():
+    global _STDOUT_FD
+    if _STDOUT_FD is not None:
+        sys.stdout.flush()
+        os.dup2(_STDOUT_FD, 1)
+        os.close(_STDOUT_FD)
+        _STDOUT_FD = None
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -204,6 +225,7 @@ def main():
     # --nproc-per-node 1, so the RCCL plumbing is exercised identically at every N
     use_dist = "RANK" in os.environ
     if use_dist:
+        _stdout_to_stderr()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -345,7 +367,10 @@ def main():
             # every predict math on the same leaves in the same run: throughput + accuracy vs the oracle
             out["predict_math_modes"] = split_bf16_report(eng, leaves_dev, leaves_all, varsigma, m_total,
                                                   flops_per_leaf, post, max(3, args.steps // 2))
-        print(json.dumps(out))
+        _stdout_back()
+        print(json.dumps(out), flush=True)
+        if use_dist:
+            _stdout_to_stderr()  # (library chatter at tear-down)
     if use_dist:
         eng.comm_destroy()
         dist.destroy_process_group()
