@@ -81,8 +81,9 @@ static void run(int64_t npad, int d, int ns, int64_t m, int reps) {
 
 int main(int argc, char** argv) {
   const int reps = (argc > 1) ? atoi(argv[1]) : 200;
-  if (argc > 2) {  // any second argument: only the configuration that fails
-    run<double>(2048, 12, 2, 4096, reps);
+  if (argc > 2) {  // second argument: only the configuration that fails ("f": the same with float generation)
+    if (argv[2][0] == 'f') run<float>(2048, 12, 2, 4096, reps);
+    else run<double>(2048, 12, 2, 4096, reps);
     return 0;
   }
   for (int ns = 2; ns <= 3; ++ns) {
