@@ -210,6 +210,35 @@ int gpso_best_ucb_sharded(gpso_ctx* ctx, const void* xs, int xs_dtype, int xs_me
 int gpso_best_ucb_grow_sharded(gpso_ctx* ctx, const double* bounds, int nseg, int depth, double varsigma,
                                int64_t* idx, double* mean, double* var, double* ucb);
 
+/* Collective safety: every rank takes part in every collective of a group call whatever happened in its own half
+ * of it (bad arguments, no posterior, GPSO_E_PRECISION from the self-test, a failed allocation): a failing rank
+ * sends an empty payload carrying its status, the fold takes the worst status over the ranks, and EVERY rank
+ * returns that code (its own message on the rank that failed, "rank r failed ..." on the others).  In particular a
+ * posterior that fails the precision self-test on the fitting rank makes gpso_broadcast_posterior return
+ * GPSO_E_PRECISION on every rank.  What cannot be agreed on is a failure of HIP or RCCL itself in the middle of
+ * a call; gpso_comm_abort (ncclCommAbort), called from another thread for the context whose call is blocked, is
+ * the way out of that one -- the blocked call then returns GPSO_E_RCCL / GPSO_E_HIP and the context must leave the
+ * group (gpso_comm_destroy) before it joins another. */
+int gpso_comm_abort(gpso_ctx* ctx);
+
+/* The two halves of the sharded calls on their own, for an arbitrary (rank, world) and WITHOUT a communicator: what
+ * a group of `world` ranks computes can be replayed on one device (tests, debugging; also a transport other than
+ * RCCL): gpso_shard_winners / gpso_shard_winners_grow run rank `rank`'s local half of gpso_best_ucb_sharded /
+ * gpso_best_ucb_grow_sharded and copy out its payload -- gpso_group_payload_doubles(nseg) doubles: nseg x (mean, var,
+ * ucb, bit-cast int64 index), a spare slot, the status of the half (also the return value); gpso_fold_winners takes
+ * the payloads of all ranks concatenated in rank order (m_global >= 0 with seg_off: payloads of gpso_shard_winners,
+ * whose indices are relative to the local piece of each segment; m_global < 0: of gpso_shard_winners_grow) and
+ * returns what the group call returns, the worst status included.  These run the very kernels and index arithmetic
+ * of the group calls; only ncclAllGather is replaced by the caller's concatenation. */
+int gpso_group_payload_doubles(int nseg);
+int gpso_shard_winners(gpso_ctx* ctx, int rank, int world, const void* xs, int xs_dtype, int xs_mem,
+                       int64_t m_local, int64_t m_global, const int64_t* seg_off, int nseg, double varsigma,
+                       double* payload);
+int gpso_shard_winners_grow(gpso_ctx* ctx, int rank, int world, const double* bounds, int nseg, int depth,
+                            double varsigma, double* payload);
+int gpso_fold_winners(gpso_ctx* ctx, const double* gathered, int world, int64_t m_global, const int64_t* seg_off,
+                      int nseg, int64_t* idx, double* mean, double* var, double* ucb);
+
 /* ---- introspection ------------------------------------------------------------------------- */
 
 /* padded problem size the device works with (multiple of 128), 0 before gpso_set_data */

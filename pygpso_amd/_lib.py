@@ -93,6 +93,14 @@ SIGNATURES = {
                                         _c_double_p, _c_double_p]),
     "gpso_best_ucb_grow_sharded": (C.c_int, [C.c_void_p, _c_double_p, C.c_int, C.c_int, C.c_double,
                                              _c_int64_p, _c_double_p, _c_double_p, _c_double_p]),
+    "gpso_comm_abort": (C.c_int, [C.c_void_p]),
+    "gpso_group_payload_doubles": (C.c_int, [C.c_int]),
+    "gpso_shard_winners": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int64,
+                                     C.c_int64, _c_int64_p, C.c_int, C.c_double, _c_double_p]),
+    "gpso_shard_winners_grow": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_double_p, C.c_int, C.c_int,
+                                          C.c_double, _c_double_p]),
+    "gpso_fold_winners": (C.c_int, [C.c_void_p, _c_double_p, C.c_int, C.c_int64, _c_int64_p, C.c_int,
+                                    _c_int64_p, _c_double_p, _c_double_p, _c_double_p]),
     "gpso_last_ms": (C.c_double, [C.c_void_p, C.c_int]),
     "gpso_last_count": (C.c_int64, [C.c_void_p, C.c_int]),
     "gpso_version": (C.c_char_p, []),

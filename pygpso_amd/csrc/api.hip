@@ -99,6 +99,13 @@ struct Engine {
                                double* var, double* ucb) = 0;
   virtual int best_ucb_grow_sharded(const double* bounds, int nseg, int depth, double varsigma, int64_t* idx,
                                     double* mean, double* var, double* ucb) = 0;
+  // the two halves of the sharded calls for an arbitrary (rank, world), without a communicator
+  virtual int shard_winners(int rank, int world, const void* xs, int xs_dtype, int xs_mem, int64_t m_local,
+                            int64_t m_global, const int64_t* seg_off, int nseg, double varsigma, double* payload) = 0;
+  virtual int shard_winners_grow(int rank, int world, const double* bounds, int nseg, int depth, double varsigma,
+                                 double* payload) = 0;
+  virtual int fold_winners(const double* gathered, int world, int64_t m_global, const int64_t* seg_off, int nseg,
+                           int64_t* idx, double* mean, double* var, double* ucb) = 0;
 };
 
 // contiguous share [lo, hi) of m items for `rank` of `world`: global order is preserved across ranks
@@ -135,6 +142,7 @@ struct gpso_ctx {
   double last_ms[3] = {0, 0, 0};
   // multi-GPU group (gpso_comm_init): one RCCL communicator per context, collectives on ctx->stream
   ncclComm_t comm = nullptr;
+  bool comm_aborted = false;  // gpso_comm_abort: the communicator is gone (not to be destroyed again)
   int rank = 0, world = 1;
   int64_t last_count[2] = {0, 0};  // leaves scored / leaves asked for by the last predict-type call
   std::string err;
@@ -980,7 +988,7 @@ struct EngineT : Engine {
     if ((rc = ensure(oucb, (size_t)m * 8))) return rc;
     if ((rc = ensure(segoff, (size_t)(nseg + 1) * 8))) return rc;
     if ((rc = ensure(best, (size_t)nseg * kArgmaxBlocks * kArgmaxPartialBytes))) return rc;
-    if ((rc = ensure(ovals, (size_t)(nseg * 4 + 1) * 8))) return rc;
+    if ((rc = ensure(ovals, (size_t)group_payload_doubles(nseg) * 8))) return rc;
     std::vector<int64_t> so(nseg + 1);
     if (seg_off) {
       for (int i = 0; i <= nseg; ++i) so[i] = seg_off[i];
@@ -1027,7 +1035,7 @@ struct EngineT : Engine {
     if ((rc = ensure(oucb, (size_t)cap * 8))) return rc;
     if ((rc = ensure(best, (size_t)nseg * kArgmaxBlocks * kArgmaxPartialBytes))) return rc;
     if ((rc = ensure(best_pos, (size_t)nseg * kArgmaxBlocks * 8))) return rc;
-    if ((rc = ensure(ovals, (size_t)(nseg * 4 + 1) * 8))) return rc;
+    if ((rc = ensure(ovals, (size_t)group_payload_doubles(nseg) * 8))) return rc;
     double* bdev = reinterpret_cast<double*>(static_cast<char*>(leaves_raw.p) + ob);
     double* stage = ctx->pinned_stage((size_t)nseg * d * 2 + 1);
     if (!stage) return ctx->fail(GPSO_E_OOM, "pinned host staging");
@@ -1048,9 +1056,45 @@ struct EngineT : Engine {
     return launch_status();
   }
 
-  // multi-GPU: all-gather every rank's ovals and fold them with the arg-max rule on (ucb, global index);
-  // base (host, [world][nseg], nullable) is added to a rank's indices first.  Result -> ovals2.
-  // (upload_base, called BEFORE the local work is queued, puts base into wbase through the pinned stage)
+  // ---- group calls ---------------------------------------------------------------------------------------
+  // Every rank takes part in every collective of a call, whatever happened in its local half: a rank whose half
+  // fails (arguments, state, precision gate, allocation) still sends a payload -- no winners and its status in the
+  // last slot (kernels.hpp: group_payload_doubles) -- the fold takes the worst status over the ranks, and EVERY rank
+  // returns that code.  No rank is left inside a collective by a peer that returned early, and a posterior that
+  // fails the precision self-test on the fitting rank makes the whole group return GPSO_E_PRECISION together.
+  int ensure_group_buffers(int nseg, int world) {
+    int rc;
+    const size_t pd = (size_t)group_payload_doubles(nseg);
+    if ((rc = ensure(ovals, pd * 8))) return rc;
+    if ((rc = ensure(gath, (size_t)world * pd * 8))) return rc;
+    if ((rc = ensure(ovals2, pd * 8))) return rc;
+    return GPSO_OK;
+  }
+  // base (host, [world][nseg]): what is added to a rank's winner index to make it relative to the GLOBAL segment
+  // start -- the offset of the rank's piece of the segment inside the segment
+  static void segment_bases(int64_t m_global, const std::vector<int64_t>& so, int nseg, int world,
+                            std::vector<int64_t>& base) {
+    base.assign((size_t)world * nseg, 0);
+    for (int r = 0; r < world; ++r) {
+      int64_t rlo, rhi;
+      shard_range(m_global, r, world, &rlo, &rhi);
+      for (int i = 0; i < nseg; ++i) base[(size_t)r * nseg + i] = std::min(std::max(so[i], rlo), rhi) - so[i];
+    }
+  }
+  int global_segments(int64_t m_global, const int64_t* seg_off, int nseg, std::vector<int64_t>& so) {
+    so.resize(nseg + 1);
+    if (seg_off) {
+      for (int i = 0; i <= nseg; ++i) so[i] = seg_off[i];
+      if (so[0] != 0 || so[nseg] != m_global) return ctx->fail(GPSO_E_ARG, "seg_off must start at 0 and end at the global M");
+      for (int i = 0; i < nseg; ++i)
+        if (so[i + 1] < so[i]) return ctx->fail(GPSO_E_ARG, "seg_off must be non-decreasing");
+    } else {
+      if (nseg != 1) return ctx->fail(GPSO_E_ARG, "seg_off == NULL requires nseg == 1");
+      so[0] = 0;
+      so[1] = m_global;
+    }
+    return GPSO_OK;
+  }
   int upload_base(const std::vector<int64_t>& base) {
     int rc = ensure(wbase, base.size() * 8);
     if (rc) return rc;
@@ -1060,24 +1104,72 @@ struct EngineT : Engine {
     HIPCHECK(hipMemcpyAsync(wbase.p, stage, base.size() * 8, hipMemcpyHostToDevice, st()));
     return GPSO_OK;
   }
+  // local half of gpso_best_ucb_sharded for (rank, world): rows shard_range(m_global, rank, world) of the batch ->
+  // this rank's per-segment winners in ovals (indices relative to the LOCAL piece of each segment), status slot 0
+  int sharded_local(int rank, int world, const void* xs, int xs_dtype, int xs_mem, int64_t m_local, int64_t m_global,
+                    const int64_t* seg_off, int nseg, double varsigma) {
+    int rc = check_predict_args(xs, xs_dtype, xs_mem, m_local);
+    if (rc) return rc;
+    int64_t lo, hi;
+    shard_range(m_global, rank, world, &lo, &hi);
+    if (m_local != hi - lo)
+      return ctx->fail(GPSO_E_ARG, "rank %d of %d must pass rows [%lld, %lld) of the %lld leaves (gpso_shard_range), got %lld rows",
+                       rank, world, (long long)lo, (long long)hi, (long long)m_global, (long long)m_local);
+    std::vector<int64_t> so, sl(nseg + 1);
+    if ((rc = global_segments(m_global, seg_off, nseg, so))) return rc;
+    // local segmentation: the part of every global segment inside [lo, hi)
+    for (int i = 0; i <= nseg; ++i) sl[i] = std::min(std::max(so[i], lo), hi) - lo;
+    const void* dev = nullptr;
+    if (m_local > 0 && (rc = stage_leaves(xs, xs_dtype, xs_mem, m_local, &dev))) return rc;
+    return enqueue_best_leaves(dev, xs_dtype, m_local, sl.data(), nseg, varsigma);
+  }
+  int sharded_local_grow(int rank, int world, const double* bounds, int nseg, int depth, double varsigma) {
+    if (!have_post) return ctx->fail(GPSO_E_STATE, "no posterior resident: call gpso_broadcast_posterior first");
+    int rc = precision_gate();
+    if (rc) return rc;
+    int64_t lo, hi;
+    shard_range(gpso_grow_rows(depth), rank, world, &lo, &hi);
+    return enqueue_best_grow(bounds, nseg, depth, lo, hi, varsigma);
+  }
+  // after the local half: on failure replace whatever it left in ovals by "no winner" rows and the status
+  // (on success the arg-max kernels have written the status slot themselves: no host step on the fast path)
+  int publish_local(int nseg, int local_rc) {
+    if (local_rc == GPSO_OK) return GPSO_OK;
+    const std::string keep = ctx->err;  // the local half's message
+    hipStream_t s = st();
+    const size_t pd = (size_t)group_payload_doubles(nseg);
+    double* stage = ctx->pinned_stage(pd);  // (waits for the stream)
+    if (!stage) return ctx->fail(GPSO_E_OOM, "pinned host staging");
+    const int64_t none = -1;
+    for (int i = 0; i < nseg; ++i) {
+      stage[4 * i] = stage[4 * i + 1] = stage[4 * i + 2] = std::nan("");
+      std::memcpy(&stage[4 * i + 3], &none, 8);
+    }
+    stage[4 * nseg] = 0.0;
+    stage[4 * nseg + 1] = (double)local_rc;
+    HIPCHECK(hipMemcpyAsync(ovals.p, stage, pd * 8, hipMemcpyHostToDevice, s));
+    ctx->err = keep;
+    return GPSO_OK;
+  }
+  // multi-GPU: all-gather every rank's payload and fold the winners with the arg-max rule on (ucb, global index)
+  // and the statuses with min; base = wbase (uploaded before the local half) or none.  Result -> ovals2.
   int exchange_winners(int nseg, bool with_base) {
     RcclApi& R = RcclApi::get();
-    int rc;
     hipStream_t s = st();
-    const int world = ctx->world;
-    if ((rc = ensure(gath, (size_t)world * nseg * 4 * 8))) return rc;
-    if ((rc = ensure(ovals2, (size_t)(nseg * 4 + 1) * 8))) return rc;
-    const int64_t* base_dev = with_base ? as<int64_t>(wbase) : nullptr;
-    RCCLCHECK(R.AllGather(ovals.p, gath.p, (size_t)nseg * 4, ncclDouble, ctx->comm, s));
-    launch_reduce_winners(s, as<double>(gath), base_dev, world, nseg, as<double>(ovals2));
+    const int pd = group_payload_doubles(nseg);
+    RCCLCHECK(R.AllGather(ovals.p, gath.p, (size_t)pd, ncclDouble, ctx->comm, s));
+    launch_reduce_winners(s, as<double>(gath), with_base ? as<int64_t>(wbase) : nullptr, ctx->world, nseg, pd,
+                          as<double>(ovals2));
     return launch_status();
   }
 
-  // one read-back of nseg x (mean, var, ucb, index) [+ the live row count], then the host wait
-  int finish_best(const DevBuf& src, int nseg, bool with_count, int64_t* idx, double* mean, double* var,
-                  double* ucb) {
+  // one read-back of nseg x (mean, var, ucb, index) [+ the live row count] [+ the group's verdict], then the host
+  // wait.  mode 0: winners only; 1: + live count -> last_count[0]; 2: a folded group payload -- *verdict_out: the worst
+  // status of the group (*who: the rank it came from); the outputs are only written when that is GPSO_OK
+  int finish_best(const DevBuf& src, int nseg, int mode, int64_t* idx, double* mean, double* var, double* ucb,
+                  int* verdict_out = nullptr, int64_t* who = nullptr) {
     hipStream_t s = st();
-    const size_t doubles = (size_t)nseg * 4 + (with_count ? 1 : 0);
+    const size_t doubles = (size_t)nseg * 4 + (mode == 2 ? 2 : mode);
     double* vals = ctx->pinned_scratch(doubles);
     if (!vals) return ctx->fail(GPSO_E_OOM, "pinned host scratch");
     HIPCHECK(hipMemcpyAsync(vals, src.p, doubles * 8, hipMemcpyDeviceToHost, s));
@@ -1086,16 +1178,32 @@ struct EngineT : Engine {
     int rc;
     if ((rc = launch_status())) return rc;
     collect_tile_ms();
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ms[1] = ms;
+    if (mode == 2) {
+      const int verdict = (int)vals[4 * nseg + 1];
+      if (verdict_out) *verdict_out = verdict;
+      if (who) std::memcpy(who, &vals[4 * nseg], 8);
+      if (verdict != GPSO_OK) return GPSO_OK;  // (outputs untouched; the caller turns the verdict into its return value)
+    }
     for (int i = 0; i < nseg; ++i) {
       if (idx) std::memcpy(&idx[i], &vals[4 * i + 3], 8);
       if (mean) mean[i] = vals[4 * i];
       if (var) var[i] = vals[4 * i + 1];
       if (ucb) ucb[i] = vals[4 * i + 2];
     }
-    if (with_count) std::memcpy(&ctx->last_count[0], &vals[4 * nseg], 8);
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ms[1] = ms;
+    if (mode == 1) std::memcpy(&ctx->last_count[0], &vals[4 * nseg], 8);
     return GPSO_OK;
+  }
+  // the group's verdict as this rank's return value: its own failure keeps its own message
+  int group_verdict(int verdict, int64_t who, int local_rc, const std::string& local_msg, const char* call) {
+    if (verdict == GPSO_OK) return GPSO_OK;
+    if (local_rc != GPSO_OK) {
+      ctx->err = local_msg;
+      return local_rc;
+    }
+    return ctx->fail(verdict, "%s: rank %lld of the group failed its half of the call with status %d (its message is "
+                     "on that rank); every rank returns together", call, (long long)who, verdict);
   }
 
   int best_ucb(const void* xs, int xs_dtype, int xs_mem, int64_t m, const int64_t* seg_off, int nseg,
@@ -1107,7 +1215,7 @@ struct EngineT : Engine {
     const void* dev = nullptr;
     if (m > 0 && (rc = stage_leaves(xs, xs_dtype, xs_mem, m, &dev))) return rc;
     if ((rc = enqueue_best_leaves(dev, xs_dtype, m, seg_off, nseg, varsigma))) return rc;
-    return finish_best(ovals, nseg, false, idx, mean, var, ucb);
+    return finish_best(ovals, nseg, 0, idx, mean, var, ucb);
   }
 
   int need_comm() {
@@ -1123,40 +1231,24 @@ struct EngineT : Engine {
                        double* var, double* ucb) override {
     int rc = need_comm();
     if (rc) return rc;
-    if ((rc = check_predict_args(xs, xs_dtype, xs_mem, m_local))) return rc;
+    // (arguments every rank passes alike fail alike: no collective has started yet)
     if (nseg < 1) return ctx->fail(GPSO_E_ARG, "nseg must be >= 1");
-    int64_t lo, hi;
-    shard_range(m_global, ctx->rank, ctx->world, &lo, &hi);
-    if (m_local != hi - lo)
-      return ctx->fail(GPSO_E_ARG, "rank %d of %d must pass rows [%lld, %lld) of the %lld leaves (gpso_shard_range), got %lld rows",
-                       ctx->rank, ctx->world, (long long)lo, (long long)hi, (long long)m_global, (long long)m_local);
-    std::vector<int64_t> so(nseg + 1);
-    if (seg_off) {
-      for (int i = 0; i <= nseg; ++i) so[i] = seg_off[i];
-      if (so[0] != 0 || so[nseg] != m_global) return ctx->fail(GPSO_E_ARG, "seg_off must start at 0 and end at the global M");
-      for (int i = 0; i < nseg; ++i)
-        if (so[i + 1] < so[i]) return ctx->fail(GPSO_E_ARG, "seg_off must be non-decreasing");
-    } else {
-      if (nseg != 1) return ctx->fail(GPSO_E_ARG, "seg_off == NULL requires nseg == 1");
-      so[0] = 0;
-      so[1] = m_global;
-    }
-    // local segmentation: the part of every global segment inside [lo, hi); and for EVERY rank r the
-    // offset of its local piece of segment s inside the global segment (added to its winner's index)
-    std::vector<int64_t> sl(nseg + 1), base((size_t)ctx->world * nseg);
-    for (int i = 0; i <= nseg; ++i) sl[i] = std::min(std::max(so[i], lo), hi) - lo;
-    for (int r = 0; r < ctx->world; ++r) {
-      int64_t rlo, rhi;
-      shard_range(m_global, r, ctx->world, &rlo, &rhi);
-      for (int i = 0; i < nseg; ++i) base[(size_t)r * nseg + i] = std::min(std::max(so[i], rlo), rhi) - so[i];
-    }
+    if (m_global < 0) return ctx->fail(GPSO_E_ARG, "negative global leaf count");
+    std::vector<int64_t> so, base;
+    if ((rc = global_segments(m_global, seg_off, nseg, so))) return rc;
+    if ((rc = ensure_group_buffers(nseg, ctx->world))) return rc;
     HIPCHECK(hipEventRecord(ctx->ev[2], st()));
-    if ((rc = upload_base(base))) return rc;
-    const void* dev = nullptr;
-    if (m_local > 0 && (rc = stage_leaves(xs, xs_dtype, xs_mem, m_local, &dev))) return rc;
-    if ((rc = enqueue_best_leaves(dev, xs_dtype, m_local, sl.data(), nseg, varsigma))) return rc;
+    segment_bases(m_global, so, nseg, ctx->world, base);
+    int local = upload_base(base);
+    if (local == GPSO_OK)
+      local = sharded_local(ctx->rank, ctx->world, xs, xs_dtype, xs_mem, m_local, m_global, seg_off, nseg, varsigma);
+    const std::string local_msg = ctx->err;
+    if ((rc = publish_local(nseg, local))) return rc;
     if ((rc = exchange_winners(nseg, true))) return rc;
-    return finish_best(ovals2, nseg, false, idx, mean, var, ucb);
+    int64_t who = -1;
+    int verdict = GPSO_OK;
+    if ((rc = finish_best(ovals2, nseg, 2, idx, mean, var, ucb, &verdict, &who))) return rc;
+    return group_verdict(verdict, who, local, local_msg, "gpso_best_ucb_sharded");
   }
 
   // ------------------------------------------------------------------------------------------
@@ -1203,7 +1295,7 @@ struct EngineT : Engine {
     if (rc) return rc;
     HIPCHECK(hipEventRecord(ctx->ev[2], st()));
     if ((rc = enqueue_best_grow(bounds, nseg, depth, 0, gpso_grow_rows(depth), varsigma))) return rc;
-    return finish_best(ovals, nseg, true, idx, mean, var, ucb);
+    return finish_best(ovals, nseg, 1, idx, mean, var, ucb);
   }
 
   // The same on a group: every rank generates and scores the reference rows shard_range(rows, rank, world)
@@ -1213,22 +1305,104 @@ struct EngineT : Engine {
                             double* mean, double* var, double* ucb) override {
     int rc = need_comm();
     if (rc) return rc;
-    if (!have_post) return ctx->fail(GPSO_E_STATE, "no posterior resident: call gpso_broadcast_posterior first");
-    if ((rc = precision_gate())) return rc;
+    if (nseg < 1) return ctx->fail(GPSO_E_ARG, "nseg must be >= 1");
+    if (depth < 0 || depth > 16) return ctx->fail(GPSO_E_ARG, "depth %d outside [0, 16]", depth);
+    if ((rc = ensure_group_buffers(nseg, ctx->world))) return rc;
     HIPCHECK(hipEventRecord(ctx->ev[2], st()));
-    int64_t lo, hi;
-    shard_range(gpso_grow_rows(depth), ctx->rank, ctx->world, &lo, &hi);
-    if ((rc = enqueue_best_grow(bounds, nseg, depth, lo, hi, varsigma))) return rc;
+    const int local = sharded_local_grow(ctx->rank, ctx->world, bounds, nseg, depth, varsigma);
+    const std::string local_msg = ctx->err;
+    if ((rc = publish_local(nseg, local))) return rc;
     if ((rc = exchange_winners(nseg, false))) return rc;
-    if ((rc = finish_best(ovals2, nseg, false, idx, mean, var, ucb))) return rc;
+    int64_t who = -1;
+    int verdict = GPSO_OK;
+    if ((rc = finish_best(ovals2, nseg, 2, idx, mean, var, ucb, &verdict, &who))) return rc;
     ctx->last_count[0] = -1;  // (the local live count stays on the device: no second read-back)
+    return group_verdict(verdict, who, local, local_msg, "gpso_best_ucb_grow_sharded");
+  }
+
+  // ---- the two halves on their own, for an arbitrary (rank, world) and without a communicator: what a group of
+  // `world` ranks computes can be replayed on ONE device, the all-gather replaced by the caller's concatenation ----
+  int shard_winners(int rank, int world, const void* xs, int xs_dtype, int xs_mem, int64_t m_local, int64_t m_global,
+                    const int64_t* seg_off, int nseg, double varsigma, double* payload) override {
+    if (!payload) return ctx->fail(GPSO_E_ARG, "payload must not be NULL");
+    if (world < 1 || rank < 0 || rank >= world) return ctx->fail(GPSO_E_ARG, "rank %d / world %d", rank, world);
+    if (nseg < 1) return ctx->fail(GPSO_E_ARG, "nseg must be >= 1");
+    int rc = ensure_group_buffers(nseg, world);
+    if (rc) return rc;
+    HIPCHECK(hipEventRecord(ctx->ev[2], st()));
+    const int local = sharded_local(rank, world, xs, xs_dtype, xs_mem, m_local, m_global, seg_off, nseg, varsigma);
+    return payload_out(nseg, local, payload);
+  }
+  int shard_winners_grow(int rank, int world, const double* bounds, int nseg, int depth, double varsigma,
+                         double* payload) override {
+    if (!payload) return ctx->fail(GPSO_E_ARG, "payload must not be NULL");
+    if (world < 1 || rank < 0 || rank >= world) return ctx->fail(GPSO_E_ARG, "rank %d / world %d", rank, world);
+    if (nseg < 1) return ctx->fail(GPSO_E_ARG, "nseg must be >= 1");
+    int rc = ensure_group_buffers(nseg, world);
+    if (rc) return rc;
+    HIPCHECK(hipEventRecord(ctx->ev[2], st()));
+    const int local = sharded_local_grow(rank, world, bounds, nseg, depth, varsigma);
+    return payload_out(nseg, local, payload);
+  }
+  int payload_out(int nseg, int local, double* payload) {
+    const std::string local_msg = ctx->err;
+    int rc = publish_local(nseg, local);
+    if (rc) return rc;
+    const size_t pd = (size_t)group_payload_doubles(nseg);
+    HIPCHECK(hipMemcpyAsync(payload, ovals.p, pd * 8, hipMemcpyDeviceToHost, st()));
+    HIPCHECK(hipStreamSynchronize(st()));
+    collect_tile_ms();
+    ctx->err = local_msg;
+    return local;  // (the payload carries the same status in its last slot)
+  }
+  // gathered [world][group_payload_doubles(nseg)] (host, rank order) -> the group's result.  m_global >= 0: payloads
+  // of gpso_shard_winners (indices relative to local segment pieces: the bases are added); < 0: of
+  // gpso_shard_winners_grow (global reference row indices)
+  int fold_winners(const double* gathered, int world, int64_t m_global, const int64_t* seg_off, int nseg, int64_t* idx,
+                   double* mean, double* var, double* ucb) override {
+    if (!gathered) return ctx->fail(GPSO_E_ARG, "gathered must not be NULL");
+    if (world < 1 || nseg < 1) return ctx->fail(GPSO_E_ARG, "world %d / nseg %d", world, nseg);
+    int rc = ensure_group_buffers(nseg, world);
+    if (rc) return rc;
+    hipStream_t s = st();
+    HIPCHECK(hipEventRecord(ctx->ev[2], s));
+    const bool with_base = m_global >= 0;
+    if (with_base) {
+      std::vector<int64_t> so, base;
+      if ((rc = global_segments(m_global, seg_off, nseg, so))) return rc;
+      segment_bases(m_global, so, nseg, world, base);
+      if ((rc = upload_base(base))) return rc;
+    }
+    const int pd = group_payload_doubles(nseg);
+    HIPCHECK(hipMemcpyAsync(gath.p, gathered, (size_t)world * pd * 8, hipMemcpyHostToDevice, s));
+    launch_reduce_winners(s, as<double>(gath), with_base ? as<int64_t>(wbase) : nullptr, world, nseg, pd,
+                          as<double>(ovals2));
+    if ((rc = launch_status())) return rc;
+    int64_t who = -1;
+    int verdict = GPSO_OK;
+    if ((rc = finish_best(ovals2, nseg, 2, idx, mean, var, ucb, &verdict, &who))) return rc;
+    if (verdict != GPSO_OK)
+      return ctx->fail(verdict, "gpso_fold_winners: the payload of rank %lld carries status %d", (long long)who, verdict);
     return GPSO_OK;
   }
 
-  // Make the posterior resident on `root` resident on every rank of the group: a 32-byte header (shape
-  // and arithmetic options, checked on every rank and agreed with an all-reduce so that either all ranks
-  // go on or all return), then one RCCL broadcast per predict buffer (gpso_posterior_buffers) straight
-  // out of / into the library's device memory, on the context's stream.
+  // Make the posterior resident on `root` resident on every rank of the group: a 48-byte header (shape,
+  // arithmetic options and the root's status), checked on every rank and agreed with an all-reduce(min) so that
+  // either all ranks go on or all return the same code; the receivers' allocation is agreed the same way; then
+  // one RCCL broadcast per predict buffer (gpso_posterior_buffers) straight out of / into the library's device
+  // memory, on the context's stream.  A posterior that fails the precision self-test on the root is NOT sent:
+  // every rank returns GPSO_E_PRECISION (the root is the only rank that can test it -- it holds the targets).
+  int agree_min(int64_t* hd_slot, int64_t* host_slot, int64_t mine, int64_t* agreed) {
+    RcclApi& R = RcclApi::get();
+    hipStream_t s = st();
+    *host_slot = mine;
+    HIPCHECK(hipMemcpyAsync(hd_slot, host_slot, 8, hipMemcpyHostToDevice, s));
+    RCCLCHECK(R.AllReduce(hd_slot, hd_slot, 1, ncclInt64, ncclMin, ctx->comm, s));
+    HIPCHECK(hipMemcpyAsync(host_slot, hd_slot, 8, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    *agreed = *host_slot;
+    return GPSO_OK;
+  }
   int broadcast_posterior(int root) override {
     int rc = need_comm();
     if (rc) return rc;
@@ -1240,47 +1414,72 @@ struct EngineT : Engine {
     int64_t* hd = as<int64_t>(bhdr);
     int64_t* host = reinterpret_cast<int64_t*>(ctx->pinned_scratch(8));
     if (!host) return ctx->fail(GPSO_E_OOM, "pinned host scratch");
-    int64_t ok = 1;
+    int64_t mine = GPSO_OK;  // this rank's status of the call so far
+    std::string why;
     if (is_root) {
       // still take part in the collectives below when something is wrong: every rank must leave together
-      if (!have_post || decide_generation() != GPSO_OK) ok = 0;
-      else if (check && st_have && have_data && selftest_with_fallback() != GPSO_OK) ok = 0;  // settles GPSO_MATH_AUTO
+      if (!have_post) {
+        mine = ctx->fail(GPSO_E_STATE, "gpso_broadcast_posterior: the root has no posterior resident");
+      } else if ((rc = decide_generation()) != GPSO_OK) {
+        mine = rc;
+      } else if (check && st_have && have_data) {
+        if ((rc = selftest_with_fallback()) != GPSO_OK) mine = rc;  // (settles GPSO_MATH_AUTO)
+        else if (!st_pass()) mine = precision_gate();                // GPSO_E_PRECISION with the measured errors
+      }
+      why = ctx->err;
     }
     // the predict math the posterior travels with (under GPSO_MATH_AUTO the root's self-test has chosen)
     const int64_t my_opts = (int64_t)(math_native_fallback ? GPSO_MATH_NATIVE : math) | ((int64_t)ctx->dtype << 16);
     if (is_root) {
-      host[0] = n; host[1] = d; host[2] = my_opts; host[3] = ok;
+      host[0] = n; host[1] = d; host[2] = my_opts; host[3] = mine;
       HIPCHECK(hipMemcpyAsync(hd, host, 48, hipMemcpyHostToDevice, s));
     }
     RCCLCHECK(R.Broadcast(hd, hd, 48, ncclChar, root, ctx->comm, s));
     HIPCHECK(hipMemcpyAsync(host, hd, 48, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
-    const int64_t rn = host[0], rd = host[1], ropts = host[2];
-    ok = host[3];
-    const char* why = ok ? nullptr : "the root has no usable posterior resident";
-    if (ok && !is_root) {
+    const int64_t rn = host[0], rd = host[1], ropts = host[2], root_status = host[3];
+    if (!is_root && root_status == GPSO_OK) {
       const int64_t rmath = ropts & 0xffff, rdtype = ropts >> 16;
       if (rdtype == (int64_t)ctx->dtype && math_auto && (rmath == math || rmath == GPSO_MATH_NATIVE)) {
         math_native_fallback = rmath == GPSO_MATH_NATIVE && math != GPSO_MATH_NATIVE;  // the root's choice
       } else if (rdtype != (int64_t)ctx->dtype || rmath != math) {
-        ok = 0;
-        why = "dtype / predict math options differ from the root's";
+        mine = ctx->fail(GPSO_E_ARG, "gpso_broadcast_posterior: dtype / predict math options differ from the root's");
+        why = ctx->err;
       }
     }
-    // agree: min over the ranks of `ok` (slot 4 of the header block)
-    host[4] = ok;
-    HIPCHECK(hipMemcpyAsync(hd + 4, host + 4, 8, hipMemcpyHostToDevice, s));
-    RCCLCHECK(R.AllReduce(hd + 4, hd + 4, 1, ncclInt64, ncclMin, ctx->comm, s));
-    HIPCHECK(hipMemcpyAsync(host + 4, hd + 4, 8, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
-    if (host[4] == 0)
-      return ctx->fail(why && !is_root ? GPSO_E_ARG : GPSO_E_STATE, "gpso_broadcast_posterior: %s",
-                       why ? why : "another rank of the group cannot take the root's posterior");
-    if (!is_root && (rc = alloc_posterior(rn, (int)rd))) return rc;
+    // agree: min over the ranks (slot 4 of the header block); the root's status counts on every rank
+    int64_t agreed = 0;
+    if ((rc = agree_min(hd + 4, host + 4, std::min<int64_t>(mine, root_status), &agreed))) return rc;
+    if (agreed != GPSO_OK) {
+      if (mine != GPSO_OK) {
+        ctx->err = why;
+        return (int)mine;
+      }
+      return ctx->fail((int)agreed, "gpso_broadcast_posterior: %s (status %d); every rank returns together",
+                       root_status != GPSO_OK ? "the root cannot send its posterior" : "another rank of the group cannot take the root's posterior",
+                       (int)agreed);
+    }
+    // receivers allocate; agreed again, so that an allocation failure leaves no rank inside the broadcasts
+    mine = is_root ? GPSO_OK : alloc_posterior(rn, (int)rd);
+    why = ctx->err;
     void* ptrs[8];
     int64_t nb[8];
-    const int cnt = posterior_buffers(ptrs, nb, 8);
-    if (cnt < 0) return cnt;
+    int cnt = 0;
+    if (mine == GPSO_OK) {
+      cnt = posterior_buffers(ptrs, nb, 8);
+      if (cnt < 0) {
+        mine = cnt;
+        why = ctx->err;
+      }
+    }
+    if ((rc = agree_min(hd + 5, host + 5, mine, &agreed))) return rc;
+    if (agreed != GPSO_OK) {
+      if (mine != GPSO_OK) {
+        ctx->err = why;
+        return (int)mine;
+      }
+      return ctx->fail((int)agreed, "gpso_broadcast_posterior: a rank of the group could not allocate the posterior (status %d)", (int)agreed);
+    }
     for (int i = 0; i < cnt; ++i) RCCLCHECK(R.Broadcast(ptrs[i], ptrs[i], (size_t)nb[i], ncclChar, root, ctx->comm, s));
     if (!is_root) return adopt_posterior();  // (synchronises the stream)
     HIPCHECK(ctx->wait(s));
@@ -1342,7 +1541,7 @@ struct EngineT : Engine {
       if (rc) return rc;
       if (check && st_have && have_data && (rc = selftest_with_fallback())) return rc;  // settles GPSO_MATH_AUTO
       double* flag = ctx->pinned_scratch(256) + 120;  // (a slot neither the read-backs nor set_theta use)
-      *flag = (gen_double() ? 0.0 : 1.0) + (math_native_fallback ? 2.0 : 0.0);
+      *flag = (gen_double() ? 0.0 : 1.0) + (math_native_fallback ? 2.0 : 0.0) + ((bf16_usable() && linv_b_valid) ? 4.0 : 0.0);
       HIPCHECK(hipMemcpyAsync(as<double>(hyper) + 7, flag, 8, hipMemcpyHostToDevice, st()));
       HIPCHECK(hipStreamSynchronize(st()));  // callers copy these buffers on streams of their own
     }
@@ -1354,6 +1553,9 @@ struct EngineT : Engine {
     ptrs[k] = xs_p64.p;  nbytes[k++] = (int64_t)(npad * dp * 8);
     ptrs[k] = xnorm64.p; nbytes[k++] = (int64_t)(npad * 8);
     ptrs[k] = alpha.p;   nbytes[k++] = (int64_t)(npad * s);
+    // the bf16 pieces of L^-1 travel when the mode is on -- a sender whose pieces were never built (a posterior it
+    // adopted itself, math switched afterwards) still sends the buffer, so that both sides of a broadcast list the
+    // same buffers, and says so in the hyper block (bit 4 of slot 7 clear): the receivers then run the f32 kernel
     if (bf16_usable()) {
       int rc = ensure(linv_b, (size_t)nsplit() * npad * npad * 2);
       if (rc) return rc;
@@ -1389,11 +1591,10 @@ struct EngineT : Engine {
     chol_valid = have_kinv = false;
     small_tile_rows = 8;           // linv_p came from elsewhere
     st_done = st_have = false;     // the fitting rank ran the self-test; no targets here
-    linv_b_valid = bf16_usable();  // the bf16 pieces travel with the posterior when the mode is on
-    // generation arithmetic: the sender's choice (its self-test ruled), unless this context insists
+    // generation arithmetic and predict math: the sender's choice (its self-test ruled), unless this context insists
     const int sender = (int)h[7];
     math_native_fallback = math_auto && (sender & 2) != 0;
-    linv_b_valid = bf16_usable();
+    linv_b_valid = bf16_usable() && (sender & 4) != 0;  // the bf16 pieces the sender actually built travel with it
     gen_eff32 = kFloatPredict && (gen_mode == GPSO_GEN_F32 || (gen_mode == GPSO_GEN_AUTO && (sender & 1) != 0));
     gen_decided = true;
     gen32_inputs_ok = false;
@@ -1465,7 +1666,7 @@ void gpso_destroy(gpso_ctx* ctx) {
   if (!ctx) return;
   DeviceGuard guard(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->comm) (void)RcclApi::get().CommDestroy(ctx->comm);
+  if (ctx->comm && !ctx->comm_aborted) (void)RcclApi::get().CommDestroy(ctx->comm);
   delete ctx->eng;
   for (auto& ev : ctx->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -1663,11 +1864,12 @@ int gpso_comm_init(gpso_ctx* ctx, int rank, int world, const void* unique_id) {
 
 int gpso_comm_destroy(gpso_ctx* ctx) {
   ENTER();
-  if (ctx->comm) {
+  if (ctx->comm && !ctx->comm_aborted) {
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     RCCLCHECK(RcclApi::get().CommDestroy(ctx->comm));
   }
   ctx->comm = nullptr;
+  ctx->comm_aborted = false;
   ctx->rank = 0;
   ctx->world = 1;
   return GPSO_OK;
@@ -1706,11 +1908,44 @@ int gpso_best_ucb_grow_sharded(gpso_ctx* ctx, const double* bounds, int nseg, in
   return ctx->eng->best_ucb_grow_sharded(bounds, nseg, depth, varsigma, idx, mean, var, ucb);
 }
 
+int gpso_shard_winners(gpso_ctx* ctx, int rank, int world, const void* xs, int xs_dtype, int xs_mem,
+                       int64_t m_local, int64_t m_global, const int64_t* seg_off, int nseg, double varsigma,
+                       double* payload) {
+  ENTER();
+  return ctx->eng->shard_winners(rank, world, xs, xs_dtype, xs_mem, m_local, m_global, seg_off, nseg, varsigma, payload);
+}
+
+int gpso_shard_winners_grow(gpso_ctx* ctx, int rank, int world, const double* bounds, int nseg, int depth,
+                            double varsigma, double* payload) {
+  ENTER();
+  return ctx->eng->shard_winners_grow(rank, world, bounds, nseg, depth, varsigma, payload);
+}
+
+int gpso_fold_winners(gpso_ctx* ctx, const double* gathered, int world, int64_t m_global, const int64_t* seg_off,
+                      int nseg, int64_t* idx, double* mean, double* var, double* ucb) {
+  ENTER();
+  return ctx->eng->fold_winners(gathered, world, m_global, seg_off, nseg, idx, mean, var, ucb);
+}
+
+int gpso_group_payload_doubles(int nseg) { return nseg < 0 ? 0 : gpso::group_payload_doubles(nseg); }
+
+// Callable from ANOTHER thread than the one blocked inside a group call of this context: it only touches the
+// communicator (ncclCommAbort makes the collective kernels in flight exit, so the blocked call returns an error).
+int gpso_comm_abort(gpso_ctx* ctx) {
+  if (!ctx) return GPSO_E_ARG;
+  ncclComm_t c = ctx->comm;
+  if (c == nullptr) return GPSO_OK;
+  RcclApi& R = RcclApi::get();
+  if (!R.ok || R.CommAbort == nullptr) return GPSO_E_RCCL;
+  ctx->comm_aborted = true;
+  return R.CommAbort(c) == ncclSuccess ? GPSO_OK : GPSO_E_RCCL;
+}
+
 int64_t gpso_last_count(gpso_ctx* ctx, int what) {
   if (!ctx || what < 0 || what > 1) return -1;
   return ctx->last_count[what];
 }
 
-const char* gpso_version(void) { return "gpso-hip 0.2.0 (gfx950)"; }
+const char* gpso_version(void) { return "gpso-hip 0.3.0 (gfx950)"; }
 
 }  // extern "C"

@@ -58,9 +58,9 @@ void launch_leaf_finalize(hipStream_t st, const double* part_var, const double* 
                           double* mean, double* var, double* ucb);
 void launch_seg_argmax(hipStream_t st, const double* mean, const double* var, const double* ucb,
                        const int64_t* seg_off_dev, int nseg, int nblk, void* partial_dev,
-                       double* out_vals_dev /* [nseg*4]: mean, var, ucb, bit-cast int64 index */);
-// arg-max over a de-duplicated, keyed leaf list (grow.hip: launch_grow_unique); out_vals_dev[nseg*4 + 1]:
-// per segment mean, var, ucb, bit-cast reference row index; then the bit-cast live row count
+                       double* out_vals_dev /* [nseg*4 + 2]: per segment mean, var, ucb, bit-cast int64 index; spare; 0.0 (status slot) */);
+// arg-max over a de-duplicated, keyed leaf list (grow.hip: launch_grow_unique); out_vals_dev[nseg*4 + 2]:
+// per segment mean, var, ucb, bit-cast reference row index; then the bit-cast live row count; then 0.0 (status slot)
 void launch_keyed_argmax(hipStream_t st, const double* mean, const double* var, const double* ucb,
                          const int64_t* key_dev, int64_t rows, int64_t uniq, int nseg, const int64_t* live_dev,
                          int nblk, void* partial_dev, int64_t* pos_dev, double* out_vals_dev);
@@ -208,9 +208,12 @@ int64_t grow_unique_before(int64_t row);
 void launch_grow_unique(hipStream_t st, const double* bounds_dev, int nseg, int d, int depth, int64_t row_lo,
                         int64_t row_hi, double* out_dev, int64_t* key_dev, int64_t* count_dev);
 // winners of several ranks -> the global winner per segment, np.argmax order on (ucb, global index):
-// gathered[world][nseg][4] = (mean, var, ucb, bit-cast index), base[world][nseg] (nullable) is added to a
-// rank's indices first; out[nseg][4]
+// gathered[world][stride], a rank's payload = nseg x (mean, var, ucb, bit-cast index) [, spare, status: stride ==
+// kGroupPayload(nseg)]; base[world][nseg] (nullable) is added to a rank's indices first; out[nseg][4] [, bit-cast rank
+// of the worst status, worst status]
 void launch_reduce_winners(hipStream_t st, const double* gathered, const int64_t* base, int world, int nseg,
-                           double* out);
+                           int stride, double* out);
+// doubles of one rank's group payload: the winners, the live row count of a growth call (bit-cast), the status
+inline int group_payload_doubles(int nseg) { return nseg * 4 + 2; }
 
 }  // namespace gpso

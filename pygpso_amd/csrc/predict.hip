@@ -596,6 +596,9 @@ __device__ __forceinline__ void leaf_bf16_apply(int q, int q_diag0, int lane, co
   }
 }
 
+#ifdef GPSO_PROBE_DUMP_MACC
+__device__ float* gpso_probe_macc = nullptr;
+#endif
 template <int NS, typename TG, int KERNEL>
 __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     const u32x4* __restrict__ linv_b, const TG* __restrict__ xs_p, const TG* __restrict__ xnorm,
@@ -728,6 +731,13 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     GPSO_BSTAMP(q, 5);
   }
   if (ahead) __syncthreads();
+#ifdef GPSO_PROBE_DUMP_MACC  // tools/micro/packed_mean_probe.hip: every lane's mean accumulators, before the reduction
+  if (gpso_probe_macc != nullptr) {
+    float* o = gpso_probe_macc + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 512 + tid) * 2;
+    o[0] = macc[0];
+    o[1] = macc[1];
+  }
+#endif
 
 #pragma unroll
   for (int t = 0; t < CT; ++t) {
@@ -887,7 +897,7 @@ __global__ __launch_bounds__(256) void seg_argmax_stage2(const Best* __restrict_
                                                          const double* __restrict__ mean,
                                                          const double* __restrict__ var,
                                                          const double* __restrict__ ucb,
-                                                         double* __restrict__ out_vals /*[nseg*4]*/) {
+                                                         double* __restrict__ out_vals /*[nseg*4 + 2]*/) {
   __shared__ Best sh[4];
   const int seg = blockIdx.x;
   Best mine{0.0, -1};
@@ -908,6 +918,7 @@ __global__ __launch_bounds__(256) void seg_argmax_stage2(const Best* __restrict_
       out_vals[seg * 4 + 2] = ucb[mine.i];
       out_vals[seg * 4 + 3] = __builtin_bit_cast(double, (int64_t)(mine.i - seg_off[seg]));
     }
+    if (seg == 0) out_vals[gridDim.x * 4 + 1] = 0.0;  // status slot of a group payload: this rank's half succeeded
   }
 }
 
@@ -981,7 +992,7 @@ __global__ __launch_bounds__(256) void keyed_argmax_stage2(const Best* __restric
                                                            const double* __restrict__ var,
                                                            const double* __restrict__ ucb,
                                                            const int64_t* __restrict__ live, int nseg,
-                                                           double* __restrict__ out_vals /*[nseg*4 + 1]*/) {
+                                                           double* __restrict__ out_vals /*[nseg*4 + 2]*/) {
   __shared__ Best sh[4];
   const int seg = blockIdx.x;
   Best mine{0.0, -1};
@@ -1003,19 +1014,39 @@ __global__ __launch_bounds__(256) void keyed_argmax_stage2(const Best* __restric
       out_vals[seg * 4 + 2] = ucb[at];
       out_vals[seg * 4 + 3] = __builtin_bit_cast(double, (int64_t)(mine.i - (int64_t)seg * rows));
     }
-    if (seg == 0) out_vals[nseg * 4] = __builtin_bit_cast(double, *live);
+    if (seg == 0) {
+      out_vals[nseg * 4] = __builtin_bit_cast(double, *live);
+      out_vals[nseg * 4 + 1] = 0.0;  // status slot of a group payload
+    }
   }
 }
 
-// multi-GPU: one thread per segment folds the ranks' winners in rank order with the same rule
+// multi-GPU: one thread per segment folds the ranks' winners in rank order with the same rule.  A rank's payload is
+// `stride` doubles: nseg x (mean, var, ucb, bit-cast index), then -- stride == nseg * 4 + 2 -- a spare slot and the
+// rank's STATUS of the call (0 or a negative GPSO_E_* code): the fold also takes the worst status over the ranks
+// (out[nseg * 4 + 1], and the rank it came from bit-cast into out[nseg * 4]), so that every rank of a group returns the
+// same verdict and none is left inside a collective by a peer that failed locally.
 __global__ void reduce_winners_kernel(const double* __restrict__ gathered, const int64_t* __restrict__ base,
-                                      int world, int nseg, double* __restrict__ out) {
+                                      int world, int nseg, int stride, double* __restrict__ out) {
   const int seg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (seg == 0 && stride >= nseg * 4 + 2) {
+    double worst = 0.0;
+    int64_t who = -1;
+    for (int r = 0; r < world; ++r) {
+      const double st = gathered[(int64_t)r * stride + nseg * 4 + 1];
+      if (!(st >= worst)) {  // more negative, or not a number (a payload that never arrived): a failure
+        worst = (st == st) ? st : -6.0 /* GPSO_E_RCCL */;
+        who = r;
+      }
+    }
+    out[nseg * 4] = __builtin_bit_cast(double, who);
+    out[nseg * 4 + 1] = worst;
+  }
   if (seg >= nseg) return;
   Best best{0.0, -1};
   int from = -1;
   for (int r = 0; r < world; ++r) {
-    const double* row = gathered + ((int64_t)r * nseg + seg) * 4;
+    const double* row = gathered + (int64_t)r * stride + (int64_t)seg * 4;
     int64_t i = __builtin_bit_cast(int64_t, row[3]);
     if (i >= 0 && base != nullptr) i += base[(int64_t)r * nseg + seg];
     const Best c{row[2], i};
@@ -1029,7 +1060,7 @@ __global__ void reduce_winners_kernel(const double* __restrict__ gathered, const
     o[0] = o[1] = o[2] = __builtin_nan("");
     o[3] = __builtin_bit_cast(double, (int64_t)-1);
   } else {
-    const double* row = gathered + ((int64_t)from * nseg + seg) * 4;
+    const double* row = gathered + (int64_t)from * stride + (int64_t)seg * 4;
     o[0] = row[0];
     o[1] = row[1];
     o[2] = row[2];
@@ -1159,9 +1190,9 @@ void launch_keyed_argmax(hipStream_t st, const double* mean, const double* var, 
 }
 
 void launch_reduce_winners(hipStream_t st, const double* gathered, const int64_t* base, int world, int nseg,
-                           double* out) {
+                           int stride, double* out) {
   hipLaunchKernelGGL(reduce_winners_kernel, dim3((unsigned)((nseg + 63) / 64)), dim3(64), 0, st, gathered, base,
-                     world, nseg, out);
+                     world, nseg, stride, out);
 }
 
 void launch_chunk_live(hipStream_t st, const int64_t* live_dev, int64_t chunk, int nchunk, int64_t* out_dev) {

@@ -15,6 +15,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
@@ -50,6 +51,7 @@ struct RcclApi {
     GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
     CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
     CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+    CommAbort = reinterpret_cast<decltype(CommAbort)>(sym("ncclCommAbort"));
     Broadcast = reinterpret_cast<decltype(Broadcast)>(sym("ncclBroadcast"));
     AllGather = reinterpret_cast<decltype(AllGather)>(sym("ncclAllGather"));
     AllReduce = reinterpret_cast<decltype(AllReduce)>(sym("ncclAllReduce"));

@@ -23,9 +23,11 @@ Two ways to form a group:
   * ONE process, several GPUs (``GPRSurrogate(devices=[...])``): ``HipGPEngineGroup`` drives one engine
     per device from its own thread (ctypes releases the GIL; RCCL supports one communicator per thread).
 
-Engines without a native communicator (the CPU test double of tests/) go through ``HostGroup``, the
-same sharding and the same winner rule over a caller-supplied all-gather -- that is what the
-world-size-2 ``gloo`` tests exercise on CPU.
+What a group of N ranks computes can be replayed on ONE device through the two halves of the sharded calls
+(``HipGPEngine.shard_winners`` / ``shard_winners_grow`` / ``fold_winners``: the very kernels and index arithmetic
+of the group calls, the all-gather replaced by a concatenation) -- tests/test_gpu_distributed.py does so for
+world sizes 2, 3 and 8; the host mirror of the protocol used by the world-size-2 ``gloo`` tests on CPU lives
+with the tests (tests/host_group.py).
 """
 from __future__ import annotations
 
@@ -34,7 +36,7 @@ import os
 import socket
 import struct
 import time
-from concurrent.futures import ThreadPoolExecutor
+from concurrent.futures import FIRST_EXCEPTION, ThreadPoolExecutor, wait
 
 import numpy as np
 
@@ -52,34 +54,57 @@ def unique_id():
     return bytes(buf.raw)
 
 
+def _id_token():
+    """What a rank must present to be served the group id: the launcher's run id when there is one
+    (TORCHELASTIC_RUN_ID), so that a stray connection to the port is neither served nor counted."""
+    return (os.environ.get("GPSO_GROUP_TOKEN") or os.environ.get("TORCHELASTIC_RUN_ID") or "gpso").encode()[:64]
+
+
 def exchange_unique_id(rank, world, addr=None, port=None, timeout=120.0, make_id=None):
     """Rank 0 creates the id and serves it to the other ranks over TCP on (addr, port) -- by default
     MASTER_ADDR and MASTER_PORT + 1 of the launcher's environment (the port itself belongs to the
-    launcher's own store)."""
+    launcher's own store).  A client introduces itself with its rank and the group token; rank 0 answers
+    every DISTINCT rank 1..world-1 once and ignores anything else (a port scanner, a duplicate, a retry
+    of a rank already served)."""
     make_id = make_id or unique_id
     if world == 1:
         return make_id()
     addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
     port = int(port if port is not None else int(os.environ.get("MASTER_PORT", "29500")) + 1)
+    token = _id_token()
     if rank == 0:
         uid = make_id()
+        served = set()
+        deadline = time.monotonic() + timeout
         with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             srv.bind((addr, port))
             srv.listen(world)
-            srv.settimeout(timeout)
-            for _ in range(world - 1):
+            while len(served) < world - 1:
+                left = deadline - time.monotonic()
+                if left <= 0:
+                    raise TimeoutError(f"group id exchange: ranks {sorted(set(range(1, world)) - served)} never asked")
+                srv.settimeout(left)
                 conn, _peer = srv.accept()
                 with conn:
-                    conn.sendall(struct.pack("<I", len(uid)) + uid)
+                    try:
+                        conn.settimeout(5.0)
+                        r, n = struct.unpack("<II", _recv_exact(conn, 8))
+                        if n > 64 or _recv_exact(conn, n) != token or not 1 <= r < world:
+                            continue  # not one of ours
+                        conn.sendall(struct.pack("<I", len(uid)) + uid)
+                        served.add(r)  # (a retry of a served rank is answered again: its first answer may have been lost)
+                    except (OSError, ConnectionError, struct.error):
+                        continue
         return uid
     deadline = time.monotonic() + timeout
     while True:
         try:
             with socket.create_connection((addr, port), timeout=5.0) as conn:
+                conn.sendall(struct.pack("<II", int(rank), len(token)) + token)
                 head = _recv_exact(conn, 4)
                 return _recv_exact(conn, struct.unpack("<I", head)[0])
-        except (ConnectionRefusedError, socket.timeout, OSError):
+        except (ConnectionError, socket.timeout, OSError):
             if time.monotonic() > deadline:
                 raise
             time.sleep(0.05)
@@ -103,31 +128,6 @@ def shard_range(m, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-# -- winner rule (host mirror of predict.hip: reduce_winners_kernel) ---------------------------------
-def _better(a, b):
-    """np.argmax order on (ucb, global index): NaN is the maximum, ties go to the lower index."""
-    (ua, ia), (ub, ib) = a, b
-    if ia < 0:
-        return False
-    if ib < 0:
-        return True
-    na, nb = np.isnan(ua), np.isnan(ub)
-    if na != nb:
-        return bool(na)
-    if not na and ua != ub:
-        return bool(ua > ub)
-    return ia < ib
-
-
-def reduce_winners(rows):
-    """rows [world, 4] of (ucb, global idx, mean, var) -> the winning row."""
-    best = None
-    for r in rows:
-        if best is None or _better((r[0], int(r[1])), (best[0], int(best[1]))):
-            best = r
-    return best
-
-
 # -- collective calls: native for HIP engines ---------------------------------------------------------
 def broadcast_posterior(engine, src=0):
     """Make the posterior resident on rank ``src`` resident on every rank of the engine's group."""
@@ -143,53 +143,6 @@ def best_ucb_sharded(engine, local_leaves, m_global, varsigma, seg_off=None):
 
 def best_ucb_grow_sharded(engine, bounds, depth, varsigma):
     return engine.best_ucb_grow_sharded(bounds, depth, varsigma)
-
-
-# -- the same protocol over a caller-supplied transport (engines without a native communicator) -------
-class HostGroup:
-    """Sharding + winner rule on the host for an engine object that has no RCCL communicator of its
-    own (the oracle-backed test double).  ``allgather(a)``: float64 array -> [world, *a.shape] stacked
-    in rank order; ``bcast(obj, src)``: python object from ``src`` to all."""
-
-    def __init__(self, engine, rank, world, allgather, bcast):
-        self.engine, self.rank, self.world = engine, int(rank), int(world)
-        self._allgather, self._bcast = allgather, bcast
-
-    def broadcast_posterior(self, src=0):
-        state = self.engine.export_posterior() if self.rank == src else None
-        state = self._bcast(state, src)
-        if self.rank != src:
-            self.engine.import_posterior(state)
-
-    def _fold(self, mine):
-        """mine [nseg, 4] = (ucb, global idx or -1, mean, var) -> winners [nseg, 4]"""
-        rows = np.asarray(self._allgather(np.ascontiguousarray(mine, dtype=np.float64)))
-        return np.stack([reduce_winners(rows[:, s, :]) for s in range(mine.shape[0])])
-
-    def best_ucb_sharded(self, local_leaves, m_global, varsigma, seg_off=None):
-        lo, hi = shard_range(m_global, self.rank, self.world)
-        assert local_leaves.shape[0] == hi - lo
-        so = np.array([0, m_global], dtype=np.int64) if seg_off is None else np.asarray(seg_off, dtype=np.int64)
-        local = np.clip(so, lo, hi) - lo
-        idx, mean, var, ucb = self.engine.best_ucb(local_leaves, varsigma, local)
-        # index relative to the GLOBAL segment start
-        gidx = np.where(idx >= 0, idx + (np.clip(so[:-1], lo, hi) - so[:-1]), -1).astype(np.float64)
-        w = self._fold(np.stack([ucb, gidx, mean, var], axis=1))
-        return w[:, 1].astype(np.int64), w[:, 2], w[:, 3], w[:, 0]
-
-    def best_ucb_grow_sharded(self, bounds, depth, varsigma):
-        b = np.asarray(bounds, dtype=np.float64)
-        if b.ndim == 2:
-            b = b[None]
-        rows = self.engine.grow_rows(depth)
-        lo, hi = shard_range(rows, self.rank, self.world)
-        grown = self.engine.grow(b, depth)[:, lo:hi, :]  # this rank's reference rows of every box
-        nseg = b.shape[0]
-        flat = grown.reshape(nseg * (hi - lo), b.shape[1])
-        idx, mean, var, ucb = self.engine.best_ucb(flat, varsigma, np.arange(nseg + 1) * (hi - lo))
-        gidx = np.where(idx >= 0, idx + lo, -1).astype(np.float64)
-        w = self._fold(np.stack([ucb, gidx, mean, var], axis=1))
-        return w[:, 1].astype(np.int64), w[:, 2], w[:, 3], w[:, 0]
 
 
 # -- ONE process, several GPUs --------------------------------------------------------------------------
@@ -212,15 +165,30 @@ class HipGPEngineGroup:
         self.dtype_name, self.dtype = self.engines[0].dtype_name, self.engines[0].dtype
         self.device = self.devices[0]
         self._pool = ThreadPoolExecutor(self.world)
+        self.abort_after = 30.0  # seconds a failed group call waits for the other ranks before aborting them
+        self._broken = False     # a communicator was aborted: the group cannot make group calls any more
         uid = (make_id or unique_id)()
         self._all(lambda r, e: e.comm_init(r, self.world, uid))
         self._stale = False  # peers lag behind the root's posterior?
         self.n = self.d = 0
 
     def _all(self, fn):
-        """fn(rank, engine) on every engine, each on its own thread; returns the results in rank order
-        (the first exception, if any, is raised after all threads are back)."""
+        """fn(rank, engine) on every engine, each on its own thread; returns the results in rank order (the
+        first exception, if any, is raised after all threads are back).  The library keeps every rank inside
+        every collective of a call whatever fails locally, so the threads come back together; should one
+        raise while others are still inside a collective after ``abort_after`` seconds (a HIP / RCCL failure
+        in the middle of a call), their communicators are aborted (``gpso_comm_abort``) so that they return
+        an error too instead of waiting for ever."""
         futs = [self._pool.submit(fn, r, e) for r, e in enumerate(self.engines)]
+        done, pending = wait(futs, return_when=FIRST_EXCEPTION)
+        if pending and any(f.exception() is not None for f in done):
+            done2, pending = wait(pending, timeout=self.abort_after)
+            for f in pending:
+                eng = self.engines[futs.index(f)]
+                if hasattr(eng, "comm_abort"):
+                    eng.comm_abort()
+                self._broken = True
+            wait(pending)
         out, err = [], None
         for f in futs:
             try:
@@ -287,8 +255,31 @@ class HipGPEngineGroup:
         self._sync_posterior()
         return self._all(lambda r, e: e.best_ucb_grow_sharded(bounds, depth, varsigma))[0]
 
-    # everything else: the first engine
+    # options: the arithmetic options of a group must match on every rank (the library checks dtype and
+    # predict math at the broadcast; generation, self-test and tolerances would silently differ otherwise)
+    def set_predict_math(self, mode):
+        self._all(lambda r, e: e.set_predict_math(mode))
+        self._stale = True
+
+    def set_generation(self, mode):
+        self._all(lambda r, e: e.set_generation(mode))
+        self._stale = True
+
+    def set_precision_check(self, on):
+        self._all(lambda r, e: e.set_precision_check(on))
+
+    def set_tolerances(self, tol_var=None, tol_mean=None):
+        self._all(lambda r, e: e.set_tolerances(tol_var, tol_mean))
+
+    def synchronize(self):
+        self._all(lambda r, e: e.synchronize())
+
+    # read-only introspection of the fitting rank (first device); anything that would CHANGE one engine only is
+    # not forwarded
+    _ROOT_READS = ("precision_info", "last_ms", "last_count", "padded_n", "get_matrix", "get_vector", "grow",
+                   "grow_rows", "posterior_buffers", "rank")
+
     def __getattr__(self, name):
-        if name in ("engines", "_pool"):
-            raise AttributeError(name)
-        return getattr(self.engines[0], name)
+        if name in HipGPEngineGroup._ROOT_READS:
+            return getattr(self.engines[0], name)
+        raise AttributeError(f"HipGPEngineGroup has no attribute {name!r} (per-engine calls: use .engines[i])")

@@ -347,6 +347,53 @@ class HipGPEngine:
                                                          L.i64ptr(idx), L.dptr(mean), L.dptr(var), L.dptr(ucb)))
         return idx, mean, var, ucb
 
+    def comm_abort(self):
+        """Abort this engine's communicator (``ncclCommAbort``).  The one call that may come from ANOTHER thread
+        than the one blocked inside a group call of this engine: that call then returns an error."""
+        self._lib.gpso_comm_abort(self._h)
+
+    # -- the two halves of the sharded calls, for an arbitrary (rank, world), no communicator needed ----
+    def shard_winners(self, rank, world, local_leaves, m_global, varsigma, seg_off=None):
+        """Rank ``rank``'s local half of ``best_ucb_sharded`` in a group of ``world``: its payload
+        (``gpso_group_payload_doubles(nseg)`` float64: nseg x (mean, var, ucb, bit-cast index), spare, status)."""
+        ptr, dt, mem, m, keep = self._leaf_args(local_leaves)
+        if seg_off is None:
+            nseg, so_ptr = 1, None
+        else:
+            so = np.ascontiguousarray(seg_off, dtype=np.int64)
+            nseg, so_ptr = int(so.shape[0] - 1), L.i64ptr(so)
+        payload = np.empty(self._lib.gpso_group_payload_doubles(nseg), dtype=np.float64)
+        self._check(self._lib.gpso_shard_winners(self._h, int(rank), int(world), ptr, dt, mem, m, int(m_global),
+                                                 so_ptr, nseg, float(varsigma), L.dptr(payload)))
+        return payload
+
+    def shard_winners_grow(self, rank, world, bounds, depth, varsigma):
+        b = L.as_f64(bounds)
+        if b.ndim == 2:
+            b = b[None]
+        nseg = b.shape[0]
+        payload = np.empty(self._lib.gpso_group_payload_doubles(nseg), dtype=np.float64)
+        self._check(self._lib.gpso_shard_winners_grow(self._h, int(rank), int(world), L.dptr(b), nseg, int(depth),
+                                                      float(varsigma), L.dptr(payload)))
+        return payload
+
+    def fold_winners(self, payloads, nseg, m_global=-1, seg_off=None):
+        """Payloads of all ranks (rank order) -> (idx, mean, var, ucb) per segment, as the group call returns
+        them.  ``m_global`` >= 0 (with the global ``seg_off``): payloads of ``shard_winners``; < 0: of
+        ``shard_winners_grow``."""
+        g = np.ascontiguousarray(np.stack([np.asarray(q, dtype=np.float64) for q in payloads]))
+        so_ptr = None
+        if seg_off is not None:
+            so = np.ascontiguousarray(seg_off, dtype=np.int64)
+            so_ptr = L.i64ptr(so)
+        idx = np.empty(nseg, dtype=np.int64)
+        mean = np.empty(nseg, dtype=np.float64)
+        var = np.empty(nseg, dtype=np.float64)
+        ucb = np.empty(nseg, dtype=np.float64)
+        self._check(self._lib.gpso_fold_winners(self._h, L.dptr(g), int(g.shape[0]), int(m_global), so_ptr, int(nseg),
+                                                L.i64ptr(idx), L.dptr(mean), L.dptr(var), L.dptr(ucb)))
+        return idx, mean, var, ucb
+
     # -- introspection -----------------------------------------------------------------------
     def get_matrix(self, which):
         out = np.empty((self.n, self.n), dtype=np.float64)

@@ -1,6 +1,6 @@
 """
 World-size-2 ``gloo`` tests of the multi-GPU path (leaf sharding, posterior hand-off, on-device-growth
-row sharding, multi-segment batches, winner folding) on CPU: ``pygpso_amd.distributed.HostGroup`` --
+row sharding, multi-segment batches, winner folding) on CPU: ``tests.host_group.HostGroup`` --
 the host mirror of what the C-ABI group calls do with RCCL -- over torch.distributed's gloo backend,
 with the oracle-backed test double as the per-rank engine.  (torch lives in the TEST: the package
 itself imports no torch.)
@@ -46,6 +46,7 @@ def _worker(rank, world, port, case, m, out):
     from oracle import gpr, tree
     from pygpso_amd import distributed as D
     from tests.helpers import synthetic_leaves, synthetic_problem
+    from tests.host_group import HostGroup
     from tests.oracle_engine import OracleEngine
 
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
@@ -59,7 +60,7 @@ def _worker(rank, world, port, case, m, out):
         if rank == 0:  # only the root fits
             eng.set_data(X, y)
             eng.fit_eval("Matern52", [0.4], 1.0, 1e-3, 0.0, want_grad=False)
-        grp = D.HostGroup(eng, rank, world, *_gloo_transport(dist))
+        grp = HostGroup(eng, rank, world, *_gloo_transport(dist))
         grp.broadcast_posterior(src=0)
         if case in ("plain", "dup", "segments"):
             leaves = synthetic_leaves(m, 3, seed=1)
@@ -130,7 +131,7 @@ def test_shard_range_of_the_library_matches_the_host_rule():
 
 
 def test_reduce_winners_first_max_and_nan_rules():
-    from pygpso_amd.distributed import reduce_winners
+    from tests.host_group import reduce_winners
 
     rows = np.array([[1.0, 10, 0, 0], [2.0, 700, 0, 0], [2.0, 300, 0, 0], [0.5, 2, 0, 0]])
     assert int(reduce_winners(rows)[1]) == 300  # tie -> lowest global index
@@ -177,6 +178,7 @@ def test_engine_group_threads_with_two_fake_devices():
     from oracle import gpr, tree
     from pygpso_amd import distributed as D
     from tests.helpers import synthetic_leaves, synthetic_problem
+    from tests.host_group import HostGroup
     from tests.oracle_engine import OracleEngine
 
     world = 2
@@ -197,7 +199,7 @@ def test_engine_group_threads_with_two_fake_devices():
         def comm_init(self, rank, nranks, uid):
             assert uid == b"id" * 64
             self.rank, self.world = rank, nranks
-            self._grp = D.HostGroup(self, rank, nranks, self._allgather, self._bcast)
+            self._grp = HostGroup(self, rank, nranks, self._allgather, self._bcast)
 
         def _allgather(self, a):
             slots[("g", self.rank)] = np.array(a)

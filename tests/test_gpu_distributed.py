@@ -1,8 +1,11 @@
 """GPU checks of the multi-GPU plumbing that can run on ONE device: the posterior hand-off protocol on
 real device memory (what a broadcast does, spelled out with device-to-device copies), and the RCCL
 group calls of the C-ABI in a world of size 1 -- per-rank style and the thread-driven
-``HipGPEngineGroup`` behind ``GPRSurrogate(devices=[...])``.  (World sizes > 1: the world-2 ``gloo``
-tests of tests/test_distributed_cpu.py cover the sharding logic; the driver's scaling run covers RCCL.)"""
+``HipGPEngineGroup`` behind ``GPRSurrogate(devices=[...])``.  World sizes > 1 on the DEVICE: the two halves of the
+sharded calls (gpso_shard_winners / gpso_shard_winners_grow / gpso_fold_winners: the group calls' own kernels and
+index arithmetic, the all-gather replaced by a concatenation) replay groups of 2, 3 and 8 ranks on two contexts of
+this one GPU and must reproduce the single-context call bit for bit.  (RCCL itself with more than one rank: the
+driver's scaling run; the host-side choreography: the world-2 ``gloo`` tests of tests/test_distributed_cpu.py.)"""
 import numpy as np
 import pytest
 
@@ -150,3 +153,143 @@ def test_G4_through_the_devices_argument():
     assert isinstance(surr.gpflow_model.engine, HipGPEngineGroup)
     np.testing.assert_almost_equal(G["G4"]["best_coords"], best.normed_coord)
     assert np.around(best.score_mu, decimals=8) == G["G4"]["best_score"]
+
+
+# ---- groups of 2, 3 and 8 ranks replayed on one device -------------------------------------------------------
+def _replay_group(engines, world, Xs, seg):
+    """rank r's half runs on engines[r % len(engines)] (every context holds the same posterior)."""
+    from pygpso_amd.distributed import shard_range
+
+    m = Xs.shape[0]
+    payloads = [engines[r % len(engines)].shard_winners(r, world, Xs[slice(*shard_range(m, r, world))], m, VS, seg)
+                for r in range(world)]
+    nseg = 1 if seg is None else len(seg) - 1
+    return engines[0].fold_winners(payloads, nseg, m, seg), payloads
+
+
+@pytest.mark.parametrize("dtype,math", [("float64", None), ("mixed", "bf16x6"), ("float32", "native")])
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_replayed_group_matches_the_single_context_call(dtype, math, world):
+    """Leaf shards: multi-segment batches with empty segments and segments that straddle shard boundaries, a
+    duplicate of the winner in a later shard, fewer leaves than ranks (empty shards) and a NaN leaf -- the folded
+    result of `world` local halves is the single call's, bit for bit, indices included."""
+    from pygpso_amd import HipGPEngine
+
+    opts = {} if math is None else {"predict_math": math}
+    root = _fitted(dtype, n=512, **opts)
+    peer = HipGPEngine(dtype, **opts)
+    _handoff(root, peer)  # the second context holds the posterior as a broadcast would leave it
+    engines = [root, peer]
+    m = 3001
+    Xs = synthetic_leaves(m, 5, seed=3)
+    i0 = int(root.best_ucb(Xs, VS)[0][0])
+    Xs[(i0 + m // 2) % m] = Xs[i0]  # the winner again, in another shard: the lower index must win
+    segs = [None, np.array([0, 100, 100, 1777, m], dtype=np.int64),
+            np.array([0, 1, 2, m // world, m // world + 1, m - 1, m, m], dtype=np.int64)]
+    for seg in segs:
+        got, _ = _replay_group(engines, world, Xs, seg)
+        exp = root.best_ucb(Xs, VS, seg)
+        assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(got, exp)), (world, seg)
+    few = Xs[: world - 1]  # the last rank's shard is empty
+    got, payloads = _replay_group(engines, world, few, None)
+    assert all(np.array_equal(a, b) for a, b in zip(got, root.best_ucb(few, VS)))
+    assert np.isnan(payloads[-1][2]) and payloads[-1].view(np.int64)[3] == -1 and payloads[-1][-1] == 0.0
+    Xn = Xs[:500].copy()
+    Xn[333] = np.nan  # np.argmax: the first NaN wins
+    got, _ = _replay_group(engines, world, Xn, None)
+    exp = root.best_ucb(Xn, VS)
+    assert int(got[0][0]) == int(exp[0][0]) == 333 and np.isnan(got[3][0])
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("depth", [1, 2, 6, 8])
+def test_replayed_group_growth_matches_the_single_context_call(world, depth):
+    """On-device growth: every rank grows and scores its share of the reference rows of every box (closed-form
+    slot ranges, appended near-duplicates of arbitrary boxes included); keys are global reference rows."""
+    from pygpso_amd import HipGPEngine
+
+    root = _fitted("float64")
+    peer = HipGPEngine("float64")
+    _handoff(root, peer)
+    engines = [root, peer]
+    rng = np.random.default_rng(depth)
+    kids = tree.split_bounds([(0.0, 1.0)] * 5)
+    lo = rng.random((2, 5)) * 0.5
+    arbitrary = np.stack([lo, lo + 0.1 + 0.4 * rng.random((2, 5))], axis=2)  # boxes not cut from the unit cube
+    boxes = np.concatenate([np.array([kids[0], kids[2]]), arbitrary])
+    payloads = [engines[r % 2].shard_winners_grow(r, world, boxes, depth, VS) for r in range(world)]
+    got = root.fold_winners(payloads, len(boxes))
+    exp = root.best_ucb_grow(boxes, depth, VS)
+    assert all(np.array_equal(a, b) for a, b in zip(got, exp))
+
+
+def test_a_failed_half_reaches_every_rank():
+    """Collective safety: a rank whose half fails still produces a payload (no winners, its status in the last
+    slot) and the fold hands that status to every rank -- here a shard of the wrong size on one rank."""
+    from pygpso_amd import _lib as L
+    from pygpso_amd.distributed import shard_range
+
+    eng = _fitted("float64")
+    Xs = synthetic_leaves(1000, 5)
+    good = eng.shard_winners(0, 2, Xs[slice(*shard_range(1000, 0, 2))], 1000, VS)
+    n_pay = good.shape[0]
+    bad = np.empty(n_pay)
+    rc = eng._lib.gpso_shard_winners(eng._h, 1, 2, Xs.ctypes.data, L.F64, L.MEM_HOST, 17, 1000, None, 1, VS,
+                                     bad.ctypes.data_as(L._c_double_p))
+    assert rc == L.E_ARG and bad[-1] == L.E_ARG and bad.view(np.int64)[3] == -1
+    with pytest.raises(ValueError, match="payload of rank 1"):
+        eng.fold_winners([good, bad], 1, 1000)
+    # and the healthy group still folds afterwards
+    ok = eng.shard_winners(1, 2, Xs[slice(*shard_range(1000, 1, 2))], 1000, VS)
+    assert all(np.array_equal(a, b) for a, b in zip(eng.fold_winners([good, ok], 1, 1000), eng.best_ucb(Xs, VS)))
+
+
+def test_precision_failure_is_a_group_verdict():
+    """A float32 posterior at the reference's noise floor fails the self-test on the fitting rank: the broadcast
+    returns GPSO_E_PRECISION (on every rank: the verdict is agreed before any buffer moves) instead of leaving the
+    peers inside a collective, and ``GPRSurrogate(devices=[...], dtype="float32")`` escalates on the device."""
+    from pygpso_amd import HipGPEngine
+    from pygpso_amd import _lib as L
+    from pygpso_amd import distributed as D
+    from pygpso_amd.distributed import HipGPEngineGroup
+    from pygpso_amd.model import HipGPR
+    from pygpso_amd.kernels import Constant, Matern52
+
+    X, y = synthetic_problem(200, 3, seed=0)
+    theta = ("Matern52", [0.12], 3.0, 1.05e-6, float(y.mean()))
+    eng = HipGPEngine("float32", tol_var=1e-7, tol_mean=1e-7)  # (tolerances no float engine meets: forces the verdict)
+    eng.set_data(X, y)
+    eng.fit_eval(*theta, want_grad=False)
+    eng.comm_init(0, 1, D.exchange_unique_id(0, 1))
+    try:
+        with pytest.raises(L.GpsoPrecisionError):
+            eng.broadcast_posterior(0)
+        with pytest.raises(L.GpsoPrecisionError):
+            eng.best_ucb_grow_sharded(np.array([[(0.0, 1.0)] * 3]), 3, VS)
+        with pytest.raises(L.GpsoPrecisionError):
+            eng.best_ucb_sharded(X, X.shape[0], VS)
+    finally:
+        eng.comm_destroy()
+    # the group engine: options reach every rank; the verdict raises out of the group's threads ...
+    grp = HipGPEngineGroup("float32", devices=[0])
+    grp.set_tolerances(1e-7, 1e-7)
+    grp.set_data(X, y)
+    grp.fit_eval(*theta, want_grad=False)
+    with pytest.raises(L.GpsoPrecisionError):
+        grp.best_ucb(X, VS)
+    grp.close()
+    # ... and a model whose engine is a group escalates on the device (mixed, then float64)
+    opts = {"tol_var": 1e-7, "tol_mean": 1e-7}
+    model = HipGPR((X, y[:, None]), Matern52(lengthscales=0.12, variance=3.0), Constant(float(y.mean())),
+                   noise_variance=1.05e-6, dtype="float64", engine_options=opts)
+    model._open_engine = lambda dtype: HipGPEngineGroup(dtype, devices=[0], **opts)
+    model.engine.close()
+    model.engine = model._open_engine("float32")
+    model.data = (X, y[:, None])
+    mean, var = model.predict_y(X[:10])
+    assert isinstance(model.engine, HipGPEngineGroup) and model.engine.dtype_name == "float64"
+    ref = gpr.posterior(gpr.Theta(*theta), X, y)
+    m_ref, v_ref = gpr.predict_y(ref, X[:10])
+    np.testing.assert_allclose(np.asarray(mean)[:, 0], m_ref, rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(np.asarray(var)[:, 0], v_ref, rtol=1e-6, atol=1e-9)
+    model.engine.close()

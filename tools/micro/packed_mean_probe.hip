@@ -79,7 +79,106 @@ static void run(int64_t npad, int d, int ns, int64_t m, int reps) {
   hipFree(dl); hipFree(da); hipFree(dx); hipFree(dn); hipFree(dlv); hipFree(dln); hipFree(pv); hipFree(pm); hipFree(lb); hipFree(lb2);
 }
 
+#ifdef GPSO_PROBE_DUMP_MACC
+// Which link of the chain goes wrong: every lane's mean accumulators of the FIRST launch of a process against a warm
+// launch's; a lane that differs is compared with the candidate single faults of its 64 updates (8 k-steps of the
+// diagonal block x 8 updates per column tile), recomputed on the host in double.
+static void dump_run() {
+  typedef double TG;
+  const int64_t npad = 2048, m = 4096; const int d = 12, ns = 2;
+  const int dp4 = (d + 3) / 4, dp = dp4 * 4, nbi = (int)(npad / 256);
+  std::vector<float> linv((size_t)npad * npad, 0.f), al(npad);
+  std::vector<TG> xsp((size_t)npad * dp, (TG)0), xn(npad), lv((size_t)m * dp, (TG)0), ln(m);
+  unsigned s = 1; auto rnd = [&] { s = s * 1664525u + 1013904223u; return (float)(s >> 8) / (1 << 24); };
+  for (int64_t i = 0; i < npad; ++i)
+    for (int64_t j = 0; j <= i; ++j) linv[i * npad + j] = 0.01f * (rnd() - 0.5f);
+  for (auto& v : xsp) v = (TG)rnd();
+  for (auto& v : xn) v = (TG)(3.0f + rnd());
+  for (auto& v : al) v = 40.0f * (rnd() - 0.5f);
+  for (auto& v : lv) v = (TG)rnd();
+  for (auto& v : ln) v = (TG)(3.0f + rnd());
+  float *dl, *da; TG *dx, *dn, *dlv, *dln; double *pv, *pm; void* lb;
+  hipMalloc(&dl, linv.size() * 4); hipMalloc(&dx, xsp.size() * sizeof(TG)); hipMalloc(&dn, npad * sizeof(TG)); hipMalloc(&da, npad * 4);
+  hipMalloc(&dlv, lv.size() * sizeof(TG)); hipMalloc(&dln, m * sizeof(TG)); hipMalloc(&pv, (size_t)nbi * m * 8); hipMalloc(&pm, (size_t)nbi * m * 8);
+  hipMalloc(&lb, (size_t)ns * npad * npad * 2);
+  hipMemcpy(dl, linv.data(), linv.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dx, xsp.data(), xsp.size() * sizeof(TG), hipMemcpyHostToDevice);
+  hipMemcpy(dn, xn.data(), npad * sizeof(TG), hipMemcpyHostToDevice); hipMemcpy(da, al.data(), npad * 4, hipMemcpyHostToDevice);
+  hipMemcpy(dlv, lv.data(), lv.size() * sizeof(TG), hipMemcpyHostToDevice); hipMemcpy(dln, ln.data(), m * sizeof(TG), hipMemcpyHostToDevice);
+  launch_pack_linv_bf16<float>(0, ns, dl, npad, npad, lb);
+  const size_t nd = (size_t)nbi * (m / 256) * 512 * 2;
+  float* dd; hipMalloc(&dd, nd * 4); hipMemset(dd, 0, nd * 4);
+  hipMemcpyToSymbol(HIP_SYMBOL(gpso_probe_macc), &dd, sizeof(dd));
+  KernParams kp{0, 1.0, 1e-3, 0.0};
+  std::vector<float> A(nd), B(nd);
+  launch_leaf_tiles_bf16<TG>(0, ns, lb, dx, dn, da, dlv, dln, pv, pm, npad, dp4, m, kp, nullptr);
+  hipDeviceSynchronize();
+  hipMemcpy(A.data(), dd, nd * 4, hipMemcpyDeviceToHost);
+  for (int w = 0; w < 3; ++w) launch_leaf_tiles_bf16<TG>(0, ns, lb, dx, dn, da, dlv, dln, pv, pm, npad, dp4, m, kp, nullptr);
+  hipDeviceSynchronize();
+  hipMemcpy(B.data(), dd, nd * 4, hipMemcpyDeviceToHost);
+  size_t ndiff = 0;
+  for (size_t i = 0; i < nd; ++i) ndiff += memcmp(&A[i], &B[i], 4) != 0;
+  printf("dump: %zu of %zu lane accumulators of the first launch differ from the warm launch's\n", ndiff, nd);
+  if (!ndiff) return;
+  auto kern = [&](int64_t n, int64_t leaf) {  // Matern-5/2 at (training point n, leaf), the kernel's formula in double
+    const int kt = (int)(n / 16), i = (int)(n % 16);  // xs_p row: fragment lane (k, i) holds A[i][k]
+    double sdot = 0;
+    for (int c = 0; c < dp4; ++c)
+      for (int k = 0; k < 4; ++k) sdot += (double)xsp[((size_t)kt * dp4 + c) * 64 + 16 * k + i] * (double)lv[(size_t)leaf * dp + 4 * c + k];
+    double u = -2.0 * 5.0 * sdot + ((double)xn[n] * 5.0 + (double)ln[leaf] * 5.0);
+    u = std::fmax(u, 5e-36);
+    const double tt = std::sqrt(u);
+    return (1.0 + tt + tt * tt / 3.0) * std::exp(-tt);
+  };
+  int shown = 0;
+  int wave_count[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_count[2] = {0, 0};
+  for (size_t i = 0; i < nd; ++i) {
+    if (!memcmp(&A[i], &B[i], 4)) continue;
+    const int t = (int)(i & 1), tid = (int)((i >> 1) % 512);
+    const size_t wg = (i >> 1) / 512;
+    const int bx = (int)(wg % (m / 256)), by = (int)(wg / (m / 256)), bi = nbi - 1 - by;
+    const int wave = tid >> 6, lane = tid & 63;
+    ++wave_count[wave]; ++t_count[t];
+    if (shown >= 24) continue;
+    ++shown;
+    const int64_t leaf = ((int64_t)bx * 8 + wave) * 32 + 16 * t + (lane & 15), leaf_o = ((int64_t)bx * 8 + wave) * 32 + 16 * (1 - t) + (lane & 15);
+    const double dlt = (double)A[i] - (double)B[i];
+    // the 64 updates in order: step q, half h, register r
+    double best = 1e300; char what[160] = "";
+    double run_sum = 0;
+    for (int q = bi * 8; q < bi * 8 + 8; ++q)
+      for (int h = 0; h < 2; ++h)
+        for (int r = 0; r < 4; ++r) {
+          const int64_t n = 32 * (int64_t)q + 16 * h + 4 * (lane >> 4) + r;
+          const double p1 = kern(n, leaf), p0 = kern(n, leaf_o), a = al[n];
+          auto cand = [&](double c, const char* label, int64_t aux) {
+            const double e = std::fabs(dlt - c);
+            if (e < best) { best = e; snprintf(what, sizeof what, "%s step %d h %d r %d (aux %lld): candidate %.6g", label, q - bi * 8, h, r, (long long)aux, c); }
+          };
+          cand(-p1 * a, "update DROPPED", n);
+          cand(p1 * a, "update DOUBLED", n);
+          cand((p0 - p1) * a, "OTHER tile's p", n);
+          cand(-run_sum, "accumulator RESET before", n);  // everything before this update lost
+          for (int h2 = 0; h2 < 2; ++h2)
+            for (int r2 = 0; r2 < 4; ++r2) {
+              const int64_t n2 = 32 * (int64_t)q + 16 * h2 + 4 * (lane >> 4) + r2;
+              if (n2 != n) cand(p1 * ((double)al[n2] - a), "WRONG alpha (same lane group)", n2);
+            }
+          run_sum += p1 * a;
+        }
+    printf("  row block %d workgroup %d wave %d lane %2d tile %d: first %.7g warm %.7g diff %.6g | best single fault: %s (residual %.2g)\n",
+           bi, bx, wave, lane, t, A[i], B[i], dlt, what, best);
+  }
+  printf("  differing accumulators by wave:");
+  for (int w = 0; w < 8; ++w) printf(" %d", wave_count[w]);
+  printf("; by column tile: %d %d\n", t_count[0], t_count[1]);
+}
+#endif
+
 int main(int argc, char** argv) {
+#ifdef GPSO_PROBE_DUMP_MACC
+  if (argc > 1 && !strcmp(argv[1], "dump")) { dump_run(); return 0; }
+#endif
   const int reps = (argc > 1) ? atoi(argv[1]) : 200;
   if (argc > 2) {  // second argument: only the configuration that fails ("f": the same with float generation)
     if (argv[2][0] == 'f') run<float>(2048, 12, 2, 4096, reps);
