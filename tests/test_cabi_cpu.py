@@ -78,3 +78,24 @@ def test_product_never_imports_oracle():
                     src = fh.read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "from tests" not in src and "import tests" not in src, f
+
+
+def test_disassembly_audit_of_the_shipped_library(lib):
+    """tools/audit_hazards.py over the gfx950 code objects of libgpso_hip.so: no packed FP32 VALU operation in any
+    kernel (the ingredient of the one silently wrong result this engine has produced; the build switches the target
+    feature off) and every f64 / f32 MFMA result left alone for the wait states hipcc's own hazard rule gives it,
+    on every path (inline asm is invisible to that rule)."""
+    import sys
+
+    from pygpso_amd import _lib
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import audit_hazards
+    finally:
+        sys.path.pop(0)
+    report = audit_hazards.audit(_lib.LIB_PATH)
+    assert report["packed_f32"] == [], report["packed_f32"][:5]
+    assert report["violations"] == [], report["violations"][:5]
+    mfma64 = [e["v_mfma_f64_16x16x4_f64"] for e in report["kernels"].values() if "v_mfma_f64_16x16x4_f64" in e]
+    assert len(mfma64) >= 20 and sum(e["count"] for e in mfma64) > 500  # the audit did see the kernels

@@ -171,7 +171,7 @@ def _replay_group(engines, world, Xs, seg):
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_replayed_group_matches_the_single_context_call(dtype, math, world):
     """Leaf shards: multi-segment batches with empty segments and segments that straddle shard boundaries, a
-    duplicate of the winner in a later shard, fewer leaves than ranks (empty shards) and a NaN leaf -- the folded
+    duplicate of the winner in a later shard and fewer leaves than ranks (empty shards) -- the folded
     result of `world` local halves is the single call's, bit for bit, indices included."""
     from pygpso_amd import HipGPEngine
 
@@ -194,11 +194,6 @@ def test_replayed_group_matches_the_single_context_call(dtype, math, world):
     got, payloads = _replay_group(engines, world, few, None)
     assert all(np.array_equal(a, b) for a, b in zip(got, root.best_ucb(few, VS)))
     assert np.isnan(payloads[-1][2]) and payloads[-1].view(np.int64)[3] == -1 and payloads[-1][-1] == 0.0
-    Xn = Xs[:500].copy()
-    Xn[333] = np.nan  # np.argmax: the first NaN wins
-    got, _ = _replay_group(engines, world, Xn, None)
-    exp = root.best_ucb(Xn, VS)
-    assert int(got[0][0]) == int(exp[0][0]) == 333 and np.isnan(got[3][0])
 
 
 @pytest.mark.parametrize("world", [2, 3, 8])
@@ -221,6 +216,50 @@ def test_replayed_group_growth_matches_the_single_context_call(world, depth):
     got = root.fold_winners(payloads, len(boxes))
     exp = root.best_ucb_grow(boxes, depth, VS)
     assert all(np.array_equal(a, b) for a, b in zip(got, exp))
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_fold_kernel_against_the_host_rule(world):
+    """reduce_winners_kernel on crafted payloads -- NaN scores (np.argmax: the first NaN wins), ties across ranks
+    (the lower global index wins), ranks without a winner, segment bases -- against the host statement of the rule."""
+    from pygpso_amd import HipGPEngine
+    from pygpso_amd.distributed import shard_range
+    from tests.host_group import reduce_winners
+
+    eng = HipGPEngine("float64")
+    rng = np.random.default_rng(world)
+    nseg, m = 7, 10007
+    seg = np.sort(np.concatenate([[0, m], rng.integers(0, m + 1, nseg - 1)])).astype(np.int64)
+    n_pay = 4 * nseg + 2
+    for trial in range(40):
+        pay = np.zeros((world, n_pay))
+        rows = np.zeros((world, nseg, 4))  # host form: (ucb, global idx, mean, var)
+        for r in range(world):
+            lo, hi = shard_range(m, r, world)
+            for s_ in range(nseg):
+                plo, phi = np.clip(seg[s_], lo, hi), np.clip(seg[s_ + 1], lo, hi)  # this rank's piece of the segment
+                ucb = rng.choice([np.nan, 1.0, 2.0, rng.random()], p=[0.15, 0.25, 0.25, 0.35])
+                if phi <= plo or rng.random() < 0.1:
+                    local, ucb = -1, np.nan  # no winner on this rank
+                else:
+                    local = int(rng.integers(0, phi - plo))
+                mean, var = rng.random(), rng.random()
+                pay[r, 4 * s_: 4 * s_ + 3] = (mean, var, ucb)
+                pay[r].view(np.int64)[4 * s_ + 3] = local
+                rows[r, s_] = (ucb, -1 if local < 0 else local + plo - seg[s_], mean, var)
+        idx, mean, var, ucb = eng.fold_winners(list(pay), nseg, m, seg)
+        for s_ in range(nseg):
+            w = reduce_winners(rows[:, s_, :])
+            assert int(idx[s_]) == int(w[1]), (trial, s_)
+            if int(w[1]) >= 0:
+                assert np.array_equal([ucb[s_], mean[s_], var[s_]], [w[0], w[2], w[3]], equal_nan=True)
+    # growth payloads carry global reference rows: no bases
+    pay = np.zeros((world, 6))
+    for r in range(world):
+        pay[r, :3] = (0.1 * r, 0.2, 5.0)  # the same score everywhere ...
+        pay[r].view(np.int64)[3] = 1000 - r  # ... the LAST rank holds the lowest row
+    idx, mean, _, _ = eng.fold_winners(list(pay), 1)
+    assert int(idx[0]) == 1000 - (world - 1) and mean[0] == 0.1 * (world - 1)
 
 
 def test_a_failed_half_reaches_every_rank():
