@@ -136,6 +136,18 @@ int gpso_set_data(gpso_ctx* ctx, const double* X, const double* y, int64_t n, in
 int gpso_fit_eval(gpso_ctx* ctx, int kernel, const double* lengthscales, int n_ls, double variance,
                   double noise, double mean_c, double* nlml, double* grad);
 
+/* The same evaluation in the OPTIMISER's variables -- what one call of the closure SciPy's L-BFGS-B drives costs in
+ * the reference: GPflow's parameter transforms, training_loss and its reverse-mode gradient
+ * (gpso/gp_surrogate.py:500-503; transforms: SURVEY.md Appendix A.1).  u = the unconstrained vector in tf.Module's
+ * order: lengthscales[n_ls], kernel variance, likelihood variance [, constant mean when train_mean != 0; otherwise the
+ * mean is mean_c_fixed].  lengthscale = softplus(u), variance = softplus(u), noise = 1e-6 + softplus(u), mean = u; the
+ * transforms and the chain rule d/du = d/dtheta * sigmoid(u) run on the host side of the library with numpy's own
+ * formulas (bit-identical to evaluating them in Python and calling gpso_fit_eval).  Outputs: *nlml; grad_u (nullable)
+ * [n_ls + 2 + (train_mean != 0)]; theta_out (nullable) [n_ls + 3]: the constrained values used (lengthscales...,
+ * variance, noise, mean). */
+int gpso_fit_eval_u(gpso_ctx* ctx, int kernel, const double* u, int n_ls, int train_mean, double mean_c_fixed,
+                    double* nlml, double* grad_u, double* theta_out);
+
 /* Interop / debug: install a posterior computed elsewhere (host float64: X[N*D], L[N*N] row-major
  * lower, alpha[N]) -- the device still derives L^-1 and its tile packing itself.  Mirrors loading
  * saved GPflow parameters into a placeholder model (gpso/gp_surrogate.py:463-473). */

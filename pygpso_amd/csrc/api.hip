@@ -1742,6 +1742,41 @@ int gpso_fit_eval(gpso_ctx* ctx, int kernel, const double* lengthscales, int n_l
   return ctx->eng->fit_eval(kernel, lengthscales, n_ls, variance, noise, mean_c, nlml, grad);
 }
 
+// GPflow-2's parameter transforms, bit for bit what numpy computes for them on the host
+// side of the reference's optimiser loop: softplus(u) = logaddexp(0, u) in numpy's own case split (libm log1p / exp),
+// sigmoid(u) = (1 + tanh(u / 2)) / 2.
+static double gpso_softplus(double u) {
+  if (u == 0.0) return 0.693147180559945309417232121458176568;  // log 2
+  if (u < 0.0) return 0.0 + std::log1p(std::exp(u));
+  if (u > 0.0) return u + std::log1p(std::exp(-u));
+  return u;  // NaN
+}
+static double gpso_sigmoid(double u) { return 0.5 * (1.0 + std::tanh(0.5 * u)); }
+
+int gpso_fit_eval_u(gpso_ctx* ctx, int kernel, const double* u, int n_ls, int train_mean, double mean_c_fixed,
+                    double* nlml, double* grad_u, double* theta_out) {
+  ENTER();
+  if (!u) return ctx->fail(GPSO_E_ARG, "u must not be NULL");
+  if (n_ls < 1 || n_ls > kGradMaxLs) return ctx->fail(GPSO_E_ARG, "n_ls=%d outside [1, %d]", n_ls, kGradMaxLs);
+  double ls[kGradMaxLs], g[kGradMaxLs + 3];
+  for (int k = 0; k < n_ls; ++k) ls[k] = gpso_softplus(u[k]);
+  const double variance = gpso_softplus(u[n_ls]);
+  const double noise = 1.0e-6 + gpso_softplus(u[n_ls + 1]);  // gpflow.likelihoods.Gaussian DEFAULT_VARIANCE_LOWER_BOUND
+  const double mean_c = train_mean ? u[n_ls + 2] : mean_c_fixed;
+  if (theta_out) {
+    for (int k = 0; k < n_ls; ++k) theta_out[k] = ls[k];
+    theta_out[n_ls] = variance;
+    theta_out[n_ls + 1] = noise;
+    theta_out[n_ls + 2] = mean_c;
+  }
+  const int rc = ctx->eng->fit_eval(kernel, ls, n_ls, variance, noise, mean_c, nlml, grad_u ? g : nullptr);
+  if (rc != GPSO_OK || !grad_u) return rc;
+  // chain rule: d/du = d/dtheta * sigmoid(u) for the softplus-transformed parameters, identity for the mean
+  for (int k = 0; k < n_ls + 2; ++k) grad_u[k] = g[k] * gpso_sigmoid(u[k]);
+  if (train_mean) grad_u[n_ls + 2] = g[n_ls + 2];
+  return GPSO_OK;
+}
+
 int gpso_set_posterior(gpso_ctx* ctx, const double* X, const double* L, const double* alpha,
                        int64_t n, int d, int kernel, const double* lengthscales, int n_ls,
                        double variance, double noise, double mean_c) {

@@ -223,6 +223,10 @@ class HipGPEngineGroup:
         self._stale = True
         return self.engines[0].fit_eval(*a, **kw)
 
+    def fit_eval_u(self, *a, **kw):
+        self._stale = True
+        return self.engines[0].fit_eval_u(*a, **kw)
+
     def set_posterior(self, *a, **kw):
         self.engines[0].set_posterior(*a, **kw)
         self.n, self.d = self.engines[0].n, self.engines[0].d

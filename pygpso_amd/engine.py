@@ -63,6 +63,7 @@ class HipGPEngine:
         self.n = 0
         self.d = 0
         self.rank, self.world = 0, 1
+        self._u_bufs = {}
         if predict_math is not None and not (predict_math in ("native", "f32") and self.dtype == L.F64):
             self.set_predict_math(predict_math)
         if generation is not None:
@@ -179,6 +180,25 @@ class HipGPEngine:
         self._check(self._lib.gpso_fit_eval(self._h, kid, L.dptr(ls), n_ls, var, nz, mc,
                                             C.byref(nlml), L.dptr(grad) if want_grad else None))
         return nlml.value, grad
+
+    def fit_eval_u(self, kernel, u, n_ls, train_mean, mean_c_fixed=0.0):
+        """One loss evaluation in the optimiser's unconstrained variables (``gpso_fit_eval_u``: transforms and chain
+        rule inside the library).  Returns (nlml, grad_u, theta): theta = constrained (ls..., variance, noise, mean)."""
+        kid = L.KERNEL_IDS[kernel] if isinstance(kernel, str) else int(kernel)
+        n_u = int(n_ls) + 2 + (1 if train_mean else 0)
+        buf = self._u_bufs.get(n_u)
+        if buf is None:  # marshalling buffers are made once per problem shape: this call is the optimiser's inner loop
+            ua = np.empty(n_u, dtype=np.float64)
+            ga = np.empty(n_u, dtype=np.float64)
+            ta = np.empty(int(n_ls) + 3, dtype=np.float64)
+            nl = C.c_double()
+            buf = self._u_bufs[n_u] = (ua, ga, ta, nl, L.dptr(ua), L.dptr(ga), L.dptr(ta), C.byref(nl))
+        ua, ga, ta, nl, up, gp, tp, nlp = buf
+        ua[:] = u
+        rc = self._lib.gpso_fit_eval_u(self._h, kid, up, int(n_ls), 1 if train_mean else 0, float(mean_c_fixed), nlp, gp, tp)
+        if rc < 0:
+            self._check(rc)
+        return nl.value, ga.copy(), ta.copy()
 
     def set_posterior(self, X, Lchol, alpha, kernel, lengthscales, variance, noise, mean_c):
         X = L.as_f64(X)

@@ -10,6 +10,7 @@ lengthscales / kernel variance, 1e-6 + softplus for the likelihood variance, ide
 from __future__ import annotations
 
 import logging
+import math
 import types
 
 import numpy as np
@@ -24,8 +25,23 @@ NOISE_FLOOR = 1.0e-6  # gpflow.likelihoods.Gaussian DEFAULT_VARIANCE_LOWER_BOUND
 PRECISION_ESCALATION = {"float32": "mixed", "mixed": "float64"}
 
 
+def _softplus1(u):
+    """softplus(u) = numpy's ``logaddexp(0, u)``, spelled out with its case split on libm's log1p / exp (what numpy's
+    scalar loop calls) so that this module and ``gpso_fit_eval_u`` (csrc/api.hip: gpso_softplus) give the same bits."""
+    if u == 0.0:
+        return 0.693147180559945309417232121458176568
+    if u < 0.0:
+        return 0.0 + math.log1p(math.exp(u))
+    if u > 0.0:
+        return u + math.log1p(math.exp(-u))
+    return u
+
+
 def _softplus(u):
-    return np.logaddexp(0.0, u)
+    u = np.asarray(u, dtype=np.float64)
+    if u.ndim == 0:
+        return np.float64(_softplus1(float(u)))
+    return np.array([_softplus1(float(v)) for v in u.ravel()], dtype=np.float64).reshape(u.shape)
 
 
 def _softplus_inv(x):
@@ -34,7 +50,9 @@ def _softplus_inv(x):
 
 
 def _sigmoid(u):
-    return 0.5 * (1.0 + np.tanh(0.5 * np.asarray(u, dtype=np.float64)))
+    """(1 + tanh(u / 2)) / 2 on libm's tanh (the same bits as csrc/api.hip: gpso_sigmoid)."""
+    u = np.asarray(u, dtype=np.float64)
+    return np.array([0.5 * (1.0 + math.tanh(0.5 * float(v))) for v in u.ravel()], dtype=np.float64).reshape(u.shape)
 
 
 class _Result(np.ndarray):
@@ -70,6 +88,7 @@ class HipGPR:
         self._devices = list(devices) if devices is not None else None
         self._owns_engine = engine is None
         self.escalate = bool(escalate)
+        self.fused_transforms = True  # loss evaluations through gpso_fit_eval_u (False: transforms in Python)
         self.engine = engine if engine is not None else self._open_engine(dtype)
         self._data = None
         self._resident = False  # posterior on the device matches (data, hyper-parameters)?
@@ -147,14 +166,23 @@ class HipGPR:
     # -- loss ---------------------------------------------------------------------------------
     def _loss_and_grad(self, u):
         """f(u), df/du for L-BFGS-B: one device evaluation (Gram -> Cholesky -> ... -> gradient)."""
-        ls, var, noise, c = self._unpack(u)
         self._device_theta = None
+        k = self.n_ls
+        if self.fused_transforms and hasattr(self.engine, "fit_eval_u"):
+            # transforms + chain rule inside the library: one C-ABI call per evaluation (bit-identical to the branch
+            # below: tests/test_gpu_goldens.py::test_loss_evaluation_in_the_optimisers_variables)
+            f, gu, th = self.engine.fit_eval_u(self.kernel.name, u, k, self._train_mean, float(self.mean_function.c))
+            self._device_theta = self._theta_key(self.kernel.name, th[:k], th[k], th[k + 1], th[k + 2])
+            self._last_nlml = f
+            self.num_loss_evals += 1
+            self._resident = False
+            return f, gu
+        ls, var, noise, c = self._unpack(u)
         f, g = self.engine.fit_eval(self.kernel.name, ls, var, noise, c, want_grad=True)
         self._device_theta = self._theta_key(self.kernel.name, ls, var, noise, c)
         self._last_nlml = f
         self.num_loss_evals += 1
         self._resident = False  # resident for u, not necessarily for the stored hyper-parameters
-        k = self.n_ls
         gu = np.empty(k + 2 + (1 if self._train_mean else 0))
         gu[: k + 2] = g[: k + 2] * _sigmoid(np.asarray(u[: k + 2]))
         if self._train_mean:

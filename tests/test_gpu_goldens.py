@@ -208,3 +208,42 @@ def test_conditional_surrogate_grids_against_per_pair_oracle_predictions(dtype, 
         m_ref, v_ref = gpr.predict_y(post, at)
         assert np.max(np.abs(mean - m_ref.reshape(g, g))) <= tol * scale, (i, j)
         assert np.max(np.abs(var - v_ref.reshape(g, g))) <= tol * th.variance, (i, j)
+
+
+def test_loss_evaluation_in_the_optimisers_variables():
+    """gpso_fit_eval_u (transforms and chain rule inside the library: one C-ABI call per L-BFGS-B evaluation) against
+    the same evaluation with the transforms in Python around gpso_fit_eval: the SAME BITS -- loss, gradient, the
+    constrained values -- for isotropic, ARD and fixed-mean models, and therefore the same L-BFGS-B iterates: a whole
+    hyper-parameter fit ends at the same point after the same number of evaluations."""
+    from pygpso_amd import kernels as K
+    from pygpso_amd.model import HipGPR
+    from tests.helpers import synthetic_problem
+
+    rng = np.random.default_rng(5)
+    cases = [(K.Matern52(), K.Constant(), 40, 2), (K.Matern32(lengthscales=[0.3, 0.5, 0.7]), K.Constant(0.2), 90, 3),
+             (K.SquaredExponential(lengthscales=0.4), None, 150, 4)]
+    for kern, meanf, n, d in cases:
+        X, y = synthetic_problem(n, d, seed=n)
+        a = HipGPR((X, y[:, None]), kern, meanf, noise_variance=1e-3)
+        b = HipGPR((X, y[:, None]), kern, meanf, noise_variance=1e-3)
+        b.fused_transforms = False
+        u0 = a._pack()
+        for _ in range(6):
+            u = u0 + rng.normal(size=u0.shape)
+            fa, ga = a._loss_and_grad(u)
+            fb, gb = b._loss_and_grad(u)
+            assert fa == fb and ga.tobytes() == gb.tobytes()
+            assert a._device_theta == b._device_theta
+    # a whole fit, both ways (the KAT fixture of G1: a degenerate optimum, 30-odd iterations)
+    s0 = _kat_surrogate()
+    x, y = s0.current_training_data
+    res = []
+    for fused in (True, False):
+        model = HipGPR((x, y[:, np.newaxis]), K.Matern52(), K.Constant(), noise_variance=1e-3)
+        model.fused_transforms = fused
+        out = K.Scipy().minimize(model.training_loss, model.trainable_variables)
+        mean, var = model.predict_y(np.array([[0.5, 0.5]]))
+        res.append((model._pack().tobytes(), model.num_loss_evals, out.nit, float(mean[0, 0]), float(var[0, 0])))
+        assert float(np.around(mean[0, 0], decimals=8)) == G["G1"]["mean"]
+        assert float(np.around(var[0, 0], decimals=8)) == G["G1"]["var"]
+    assert res[0] == res[1]

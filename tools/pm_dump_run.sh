@@ -12,6 +12,9 @@ CTL=gpurun_out/pm_control.log
 for i in $(seq 1 $N); do
   timeout -k 5 60 tools/micro/packed_mean_probe_packed.bin 3 d >> $CTL 2>&1 || echo "exit $?" >> $CTL
 done
+# the minimal probe (tools/micro/pk_hazard_probe.hip): dependent v_pk_fma_f32 chains beside a partner wave's MFMAs
+timeout -k 5 120 tools/micro/pk_hazard_probe.bin 2000 256 3 > gpurun_out/pk_hazard.log 2>&1 || echo "exit $?" >> gpurun_out/pk_hazard.log
+cat gpurun_out/pk_hazard.log
 BAD=$(grep -c DIFFERS $CTL)
 echo "control: processes whose first launch differs: $BAD of $N"
 if [ "$BAD" -eq 0 ]; then echo "this box does not show the failure"; exit 0; fi
