@@ -362,7 +362,11 @@ def main():
             mean_ref, var_ref = gpr.predict_y(post, leaves_all[: max(n_s, 1)])
             ucb_ref = mean_ref + varsigma * var_ref
             if winner[0] < n_s:
+                # the oracle's own arg-max over the sample and how far (in oracle UCB) the GPU's winner is from it
                 out["winner"]["oracle_ucb_at_index"] = float(ucb_ref[winner[0]])
+                out["winner"]["oracle_argmax_over_sample"] = int(np.argmax(ucb_ref))
+                out["winner"]["oracle_ucb_gap"] = float(ucb_ref.max() - ucb_ref[winner[0]])
+                out["winner"]["same_argmax_as_oracle"] = bool(int(np.argmax(ucb_ref)) == winner[0]) if n_s == leaves_all.shape[0] else None
         if world == 1 and dtype == "float32" and math_opt == "auto":
             # every predict math on the same leaves in the same run: throughput + accuracy vs the oracle
             out["predict_math_modes"] = split_bf16_report(eng, leaves_dev, leaves_all, varsigma, m_total,
