@@ -61,7 +61,7 @@ WORKLOADS = {
     "c5": (40, 16384, 131072, "float32", "C5 (one GPU's share): D=40 N_train=16384 leaves=131072/GPU fp32 Matern52"),
 }
 PEAK_TFLOPS = {"float32": 157.3, "float64": 78.6}  # dense MFMA peaks, MI355X_MICROARCH.md
-PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak; a split product costs 6 (bf16x6) or 3 (bf16x3) bf16 MFMAs
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak; a split product costs 6 (bf16x6) or 3 (f16x3, bf16x3) MFMAs
 # HBM bytes per launch of the dominant kernel come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
 # cannot be read from inside the process); the committed record of the latest collection:
 PMC_TRAFFIC = {("c3", "native"): "profiles/r02f_pmc_leaf_tiles_c3.json",
@@ -171,7 +171,7 @@ def split_bf16_report(eng, leaves_dev, leaves_all, varsigma, m_total, flops_per_
     sample = leaves_all[:2048]
     ref = gpr.predict_y(post, sample) if post is not None else None
     time.sleep(0.5)  # let the BLAS worker threads of the CPU-baseline leg stop spinning
-    for mode in ("native", "bf16x6", "bf16x3"):
+    for mode in ("native", "bf16x6", "f16x3", "bf16x3"):
         eng.set_predict_math(mode)
         for _ in range(3):
             eng.best_ucb(leaves_dev, varsigma)
@@ -195,14 +195,14 @@ def split_bf16_report(eng, leaves_dev, leaves_all, varsigma, m_total, flops_per_
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--noise", type=float, default=1.0e-3, help="noise variance of the synthetic posterior")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--math", default="auto", choices=["auto", "native", "bf16x3", "bf16x6"],
-                    help="predict math of float32 workloads (auto = the library default: bf16x6 where the "
-                         "posterior's self-test passes with it, else native f32)")
+    ap.add_argument("--math", default="auto", choices=["auto", "native", "bf16x3", "bf16x6", "f16x3"],
+                    help="predict math of float32 workloads (auto = the library default: the first rung of the ladder "
+                         "f16x3 -> bf16x6 -> native f32 the posterior's self-test passes with)")
     args = ap.parse_args()
 
     import torch
@@ -342,8 +342,8 @@ def main():
                 "kernel": "leaf_tiles_kernel" if math_mode == "native" else f"leaf_tiles_bf16_kernel({math_mode})",
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "peak_note": "dense f32 / f64 MFMA peak" if math_mode == "native" else
-                f"algorithmic (f32-equivalent) FLOPs; the kernel forms every f32 product from {math_mode[-1]} bf16 MFMAs "
-                f"with f32 accumulation, so the bound is the dense bf16 peak / {math_mode[-1]} = {peak:.0f} TFLOP/s",
+                f"algorithmic (f32-equivalent) FLOPs; the kernel forms every f32 product from {math_mode[-1]} {'fp16' if math_mode[0] == 'f' else 'bf16'} MFMAs "
+                f"with f32 accumulation, so the bound is the dense bf16 / fp16 peak / {math_mode[-1]} = {peak:.0f} TFLOP/s",
                 "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC, gfx950-corrected)",
                 "traffic_source": traffic_src,
                 "algorithmic_bytes": int((hi - lo) * (d + 3) * (4 if dtype == "float32" else 8)

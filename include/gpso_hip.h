@@ -61,12 +61,15 @@ typedef struct gpso_ctx gpso_ctx;
 /* options (gpso_set_option) */
 #define GPSO_OPT_PREDICT_MATH 1 /* arithmetic of the L^-1 apply in predict/best_ucb, float-predict contexts: */
 #define GPSO_MATH_NATIVE 0      /*   f32 MFMA (what GPSO_F64 contexts always use, in double)             */
-#define GPSO_MATH_AUTO 1        /*   default: BF16X6 where the posterior allows it (padded N a multiple  */
-                                /*   of 256, leaf fragments fit LDS) and its self-test passes with it,    */
-                                /*   the f32 MFMA kernel otherwise                                        */
+#define GPSO_MATH_AUTO 1        /*   default: a ladder walked per posterior -- F16X3 where the posterior */
+                                /*   allows it (padded N a multiple of 256, leaf fragments fit LDS) and   */
+                                /*   its self-test passes with it, else BF16X6, else the f32 MFMA kernel  */
 #define GPSO_MATH_BF16X3 3      /*   2-way bf16 split, 3 bf16 MFMAs per product: |d var| ~ 2e-5 sigma^2  */
 #define GPSO_MATH_BF16X6 6      /*   3-way bf16 split, 6 bf16 MFMAs per f32 product, f32 accumulation:   */
                                 /*   f32-class accuracy (measured beside native f32 in bench.py)         */
+#define GPSO_MATH_F16X3 13      /*   2-way fp16 split (2 x 11 bits), 3 fp16 MFMAs per product, operands   */
+                                /*   scaled by powers of two into fp16's range, f32 accumulation: each    */
+                                /*   operand carried to 2^-22, the dropped low x low product 2^-22        */
 #define GPSO_OPT_FIT_SINGLE_LEVEL_MAX 2 /* tuning / test hook: largest padded N whose Cholesky runs single-level */
                                         /* with L^-1 built beside it (default 3584, double 2560); 0 = always two-level +     */
                                         /* level-doubling triangular inverse.  Results agree to rounding.       */
@@ -283,7 +286,7 @@ int gpso_adopt_posterior(gpso_ctx* ctx);
  *       unamplified, a general leaf amplified by the solve weights (calibrated heuristic)
  *   [9] max_i (K_y^-1)_ii
  *   [10] generation arithmetic in use on this posterior: 0 double, 1 float (GPSO_GEN_AUTO's choice)
- *   [11] predict math in use on this posterior (GPSO_MATH_NATIVE / BF16X3 / BF16X6)
+ *   [11] predict math in use on this posterior (GPSO_MATH_NATIVE / BF16X3 / BF16X6 / F16X3)
  * Returns GPSO_OK, GPSO_E_PRECISION when sqrt(a) [0] > [6] or a [1] > [7] (or a value is not finite), or
  * GPSO_E_STATE when no fitted posterior with targets is resident. */
 int gpso_precision_info(gpso_ctx* ctx, double* out);

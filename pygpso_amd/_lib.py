@@ -34,8 +34,9 @@ OPTF_TOL_VAR, OPTF_TOL_MEAN = 100, 101
 GEN_F64, GEN_F32, GEN_AUTO = 0, 1, 2
 GEN_IDS = {"float64": GEN_F64, "f64": GEN_F64, "float32": GEN_F32, "f32": GEN_F32, "auto": GEN_AUTO}
 DTYPE_IDS = {"float64": F64, "fp64": F64, "f64": F64, "float32": F32, "fp32": F32, "f32": F32, "mixed": MIXED}
-MATH_NATIVE, MATH_AUTO, MATH_BF16X3, MATH_BF16X6 = 0, 1, 3, 6
-MATH_IDS = {"native": MATH_NATIVE, "f32": MATH_NATIVE, "auto": MATH_AUTO, "bf16x3": MATH_BF16X3, "bf16x6": MATH_BF16X6}
+MATH_NATIVE, MATH_AUTO, MATH_BF16X3, MATH_BF16X6, MATH_F16X3 = 0, 1, 3, 6, 13
+MATH_IDS = {"native": MATH_NATIVE, "f32": MATH_NATIVE, "auto": MATH_AUTO, "bf16x3": MATH_BF16X3, "bf16x6": MATH_BF16X6,
+            "f16x3": MATH_F16X3}
 
 KERNEL_IDS = {
     "Matern52": MATERN52,

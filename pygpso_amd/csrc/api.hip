@@ -261,7 +261,10 @@ struct EngineT : Engine {
   bool bf16_fit = true;             // GPSO_OPT_FIT_BF16_SYRK
   // predict math: the OPTION (math_auto: GPSO_MATH_AUTO) and what the resident posterior uses (math, and
   // math_native_fallback when the self-test preferred the f32 MFMA kernel for it)
-  int math = kFloatPredict ? GPSO_MATH_BF16X6 : GPSO_MATH_NATIVE;
+  // GPSO_MATH_AUTO walks the ladder fp16 split (3 MFMAs per product) -> bf16x6 -> f32 MFMA kernel, one rung down each
+  // time the self-test of the posterior at hand fails with the rung it is on (selftest_with_fallback)
+  static constexpr int kAutoFirst = kFloatPredict ? GPSO_MATH_F16X3 : GPSO_MATH_NATIVE;
+  int math = kAutoFirst;
   bool math_auto = kFloatPredict, math_native_fallback = false;
   // generation of the cross-Gram tile in float-predict contexts: the OPTION (gen_mode) and what the
   // resident posterior actually uses (gen_eff32).  GPSO_GEN_AUTO starts every posterior in float -- the
@@ -307,15 +310,23 @@ struct EngineT : Engine {
   // decides the generation type, the kernel follows)
   bool bf16_fits(bool gen64) const { return leaf_bf16_lds_bytes(nsplit(), dp / 4, gen64 ? 8 : 4) <= 160 * 1024; }
   int nsplit() const { return math == GPSO_MATH_BF16X6 ? 3 : 2; }
+  bool f16_split() const { return math == GPSO_MATH_F16X3; }
+  // bytes of the split copy of L^-1: the planes and, behind them, one 256-byte slot for the power-of-two scale of the
+  // fp16 split (2 floats, written on the device at packing time) -- it travels with the planes in a hand-off.  Under
+  // GPSO_MATH_AUTO room for three planes whatever the stage, so that both sides of a hand-off list the same sizes.
+  size_t split_planes_alloc() const { return (size_t)(math_auto ? 3 : nsplit()) * npad * npad * 2; }
+  size_t split_bytes() const { return split_planes_alloc() + 256; }
+  float* f16_scale() const { return reinterpret_cast<float*>(static_cast<char*>(linv_b.p) + split_planes_alloc()); }
   bool bf16_usable() const { return kFloatPredict && math != GPSO_MATH_NATIVE && !math_native_fallback && npad > 0 && npad % 256 == 0; }
 
   // (re)build the bf16 pieces of L^-1 from the fit-type L^-1 resident in `linv`
   int pack_bf16() {
     linv_b_valid = false;
     if (!bf16_usable()) return GPSO_OK;
-    int rc = ensure(linv_b, (size_t)nsplit() * npad * npad * 2);
+    int rc = ensure(linv_b, split_bytes());
     if (rc) return rc;
-    launch_pack_linv_bf16<TF>(st(), nsplit(), as<TF>(linv), n, npad, linv_b.p);
+    if (f16_split()) launch_pack_linv_f16<TF>(st(), as<TF>(linv), n, npad, f16_scale(), linv_b.p);
+    else launch_pack_linv_bf16<TF>(st(), nsplit(), as<TF>(linv), n, npad, linv_b.p);
     HIPCHECK(hipGetLastError());
     linv_b_valid = true;
     return GPSO_OK;
@@ -358,12 +369,13 @@ struct EngineT : Engine {
       default:
         return ctx->fail(GPSO_E_ARG, "unknown option %d", option);
     }
-    if (value != GPSO_MATH_NATIVE && value != GPSO_MATH_BF16X3 && value != GPSO_MATH_BF16X6 && value != GPSO_MATH_AUTO)
+    if (value != GPSO_MATH_NATIVE && value != GPSO_MATH_BF16X3 && value != GPSO_MATH_BF16X6 && value != GPSO_MATH_F16X3 &&
+        value != GPSO_MATH_AUTO)
       return ctx->fail(GPSO_E_ARG, "unknown predict math %d", value);
     if (value != GPSO_MATH_NATIVE && value != GPSO_MATH_AUTO && !kFloatPredict)
-      return ctx->fail(GPSO_E_ARG, "split-bf16 predict math needs a GPSO_F32 or GPSO_MIXED context");
+      return ctx->fail(GPSO_E_ARG, "split (bf16 / fp16) predict math needs a GPSO_F32 or GPSO_MIXED context");
     const bool want_auto = value == GPSO_MATH_AUTO;
-    if (want_auto) value = kFloatPredict ? GPSO_MATH_BF16X6 : GPSO_MATH_NATIVE;
+    if (want_auto) value = kAutoFirst;
     if (value == math && want_auto == math_auto && !math_native_fallback) return GPSO_OK;
     math = value;
     math_auto = want_auto;
@@ -516,6 +528,7 @@ struct EngineT : Engine {
   // self-test has to rule again
   void reset_generation() {
     math_native_fallback = false;
+    if (math_auto) math = kAutoFirst;  // the ladder starts over with every posterior
     gen_eff32 = kFloatPredict && gen_mode != GPSO_GEN_F64;
     gen_decided = false;
     gen32_inputs_ok = false;
@@ -747,7 +760,7 @@ struct EngineT : Engine {
         if constexpr (kFloatPredict)
           rc = launch_leaf_tiles_bf16<TG>(s, nsplit(), linv_b.p, xsp, xnr, as<float>(alpha), as<TG>(leaves_s),
                                           as<TG>(lnorm), as<double>(pvar), as<double>(pmean), npad, dp / 4, mp,
-                                          kp, m_live_c);
+                                          kp, m_live_c, f16_split() ? f16_scale() : nullptr);
       } else {
         rc = launch_leaf_tiles<TP, TG>(s, as<TP>(linv_p), xsp, xnr, as<TP>(alpha), as<TG>(leaves_s),
                                        as<TG>(lnorm), as<double>(pvar), as<double>(pmean), npad, dp / 4, mp, kp,
@@ -879,6 +892,12 @@ struct EngineT : Engine {
     int rc = run_selftest();
     if (rc) return rc;
     if (!st_pass() && math_auto && bf16_usable() && linv_b_valid) {
+      if (math == GPSO_MATH_F16X3 && chol_valid) {  // next rung: six bf16 products (L^-1 is resident: repack)
+        math = GPSO_MATH_BF16X6;
+        if ((rc = pack_bf16())) return rc;
+        st_done = false;
+        if ((rc = run_selftest()) || st_pass()) return rc;
+      }
       math_native_fallback = true;
       st_done = false;
       rc = run_selftest();
@@ -1429,7 +1448,8 @@ struct EngineT : Engine {
       why = ctx->err;
     }
     // the predict math the posterior travels with (under GPSO_MATH_AUTO the root's self-test has chosen)
-    const int64_t my_opts = (int64_t)(math_native_fallback ? GPSO_MATH_NATIVE : math) | ((int64_t)ctx->dtype << 16);
+    // (bit 12: GPSO_MATH_AUTO -- its split buffer has room for three planes whatever the rung, so the option itself must agree)
+    const int64_t my_opts = (int64_t)(math_native_fallback ? GPSO_MATH_NATIVE : math) | ((int64_t)math_auto << 12) | ((int64_t)ctx->dtype << 16);
     if (is_root) {
       host[0] = n; host[1] = d; host[2] = my_opts; host[3] = mine;
       HIPCHECK(hipMemcpyAsync(hd, host, 48, hipMemcpyHostToDevice, s));
@@ -1439,10 +1459,13 @@ struct EngineT : Engine {
     HIPCHECK(hipStreamSynchronize(s));
     const int64_t rn = host[0], rd = host[1], ropts = host[2], root_status = host[3];
     if (!is_root && root_status == GPSO_OK) {
-      const int64_t rmath = ropts & 0xffff, rdtype = ropts >> 16;
-      if (rdtype == (int64_t)ctx->dtype && math_auto && (rmath == math || rmath == GPSO_MATH_NATIVE)) {
-        math_native_fallback = rmath == GPSO_MATH_NATIVE && math != GPSO_MATH_NATIVE;  // the root's choice
-      } else if (rdtype != (int64_t)ctx->dtype || rmath != math) {
+      const int64_t rmath = ropts & 0xfff, rauto = (ropts >> 12) & 1, rdtype = ropts >> 16;
+      if (rdtype == (int64_t)ctx->dtype && math_auto && rauto &&
+          (rmath == GPSO_MATH_F16X3 || rmath == GPSO_MATH_BF16X6 || rmath == GPSO_MATH_NATIVE)) {
+        // the root's choice (its self-test ruled): the rung of the ladder, or the f32 MFMA kernel
+        math_native_fallback = rmath == GPSO_MATH_NATIVE && kFloatPredict;
+        if (rmath != GPSO_MATH_NATIVE) math = (int)rmath;
+      } else if (rdtype != (int64_t)ctx->dtype || rmath != math || rauto != (int64_t)math_auto) {
         mine = ctx->fail(GPSO_E_ARG, "gpso_broadcast_posterior: dtype / predict math options differ from the root's");
         why = ctx->err;
       }
@@ -1541,7 +1564,8 @@ struct EngineT : Engine {
       if (rc) return rc;
       if (check && st_have && have_data && (rc = selftest_with_fallback())) return rc;  // settles GPSO_MATH_AUTO
       double* flag = ctx->pinned_scratch(256) + 120;  // (a slot neither the read-backs nor set_theta use)
-      *flag = (gen_double() ? 0.0 : 1.0) + (math_native_fallback ? 2.0 : 0.0) + ((bf16_usable() && linv_b_valid) ? 4.0 : 0.0);
+      *flag = (gen_double() ? 0.0 : 1.0) + (math_native_fallback ? 2.0 : 0.0) + ((bf16_usable() && linv_b_valid) ? 4.0 : 0.0) +
+              256.0 * math;  // (which split the pieces are: a receiver under GPSO_MATH_AUTO follows)
       HIPCHECK(hipMemcpyAsync(as<double>(hyper) + 7, flag, 8, hipMemcpyHostToDevice, st()));
       HIPCHECK(hipStreamSynchronize(st()));  // callers copy these buffers on streams of their own
     }
@@ -1557,9 +1581,9 @@ struct EngineT : Engine {
     // adopted itself, math switched afterwards) still sends the buffer, so that both sides of a broadcast list the
     // same buffers, and says so in the hyper block (bit 4 of slot 7 clear): the receivers then run the f32 kernel
     if (bf16_usable()) {
-      int rc = ensure(linv_b, (size_t)nsplit() * npad * npad * 2);
+      int rc = ensure(linv_b, split_bytes());
       if (rc) return rc;
-      ptrs[k] = linv_b.p; nbytes[k++] = (int64_t)nsplit() * npad * npad * 2;
+      ptrs[k] = linv_b.p; nbytes[k++] = (int64_t)split_bytes();
     }
     return k;
   }
@@ -1594,7 +1618,10 @@ struct EngineT : Engine {
     // generation arithmetic and predict math: the sender's choice (its self-test ruled), unless this context insists
     const int sender = (int)h[7];
     math_native_fallback = math_auto && (sender & 2) != 0;
-    linv_b_valid = bf16_usable() && (sender & 4) != 0;  // the bf16 pieces the sender actually built travel with it
+    const int sender_math = sender >> 8;
+    if (math_auto && kFloatPredict && (sender_math == GPSO_MATH_F16X3 || sender_math == GPSO_MATH_BF16X6)) math = sender_math;
+    // the split pieces the sender actually built travel with it (and are the split this context runs)
+    linv_b_valid = bf16_usable() && (sender & 4) != 0 && sender_math == math;
     gen_eff32 = kFloatPredict && (gen_mode == GPSO_GEN_F32 || (gen_mode == GPSO_GEN_AUTO && (sender & 1) != 0));
     gen_decided = true;
     gen32_inputs_ok = false;

@@ -48,11 +48,16 @@ inline size_t leaf_bf16_lds_bytes(int nsplit, int dp4, int tg_bytes) {
   return (size_t)2 * nsplit * 16 * 64 * 16 + (size_t)3 * (2 * dp4 * 64 * tg_bytes + 64 * tg_bytes + 256) +
          (size_t)8 * 2 * dp4 * 64 * tg_bytes;
 }
+// f16_inv_scale_a != nullptr: the fp16 split (two pieces, three products; predict.hip) -- linv_b and the scale (device,
+// 2 floats: max |L^-1|, 2^-sa) come from launch_pack_linv_f16
 template <typename TG>
 int launch_leaf_tiles_bf16(hipStream_t st, int nsplit, const void* linv_b, const TG* xs_p,
                            const TG* xnorm, const float* alpha, const TG* leaves_s,
                            const TG* lnorm, double* part_var, double* part_mean, int64_t npad,
-                           int dp4, int64_t mpad, const KernParams& kp, const int64_t* m_live);
+                           int dp4, int64_t mpad, const KernParams& kp, const int64_t* m_live,
+                           const float* f16_inv_scale_a = nullptr);
+template <typename TF>
+void launch_pack_linv_f16(hipStream_t st, const TF* linv, int64_t n, int64_t npad, float* scal /* [2] device */, void* linv_b);
 void launch_leaf_finalize(hipStream_t st, const double* part_var, const double* part_mean, int nbi,
                           int64_t mpad, int64_t m, const KernParams& kp, double varsigma,
                           double* mean, double* var, double* ucb);

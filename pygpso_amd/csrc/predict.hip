@@ -467,6 +467,70 @@ __global__ __launch_bounds__(256) void pack_linv_bf16_kernel(const TF* __restric
   }
 }
 
+// ---- fp16 split ("f16x3"): x = h0 + h1 with fp16 pieces (11 significant bits each, round to nearest: |x - h0 - h1| <=
+// 2^-23 |x|), a product = h0 h0' + h0 h1' + h1 h0' on v_mfma_f32_16x16x32_f16 -- THREE matrix instructions instead of
+// six, the dropped h1 h1' is 2^-22 relative.  fp16 has 5 exponent bits, so both operands are scaled by powers of two
+// (exact): L^-1 by 2^sa with max |L^-1| 2^sa in [2^13, 2^14) (found on the device at packing time, absmax_kernel), the
+// generated tile by 2^sb with sigma^2 2^sb in [2^13, 2^14) (folded into the variance the kernel map multiplies with).
+// An entry 2^-28 below its operand's maximum is still a normal fp16 number; below that the ABSOLUTE error per entry
+// stays under 2^-25 of the scaled maximum -- far inside the 2^-22 the dropped product costs.  Accumulation is f32 as
+// everywhere; the epilogue undoes the scales (sum of squares x 2^-2(sa+sb), mean x 2^-sb).
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// (a, b) -> packed fp16 pair (round to nearest even); a, b are replaced by the remainders
+__device__ __forceinline__ unsigned f16_split_pair(float& a, float& b) {
+  const f32x2 v = {a, b};
+  const f16x2 h = __builtin_convertvector(v, f16x2);
+  a -= (float)h[0];
+  b -= (float)h[1];
+  return __builtin_bit_cast(unsigned, h);
+}
+
+// max |linv| over the lower triangle of the first n rows -> out[0] (as float bits: non-negative floats order like
+// unsigned integers); out[0] must be zero on entry
+template <typename TF>
+__global__ __launch_bounds__(256) void absmax_kernel(const TF* __restrict__ linv, int64_t n, int64_t npad,
+                                                     unsigned* __restrict__ out) {
+  float m = 0.0f;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n * npad; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / npad, c = idx - r * npad;
+    if (c <= r) m = fmaxf(m, fabsf((float)linv[idx]));
+  }
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned, m));
+}
+
+// fp16 pieces of L^-1 2^sa in the fragment order of pack_linv_bf16_kernel<2>; scal[0] = max |L^-1| (absmax_kernel),
+// scal[1] := 2^-sa (read by the predict kernel's epilogue)
+template <typename TF>
+__global__ __launch_bounds__(256) void pack_linv_f16_kernel(const TF* __restrict__ linv, int64_t n, int64_t npad,
+                                                            float* __restrict__ scal, u32x4* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (rt, kq, lane)
+  const int64_t npad16 = npad / 16, npad32 = npad / 32;
+  int e = 0;
+  (void)frexpf(fmaxf(scal[0], 1e-30f), &e);  // max = m 2^e, m in [0.5, 1)
+  const float up = ldexpf(1.0f, 14 - e);
+  if (idx == 0) scal[1] = ldexpf(1.0f, e - 14);
+  if (idx >= npad16 * npad32 * 64) return;
+  const int lane = (int)(idx & 63);
+  const int64_t kq = (idx >> 6) % npad32, rt = (idx >> 6) / npad32;
+  const int64_t row = rt * 16 + (lane & 15);
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int64_t col = kq * 32 + (j >> 2) * 16 + 4 * (lane >> 4) + (j & 3);
+    // (a double L^-1 is rounded to float first: the two fp16 pieces hold 22 bits, float's 24 are enough)
+    v[j] = (row < n && col <= row) ? (float)linv[row * npad + col] * up : 0.0f;
+  }
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_) {
+    u32x4 f;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) f[h] = f16_split_pair(v[2 * h], v[2 * h + 1]);
+    out[((int64_t)s_ * npad16 + rt) * npad32 * 64 + kq * 64 + lane] = f;
+  }
+}
+
 template <typename TG>
 struct Bf16Lds {
   // bytes of one X buffer: 2 k-tiles of fragments (TG), 32 norms (TG, padded to 64), 32 alphas (float, padded to 64)
@@ -480,7 +544,7 @@ struct Bf16Lds {
 // queue for the matrix pipe.  So the waves of a SIMD run the two stretches in OPPOSITE order (waves 0-3 generate
 // step q, then apply it; waves 4-7 apply step q with the pieces they generated during step q - 1, then generate
 // step q + 1): one wave's vector work runs under the other's MFMAs.
-template <int NS, typename TG, int KERNEL>
+template <int NS, typename TG, int KERNEL, bool F16 = false>
 __device__ __forceinline__ void leaf_bf16_gen(bool diag, int lane, int dp4,
                                               const unsigned char* xs_b /* [2][dp4] X fragments | norms | alpha */,
                                               const TG* xb, const TG (&nb)[2], float variance,
@@ -556,15 +620,16 @@ __device__ __forceinline__ void leaf_bf16_gen(bool diag, int lane, int dp4,
     for (int sp = 0; sp < NS; ++sp) {
       u32x4 f;
 #pragma unroll
-      for (int h = 0; h < 4; ++h) f[h] = bf16_split_pair(p[t][2 * h], p[t][2 * h + 1]);
-      bfrag[sp][t] = __builtin_bit_cast(bf16x8, f);
+      for (int h = 0; h < 4; ++h) f[h] = F16 ? f16_split_pair(p[t][2 * h], p[t][2 * h + 1]) : bf16_split_pair(p[t][2 * h], p[t][2 * h + 1]);
+      bfrag[sp][t] = __builtin_bit_cast(bf16x8, f);  // (fp16 pieces travel in the same 16-byte registers)
     }
 }
 
 // apply: acc[rt][t] += sum over the kept piece products, small terms first
-template <int NS>
+template <int NS, bool F16 = false>
 __device__ __forceinline__ void leaf_bf16_apply(int q, int q_diag0, int lane, const u32x4* panel_b /* [NS][16][64] */,
                                                 const bf16x8 (&bfrag)[NS][2], f32x4 (&acc)[16][2]) {
+  static_assert(!F16 || NS == 2, "the fp16 split has two pieces");
   constexpr int RT = 16, CT = 2;
   u32x4 a[2][NS];
 #pragma unroll
@@ -580,8 +645,9 @@ __device__ __forceinline__ void leaf_bf16_apply(int q, int q_diag0, int lane, co
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
       f32x4 c = acc[rt][t];
-#define GPSO_BF(SA, SB) \
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[rt & 1][SA]), bfrag[SB][t], c, 0, 0, 0)
+#define GPSO_BF(SA, SB)                                                                                                   \
+  c = F16 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[rt & 1][SA]), __builtin_bit_cast(f16x8, bfrag[SB][t]), c, 0, 0, 0) \
+          : __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[rt & 1][SA]), bfrag[SB][t], c, 0, 0, 0)
       if (NS == 3) {
         GPSO_BF(2, 0);
         GPSO_BF(0, 2);
@@ -599,12 +665,15 @@ __device__ __forceinline__ void leaf_bf16_apply(int q, int q_diag0, int lane, co
 #ifdef GPSO_PROBE_DUMP_MACC
 __device__ float* gpso_probe_macc = nullptr;
 #endif
-template <int NS, typename TG, int KERNEL>
+// F16: the fp16 split (two pieces, three products); `variance` then arrives multiplied by 2^sb, inv_scale_a[1] is
+// 2^-sa (device, written by pack_linv_f16_kernel) and inv_scale_b = 2^-sb
+template <int NS, typename TG, int KERNEL, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     const u32x4* __restrict__ linv_b, const TG* __restrict__ xs_p, const TG* __restrict__ xnorm,
     const float* __restrict__ alpha, const TG* __restrict__ leaves_s,
     const TG* __restrict__ lnorm, double* __restrict__ part_var, double* __restrict__ part_mean,
-    int npad16, int dp4, int64_t mpad, int nbi, float variance, const int64_t* __restrict__ m_live) {
+    int npad16, int dp4, int64_t mpad, int nbi, float variance, const int64_t* __restrict__ m_live,
+    const float* __restrict__ inv_scale_a, float inv_scale_b) {
   constexpr int RT = 16, CT = 2, NW = 8;
   constexpr int XB = 64 * (int)sizeof(TG);
   constexpr TG C2 = (TG)KernScale<KERNEL>::C2;
@@ -721,11 +790,11 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     if (!ahead || q == 0) issue_for(q);
     else if (q >= 2) issue_for(q - 1);  // (this wave's iteration q starts in interval q - 1)
     GPSO_BSTAMP(q, 1);
-    leaf_bf16_gen<NS, TG, KERNEL>(q >= q_diag0, lane, dp4, xsl + (q % 3) * xstride, xb, nb, variance, bfrag, macc);
+    leaf_bf16_gen<NS, TG, KERNEL, F16>(q >= q_diag0, lane, dp4, xsl + (q % 3) * xstride, xb, nb, variance, bfrag, macc);
     GPSO_BSTAMP(q, 2);
     if (ahead && q > 0) __syncthreads();
     GPSO_BSTAMP(q, 3);
-    leaf_bf16_apply<NS>(q, q_diag0, lane, panel + (q & 1) * NS * RT * 64, bfrag, acc);
+    leaf_bf16_apply<NS, F16>(q, q_diag0, lane, panel + (q & 1) * NS * RT * 64, bfrag, acc);
     GPSO_BSTAMP(q, 4);
     if (!ahead) __syncthreads();
     GPSO_BSTAMP(q, 5);
@@ -739,6 +808,13 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   }
 #endif
 
+  // (fp16 split: undo the power-of-two scales of the two operands -- exact)
+  double unscale2 = 1.0, unscale_m = 1.0;
+  if constexpr (F16) {
+    const double ia = (double)inv_scale_a[1], ib = (double)inv_scale_b;  // ([0] is max |L^-1|, [1] = 2^-sa)
+    unscale2 = (ia * ib) * (ia * ib);
+    unscale_m = ib;
+  }
 #pragma unroll
   for (int t = 0; t < CT; ++t) {
     double sq = 0;
@@ -751,6 +827,10 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     double mm = (double)macc[t];
     mm += __shfl_xor(mm, 16);
     mm += __shfl_xor(mm, 32);
+    if constexpr (F16) {
+      sq *= unscale2;
+      mm *= unscale_m;
+    }
     if (lane < 16) {
       const int64_t col = col0 + t * 16 + lane;
       part_var[(int64_t)bi * mpad + col] = sq;
@@ -759,12 +839,12 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   }
 }
 
-template <int NS, typename TG>
+template <int NS, typename TG, bool F16 = false>
 static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const TG* xs_p,
                                      const TG* xnorm, const float* alpha, const TG* leaves_s,
                                      const TG* lnorm, double* part_var, double* part_mean,
                                      int64_t npad, int dp4, int64_t mpad, const KernParams& kp,
-                                     const int64_t* m_live) {
+                                     const int64_t* m_live, const float* inv_scale_a = nullptr) {
   const int nbi = (int)(npad / 256);
   const dim3 grid((unsigned)(mpad / 256), (unsigned)nbi);
   const size_t lds = leaf_bf16_lds_bytes(NS, dp4, (int)sizeof(TG));
@@ -772,14 +852,19 @@ static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const T
     note_launch_error("launch_leaf_tiles_bf16: more than 32 X pieces per k-step");
     return 1;
   }
+  // fp16 split: the generated tile is scaled by 2^sb, sigma^2 2^sb in [2^13, 2^14) (folded into the variance)
+  int eb = 0;
+  (void)frexp(kp.variance, &eb);
+  const float var_arg = F16 ? (float)ldexp(kp.variance, 14 - eb) : (float)kp.variance;
+  const float inv_b = F16 ? (float)ldexp(1.0, eb - 14) : 1.0f;
 #define GPSO_L(K)                                                                                   \
   do {                                                                                              \
-    const int rc = ensure_dyn_lds((const void*)leaf_tiles_bf16_kernel<NS, TG, K>, (int)lds);        \
+    const int rc = ensure_dyn_lds((const void*)leaf_tiles_bf16_kernel<NS, TG, K, F16>, (int)lds);   \
     if (rc) return rc;                                                                              \
-    hipLaunchKernelGGL((leaf_tiles_bf16_kernel<NS, TG, K>), grid, dim3(512), lds, st,               \
+    hipLaunchKernelGGL((leaf_tiles_bf16_kernel<NS, TG, K, F16>), grid, dim3(512), lds, st,          \
                        static_cast<const u32x4*>(linv_b), xs_p, xnorm, alpha, leaves_s, lnorm,      \
-                       part_var, part_mean, (int)(npad / 16), dp4, mpad, nbi, (float)kp.variance,   \
-                       m_live);                                                                     \
+                       part_var, part_mean, (int)(npad / 16), dp4, mpad, nbi, var_arg, m_live,      \
+                       inv_scale_a, inv_b);                                                         \
   } while (0)
   switch (kp.kernel) {
     case 0: GPSO_L(0); break;
@@ -795,13 +880,16 @@ template <typename TG>
 int launch_leaf_tiles_bf16(hipStream_t st, int nsplit, const void* linv_b, const TG* xs_p,
                            const TG* xnorm, const float* alpha, const TG* leaves_s,
                            const TG* lnorm, double* part_var, double* part_mean, int64_t npad,
-                           int dp4, int64_t mpad, const KernParams& kp, const int64_t* m_live) {
+                           int dp4, int64_t mpad, const KernParams& kp, const int64_t* m_live,
+                           const float* f16_inv_scale_a) {
+  if (f16_inv_scale_a != nullptr)  // fp16 split (nsplit == 2 pieces)
+    return launch_leaf_tiles_bf16_ns<2, TG, true>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a);
   if (nsplit == 3)
     return launch_leaf_tiles_bf16_ns<3, TG>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live);
   return launch_leaf_tiles_bf16_ns<2, TG>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live);
 }
-template int launch_leaf_tiles_bf16<float>(hipStream_t, int, const void*, const float*, const float*, const float*, const float*, const float*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*);
-template int launch_leaf_tiles_bf16<double>(hipStream_t, int, const void*, const double*, const double*, const float*, const double*, const double*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*);
+template int launch_leaf_tiles_bf16<float>(hipStream_t, int, const void*, const float*, const float*, const float*, const float*, const float*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*, const float*);
+template int launch_leaf_tiles_bf16<double>(hipStream_t, int, const void*, const double*, const double*, const float*, const double*, const double*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*, const float*);
 
 template <typename TF>
 void launch_pack_linv_bf16(hipStream_t st, int nsplit, const TF* linv, int64_t n, int64_t npad,
@@ -813,6 +901,16 @@ void launch_pack_linv_bf16(hipStream_t st, int nsplit, const TF* linv, int64_t n
   else
     hipLaunchKernelGGL((pack_linv_bf16_kernel<2, TF>), grid, dim3(256), 0, st, linv, n, npad, static_cast<u32x4*>(linv_b));
 }
+template <typename TF>
+void launch_pack_linv_f16(hipStream_t st, const TF* linv, int64_t n, int64_t npad, float* scal, void* linv_b) {
+  (void)hipMemsetAsync(scal, 0, 8, st);
+  hipLaunchKernelGGL((absmax_kernel<TF>), dim3(512), dim3(256), 0, st, linv, n, npad, reinterpret_cast<unsigned*>(scal));
+  const int64_t total = (npad / 16) * (npad / 32) * 64;
+  hipLaunchKernelGGL((pack_linv_f16_kernel<TF>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, linv, n, npad,
+                     scal, static_cast<u32x4*>(linv_b));
+}
+template void launch_pack_linv_f16<float>(hipStream_t, const float*, int64_t, int64_t, float*, void*);
+template void launch_pack_linv_f16<double>(hipStream_t, const double*, int64_t, int64_t, float*, void*);
 template void launch_pack_linv_bf16<float>(hipStream_t, int, const float*, int64_t, int64_t, void*);
 template void launch_pack_linv_bf16<double>(hipStream_t, int, const double*, int64_t, int64_t, void*);
 

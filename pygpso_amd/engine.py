@@ -125,7 +125,7 @@ class HipGPEngine:
                 "kernel_variance", "tol_mean_abs", "tol_var_abs", "amplification", "max_kinv_diag")
         info = dict(zip(keys, (float(v) for v in out)))
         info["generation"] = "float32" if out[10] else "float64"
-        info["predict_math"] = {L.MATH_NATIVE: "native", L.MATH_BF16X3: "bf16x3", L.MATH_BF16X6: "bf16x6"}[int(out[11])]
+        info["predict_math"] = {L.MATH_NATIVE: "native", L.MATH_BF16X3: "bf16x3", L.MATH_BF16X6: "bf16x6", L.MATH_F16X3: "f16x3"}[int(out[11])]
         info["passed"] = rc == L.OK
         return info
 

@@ -167,7 +167,7 @@ def _replay_group(engines, world, Xs, seg):
     return engines[0].fold_winners(payloads, nseg, m, seg), payloads
 
 
-@pytest.mark.parametrize("dtype,math", [("float64", None), ("mixed", "bf16x6"), ("float32", "native")])
+@pytest.mark.parametrize("dtype,math", [("float64", None), ("mixed", "bf16x6"), ("mixed", "f16x3"), ("float32", "native")])
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_replayed_group_matches_the_single_context_call(dtype, math, world):
     """Leaf shards: multi-segment batches with empty segments and segments that straddle shard boundaries, a

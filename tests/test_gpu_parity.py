@@ -106,9 +106,11 @@ def test_fit_and_predict_fp32(n, d, m):
 
 # ---- split-bf16 predict math (float32 contexts): stated tolerances vs the float64 oracle ----------
 #   bf16x6: the f32 tolerances (|d mean| <= 2e-3 max|y|, |d var| <= 2e-4 sigma^2); measured ~3e-6 sigma^2
+#   f16x3:  (two fp16 pieces, three products, power-of-two scaling) the same: measured 1.3e-7 .. 2.8e-6 sigma^2, at or
+#           below native f32 on every posterior of tools/split_math_accuracy.py (profiles/r03_split_math_accuracy.jsonl)
 #   bf16x3: same bound on the mean (the mean never goes through the split), |d var| <= 2e-4 sigma^2;
 #           measured ~2e-5 sigma^2
-@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3"])
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x6", "bf16x3"])
 @pytest.mark.parametrize("n,d,m,kernel", [(256, 6, 4096, "Matern52"), (512, 12, 3000, "SquaredExponential"),
                                           (2048, 12, 4096, "Matern52"), (1024, 40, 2048, "Matern32"),
                                           (300, 5, 1000, "Matern52")])  # last: N_pad % 256 != 0 -> native kernel
@@ -124,7 +126,7 @@ def test_split_bf16_predict_math(mode, n, d, m, kernel):
     mean_ref, var_ref = gpr.predict_y(post, Xs)
     assert np.max(np.abs(mean - mean_ref)) <= 2e-3 * np.max(np.abs(y))
     assert np.max(np.abs(var - var_ref)) <= 2e-4 * th.variance
-    if mode == "bf16x6":  # f32-class: within 4x of what the native f32 kernel achieves on the same problem
+    if mode in ("bf16x6", "f16x3"):  # f32-class: within 4x of what the native f32 kernel achieves on the same problem
         nat = HipGPEngine("float32")
         _fit(nat, X, y, th, grad=False)
         _, var_nat = nat.predict(Xs)
@@ -138,6 +140,34 @@ def test_split_bf16_predict_math(mode, n, d, m, kernel):
     assert np.array_equal(mean[perm], m2) and np.array_equal(var[perm], v2)
 
 
+def test_auto_ladder_walks_down_and_starts_over():
+    """GPSO_MATH_AUTO: fp16 split -> bf16x6 -> f32 MFMA kernel, one rung down per failed self-test of the posterior at
+    hand, from the top again with the next posterior.  Tolerances nothing in float can meet walk the whole ladder (and
+    end in the refusal); the next fit with ordinary tolerances is served by the first rung, with the bits a fresh
+    engine produces."""
+    from pygpso_amd import HipGPEngine
+    from pygpso_amd._lib import GpsoPrecisionError
+
+    X, y, th = _problem(512, 4)
+    Xs = synthetic_leaves(700, 4)
+    eng = HipGPEngine("mixed", tol_var=1e-13, tol_mean=1e-13)
+    _fit(eng, X, y, th, grad=False)
+    with pytest.raises(GpsoPrecisionError):
+        eng.predict(Xs)
+    eng.set_tolerances(1e-4, 1e-4)
+    _fit(eng, X, y, th, grad=False)
+    a = eng.predict(Xs)
+    assert eng.precision_info()["predict_math"] == "f16x3"
+    fresh = HipGPEngine("mixed")
+    _fit(fresh, X, y, th, grad=False)
+    b = fresh.predict(Xs)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    exp = HipGPEngine("mixed", predict_math="f16x3")
+    _fit(exp, X, y, th, grad=False)
+    c = exp.predict(Xs)
+    assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+
+
 def test_predict_math_option_rules():
     from pygpso_amd import HipGPEngine, _lib as L
 
@@ -147,12 +177,12 @@ def test_predict_math_option_rules():
     Xs = synthetic_leaves(700, 4)
     eng = HipGPEngine("float32")
     _fit(eng, X, y, th, grad=False)
-    d = eng.predict(Xs)  # the default, GPSO_MATH_AUTO: bf16x6 here (padded N a multiple of 256, self-test passes)
-    assert eng.precision_info()["predict_math"] == "bf16x6"
+    d = eng.predict(Xs)  # the default, GPSO_MATH_AUTO: its first rung here (padded N a multiple of 256, self-test passes)
+    assert eng.precision_info()["predict_math"] == "f16x3"
     eng.set_predict_math("native")  # switching after the fit takes effect on the spot
     a = eng.predict(Xs)
     assert eng.precision_info()["predict_math"] == "native"
-    eng.set_predict_math("bf16x6")  # ... and repacks L^-1
+    eng.set_predict_math("f16x3")  # ... and repacks L^-1
     b = eng.predict(Xs)
     eng.set_predict_math("native")
     c = eng.predict(Xs)
@@ -552,7 +582,7 @@ def test_config_C5_one_gpu_share_at_size():
     f, _ = _fit(eng, X, y, th, grad=False)
     assert abs(f - post.nlml) <= 1e-4 * abs(post.nlml)
     results = {}
-    for math in ("native", "bf16x6", "bf16x3"):
+    for math in ("native", "bf16x6", "f16x3", "bf16x3"):
         eng.set_predict_math(math)
         mean, var = eng.predict(Xs)
         assert np.all(np.isfinite(mean)) and var.min() > 0 and var.max() <= (th.variance + th.noise) * (1 + 1e-5)
@@ -567,7 +597,10 @@ def test_config_C5_one_gpu_share_at_size():
     assert np.max(np.abs(mt - y[:512])) < 0.5 and np.all(vt < 4 * th.noise + 1e-3)
     # the mean never goes through the split: identical in both split modes
     assert np.array_equal(results["bf16x6"][0], results["bf16x3"][0])
+    # (the fp16 split scales the generated tile by a power of two -- exact -- and undoes it on the partial sums in double)
+    assert np.max(np.abs(results["f16x3"][0] - results["bf16x6"][0])) <= 1e-12 * ys
     assert np.max(np.abs(results["bf16x6"][1] - results["native"][1])) <= 5e-5
+    assert np.max(np.abs(results["f16x3"][1] - results["native"][1])) <= 5e-5
     assert np.max(np.abs(results["bf16x3"][1] - results["native"][1])) <= 2e-4
 
 
@@ -593,7 +626,7 @@ def test_config_C3_properties_fp32():
     _properties(eng, X, y, th, synthetic_leaves(m, d), post, 512)
 
 
-@pytest.mark.parametrize("math", ["native", "bf16x6", "bf16x3"])
+@pytest.mark.parametrize("math", ["native", "f16x3", "bf16x6", "bf16x3"])
 def test_config_C4_one_gpu_shard_properties_fp32(math):
     from pygpso_amd import HipGPEngine
 
@@ -647,8 +680,8 @@ def test_float_fit_on_the_bf16_matrix_cores_agrees_with_the_f32_path():
     assert np.max(np.abs(res[1][4] - res[0][4]) / np.maximum(1.0, np.abs(res[0][4]))) < 2e-2
 
 
-@pytest.mark.parametrize("dtype,math", [("float32", "bf16x6"), ("float32", "bf16x3"), ("float32", "native"),
-                                        ("mixed", "bf16x6"), ("mixed", "bf16x3"), ("mixed", "native"),
+@pytest.mark.parametrize("dtype,math", [("float32", "f16x3"), ("float32", "bf16x6"), ("float32", "bf16x3"), ("float32", "native"),
+                                        ("mixed", "f16x3"), ("mixed", "bf16x6"), ("mixed", "bf16x3"), ("mixed", "native"),
                                         ("float64", "native")])
 @pytest.mark.parametrize("n,d", [(200, 3), (512, 1), (1024, 12)])
 def test_run_to_run_determinism(dtype, math, n, d):
@@ -687,7 +720,7 @@ def test_run_to_run_determinism(dtype, math, n, d):
         assert cur == ref
 
 
-@pytest.mark.parametrize("math,tol_var", [("bf16x3", 1e-4), ("bf16x6", 5e-6), ("native", 5e-6)])
+@pytest.mark.parametrize("math,tol_var", [("bf16x3", 1e-4), ("bf16x6", 5e-6), ("f16x3", 5e-6), ("native", 5e-6)])
 def test_run_to_run_determinism_c3_g7(math, tol_var):
     """The posterior on which the packed-mean failure showed most often (18 % of the predict calls,
     profiles/r02h_packed_mean_bug.txt B): "C3-G7" of tests/test_gpu_precision.py -- C3's shape (N = 2048, D = 12) with

@@ -7,7 +7,7 @@ cond(K + sigma_n^2 I) ~ 1e6 .. 1e7.  Hyper-parameters come from tests/golden/ref
 (G6 final theta, G7 theta after the first update).
 
 Stated tolerances (against the float64 oracle)
-  mixed, native / bf16x6 ... |d var| <= 5e-6 sigma^2, |d mean| <= 5e-6 max|y - c| * max(1, max|alpha|)
+  mixed, native / bf16x6 / f16x3 (the default ladder's rungs) |d var| <= 5e-6 sigma^2, |d mean| <= 5e-6 max|y - c| * max(1, max|alpha|)
                              identical arg-max, or an oracle UCB within 2e-5 of the oracle's maximum
   mixed, bf16x3 ............ |d var| <= 1e-4 sigma^2 (its 16 mantissa bits), same mean bound
   float32 (float factor) ... with gate tolerances 1e-4: |d var| <= 4e-4 sigma^2, |d mean| <= 4e-4 max|y - c| at
@@ -83,7 +83,7 @@ def _check(eng, name, tol_var, th, y, leaves, post, mean_ref, var_ref, tol_mean_
     assert idx == int(np.argmax(ucb_ref)) or ucb_ref.max() - ucb_ref[idx] <= 2e-5 * max(1.0, abs(ucb_ref.max()))
 
 
-@pytest.mark.parametrize("math,tol_var", [("native", 5e-6), ("bf16x6", 5e-6), ("bf16x3", 1e-4)])
+@pytest.mark.parametrize("math,tol_var", [("native", 5e-6), ("bf16x6", 5e-6), ("f16x3", 5e-6), ("bf16x3", 1e-4)])
 @pytest.mark.parametrize("name", sorted(PROBLEMS))
 def test_mixed_engine_at_the_reference_noise_floor(name, math, tol_var):
     from pygpso_amd import HipGPEngine
@@ -155,7 +155,7 @@ def _optimiser(dtype, **engine_options):
                         stopping_condition="evaluations", update_cycle=1, n_workers=1)
 
 
-@pytest.mark.parametrize("dtype,math", [("mixed", "native"), ("mixed", "bf16x6"), ("float32", "native")])
+@pytest.mark.parametrize("dtype,math", [("mixed", "native"), ("mixed", "bf16x6"), ("mixed", "f16x3"), ("float32", "native")])
 def test_G6_replay_in_float_arithmetic(dtype, math, caplog):
     opt = _optimiser(dtype, predict_math=math)
     with caplog.at_level(logging.WARNING):
