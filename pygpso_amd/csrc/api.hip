@@ -595,6 +595,9 @@ struct EngineT : Engine {
       a.Lf = Lf.p; a.linv = linv.p; a.kinv = grad ? kinvb.p : nullptr;
       a.white = white.p; a.alpha_f = alpha_f.p; a.alpha_p = alpha.p; a.linv_p = linv_p.p;
       a.diag64 = as<double>(logdet); a.kinv_diag = as<double>(kinv_diag); a.scal = as<double>(scal);
+      // the loss, the factorisation's verdict and the gradient land in pinned host memory straight from the kernel
+      a.scal_host = ctx->pinned_scratch(8 + kGradMaxLs + 3);
+      if (!a.scal_host) return ctx->fail(GPSO_E_OOM, "pinned host scratch");
       if ((rc = launch_small_fit<TF, TP>(s, a))) return launch_status();
     } else {
       if ((rc = scale_inputs())) return rc;
@@ -652,7 +655,7 @@ struct EngineT : Engine {
     constexpr size_t kHostDoubles = 8 + kGradMaxLs + 3;
     double* host = ctx->pinned_scratch(kHostDoubles);
     if (!host) return ctx->fail(GPSO_E_OOM, "pinned host scratch");
-    HIPCHECK(hipMemcpyAsync(host, scal.p, kHostDoubles * 8, hipMemcpyDeviceToHost, s));
+    if (!small) HIPCHECK(hipMemcpyAsync(host, scal.p, kHostDoubles * 8, hipMemcpyDeviceToHost, s));
     HIPCHECK(ctx->wait(s));
     float ms = 0;
     if (hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->last_ms[2] = ms;

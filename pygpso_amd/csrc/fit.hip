@@ -1143,16 +1143,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel(GemmBf16Desc g) {
       rem = nxt.nsteps;
       switched = true;
     }
-#ifdef GPSO_EXP_NODMA
-    const bool do_dma = false;
-#else
     const bool do_dma = kSteady || rem > 0;
-#endif
-#ifdef GPSO_EXP_NORD
-    const bool do_rd = false;
-#else
     const bool do_rd = kSteady || st + 1 < cur.nsteps || have_next;
-#endif
     // item e + 1 has landed (the reads below need it); the fragments of this item, read during the last one, are
     // in registers on every wave once all have passed the barrier, so its buffer may be overwritten.  (Step 0 of
     // a later tile: that wait was made before the stores of the previous tile's epilogue, see below.)
@@ -2685,8 +2677,15 @@ __global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs g) {
   if (tid == 0) {
     const double quad = (red[0] + red[1]) + (red[2] + red[3]);
     const double ldet = (red[4] + red[5]) + (red[6] + red[7]);
-    g.scal[0] = 0.5 * quad + ldet + 0.5 * (double)n * 1.83787706640934548356;  // log(2 pi)
-    if (g.want_grad) g.scal[8 + g.n_ls + 2] = -((red[8] + red[9]) + (red[10] + red[11]));
+    const double nl = 0.5 * quad + ldet + 0.5 * (double)n * 1.83787706640934548356;  // log(2 pi)
+    const double gc = -((red[8] + red[9]) + (red[10] + red[11]));
+    g.scal[0] = nl;
+    if (g.want_grad) g.scal[8 + g.n_ls + 2] = gc;
+    if (g.scal_host != nullptr) {
+      g.scal_host[0] = nl;
+      *reinterpret_cast<int*>(g.scal_host + 1) = atomicMin(info, INT_MAX);  // (the factorisation's verdict, as the device holds it)
+      if (g.want_grad) g.scal_host[8 + g.n_ls + 2] = gc;
+    }
   }
   GPSO_SSTAMP(10);
   if (!g.want_grad) return;
@@ -2779,6 +2778,7 @@ __global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs g) {
     double v = (gacc[tid] + gacc[(kGradMaxLs + 2) + tid]) + (gacc[2 * (kGradMaxLs + 2) + tid] + gacc[3 * (kGradMaxLs + 2) + tid]);
     if (tid < g.n_ls) v /= g.ls[g.n_ls == 1 ? 0 : tid];
     g.scal[8 + tid] = v;
+    if (g.scal_host != nullptr) g.scal_host[8 + tid] = v;
   }
   GPSO_SSTAMP(11);
 }

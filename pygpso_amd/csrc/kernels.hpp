@@ -172,6 +172,8 @@ struct SmallFitArgs {
   double* diag64;  // [128]
   double* kinv_diag;  // [128]
   double* scal;    // [0] nlml, [1] info (int), [8 ..] gradient (ls..., variance, noise, c)
+  double* scal_host;  // nullable: pinned host memory (device-visible) that receives the same scalars straight from the
+                      // kernel -- the evaluation then needs no device-to-host copy operation behind it either
 };
 
 bool small_fit_eligible(int64_t n, int dp);

@@ -38,6 +38,20 @@ def _fit(eng, X, y, th, grad=True):
     return eng.fit_eval(th.kernel, th.lengthscales, th.variance, th.noise, th.mean_c, want_grad=grad)
 
 
+# float32 engines: the winner is the oracle's arg-max, or a leaf whose ORACLE ucb lies within the rounding of a float
+# prediction of it -- 2e-5 max(1, |ucb_max|): the mean carries ~1e-5-class float error (|d mean| measured 1e-5 ..
+# 3e-4 max|y| across the float32 cases; a tie within that band cannot be told apart in float), the variance 3e-6 sigma^2
+# x varsigma.  The same rule tests/test_gpu_precision.py:_check applies.
+WINNER_GAP = 2e-5
+
+
+def _winner_is_the_oracles(best, mean_ref, var_ref, gap=WINNER_GAP):
+    idx = int(best[0][0])
+    ucb_ref = mean_ref + VS * var_ref
+    assert idx == int(np.argmax(ucb_ref)) or ucb_ref.max() - ucb_ref[idx] <= gap * max(1.0, abs(ucb_ref.max())), \
+        (idx, int(np.argmax(ucb_ref)), float(ucb_ref.max() - ucb_ref[idx]))
+
+
 def _rel(a, b):
     return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(1e-300, np.max(np.abs(b))))
 
@@ -99,9 +113,7 @@ def test_fit_and_predict_fp32(n, d, m):
     mean_ref, var_ref = gpr.predict_y(post, Xs)
     assert np.max(np.abs(mean - mean_ref)) <= 2e-3 * np.max(np.abs(y))
     assert np.max(np.abs(var - var_ref)) <= 2e-4 * th.variance
-    idx, mu, vv, ucb = eng.best_ucb(Xs, VS)
-    ucb_ref = mean_ref + VS * var_ref
-    assert ucb_ref[int(idx[0])] >= ucb_ref.max() - 4e-3 * np.max(np.abs(y))
+    _winner_is_the_oracles(eng.best_ucb(Xs, VS), mean_ref, var_ref)
 
 
 # ---- split-bf16 predict math (float32 contexts): stated tolerances vs the float64 oracle ----------
@@ -131,9 +143,7 @@ def test_split_bf16_predict_math(mode, n, d, m, kernel):
         _fit(nat, X, y, th, grad=False)
         _, var_nat = nat.predict(Xs)
         assert np.max(np.abs(var - var_ref)) <= 4 * np.max(np.abs(var_nat - var_ref)) + 1e-6
-    idx, mu, vv, ucb = eng.best_ucb(Xs, VS)
-    ucb_ref = mean_ref + VS * var_ref
-    assert ucb_ref[int(idx[0])] >= ucb_ref.max() - 4e-3 * np.max(np.abs(y))
+    _winner_is_the_oracles(eng.best_ucb(Xs, VS), mean_ref, var_ref)
     # position independence and determinism hold in these modes too
     perm = np.random.default_rng(1).permutation(m)
     m2, v2 = eng.predict(Xs[perm])
@@ -250,25 +260,32 @@ def test_empty_batch_and_error_paths():
         eng.fit_eval("NoSuchKernel", [0.3], 1.0, 1e-3, 0.0)
 
 
-@pytest.mark.parametrize("dtype,n,d", [("float64", 700, 5), ("float64", 1100, 3), ("float32", 900, 6)])
-def test_two_level_cholesky_path_matches_oracle(dtype, n, d):
+@pytest.mark.parametrize("dtype,n,d,noise", [("float64", 700, 5, 1e-3), ("float64", 1100, 3, 1e-3), ("float32", 900, 6, 1e-2),
+                                             ("float32", 900, 6, 1e-3)])
+def test_two_level_cholesky_path_matches_oracle(dtype, n, d, noise):
     """Sizes above 4096 factorise two-level (outer rank-256 SYRK + look-ahead column) and invert L by
     level doubling; GPSO_OPT_FIT_SINGLE_LEVEL_MAX = 0 forces that path at a size the oracle can check."""
     from pygpso_amd import _lib as L
 
-    X, y, th = _problem(n, d, noise=1e-3 if dtype == "float64" else 1e-2)
+    X, y, th = _problem(n, d, noise=noise)
     post = gpr.posterior(th, X, y)
     f_ref, g_ref = gpr.nlml_and_grad(th, X, y)
     eng = _engine(dtype)
     eng.set_fit_single_level_max(0)
     f, g = _fit(eng, X, y, th)
     Linv_ref = np.linalg.inv(post.L)
+    # float: L to a few float ulps of its largest entry; L^-1 and K^-1 carry cond(L) = sqrt(cond(K_y)) x eps on top
+    # (cond(K_y) ~ sigma^2 N / noise x clustering: 1e5 at noise 1e-2, 1e6 at 1e-3)
     tol = 1e-9 if dtype == "float64" else 2e-4
+    tol_inv = tol * 10 * (1.0 if dtype == "float64" or noise >= 1e-2 else 4.0)
     assert _rel(eng.get_matrix(L.MAT_CHOL), post.L) < tol
-    assert _rel(eng.get_matrix(L.MAT_LINV), Linv_ref) < tol * 10
-    assert _rel(eng.get_matrix(L.MAT_KINV), Linv_ref.T @ Linv_ref) < tol * 10
+    assert _rel(eng.get_matrix(L.MAT_LINV), Linv_ref) < tol_inv
+    assert _rel(eng.get_matrix(L.MAT_KINV), Linv_ref.T @ Linv_ref) < tol_inv
     assert abs(f - f_ref) <= (tol if dtype == "float64" else 2e-5) * abs(f_ref)
-    assert np.max(np.abs(g - g_ref) / np.maximum(1.0, np.abs(g_ref))) < tol * (10 if dtype == "float64" else 100)
+    # gradient of a float fit: measured 7e-5 .. 4e-4 at N = 4096 .. 4600 (tools/grad_error_probe.py,
+    # profiles/r03_grad_error.jsonl), LAPACK's float32 potrf / trtri / gemm on the host reach 7e-6 .. 5e-5 on the same
+    # problems, eps x cond is 1e-2 .. 1e-1: rounding of a float factorisation, five times inside this bound
+    assert np.max(np.abs(g - g_ref) / np.maximum(1.0, np.abs(g_ref))) < (1e-8 if dtype == "float64" else 2e-3)
     # and the two paths agree with each other on predictions
     Xs = synthetic_leaves(300, d)
     m2, v2 = eng.predict(Xs)
@@ -279,13 +296,13 @@ def test_two_level_cholesky_path_matches_oracle(dtype, n, d):
     assert np.max(np.abs(m1 - m2)) < ptol * max(1.0, np.max(np.abs(y))) and np.max(np.abs(v1 - v2)) < ptol
 
 
-@pytest.mark.parametrize("dtype", ["float64", "float32"])
-def test_fit_and_gradient_at_4600_points(dtype):
+@pytest.mark.parametrize("dtype,noise", [("float64", 1e-3), ("float32", 1e-2), ("float32", 1e-3)])
+def test_fit_and_gradient_at_4600_points(dtype, noise):
     """N = 4600 is past the single-level limit and large enough for the 128x128-tile instantiations of
     the LDS-DMA GEMM (rank-256 SYRK, K^-1 = L^-T L^-1) in both element types: NLML, gradient and a few
     predictions against the float64 oracle."""
     n, d = 4600, 8
-    X, y, th = _problem(n, d, noise=1e-3 if dtype == "float64" else 1e-2)
+    X, y, th = _problem(n, d, noise=noise)
     f_ref, g_ref = gpr.nlml_and_grad(th, X, y)
     post = gpr.posterior(th, X, y)
     eng = _engine(dtype)
@@ -299,7 +316,9 @@ def test_fit_and_gradient_at_4600_points(dtype):
         assert np.max(np.abs(mean - mean_ref)) < 1e-8 and np.max(np.abs(var - var_ref)) < 1e-8
     else:
         assert abs(f - f_ref) <= 5e-5 * abs(f_ref)
-        assert np.max(np.abs(g - g_ref) / np.maximum(1.0, np.abs(g_ref))) < 5e-2
+        # measured 7e-5 (both noise levels; LAPACK in float32 on the host: 7e-6 .. 9e-6; eps x cond(K_y) = 1e-2 .. 4e-2):
+        # profiles/r03_grad_error.jsonl
+        assert np.max(np.abs(g - g_ref) / np.maximum(1.0, np.abs(g_ref))) < 2e-3
         assert np.max(np.abs(mean - mean_ref)) < 3e-3 * np.max(np.abs(y))
         assert np.max(np.abs(var - var_ref)) < 3e-4 * th.variance
 
@@ -565,14 +584,15 @@ def test_dimension_and_size_limits():
     assert eng.predict(synthetic_leaves(5, 48))[0].shape == (5,)
 
 
-def test_config_C5_one_gpu_share_at_size():
+@pytest.mark.parametrize("noise", [1e-2, 1e-3])  # 1e-3: SURVEY 8(d)'s and bench.py --workload c5's
+def test_config_C5_one_gpu_share_at_size(noise):
     """Config C5 at its size: D = 40, N_train = 16384, ONE GPU's share of the 1 M leaves = 131 072, in
     float32 and in the split-bf16 modes (the variant the config's "bf16" names here: DESIGN.md 4.1b).
     Size-independent properties on all leaves + the float64 oracle (a CPU potrf at 16384) on a sub-sample."""
     from pygpso_amd import HipGPEngine
 
     n, d, m = 16384, 40, 131072
-    X, y, th = _problem(n, d, variance=1.0, noise=1e-2)
+    X, y, th = _problem(n, d, variance=1.0, noise=noise)
     Xs = synthetic_leaves(m, d).astype(np.float32)
     post = gpr.posterior(th, X, y)
     sub = np.random.default_rng(5).choice(m, 96, replace=False)
@@ -648,7 +668,8 @@ def _c4_posterior(th, X, y):
     return _c4_cache["post"]
 
 
-def test_float_fit_on_the_bf16_matrix_cores_agrees_with_the_f32_path():
+@pytest.mark.parametrize("noise", [1e-2, 1e-3])
+def test_float_fit_on_the_bf16_matrix_cores_agrees_with_the_f32_path(noise):
     """Float fits above the single-level limit run their large products (rank-W trailing updates, level-doubling
     inverse) as 3-way split bf16 products by default (GPSO_OPT_FIT_BF16_SYRK): float-class accuracy.  N = 4096
     (N_pad / panel a power of two: both the update and the inverse take the bf16 path) against the same fit on
@@ -656,7 +677,7 @@ def test_float_fit_on_the_bf16_matrix_cores_agrees_with_the_f32_path():
     from pygpso_amd import HipGPEngine, _lib as L
 
     n, d = 4096, 6
-    X, y, th = _problem(n, d, variance=1.0, noise=1e-2)
+    X, y, th = _problem(n, d, variance=1.0, noise=noise)
     post = gpr.posterior(th, X, y)
     res = {}
     for flag in (1, 0):
@@ -669,15 +690,19 @@ def test_float_fit_on_the_bf16_matrix_cores_agrees_with_the_f32_path():
     for flag in (1, 0):  # each path against the oracle, float tolerances
         f, linv, alpha, chol, g, kinv = res[flag]
         assert abs(f - post.nlml) <= 2e-5 * abs(post.nlml), flag
-        assert np.max(np.abs(g - g_ref) / np.maximum(1.0, np.abs(g_ref))) < 2e-2, flag
+        # measured (profiles/r03_grad_error.jsonl): split-bf16 products 8e-5 / 1.7e-4, f32 MFMA products 3.6e-4 / 3.8e-4 at
+        # noise 1e-2 / 1e-3; LAPACK float32 on the host 4e-5 / 5e-5; eps x cond(K_y) = 1.4e-2 / 1.1e-1
+        assert np.max(np.abs(g - g_ref) / np.maximum(1.0, np.abs(g_ref))) < 2e-3, flag
         assert np.max(np.abs(chol - post.L)) <= 2e-4 * np.max(np.abs(post.L)), flag
-        assert np.max(np.abs(alpha - post.alpha)) <= 2e-3 * np.max(np.abs(post.alpha)), flag
+        # alpha = K_y^-1 (y - c): a forward error, it scales with cond(K_y) = 1.2e5 / 9.3e5 at the two noise levels
+        # (measured 2.4e-3 at 1e-3 on both product paths; eps x cond = 0.11)
+        assert np.max(np.abs(alpha - post.alpha)) <= (2e-3 if noise >= 1e-2 else 1e-2) * np.max(np.abs(post.alpha)), flag
     # and against each other: the split products are float-class
     scale = np.max(np.abs(res[0][1]))
     assert np.max(np.abs(res[1][1] - res[0][1])) <= 2e-4 * scale
     assert np.max(np.abs(res[1][3] - res[0][3])) <= 5e-5 * np.max(np.abs(res[0][3]))
     assert np.max(np.abs(res[1][5] - res[0][5])) <= 2e-4 * np.max(np.abs(res[0][5]))
-    assert np.max(np.abs(res[1][4] - res[0][4]) / np.maximum(1.0, np.abs(res[0][4]))) < 2e-2
+    assert np.max(np.abs(res[1][4] - res[0][4]) / np.maximum(1.0, np.abs(res[0][4]))) < 2e-3
 
 
 @pytest.mark.parametrize("dtype,math", [("float32", "f16x3"), ("float32", "bf16x6"), ("float32", "bf16x3"), ("float32", "native"),

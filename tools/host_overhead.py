@@ -23,6 +23,18 @@ for _ in range(reps):
     dev += eng.last_ms(2)
 wall = (time.perf_counter() - t) / reps * 1e3
 print(f"engine.fit_eval n={n}: wall {wall:.3f} ms/call, device {dev / reps:.3f} ms/call")
+# the optimiser's own call: unconstrained variables in, (f, df/du) out -- transforms and chain rule inside the library
+from oracle import gpr  # (only for the inverse softplus of the starting point)
+u = np.array([gpr.softplus_inv(ls[0]), gpr.softplus_inv(1.0), gpr.softplus_inv(1e-3 - 1e-6), float(y.mean())])
+for _ in range(20):
+    eng.fit_eval_u("Matern52", u, 1, True)
+t = time.perf_counter()
+dev = 0.0
+for _ in range(reps):
+    eng.fit_eval_u("Matern52", u, 1, True)
+    dev += eng.last_ms(2)
+wall = (time.perf_counter() - t) / reps * 1e3
+print(f"engine.fit_eval_u n={n}: wall {wall:.3f} ms/call, device {dev / reps:.3f} ms/call")
 
 from pygpso_amd import GPRSurrogate, kernels
 surr = GPRSurrogate.default()
