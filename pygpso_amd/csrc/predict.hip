@@ -551,9 +551,21 @@ __device__ __forceinline__ void leaf_bf16_gen(bool diag, int lane, int dp4,
                                               bf16x8 (&bfrag)[NS][2], float (&macc)[2]) {
   using MG = Mfma<TG>;
   using vecG = typename MG::vec4;
+#if defined(GPSO_ABL_HALFGEN)  // tools/micro ablation builds (never shipped): generate one column tile, use it twice
+  constexpr int CT = 1;
+#else
   constexpr int CT = 2;
+#endif
   constexpr int XB = 64 * (int)sizeof(TG);
   constexpr TG C2 = (TG)KernScale<KERNEL>::C2;
+#if defined(GPSO_ABL_NOGEN)  // ... or nothing at all: what the apply + DMA + barriers cost alone
+  {
+    u32x4 f = {0x3c003c00u + (unsigned)lane, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+    asm volatile("" : "+v"(f));
+    for (int sp = 0; sp < NS; ++sp) bfrag[sp][0] = bfrag[sp][1] = __builtin_bit_cast(bf16x8, f);
+    return;
+  }
+#endif
   // ---- generate the two 16-point tiles of this k-step (TG) --------------------------------------
   vecG s[2][CT];
 #pragma unroll
@@ -623,6 +635,9 @@ __device__ __forceinline__ void leaf_bf16_gen(bool diag, int lane, int dp4,
       for (int h = 0; h < 4; ++h) f[h] = F16 ? f16_split_pair(p[t][2 * h], p[t][2 * h + 1]) : bf16_split_pair(p[t][2 * h], p[t][2 * h + 1]);
       bfrag[sp][t] = __builtin_bit_cast(bf16x8, f);  // (fp16 pieces travel in the same 16-byte registers)
     }
+#if defined(GPSO_ABL_HALFGEN)
+  for (int sp = 0; sp < NS; ++sp) bfrag[sp][1] = bfrag[sp][0];
+#endif
 }
 
 // apply: acc[rt][t] += sum over the kept piece products, small terms first
