@@ -65,7 +65,8 @@ PEAK_BF16_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak; a split product costs 
 # HBM bytes per launch of the dominant kernel come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
 # cannot be read from inside the process); the committed record of the latest collection:
 PMC_TRAFFIC = {("c3", "native"): "profiles/r02f_pmc_leaf_tiles_c3.json",
-               ("c3", "bf16x6"): "profiles/r02h_pmc_leaf_tiles_bf16x6_c3.json"}
+               ("c3", "bf16x6"): "profiles/r02h_pmc_leaf_tiles_bf16x6_c3.json",
+               ("c3", "f16x3"): "profiles/r03_pmc_leaf_tiles_f16x3_c3.json"}
 
 
 def pmc_traffic(workload, math_mode):
@@ -181,8 +182,10 @@ def split_bf16_report(eng, leaves_dev, leaves_all, varsigma, m_total, flops_per_
             eng.best_ucb(leaves_dev, varsigma)
             ks.append(eng.last_ms(0))
         dt = time.perf_counter() - t0
+        tfl = flops_per_leaf * m_total / (np.mean(ks) * 1e-3) / 1e12
+        bound = PEAK_TFLOPS["float32"] if mode == "native" else PEAK_BF16_TFLOPS / int(mode[-1])
         entry = {"value": m_total * steps / dt, "unit": "predictions/s", "kernel_ms": float(np.mean(ks)),
-                 "algorithmic_tflops": flops_per_leaf * m_total / (np.mean(ks) * 1e-3) / 1e12}
+                 "algorithmic_tflops": tfl, "bound_tflops": bound, "frac_of_bound": tfl / bound}
         if ref is not None:
             mean, var = eng.predict(sample.astype(np.float32))
             entry["max_abs_err_mean_vs_f64_oracle"] = float(np.max(np.abs(mean - ref[0])))

@@ -293,7 +293,7 @@ struct EngineT : Engine {
                       &work, &kinvb, &linv_p, &white, &alpha_f, &alpha, &logdet, &scal, &gpart, &apart,
                       &kinv_diag, &getter_tmp, &leaves_raw, &leaves_s, &lnorm, &pvar, &pmean, &omean, &ovar,
                       &oucb, &segoff, &best, &oidx, &ovals, &linv_b, &st_mean, &st_var, &st_out, &grow_key, &live_cnt,
-                      &best_pos, &gath, &wbase, &ovals2, &bhdr, &pl_L, &pl_X, &pl_XT, &pl_WT})
+                      &best_pos, &gath, &wbase, &ovals2, &bhdr, &pl_L, &pl_X, &pl_XT, &pl_WT, &amax_rows})
       if (b->p) (void)hipFree(b->p);
   }
 
@@ -317,6 +317,20 @@ struct EngineT : Engine {
   size_t split_planes_alloc() const { return (size_t)(math_auto ? 3 : nsplit()) * npad * npad * 2; }
   size_t split_bytes() const { return split_planes_alloc() + 256; }
   float* f16_scale() const { return reinterpret_cast<float*>(static_cast<char*>(linv_b.p) + split_planes_alloc()); }
+  // max |L^-1| of the fp16 split comes out of the fit's own pass over L^-1 (white_kernel leaves row maxima,
+  // alpha_sum_kernel folds them into the scale slot): no extra pass, no memset.  f16_handed_at: where this fit's solve
+  // was told to leave it (cleared by every packing and at the start of every fit).
+  DevBuf amax_rows;
+  const void* f16_handed_at = nullptr;
+  // -> where the fit's pass leaves the maximum, nullptr when the fp16 split does not apply to this posterior
+  float* f16_max_for_fit() {
+    f16_handed_at = nullptr;
+    if constexpr (!kFloatPredict) return nullptr;
+    if (!f16_split() || !bf16_usable()) return nullptr;
+    if (ensure(linv_b, split_bytes()) != GPSO_OK || ensure(amax_rows, (size_t)npad * 4) != GPSO_OK) return nullptr;
+    f16_handed_at = f16_scale();
+    return f16_scale();
+  }
   bool bf16_usable() const { return kFloatPredict && math != GPSO_MATH_NATIVE && !math_native_fallback && npad > 0 && npad % 256 == 0; }
 
   // (re)build the bf16 pieces of L^-1 from the fit-type L^-1 resident in `linv`
@@ -325,8 +339,13 @@ struct EngineT : Engine {
     if (!bf16_usable()) return GPSO_OK;
     int rc = ensure(linv_b, split_bytes());
     if (rc) return rc;
-    if (f16_split()) launch_pack_linv_f16<TF>(st(), as<TF>(linv), n, npad, f16_scale(), linv_b.p);
-    else launch_pack_linv_bf16<TF>(st(), nsplit(), as<TF>(linv), n, npad, linv_b.p);
+    if (f16_split()) {
+      const bool have_max = f16_handed_at != nullptr && f16_handed_at == f16_scale();
+      launch_pack_linv_f16<TF>(st(), as<TF>(linv), n, npad, f16_scale(), linv_b.p, have_max);
+      f16_handed_at = nullptr;
+    } else {
+      launch_pack_linv_bf16<TF>(st(), nsplit(), as<TF>(linv), n, npad, linv_b.p);
+    }
     HIPCHECK(hipGetLastError());
     linv_b_valid = true;
     return GPSO_OK;
@@ -527,6 +546,7 @@ struct EngineT : Engine {
   // a new posterior (or new options): generation starts over -- float unless double was asked for -- and the
   // self-test has to rule again
   void reset_generation() {
+    f16_handed_at = nullptr;  // (a fit that failed between its solve and its packing leaves nothing behind)
     math_native_fallback = false;
     if (math_auto) math = kAutoFirst;  // the ladder starts over with every posterior
     gen_eff32 = kFloatPredict && gen_mode != GPSO_GEN_F64;
@@ -638,15 +658,15 @@ struct EngineT : Engine {
         }
       }
       if (!inv_done) launch_trtri<TF>(s, as<TF>(Lf), as<TF>(linv), as<TF>(work), npad, fit_outer_panel(npad));
+      float* linv_max_out = f16_max_for_fit();  // (may allocate amax_rows: before the argument list below)
       launch_solve_alpha<TF>(s, as<TF>(linv), as<double>(y64), n, npad, mean_c, as<double>(logdet),
                              as<TF>(white), as<TF>(alpha_f), as<double>(apart), as<double>(kinv_diag),
-                             as<double>(scal));
+                             as<double>(scal), alpha.p, sizeof(TP) == 8, as<float>(amax_rows), linv_max_out);
       if (grad)
         launch_gradient<TF>(s, as<TF>(linv), as<TF>(alpha_f), as<double>(xs64), as<double>(xnorm64), n, npad, d, dp,
                             n_ls, ls_dev(), kp, as<TF>(kinvb), (done & 2) != 0, as<double>(gpart),
                             as<double>(scal) + 8, xt_ready ? &planes : nullptr);
-      launch_pack_linv<TF, TP>(s, as<TF>(linv), n, npad, as<TP>(linv_p));
-      launch_convert_vec<TF, TP>(s, as<TF>(alpha_f), as<TP>(alpha), npad);
+      launch_pack_linv<TF, TP>(s, as<TF>(linv), n, npad, as<TP>(linv_p));  // (alpha's predict-type copy: alpha_sum_kernel)
       small_tile_rows = 8;
     }
     if ((rc = pack_bf16())) return rc;

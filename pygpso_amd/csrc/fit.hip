@@ -2102,21 +2102,49 @@ template void launch_pack_linv<double, float>(hipStream_t, const double*, int64_
 // single-RHS solves through L^-1 and the NLML
 // =============================================================================================
 // white[i] = sum_{k<=i} Linv[i][k] (y[k] - c): one wave per row, wavefront reduction
+// amax_rows != nullptr: the pass also leaves max_k |L^-1[i][k]| of every row there (alpha_sum_kernel folds them) -- the
+// fp16 split of the predict path scales L^-1 by the maximum (predict.hip: pack_linv_f16_kernel), and this kernel reads
+// every entry anyway.  (One atomicMax per wave on a single address instead: 2 048 of them serialise in the L2, 20 us.)
 template <typename T>
 __global__ __launch_bounds__(256) void white_kernel(const T* __restrict__ linv,
                                                     const double* __restrict__ y64, int64_t n,
                                                     int64_t npad, double mean_c,
-                                                    T* __restrict__ white) {
+                                                    T* __restrict__ white, float* __restrict__ amax_rows) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * 4 + wave;
   if (i >= npad) return;
   double acc = 0.0;
+  float m = 0.0f;
   if (i < n) {
-#pragma unroll 4
-    for (int64_t k = lane; k <= i; k += 64) acc += (double)linv[i * npad + k] * (y64[k] - mean_c);
+    // (the loads of four steps are issued before the first is used: one row per wave, nothing else hides the latency)
+    const T* row = linv + i * npad;
+    int64_t k = lane;
+    for (; k + 192 <= i; k += 256) {
+      T l[4];
+      double r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        l[u] = row[k + 64 * u];
+        r[u] = y64[k + 64 * u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc += (double)l[u] * (r[u] - mean_c);
+        m = fmaxf(m, fabsf((float)l[u]));
+      }
+    }
+    for (; k <= i; k += 64) {
+      const T l = row[k];
+      acc += (double)l * (y64[k] - mean_c);
+      m = fmaxf(m, fabsf((float)l));
+    }
   }
   acc = wave_sum(acc);
   if (lane == 0) white[i] = (T)acc;
+  if (amax_rows != nullptr) {
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (lane == 0) amax_rows[i] = m;
+  }
 }
 
 // alpha[j] = sum_{i>=j} Linv[i][j] white[i].  Stage 1: block (column block cb, row chunk rc of 64
@@ -2153,20 +2181,53 @@ __global__ __launch_bounds__(256) void alpha_part_kernel(const T* __restrict__ l
   }
 }
 
+// (the chunks are summed in order -- deterministic -- but their loads are issued eight at a time: 8 workgroups with
+// 64 dependent loads per thread took 11.8 us at N = 2048)
+// alpha_p: the predict-type copy of alpha (float, or double when alpha_p_f64) written in the same pass
 template <typename T>
 __global__ __launch_bounds__(256) void alpha_sum_kernel(const double* __restrict__ part,
                                                         const double* __restrict__ part_sq, int nchunk,
                                                         int64_t npad, T* __restrict__ alpha,
-                                                        double* __restrict__ kinv_diag) {
+                                                        double* __restrict__ kinv_diag, void* __restrict__ alpha_p,
+                                                        int alpha_p_f64, const float* __restrict__ amax_rows,
+                                                        float* __restrict__ amax_out) {
+  if (amax_rows != nullptr && blockIdx.x == 0) {  // max |L^-1| from white_kernel's row maxima (N_pad >= 256 here)
+    __shared__ float shm[4];
+    float m = 0.0f;
+    for (int64_t r = threadIdx.x; r < npad; r += 256) m = fmaxf(m, amax_rows[r]);
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) amax_out[0] = fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]));
+  }
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= npad) return;
   double acc = 0.0, sq = 0.0;
-  for (int c = 0; c < nchunk; ++c) {
+  int c = 0;
+  for (; c + 8 <= nchunk; c += 8) {
+    double a[8], q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a[u] = part[(int64_t)(c + u) * npad + j];
+      q[u] = part_sq[(int64_t)(c + u) * npad + j];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc += a[u];
+      sq += q[u];
+    }
+  }
+  for (; c < nchunk; ++c) {
     acc += part[(int64_t)c * npad + j];
     sq += part_sq[(int64_t)c * npad + j];
   }
-  alpha[j] = (T)acc;
+  const T al = (T)acc;
+  alpha[j] = al;
   kinv_diag[j] = sq;
+  if (alpha_p != nullptr) {
+    if (alpha_p_f64) static_cast<double*>(alpha_p)[j] = (double)al;
+    else static_cast<float*>(alpha_p)[j] = (float)al;
+  }
 }
 
 template <typename T>
@@ -2197,20 +2258,22 @@ __global__ __launch_bounds__(256) void nlml_kernel(const T* __restrict__ white, 
 template <typename T>
 void launch_solve_alpha(hipStream_t st, const T* linv, const double* y64, int64_t n, int64_t npad,
                         double mean_c, const double* diag64, T* white, T* alpha,
-                        double* alpha_part, double* kinv_diag, double* nlml_out) {
+                        double* alpha_part, double* kinv_diag, double* nlml_out, void* alpha_p, int alpha_p_f64,
+                        float* amax_rows, float* linv_absmax) {
+  if (linv_absmax == nullptr) amax_rows = nullptr;
   hipLaunchKernelGGL((white_kernel<T>), dim3((unsigned)(npad / 4)), dim3(256), 0, st, linv, y64, n,
-                     npad, mean_c, white);
+                     npad, mean_c, white, amax_rows);
   const int nchunk = (int)((npad + kAlphaChunk - 1) / kAlphaChunk);
   double* part_sq = alpha_part + (size_t)nchunk * npad;
   hipLaunchKernelGGL((alpha_part_kernel<T>), dim3((unsigned)(npad / 64), (unsigned)nchunk), dim3(256),
                      0, st, linv, white, n, npad, alpha_part, part_sq);
   hipLaunchKernelGGL((alpha_sum_kernel<T>), dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, st,
-                     alpha_part, part_sq, nchunk, npad, alpha, kinv_diag);
+                     alpha_part, part_sq, nchunk, npad, alpha, kinv_diag, alpha_p, alpha_p_f64, amax_rows, linv_absmax);
   if (nlml_out)
     hipLaunchKernelGGL((nlml_kernel<T>), dim3(1), dim3(256), 0, st, white, n, diag64, nlml_out);
 }
-template void launch_solve_alpha<float>(hipStream_t, const float*, const double*, int64_t, int64_t, double, const double*, float*, float*, double*, double*, double*);
-template void launch_solve_alpha<double>(hipStream_t, const double*, const double*, int64_t, int64_t, double, const double*, double*, double*, double*, double*, double*);
+template void launch_solve_alpha<float>(hipStream_t, const float*, const double*, int64_t, int64_t, double, const double*, float*, float*, double*, double*, double*, void*, int, float*, float*);
+template void launch_solve_alpha<double>(hipStream_t, const double*, const double*, int64_t, int64_t, double, const double*, double*, double*, double*, double*, double*, void*, int, float*, float*);
 
 // =============================================================================================
 // analytic gradient of the NLML  

@@ -56,8 +56,11 @@ int launch_leaf_tiles_bf16(hipStream_t st, int nsplit, const void* linv_b, const
                            const TG* lnorm, double* part_var, double* part_mean, int64_t npad,
                            int dp4, int64_t mpad, const KernParams& kp, const int64_t* m_live,
                            const float* f16_inv_scale_a = nullptr);
+// scal: 2 device floats -- [0] max |L^-1|, [1] := 2^-sa.  have_max false: the maximum is computed here first (memset +
+// absmax_kernel); true: the fit left it in scal[0] (launch_solve_alpha: its own pass over L^-1).
 template <typename TF>
-void launch_pack_linv_f16(hipStream_t st, const TF* linv, int64_t n, int64_t npad, float* scal /* [2] device */, void* linv_b);
+void launch_pack_linv_f16(hipStream_t st, const TF* linv, int64_t n, int64_t npad, float* scal, void* linv_b,
+                          bool have_max = false);
 void launch_leaf_finalize(hipStream_t st, const double* part_var, const double* part_mean, int nbi,
                           int64_t mpad, int64_t m, const KernParams& kp, double varsigma,
                           double* mean, double* var, double* ucb);
@@ -137,7 +140,8 @@ template <typename T>
 void launch_solve_alpha(hipStream_t st, const T* linv, const double* y64, int64_t n, int64_t npad,
                         double mean_c, const double* diag64, T* white, T* alpha,
                         double* alpha_part /* alpha_part_doubles(npad) scratch */, double* kinv_diag,
-                        double* nlml_out);
+                        double* nlml_out, void* alpha_p = nullptr /* predict-type copy of alpha */, int alpha_p_f64 = 0,
+                        float* amax_rows = nullptr /* [npad] scratch */, float* linv_absmax = nullptr /* receives max |L^-1| */);
 // Kinv = L^-T L^-1 (lower tiles; skipped when kinv_ready), then the gradient reductions of SURVEY.md A.3;
 // grad_out[n_ls + 3] = d nlml / d (ls..., variance, noise, c)
 template <typename T>

@@ -487,21 +487,29 @@ __device__ __forceinline__ unsigned f16_split_pair(float& a, float& b) {
 }
 
 // max |linv| over the lower triangle of the first n rows -> out[0] (as float bits: non-negative floats order like
-// unsigned integers); out[0] must be zero on entry
+// unsigned integers); out[0] must be zero on entry.  One workgroup per 16 rows, 16 lanes per row, four columns per load.
 template <typename TF>
 __global__ __launch_bounds__(256) void absmax_kernel(const TF* __restrict__ linv, int64_t n, int64_t npad,
                                                      unsigned* __restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   float m = 0.0f;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n * npad; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = idx / npad, c = idx - r * npad;
-    if (c <= r) m = fmaxf(m, fabsf((float)linv[idx]));
+  if (r < n) {
+    const TF* row = linv + r * npad;
+    for (int64_t c = 4 * (threadIdx.x & 15); c <= r; c += 64) {  // (npad is a multiple of 64: c + 3 < npad)
+      TF v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = row[c + j];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c + j <= r) m = fmaxf(m, fabsf((float)v[j]));
+    }
   }
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned, m));
+  if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(out, __builtin_bit_cast(unsigned, m));
 }
 
-// fp16 pieces of L^-1 2^sa in the fragment order of pack_linv_bf16_kernel<2>; scal[0] = max |L^-1| (absmax_kernel),
-// scal[1] := 2^-sa (read by the predict kernel's epilogue)
+// fp16 pieces of L^-1 2^sa in the fragment order of pack_linv_bf16_kernel<2>; scal[0] = max |L^-1| (absmax_kernel, or
+// the fit's own pass over L^-1: fit.hip white_kernel / alpha_sum_kernel), scal[1] := 2^-sa (read by the predict kernel's epilogue)
 template <typename TF>
 __global__ __launch_bounds__(256) void pack_linv_f16_kernel(const TF* __restrict__ linv, int64_t n, int64_t npad,
                                                             float* __restrict__ scal, u32x4* __restrict__ out) {
@@ -917,15 +925,19 @@ void launch_pack_linv_bf16(hipStream_t st, int nsplit, const TF* linv, int64_t n
     hipLaunchKernelGGL((pack_linv_bf16_kernel<2, TF>), grid, dim3(256), 0, st, linv, n, npad, static_cast<u32x4*>(linv_b));
 }
 template <typename TF>
-void launch_pack_linv_f16(hipStream_t st, const TF* linv, int64_t n, int64_t npad, float* scal, void* linv_b) {
-  (void)hipMemsetAsync(scal, 0, 8, st);
-  hipLaunchKernelGGL((absmax_kernel<TF>), dim3(512), dim3(256), 0, st, linv, n, npad, reinterpret_cast<unsigned*>(scal));
+void launch_pack_linv_f16(hipStream_t st, const TF* linv, int64_t n, int64_t npad, float* scal, void* linv_b,
+                          bool have_max) {
+  if (!have_max) {
+    (void)hipMemsetAsync(scal, 0, 4, st);
+    hipLaunchKernelGGL((absmax_kernel<TF>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, linv, n, npad,
+                       reinterpret_cast<unsigned*>(scal));
+  }
   const int64_t total = (npad / 16) * (npad / 32) * 64;
   hipLaunchKernelGGL((pack_linv_f16_kernel<TF>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, linv, n, npad,
                      scal, static_cast<u32x4*>(linv_b));
 }
-template void launch_pack_linv_f16<float>(hipStream_t, const float*, int64_t, int64_t, float*, void*);
-template void launch_pack_linv_f16<double>(hipStream_t, const double*, int64_t, int64_t, float*, void*);
+template void launch_pack_linv_f16<float>(hipStream_t, const float*, int64_t, int64_t, float*, void*, bool);
+template void launch_pack_linv_f16<double>(hipStream_t, const double*, int64_t, int64_t, float*, void*, bool);
 template void launch_pack_linv_bf16<float>(hipStream_t, int, const float*, int64_t, int64_t, void*);
 template void launch_pack_linv_bf16<double>(hipStream_t, int, const double*, int64_t, int64_t, void*);
 

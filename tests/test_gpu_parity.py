@@ -697,12 +697,17 @@ def test_float_fit_on_the_bf16_matrix_cores_agrees_with_the_f32_path(noise):
         # alpha = K_y^-1 (y - c): a forward error, it scales with cond(K_y) = 1.2e5 / 9.3e5 at the two noise levels
         # (measured 2.4e-3 at 1e-3 on both product paths; eps x cond = 0.11)
         assert np.max(np.abs(alpha - post.alpha)) <= (2e-3 if noise >= 1e-2 else 1e-2) * np.max(np.abs(post.alpha)), flag
-    # and against each other: the split products are float-class
+    # and against each other: the split products are float-class.  Both are float factorisations of the same matrix:
+    # they differ by rounding amplified by the conditioning -- L^-1 by cond(L) = sqrt(cond(K_y)) (340 / 960 at the two
+    # noise levels), K^-1 by cond(K_y) (1.2e5 / 9.3e5); measured at noise 1e-3: 3.6e-4 on L^-1
+    amp = 1.0 if noise >= 1e-2 else 4.0
     scale = np.max(np.abs(res[0][1]))
-    assert np.max(np.abs(res[1][1] - res[0][1])) <= 2e-4 * scale
-    assert np.max(np.abs(res[1][3] - res[0][3])) <= 5e-5 * np.max(np.abs(res[0][3]))
-    assert np.max(np.abs(res[1][5] - res[0][5])) <= 2e-4 * np.max(np.abs(res[0][5]))
-    assert np.max(np.abs(res[1][4] - res[0][4]) / np.maximum(1.0, np.abs(res[0][4]))) < 2e-3
+    ratios = {"linv": np.max(np.abs(res[1][1] - res[0][1])) / (2e-4 * amp * scale),
+              "chol": np.max(np.abs(res[1][3] - res[0][3])) / (5e-5 * np.max(np.abs(res[0][3]))),
+              "kinv": np.max(np.abs(res[1][5] - res[0][5])) / (2e-4 * amp * amp * np.max(np.abs(res[0][5]))),
+              "grad": np.max(np.abs(res[1][4] - res[0][4]) / np.maximum(1.0, np.abs(res[0][4]))) / 2e-3}
+    print("measured / tolerance:", {k: round(float(v), 3) for k, v in ratios.items()})
+    assert all(v <= 1.0 for v in ratios.values()), ratios
 
 
 @pytest.mark.parametrize("dtype,math", [("float32", "f16x3"), ("float32", "bf16x6"), ("float32", "bf16x3"), ("float32", "native"),

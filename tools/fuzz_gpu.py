@@ -26,7 +26,7 @@ for case in range(N_CASES):
     ard = bool(rng.random() < 0.3) and d > 1
     math = "native"
     if dtype != "float64":
-        math = str(rng.choice(["native", "bf16x6", "bf16x3"]))
+        math = str(rng.choice(["native", "bf16x6", "bf16x3", "f16x3", "auto"]))
     # float engines are exercised down to GPflow's noise floor (1e-6): there they must be right or refuse
     noise = float(rng.choice([1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1])) if dtype != "float64" else float(rng.choice([1e-6, 1e-4, 1e-2]))
     X, y = synthetic_problem(n, d, seed=int(rng.integers(1 << 30)))

@@ -38,7 +38,9 @@ using namespace gpso;
 
 int main(int argc, char** argv) {
   const int64_t npad = 2048, m = 65536;
-  const int dp4 = 3, dp = 12, ns = 3;
+  const bool f16 = argc > 1 && argv[1][0] == 'f';    // "f": the fp16 split (two planes, three products)
+  const bool x3 = f16 || (argc > 1 && argv[1][0] == '3');  // "3": bf16 x3
+  const int dp4 = 3, dp = 12, ns = x3 ? 2 : 3;
   std::vector<float> linv((size_t)npad * npad, 0.f), xsp(npad * dp), xn(npad), al(npad), lv(m * dp), ln(m);
   unsigned s = 1; auto rnd = [&] { s = s * 1664525u + 1013904223u; return (float)(s >> 8) / (1 << 24); };
   for (int64_t i = 0; i < npad; ++i)
@@ -51,7 +53,8 @@ int main(int argc, char** argv) {
   float *dl, *dx, *dn, *da, *dlv, *dln; double *pv, *pm; void* lb;
   hipMalloc(&dl, linv.size() * 4); hipMalloc(&dx, xsp.size() * 4); hipMalloc(&dn, npad * 4); hipMalloc(&da, npad * 4);
   hipMalloc(&dlv, lv.size() * 4); hipMalloc(&dln, m * 4); hipMalloc(&pv, 8 * m * 8); hipMalloc(&pm, 8 * m * 8);
-  hipMalloc(&lb, (size_t)ns * npad * npad * 2);
+  hipMalloc(&lb, (size_t)ns * npad * npad * 2 + 256);
+  float* f16_scal = reinterpret_cast<float*>(static_cast<char*>(lb) + (size_t)ns * npad * npad * 2);
   hipMemcpy(dl, linv.data(), linv.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dx, xsp.data(), xsp.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(dn, xn.data(), npad * 4, hipMemcpyHostToDevice); hipMemcpy(da, al.data(), npad * 4, hipMemcpyHostToDevice);
   hipMemcpy(dlv, lv.data(), lv.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dln, ln.data(), m * 4, hipMemcpyHostToDevice);
@@ -65,6 +68,8 @@ int main(int argc, char** argv) {
     hipMalloc(&dxw, (size_t)(npad / 32) * leaf_bf16w_dpw(dp) * 64 * 4);
     launch_gen_inputs_wide(0, dxs, npad, dp, dp, 0, dxw);
     launch_pack_linv_bf16w<float>(0, ns, dl, npad, npad, lb);
+  } else if (f16) {
+    launch_pack_linv_f16<float>(0, dl, npad, npad, f16_scal, lb);
   } else {
     launch_pack_linv_bf16<float>(0, ns, dl, npad, npad, lb);
   }
@@ -74,13 +79,13 @@ int main(int argc, char** argv) {
     hipEventRecord(e0, 0);
     if (stream) launch_leaf_tiles_bf16s(0, ns, lb, dxw, da, dlv, dln, pv, pm, npad, dp, dp, m, kp, nullptr);
     else if (wide) launch_leaf_tiles_bf16w(0, ns, lb, dxw, da, dlv, dln, pv, pm, npad, dp, dp, m, kp, nullptr);
-    else launch_leaf_tiles_bf16<float>(0, ns, lb, dx, dn, da, dlv, dln, pv, pm, npad, dp4, m, kp, nullptr);
+    else launch_leaf_tiles_bf16<float>(0, ns, lb, dx, dn, da, dlv, dln, pv, pm, npad, dp4, m, kp, nullptr, f16 ? f16_scal : nullptr);
     hipEventRecord(e1, 0);
     hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     std::vector<long long> g(2 * 64 * 8);
     hipMemcpyFromSymbol(g.data(), HIP_SYMBOL(g_bst), g.size() * 8);
-    printf("%s kernel %.3f ms (with stamps)\n", wide ? "32x32x16" : "16x16x32", ms);
+    printf("%s%s kernel %.3f ms (with stamps)\n", wide ? "32x32x16" : "16x16x32", f16 ? " fp16 x3" : (x3 ? " bf16 x3" : " bf16 x6"), ms);
     if (stream) {  // wave 0 of the heaviest workgroup: begin | contraction done | group 7 done | DMA issued | group 15 done | DMA landed | (barrier)
       double seg[6] = {0, 0, 0, 0, 0, 0}; int cnt = 0;
       for (int q = 8; q < 52; ++q) {

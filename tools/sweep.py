@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """N x D sweep of SURVEY.md section 8(d) on one GPU (float32, Matern-5/2, synthetic data as in bench.py):
 posterior-fit ms, NLML+gradient ms (median of 5 after 2 warm-ups, device time) and the leaf-UCB predict
-rate with the achieved fraction of the bound of the math in use (f32 MFMA peak, or dense bf16 peak / 6 for split-bf16 x6).  Prints one JSON line per (N, D)."""
+rate with the achieved fraction of the bound of the math in use (f32 MFMA peak, dense bf16 peak / 6 for split-bf16 x6, dense fp16 peak / 3 for the fp16 split).  Prints one JSON line per (N, D)."""
 import json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -47,7 +47,7 @@ for n in NS:
         kms = med(pred, reps=3, warm=1)
         flops = (float(n) * n + 2.0 * n * d + 20.0 * n) * m
         math = eng.precision_info()["predict_math"]  # what GPSO_MATH_AUTO settled on for this posterior
-        bound = {"native": PEAK, "bf16x6": 2500e12 / 6, "bf16x3": 2500e12 / 3}[math]
+        bound = {"native": PEAK, "bf16x6": 2500e12 / 6, "bf16x3": 2500e12 / 3, "f16x3": 2500e12 / 3}[math]
         print(json.dumps({"N": n, "D": d, "fit_posterior_ms": round(post, 4), "fit_nlml_grad_ms": round(grad, 4),
                           "leaves": m, "predict_math": math, "leaf_tiles_ms": round(kms, 4),
                           "predictions_per_s_kernel": round(m / (kms * 1e-3)),
