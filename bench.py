@@ -351,7 +351,11 @@ def main():
                 "traffic_source": traffic_src,
                 "algorithmic_bytes": int((hi - lo) * (d + 3) * (4 if dtype == "float32" else 8)
                                          + (n * n // 2 + n * d + n) * (4 if dtype == "float32" else 8)),
-                "kernel_ms": kern_ms, "flops_per_leaf": flops_per_leaf, "leaves_per_launch": hi - lo,
+                "kernel_ms": kern_ms,
+                # the same algorithmic flops against round 2's bound (six bf16 MFMAs per product): the fp16 split does
+                # half the matrix work for an f32-class product, so the figures of the two rounds compare on this line
+                **({"achieved_over_bf16x6_bound": achieved / (PEAK_BF16_TFLOPS / 6)} if math_mode == "f16x3" else {}),
+                "flops_per_leaf": flops_per_leaf, "leaves_per_launch": hi - lo,
             },
         }
         post = None
