@@ -16,7 +16,7 @@ from tests.helpers import synthetic_problem, synthetic_leaves
 
 REPEATS = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 total_bad = 0
-cases = list(itertools.product(["float32", "mixed", "float64"], ["native", "bf16x6", "bf16x3"],
+cases = list(itertools.product(["float32", "mixed", "float64"], ["native", "f16x3", "bf16x6", "bf16x3"],
                                [1, 3, 6, 12, 40], [200, 512, 1024], ["Matern32", "SquaredExponential"]))
 for dtype, math, d, n, kernel in cases:
     if dtype == "float64" and math != "native":
