@@ -430,7 +430,17 @@ __device__ __forceinline__ void chol_panel16(double* Ls, F* Cs, int c0, int lane
 }
 
 // (scratch: 8 KB that nothing else uses until trinv64_lds -- its Ts)
-template <int NEWTON, typename T, bool F32CHAIN = false>
+// EARLY (the step kernel's diagonal role): the waves that idle while wave 0 factors panels 2 and 3 form the products
+// of the block inverse that only need finished panels -- panel 2: T10 = L10 X00 (wave 3); panel 3: X10 = -X11 T10, then
+// the k <= 31 tiles of T = L21 [X00 0; X10 X11] (wave 3), its other two tiles (wave 2, behind its stores) and
+// T32 = L32 X22 (wave 1, behind the diagonal inverse it has just formed) -- so that trinv64_lds<.., EARLY> is left with
+// three stages instead of five on the pivot chain.  The products wait in the parts of Xs ABOVE its diagonal blocks,
+// which nothing reads (every store of the inverse masks them): block (0,1) T10, block (2,3) T32, rows 0-31 x columns
+// 32-63 T.  Same operations on the same operands as trinv64_lds's own stages: same bits.
+__device__ __forceinline__ double* early_t10(double* Xs) { return Xs + kPB; }
+__device__ __forceinline__ double* early_t32(double* Xs) { return Xs + 2 * kPB * kDS + 3 * kPB; }
+__device__ __forceinline__ double* early_t(double* Xs) { return Xs + 2 * kPB; }
+template <int NEWTON, typename T, bool F32CHAIN = false, bool EARLY = false>
 __device__ __forceinline__ void chol64_lds(double* Ls, double* Xs, T* __restrict__ Lout, int64_t ld,
                                            int64_t k0, int64_t n, int* info, double* scratch) {
   const int tid = threadIdx.x, lane = tid & 63;
@@ -442,8 +452,39 @@ __device__ __forceinline__ void chol64_lds(double* Ls, double* Xs, T* __restrict
       else chol_panel16<double, NEWTON>(Ls, scratch, c0, lane);
     } else if (wave == 1 && c0 > 0) {
       for (int cb = 0; cb < kPB; cb += 4) diag_inv16(Ls, Xs, c0 - kPB, cb, lane);
+      if (EARLY && c0 == 3 * kPB) {  // X22 is this wave's own work of a moment ago; L32 is final since panel 2
+        const f64x4 t = mma16_lds<kPB>(Ls + 3 * kPB * kDS + 2 * kPB, kDS, 1, Xs + 2 * kPB * kDS + 2 * kPB, kDS, 1, lane);
+        double* t32 = early_t32(Xs);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t32[((lane >> 4) + 4 * r) * kDS + (lane & 15)] = t[r];
+      }
     } else if (wave == 2 && c0 > 0) {
       lower_cols_to_global<T>(Ls, Lout, ld, lane, c0 - kPB);
+      if (EARLY && c0 == 3 * kPB) {  // T[a][1] = L21[a][1] X11: X11 was finished during panel 2
+        for (int a = 0; a < 2; ++a) {
+          const f64x4 t = mma16_lds<16>(Ls + (32 + kPB * a) * kDS + kPB, kDS, 1, Xs + kPB * kDS + kPB, kDS, 1, lane);
+          double* tt = early_t(Xs);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tt[(kPB * a + (lane >> 4) + 4 * r) * kDS + kPB + (lane & 15)] = t[r];
+        }
+      }
+    } else if (EARLY && wave == 3 && c0 == 2 * kPB) {  // T10 = L10 X00 (X00: finished during panel 1)
+      const f64x4 t = mma16_lds<kPB>(Ls + kPB * kDS, kDS, 1, Xs, kDS, 1, lane);
+      double* t10 = early_t10(Xs);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t10[((lane >> 4) + 4 * r) * kDS + (lane & 15)] = t[r];
+    } else if (EARLY && wave == 3 && c0 == 3 * kPB) {
+      {  // X10 = -X11 T10
+        const f64x4 x = mma16_lds<kPB>(Xs + kPB * kDS + kPB, kDS, 1, early_t10(Xs), kDS, 1, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xs[(kPB + (lane >> 4) + 4 * r) * kDS + (lane & 15)] = -x[r];
+      }
+      for (int a = 0; a < 2; ++a) {  // T[a][0] = L21[a][0:2] [X00; X10]
+        const f64x4 t = mma16_lds<32>(Ls + (32 + kPB * a) * kDS, kDS, 1, Xs, kDS, 1, lane);
+        double* tt = early_t(Xs);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tt[(kPB * a + (lane >> 4) + 4 * r) * kDS + (lane & 15)] = t[r];
+      }
     }
     __syncthreads();
     GPSO_STAMP(2 * (c0 / kPB) + 1);
@@ -484,9 +525,10 @@ constexpr int kTsLd = 33;                  // row stride of the 32x32 scratch
 constexpr int kTsDoubles = 32 * kTsLd;
 // Lout != nullptr: waves 2 and 3, idle in the level-16 stages, store the last 16 columns of the L
 // tile there (chol64_lds stored the others beside the factorisation).
-template <bool FIRST3_DONE, typename T>
+template <bool FIRST3_DONE, typename T, bool EARLY = false>
 __device__ __forceinline__ void trinv64_lds(const double* Ls, double* Xs,
                                             double* Ts /* [32][33] scratch */, T* Lout, int64_t ld) {
+  static_assert(!EARLY || FIRST3_DONE, "the early products are formed beside the factorisation (chol64_lds<.., EARLY>)");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   GPSO_STAMP(8);
@@ -497,6 +539,32 @@ __device__ __forceinline__ void trinv64_lds(const double* Ls, double* Xs,
   }
   __syncthreads();
   GPSO_STAMP(9);
+  if constexpr (EARLY) {
+    // X10, T32 and T are there already: X32 = -X33 T32, then X21 = -X22' T
+    if (wave == 1) {
+      const f64x4 x = mma16_lds<kPB>(Xs + 3 * kPB * kDS + 3 * kPB, kDS, 1, early_t32(Xs), kDS, 1, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Xs[(3 * kPB + (lane >> 4) + 4 * r) * kDS + 2 * kPB + (lane & 15)] = -x[r];
+    } else if (Lout != nullptr && lane < kPB) {
+      if (wave == 2) lower_cols_to_global<T, 0, 2>(Ls, Lout, ld, 3 * kPB + lane, 3 * kPB);
+      if (wave == 3) lower_cols_to_global<T, 2, 4>(Ls, Lout, ld, 3 * kPB + lane, 3 * kPB);
+    }
+    __syncthreads();
+    GPSO_STAMP(12);
+    {
+      const int a = wave >> 1, b = wave & 1;
+      const double* Ab = Xs + (32 + kPB * a) * kDS + 32;
+      const double* tt = early_t(Xs);
+      const f64x4 x = (a == 1) ? mma16_lds<32>(Ab, kDS, 1, tt + kPB * b, kDS, 1, lane)
+                               : mma16_lds<16>(Ab, kDS, 1, tt + kPB * b, kDS, 1, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        Xs[(32 + kPB * a + (lane >> 4) + 4 * r) * kDS + kPB * b + (lane & 15)] = -x[r];
+    }
+    __syncthreads();
+    GPSO_STAMP(13);
+    return;
+  }
   // level 16: blocks (1,0) and (3,2)
   if (wave < 2) {
     const int jb = 2 * wave, ib = jb + 1;
@@ -1723,11 +1791,11 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
     GPSO_STAMP(15);
     // (row_base: global row of this sub-matrix's first row -- pivot indices, padding test and the
     // diagonal go by global row; every tile address above is relative to the sub-matrix)
-    chol64_lds<(sizeof(T) == 4) ? 1 : 2, T, sizeof(T) == 4>(Ls, Xs, Lf + k0 * ld + k0, ld, row_base + k0, n, info, Ts);
+    chol64_lds<(sizeof(T) == 4) ? 1 : 2, T, sizeof(T) == 4, true>(Ls, Xs, Lf + k0 * ld + k0, ld, row_base + k0, n, info, Ts);
     // the unrounded diagonal: its logarithms are summed by nlml_kernel, off this chain
     if (tid < kFitBlock) diag64[row_base + k0 + tid] = Ls[tid * kDS + tid];
     GPSO_STAMP(7);
-    trinv64_lds<true, T>(Ls, Xs, Ts, Lf + k0 * ld + k0, ld);
+    trinv64_lds<true, T, true>(Ls, Xs, Ts, Lf + k0 * ld + k0, ld);
     lower_tile_to_global<T>(Xs, linv + k0 * ld + k0, ld, tid);
     GPSO_STAMP(16);
     return;

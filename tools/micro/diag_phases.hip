@@ -41,7 +41,8 @@ int main(int argc, char** argv) {
            ms * 1e3, (long long)(n / 64), inf == imax ? -1 : inf, g[17] - g[14], g[18] - g[17], g[15] - g[18]);
     for (int i = 1; i < 7; ++i) printf(" %lld", g[i] - g[i - 1]);
     printf(" | last panel+check %lld | trinv:", g[7 + 1] - g[6] - (g[8] - g[7]));
-    for (int i = 8; i < 14; ++i) printf(" %lld", g[i] - g[i - 1]);
+    // (the step kernel's diagonal role forms part of the inverse beside the panels -- chol64_lds<.., EARLY>: stamps 10 / 11 do not exist)
+    printf(" %lld %lld %lld %lld", g[8] - g[7], g[9] - g[8], g[12] - g[9], g[13] - g[12]);
     printf(" | store %lld | total %lld\n", g[16] - g[13], g[16] - g[14]);
   }
   return 0;
