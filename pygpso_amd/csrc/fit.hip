@@ -445,8 +445,25 @@ __device__ __forceinline__ void chol64_lds(double* Ls, double* Xs, T* __restrict
                                            int64_t k0, int64_t n, int* info, double* scratch) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // trailing update on the f64 MFMA: tile t of the lower triangle (row-major) right of panel p,
+  // A[ib][mb] -= L[ib][panel] L[mb][panel]^T
+  auto update_tile = [&](int p, int t) {
+    int ib = 0, mb = t;
+    while (mb > ib) {
+      mb -= ib + 1;
+      ++ib;
+    }
+    const int c = p * kPB, r0 = (p + 1 + ib) * kPB, m0 = (p + 1 + mb) * kPB;
+    const f64x4 d = mma16_lds<kPB>(Ls + r0 * kDS + c, kDS, 1, Ls + m0 * kDS + c, 1, kDS, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ls[(r0 + (lane >> 4) + 4 * r) * kDS + m0 + (lane & 15)] -= d[r];
+  };
   for (int c0 = 0; c0 < kFitBlock; c0 += kPB) {
     GPSO_STAMP(2 * (c0 / kPB));
+    // EARLY: the two tiles of panel 0's update that panel 1 does not read -- (3,2) and (3,3) -- are left to waves 2 and
+    // 3 beside panel 1 (one round of four tiles behind panel 0 instead of two); they are in place before the update of
+    // panel 1 touches the same tiles, so every entry still receives its updates in the order 0, 1, 2
+    if (EARLY && c0 == kPB && wave >= 2) update_tile(0, wave + 2);
     if (wave == 0) {
       if constexpr (F32CHAIN) chol_panel16<float, NEWTON>(Ls, reinterpret_cast<float*>(scratch), c0, lane);
       else chol_panel16<double, NEWTON>(Ls, scratch, c0, lane);
@@ -488,21 +505,11 @@ __device__ __forceinline__ void chol64_lds(double* Ls, double* Xs, T* __restrict
     }
     __syncthreads();
     GPSO_STAMP(2 * (c0 / kPB) + 1);
-    // trailing update on the f64 MFMA: for the 16x16 tiles (ib >= mb) right of the panel,
-    // A[ib][mb] -= L[ib][panel] L[mb][panel]^T; one tile per wave and step
+    // trailing update: one tile per wave and step
     {
       const int p = c0 / kPB, nt = 3 - p;  // trailing tiles per side
-      for (int t = wave; t < nt * (nt + 1) / 2; t += 4) {
-        int ib = 0, mb = t;  // t -> (ib, mb) in the lower triangle, row-major
-        while (mb > ib) {
-          mb -= ib + 1;
-          ++ib;
-        }
-        const int r0 = (p + 1 + ib) * kPB, m0 = (p + 1 + mb) * kPB;
-        const f64x4 d = mma16_lds<kPB>(Ls + r0 * kDS + c0, kDS, 1, Ls + m0 * kDS + c0, 1, kDS, lane);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Ls[(r0 + (lane >> 4) + 4 * r) * kDS + m0 + (lane & 15)] -= d[r];
-      }
+      const int ntile = (EARLY && p == 0) ? 4 : nt * (nt + 1) / 2;
+      for (int t = wave; t < ntile; t += 4) update_tile(p, t);
     }
     __syncthreads();
   }
