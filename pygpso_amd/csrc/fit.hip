@@ -1799,7 +1799,7 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
     // (row_base: global row of this sub-matrix's first row -- pivot indices, padding test and the
     // diagonal go by global row; every tile address above is relative to the sub-matrix)
     chol64_lds<(sizeof(T) == 4) ? 1 : 2, T, sizeof(T) == 4, true>(Ls, Xs, Lf + k0 * ld + k0, ld, row_base + k0, n, info, Ts);
-    // the unrounded diagonal: its logarithms are summed by nlml_kernel, off this chain
+    // the unrounded diagonal: its logarithms are summed by nlml_block (alpha_sum_kernel's last workgroup), off this chain
     if (tid < kFitBlock) diag64[row_base + k0 + tid] = Ls[tid * kDS + tid];
     GPSO_STAMP(7);
     trinv64_lds<true, T, true>(Ls, Xs, Ts, Lf + k0 * ld + k0, ld);
@@ -2256,8 +2256,13 @@ __global__ __launch_bounds__(256) void alpha_part_kernel(const T* __restrict__ l
   }
 }
 
+template <typename T>
+__device__ __forceinline__ void nlml_block(const T* __restrict__ white, int64_t n, const double* __restrict__ diag64,
+                                           double* __restrict__ out);
 // (the chunks are summed in order -- deterministic -- but their loads are issued eight at a time: 8 workgroups with
 // 64 dependent loads per thread took 11.8 us at N = 2048)
+// nlml_out != nullptr: one workgroup more than the columns need, which sums the NLML (white and the diagonal of L are
+// complete when this kernel starts) -- a launch of its own cost 5 us behind this one
 // alpha_p: the predict-type copy of alpha (float, or double when alpha_p_f64) written in the same pass
 template <typename T>
 __global__ __launch_bounds__(256) void alpha_sum_kernel(const double* __restrict__ part,
@@ -2265,7 +2270,13 @@ __global__ __launch_bounds__(256) void alpha_sum_kernel(const double* __restrict
                                                         int64_t npad, T* __restrict__ alpha,
                                                         double* __restrict__ kinv_diag, void* __restrict__ alpha_p,
                                                         int alpha_p_f64, const float* __restrict__ amax_rows,
-                                                        float* __restrict__ amax_out) {
+                                                        float* __restrict__ amax_out, const T* __restrict__ white,
+                                                        int64_t n, const double* __restrict__ diag64,
+                                                        double* __restrict__ nlml_out) {
+  if (nlml_out != nullptr && blockIdx.x == gridDim.x - 1) {  // (workgroup-uniform)
+    nlml_block<T>(white, n, diag64, nlml_out);
+    return;
+  }
   if (amax_rows != nullptr && blockIdx.x == 0) {  // max |L^-1| from white_kernel's row maxima (N_pad >= 256 here)
     __shared__ float shm[4];
     float m = 0.0f;
@@ -2306,9 +2317,8 @@ __global__ __launch_bounds__(256) void alpha_sum_kernel(const double* __restrict
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void nlml_kernel(const T* __restrict__ white, int64_t n,
-                                                   const double* __restrict__ diag64,
-                                                   double* __restrict__ out) {
+__device__ __forceinline__ void nlml_block(const T* __restrict__ white, int64_t n, const double* __restrict__ diag64,
+                                           double* __restrict__ out) {
   __shared__ double sh[8];
   double acc = 0.0, lg = 0.0;
   for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
@@ -2342,10 +2352,9 @@ void launch_solve_alpha(hipStream_t st, const T* linv, const double* y64, int64_
   double* part_sq = alpha_part + (size_t)nchunk * npad;
   hipLaunchKernelGGL((alpha_part_kernel<T>), dim3((unsigned)(npad / 64), (unsigned)nchunk), dim3(256),
                      0, st, linv, white, n, npad, alpha_part, part_sq);
-  hipLaunchKernelGGL((alpha_sum_kernel<T>), dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, st,
-                     alpha_part, part_sq, nchunk, npad, alpha, kinv_diag, alpha_p, alpha_p_f64, amax_rows, linv_absmax);
-  if (nlml_out)
-    hipLaunchKernelGGL((nlml_kernel<T>), dim3(1), dim3(256), 0, st, white, n, diag64, nlml_out);
+  hipLaunchKernelGGL((alpha_sum_kernel<T>), dim3((unsigned)((npad + 255) / 256) + (nlml_out ? 1u : 0u)), dim3(256), 0, st,
+                     alpha_part, part_sq, nchunk, npad, alpha, kinv_diag, alpha_p, alpha_p_f64, amax_rows, linv_absmax,
+                     white, n, diag64, nlml_out);
 }
 template void launch_solve_alpha<float>(hipStream_t, const float*, const double*, int64_t, int64_t, double, const double*, float*, float*, double*, double*, double*, void*, int, float*, float*);
 template void launch_solve_alpha<double>(hipStream_t, const double*, const double*, int64_t, int64_t, double, const double*, double*, double*, double*, double*, double*, void*, int, float*, float*);
