@@ -39,7 +39,7 @@ using namespace gpso;
 int main(int argc, char** argv) {
   const int64_t npad = 2048, m = 65536;
   const bool f16 = argc > 1 && argv[1][0] == 'f';    // "f": the fp16 split (two planes, three products)
-  const bool x3 = f16 || (argc > 1 && argv[1][0] == '3');  // "3": bf16 x3
+  const bool x3 = f16 || (argc > 1 && argv[1][0] == '3') || (argc > 2 && argv[2][0] == '3');  // "3" (also as a second argument, behind w / s): bf16 x3
   const int dp4 = 3, dp = 12, ns = x3 ? 2 : 3;
   std::vector<float> linv((size_t)npad * npad, 0.f), xsp(npad * dp), xn(npad), al(npad), lv(m * dp), ln(m);
   unsigned s = 1; auto rnd = [&] { s = s * 1664525u + 1013904223u; return (float)(s >> 8) / (1 << 24); };
