@@ -12,6 +12,11 @@ gets the same number of leaves (weak scaling): rank 0 fits, the predict-ready po
 broadcast over RCCL, each rank scores its shard, the winners are all-gathered -- all of it inside the
 library (gpso_comm_init / gpso_broadcast_posterior / gpso_best_ucb_sharded).
 
+Order of a run: fit (timed by the library's events: ``fit_ms``) -> [broadcast] -> leaves to HBM -> ``--settle-s`` seconds
+(default 0.3) of UNTIMED calls of the same step, so that the device holds busy-state clocks (reported as ``settle_s``;
+with 20 / 5 steps the kernel otherwise runs at start-up clocks: 0.93 ms against 0.86) -> W untimed warm-up steps ->
+barrier + synchronize -> EXACTLY K timed steps -> synchronize + barrier -> CPU baseline and accuracy report (untimed).
+
 Rank 0 prints ONE JSON line.  ``roofline`` is for the dominant kernel (leaf_tiles_kernel):
 achieved = algorithmic FLOPs per launch (N^2 + 2ND + 20N per leaf) / its average
 duration measured with HIP events on the library's stream inside the timed region.
