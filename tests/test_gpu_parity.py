@@ -150,6 +150,30 @@ def test_split_bf16_predict_math(mode, n, d, m, kernel):
     assert np.array_equal(mean[perm], m2) and np.array_equal(var[perm], v2)
 
 
+@pytest.mark.parametrize("variance,yscale", [(1e-4, 1e-2), (3.7e3, 60.0), (2.0 ** 20, 1024.0)])
+def test_fp16_split_scaling_over_kernel_variances(variance, yscale):
+    """The fp16 split scales L^-1 and the generated tile by powers of two into fp16's range (max |L^-1| 2^sa and
+    sigma^2 2^sb in [2^13, 2^14)): the accuracy relative to sigma^2 must not depend on the scale of the problem."""
+    from pygpso_amd import HipGPEngine
+
+    n, d, m = 512, 6, 2048
+    X, y0 = synthetic_problem(n, d, seed=4)
+    y = y0 * yscale
+    th = gpr.Theta("Matern52", 0.25 * np.sqrt(d) * np.ones(1), variance, 1e-3 * variance, float(y.mean()))
+    post = gpr.posterior(th, X, y)
+    Xs = synthetic_leaves(m, d, seed=5)
+    mean_ref, var_ref = gpr.predict_y(post, Xs)
+    errs = {}
+    for math in ("f16x3", "native"):
+        eng = HipGPEngine("mixed", predict_math=math)
+        _fit(eng, X, y, th, grad=False)
+        mean, var = eng.predict(Xs)
+        assert eng.precision_info()["predict_math"] == math
+        errs[math] = (float(np.max(np.abs(var - var_ref)) / variance), float(np.max(np.abs(mean - mean_ref)) / np.max(np.abs(y))))
+    assert errs["f16x3"][0] <= 5e-6 and errs["f16x3"][1] <= 5e-6, errs
+    assert errs["f16x3"][0] <= 4 * errs["native"][0] + 1e-6, errs
+
+
 def test_auto_ladder_walks_down_and_starts_over():
     """GPSO_MATH_AUTO: fp16 split -> bf16x6 -> f32 MFMA kernel, one rung down per failed self-test of the posterior at
     hand, from the top again with the next posterior.  Tolerances nothing in float can meet walk the whole ladder (and
