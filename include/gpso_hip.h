@@ -89,6 +89,9 @@ typedef struct gpso_ctx gpso_ctx;
                                    /* of the fit (rank-W trailing updates, level-doubling inverse) run on the bf16    */
                                    /* matrix cores as 3-way split products (6 bf16 MFMAs per product, f32             */
                                    /* accumulation: f32-class accuracy; 4 x 6 N^2 bytes of bf16 planes); 0: f32 MFMA   */
+#define GPSO_OPT_TIMING 7          /* 1 (default): every fit / predict entry point records the event pairs gpso_last_ms  */
+                                   /* reads (two to four HIP calls); 0: none, gpso_last_ms returns 0 -- for callers in a  */
+                                   /* loop of small evaluations (the drop-in surrogate switches it off)                   */
 /* floating-point options (gpso_set_option_f64): tolerances of the self-test */
 #define GPSO_OPTF_TOL_VAR 100  /* max |d var| at the training inputs, relative to the kernel variance (default 1e-4; GPSO_F32: 1e-3) */
 #define GPSO_OPTF_TOL_MEAN 101 /* max |d mean| at the training inputs, relative to max |y - c|   (default 1e-4; GPSO_F32: 1e-3) */

@@ -30,6 +30,7 @@ OPT_GENERATION = 3
 OPT_PRECISION_CHECK = 4
 OPT_FIT_FUSED_SMALL = 5
 OPT_FIT_BF16_SYRK = 6
+OPT_TIMING = 7
 OPTF_TOL_VAR, OPTF_TOL_MEAN = 100, 101
 GEN_F64, GEN_F32, GEN_AUTO = 0, 1, 2
 GEN_IDS = {"float64": GEN_F64, "f64": GEN_F64, "float32": GEN_F32, "f32": GEN_F32, "auto": GEN_AUTO}

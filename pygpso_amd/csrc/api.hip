@@ -140,6 +140,7 @@ struct gpso_ctx {
   std::vector<hipEvent_t> tile_ev;  // start/stop pairs around the leaf-tile kernel, one per chunk
   int tile_pairs = 0;               // pairs recorded by the call in flight
   double last_ms[3] = {0, 0, 0};
+  bool timing = true;  // GPSO_OPT_TIMING: record the event pairs gpso_last_ms reads (two to four HIP calls per entry point)
   // multi-GPU group (gpso_comm_init): one RCCL communicator per context, collectives on ctx->stream
   ncclComm_t comm = nullptr;
   bool comm_aborted = false;  // gpso_comm_abort: the communicator is gone (not to be destroyed again)
@@ -360,6 +361,11 @@ struct EngineT : Engine {
       case GPSO_OPT_FIT_BF16_SYRK:
         if (value != 0 && value != 1) return ctx->fail(GPSO_E_ARG, "bf16 SYRK must be 0 or 1");
         bf16_fit = value != 0;
+        return GPSO_OK;
+      case GPSO_OPT_TIMING:
+        if (value != 0 && value != 1) return ctx->fail(GPSO_E_ARG, "timing must be 0 or 1");
+        ctx->timing = value != 0;
+        if (!ctx->timing) ctx->last_ms[0] = ctx->last_ms[1] = ctx->last_ms[2] = 0.0;
         return GPSO_OK;
       case GPSO_OPT_FIT_FUSED_SMALL:
         if (value != 0 && value != 1) return ctx->fail(GPSO_E_ARG, "fused small fit must be 0 or 1");
@@ -600,7 +606,7 @@ struct EngineT : Engine {
     st_done = st_have = false;
     reset_generation();
     hipStream_t s = st();
-    HIPCHECK(hipEventRecord(ctx->ev[4], s));
+    if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[4], s));
     if (grad && (rc = ensure(kinvb, (size_t)npad * npad * sizeof(TF)))) return rc;
     if (small) {
       // N <= 128: the whole evaluation in ONE launch (fit.hip: small_fit_kernel)
@@ -671,14 +677,14 @@ struct EngineT : Engine {
     }
     if ((rc = pack_bf16())) return rc;
     if ((rc = launch_status())) return rc;
-    HIPCHECK(hipEventRecord(ctx->ev[5], s));
+    if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[5], s));
     constexpr size_t kHostDoubles = 8 + kGradMaxLs + 3;
     double* host = ctx->pinned_scratch(kHostDoubles);
     if (!host) return ctx->fail(GPSO_E_OOM, "pinned host scratch");
     if (!small) HIPCHECK(hipMemcpyAsync(host, scal.p, kHostDoubles * 8, hipMemcpyDeviceToHost, s));
     HIPCHECK(ctx->wait(s));
     float ms = 0;
-    if (hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->last_ms[2] = ms;
+    if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->last_ms[2] = ms;
     int info;
     std::memcpy(&info, &host[1], sizeof(int));
     if (info != INT_MAX)
@@ -778,7 +784,7 @@ struct EngineT : Engine {
         HIPCHECK(hipEventCreate(&e));
         ctx->tile_ev.push_back(e);
       }
-      HIPCHECK(hipEventRecord(ctx->tile_ev[2 * ctx->tile_pairs], s));
+      if (ctx->timing) HIPCHECK(hipEventRecord(ctx->tile_ev[2 * ctx->tile_pairs], s));
       if (use_bf16) {
         if constexpr (kFloatPredict)
           rc = launch_leaf_tiles_bf16<TG>(s, nsplit(), linv_b.p, xsp, xnr, as<float>(alpha), as<TG>(leaves_s),
@@ -790,7 +796,7 @@ struct EngineT : Engine {
                                        m_live_c);
       }
       if (rc) return launch_status();
-      HIPCHECK(hipEventRecord(ctx->tile_ev[2 * ctx->tile_pairs + 1], s));
+      if (ctx->timing) HIPCHECK(hipEventRecord(ctx->tile_ev[2 * ctx->tile_pairs + 1], s));
       ++ctx->tile_pairs;
       launch_leaf_finalize(s, as<double>(pvar), as<double>(pmean), nbi, mp, mc, kp, varsigma, mean_dev + off,
                            var_dev + off, want_ucb ? ucb_dev + off : nullptr);
@@ -812,6 +818,10 @@ struct EngineT : Engine {
 
   // after the stream has been synchronised: total leaf-tile kernel time of the call
   void collect_tile_ms() {
+    if (!ctx->timing) {
+      ctx->tile_pairs = 0;
+      return;
+    }
     float total = 0;
     for (int i = 0; i < ctx->tile_pairs; ++i) {
       float ms = 0;
@@ -993,7 +1003,7 @@ struct EngineT : Engine {
     if (m == 0) return GPSO_OK;
     if (!mean || !var) return ctx->fail(GPSO_E_ARG, "mean / var must not be NULL");
     hipStream_t s = st();
-    HIPCHECK(hipEventRecord(ctx->ev[2], s));
+    if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[2], s));
     const void* dev = nullptr;
     if ((rc = stage_leaves(xs, xs_dtype, xs_mem, m, &dev))) return rc;
     double *md = mean, *vd = var;
@@ -1008,12 +1018,12 @@ struct EngineT : Engine {
       HIPCHECK(hipMemcpyAsync(mean, md, (size_t)m * 8, hipMemcpyDeviceToHost, s));
       HIPCHECK(hipMemcpyAsync(var, vd, (size_t)m * 8, hipMemcpyDeviceToHost, s));
     }
-    HIPCHECK(hipEventRecord(ctx->ev[3], s));
+    if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[3], s));
     HIPCHECK(ctx->wait(s));
     collect_tile_ms();
     ctx->last_count[0] = ctx->last_count[1] = m;
     float ms = 0;
-    if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ms[1] = ms;
+    if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ms[1] = ms;
     return GPSO_OK;
   }
 
@@ -1215,13 +1225,13 @@ struct EngineT : Engine {
     double* vals = ctx->pinned_scratch(doubles);
     if (!vals) return ctx->fail(GPSO_E_OOM, "pinned host scratch");
     HIPCHECK(hipMemcpyAsync(vals, src.p, doubles * 8, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipEventRecord(ctx->ev[3], s));
+    if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[3], s));
     HIPCHECK(ctx->wait(s));
     int rc;
     if ((rc = launch_status())) return rc;
     collect_tile_ms();
     float ms = 0;
-    if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ms[1] = ms;
+    if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ms[1] = ms;
     if (mode == 2) {
       const int verdict = (int)vals[4 * nseg + 1];
       if (verdict_out) *verdict_out = verdict;
@@ -1253,7 +1263,7 @@ struct EngineT : Engine {
     int rc = check_predict_args(xs, xs_dtype, xs_mem, m);
     if (rc) return rc;
     if (nseg < 1) return ctx->fail(GPSO_E_ARG, "nseg must be >= 1");
-    HIPCHECK(hipEventRecord(ctx->ev[2], st()));
+    if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[2], st()));
     const void* dev = nullptr;
     if (m > 0 && (rc = stage_leaves(xs, xs_dtype, xs_mem, m, &dev))) return rc;
     if ((rc = enqueue_best_leaves(dev, xs_dtype, m, seg_off, nseg, varsigma))) return rc;
@@ -1279,7 +1289,7 @@ struct EngineT : Engine {
     std::vector<int64_t> so, base;
     if ((rc = global_segments(m_global, seg_off, nseg, so))) return rc;
     if ((rc = ensure_group_buffers(nseg, ctx->world))) return rc;
-    HIPCHECK(hipEventRecord(ctx->ev[2], st()));
+    if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[2], st()));
     segment_bases(m_global, so, nseg, ctx->world, base);
     int local = upload_base(base);
     if (local == GPSO_OK)
@@ -1335,7 +1345,7 @@ struct EngineT : Engine {
     if (!have_post) return ctx->fail(GPSO_E_STATE, "no posterior resident: call gpso_fit_eval / gpso_set_posterior first");
     int rc = precision_gate();
     if (rc) return rc;
-    HIPCHECK(hipEventRecord(ctx->ev[2], st()));
+    if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[2], st()));
     if ((rc = enqueue_best_grow(bounds, nseg, depth, 0, gpso_grow_rows(depth), varsigma))) return rc;
     return finish_best(ovals, nseg, 1, idx, mean, var, ucb);
   }
@@ -1350,7 +1360,7 @@ struct EngineT : Engine {
     if (nseg < 1) return ctx->fail(GPSO_E_ARG, "nseg must be >= 1");
     if (depth < 0 || depth > 16) return ctx->fail(GPSO_E_ARG, "depth %d outside [0, 16]", depth);
     if ((rc = ensure_group_buffers(nseg, ctx->world))) return rc;
-    HIPCHECK(hipEventRecord(ctx->ev[2], st()));
+    if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[2], st()));
     const int local = sharded_local_grow(ctx->rank, ctx->world, bounds, nseg, depth, varsigma);
     const std::string local_msg = ctx->err;
     if ((rc = publish_local(nseg, local))) return rc;
@@ -1371,7 +1381,7 @@ struct EngineT : Engine {
     if (nseg < 1) return ctx->fail(GPSO_E_ARG, "nseg must be >= 1");
     int rc = ensure_group_buffers(nseg, world);
     if (rc) return rc;
-    HIPCHECK(hipEventRecord(ctx->ev[2], st()));
+    if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[2], st()));
     const int local = sharded_local(rank, world, xs, xs_dtype, xs_mem, m_local, m_global, seg_off, nseg, varsigma);
     return payload_out(nseg, local, payload);
   }
@@ -1382,7 +1392,7 @@ struct EngineT : Engine {
     if (nseg < 1) return ctx->fail(GPSO_E_ARG, "nseg must be >= 1");
     int rc = ensure_group_buffers(nseg, world);
     if (rc) return rc;
-    HIPCHECK(hipEventRecord(ctx->ev[2], st()));
+    if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[2], st()));
     const int local = sharded_local_grow(rank, world, bounds, nseg, depth, varsigma);
     return payload_out(nseg, local, payload);
   }
@@ -1407,7 +1417,7 @@ struct EngineT : Engine {
     int rc = ensure_group_buffers(nseg, world);
     if (rc) return rc;
     hipStream_t s = st();
-    HIPCHECK(hipEventRecord(ctx->ev[2], s));
+    if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[2], s));
     const bool with_base = m_global >= 0;
     if (with_base) {
       std::vector<int64_t> so, base;

@@ -272,6 +272,9 @@ class HipGPEngineGroup:
     def set_precision_check(self, on):
         self._all(lambda r, e: e.set_precision_check(on))
 
+    def set_timing(self, on):
+        self._all(lambda r, e: e.set_timing(on))
+
     def set_tolerances(self, tol_var=None, tol_mean=None):
         self._all(lambda r, e: e.set_tolerances(tol_var, tol_mean))
 

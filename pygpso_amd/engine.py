@@ -104,6 +104,11 @@ class HipGPEngine:
         """"auto" (default) | "float64" | "float32": arithmetic of the cross-Gram x.x* contraction and r^2."""
         self._check(self._lib.gpso_set_option(self._h, L.OPT_GENERATION, L.GEN_IDS[mode]))
 
+    def set_timing(self, on):
+        """GPSO_OPT_TIMING: record the event pairs ``last_ms`` reads (default on); off saves two to four HIP calls per
+        entry point -- what a loop of small evaluations wants."""
+        self._check(self._lib.gpso_set_option(self._h, L.OPT_TIMING, 1 if on else 0))
+
     def set_precision_check(self, on):
         self._check(self._lib.gpso_set_option(self._h, L.OPT_PRECISION_CHECK, 1 if on else 0))
 

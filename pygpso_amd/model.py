@@ -102,7 +102,9 @@ class HipGPR:
             from .distributed import HipGPEngineGroup
 
             return HipGPEngineGroup(dtype=dtype, devices=self._devices, **self._engine_options)
-        return HipGPEngine(dtype=dtype, device=self._device, **self._engine_options)
+        eng = HipGPEngine(dtype=dtype, device=self._device, **self._engine_options)
+        eng.set_timing(False)  # nobody reads last_ms behind the drop-in surrogate: 10 - 45 small evaluations per update
+        return eng
 
     # -- data ---------------------------------------------------------------------------------
     @property

@@ -35,6 +35,15 @@ for _ in range(reps):
     dev += eng.last_ms(2)
 wall = (time.perf_counter() - t) / reps * 1e3
 print(f"engine.fit_eval_u n={n}: wall {wall:.3f} ms/call, device {dev / reps:.3f} ms/call")
+eng.set_timing(False)  # GPSO_OPT_TIMING 0: what the drop-in surrogate's engine runs with
+for _ in range(20):
+    eng.fit_eval_u("Matern52", u, 1, True)
+t = time.perf_counter()
+for _ in range(reps):
+    eng.fit_eval_u("Matern52", u, 1, True)
+wall = (time.perf_counter() - t) / reps * 1e3
+print(f"engine.fit_eval_u n={n}, timing events off: wall {wall:.3f} ms/call")
+eng.set_timing(True)
 
 from pygpso_amd import GPRSurrogate, kernels
 surr = GPRSurrogate.default()
