@@ -300,9 +300,18 @@ def main():
     # clock settle (untimed, BEFORE the W warm-up steps the contract asks for): the fit, the uploads and the process
     # start-up leave the GPU at whatever clock the power management had reached; the same call is repeated for
     # --settle-s seconds so that warm-up and timed steps run at the clocks a busy device holds.  Reported as "settle_s".
-    t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < args.settle_s:
+    # (the NUMBER of settle steps must be the same on every rank -- each step is a collective call under --gpus N: it is
+    # derived from one measured step, maximum over the ranks)
+    if args.settle_s > 0:
+        t_one = time.perf_counter()
         winner = step()
+        t_one = time.perf_counter() - t_one
+        if use_dist:
+            t = torch.tensor([t_one], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t_one = float(t.item())
+        for _ in range(min(2000, int(math.ceil(args.settle_s / max(t_one, 1e-6))))):
+            winner = step()
     for _ in range(args.warmup):
         winner = step()
     torch.cuda.synchronize()
