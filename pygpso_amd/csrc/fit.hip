@@ -32,14 +32,20 @@ template <typename T>
 __global__ __launch_bounds__(256) void scale_x_kernel(const double* __restrict__ x64, int64_t n,
                                                       int64_t npad, int d, int dp,
                                                       const double* __restrict__ ls,
-                                                      T* __restrict__ xs, T* __restrict__ xnorm) {
+                                                      T* __restrict__ xs, T* __restrict__ xnorm,
+                                                      T* __restrict__ xs_p /* nullable: the fragment packing as well */) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npad) return;
+  // packed element ((kt * dp4 + c) * 64 + lane) holds row kt * 16 + arow_for_k4(lane & 15), column 4 c + (lane >> 4)
+  // (pack_xs_kernel); arow_for_k4 is its own inverse (identity, or the transpose of a 4 x 4 index)
+  const int dp4 = dp / 4;
+  const int64_t pbase = (i >> 4) * dp4 * 64 + Mfma<T>::arow_for_k4((int)(i & 15));
   T acc = 0;
   for (int k = 0; k < dp; ++k) {
     T v = 0;
     if (i < n && k < d) v = (T)(x64[i * d + k] / ls[k]);
     xs[i * dp + k] = v;
+    if (xs_p != nullptr) xs_p[pbase + (k >> 2) * 64 + 16 * (k & 3)] = v;
     acc += v * v;
   }
   xnorm[i] = acc;
@@ -64,10 +70,7 @@ template <typename T>
 void launch_scale_x(hipStream_t st, const double* x64, int64_t n, int64_t npad, int d, int dp,
                     const double* ls, T* xs, T* xnorm, T* xs_p) {
   hipLaunchKernelGGL((scale_x_kernel<T>), dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, st,
-                     x64, n, npad, d, dp, ls, xs, xnorm);
-  if (xs_p != nullptr)
-    hipLaunchKernelGGL((pack_xs_kernel<T>), dim3((unsigned)((npad * dp + 255) / 256)), dim3(256), 0,
-                       st, xs, npad, dp, xs_p);
+                     x64, n, npad, d, dp, ls, xs, xnorm, xs_p);  // (one launch: the packing rides along)
 }
 // float copies of the (double) scaled inputs for float generation of the cross-Gram tile: exactly what
 // scale_x_kernel<float> computes from the raw inputs -- (float)(x / l) is the rounding of the double
