@@ -2,6 +2,7 @@
 // No torch, no BLAS/solver libraries: every kernel launched here is hand-written (predict.hip,
 // fit.hip, grow.hip).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <climits>
 #include <cmath>
@@ -143,7 +144,9 @@ struct gpso_ctx {
   bool timing = true;  // GPSO_OPT_TIMING: record the event pairs gpso_last_ms reads (two to four HIP calls per entry point)
   // multi-GPU group (gpso_comm_init): one RCCL communicator per context, collectives on ctx->stream
   ncclComm_t comm = nullptr;
-  bool comm_aborted = false;  // gpso_comm_abort: the communicator is gone (not to be destroyed again)
+  // gpso_comm_abort (callable from another thread): the communicator is gone -- not to be destroyed again, and not to be
+  // handed to a collective again either (need_comm refuses until gpso_comm_destroy + gpso_comm_init)
+  std::atomic<bool> comm_aborted{false};
   int rank = 0, world = 1;
   int64_t last_count[2] = {0, 0};  // leaves scored / leaves asked for by the last predict-type call
   std::string err;
@@ -1272,6 +1275,9 @@ struct EngineT : Engine {
 
   int need_comm() {
     if (ctx->comm == nullptr) return ctx->fail(GPSO_E_STATE, "this context is not part of a group: call gpso_comm_init first");
+    if (ctx->comm_aborted.load())
+      return ctx->fail(GPSO_E_STATE, "the communicator of this context was aborted (gpso_comm_abort): gpso_comm_destroy + "
+                                     "gpso_comm_init again before the next group call");
     return GPSO_OK;
   }
 
@@ -1946,7 +1952,8 @@ int gpso_comm_init(gpso_ctx* ctx, int rank, int world, const void* unique_id) {
   ENTER();
   if (!unique_id) return ctx->fail(GPSO_E_ARG, "unique_id must not be NULL");
   if (world < 1 || rank < 0 || rank >= world) return ctx->fail(GPSO_E_ARG, "rank %d / world %d", rank, world);
-  if (ctx->comm) return ctx->fail(GPSO_E_STATE, "the context already belongs to a group (gpso_comm_destroy first)");
+  if (ctx->comm) return ctx->fail(GPSO_E_STATE, "the context already belongs to a group%s (gpso_comm_destroy first)",
+                                  ctx->comm_aborted.load() ? " whose communicator was aborted" : "");
   RcclApi& R = RcclApi::get();
   if (!R.ok) return ctx->fail(GPSO_E_RCCL, "%s", R.load_error.c_str());
   ncclUniqueId id;
@@ -2032,7 +2039,7 @@ int gpso_comm_abort(gpso_ctx* ctx) {
   if (c == nullptr) return GPSO_OK;
   RcclApi& R = RcclApi::get();
   if (!R.ok || R.CommAbort == nullptr) return GPSO_E_RCCL;
-  ctx->comm_aborted = true;
+  if (ctx->comm_aborted.exchange(true)) return GPSO_OK;  // (already aborted: the handle is gone)
   return R.CommAbort(c) == ncclSuccess ? GPSO_OK : GPSO_E_RCCL;
 }
 

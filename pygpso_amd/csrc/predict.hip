@@ -1021,10 +1021,11 @@ __global__ __launch_bounds__(256) void seg_argmax_stage2(const Best* __restrict_
                                                          const int64_t* __restrict__ seg_off,
                                                          const double* __restrict__ mean,
                                                          const double* __restrict__ var,
-                                                         const double* __restrict__ ucb,
+                                                         const double* __restrict__ ucb, int nseg,
                                                          double* __restrict__ out_vals /*[nseg*4 + 2]*/) {
   __shared__ Best sh[4];
   const int seg = blockIdx.x;
+  if (seg >= nseg) return;
   Best mine{0.0, -1};
   for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
     Best c = partial[(int64_t)seg * nblk + b];
@@ -1043,7 +1044,7 @@ __global__ __launch_bounds__(256) void seg_argmax_stage2(const Best* __restrict_
       out_vals[seg * 4 + 2] = ucb[mine.i];
       out_vals[seg * 4 + 3] = __builtin_bit_cast(double, (int64_t)(mine.i - seg_off[seg]));
     }
-    if (seg == 0) out_vals[gridDim.x * 4 + 1] = 0.0;  // status slot of a group payload: this rank's half succeeded
+    if (seg == 0) out_vals[nseg * 4 + 1] = 0.0;  // status slot of a group payload: this rank's half succeeded
   }
 }
 
@@ -1158,9 +1159,12 @@ __global__ void reduce_winners_kernel(const double* __restrict__ gathered, const
     double worst = 0.0;
     int64_t who = -1;
     for (int r = 0; r < world; ++r) {
-      const double st = gathered[(int64_t)r * stride + nseg * 4 + 1];
-      if (!(st >= worst)) {  // more negative, or not a number (a payload that never arrived): a failure
-        worst = (st == st) ? st : -6.0 /* GPSO_E_RCCL */;
+      // not a number (a payload that never arrived) counts as GPSO_E_RCCL; the verdict is the true minimum over the
+      // ranks, and `who` only moves when the minimum does
+      const double raw = gathered[(int64_t)r * stride + nseg * 4 + 1];
+      const double st = (raw == raw) ? raw : -6.0 /* GPSO_E_RCCL */;
+      if (st < worst) {
+        worst = st;
         who = r;
       }
     }
@@ -1300,7 +1304,7 @@ void launch_seg_argmax(hipStream_t st, const double* mean, const double* var, co
   hipLaunchKernelGGL(seg_argmax_stage1, dim3((unsigned)nblk, (unsigned)nseg), dim3(256), 0, st, ucb,
                      seg_off_dev, reinterpret_cast<Best*>(partial_dev));
   hipLaunchKernelGGL(seg_argmax_stage2, dim3((unsigned)nseg), dim3(256), 0, st,
-                     reinterpret_cast<const Best*>(partial_dev), nblk, seg_off_dev, mean, var, ucb,
+                     reinterpret_cast<const Best*>(partial_dev), nblk, seg_off_dev, mean, var, ucb, nseg,
                      out_vals_dev);
 }
 

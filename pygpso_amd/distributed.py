@@ -60,12 +60,14 @@ def _id_token():
     return (os.environ.get("GPSO_GROUP_TOKEN") or os.environ.get("TORCHELASTIC_RUN_ID") or "gpso").encode()[:64]
 
 
-def exchange_unique_id(rank, world, addr=None, port=None, timeout=120.0, make_id=None):
+def exchange_unique_id(rank, world, addr=None, port=None, timeout=120.0, make_id=None, grace=0.25):
     """Rank 0 creates the id and serves it to the other ranks over TCP on (addr, port) -- by default
     MASTER_ADDR and MASTER_PORT + 1 of the launcher's environment (the port itself belongs to the
     launcher's own store).  A client introduces itself with its rank and the group token; rank 0 answers
-    every DISTINCT rank 1..world-1 once and ignores anything else (a port scanner, a duplicate, a retry
-    of a rank already served)."""
+    every rank 1..world-1 and ignores anything else (a port scanner, a wrong token); once every distinct rank
+    has been answered the port stays open for ``grace`` more seconds, so that a rank whose answer was lost can
+    ask again.  The token is the launcher's run id under torchrun (TORCHELASTIC_RUN_ID); outside torchrun set
+    GPSO_GROUP_TOKEN to something private to the job -- the fallback "gpso" only keeps strangers out by accident."""
     make_id = make_id or unique_id
     if world == 1:
         return make_id()
@@ -85,7 +87,10 @@ def exchange_unique_id(rank, world, addr=None, port=None, timeout=120.0, make_id
                 if left <= 0:
                     raise TimeoutError(f"group id exchange: ranks {sorted(set(range(1, world)) - served)} never asked")
                 srv.settimeout(left)
-                conn, _peer = srv.accept()
+                try:
+                    conn, _peer = srv.accept()
+                except socket.timeout:
+                    raise TimeoutError(f"group id exchange: ranks {sorted(set(range(1, world)) - served)} never asked") from None
                 with conn:
                     try:
                         conn.settimeout(5.0)
@@ -93,7 +98,23 @@ def exchange_unique_id(rank, world, addr=None, port=None, timeout=120.0, make_id
                         if n > 64 or _recv_exact(conn, n) != token or not 1 <= r < world:
                             continue  # not one of ours
                         conn.sendall(struct.pack("<I", len(uid)) + uid)
-                        served.add(r)  # (a retry of a served rank is answered again: its first answer may have been lost)
+                        served.add(r)
+                    except (OSError, ConnectionError, struct.error):
+                        continue
+            # every rank has been answered once; an answer may still have been lost on the way, so the port stays
+            # open for a short grace period and a rank that asks again is answered again
+            srv.settimeout(grace)
+            while True:
+                try:
+                    conn, _peer = srv.accept()
+                except (socket.timeout, OSError):
+                    break
+                with conn:
+                    try:
+                        conn.settimeout(2.0)
+                        r, n = struct.unpack("<II", _recv_exact(conn, 8))
+                        if n <= 64 and _recv_exact(conn, n) == token and 1 <= r < world:
+                            conn.sendall(struct.pack("<I", len(uid)) + uid)
                     except (OSError, ConnectionError, struct.error):
                         continue
         return uid
@@ -168,27 +189,32 @@ class HipGPEngineGroup:
         self.abort_after = 30.0  # seconds a failed group call waits for the other ranks before aborting them
         self._broken = False     # a communicator was aborted: the group cannot make group calls any more
         uid = (make_id or unique_id)()
-        self._all(lambda r, e: e.comm_init(r, self.world, uid))
+        self._all(lambda r, e: e.comm_init(r, self.world, uid), collective=True)
         self._stale = False  # peers lag behind the root's posterior?
         self.n = self.d = 0
 
-    def _all(self, fn):
+    def _all(self, fn, collective=False):
         """fn(rank, engine) on every engine, each on its own thread; returns the results in rank order (the
-        first exception, if any, is raised after all threads are back).  The library keeps every rank inside
+        first exception, if any, is raised after all threads are back).  ``collective``: fn contains RCCL
+        collectives (comm_init, broadcast_posterior, the *_sharded calls).  The library keeps every rank inside
         every collective of a call whatever fails locally, so the threads come back together; should one
         raise while others are still inside a collective after ``abort_after`` seconds (a HIP / RCCL failure
         in the middle of a call), their communicators are aborted (``gpso_comm_abort``) so that they return
-        an error too instead of waiting for ever."""
+        an error too instead of waiting for ever -- the group is then broken (``_check_usable`` refuses further
+        group calls; ``rebuild()`` makes new communicators).  Fan-outs without a collective (predict shards,
+        options) have nobody to wait for: a slow rank is simply joined."""
+        if collective:
+            self._check_usable()
         futs = [self._pool.submit(fn, r, e) for r, e in enumerate(self.engines)]
         done, pending = wait(futs, return_when=FIRST_EXCEPTION)
-        if pending and any(f.exception() is not None for f in done):
+        if collective and pending and any(f.exception() is not None for f in done):
             done2, pending = wait(pending, timeout=self.abort_after)
             for f in pending:
                 eng = self.engines[futs.index(f)]
                 if hasattr(eng, "comm_abort"):
                     eng.comm_abort()
                 self._broken = True
-            wait(pending)
+        wait(futs)
         out, err = [], None
         for f in futs:
             try:
@@ -199,6 +225,21 @@ class HipGPEngineGroup:
         if err is not None:
             raise err
         return out
+
+    def _check_usable(self):
+        if self._broken:
+            raise L.GpsoHipError(L.E_STATE, "a communicator of this group was aborted after a failed group call: "
+                                            "HipGPEngineGroup.rebuild() makes new ones (or create a new group)")
+
+    def rebuild(self, make_id=None):
+        """New communicators on every engine after an abort (``gpso_comm_destroy`` + ``gpso_comm_init``); the
+        posterior is broadcast again by the next predict-type call."""
+        for e in self.engines:
+            e.comm_destroy()
+        self._broken = False
+        uid = (make_id or unique_id)()
+        self._all(lambda r, e: e.comm_init(r, self.world, uid), collective=True)
+        self._stale = True
 
     def close(self):
         for e in getattr(self, "engines", []):
@@ -234,7 +275,7 @@ class HipGPEngineGroup:
 
     def _sync_posterior(self):
         if self._stale and self.world > 1:
-            self._all(lambda r, e: e.broadcast_posterior(0))
+            self._all(lambda r, e: e.broadcast_posterior(0), collective=True)
         self._stale = False
 
     # predict-type calls: sharded
@@ -252,12 +293,12 @@ class HipGPEngineGroup:
         xs = np.asarray(xs)
         m = xs.shape[0]
         res = self._all(lambda r, e: e.best_ucb_sharded(xs[slice(*shard_range(m, r, self.world))], m, varsigma,
-                                                        seg_off))
+                                                        seg_off), collective=True)
         return res[0]
 
     def best_ucb_grow(self, bounds, depth, varsigma):
         self._sync_posterior()
-        return self._all(lambda r, e: e.best_ucb_grow_sharded(bounds, depth, varsigma))[0]
+        return self._all(lambda r, e: e.best_ucb_grow_sharded(bounds, depth, varsigma), collective=True)[0]
 
     # options: the arithmetic options of a group must match on every rank (the library checks dtype and
     # predict math at the broadcast; generation, self-test and tolerances would silently differ otherwise)

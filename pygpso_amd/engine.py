@@ -191,13 +191,14 @@ class HipGPEngine:
         rule inside the library).  Returns (nlml, grad_u, theta): theta = constrained (ls..., variance, noise, mean)."""
         kid = L.KERNEL_IDS[kernel] if isinstance(kernel, str) else int(kernel)
         n_u = int(n_ls) + 2 + (1 if train_mean else 0)
-        buf = self._u_bufs.get(n_u)
+        key = (int(n_ls), bool(train_mean))  # (n_u alone is ambiguous: theta_out has n_ls + 3 entries whatever train_mean)
+        buf = self._u_bufs.get(key)
         if buf is None:  # marshalling buffers are made once per problem shape: this call is the optimiser's inner loop
             ua = np.empty(n_u, dtype=np.float64)
             ga = np.empty(n_u, dtype=np.float64)
             ta = np.empty(int(n_ls) + 3, dtype=np.float64)
             nl = C.c_double()
-            buf = self._u_bufs[n_u] = (ua, ga, ta, nl, L.dptr(ua), L.dptr(ga), L.dptr(ta), C.byref(nl))
+            buf = self._u_bufs[key] = (ua, ga, ta, nl, L.dptr(ua), L.dptr(ga), L.dptr(ta), C.byref(nl))
         ua, ga, ta, nl, up, gp, tp, nlp = buf
         ua[:] = u
         rc = self._lib.gpso_fit_eval_u(self._h, kid, up, int(n_ls), 1 if train_mean else 0, float(mean_c_fixed), nlp, gp, tp)

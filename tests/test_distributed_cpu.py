@@ -251,3 +251,102 @@ def test_engine_group_threads_with_two_fake_devices():
     ref.fit_eval("Matern52", [0.5], 1.2, 1e-3, 0.1, want_grad=False)
     assert np.array_equal(grp.best_ucb(Xs, VS)[0], ref.best_ucb(Xs, VS)[0])
     grp.close()
+
+
+def test_group_aborts_only_inside_collectives_and_a_broken_group_says_so():
+    """(i) a slow but healthy rank of a NON-collective fan-out (predict shards, options) is joined, not
+    aborted; (ii) a rank stuck in a collective after a peer failed IS aborted after ``abort_after`` seconds, the group
+    is then broken -- every further group call raises a clear error instead of handing a freed communicator to RCCL --
+    and ``rebuild()`` makes it usable again."""
+    import threading
+    import time
+
+    from pygpso_amd import _lib as L
+    from pygpso_amd import distributed as D
+
+    release = threading.Event()
+    log = []
+
+    class Eng:
+        dtype_name, dtype = "float64", 0
+
+        def __init__(self, dtype="float64", device=0, **_):
+            self.device, self.n, self.d = device, 0, 0
+            self.rank, self.world = 0, 1
+
+        def close(self):
+            pass
+
+        def comm_init(self, rank, world, uid):
+            self.rank, self.world = rank, world
+            log.append(("init", rank, uid))
+
+        def comm_destroy(self):
+            log.append(("destroy", self.rank))
+
+        def comm_abort(self):
+            log.append(("abort", self.rank))
+            release.set()  # what ncclCommAbort does for the blocked call
+
+        def set_timing(self, on):  # a non-collective fan-out: rank 0 fails at once, rank 1 is slow but healthy
+            if self.rank == 0:
+                raise ValueError("bad option")
+            time.sleep(0.3)
+            log.append(("slow rank done", self.rank))
+
+        def broadcast_posterior(self, root=0):  # a collective: rank 0 fails, rank 1 hangs until aborted
+            if self.rank == 0:
+                raise RuntimeError("rank 0 died inside the call")
+            assert release.wait(10.0)
+            raise L.GpsoHipError(L.E_RCCL, "aborted")
+
+    grp = D.HipGPEngineGroup("float64", devices=[0, 1], engine_cls=Eng, make_id=lambda: b"a" * 128)
+    grp.abort_after = 0.1
+    with pytest.raises(ValueError):
+        grp.set_timing(True)
+    assert ("slow rank done", 1) in log and not any(e[0] == "abort" for e in log) and not grp._broken
+    grp._stale = True
+    with pytest.raises(RuntimeError):
+        grp._sync_posterior()
+    assert ("abort", 1) in log and grp._broken
+    with pytest.raises(L.GpsoHipError, match="aborted"):
+        grp.best_ucb(np.zeros((4, 2)), 1.0)
+    grp.rebuild(make_id=lambda: b"b" * 128)
+    assert not grp._broken and [e for e in log if e[0] == "init"][-2:] == [("init", 0, b"b" * 128), ("init", 1, b"b" * 128)]
+    grp.close()
+
+
+def test_group_id_exchange_timeout_names_the_missing_ranks_and_answers_a_retry():
+    import socket
+    import struct
+    import threading
+
+    from pygpso_amd import distributed as D
+
+    port = _free_port()
+    with pytest.raises(TimeoutError, match=r"ranks \[1, 2\] never asked"):
+        D.exchange_unique_id(0, 3, addr="127.0.0.1", port=port, timeout=0.3, make_id=lambda: b"x" * 128)
+    # a rank whose answer was lost asks again inside the grace period and is answered again
+    port = _free_port()
+    got = []
+
+    def client_twice():
+        for attempt in range(2):
+            for _ in range(200):
+                try:
+                    conn = socket.create_connection(("127.0.0.1", port), timeout=2.0)
+                    break
+                except OSError:
+                    import time
+                    time.sleep(0.01)
+            with conn:
+                tok = D._id_token()
+                conn.sendall(struct.pack("<II", 1, len(tok)) + tok)
+                n = struct.unpack("<I", D._recv_exact(conn, 4))[0]
+                got.append(D._recv_exact(conn, n))
+
+    t = threading.Thread(target=client_twice)
+    t.start()
+    uid = D.exchange_unique_id(0, 2, addr="127.0.0.1", port=port, timeout=10.0, make_id=lambda: b"y" * 128, grace=1.0)
+    t.join()
+    assert got == [uid, uid]
