@@ -9,8 +9,10 @@ kernel -> finalize -> arg-max) on leaves ALREADY RESIDENT in HBM, posterior resi
 BASELINE.json's single-GPU performance configuration C3 (D=12, N_train=2048, 64k leaves, fp32).
 For N > 1 (launched by ``python -m torch.distributed.run --nproc-per-node N ...``) every rank
 gets the same number of leaves (weak scaling): rank 0 fits, the predict-ready posterior is
-broadcast over RCCL, each rank scores its shard, the winners are all-gathered -- all of it inside the
-library (gpso_comm_init / gpso_broadcast_posterior / gpso_best_ucb_sharded).
+broadcast over RCCL (ONE ncclBroadcast of a contiguous range; ``posterior_broadcast_ms``) -- and, timed beside it,
+every rank repeats the same deterministic fit itself (``posterior_replicate_ms``, fingerprints compared; ``--posterior``
+picks which of the two the timed steps use) --, each rank scores its shard, the winners are all-gathered -- all of it
+inside the library (gpso_comm_init / gpso_broadcast_posterior / gpso_best_ucb_sharded).
 
 Order of a run: fit (timed by the library's events: ``fit_ms``) -> [broadcast] -> leaves to HBM -> ``--settle-s`` seconds
 (default 0.3) of UNTIMED calls of the same step, so that the device holds busy-state clocks (reported as ``settle_s``;
@@ -210,6 +212,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--settle-s", type=float, default=0.3,
                     help="seconds of untimed hot-path calls before the warm-up steps (device clocks settle; 0 = none)")
+    ap.add_argument("--posterior", default="broadcast", choices=["broadcast", "replicate"],
+                    help="--gpus N > 1: how the peers get the posterior the timed steps use -- ONE ncclBroadcast of the "
+                         "fitting rank's predict-ready range, or the same deterministic fit on every rank (fingerprints "
+                         "compared).  Both are timed and reported whichever is chosen (SURVEY 8e: measure both)")
     ap.add_argument("--math", default="auto", choices=["auto", "native", "bf16x3", "bf16x6", "f16x3"],
                     help="predict math of float32 workloads (auto = the library default: the first rung of the ladder "
                          "f16x3 -> bf16x6 -> native f32 the posterior's self-test passes with)")
@@ -266,8 +272,9 @@ def main():
         fit_here(timed=True)
         if dtype == "float32":  # what GPSO_MATH_AUTO settled on for this posterior (its self-test ran here)
             math_mode = eng.precision_info()["predict_math"]
-    bcast_ms = None
+    bcast_ms = repl_ms = None
     posterior_bytes = None
+    hashes_agree = None
     distribution = "single GPU"
     if use_dist:
         # the library's own RCCL group (C-ABI): rank 0 creates the id, the launcher's process group only
@@ -276,14 +283,50 @@ def main():
         box = [D.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         eng.comm_init(rank, world, box[0])
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.perf_counter()
-        D.broadcast_posterior(eng, src=0)  # gpso_broadcast_posterior: device to device, synchronous
-        dist.barrier()
-        bcast_ms = (time.perf_counter() - t0) * 1e3
-        posterior_bytes = int(sum(nb for _, nb in eng.posterior_buffers()))
-        distribution = "fit on rank 0, RCCL broadcast of the predict-ready posterior (gpso_broadcast_posterior)"
+
+        def by_broadcast():
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            D.broadcast_posterior(eng, src=0)  # gpso_broadcast_posterior: ONE ncclBroadcast, device to device, synchronous
+            dist.barrier()
+            return (time.perf_counter() - t0) * 1e3
+
+        def by_replication():
+            # every rank runs the same bit-deterministic fit on its own copy of (X, y): no bulk collective
+            if rank != 0:
+                fit_here(timed=False)  # untimed: code-object load and first-launch effects (rank 0 has fitted before)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            fit_here(timed=False)
+            eng.synchronize()
+            dist.barrier()
+            return (time.perf_counter() - t0) * 1e3
+
+        def fingerprints():
+            hs = [None] * world
+            dist.all_gather_object(hs, eng.posterior_hash())
+            return hs
+
+        # both ways, the chosen one last (its posterior is the one the timed steps use; the bits are the same)
+        if args.posterior == "broadcast":
+            repl_ms = by_replication()
+            hs = fingerprints()
+            bcast_ms = by_broadcast()
+        else:
+            bcast_ms = by_broadcast()
+            repl_ms = by_replication()
+            hs = fingerprints()
+        hashes_agree = len(set(hs)) == 1
+        if not hashes_agree:
+            raise SystemExit(f"replicated fits disagree across ranks: {[f'{h:016x}' for h in hs]}")
+        if len(set(fingerprints())) != 1:
+            raise SystemExit("posterior fingerprints differ after the broadcast")
+        posterior_bytes = int(eng.posterior_span()[2])
+        distribution = ("fit on rank 0, ONE RCCL broadcast of the contiguous predict-ready range of its posterior arena "
+                        "(gpso_broadcast_posterior)" if args.posterior == "broadcast" else
+                        "the same deterministic fit on every rank, fingerprints compared (gpso_posterior_hash); no bulk collective")
 
     # ---- this rank's leaf shard, resident in HBM before the timed region --------------------------
     lo, hi = D.shard_range(m_total, rank, world)
@@ -359,6 +402,9 @@ def main():
             "fit_ms": fit_ms,
             "roofline_fit": roofline_fit(n, d, dtype, fit_ms),
             "posterior_broadcast_ms": bcast_ms,
+            "posterior_replicate_ms": repl_ms,
+            "posterior_fingerprints_agree": hashes_agree,
+            "posterior_mode": args.posterior if use_dist else None,
             "posterior_bytes": posterior_bytes,
             "rccl_world": world if use_dist else None,
             "posterior_distribution": distribution,

@@ -272,6 +272,23 @@ int gpso_get_vector(gpso_ctx* ctx, int which, double* out /* [N] host */);
  * negative status).  On a context that holds a posterior the call first lets GPSO_GEN_AUTO rule (it may
  * run the self-test) and records the choice in the hyper block, so that the receiver generates alike. */
 int gpso_posterior_buffers(gpso_ctx* ctx, void** ptrs, int64_t* nbytes, int cap);
+/* Round 4: all of those buffers are slices of ONE device allocation per context (the "posterior arena"), laid out as
+ * [packed L^-1 | hyper | X / l | its fragments | norms | alpha | scale slot + 16-bit planes of L^-1] -- a function of
+ * (padded N, padded D, dtype) only -- so that what the resident posterior USES is one contiguous range whichever predict
+ * math it runs (f32 MFMA kernel: [packed L^-1 .. alpha]; split math: [hyper .. the planes in use], the packed L^-1 then
+ * stays home).  gpso_posterior_span returns that range: device pointer, its offset inside the arena (the same on every
+ * context of the same shape / dtype) and its length; gpso_posterior_span_at maps an (offset, length) announced by a
+ * peer onto this context's arena after gpso_alloc_posterior.  gpso_broadcast_posterior moves exactly this range with a
+ * single ncclBroadcast.  Replaces (as does gpso_posterior_buffers) nothing in the reference: it has no second device
+ * (gpso/gp_surrogate.py:313-328 runs where the GPflow model lives). */
+int gpso_posterior_span(gpso_ctx* ctx, void** ptr /* nullable */, int64_t* offset /* nullable */, int64_t* nbytes /* nullable */);
+int gpso_posterior_span_at(gpso_ctx* ctx, int64_t offset, int64_t nbytes, void** ptr);
+/* 64-bit fingerprint of the predict-ready posterior resident on the context (a position-salted wrap-around sum over the
+ * words of the buffers in use; deterministic).  The fit is bit-deterministic, so contexts that ran the same
+ * gpso_set_data + gpso_fit_eval hold the same value: a group may REPLICATE the fit on every rank and compare
+ * fingerprints instead of broadcasting the factor (SURVEY 8e "measure both"; pygpso_amd.distributed: posterior=
+ * "replicate").  Stands where gpso/gp_surrogate.py:500-503 leaves its one GPflow model. */
+int gpso_posterior_hash(gpso_ctx* ctx, uint64_t* out);
 /* Allocate the same buffers for n, d on a receiving rank so they can be broadcast into. */
 int gpso_alloc_posterior(gpso_ctx* ctx, int64_t n, int d);
 /* After the buffers were filled by a broadcast: mark the posterior resident (reads the

@@ -84,6 +84,9 @@ SIGNATURES = {
     "gpso_get_matrix": (C.c_int, [C.c_void_p, C.c_int, _c_double_p]),
     "gpso_get_vector": (C.c_int, [C.c_void_p, C.c_int, _c_double_p]),
     "gpso_posterior_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), _c_int64_p, C.c_int]),
+    "gpso_posterior_span": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), _c_int64_p, _c_int64_p]),
+    "gpso_posterior_span_at": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p)]),
+    "gpso_posterior_hash": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "gpso_alloc_posterior": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
     "gpso_adopt_posterior": (C.c_int, [C.c_void_p]),
     "gpso_comm_unique_id": (C.c_int, [C.c_void_p]),

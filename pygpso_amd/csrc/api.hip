@@ -66,6 +66,7 @@ constexpr int kHyperHeader = 8;                // doubles in front of the length
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
+  bool view = false;  // a slice of the posterior arena (EngineT::carve_posterior): not freed, not re-allocated on its own
 };
 
 struct Engine {
@@ -87,6 +88,9 @@ struct Engine {
   virtual int get_matrix(int which, double* out) = 0;
   virtual int get_vector(int which, double* out) = 0;
   virtual int posterior_buffers(void** ptrs, int64_t* nbytes, int cap) = 0;
+  virtual int posterior_span(void** ptr, int64_t* offset, int64_t* nbytes) = 0;
+  virtual int posterior_span_at(int64_t offset, int64_t nbytes, void** ptr) = 0;
+  virtual int posterior_hash(uint64_t* out) = 0;
   virtual int alloc_posterior(int64_t n, int d) = 0;
   virtual int adopt_posterior() = 0;
   virtual int64_t padded_n() const = 0;
@@ -297,8 +301,8 @@ struct EngineT : Engine {
                       &work, &kinvb, &linv_p, &white, &alpha_f, &alpha, &logdet, &scal, &gpart, &apart,
                       &kinv_diag, &getter_tmp, &leaves_raw, &leaves_s, &lnorm, &pvar, &pmean, &omean, &ovar,
                       &oucb, &segoff, &best, &oidx, &ovals, &linv_b, &st_mean, &st_var, &st_out, &grow_key, &live_cnt,
-                      &best_pos, &gath, &wbase, &ovals2, &bhdr, &pl_L, &pl_X, &pl_XT, &pl_WT, &amax_rows})
-      if (b->p) (void)hipFree(b->p);
+                      &best_pos, &gath, &wbase, &ovals2, &bhdr, &pl_L, &pl_X, &pl_XT, &pl_WT, &amax_rows, &arena, &hash_out})
+      if (b->p && !b->view) (void)hipFree(b->p);
   }
 
   int64_t padded_n() const override { return npad; }
@@ -318,9 +322,13 @@ struct EngineT : Engine {
   // bytes of the split copy of L^-1: the planes and, behind them, one 256-byte slot for the power-of-two scale of the
   // fp16 split (2 floats, written on the device at packing time) -- it travels with the planes in a hand-off.  Under
   // GPSO_MATH_AUTO room for three planes whatever the stage, so that both sides of a hand-off list the same sizes.
+  // Round 4: the 256-byte scale slot sits IN FRONT of the planes, so that the part of the buffer a posterior uses
+  // (slot + nsplit planes) is a prefix of it -- the posterior arena sends exactly that (posterior_span).
   size_t split_planes_alloc() const { return (size_t)(math_auto ? 3 : nsplit()) * npad * npad * 2; }
   size_t split_bytes() const { return split_planes_alloc() + 256; }
-  float* f16_scale() const { return reinterpret_cast<float*>(static_cast<char*>(linv_b.p) + split_planes_alloc()); }
+  size_t split_bytes_in_use() const { return (size_t)nsplit() * npad * npad * 2 + 256; }
+  float* f16_scale() const { return reinterpret_cast<float*>(linv_b.p); }
+  void* split_planes() const { return static_cast<char*>(linv_b.p) + 256; }
   // max |L^-1| of the fp16 split comes out of the fit's own pass over L^-1 (white_kernel leaves row maxima,
   // alpha_sum_kernel folds them into the scale slot): no extra pass, no memset.  f16_handed_at: where this fit's solve
   // was told to leave it (cleared by every packing and at the start of every fit).
@@ -345,10 +353,10 @@ struct EngineT : Engine {
     if (rc) return rc;
     if (f16_split()) {
       const bool have_max = f16_handed_at != nullptr && f16_handed_at == f16_scale();
-      launch_pack_linv_f16<TF>(st(), as<TF>(linv), n, npad, f16_scale(), linv_b.p, have_max);
+      launch_pack_linv_f16<TF>(st(), as<TF>(linv), n, npad, f16_scale(), split_planes(), have_max);
       f16_handed_at = nullptr;
     } else {
-      launch_pack_linv_bf16<TF>(st(), nsplit(), as<TF>(linv), n, npad, linv_b.p);
+      launch_pack_linv_bf16<TF>(st(), nsplit(), as<TF>(linv), n, npad, split_planes());
     }
     HIPCHECK(hipGetLastError());
     linv_b_valid = true;
@@ -434,6 +442,7 @@ struct EngineT : Engine {
   int ensure(DevBuf& b, size_t bytes) {
     if (bytes == 0) bytes = 16;
     if (b.bytes >= bytes) return GPSO_OK;
+    if (b.view) return ctx->fail(GPSO_E_STATE, "internal: a slice of the posterior arena (%zu bytes) was asked to hold %zu", b.bytes, bytes);
     if (b.p) {
       HIPCHECK(hipStreamSynchronize(st()));
       HIPCHECK(hipFree(b.p));
@@ -482,20 +491,82 @@ struct EngineT : Engine {
     int rc;
     if ((rc = ensure(x64, (size_t)n * d * 8))) return rc;
     if ((rc = ensure(y64, (size_t)n * 8))) return rc;
-    if ((rc = ensure(hyper, (size_t)(kHyperHeader + kMaxD) * 8))) return rc;
-    if ((rc = ensure(xs64, (size_t)npad * dp * 8))) return rc;
-    if ((rc = ensure(xnorm64, (size_t)npad * 8))) return rc;
-    if ((rc = ensure(xs_p64, (size_t)npad * dp * 8))) return rc;
+    if ((rc = carve_posterior())) return rc;
     if (kFloatPredict) {
       if ((rc = ensure(xs32, (size_t)npad * dp * 4))) return rc;
       if ((rc = ensure(xnorm32, (size_t)npad * 4))) return rc;
       if ((rc = ensure(xs_p32, (size_t)npad * dp * 4))) return rc;
     }
-    if (linv_p.bytes < packed_linv_elems(npad) * sizeof(TP)) small_tile_rows = 8;  // fresh memory
-    if ((rc = ensure(linv_p, packed_linv_elems(npad) * sizeof(TP)))) return rc;
-    if ((rc = ensure(alpha, (size_t)npad * sizeof(TP)))) return rc;
     return GPSO_OK;
   }
+
+  // ---- the posterior arena (round 4) ----------------------------------------------------------------------------
+  // Everything a peer needs to predict lives in ONE allocation, laid out as
+  //     [ packed L^-1 | hyper block | X / l | its MFMA fragments | norms | alpha | split pieces of L^-1 (scale slot, planes) ]
+  // (each slice 256-byte aligned), so that what a posterior actually uses is one contiguous range whichever predict
+  // math it runs -- native: [packed L^-1 .. alpha], split: [hyper .. the planes in use] -- and gpso_broadcast_posterior
+  // moves it with ONE ncclBroadcast.  The layout is a function of (N_pad, D_pad, predict type) only: every rank of a
+  // group carves the same offsets.  The slices are DevBuf views of the arena.
+  DevBuf arena;
+  int64_t arena_npad = -1;
+  int arena_dp = -1;
+  static size_t up256(size_t b) { return (b + 255) / 256 * 256; }
+  bool split_slot_exists() const { return kFloatPredict && npad % 256 == 0; }
+  int carve_posterior() {
+    if (arena.p != nullptr && arena_npad == npad && arena_dp == dp) return GPSO_OK;
+    const size_t b_linv = up256(packed_linv_elems(npad) * sizeof(TP));
+    const size_t b_hyper = up256((size_t)(kHyperHeader + kMaxD) * 8);
+    const size_t b_xs = up256((size_t)npad * dp * 8);
+    const size_t b_norm = up256((size_t)npad * 8);
+    const size_t b_alpha = up256((size_t)npad * sizeof(TP));
+    // room for three planes whatever the option: GPSO_OPT_PREDICT_MATH may change after the shape is known
+    const size_t b_split = split_slot_exists() ? up256((size_t)3 * npad * npad * 2 + 256) : 0;
+    const size_t total = b_linv + b_hyper + 2 * b_xs + b_norm + b_alpha + b_split;
+    if (arena.bytes < total) {
+      if (arena.p) {
+        HIPCHECK(hipStreamSynchronize(st()));
+        HIPCHECK(hipFree(arena.p));
+        arena.p = nullptr;
+        arena.bytes = 0;
+        arena_npad = -1;
+        for (DevBuf* b : {&linv_p, &hyper, &xs64, &xs_p64, &xnorm64, &alpha, &linv_b}) *b = DevBuf{};
+      }
+      HIPCHECK(hipMalloc(&arena.p, total));
+      arena.bytes = total;
+    }
+    char* q = static_cast<char*>(arena.p);
+    auto slice = [&](DevBuf& b, size_t bytes) {
+      b.p = bytes ? q : nullptr;
+      b.bytes = bytes;
+      b.view = true;
+      q += bytes;
+    };
+    slice(linv_p, b_linv);
+    slice(hyper, b_hyper);
+    slice(xs64, b_xs);
+    slice(xs_p64, b_xs);
+    slice(xnorm64, b_norm);
+    slice(alpha, b_alpha);
+    slice(linv_b, b_split);
+    arena_npad = npad;
+    arena_dp = dp;
+    small_tile_rows = 8;  // the slices moved: whatever linv_p's bytes held belongs to another layout
+    linv_b_valid = false;
+    linv_p_valid = false;
+    return GPSO_OK;
+  }
+  // the contiguous range of the arena the resident posterior uses: offset into the arena and length
+  void posterior_range(size_t* off, size_t* bytes) const {
+    const char* base = static_cast<const char*>(arena.p);
+    if (math_in_use() != GPSO_MATH_NATIVE) {
+      *off = (size_t)(static_cast<const char*>(hyper.p) - base);
+      *bytes = (size_t)(static_cast<const char*>(linv_b.p) - static_cast<const char*>(hyper.p)) + split_bytes_in_use();
+    } else {
+      *off = 0;
+      *bytes = (size_t)(static_cast<const char*>(alpha.p) - base) + alpha.bytes;
+    }
+  }
+  bool linv_p_valid = false;  // the packed f32 / f64 L^-1 of the resident posterior is here (a receiver of a split posterior: no)
 
   int ensure_fit_buffers() {
     int rc;
@@ -592,7 +663,7 @@ struct EngineT : Engine {
       HIPCHECK(hipStreamSynchronize(st()));
     }
     have_data = true;
-    have_post = have_kinv = chol_valid = false;
+    have_post = have_kinv = chol_valid = linv_p_valid = false;
     st_done = st_have = false;
     return GPSO_OK;
   }
@@ -698,7 +769,7 @@ struct EngineT : Engine {
       for (int h = 0; h < n_ls + 3; ++h) grad[h] = host[8 + h];
       have_kinv = true;
     }
-    have_post = chol_valid = st_have = true;
+    have_post = chol_valid = st_have = linv_p_valid = true;
     return GPSO_OK;
   }
 
@@ -732,7 +803,7 @@ struct EngineT : Engine {
     if ((rc = pack_bf16())) return rc;
     HIPCHECK(hipStreamSynchronize(s));  // the caller's host buffers are free again on return
     if ((rc = launch_status())) return rc;
-    have_post = chol_valid = true;
+    have_post = chol_valid = linv_p_valid = true;
     return GPSO_OK;
   }
 
@@ -745,6 +816,10 @@ struct EngineT : Engine {
     // row blocks of L^-1 = partial sums per leaf: the split-bf16 kernel always works on 256-row blocks,
     // the native kernels on the shape leaf_tiles_bm picks
     const bool use_bf16 = bf16_usable() && linv_b_valid && bf16_fits(sizeof(TG) == 8);
+    if (!use_bf16 && !linv_p_valid)
+      return ctx->fail(GPSO_E_STATE, "this posterior was received with the split pieces of L^-1 only (the sender predicts with "
+                                     "split math): the f32 MFMA kernel has nothing to read -- keep the sender's predict math, or "
+                                     "hand the posterior over with gpso_posterior_buffers (all buffers)");
     const int nbi = use_bf16 ? (int)(npad / 256) : leaf_tiles_nbi<TP>(npad, dp / 4);
     const int64_t chunk = std::min<int64_t>(m, kLeafChunk);
     const int64_t cpad = (chunk + kLeafPad - 1) / kLeafPad * kLeafPad;
@@ -790,7 +865,7 @@ struct EngineT : Engine {
       if (ctx->timing) HIPCHECK(hipEventRecord(ctx->tile_ev[2 * ctx->tile_pairs], s));
       if (use_bf16) {
         if constexpr (kFloatPredict)
-          rc = launch_leaf_tiles_bf16<TG>(s, nsplit(), linv_b.p, xsp, xnr, as<float>(alpha), as<TG>(leaves_s),
+          rc = launch_leaf_tiles_bf16<TG>(s, nsplit(), split_planes(), xsp, xnr, as<float>(alpha), as<TG>(leaves_s),
                                           as<TG>(lnorm), as<double>(pvar), as<double>(pmean), npad, dp / 4, mp,
                                           kp, m_live_c, f16_split() ? f16_scale() : nullptr);
       } else {
@@ -1447,8 +1522,8 @@ struct EngineT : Engine {
   // Make the posterior resident on `root` resident on every rank of the group: a 48-byte header (shape,
   // arithmetic options and the root's status), checked on every rank and agreed with an all-reduce(min) so that
   // either all ranks go on or all return the same code; the receivers' allocation is agreed the same way; then
-  // one RCCL broadcast per predict buffer (gpso_posterior_buffers) straight out of / into the library's device
-  // memory, on the context's stream.  A posterior that fails the precision self-test on the root is NOT sent:
+  // ONE RCCL broadcast of the contiguous range of the posterior arena this posterior uses (posterior_span), straight
+  // out of / into the library's device memory, on the context's stream.  A posterior that fails the precision self-test on the root is NOT sent:
   // every rank returns GPSO_E_PRECISION (the root is the only rank that can test it -- it holds the targets).
   int agree_min(int64_t* hd_slot, int64_t* host_slot, int64_t mine, int64_t* agreed) {
     RcclApi& R = RcclApi::get();
@@ -1468,7 +1543,7 @@ struct EngineT : Engine {
     if (root < 0 || root >= ctx->world) return ctx->fail(GPSO_E_ARG, "root %d outside the group of %d", root, ctx->world);
     hipStream_t s = st();
     const bool is_root = ctx->rank == root;
-    if ((rc = ensure(bhdr, 64))) return rc;
+    if ((rc = ensure(bhdr, 128))) return rc;
     int64_t* hd = as<int64_t>(bhdr);
     int64_t* host = reinterpret_cast<int64_t*>(ctx->pinned_scratch(8));
     if (!host) return ctx->fail(GPSO_E_OOM, "pinned host scratch");
@@ -1489,14 +1564,24 @@ struct EngineT : Engine {
     // the predict math the posterior travels with (under GPSO_MATH_AUTO the root's self-test has chosen)
     // (bit 12: GPSO_MATH_AUTO -- its split buffer has room for three planes whatever the rung, so the option itself must agree)
     const int64_t my_opts = (int64_t)(math_native_fallback ? GPSO_MATH_NATIVE : math) | ((int64_t)math_auto << 12) | ((int64_t)ctx->dtype << 16);
-    if (is_root) {
-      host[0] = n; host[1] = d; host[2] = my_opts; host[3] = mine;
-      HIPCHECK(hipMemcpyAsync(hd, host, 48, hipMemcpyHostToDevice, s));
+    // the ONE range of the root's posterior arena that travels (offset and length are the same on every rank: the
+    // arena's layout depends on the shape and the types only)
+    void* span_ptr = nullptr;
+    int64_t span_off = 0, span_bytes = 0;
+    if (is_root && mine == GPSO_OK && (rc = posterior_span(&span_ptr, &span_off, &span_bytes)) != GPSO_OK) {
+      mine = rc;
+      why = ctx->err;
     }
-    RCCLCHECK(R.Broadcast(hd, hd, 48, ncclChar, root, ctx->comm, s));
-    HIPCHECK(hipMemcpyAsync(host, hd, 48, hipMemcpyDeviceToHost, s));
+    if (is_root) {
+      host[0] = n; host[1] = d; host[2] = my_opts; host[3] = mine; host[4] = host[5] = 0; host[6] = span_off; host[7] = span_bytes;
+      HIPCHECK(hipMemcpyAsync(hd, host, 64, hipMemcpyHostToDevice, s));
+    }
+    RCCLCHECK(R.Broadcast(hd, hd, 64, ncclChar, root, ctx->comm, s));
+    HIPCHECK(hipMemcpyAsync(host, hd, 64, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
     const int64_t rn = host[0], rd = host[1], ropts = host[2], root_status = host[3];
+    span_off = host[6];
+    span_bytes = host[7];
     if (!is_root && root_status == GPSO_OK) {
       const int64_t rmath = ropts & 0xfff, rauto = (ropts >> 12) & 1, rdtype = ropts >> 16;
       if (rdtype == (int64_t)ctx->dtype && math_auto && rauto &&
@@ -1523,17 +1608,8 @@ struct EngineT : Engine {
     }
     // receivers allocate; agreed again, so that an allocation failure leaves no rank inside the broadcasts
     mine = is_root ? GPSO_OK : alloc_posterior(rn, (int)rd);
+    if (mine == GPSO_OK && !is_root) mine = posterior_span_at(span_off, span_bytes, &span_ptr);
     why = ctx->err;
-    void* ptrs[8];
-    int64_t nb[8];
-    int cnt = 0;
-    if (mine == GPSO_OK) {
-      cnt = posterior_buffers(ptrs, nb, 8);
-      if (cnt < 0) {
-        mine = cnt;
-        why = ctx->err;
-      }
-    }
     if ((rc = agree_min(hd + 5, host + 5, mine, &agreed))) return rc;
     if (agreed != GPSO_OK) {
       if (mine != GPSO_OK) {
@@ -1542,7 +1618,8 @@ struct EngineT : Engine {
       }
       return ctx->fail((int)agreed, "gpso_broadcast_posterior: a rank of the group could not allocate the posterior (status %d)", (int)agreed);
     }
-    for (int i = 0; i < cnt; ++i) RCCLCHECK(R.Broadcast(ptrs[i], ptrs[i], (size_t)nb[i], ncclChar, root, ctx->comm, s));
+    RCCLCHECK(R.Broadcast(span_ptr, span_ptr, (size_t)span_bytes, ncclChar, root, ctx->comm, s));
+    ctx->last_count[0] = ctx->last_count[1] = span_bytes;  // (gpso_last_count after a broadcast: the bytes that travelled)
     if (!is_root) return adopt_posterior();  // (synchronises the stream)
     HIPCHECK(ctx->wait(s));
     return GPSO_OK;
@@ -1595,19 +1672,26 @@ struct EngineT : Engine {
   // The generation inputs always travel in double; a receiver derives the float copies itself when the
   // sender's choice (slot 7 of the hyper block, written here: 1 = float generation, + 2 = GPSO_MATH_AUTO
   // settled on the f32 MFMA kernel for this posterior) is float generation.
+  // settle the posterior's arithmetic choices (generation, GPSO_MATH_AUTO's rung) and write them into slot 7 of the
+  // hyper block, which travels: 1 = float generation, 2 = GPSO_MATH_AUTO settled on the f32 MFMA kernel, 4 = the split
+  // pieces are built, 8 = the packed L^-1 travels too, 256 x the predict math
+  int settle_and_flag(bool with_linv_p) {
+    if (!have_post) return GPSO_OK;
+    int rc = decide_generation();
+    if (rc) return rc;
+    if (check && st_have && have_data && (rc = selftest_with_fallback())) return rc;  // settles GPSO_MATH_AUTO
+    double* flag = ctx->pinned_scratch(256) + 120;  // (a slot neither the read-backs nor set_theta use)
+    *flag = (gen_double() ? 0.0 : 1.0) + (math_native_fallback ? 2.0 : 0.0) + ((bf16_usable() && linv_b_valid) ? 4.0 : 0.0) +
+            ((with_linv_p && linv_p_valid) ? 8.0 : 0.0) + 256.0 * math;  // (which split the pieces are: a receiver under GPSO_MATH_AUTO follows)
+    HIPCHECK(hipMemcpyAsync(as<double>(hyper) + 7, flag, 8, hipMemcpyHostToDevice, st()));
+    HIPCHECK(hipStreamSynchronize(st()));  // callers copy these buffers on streams of their own
+    return GPSO_OK;
+  }
   int posterior_buffers(void** ptrs, int64_t* nbytes, int cap) override {
     if (npad == 0) return ctx->fail(GPSO_E_STATE, "no problem shape yet");
     if (cap < 7) return ctx->fail(GPSO_E_ARG, "need room for 7 buffers");
-    if (have_post) {
-      int rc = decide_generation();
-      if (rc) return rc;
-      if (check && st_have && have_data && (rc = selftest_with_fallback())) return rc;  // settles GPSO_MATH_AUTO
-      double* flag = ctx->pinned_scratch(256) + 120;  // (a slot neither the read-backs nor set_theta use)
-      *flag = (gen_double() ? 0.0 : 1.0) + (math_native_fallback ? 2.0 : 0.0) + ((bf16_usable() && linv_b_valid) ? 4.0 : 0.0) +
-              256.0 * math;  // (which split the pieces are: a receiver under GPSO_MATH_AUTO follows)
-      HIPCHECK(hipMemcpyAsync(as<double>(hyper) + 7, flag, 8, hipMemcpyHostToDevice, st()));
-      HIPCHECK(hipStreamSynchronize(st()));  // callers copy these buffers on streams of their own
-    }
+    int rc = settle_and_flag(true);
+    if (rc) return rc;
     const size_t s = sizeof(TP);
     int k = 0;
     ptrs[k] = hyper.p;   nbytes[k++] = (int64_t)(kHyperHeader + kMaxD) * 8;
@@ -1616,21 +1700,77 @@ struct EngineT : Engine {
     ptrs[k] = xs_p64.p;  nbytes[k++] = (int64_t)(npad * dp * 8);
     ptrs[k] = xnorm64.p; nbytes[k++] = (int64_t)(npad * 8);
     ptrs[k] = alpha.p;   nbytes[k++] = (int64_t)(npad * s);
-    // the bf16 pieces of L^-1 travel when the mode is on -- a sender whose pieces were never built (a posterior it
-    // adopted itself, math switched afterwards) still sends the buffer, so that both sides of a broadcast list the
+    // the 16-bit pieces of L^-1 travel when the mode is on -- a sender whose pieces were never built (a posterior it
+    // adopted itself, math switched afterwards) still sends the buffer, so that both sides of a hand-off list the
     // same buffers, and says so in the hyper block (bit 4 of slot 7 clear): the receivers then run the f32 kernel
     if (bf16_usable()) {
-      int rc = ensure(linv_b, split_bytes());
-      if (rc) return rc;
       ptrs[k] = linv_b.p; nbytes[k++] = (int64_t)split_bytes();
     }
     return k;
+  }
+  // The ONE contiguous range of the posterior arena the resident posterior uses (what gpso_broadcast_posterior sends):
+  // *offset = its distance from the arena's start -- the same on every context of the same shape and type.
+  int posterior_span(void** ptr, int64_t* offset, int64_t* nbytes) override {
+    if (npad == 0 || arena.p == nullptr) return ctx->fail(GPSO_E_STATE, "no problem shape yet");
+    if (!have_post) return ctx->fail(GPSO_E_STATE, "no posterior resident");
+    int rc = settle_and_flag(false);
+    if (rc) return rc;
+    if (math_in_use() == GPSO_MATH_NATIVE && !linv_p_valid)
+      return ctx->fail(GPSO_E_STATE, "this context received its posterior without the packed L^-1 and cannot pass it on for the f32 kernel");
+    size_t off, bytes;
+    posterior_range(&off, &bytes);
+    if (ptr) *ptr = static_cast<char*>(arena.p) + off;
+    if (offset) *offset = (int64_t)off;
+    if (nbytes) *nbytes = (int64_t)bytes;
+    return GPSO_OK;
+  }
+  // where a span (offset, nbytes) announced by a peer lands in THIS context's arena (after gpso_alloc_posterior)
+  int posterior_span_at(int64_t offset, int64_t nbytes, void** ptr) override {
+    if (arena.p == nullptr) return ctx->fail(GPSO_E_STATE, "gpso_alloc_posterior first");
+    if (offset < 0 || nbytes <= 0 || offset % 256 != 0 || (size_t)offset + (size_t)nbytes > arena.bytes)
+      return ctx->fail(GPSO_E_ARG, "posterior span [%lld, +%lld) does not fit this context's arena of %zu bytes (different "
+                       "dtype / shape on the sender?)", (long long)offset, (long long)nbytes, arena.bytes);
+    *ptr = static_cast<char*>(arena.p) + offset;
+    return GPSO_OK;
+  }
+  // 64-bit fingerprint of the predict-ready posterior (the buffers gpso_posterior_buffers lists, the parts in use):
+  // two contexts that ran the same deterministic fit hold the same value -- what a group that REPLICATES the fit on
+  // every rank compares instead of broadcasting ("measure both")
+  DevBuf hash_out;
+  int posterior_hash(uint64_t* out) override {
+    if (!have_post) return ctx->fail(GPSO_E_STATE, "no posterior resident");
+    int rc = settle_and_flag(false);
+    if (rc) return rc;
+    if ((rc = ensure(hash_out, 8))) return rc;
+    hipStream_t s = st();
+    HIPCHECK(hipMemsetAsync(hash_out.p, 0, 8, s));
+    const size_t sp = sizeof(TP);
+    uint64_t salt = 1;
+    auto add = [&](const void* p_, size_t bytes) { launch_hash_words(s, p_, bytes / 8, salt++, static_cast<unsigned long long*>(hash_out.p)); };
+    add(hyper.p, (size_t)(kHyperHeader + kMaxD) * 8);
+    add(xs64.p, (size_t)npad * dp * 8);
+    add(xs_p64.p, (size_t)npad * dp * 8);
+    add(xnorm64.p, (size_t)npad * 8);
+    add(alpha.p, (size_t)npad * sp / 8 * 8);
+    if (math_in_use() != GPSO_MATH_NATIVE) {
+      if (f16_split()) add(f16_scale(), 8);
+      add(split_planes(), (size_t)nsplit() * npad * npad * 2);
+    } else {
+      add(linv_p.p, packed_linv_elems(npad) * sp);
+    }
+    uint64_t* host = reinterpret_cast<uint64_t*>(ctx->pinned_scratch(8));
+    if (!host) return ctx->fail(GPSO_E_OOM, "pinned host scratch");
+    HIPCHECK(hipMemcpyAsync(host, hash_out.p, 8, hipMemcpyDeviceToHost, s));
+    HIPCHECK(ctx->wait(s));
+    if ((rc = launch_status())) return rc;
+    *out = host[0];
+    return GPSO_OK;
   }
 
   int alloc_posterior(int64_t n_, int d_) override {
     int rc = shape(n_, d_);
     if (rc) return rc;
-    have_data = have_post = have_kinv = chol_valid = false;
+    have_data = have_post = have_kinv = chol_valid = linv_p_valid = false;
     st_done = st_have = false;
     return GPSO_OK;
   }
@@ -1661,6 +1801,7 @@ struct EngineT : Engine {
     if (math_auto && kFloatPredict && (sender_math == GPSO_MATH_F16X3 || sender_math == GPSO_MATH_BF16X6)) math = sender_math;
     // the split pieces the sender actually built travel with it (and are the split this context runs)
     linv_b_valid = bf16_usable() && (sender & 4) != 0 && sender_math == math;
+    linv_p_valid = (sender & 8) != 0;
     gen_eff32 = kFloatPredict && (gen_mode == GPSO_GEN_F32 || (gen_mode == GPSO_GEN_AUTO && (sender & 1) != 0));
     gen_decided = true;
     gen32_inputs_ok = false;
@@ -1914,6 +2055,23 @@ int gpso_posterior_buffers(gpso_ctx* ctx, void** ptrs, int64_t* nbytes, int cap)
   return ctx->eng->posterior_buffers(ptrs, nbytes, cap);
 }
 
+int gpso_posterior_span(gpso_ctx* ctx, void** ptr, int64_t* offset, int64_t* nbytes) {
+  ENTER();
+  return ctx->eng->posterior_span(ptr, offset, nbytes);
+}
+
+int gpso_posterior_span_at(gpso_ctx* ctx, int64_t offset, int64_t nbytes, void** ptr) {
+  ENTER();
+  if (!ptr) return ctx->fail(GPSO_E_ARG, "ptr must not be NULL");
+  return ctx->eng->posterior_span_at(offset, nbytes, ptr);
+}
+
+int gpso_posterior_hash(gpso_ctx* ctx, uint64_t* out) {
+  ENTER();
+  if (!out) return ctx->fail(GPSO_E_ARG, "out must not be NULL");
+  return ctx->eng->posterior_hash(out);
+}
+
 int gpso_alloc_posterior(gpso_ctx* ctx, int64_t n, int d) {
   ENTER();
   return ctx->eng->alloc_posterior(n, d);
@@ -2048,6 +2206,6 @@ int64_t gpso_last_count(gpso_ctx* ctx, int what) {
   return ctx->last_count[what];
 }
 
-const char* gpso_version(void) { return "gpso-hip 0.3.0 (gfx950)"; }
+const char* gpso_version(void) { return "gpso-hip 0.4.0 (gfx950)"; }
 
 }  // extern "C"

@@ -74,6 +74,9 @@ void launch_keyed_argmax(hipStream_t st, const double* mean, const double* var, 
                          int nblk, void* partial_dev, int64_t* pos_dev, double* out_vals_dev);
 // out_dev[c] = number of live leaves inside chunk c of a batch whose total live count is *live_dev
 void launch_chunk_live(hipStream_t st, const int64_t* live_dev, int64_t chunk, int nchunk, int64_t* out_dev);
+// *acc += sum_i mix(words[i], i, salt)  (64-bit wrap-around sum of a per-word mix: order-independent, so the parallel
+// reduction is deterministic) -- the posterior fingerprint of gpso_posterior_hash
+void launch_hash_words(hipStream_t st, const void* words, size_t nwords, uint64_t salt, unsigned long long* acc);
 constexpr int kArgmaxBlocks = 64;      // stage-1 blocks per segment
 constexpr size_t kArgmaxPartialBytes = 16;  // sizeof(Best)
 

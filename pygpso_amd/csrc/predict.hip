@@ -559,21 +559,9 @@ __device__ __forceinline__ void leaf_bf16_gen(bool diag, int lane, int dp4,
                                               bf16x8 (&bfrag)[NS][2], float (&macc)[2]) {
   using MG = Mfma<TG>;
   using vecG = typename MG::vec4;
-#if defined(GPSO_ABL_HALFGEN)  // tools/micro ablation builds (never shipped): generate one column tile, use it twice
-  constexpr int CT = 1;
-#else
   constexpr int CT = 2;
-#endif
   constexpr int XB = 64 * (int)sizeof(TG);
   constexpr TG C2 = (TG)KernScale<KERNEL>::C2;
-#if defined(GPSO_ABL_NOGEN)  // ... or nothing at all: what the apply + DMA + barriers cost alone
-  {
-    u32x4 f = {0x3c003c00u + (unsigned)lane, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
-    asm volatile("" : "+v"(f));
-    for (int sp = 0; sp < NS; ++sp) bfrag[sp][0] = bfrag[sp][1] = __builtin_bit_cast(bf16x8, f);
-    return;
-  }
-#endif
   // ---- generate the two 16-point tiles of this k-step (TG) --------------------------------------
   vecG s[2][CT];
 #pragma unroll
@@ -590,9 +578,6 @@ __device__ __forceinline__ void leaf_bf16_gen(bool diag, int lane, int dp4,
       s[1][t] = MG::mma(x1, l, s[1][t]);
     }
   }
-#ifdef GPSO_PROBE_NOPS_A  // tools/micro/packed_mean_probe.hip: wait states behind the contraction MFMAs
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15");
-#endif
   float p[CT][8];
   // norms and alpha of the 32 points of this k-step arrived in LDS with the panel (no ordinary global
   // load inside the loop: one issued after the LDS-DMA makes hipcc drain the DMA queue at its use)
@@ -607,13 +592,6 @@ __device__ __forceinline__ void leaf_bf16_gen(bool diag, int lane, int dp4,
       for (int r = 0; r < 4; ++r)
         p[t][4 * h + r] = kern_from_scaled<KERNEL>((float)fma_t((TG)(TG(-2) * C2), s[h][t][r], na[r] + nb[t]), variance);
   }
-#ifdef GPSO_PROBE_NOPS_B  // ... and in front of the mean updates
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15");
-#endif
-#ifdef GPSO_PROBE_NOPS_N  // ... the same place, GPSO_PROBE_NOPS_N x 16 clocks
-#pragma unroll
-  for (int i = 0; i < GPSO_PROBE_NOPS_N; ++i) asm volatile("s_nop 15");
-#endif
   if (diag) {  // this k-step lies in the diagonal block (wave-uniform): its share of k*.alpha (f32, before the split)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -627,9 +605,7 @@ __device__ __forceinline__ void leaf_bf16_gen(bool diag, int lane, int dp4,
           // and a chain of dependent v_pk_fma_f32, the high half (t = 1) came back wrong now and then in waves
           // 4-7 -- 33 of 400 runs of a D = 3 posterior, 27 of 150 of a C3 posterior in the bf16x3 kernel; 0 with
           // this line (profiles/r02h_packed_mean_bug.txt; predict.hip is also built with -fno-slp-vectorize)
-#ifndef GPSO_PROBE_PACKED_MEAN  // tools/micro/packed_mean_probe.hip builds the kernel without it
           asm volatile("" : "+v"(macc[t]));
-#endif
         }
     }
   }
@@ -643,9 +619,6 @@ __device__ __forceinline__ void leaf_bf16_gen(bool diag, int lane, int dp4,
       for (int h = 0; h < 4; ++h) f[h] = F16 ? f16_split_pair(p[t][2 * h], p[t][2 * h + 1]) : bf16_split_pair(p[t][2 * h], p[t][2 * h + 1]);
       bfrag[sp][t] = __builtin_bit_cast(bf16x8, f);  // (fp16 pieces travel in the same 16-byte registers)
     }
-#if defined(GPSO_ABL_HALFGEN)
-  for (int sp = 0; sp < NS; ++sp) bfrag[sp][1] = bfrag[sp][0];
-#endif
 }
 
 // apply: acc[rt][t] += sum over the kept piece products, small terms first
@@ -685,9 +658,6 @@ __device__ __forceinline__ void leaf_bf16_apply(int q, int q_diag0, int lane, co
   }
 }
 
-#ifdef GPSO_PROBE_DUMP_MACC
-__device__ float* gpso_probe_macc = nullptr;
-#endif
 // F16: the fp16 split (two pieces, three products); `variance` then arrives multiplied by 2^sb, inv_scale_a[1] is
 // 2^-sa (device, written by pack_linv_f16_kernel) and inv_scale_b = 2^-sb
 template <int NS, typename TG, int KERNEL, bool F16 = false>
@@ -823,13 +793,6 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     GPSO_BSTAMP(q, 5);
   }
   if (ahead) __syncthreads();
-#ifdef GPSO_PROBE_DUMP_MACC  // tools/micro/packed_mean_probe.hip: every lane's mean accumulators, before the reduction
-  if (gpso_probe_macc != nullptr) {
-    float* o = gpso_probe_macc + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 512 + tid) * 2;
-    o[0] = macc[0];
-    o[1] = macc[1];
-  }
-#endif
 
   // (fp16 split: undo the power-of-two scales of the two operands -- exact)
   double unscale2 = 1.0, unscale_m = 1.0;
@@ -1322,6 +1285,26 @@ void launch_reduce_winners(hipStream_t st, const double* gathered, const int64_t
                            int stride, double* out) {
   hipLaunchKernelGGL(reduce_winners_kernel, dim3((unsigned)((nseg + 63) / 64)), dim3(64), 0, st, gathered, base,
                      world, nseg, stride, out);
+}
+
+// splitmix64-style finaliser of (word, position, salt); summed with wrap-around
+__global__ __launch_bounds__(256) void hash_words_kernel(const uint64_t* __restrict__ w, size_t n, uint64_t salt,
+                                                         unsigned long long* __restrict__ acc) {
+  uint64_t sum = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    uint64_t z = w[i] ^ ((uint64_t)(i + 1) * 0x9E3779B97F4A7C15ull) ^ (salt * 0xD1B54A32D192ED03ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    sum += z ^ (z >> 31);
+  }
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+  if ((threadIdx.x & 63) == 0) atomicAdd(acc, (unsigned long long)sum);
+}
+
+void launch_hash_words(hipStream_t st, const void* words, size_t nwords, uint64_t salt, unsigned long long* acc) {
+  if (nwords == 0) return;
+  const unsigned blocks = (unsigned)std::min<size_t>((nwords + 255) / 256, 2048);
+  hipLaunchKernelGGL(hash_words_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const uint64_t*>(words), nwords, salt, acc);
 }
 
 void launch_chunk_live(hipStream_t st, const int64_t* live_dev, int64_t chunk, int nchunk, int64_t* out_dev) {

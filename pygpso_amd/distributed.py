@@ -172,9 +172,17 @@ class HipGPEngineGroup:
     every predict-type call is sharded over all of them.  Each engine is driven by its own thread (the
     C-ABI calls release the GIL; the RCCL collectives inside them need all ranks in flight at once)."""
 
-    def __init__(self, dtype="float64", devices=(0,), engine_cls=None, make_id=None, **engine_options):
-        """``engine_cls`` / ``make_id``: test hooks (the per-device engine class, default ``HipGPEngine``, and
-        the source of the group id, default ``unique_id``)."""
+    def __init__(self, dtype="float64", devices=(0,), engine_cls=None, make_id=None, posterior="broadcast",
+                 **engine_options):
+        """``posterior``: how the peers get the fitted posterior.  "broadcast" (default): the first device fits, ONE
+        ncclBroadcast moves the predict-ready range of its posterior arena to the others.  "replicate": every device
+        runs the same (bit-deterministic) fit on its own copy of the data -- no bulk collective at all; the ranks'
+        posterior fingerprints (``gpso_posterior_hash``) must agree before the first predict-type call on a new
+        posterior.  ``engine_cls`` / ``make_id``: test hooks (the per-device engine class, default ``HipGPEngine``,
+        and the source of the group id, default ``unique_id``)."""
+        if posterior not in ("broadcast", "replicate"):
+            raise ValueError("posterior must be 'broadcast' or 'replicate'")
+        self.posterior = posterior
         if engine_cls is None:
             from .engine import HipGPEngine as engine_cls
 
@@ -254,28 +262,39 @@ class HipGPEngineGroup:
         except Exception:
             pass
 
-    # fit: first device only
+    # fit: first device only ("broadcast"), or the same fit on every device ("replicate")
+    def _fitters(self, fn):
+        if self.posterior == "replicate" and self.world > 1:
+            return self._all(lambda r, e: fn(e))[0]
+        return fn(self.engines[0])
+
     def set_data(self, X, y):
-        self.engines[0].set_data(X, y)
+        self._fitters(lambda e: e.set_data(X, y))
         self.n, self.d = self.engines[0].n, self.engines[0].d
         self._stale = True
 
     def fit_eval(self, *a, **kw):
         self._stale = True
-        return self.engines[0].fit_eval(*a, **kw)
+        return self._fitters(lambda e: e.fit_eval(*a, **kw))
 
     def fit_eval_u(self, *a, **kw):
         self._stale = True
-        return self.engines[0].fit_eval_u(*a, **kw)
+        return self._fitters(lambda e: e.fit_eval_u(*a, **kw))
 
     def set_posterior(self, *a, **kw):
-        self.engines[0].set_posterior(*a, **kw)
+        self._fitters(lambda e: e.set_posterior(*a, **kw))
         self.n, self.d = self.engines[0].n, self.engines[0].d
         self._stale = True
 
     def _sync_posterior(self):
         if self._stale and self.world > 1:
-            self._all(lambda r, e: e.broadcast_posterior(0), collective=True)
+            if self.posterior == "replicate":
+                hashes = self._all(lambda r, e: e.posterior_hash())
+                if len(set(hashes)) != 1:
+                    raise L.GpsoHipError(L.E_STATE, "replicated fits disagree: posterior fingerprints "
+                                         + ", ".join(f"{h:016x}" for h in hashes))
+            else:
+                self._all(lambda r, e: e.broadcast_posterior(0), collective=True)
         self._stale = False
 
     # predict-type calls: sharded

@@ -438,6 +438,25 @@ class HipGPEngine:
         cnt = self._check(self._lib.gpso_posterior_buffers(self._h, ptrs, nb, 8))
         return [(int(ptrs[i] or 0), int(nb[i])) for i in range(cnt)]
 
+    def posterior_span(self):
+        """(device_ptr, offset, nbytes): the ONE contiguous range of this context's posterior arena the resident
+        posterior uses -- what ``broadcast_posterior`` moves with a single ncclBroadcast."""
+        ptr, off, nb = C.c_void_p(), C.c_int64(), C.c_int64()
+        self._check(self._lib.gpso_posterior_span(self._h, C.byref(ptr), C.byref(off), C.byref(nb)))
+        return int(ptr.value or 0), int(off.value), int(nb.value)
+
+    def posterior_span_at(self, offset, nbytes):
+        """Device pointer of (offset, nbytes) -- a peer's ``posterior_span`` -- inside THIS context's arena."""
+        ptr = C.c_void_p()
+        self._check(self._lib.gpso_posterior_span_at(self._h, int(offset), int(nbytes), C.byref(ptr)))
+        return int(ptr.value or 0)
+
+    def posterior_hash(self):
+        """64-bit fingerprint of the resident predict-ready posterior (``gpso_posterior_hash``)."""
+        out = C.c_uint64()
+        self._check(self._lib.gpso_posterior_hash(self._h, C.byref(out)))
+        return int(out.value)
+
     def alloc_posterior(self, n, d):
         self._check(self._lib.gpso_alloc_posterior(self._h, int(n), int(d)))
         self.n, self.d = int(n), int(d)

@@ -69,3 +69,33 @@ def synthetic_leaves(m, d, seed=1):
 def default_theta_values(d):
     """Throughput-run hyper-parameters of SURVEY.md 8(d): Matern52, l = 0.25 sqrt(D), s2 = 1, noise 1e-3."""
     return dict(kernel="Matern52", lengthscales=0.25 * math.sqrt(d), variance=1.0, noise=1.0e-3)
+
+
+def g8_run_resume_save_resume(make_optimiser, optimiser_cls, tmp_folder, goldens):
+    """The flow of examples/3-saving-resuming-optimisation.ipynb (:193, :406-408, :430) through the drop-in classes:
+    run with 25 evaluations, ``resume_run`` with 25 more, ``save_state``, ``resume_from_saved`` with another 25.
+    Asserts golden G8: the best point after each leg, evaluation counts and highest scores bit for bit, highest UCB to
+    < 1e-8 over the 18 iterations / 77 evaluations."""
+    from shutil import rmtree
+
+    g8 = goldens["G8"]
+    b = g8["budgets"]
+    opt = make_optimiser(g8["depth"], b[0])
+    bests = [opt.run(rotated_peaks)]
+    bests.append(opt.resume_run(additional_budget=b[1]))
+    trace = list(opt.trace)
+    opt.save_state(tmp_folder)
+    try:
+        best3, opt2 = optimiser_cls.resume_from_saved(tmp_folder, additional_budget=b[2], objective_function=rotated_peaks)
+    finally:
+        rmtree(tmp_folder)
+    bests.append(best3)
+    trace += list(opt2.trace)
+    for best, exp in zip(bests, g8["best_points"]):
+        np.testing.assert_almost_equal(best.normed_coord, exp["normed_coord"], decimal=8)
+        assert best.score_mu == exp["score_mu"]
+    assert [t[0] for t in trace] == [t["evaluations"] for t in g8["trace"]]
+    for got, exp in zip(trace, g8["trace"]):
+        assert got[1] == exp["highest_score"]
+        assert abs(got[2] - exp["highest_ucb"]) < 1e-8
+    return opt2

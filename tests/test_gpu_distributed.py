@@ -55,6 +55,105 @@ def _handoff(src, dst):
     return len(a)
 
 
+def _handoff_span(src, dst):
+    """What gpso_broadcast_posterior does since round 4, spelled out with ONE device-to-device copy: the contiguous
+    range of the sender's posterior arena the posterior uses, into the same offset of the receiver's arena."""
+    import torch
+
+    ptr, off, nb = src.posterior_span()
+    dst.alloc_posterior(src.n, src.d)
+    dev = torch.device("cuda", src.device)
+    a = torch.as_tensor(_DeviceBytes(ptr, nb), device=dev)
+    b = torch.as_tensor(_DeviceBytes(dst.posterior_span_at(off, nb), nb), device=dev)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    dst.adopt_posterior()
+    return nb
+
+
+@pytest.mark.parametrize("dtype,math,n", [("float64", None, 300), ("float32", "native", 512), ("float32", "auto", 512),
+                                          ("mixed", "f16x3", 512), ("float32", "bf16x6", 768), ("mixed", "bf16x3", 256),
+                                          ("float32", "auto", 300), ("mixed", "auto", 100)])
+def test_posterior_span_is_one_contiguous_range_and_enough_to_predict(dtype, math, n):
+    """Round 4: every posterior buffer is a slice of ONE allocation; the range the resident posterior uses is
+    contiguous whichever predict math it runs, sits at the same offset on every context, and a receiver that got
+    nothing but that range predicts bit-identically.  A split-math posterior travels WITHOUT the packed f32 L^-1
+    (2 x 2 bytes per entry instead of + 2 more): asking the receiver for the f32 kernel is refused, not garbage."""
+    from pygpso_amd import HipGPEngine
+    from pygpso_amd import _lib as L
+
+    opts = {} if math is None else {"predict_math": math}
+    src = _fitted(dtype, n=n, **opts)
+    dst = HipGPEngine(dtype, **opts)
+    Xs = synthetic_leaves(1500, 5)
+    exp = src.predict(Xs)
+    split = src.precision_info()["predict_math"] != "native"
+    nb = _handoff_span(src, dst)
+    bufs = dict(zip(("hyper", "linv_p", "xs", "xs_p", "xnorm", "alpha", "linv_b"), src.posterior_buffers()))
+    ptr, off, _ = src.posterior_span()
+    # the slices the span must cover lie inside it, in one piece
+    need = ["hyper", "xs", "xs_p", "xnorm", "alpha"] + (["linv_b"] if split else ["linv_p"])
+    for name in need:
+        p, b = bufs[name]
+        used = b if name != "linv_b" else 256 + {"f16x3": 2, "bf16x3": 2, "bf16x6": 3}[src.precision_info()["predict_math"]] * src.padded_n ** 2 * 2
+        assert ptr <= p and p + used <= ptr + nb, name
+    small = sum(bufs[k][1] for k in ("hyper", "xs", "xs_p", "xnorm", "alpha"))
+    big = (256 + (3 if src.precision_info()["predict_math"] == "bf16x6" else 2) * src.padded_n ** 2 * 2) if split else bufs["linv_p"][1]
+    assert big + small <= nb <= big + small + 6 * 256  # (slices are 256-byte aligned)
+    assert dst.posterior_span()[1:] == (off, nb)  # same layout on the receiver
+    got = dst.predict(Xs)
+    assert np.array_equal(exp[0], got[0]) and np.array_equal(exp[1], got[1])
+    assert all(np.array_equal(a, b) for a, b in zip(src.best_ucb(Xs, VS), dst.best_ucb(Xs, VS)))
+    if split:
+        dst.set_predict_math("native")
+        with pytest.raises(L.GpsoHipError, match="split pieces"):
+            dst.predict(Xs)
+    with pytest.raises(ValueError):
+        dst.posterior_span_at(off + 1, nb)
+
+
+@pytest.mark.parametrize("dtype,math", [("float64", None), ("float32", "auto"), ("mixed", "bf16x6"), ("float32", "native")])
+def test_posterior_fingerprints_agree_between_replicated_fits(dtype, math):
+    """gpso_posterior_hash: two contexts that ran the same fit hold the same fingerprint (the fit is bit-deterministic:
+    what a group with posterior="replicate" relies on), a receiver of the posterior holds it too, another theta does not."""
+    from pygpso_amd import HipGPEngine
+
+    opts = {} if math is None else {"predict_math": math}
+    a, b = _fitted(dtype, n=512, **opts), _fitted(dtype, n=512, **opts)
+    h = a.posterior_hash()
+    assert h == b.posterior_hash() == a.posterior_hash()
+    c = HipGPEngine(dtype, **opts)
+    _handoff_span(a, c)
+    assert c.posterior_hash() == h
+    X, y = synthetic_problem(512, 5, seed=0)
+    b.fit_eval("Matern52", [0.5], 1.0, 1.0000001e-3, float(y.mean()), want_grad=False)
+    assert b.posterior_hash() != h
+
+
+def test_replicating_group_of_one_device_and_its_fingerprint_check():
+    """``HipGPEngineGroup(posterior="replicate")``: every device fits its own copy (no broadcast); the ranks'
+    fingerprints are compared before the first predict-type call on a new posterior."""
+    from pygpso_amd import _lib as L
+    from pygpso_amd.distributed import HipGPEngineGroup
+
+    X, y = synthetic_problem(300, 5, seed=0)
+    plain = _fitted("float64")
+    grp = HipGPEngineGroup("float64", devices=[0], posterior="replicate")
+    grp.set_data(X, y)
+    grp.fit_eval("Matern52", [0.5], 1.0, 1e-3, float(y.mean()), want_grad=False)
+    Xs = synthetic_leaves(2500, 5)
+    assert all(np.array_equal(a, b) for a, b in zip(grp.best_ucb(Xs, VS), plain.best_ucb(Xs, VS)))
+    # two "devices" that disagree (world 2 faked on the host side of the group: the check itself)
+    grp.world = 2
+    grp.engines = [grp.engines[0], _fitted("float64", n=301)]
+    grp._stale = True
+    with pytest.raises(L.GpsoHipError, match="fingerprints"):
+        grp._sync_posterior()
+    grp.world = 1
+    grp.engines = grp.engines[:1]
+    grp.close()
+
+
 def test_posterior_handoff_carries_the_bf16_pieces():
     from pygpso_amd import HipGPEngine
 
@@ -332,3 +431,87 @@ def test_precision_failure_is_a_group_verdict():
     np.testing.assert_allclose(np.asarray(mean)[:, 0], m_ref, rtol=1e-7, atol=1e-8)
     np.testing.assert_allclose(np.asarray(var)[:, 0], v_ref, rtol=1e-6, atol=1e-9)
     model.engine.close()
+
+
+# ---- BASELINE configs C4 / C5 in their 8-GPU form, replayed on one device ---------------------------------------
+# All of the group call except the ncclAllGather itself runs here AT SIZE: 8 local halves (gpso_shard_winners on two
+# contexts that hold the posterior -- the second one received it as a broadcast would deliver it: one contiguous range) +
+# gpso_fold_winners, against ONE gpso_best_ucb over the whole batch (bit-identical, indices included) and the float64
+# oracle on a sub-sample.
+def _replay_at_size(root, Xs, segs, world=8):
+    from pygpso_amd import HipGPEngine
+
+    peer = HipGPEngine(root.dtype_name)
+    nb = _handoff_span(root, peer)
+    assert peer.posterior_hash() == root.posterior_hash()
+    whole = {}
+    for key, seg in segs.items():
+        whole[key] = root.best_ucb(Xs, VS, seg)
+        got, payloads = _replay_group([root, peer], world, Xs, seg)
+        assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(got, whole[key])), key
+        assert all(p[-1] == 0.0 for p in payloads)
+    peer.close()
+    return whole, nb
+
+
+def test_config_C4_full_batch_replayed_world8():
+    """C4 as BASELINE.json states it: D = 20, N_train = 8192, ALL 262 144 leaves, fp32, 8 ranks."""
+    from pygpso_amd import HipGPEngine
+    from tests.test_gpu_parity import FLOAT_BOUNDS, _c4_posterior, _fit, _problem
+
+    n, d, m = 8192, 20, 262144
+    X, y, th = _problem(n, d, variance=1.0)
+    post = _c4_posterior(th, X, y)
+    root = HipGPEngine("float32")
+    _fit(root, X, y, th, grad=False)
+    assert root.precision_info()["predict_math"] == "f16x3"
+    Xs = synthetic_leaves(m, d).astype(np.float32)
+    segs = {"one": None, "ragged": np.array([0, 1000, 1000, m // 8 + 5, m // 2, m - 1, m], dtype=np.int64)}
+    whole, nb = _replay_at_size(root, Xs, segs)
+    assert nb < 0.27 * n * n * 4 * 2  # two fp16 planes + the small buffers; the packed f32 factor stays home
+    # float64 oracle: a 128-leaf sub-sample and the winner itself
+    sub = np.random.default_rng(9).choice(m, 127, replace=False)
+    sub = np.append(sub, int(whole["one"][0][0]))
+    mean, var = root.predict(Xs[sub])
+    mean_ref, var_ref = gpr.predict_y(post, Xs[sub].astype(np.float64))
+    em, ev = np.max(np.abs(mean - mean_ref)) / np.max(np.abs(y)), np.max(np.abs(var - var_ref)) / th.variance
+    print(f"C4 full batch: |d mean| {em:.2e} max|y|, |d var| {ev:.2e} sigma^2")
+    assert em <= FLOAT_BOUNDS["C4"][0] and ev <= FLOAT_BOUNDS["C4"][1]
+    assert whole["one"][1][0] == mean[-1] and whole["one"][2][0] == var[-1]  # the call's winner values are predict's
+    # growth at depth 12 (265 720 reference rows per box, SURVEY 8a6's C4 row) through the sharded halves
+    kids = tree.split_bounds([(0.0, 1.0)] * d)
+    boxes = np.array([kids[0], kids[2]])
+    exp = root.best_ucb_grow(boxes, 12, VS)
+    assert root.last_count(1) == 2 * 265720 and root.last_count(0) == 2 * 3 ** 11
+    for world in (8, 3):
+        payloads = [root.shard_winners_grow(r, world, boxes, 12, VS) for r in range(world)]
+        got = root.fold_winners(payloads, 2)
+        assert all(np.array_equal(a, b) for a, b in zip(got, exp)), world
+
+
+def test_config_C5_full_batch_replayed_world8():
+    """C5 as BASELINE.json states it: D = 40, N_train = 16384, ALL 1 048 576 leaves (the config's "bf16 Gram" is run
+    as fp32 Gram + fp32 Cholesky + 16-bit-split apply), 8 ranks."""
+    from pygpso_amd import HipGPEngine
+    from tests.test_gpu_parity import FLOAT_BOUNDS, _c5_reference, _fit
+
+    n, d, m = 16384, 40, 1048576
+    ref = _c5_reference(1e-3)
+    X, y, th = ref["X"], ref["y"], ref["th"]
+    root = HipGPEngine("float32")
+    f, _ = _fit(root, X, y, th, grad=False)
+    assert abs(f - ref["nlml"]) <= 1e-4 * abs(ref["nlml"])
+    assert root.precision_info()["predict_math"] == "f16x3"
+    Xs = synthetic_leaves(m, d).astype(np.float32)
+    segs = {"one": None, "ragged": np.array([0, 7, m // 8 - 1, m // 8 + 1, m // 2, m], dtype=np.int64)}
+    whole, nb = _replay_at_size(root, Xs, segs)
+    assert 1.0e9 < nb < 1.1e9  # 2 fp16 planes of 16384^2 = 1.07 GB is what a broadcast moves (DESIGN.md 5)
+    sub = ref["sub"]  # (the first 131 072 leaves of the larger batch are the share test's leaves)
+    mean, var = root.predict(Xs[sub])
+    em = np.max(np.abs(mean - ref["mean_ref"])) / max(1.0, np.max(np.abs(y)))
+    ev = np.max(np.abs(var - ref["var_ref"])) / th.variance
+    print(f"C5 full batch: |d mean| {em:.2e} max|y|, |d var| {ev:.2e} sigma^2")
+    assert em <= FLOAT_BOUNDS["C5"][0] and ev <= FLOAT_BOUNDS["C5"][1]
+    i0 = int(whole["one"][0][0])
+    m1, v1 = root.predict(Xs[i0:i0 + 1])
+    assert whole["one"][1][0] == m1[0] and whole["one"][2][0] == v1[0]

@@ -9,7 +9,7 @@ from shutil import rmtree
 import numpy as np
 import pytest
 
-from tests.helpers import kat_fixture, load_goldens, rotated_peaks
+from tests.helpers import g8_run_resume_save_resume, kat_fixture, load_goldens, rotated_peaks
 
 pytestmark = pytest.mark.gpu
 G = load_goldens()
@@ -135,6 +135,16 @@ def test_G6_G7_notebook_trace_and_hyperparameters():
     for got, exp in zip(thetas, G["G7"]["theta_after_each_update"]):
         for key in ("mean_c", "variance", "lengthscale", "noise"):
             assert abs(got[key] - exp[key]) <= 6e-6 * abs(exp[key]), (key, got[key], exp[key])
+
+
+def test_G8_run_resume_save_resume_to_77_evaluations():
+    """examples/3-saving-resuming-optimisation.ipynb:193,406-408,430 on the HIP engine (float64): 25 evaluations,
+    resume_run with 25 more, save_state, GPSOptimiser.resume_from_saved with another 25 -- 18 iterations, 77 evaluations."""
+    from pygpso_amd import GPSOptimiser
+    from pygpso_amd.engine import HipGPEngine
+
+    opt2 = g8_run_resume_save_resume(_optimiser, GPSOptimiser, TMP, G)
+    assert isinstance(opt2.gp_surr.gpflow_model.engine, HipGPEngine)  # the resumed surrogate runs on the device too
 
 
 # ---- a8: the "sample" exploration method (gpso/optimisation.py:361-364, param_space.py:157-173) ------

@@ -6,8 +6,10 @@ Stated tolerances
   float64 ..... |d mean|, |d var| <= 1e-9 * scale; L, L^-1, alpha, NLML, gradient <= 1e-9 relative
                 (Matern12: 1e-5 -- its sqrt at r = 0 amplifies the rounding noise of the GEMM-form r^2
                 on the diagonal, |r^2| ~ 1e-16 -> r ~ 1e-8, differently in any two implementations)
-  float32 ..... noise/variance ratio >= 1e-3: |d mean| <= 2e-3 * max|y|,
-                |d var| <= 2e-4 * sigma^2, NLML 2e-5 relative; winners compared by oracle-UCB value
+  float32 ..... noise/variance ratio >= 1e-3: small shapes |d mean| <= 2e-3 * max|y|,
+                |d var| <= 2e-4 * sigma^2; at the BASELINE sizes the per-family bounds of FLOAT_BOUNDS (<= 5x measured) and,
+                for the f32-class split modes, within 4x of the native f32 kernel's error; NLML 2e-5 relative; winners
+                compared by oracle-UCB value
 """
 import numpy as np
 import pytest
@@ -37,6 +39,9 @@ def _fit(eng, X, y, th, grad=True):
     eng.set_data(X, y)
     return eng.fit_eval(th.kernel, th.lengthscales, th.variance, th.noise, th.mean_c, want_grad=grad)
 
+
+# float32 fit + float predict at the small shapes (N <= 2048, noise / variance = 1e-3): (|d mean| / max|y|, |d var| / sigma^2)
+SMALL_FLOAT_BOUNDS = (2e-3, 2e-4)  # tightened to <= 5x the measured maxima once a GPU run has printed them
 
 # float32 engines: the winner is the oracle's arg-max, or a leaf whose ORACLE ucb lies within the rounding of a float
 # prediction of it -- 2e-5 max(1, |ucb_max|): the mean carries ~1e-5-class float error (|d mean| measured 1e-5 ..
@@ -111,8 +116,9 @@ def test_fit_and_predict_fp32(n, d, m):
     assert np.max(np.abs(g - g_ref) / np.maximum(1.0, np.abs(g_ref))) < 5e-3
     mean, var = eng.predict(Xs)
     mean_ref, var_ref = gpr.predict_y(post, Xs)
-    assert np.max(np.abs(mean - mean_ref)) <= 2e-3 * np.max(np.abs(y))
-    assert np.max(np.abs(var - var_ref)) <= 2e-4 * th.variance
+    em, ev = np.max(np.abs(mean - mean_ref)) / np.max(np.abs(y)), np.max(np.abs(var - var_ref)) / th.variance
+    print(f"fp32 fit+predict N={n} D={d}: |d mean| {em:.2e} max|y|, |d var| {ev:.2e} sigma^2")
+    assert em <= SMALL_FLOAT_BOUNDS[0] and ev <= SMALL_FLOAT_BOUNDS[1]
     _winner_is_the_oracles(eng.best_ucb(Xs, VS), mean_ref, var_ref)
 
 
@@ -136,8 +142,9 @@ def test_split_bf16_predict_math(mode, n, d, m, kernel):
     _fit(eng, X, y, th, grad=False)
     mean, var = eng.predict(Xs)
     mean_ref, var_ref = gpr.predict_y(post, Xs)
-    assert np.max(np.abs(mean - mean_ref)) <= 2e-3 * np.max(np.abs(y))
-    assert np.max(np.abs(var - var_ref)) <= 2e-4 * th.variance
+    em, ev = np.max(np.abs(mean - mean_ref)) / np.max(np.abs(y)), np.max(np.abs(var - var_ref)) / th.variance
+    print(f"split {mode} N={n} D={d} {kernel}: |d mean| {em:.2e} max|y|, |d var| {ev:.2e} sigma^2")
+    assert em <= SMALL_FLOAT_BOUNDS[0] and ev <= (SMALL_FLOAT_BOUNDS[1] if mode != "bf16x3" else 2e-4)
     if mode in ("bf16x6", "f16x3"):  # f32-class: within 4x of what the native f32 kernel achieves on the same problem
         nat = HipGPEngine("float32")
         _fit(nat, X, y, th, grad=False)
@@ -549,7 +556,9 @@ def test_best_ucb_grow_in_several_chunks():
 
 
 # ---- BASELINE.json sizes: oracle on a subsample + size-independent properties ----------------------
-def _properties(eng, X, y, th, Xs, post, n_check):
+def _properties(eng, X, y, th, Xs, post, n_check, family="C3", native=None):
+    """``family``: which row of FLOAT_BOUNDS the oracle comparison is held to; ``native``: an engine with the f32 MFMA
+    kernel holding the same posterior -- a split-math engine must then also be within 4x of its error."""
     m = Xs.shape[0]
     mean, var = eng.predict(Xs)
     assert np.all(np.isfinite(mean)) and np.all(np.isfinite(var))
@@ -558,8 +567,15 @@ def _properties(eng, X, y, th, Xs, post, n_check):
     # oracle on a random subsample
     sub = np.random.default_rng(9).choice(m, n_check, replace=False)
     mean_ref, var_ref = gpr.predict_y(post, Xs[sub])
-    assert np.max(np.abs(mean[sub] - mean_ref)) <= 2e-3 * np.max(np.abs(y))
-    assert np.max(np.abs(var[sub] - var_ref)) <= 2e-4 * th.variance
+    bm, bv = FLOAT_BOUNDS[family]
+    math = eng.precision_info()["predict_math"]
+    em, ev = np.max(np.abs(mean[sub] - mean_ref)) / np.max(np.abs(y)), np.max(np.abs(var[sub] - var_ref)) / th.variance
+    print(f"{family} {math}: |d mean| {em:.2e} ({em / bm:.2f} of the bound), |d var| {ev:.2e} ({ev / bv:.2f})")
+    assert em <= bm
+    assert ev <= (bv if math != "bf16x3" else 2e-4)
+    if native is not None and math in ("f16x3", "bf16x6"):
+        _, var_nat = native.predict(Xs[sub])
+        assert _close_to_native(var[sub], var_nat, var_ref)
     # at the training inputs the posterior interpolates: |mean - y| small, latent variance ~ 0
     k = min(512, X.shape[0])
     mt, vt = eng.predict(X[:k])
@@ -608,6 +624,36 @@ def test_dimension_and_size_limits():
     assert eng.predict(synthetic_leaves(5, 48))[0].shape == (5,)
 
 
+_c5_cache = {}
+
+
+def _c5_reference(noise):
+    """C5's training set and what the float64 oracle says about it -- ONE CPU factorisation at N = 16384 per noise
+    level, shared by the tests that run C5 at size (the factor itself is not kept: 2 GB): NLML, and predict_y on a
+    fixed 96-leaf sub-sample of the first 131 072 synthetic leaves (the leaves of a larger batch start with the same rows)."""
+    if noise not in _c5_cache:
+        n, d, m = 16384, 40, 131072
+        X, y, th = _problem(n, d, variance=1.0, noise=noise)
+        post = gpr.posterior(th, X, y)
+        sub = np.sort(np.random.default_rng(5).choice(m, 96, replace=False))
+        leaves = synthetic_leaves(m, d).astype(np.float32)
+        mean_ref, var_ref = gpr.predict_y(post, leaves[sub].astype(np.float64))
+        _c5_cache[noise] = dict(X=X, y=y, th=th, nlml=post.nlml, sub=sub, mean_ref=mean_ref, var_ref=var_ref)
+    return _c5_cache[noise]
+
+
+# float parity bounds at the BASELINE sizes: <= 5x what is measured (printed by the tests as measured / bound), per family
+#   C3 (N 2048, D 12):  |d mean| 7.9e-5 max|y|, |d var| 2.2e-6 sigma^2 measured in the bench line  -> 4e-4 / 1.5e-5
+#   C4 (N 8192, D 20), C5 (N 16384, D 40): float32 FIT + float apply; measured values in the comments at the tests
+FLOAT_BOUNDS = {"C3": (4e-4, 1.5e-5), "C4": (4e-4, 4e-5), "C5": (8e-4, 1e-4)}
+
+
+def _close_to_native(var, var_nat, var_ref):
+    """The split modes' guard: f32-class means within 4x of what the f32 MFMA kernel achieves on the
+    same posterior and leaves."""
+    return np.max(np.abs(var - var_ref)) <= 4 * np.max(np.abs(var_nat - var_ref)) + 1e-6
+
+
 @pytest.mark.parametrize("noise", [1e-2, 1e-3])  # 1e-3: SURVEY 8(d)'s and bench.py --workload c5's
 def test_config_C5_one_gpu_share_at_size(noise):
     """Config C5 at its size: D = 40, N_train = 16384, ONE GPU's share of the 1 M leaves = 131 072, in
@@ -616,27 +662,29 @@ def test_config_C5_one_gpu_share_at_size(noise):
     from pygpso_amd import HipGPEngine
 
     n, d, m = 16384, 40, 131072
-    X, y, th = _problem(n, d, variance=1.0, noise=noise)
+    ref = _c5_reference(noise)
+    X, y, th, sub, mean_ref, var_ref = ref["X"], ref["y"], ref["th"], ref["sub"], ref["mean_ref"], ref["var_ref"]
     Xs = synthetic_leaves(m, d).astype(np.float32)
-    post = gpr.posterior(th, X, y)
-    sub = np.random.default_rng(5).choice(m, 96, replace=False)
-    mean_ref, var_ref = gpr.predict_y(post, Xs[sub].astype(np.float64))
     ys = max(1.0, float(np.max(np.abs(y))))
     eng = HipGPEngine("float32")
     f, _ = _fit(eng, X, y, th, grad=False)
-    assert abs(f - post.nlml) <= 1e-4 * abs(post.nlml)
+    assert abs(f - ref["nlml"]) <= 1e-4 * abs(ref["nlml"])
     results = {}
+    bm, bv = FLOAT_BOUNDS["C5"]
     for math in ("native", "bf16x6", "f16x3", "bf16x3"):
         eng.set_predict_math(math)
         mean, var = eng.predict(Xs)
         assert np.all(np.isfinite(mean)) and var.min() > 0 and var.max() <= (th.variance + th.noise) * (1 + 1e-5)
-        # float32 parity bounds (header): |d mean| <= 2e-3 max|y|, |d var| <= 2e-4 sigma^2
-        assert np.max(np.abs(mean[sub] - mean_ref)) <= 2e-3 * ys, math
-        assert np.max(np.abs(var[sub] - var_ref)) <= 2e-4 * th.variance, math
+        em, ev = np.max(np.abs(mean[sub] - mean_ref)) / ys, np.max(np.abs(var[sub] - var_ref)) / th.variance
+        print(f"C5 noise {noise:g} {math}: |d mean| {em:.2e} ({em / bm:.2f} of the bound), |d var| {ev:.2e} ({ev / bv:.2f})")
+        assert em <= bm, math
+        assert ev <= (bv if math != "bf16x3" else 2e-4), math
         idx, mu, vv, ucb = eng.best_ucb(Xs, VS)
         full = mean + VS * var
         assert int(idx[0]) == int(np.argmax(full)) and ucb[0] == full.max()  # fused arg-max == numpy's
         results[math] = (mean, var)
+    for math in ("bf16x6", "f16x3"):  # f32-class: within 4x of the native f32 kernel on the same leaves
+        assert _close_to_native(results[math][1][sub], results["native"][1][sub], var_ref), math
     mt, vt = eng.predict(X[:512].astype(np.float32))
     assert np.max(np.abs(mt - y[:512])) < 0.5 and np.all(vt < 4 * th.noise + 1e-3)
     # the mean never goes through the split: identical in both split modes
@@ -667,7 +715,18 @@ def test_config_C3_properties_fp32():
     post = gpr.posterior(th, X, y)
     eng = _engine("float32")
     _fit(eng, X, y, th, grad=False)
-    _properties(eng, X, y, th, synthetic_leaves(m, d), post, 512)
+    assert eng.precision_info()["predict_math"] == "f16x3"  # the default math of the bench line
+    nat = HipGPEngine_native(X, y, th)
+    _properties(eng, X, y, th, synthetic_leaves(m, d), post, 512, "C3", nat)
+    _properties(nat, X, y, th, synthetic_leaves(m, d), post, 512, "C3")
+
+
+def HipGPEngine_native(X, y, th):
+    from pygpso_amd import HipGPEngine
+
+    nat = HipGPEngine("float32", predict_math="native")
+    _fit(nat, X, y, th, grad=False)
+    return nat
 
 
 @pytest.mark.parametrize("math", ["native", "f16x3", "bf16x6", "bf16x3"])
@@ -680,7 +739,7 @@ def test_config_C4_one_gpu_shard_properties_fp32(math):
     eng = HipGPEngine("float32", predict_math=math)
     f, _ = _fit(eng, X, y, th, grad=False)
     assert abs(f - post.nlml) <= 1e-4 * abs(post.nlml)
-    _properties(eng, X, y, th, synthetic_leaves(m, d), post, 128)
+    _properties(eng, X, y, th, synthetic_leaves(m, d), post, 128, "C4", None if math == "native" else HipGPEngine_native(X, y, th))
 
 
 _c4_cache = {}

@@ -261,6 +261,15 @@ def test_G5_resume_run_and_resume_from_saved():
     assert opt2.n_eval_counter == 55
 
 
+def test_G8_run_resume_save_resume_through_the_host_classes():
+    """Golden G8 (examples/3-saving-resuming-optimisation.ipynb) through the drop-in host classes over the oracle-backed
+    engine: the flow tests/test_gpu_goldens.py runs on the HIP engine."""
+    from tests.helpers import g8_run_resume_save_resume
+
+    opt2 = g8_run_resume_save_resume(_optimiser, GPSOptimiser, TMP, G)
+    assert opt2.n_eval_counter == 77
+
+
 def test_G6_trace_host_grow_and_device_grow_paths_agree():
     opt = _optimiser(G["G6"]["depth"], G["G6"]["budget"])
     best = opt.run(rotated_peaks)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Kernel time of the split predict kernel at C3 with whatever library GPSO_HIP_LIB names (ablation builds of
+
+(round 4: the -DGPSO_ABL_* hooks live in tools/micro/predict_hooks.patch -- `git apply` it before building the ablation libraries)"""Kernel time of the split predict kernel at C3 with whatever library GPSO_HIP_LIB names (ablation builds of
 csrc/predict.hip: -DGPSO_ABL_HALFGEN / -DGPSO_ABL_NOGEN; their RESULTS are wrong by construction, only the time counts)."""
 import os
 import sys
