@@ -1675,11 +1675,14 @@ struct EngineT : Engine {
   // settle the posterior's arithmetic choices (generation, GPSO_MATH_AUTO's rung) and write them into slot 7 of the
   // hyper block, which travels: 1 = float generation, 2 = GPSO_MATH_AUTO settled on the f32 MFMA kernel, 4 = the split
   // pieces are built, 8 = the packed L^-1 travels too, 256 x the predict math
-  int settle_and_flag(bool with_linv_p) {
+  // (span_only: the flag describes the contiguous range of posterior_span -- the packed L^-1 is part of it only when the
+  // posterior runs the f32 / f64 MFMA kernel; otherwise every buffer travels)
+  int settle_and_flag(bool span_only) {
     if (!have_post) return GPSO_OK;
     int rc = decide_generation();
     if (rc) return rc;
     if (check && st_have && have_data && (rc = selftest_with_fallback())) return rc;  // settles GPSO_MATH_AUTO
+    const bool with_linv_p = !span_only || math_in_use() == GPSO_MATH_NATIVE;
     double* flag = ctx->pinned_scratch(256) + 120;  // (a slot neither the read-backs nor set_theta use)
     *flag = (gen_double() ? 0.0 : 1.0) + (math_native_fallback ? 2.0 : 0.0) + ((bf16_usable() && linv_b_valid) ? 4.0 : 0.0) +
             ((with_linv_p && linv_p_valid) ? 8.0 : 0.0) + 256.0 * math;  // (which split the pieces are: a receiver under GPSO_MATH_AUTO follows)
@@ -1690,7 +1693,7 @@ struct EngineT : Engine {
   int posterior_buffers(void** ptrs, int64_t* nbytes, int cap) override {
     if (npad == 0) return ctx->fail(GPSO_E_STATE, "no problem shape yet");
     if (cap < 7) return ctx->fail(GPSO_E_ARG, "need room for 7 buffers");
-    int rc = settle_and_flag(true);
+    int rc = settle_and_flag(false);
     if (rc) return rc;
     const size_t s = sizeof(TP);
     int k = 0;
@@ -1713,7 +1716,7 @@ struct EngineT : Engine {
   int posterior_span(void** ptr, int64_t* offset, int64_t* nbytes) override {
     if (npad == 0 || arena.p == nullptr) return ctx->fail(GPSO_E_STATE, "no problem shape yet");
     if (!have_post) return ctx->fail(GPSO_E_STATE, "no posterior resident");
-    int rc = settle_and_flag(false);
+    int rc = settle_and_flag(true);
     if (rc) return rc;
     if (math_in_use() == GPSO_MATH_NATIVE && !linv_p_valid)
       return ctx->fail(GPSO_E_STATE, "this context received its posterior without the packed L^-1 and cannot pass it on for the f32 kernel");
@@ -1739,7 +1742,7 @@ struct EngineT : Engine {
   DevBuf hash_out;
   int posterior_hash(uint64_t* out) override {
     if (!have_post) return ctx->fail(GPSO_E_STATE, "no posterior resident");
-    int rc = settle_and_flag(false);
+    int rc = settle_and_flag(true);
     if (rc) return rc;
     if ((rc = ensure(hash_out, 8))) return rc;
     hipStream_t s = st();
