@@ -92,6 +92,10 @@ typedef struct gpso_ctx gpso_ctx;
 #define GPSO_OPT_TIMING 7          /* 1 (default): every fit / predict entry point records the event pairs gpso_last_ms  */
                                    /* reads (two to four HIP calls); 0: none, gpso_last_ms returns 0 -- for callers in a  */
                                    /* loop of small evaluations (the drop-in surrogate switches it off)                   */
+#define GPSO_OPT_SPLIT_KERNEL 8    /* which step the split predict kernels (F16X3, BF16X6, BF16X3) run: 0 (default) the  */
+#define GPSO_SPLIT_KERNEL_AUTO 0   /*   FUSED step of round 4 (every wave applies step q with the generation of step q+1  */
+#define GPSO_SPLIT_KERNEL_TWO_PHASE 1 /* dealt into its MFMA shadows), 1 round 3's two-phase step.  Both give the SAME    */
+                                   /*   BITS (tests/test_gpu_parity.py); the option exists for that comparison            */
 /* floating-point options (gpso_set_option_f64): tolerances of the self-test */
 #define GPSO_OPTF_TOL_VAR 100  /* max |d var| at the training inputs, relative to the kernel variance (default 1e-4; GPSO_F32: 1e-3) */
 #define GPSO_OPTF_TOL_MEAN 101 /* max |d mean| at the training inputs, relative to max |y - c|   (default 1e-4; GPSO_F32: 1e-3) */

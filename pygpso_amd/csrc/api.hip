@@ -282,6 +282,7 @@ struct EngineT : Engine {
   bool gen_eff32 = true;
   bool gen_decided = false;     // AUTO: has the self-test ruled on this posterior?
   bool gen32_inputs_ok = false; // xs32 / xnorm32 / xs_p32 match the resident posterior
+  int split_variant = GPSO_SPLIT_KERNEL_AUTO;  // GPSO_OPT_SPLIT_KERNEL
   int64_t single_level_max = -1;  // < 0: library default
   bool fused_small = true;        // GPSO_OPT_FIT_FUSED_SMALL
   int small_tile_rows = 8;        // tile rows of the 128-padded linv_p that may be non-zero (8: all / unknown)
@@ -381,6 +382,10 @@ struct EngineT : Engine {
       case GPSO_OPT_FIT_FUSED_SMALL:
         if (value != 0 && value != 1) return ctx->fail(GPSO_E_ARG, "fused small fit must be 0 or 1");
         fused_small = value != 0;
+        return GPSO_OK;
+      case GPSO_OPT_SPLIT_KERNEL:
+        if (value != GPSO_SPLIT_KERNEL_AUTO && value != GPSO_SPLIT_KERNEL_TWO_PHASE) return ctx->fail(GPSO_E_ARG, "unknown split kernel %d", value);
+        split_variant = value;
         return GPSO_OK;
       case GPSO_OPT_PRECISION_CHECK:
         if (value != 0 && value != 1) return ctx->fail(GPSO_E_ARG, "precision check must be 0 or 1");
@@ -867,7 +872,7 @@ struct EngineT : Engine {
         if constexpr (kFloatPredict)
           rc = launch_leaf_tiles_bf16<TG>(s, nsplit(), split_planes(), xsp, xnr, as<float>(alpha), as<TG>(leaves_s),
                                           as<TG>(lnorm), as<double>(pvar), as<double>(pmean), npad, dp / 4, mp,
-                                          kp, m_live_c, f16_split() ? f16_scale() : nullptr);
+                                          kp, m_live_c, f16_split() ? f16_scale() : nullptr, split_variant);
       } else {
         rc = launch_leaf_tiles<TP, TG>(s, as<TP>(linv_p), xsp, xnr, as<TP>(alpha), as<TG>(leaves_s),
                                        as<TG>(lnorm), as<double>(pvar), as<double>(pmean), npad, dp / 4, mp, kp,

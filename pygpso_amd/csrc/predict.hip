@@ -552,47 +552,134 @@ struct Bf16Lds {
 // queue for the matrix pipe.  So the waves of a SIMD run the two stretches in OPPOSITE order (waves 0-3 generate
 // step q, then apply it; waves 4-7 apply step q with the pieces they generated during step q - 1, then generate
 // step q + 1): one wave's vector work runs under the other's MFMAs.
-template <int NS, typename TG, int KERNEL, bool F16 = false>
-__device__ __forceinline__ void leaf_bf16_gen(bool diag, int lane, int dp4,
+//
+// Round 4 -- the map of the split kernels, written for the vector ALU's issue slots (a wave's k-step is as long as
+// its OWN instruction stream: 14 vector instructions per generated value, issued value by value with every
+// transcendental waiting on the instruction in front of it, were 3 400 of a step's 7 200 clocks):
+//   * the scale of the exponent is folded into the norms and the contraction's multiplier: with
+//     u = SC r^2, SC = C2 log2(e)^2 (SE: log2(e) / 2), t' = sqrt(u) = log2(e) sqrt(C2) r and k = exp2(-t') P(t'), where
+//     P carries sigma^2 in its coefficients: sigma^2 (1 + ln2 t' + ln2^2 / 3 t'^2) for Matern-5/2 -- no separate
+//     multiplications by log2(e) and by sigma^2;
+//   * float generation takes sqrt(|u|) (a source modifier) instead of clamping: a GEMM-form r^2 that rounds to -1e-6
+//     is as wrong as one that rounds to +1e-6, and the map's error is the same second-order term either way
+//     (double generation keeps GPflow's clamp: its r^2 is exact to 1e-15);
+//   * the remainders of the fp16 split come from v_fma_mix_f32 (a - (float)h in one instruction, exact);
+//   * stage-major order: all combines, all square roots, all exponentials, all polynomials -- no instruction waits
+//     on the one in front of it.
+// 9 vector instructions per value instead of 14.
+template <int KERNEL>
+struct GenScale {
+  static constexpr double kLog2e = 1.44269504088896340736;
+  static constexpr double SC = (KERNEL == 3) ? 0.5 * kLog2e : KernScale<KERNEL>::C2 * kLog2e * kLog2e;
+};
+// (a, b) -> packed fp16 pair (round to nearest even); a, b are replaced by the remainders a - (float)h: exact, so the
+// same bits as f16_split_pair, two instructions fewer per pair
+__device__ __forceinline__ unsigned f16_split_pair_mix(float& a, float& b) {
+  const f32x2 v = {a, b};
+  const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+  float ra, rb;
+  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(h), "v"(a));
+  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(h), "v"(b));
+  a = ra;
+  b = rb;
+  return h;
+}
+// vc: sigma^2 (x 2^sb under the fp16 split) times the polynomial's coefficients in t' (see above)
+template <int KERNEL>
+__device__ __forceinline__ void gen_poly_coeffs(float variance, float (&vc)[3]) {
+  constexpr float kLn2 = 0.69314718055994530942f;
+  vc[0] = variance;
+  vc[1] = variance * kLn2;
+  vc[2] = variance * (kLn2 * kLn2 / 3.0f);
+}
+template <int NS, typename TG, int KERNEL, bool F16, bool DIAG, int CT = 2>
+__device__ __forceinline__ void leaf_bf16_gen(int lane, int dp4,
                                               const unsigned char* xs_b /* [2][dp4] X fragments | norms | alpha */,
-                                              const TG* xb, const TG (&nb)[2], float variance,
-                                              bf16x8 (&bfrag)[NS][2], float (&macc)[2]) {
+                                              const TG* xb, const TG (&nb)[CT] /* SC |x*|^2 */, const float (&vc)[3],
+                                              bf16x8 (&bfrag)[NS][CT], float (&macc)[CT]) {
   using MG = Mfma<TG>;
   using vecG = typename MG::vec4;
-  constexpr int CT = 2;
   constexpr int XB = 64 * (int)sizeof(TG);
-  constexpr TG C2 = (TG)KernScale<KERNEL>::C2;
+  constexpr TG SC = (TG)GenScale<KERNEL>::SC;
   // ---- generate the two 16-point tiles of this k-step (TG) --------------------------------------
   vecG s[2][CT];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int t = 0; t < CT; ++t) s[h][t] = vecG{0, 0, 0, 0};
-  for (int c = 0; c < dp4; ++c) {
-    const TG x0 = reinterpret_cast<const TG*>(xs_b + c * XB)[lane];
-    const TG x1 = reinterpret_cast<const TG*>(xs_b + (dp4 + c) * XB)[lane];
-#pragma unroll
-    for (int t = 0; t < CT; ++t) {
-      const TG l = xb[(t * dp4 + c) * 64 + lane];
-      s[0][t] = MG::mma(x0, l, s[0][t]);
-      s[1][t] = MG::mma(x1, l, s[1][t]);
-    }
-  }
-  float p[CT][8];
   // norms and alpha of the 32 points of this k-step arrived in LDS with the panel (no ordinary global
   // load inside the loop: one issued after the LDS-DMA makes hipcc drain the DMA queue at its use)
   const TG* nrm = reinterpret_cast<const TG*>(xs_b + 2 * dp4 * XB);
   const float* alp = reinterpret_cast<const float*>(xs_b + 2 * dp4 * XB + 64 * sizeof(TG));
+  // the contraction, software-pipelined over the groups of four dimensions: the operands of group c + 1 (and, in front
+  // of everything, the norms) are on their way from LDS while the MFMAs of group c issue -- a generator wave's step is a
+  // latency chain, not an issue budget (stamps: tools/micro/leaf_spec_phases.hip)
+  vecG nav[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) nav[h] = *reinterpret_cast<const vecG*>(nrm + 16 * h + 4 * (lane >> 4));
+  TG x0 = reinterpret_cast<const TG*>(xs_b)[lane];
+  TG x1 = reinterpret_cast<const TG*>(xs_b + dp4 * XB)[lane];
+  TG l[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) l[t] = xb[(t * dp4) * 64 + lane];
+  for (int c = 0; c < dp4; ++c) {
+    TG x0n = x0, x1n = x1, ln[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) ln[t] = l[t];
+    if (c + 1 < dp4) {
+      x0n = reinterpret_cast<const TG*>(xs_b + (c + 1) * XB)[lane];
+      x1n = reinterpret_cast<const TG*>(xs_b + (dp4 + c + 1) * XB)[lane];
+#pragma unroll
+      for (int t = 0; t < CT; ++t) ln[t] = xb[(t * dp4 + c + 1) * 64 + lane];
+    }
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      s[0][t] = MG::mma(x0, l[t], s[0][t]);
+      s[1][t] = MG::mma(x1, l[t], s[1][t]);
+    }
+    x0 = x0n;
+    x1 = x1n;
+#pragma unroll
+    for (int t = 0; t < CT; ++t) l[t] = ln[t];
+  }
+  float p[CT][8];
+  // stage 0: u = SC r^2, GPflow's GEMM form combined in TG, rounded to float
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const vecG na = *reinterpret_cast<const vecG*>(nrm + 16 * h + 4 * (lane >> 4)) * C2;
+    const vecG na = nav[h] * SC;
 #pragma unroll
     for (int t = 0; t < CT; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        p[t][4 * h + r] = kern_from_scaled<KERNEL>((float)fma_t((TG)(TG(-2) * C2), s[h][t][r], na[r] + nb[t]), variance);
+      for (int r = 0; r < 4; ++r) p[t][4 * h + r] = (float)fma_t((TG)(TG(-2) * SC), s[h][t][r], na[r] + nb[t]);
   }
-  if (diag) {  // this k-step lies in the diagonal block (wave-uniform): its share of k*.alpha (f32, before the split)
+  __builtin_amdgcn_sched_barrier(0);
+  float e[CT][8];
+  if constexpr (KERNEL != 3) {  // stage 1: t' = sqrt(u)
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if constexpr (sizeof(TG) == 4) p[t][j] = __builtin_amdgcn_sqrtf(__builtin_fabsf(p[t][j]));
+        else p[t][j] = __builtin_amdgcn_sqrtf(fmaxf(p[t][j], (float)(GenScale<KERNEL>::SC * 1e-36)));
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // stage 2: e = exp2(-t')  (SE: exp2(-u))
+#pragma unroll
+  for (int t = 0; t < CT; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[t][j] = __builtin_amdgcn_exp2f(-p[t][j]);
+  __builtin_amdgcn_sched_barrier(0);
+  // stage 3: k = e P(t')
+#pragma unroll
+  for (int t = 0; t < CT; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if constexpr (KERNEL == 0) p[t][j] = fmaf(p[t][j], fmaf(p[t][j], vc[2], vc[1]), vc[0]) * e[t][j];
+      else if constexpr (KERNEL == 1) p[t][j] = fmaf(p[t][j], vc[1], vc[0]) * e[t][j];
+      else p[t][j] = vc[0] * e[t][j];
+    }
+  if constexpr (DIAG) {  // this k-step lies in the diagonal block: its share of k*.alpha (f32, before the split)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const f32x4 a4 = *reinterpret_cast<const f32x4*>(alp + 16 * h + 4 * (lane >> 4));
@@ -609,20 +696,24 @@ __device__ __forceinline__ void leaf_bf16_gen(bool diag, int lane, int dp4,
         }
     }
   }
-  // ---- split into bf16 pieces: B operands ---------------------------------------------------------
+  // ---- split into bf16 / fp16 pieces: B operands --------------------------------------------------
 #pragma unroll
   for (int t = 0; t < CT; ++t)
 #pragma unroll
     for (int sp = 0; sp < NS; ++sp) {
       u32x4 f;
 #pragma unroll
-      for (int h = 0; h < 4; ++h) f[h] = F16 ? f16_split_pair(p[t][2 * h], p[t][2 * h + 1]) : bf16_split_pair(p[t][2 * h], p[t][2 * h + 1]);
+      for (int h = 0; h < 4; ++h) {
+        if constexpr (F16) f[h] = (sp + 1 < NS) ? f16_split_pair_mix(p[t][2 * h], p[t][2 * h + 1]) : f16_split_pair(p[t][2 * h], p[t][2 * h + 1]);
+        else f[h] = bf16_split_pair(p[t][2 * h], p[t][2 * h + 1]);
+      }
       bfrag[sp][t] = __builtin_bit_cast(bf16x8, f);  // (fp16 pieces travel in the same 16-byte registers)
     }
 }
 
-// apply: acc[rt][t] += sum over the kept piece products, small terms first
-template <int NS, bool F16 = false>
+// apply: acc[rt][t] += sum over the kept piece products, small terms first.  DIAG: k-steps of the diagonal block --
+// the tiles above the diagonal are all zero and skipped per row tile; off-diagonal steps are one branch-free stretch
+template <int NS, bool F16, bool DIAG>
 __device__ __forceinline__ void leaf_bf16_apply(int q, int q_diag0, int lane, const u32x4* panel_b /* [NS][16][64] */,
                                                 const bf16x8 (&bfrag)[NS][2], f32x4 (&acc)[16][2]) {
   static_assert(!F16 || NS == 2, "the fp16 split has two pieces");
@@ -637,7 +728,7 @@ __device__ __forceinline__ void leaf_bf16_apply(int q, int q_diag0, int lane, co
       for (int sp = 0; sp < NS; ++sp) a[(rt + 1) & 1][sp] = panel_b[(sp * RT + rt + 1) * 64 + lane];
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (2 * (q - q_diag0) > rt) continue;  // diagonal block: all-zero tiles above the diagonal (never true before it)
+    if (DIAG && 2 * (q - q_diag0) > rt) continue;  // all-zero tiles above the diagonal
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
       f32x4 c = acc[rt][t];
@@ -658,9 +749,162 @@ __device__ __forceinline__ void leaf_bf16_apply(int q, int q_diag0, int lane, co
   }
 }
 
+// ---- the FUSED step (round 4): apply of step q with the generation of step q + 1 dealt into its MFMA shadows -------
+// The two-phase step above runs generation and apply as two stretches per wave and relies on the partner wave of the
+// SIMD for overlap; a wave issues in order, so its step is the SUM of its stretches (stamps: DMA 650 + generation 2 700
+// + apply 1 900 + barriers 750 .. 1 600 = 7 000 clocks per step for a matrix pipe that works 3 840 of them).  But an
+// MFMA only holds the vector issue port for 8 of its 16 clocks: the SAME wave can issue one or two vector instructions
+// behind every MFMA for free.  So, as leaf_tiles_v2_kernel does for the f32 kernel: the contraction MFMAs of step q + 1
+// go first (their results mature under row tile 0's MFMAs), then the map and the split of step q + 1 -- in stage-major
+// order: 16 combines, 16 square roots, 16 exponentials, 16 polynomials, 8 pair splits -- are dealt over row tiles
+// 1 .. 15 of the apply of step q, a few instructions behind each tile's six MFMAs.  All eight waves run the same
+// stream, one workgroup barrier per step.  Same operations on the same operands as the two-phase step: bit-identical
+// partial sums (tests/test_gpu_parity.py compares the two kernels).
+// GMODE: 0 = nothing to generate (last step), 1 = generate step q + 1, 2 = ... and accumulate its share of k*.alpha
+template <int NS, typename TG, int KERNEL, bool F16, bool ADIAG, int GMODE>
+__device__ __forceinline__ void leaf_bf16_fused_step(int q, int q_diag0, int lane, int dp4,
+                                                     const u32x4* panel_b /* [NS][16][64]: L^-1 pieces of step q */,
+                                                     const unsigned char* xs_n /* inputs of step q + 1 */, const TG* xb,
+                                                     const TG (&nb)[2], const float (&vc)[3], const bf16x8 (&bcur)[NS][2],
+                                                     bf16x8 (&bnxt)[NS][2], f32x4 (&acc)[16][2], float (&macc)[2]) {
+  using MG = Mfma<TG>;
+  using vecG = typename MG::vec4;
+  constexpr int RT = 16, CT = 2;
+  constexpr int XB = 64 * (int)sizeof(TG);
+  constexpr TG SC = (TG)GenScale<KERNEL>::SC;
+  constexpr bool GEN = GMODE != 0;
+  // ---- contraction of step q + 1 (TG), software-pipelined over the groups of four dimensions ------------------------
+  vecG s[2][CT];
+  vecG nav[2];
+  if constexpr (GEN) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int t = 0; t < CT; ++t) s[h][t] = vecG{0, 0, 0, 0};
+    const TG* nrm = reinterpret_cast<const TG*>(xs_n + 2 * dp4 * XB);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) nav[h] = *reinterpret_cast<const vecG*>(nrm + 16 * h + 4 * (lane >> 4));
+    TG x0 = reinterpret_cast<const TG*>(xs_n)[lane];
+    TG x1 = reinterpret_cast<const TG*>(xs_n + dp4 * XB)[lane];
+    TG l[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) l[t] = xb[(t * dp4) * 64 + lane];
+    for (int c = 0; c < dp4; ++c) {
+      TG x0n = x0, x1n = x1, ln[CT];
+#pragma unroll
+      for (int t = 0; t < CT; ++t) ln[t] = l[t];
+      if (c + 1 < dp4) {
+        x0n = reinterpret_cast<const TG*>(xs_n + (c + 1) * XB)[lane];
+        x1n = reinterpret_cast<const TG*>(xs_n + (dp4 + c + 1) * XB)[lane];
+#pragma unroll
+        for (int t = 0; t < CT; ++t) ln[t] = xb[(t * dp4 + c + 1) * 64 + lane];
+      }
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        s[0][t] = MG::mma(x0, l[t], s[0][t]);
+        s[1][t] = MG::mma(x1, l[t], s[1][t]);
+      }
+      x0 = x0n;
+      x1 = x1n;
+#pragma unroll
+      for (int t = 0; t < CT; ++t) l[t] = ln[t];
+    }
+  }
+  // ---- apply of step q, the map of step q + 1 dealt over row tiles 1 .. 15 --------------------------------------------
+  // value e = 8 t + j, j = 4 h + r (column tile t, 16-point half h, accumulator register r); ops in stage-major order --
+  // within a stage every op is independent of its neighbours, and an op's input is at least 16 ops old:
+  //   norms x SC (8) | combine (16) | sqrt (16; none for the squared exponential) | exp2 (16) | polynomial x exponential
+  //   (16) | k*.alpha (16; GMODE 2) | split of pair (t, j) (8)
+  constexpr int E = 16;
+  constexpr int O_COMB = 8, O_SQRT = O_COMB + E, O_EXP = O_SQRT + (KERNEL == 3 ? 0 : E), O_POLY = O_EXP + E,
+                O_MEAN = O_POLY + E, O_SPLIT = O_MEAN + (GMODE == 2 ? E : 0), NOPS = O_SPLIT + 8;
+  float p[CT][8], ex[CT][8];
+  TG na[2][4];
+  f32x4 al4[2];
+  u32x4 fr[NS][CT];
+  if constexpr (GMODE == 2) {
+    const float* alp = reinterpret_cast<const float*>(xs_n + 2 * dp4 * XB + 64 * sizeof(TG));
+#pragma unroll
+    for (int h = 0; h < 2; ++h) al4[h] = *reinterpret_cast<const f32x4*>(alp + 16 * h + 4 * (lane >> 4));
+  }
+  auto op = [&](auto o_) {
+    constexpr int o = decltype(o_)::value;
+    if constexpr (o < O_COMB) {
+      na[o >> 2][o & 3] = nav[o >> 2][o & 3] * SC;
+    } else if constexpr (o < O_SQRT) {
+      constexpr int e = o - O_COMB, t = e >> 3, h = (e >> 2) & 1, r = e & 3;
+      p[t][4 * h + r] = (float)fma_t((TG)(TG(-2) * SC), s[h][t][r], na[h][r] + nb[t]);
+    } else if constexpr (o < O_EXP) {
+      constexpr int e = o - O_SQRT, t = e >> 3, j = e & 7;
+      if constexpr (sizeof(TG) == 4) p[t][j] = __builtin_amdgcn_sqrtf(__builtin_fabsf(p[t][j]));
+      else p[t][j] = __builtin_amdgcn_sqrtf(fmaxf(p[t][j], (float)(GenScale<KERNEL>::SC * 1e-36)));
+    } else if constexpr (o < O_POLY) {
+      constexpr int e = o - O_EXP, t = e >> 3, j = e & 7;
+      ex[t][j] = __builtin_amdgcn_exp2f(-p[t][j]);
+    } else if constexpr (o < O_MEAN) {
+      constexpr int e = o - O_POLY, t = e >> 3, j = e & 7;
+      if constexpr (KERNEL == 0) p[t][j] = fmaf(p[t][j], fmaf(p[t][j], vc[2], vc[1]), vc[0]) * ex[t][j];
+      else if constexpr (KERNEL == 1) p[t][j] = fmaf(p[t][j], vc[1], vc[0]) * ex[t][j];
+      else p[t][j] = vc[0] * ex[t][j];
+    } else if constexpr (o < O_SPLIT) {  // (GMODE 2) k*.alpha in f32, before the split; per column tile in the order j = 0 .. 7
+      constexpr int e = o - O_MEAN, t = e >> 3, j = e & 7;
+      macc[t] = fma_t(p[t][j], al4[j >> 2][j & 3], macc[t]);
+      asm volatile("" : "+v"(macc[t]));  // the two tiles' means stay in separate registers (see leaf_bf16_gen)
+    } else {
+      constexpr int e = o - O_SPLIT, t = e >> 2, j = e & 3;
+#pragma unroll
+      for (int sp = 0; sp < NS; ++sp) {
+        if constexpr (F16) fr[sp][t][j] = (sp + 1 < NS) ? f16_split_pair_mix(p[t][2 * j], p[t][2 * j + 1]) : f16_split_pair(p[t][2 * j], p[t][2 * j + 1]);
+        else fr[sp][t][j] = bf16_split_pair(p[t][2 * j], p[t][2 * j + 1]);
+      }
+    }
+  };
+  u32x4 a[2][NS];
+#pragma unroll
+  for (int sp = 0; sp < NS; ++sp) a[0][sp] = panel_b[(sp * RT + 0) * 64 + lane];
+  static_for<0, RT>([&](auto rt_) {
+    constexpr int rt = decltype(rt_)::value;
+    if constexpr (rt + 1 < RT) {
+#pragma unroll
+      for (int sp = 0; sp < NS; ++sp) a[(rt + 1) & 1][sp] = panel_b[(sp * RT + rt + 1) * 64 + lane];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(ADIAG && 2 * (q - q_diag0) > rt)) {  // (diagonal block: all-zero tiles above the diagonal)
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        f32x4 c = acc[rt][t];
+#define GPSO_BF(SA, SB)                                                                                                   \
+  c = F16 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[rt & 1][SA]), __builtin_bit_cast(f16x8, bcur[SB][t]), c, 0, 0, 0) \
+          : __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[rt & 1][SA]), bcur[SB][t], c, 0, 0, 0)
+        if (NS == 3) {
+          GPSO_BF(2, 0);
+          GPSO_BF(0, 2);
+          GPSO_BF(1, 1);
+        }
+        GPSO_BF(1, 0);
+        GPSO_BF(0, 1);
+        GPSO_BF(0, 0);
+#undef GPSO_BF
+        acc[rt][t] = c;
+      }
+    }
+    if constexpr (GEN && rt >= 1) {  // this row tile's share of the map: ops [(rt - 1) NOPS / 15, rt NOPS / 15)
+      static_for<(rt - 1) * NOPS / (RT - 1), rt * NOPS / (RT - 1)>(op);
+    }
+  });
+  if constexpr (GEN) {
+#pragma unroll
+    for (int sp = 0; sp < NS; ++sp)
+#pragma unroll
+      for (int t = 0; t < CT; ++t) bnxt[sp][t] = __builtin_bit_cast(bf16x8, fr[sp][t]);
+  }
+}
+
 // F16: the fp16 split (two pieces, three products); `variance` then arrives multiplied by 2^sb, inv_scale_a[1] is
 // 2^-sa (device, written by pack_linv_f16_kernel) and inv_scale_b = 2^-sb
-template <int NS, typename TG, int KERNEL, bool F16 = false>
+// FUSED: every wave runs the fused step (apply of step q with the generation of step q + 1 in its MFMA shadows, one
+// barrier per step); otherwise round 3's two-phase step with the waves of a SIMD in opposite order
+template <int NS, typename TG, int KERNEL, bool F16 = false, bool FUSED = false>
 __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     const u32x4* __restrict__ linv_b, const TG* __restrict__ xs_p, const TG* __restrict__ xnorm,
     const float* __restrict__ alpha, const TG* __restrict__ leaves_s,
@@ -668,8 +912,7 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     int npad16, int dp4, int64_t mpad, int nbi, float variance, const int64_t* __restrict__ m_live,
     const float* __restrict__ inv_scale_a, float inv_scale_b) {
   constexpr int RT = 16, CT = 2, NW = 8;
-  constexpr int XB = 64 * (int)sizeof(TG);
-  constexpr TG C2 = (TG)KernScale<KERNEL>::C2;
+  constexpr TG SC = (TG)GenScale<KERNEL>::SC;
   extern __shared__ __align__(16) unsigned char lds_raw[];
   if (m_live != nullptr && (int64_t)blockIdx.x * (NW * CT * 16) >= *m_live) return;  // workgroup-uniform
   u32x4* panel = reinterpret_cast<u32x4*>(lds_raw);                 // [2][NS][RT][64]
@@ -685,27 +928,25 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   const int npad32 = npad16 / 2;
   const int q_diag0 = bi * (RT / 2), q_end = q_diag0 + RT / 2;
 
-  // ---- LDS-DMA duties: ONE LDS window (one M0 value) per wave between two workgroup barriers ----------------
-  // Every DMA a wave issues in an interval goes to one window addressed as M0 + the instruction's immediate
-  // offset (13 bits, signed, applied to the global and the LDS address alike -- the global base is pre-biased by
-  // the same amount): one M0 write and one scalar add per fragment instead of ~25 scalar instructions of address
-  // arithmetic (the DMA issue phase of a k-step 1 430 - 1 550 -> 730 - 810 clocks).  M0 is written again only
-  // after the barrier that ends the interval.  (Introduced while hunting an intermittent wrong mean that turned
-  // out to be the packed accumulation in leaf_bf16_gen -- profiles/r02h_packed_mean_bug.txt; there is no evidence
-  // of an M0 hazard, the windows are kept for what they save.)
-  //   waves 0 .. NS*RT/8 - 1: eight consecutive 1 KB fragments of the L^-1 pieces (fragment f = piece f / RT, row
-  //                           tile f % RT), window centre at +4 KB;
-  //   wave 6:                 the X fragments of a step, a linear image of 256-byte pieces, window centre at +4 KB;
-  //   wave 7:                 the 32 norms and the 32 alphas of the step (two DMAs, one window).
-  constexpr int NPW = NS * RT / 8;  // 6 (bf16 x6) or 4 (bf16 x3)
-  static_assert(NPW <= NW - 2 && RT == 16, "panel waves and input waves are different waves");
+  // ---- LDS-DMA duties, dealt EVENLY over the eight waves (round 4) -------------------------------------------
+  // A step's DMAs are NS x 16 fragments of the L^-1 pieces (1 KB each), the X fragments of the step (256-byte pieces)
+  // and its 32 norms and 32 alphas.  Until round 3 waves 0 .. NS*RT/8 - 1 carried eight fragments each, wave 6 all
+  // X pieces and wave 7 norms and alphas: an LDS-DMA costs its wave ~90 clocks to issue, so the panel waves spent 740
+  // clocks of a 6 750-clock step there, and wave 6 -- which generates and applies like every other wave -- arrived last
+  // at every barrier (890 + 310 clocks of barrier wait on the others; stamps: tools/micro/leaf_bf16_phases.hip).  Now every
+  // wave moves NS*RT/8 = 4 (6) fragments + the X pieces w, w + 8, w + 16, w + 24 + (waves 6 / 7) norms / alphas.
+  // Each group is one LDS window addressed as M0 + the instruction's 13-bit immediate offset, which the hardware adds
+  // to the global and the LDS address alike (the global base is pre-biased by the same amount): one M0 write and one
+  // scalar add per DMA instead of ~25 scalar instructions of address arithmetic.
+  constexpr int FPW = NS * RT / NW;  // fragments of the L^-1 pieces per wave: 4 (two pieces) or 6 (three)
+  static_assert(FPW * NW == NS * RT && FPW * 1024 <= 8192 && RT == 16, "window of a wave's fragments");
   const int lane16 = lane * 16, lane4 = lane * 4;
-  const unsigned char* pgb[8];
+  const unsigned char* pgb[FPW];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int sp = wave >> 1, rt = 8 * (wave & 1) + j;  // fragment 8 wave + j
+  for (int j = 0; j < FPW; ++j) {
+    const int f = FPW * wave + j, sp = f / RT, rt = f % RT;  // fragment f = piece sp, row tile rt
     pgb[j] = reinterpret_cast<const unsigned char*>(linv_b + ((size_t)sp * npad16 + (bi * RT + rt)) * npad32 * 64) -
-             (j - 4) * 1024;
+             (j * 1024 - FPW * 512);
   }
   // (the empty asm keeps a wave-uniform address in scalar registers: left alone, the compiler hoists
   // base + lane offset out of the loop as per-lane 64-bit pointers and spills them)
@@ -716,49 +957,50 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     return reinterpret_cast<const unsigned char*>(((unsigned long long)hi << 32) | lo);
   };
   auto issue_panel = [&](int q, int buf) {
-    if (wave >= NPW) return;
-    unsigned char* centre = reinterpret_cast<unsigned char*>(panel) + buf * (NS * RT * 1024) + wave * 8192 + 4096;
-    static_for<0, 8>([&](auto j_) {
+    unsigned char* centre = reinterpret_cast<unsigned char*>(panel) + buf * (NS * RT * 1024) + wave * (FPW * 1024) + FPW * 512;
+    static_for<0, FPW>([&](auto j_) {
       constexpr int j = decltype(j_)::value;
-      glds16_off<(j - 4) * 1024>(uniform(pgb[j] + (size_t)q * 1024) + lane16, centre);
+      glds16_off<j * 1024 - FPW * 512>(uniform(pgb[j] + (size_t)q * 1024) + lane16, centre);
     });
   };
-  // the inputs of a k-step: a ring of three buffers -- waves 4-7 generate step q + 1 during step q.  Piece p of
-  // the X fragments is bytes [256 p, 256 p + 256) of the step's contiguous source block and of the buffer alike
-  // (<= 32 pieces: D <= 48 in float, <= 32 in double -- checked at launch): wave 6, window centre at +4 KB; wave 7 moves the 32 norms
-  // (TG, as 64 dwords; float: lanes 32-63 fetch duplicates into the unused half) and, 64 TG further, the 32 alphas
+  // the inputs of a k-step: a ring of three buffers -- waves 4-7 generate step q + 1 during step q.  Piece r of
+  // the X fragments is bytes [256 r, 256 r + 256) of the step's contiguous source block and of the buffer alike
+  // (<= 32 pieces: D <= 48 in float, <= 32 in double -- checked at launch); wave w moves pieces w + 8 jj.  Wave 6 also
+  // moves the 32 norms (TG, as 64 dwords; float: lanes 32-63 fetch duplicates into the unused half), wave 7 the 32
+  // alphas 64 TG behind them.
   const int xpieces = 2 * dp4 * ((int)sizeof(TG) / 4);
   const unsigned char* xs_bytes = reinterpret_cast<const unsigned char*>(xs_p);
   const size_t xstep = (size_t)2 * dp4 * 64 * sizeof(TG);
+  const int xmine = (xpieces - wave + 7) >> 3;  // how many of the pieces w, w + 8, ... exist
   auto issue_x = [&](int q) {
     unsigned char* xd = xsl + (q % 3) * xstride;
+    if (xmine > 0) {
+      const unsigned char* src = uniform(xs_bytes + (size_t)q * xstep + wave * 256 + 4096);
+      unsigned char* centre = xd + wave * 256 + 4096;
+      glds4_off<-4096>(src + lane4, centre);
+      if (xmine > 1) glds4_off<-2048>(src + lane4, centre);
+      if (xmine > 2) glds4_off<0>(src + lane4, centre);
+      if (xmine > 3) glds4_off<2048>(src + lane4, centre);
+    }
+    unsigned char* nd = xd + (size_t)xpieces * 256;
     if (wave == NW - 2) {
-      const unsigned char* src = uniform(xs_bytes + (size_t)q * xstep + 4096);
-      static_for<0, 32>([&](auto r_) {
-        constexpr int r = decltype(r_)::value;
-        if (r < xpieces) glds4_off<(r - 16) * 256>(src + lane4, xd + 4096);
-      });
-    } else if (wave == NW - 1) {
-      unsigned char* nd = xd + (size_t)xpieces * 256;
       const int nlane = (sizeof(TG) == 8) ? lane4 : (lane & 31) * 4;
       glds4_off<0>(uniform(reinterpret_cast<const unsigned char*>(xnorm + 32 * q)) + nlane, nd);
-      glds4_off<64 * (int)sizeof(TG)>(uniform(reinterpret_cast<const unsigned char*>(alpha + 32 * q) - 64 * sizeof(TG)) + (lane & 31) * 4, nd);
+    } else if (wave == NW - 1) {
+      glds4_off<0>(uniform(reinterpret_cast<const unsigned char*>(alpha + 32 * q)) + (lane & 31) * 4, nd + 64 * sizeof(TG));
     }
   };
 
   issue_panel(0, 0);
   issue_x(0);
-  if (1 < q_end) {
-    if (wave >= NW - 2) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): a second window for the same wave (once per workgroup)
-    issue_x(1);
-  }
+  if (1 < q_end) issue_x(1);
   for (int t = 0; t < CT; ++t)
     for (int c = 0; c < dp4; ++c)
       xb[(t * dp4 + c) * 64 + lane] =
           leaves_s[(col0 + t * 16 + (lane & 15)) * dp + 4 * c + (lane >> 4)];
   TG nb[CT];
 #pragma unroll
-  for (int t = 0; t < CT; ++t) nb[t] = lnorm[col0 + t * 16 + (lane & 15)] * C2;
+  for (int t = 0; t < CT; ++t) nb[t] = lnorm[col0 + t * 16 + (lane & 15)] * SC;
   f32x4 acc[RT][CT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
@@ -766,33 +1008,78 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     for (int t = 0; t < CT; ++t) acc[rt][t] = f32x4{0, 0, 0, 0};
   float macc[CT] = {0, 0};
   bf16x8 bfrag[NS][CT];
+  float vc[3];
+  gen_poly_coeffs<KERNEL>(variance, vc);
   __syncthreads();
 
+  auto issue_for = [&](int k) {
+    if (k + 1 < q_end) issue_panel(k + 1, (k + 1) & 1);
+    if (k + 2 < q_end) issue_x(k + 2);
+  };
+  if constexpr (FUSED) {
+    // Interval q (between workgroup barriers q - 1 and q), every wave alike: the DMAs of the L^-1 pieces of step q + 1
+    // (into the buffer step q - 1 was applied from) and of the inputs of step q + 2 (ring of three) are issued, then
+    // the fused step applies step q and generates step q + 1.  Step 0 is generated on its own.
+    bf16x8 bnxt[NS][CT];
+    if (q_diag0 == 0) leaf_bf16_gen<NS, TG, KERNEL, F16, true>(lane, dp4, xsl, xb, nb, vc, bfrag, macc);
+    else leaf_bf16_gen<NS, TG, KERNEL, F16, false>(lane, dp4, xsl, xb, nb, vc, bfrag, macc);
+    // (the step's DMAs are issued at its head: dealt behind the MFMAs of row tiles 1, 2, ... like the map they cost 2 %
+    // more -- measured, tools/ab_time.py)
+#define GPSO_FUSED_STEP(ADIAG, GMODE)                                                                                 \
+  {                                                                                                                   \
+    GPSO_BSTAMP(q, 0);                                                                                                \
+    issue_for(q);                                                                                                     \
+    GPSO_BSTAMP(q, 1);                                                                                                \
+    leaf_bf16_fused_step<NS, TG, KERNEL, F16, ADIAG, GMODE>(q, q_diag0, lane, dp4, panel + (q & 1) * NS * RT * 64,    \
+                                                            xsl + ((q + 1) % 3) * xstride, xb, nb, vc, bfrag, bnxt,   \
+                                                            acc, macc);                                               \
+    GPSO_BSTAMP(q, 4);                                                                                                \
+    __syncthreads();                                                                                                  \
+    GPSO_BSTAMP(q, 5);                                                                                                \
+    if (GMODE != 0) {                                                                                                 \
+      for (int sp = 0; sp < NS; ++sp)                                                                                 \
+        for (int t = 0; t < CT; ++t) bfrag[sp][t] = bnxt[sp][t];                                                      \
+    }                                                                                                                 \
+  }
+    int q = 0;
+    for (; q + 1 < q_diag0; ++q) GPSO_FUSED_STEP(false, 1)
+    if (q < q_diag0) {  // the last step below the diagonal block generates the block's first step: with its k*.alpha
+      GPSO_FUSED_STEP(false, 2)
+      ++q;
+    }
+    for (; q + 1 < q_end; ++q) GPSO_FUSED_STEP(true, 2)
+    GPSO_FUSED_STEP(true, 0)
+#undef GPSO_FUSED_STEP
+  } else {
   // Interval k (between workgroup barriers k - 1 and k): waves 0-3 generate and apply step k; waves 4-7 apply step
   // k and generate step k + 1.  One copy of the code: every wave runs gen(q), apply(q) for q = 0, 1, ...; only the
   // place of the barrier differs -- after apply(q) for waves 0-3, after gen(q) (q >= 1) for waves 4-7, which
   // therefore meet one last barrier after the loop.  DMA issued in interval k (L^-1 pieces of step k + 1 into the
   // buffer step k - 1 was applied from; inputs of step k + 2 into the ring of three) has landed at barrier k.
   const bool ahead = wave >= NW / 2;
-  auto issue_for = [&](int k) {
-    if (k + 1 < q_end) issue_panel(k + 1, (k + 1) & 1);
-    if (k + 2 < q_end) issue_x(k + 2);
-  };
-  for (int q = 0; q < q_end; ++q) {
-    GPSO_BSTAMP(q, 0);
-    if (!ahead || q == 0) issue_for(q);
-    else if (q >= 2) issue_for(q - 1);  // (this wave's iteration q starts in interval q - 1)
-    GPSO_BSTAMP(q, 1);
-    leaf_bf16_gen<NS, TG, KERNEL, F16>(q >= q_diag0, lane, dp4, xsl + (q % 3) * xstride, xb, nb, variance, bfrag, macc);
-    GPSO_BSTAMP(q, 2);
-    if (ahead && q > 0) __syncthreads();
-    GPSO_BSTAMP(q, 3);
-    leaf_bf16_apply<NS, F16>(q, q_diag0, lane, panel + (q & 1) * NS * RT * 64, bfrag, acc);
-    GPSO_BSTAMP(q, 4);
-    if (!ahead) __syncthreads();
-    GPSO_BSTAMP(q, 5);
+  // the k-steps below the diagonal block run a branch-free copy of the step (no per-row-tile skip, no mean); the
+  // RT / 2 steps of the diagonal block the general one
+#define GPSO_BF16_STEP(DIAGF)                                                                                         \
+  {                                                                                                                   \
+    GPSO_BSTAMP(q, 0);                                                                                                \
+    if (!ahead || q == 0) issue_for(q);                                                                               \
+    else if (q >= 2) issue_for(q - 1); /* (this wave's iteration q starts in interval q - 1) */                       \
+    GPSO_BSTAMP(q, 1);                                                                                                \
+    leaf_bf16_gen<NS, TG, KERNEL, F16, DIAGF>(lane, dp4, xsl + (q % 3) * xstride, xb, nb, vc, bfrag, macc);           \
+    GPSO_BSTAMP(q, 2);                                                                                                \
+    if (ahead && q > 0) __syncthreads();                                                                              \
+    GPSO_BSTAMP(q, 3);                                                                                                \
+    leaf_bf16_apply<NS, F16, DIAGF>(q, q_diag0, lane, panel + (q & 1) * NS * RT * 64, bfrag, acc);                    \
+    GPSO_BSTAMP(q, 4);                                                                                                \
+    if (!ahead) __syncthreads();                                                                                      \
+    GPSO_BSTAMP(q, 5);                                                                                                \
   }
+  for (int q = 0; q < q_diag0; ++q) GPSO_BF16_STEP(false)
+  for (int q = q_diag0; q < q_end; ++q) GPSO_BF16_STEP(true)
+#undef GPSO_BF16_STEP
   if (ahead) __syncthreads();
+
+  }
 
   // (fp16 split: undo the power-of-two scales of the two operands -- exact)
   double unscale2 = 1.0, unscale_m = 1.0;
@@ -830,7 +1117,7 @@ static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const T
                                      const TG* xnorm, const float* alpha, const TG* leaves_s,
                                      const TG* lnorm, double* part_var, double* part_mean,
                                      int64_t npad, int dp4, int64_t mpad, const KernParams& kp,
-                                     const int64_t* m_live, const float* inv_scale_a = nullptr) {
+                                     const int64_t* m_live, const float* inv_scale_a = nullptr, int variant = 0) {
   const int nbi = (int)(npad / 256);
   const dim3 grid((unsigned)(mpad / 256), (unsigned)nbi);
   const size_t lds = leaf_bf16_lds_bytes(NS, dp4, (int)sizeof(TG));
@@ -843,14 +1130,20 @@ static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const T
   (void)frexp(kp.variance, &eb);
   const float var_arg = F16 ? (float)ldexp(kp.variance, 14 - eb) : (float)kp.variance;
   const float inv_b = F16 ? (float)ldexp(1.0, eb - 14) : 1.0f;
-#define GPSO_L(K)                                                                                   \
+  // variant 0 (GPSO_SPLIT_KERNEL_AUTO): the fused step; 1: round 3's two-phase step.  Same bits either way.
+#define GPSO_L2(K, FUSED)                                                                           \
   do {                                                                                              \
-    const int rc = ensure_dyn_lds((const void*)leaf_tiles_bf16_kernel<NS, TG, K, F16>, (int)lds);   \
+    const int rc = ensure_dyn_lds((const void*)leaf_tiles_bf16_kernel<NS, TG, K, F16, FUSED>, (int)lds); \
     if (rc) return rc;                                                                              \
-    hipLaunchKernelGGL((leaf_tiles_bf16_kernel<NS, TG, K, F16>), grid, dim3(512), lds, st,          \
+    hipLaunchKernelGGL((leaf_tiles_bf16_kernel<NS, TG, K, F16, FUSED>), grid, dim3(512), lds, st,   \
                        static_cast<const u32x4*>(linv_b), xs_p, xnorm, alpha, leaves_s, lnorm,      \
                        part_var, part_mean, (int)(npad / 16), dp4, mpad, nbi, var_arg, m_live,      \
                        inv_scale_a, inv_b);                                                         \
+  } while (0)
+#define GPSO_L(K)                                                                                   \
+  do {                                                                                              \
+    if (variant == 0) GPSO_L2(K, true);                                                             \
+    else GPSO_L2(K, false);                                                                         \
   } while (0)
   switch (kp.kernel) {
     case 0: GPSO_L(0); break;
@@ -858,6 +1151,7 @@ static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const T
     case 2: GPSO_L(2); break;
     default: GPSO_L(3); break;
   }
+#undef GPSO_L2
 #undef GPSO_L
   return 0;
 }
@@ -867,15 +1161,15 @@ int launch_leaf_tiles_bf16(hipStream_t st, int nsplit, const void* linv_b, const
                            const TG* xnorm, const float* alpha, const TG* leaves_s,
                            const TG* lnorm, double* part_var, double* part_mean, int64_t npad,
                            int dp4, int64_t mpad, const KernParams& kp, const int64_t* m_live,
-                           const float* f16_inv_scale_a) {
+                           const float* f16_inv_scale_a, int variant) {
   if (f16_inv_scale_a != nullptr)  // fp16 split (nsplit == 2 pieces)
-    return launch_leaf_tiles_bf16_ns<2, TG, true>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a);
+    return launch_leaf_tiles_bf16_ns<2, TG, true>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, variant);
   if (nsplit == 3)
-    return launch_leaf_tiles_bf16_ns<3, TG>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live);
-  return launch_leaf_tiles_bf16_ns<2, TG>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live);
+    return launch_leaf_tiles_bf16_ns<3, TG>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, nullptr, variant);
+  return launch_leaf_tiles_bf16_ns<2, TG>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, nullptr, variant);
 }
-template int launch_leaf_tiles_bf16<float>(hipStream_t, int, const void*, const float*, const float*, const float*, const float*, const float*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*, const float*);
-template int launch_leaf_tiles_bf16<double>(hipStream_t, int, const void*, const double*, const double*, const float*, const double*, const double*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*, const float*);
+template int launch_leaf_tiles_bf16<float>(hipStream_t, int, const void*, const float*, const float*, const float*, const float*, const float*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*, const float*, int);
+template int launch_leaf_tiles_bf16<double>(hipStream_t, int, const void*, const double*, const double*, const float*, const double*, const double*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*, const float*, int);
 
 template <typename TF>
 void launch_pack_linv_bf16(hipStream_t st, int nsplit, const TF* linv, int64_t n, int64_t npad,

@@ -109,6 +109,10 @@ class HipGPEngine:
         entry point -- what a loop of small evaluations wants."""
         self._check(self._lib.gpso_set_option(self._h, L.OPT_TIMING, 1 if on else 0))
 
+    def set_split_kernel(self, which):
+        """GPSO_OPT_SPLIT_KERNEL: "auto" (the fused step) | "two-phase" (round 3's step): same bits, different speed."""
+        self._check(self._lib.gpso_set_option(self._h, L.OPT_SPLIT_KERNEL, {"auto": 0, "two-phase": 1}[which]))
+
     def set_precision_check(self, on):
         self._check(self._lib.gpso_set_option(self._h, L.OPT_PRECISION_CHECK, 1 if on else 0))
 

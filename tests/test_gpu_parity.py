@@ -862,3 +862,41 @@ def test_run_to_run_determinism_c3_g7(math, tol_var):
             assert cur == ref, (rep, call, float(np.max(np.abs(mean - mean_ref))))
             time.sleep(0.02)
         eng.close()
+
+
+@pytest.mark.parametrize("dtype,math,gen", [("float32", "f16x3", "float32"), ("mixed", "f16x3", "float64"), ("float32", "bf16x3", "float32"),
+                                            ("mixed", "bf16x3", "float64"), ("float32", "bf16x6", "float32"), ("mixed", "bf16x6", "float64")])
+@pytest.mark.parametrize("n,d,m,kernel", [(256, 6, 1000, "Matern52"), (2048, 12, 4096, "Matern52"), (768, 3, 700, "Matern32"),
+                                          (512, 24, 513, "SquaredExponential"), (1024, 40, 300, "Matern12"), (512, 1, 257, "Matern52")])
+def test_fused_step_kernel_gives_the_bits_of_the_two_phase_kernel(dtype, math, gen, n, d, m, kernel):
+    """Round 4: the split kernels run the FUSED step (every wave applies step q with the generation of step q + 1 dealt
+    into its MFMA shadows, one barrier per step) instead of round 3's two-phase step (generation and apply as two
+    stretches, the waves of a SIMD in opposite order).  Same operations on the same operands in the same order --
+    means, variances and winners must be the SAME BITS, for float and double generation, every kernel family, ragged
+    leaf counts, several row blocks, segments and on-device growth."""
+    from pygpso_amd import HipGPEngine
+
+    X, y, th = _problem(n, d, kernel, noise=1e-3, variance=1.7)
+    Xs = synthetic_leaves(m, d, seed=3)
+    res = {}
+    for which in ("auto", "two-phase"):
+        eng = HipGPEngine(dtype, predict_math=math, generation=gen, precision_check=False)
+        eng.set_split_kernel(which)
+        _fit(eng, X, y, th, grad=False)
+        if n % 256 == 0 and not (gen == "float64" and d >= (24 if math == "bf16x6" else 36)):
+            assert eng.precision_info()["predict_math"] == math  # (the split kernel really runs)
+        mean, var = eng.predict(Xs)
+        seg = np.array([0, 1, m // 3, m // 3, m], dtype=np.int64)
+        best = eng.best_ucb(Xs, VS, seg)
+        res[which] = (mean, var, best)
+        if d <= 6:
+            kids = tree.split_bounds([(0.0, 1.0)] * d)
+            res[which] += (eng.best_ucb_grow(np.array([kids[0], kids[2]]), 5, VS),)
+    a, b = res["auto"], res["two-phase"]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert all(np.array_equal(p, q, equal_nan=True) for p, q in zip(a[2], b[2]))
+    if len(a) > 3:
+        assert all(np.array_equal(p, q) for p, q in zip(a[3], b[3]))
+    post = gpr.posterior(th, X, y)
+    mean_ref, var_ref = gpr.predict_y(post, Xs)
+    assert np.max(np.abs(a[0] - mean_ref)) <= 2e-3 * max(1.0, np.max(np.abs(y))) and np.max(np.abs(a[1] - var_ref)) <= 2e-4 * th.variance
