@@ -1023,8 +1023,12 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     bf16x8 bnxt[NS][CT];
     if (q_diag0 == 0) leaf_bf16_gen<NS, TG, KERNEL, F16, true>(lane, dp4, xsl, xb, nb, vc, bfrag, macc);
     else leaf_bf16_gen<NS, TG, KERNEL, F16, false>(lane, dp4, xsl, xb, nb, vc, bfrag, macc);
-    // (the step's DMAs are issued at its head: dealt behind the MFMAs of row tiles 1, 2, ... like the map they cost 2 %
-    // more -- measured, tools/ab_time.py)
+    // Measured and NOT kept (tools/ab_time.py, same box, f16x3 at C3: two-phase 0.850 | this 0.7955 ms): the step's DMAs
+    // dealt behind the MFMAs of row tiles 1, 2, ... like the map (+2 %); a ring of THREE buffers of L^-1 pieces with the
+    // DMAs of step q + 2 issued at the tail of step q behind a raw s_barrier (0.7973); the SIMD's issue priority handed
+    // from waves 0-3 to waves 4-7 in the middle of every step (s_setprio; 0.8042 -- the arbiter serves the older wave
+    // first: stamps show waves 0-3 through a step in 3 700 clocks and waiting 1 800 at the barrier for waves 4-7, which
+    // need 5 000; flipping the priority flips who waits, the sum grows).
 #define GPSO_FUSED_STEP(ADIAG, GMODE)                                                                                 \
   {                                                                                                                   \
     GPSO_BSTAMP(q, 0);                                                                                                \

@@ -58,6 +58,7 @@ int main(int argc, char** argv) {
   hipMemcpy(dl, linv.data(), linv.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dx, xsp.data(), xsp.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(dn, xn.data(), npad * 4, hipMemcpyHostToDevice); hipMemcpy(da, al.data(), npad * 4, hipMemcpyHostToDevice);
   hipMemcpy(dlv, lv.data(), lv.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dln, ln.data(), m * 4, hipMemcpyHostToDevice);
+  const bool two_phase = argc > 2 && argv[2][0] == '2';  // second argument "2": round 3's two-phase step instead of the fused step
   const bool stream = argc > 1 && argv[1][0] == 's';  // "s": the one-wave-per-SIMD stream kernel (leaf_tiles_bf16s_kernel)
   const bool wide = stream || (argc > 1 && argv[1][0] == 'w');  // "w": the 32x32x16 kernel (leaf_tiles_bf16w_kernel)
   float* dxw = nullptr;
@@ -79,7 +80,7 @@ int main(int argc, char** argv) {
     hipEventRecord(e0, 0);
     if (stream) launch_leaf_tiles_bf16s(0, ns, lb, dxw, da, dlv, dln, pv, pm, npad, dp, dp, m, kp, nullptr);
     else if (wide) launch_leaf_tiles_bf16w(0, ns, lb, dxw, da, dlv, dln, pv, pm, npad, dp, dp, m, kp, nullptr);
-    else launch_leaf_tiles_bf16<float>(0, ns, lb, dx, dn, da, dlv, dln, pv, pm, npad, dp4, m, kp, nullptr, f16 ? f16_scal : nullptr);
+    else launch_leaf_tiles_bf16<float>(0, ns, lb, dx, dn, da, dlv, dln, pv, pm, npad, dp4, m, kp, nullptr, f16 ? f16_scal : nullptr, two_phase ? 1 : 0);
     hipEventRecord(e1, 0);
     hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -105,6 +106,15 @@ int main(int argc, char** argv) {
         for (int i = 0; i < 5; ++i) seg[i] += (double)(a[i + 1] - a[i]);
         tot += (double)(a[8] - a[0]);
         ++cnt;
+      }
+      if (!two_phase && !wide) {  // fused step: stamps 0 | 1 DMA issued | 4 fused step issued | 5 behind the barrier
+        double d = 0, f = 0, b = 0;
+        for (int q = 8; q < 52; ++q) {
+          const long long* a = g.data() + (w * 64 + q) * 8;
+          d += (double)(a[1] - a[0]); f += (double)(a[4] - a[1]); b += (double)(a[5] - a[4]);
+        }
+        printf("  wave %d, clocks per k-step (fused): issue DMA %.0f | apply(q) + generate(q + 1) %.0f | barrier %.0f | step %.0f\n", 4 * w, d / cnt, f / cnt, b / cnt, tot / cnt);
+        continue;
       }
       printf("  wave %d, clocks per k-step: issue DMA %.0f | generation %.0f | %s %.0f | apply %.0f | %s %.0f | step %.0f\n", 4 * w,
              seg[0] / cnt, seg[1] / cnt, w ? "barrier" : "-", seg[2] / cnt, seg[3] / cnt, w ? "-" : "barrier", seg[4] / cnt, tot / cnt);
