@@ -89,9 +89,12 @@ typedef struct gpso_ctx gpso_ctx;
                                    /* of the fit (rank-W trailing updates, level-doubling inverse) run on the bf16    */
                                    /* matrix cores as 3-way split products (6 bf16 MFMAs per product, f32             */
                                    /* accumulation: f32-class accuracy; 4 x 6 N^2 bytes of bf16 planes); 0: f32 MFMA   */
-#define GPSO_OPT_TIMING 7          /* 1 (default): every fit / predict entry point records the event pairs gpso_last_ms  */
-                                   /* reads (two to four HIP calls); 0: none, gpso_last_ms returns 0 -- for callers in a  */
-                                   /* loop of small evaluations (the drop-in surrogate switches it off)                   */
+#define GPSO_OPT_TIMING 7          /* 1 (default): every fit / predict-type entry point records the event pairs           */
+                                   /* gpso_last_ms reads (two to four HIP calls + an elapsed-time query: 10-25 us of a     */
+                                   /* call); 0: none, gpso_last_ms returns 0 -- for callers in a loop of small evaluations */
+                                   /* (the drop-in surrogate switches it off); k > 1: every k-th call is timed, the others */
+                                   /* leave gpso_last_ms at the last sample (bench.py: sampled kernel times inside its     */
+                                   /* timed region)                                                                        */
 #define GPSO_OPT_SPLIT_KERNEL 8    /* which step the split predict kernels (F16X3, BF16X6, BF16X3) run: 0 (default) the  */
 #define GPSO_SPLIT_KERNEL_AUTO 0   /*   FUSED step of round 4 (every wave applies step q with the generation of step q+1  */
 #define GPSO_SPLIT_KERNEL_TWO_PHASE 1 /* dealt into its MFMA shadows), 1 round 3's two-phase step.  Both give the SAME    */

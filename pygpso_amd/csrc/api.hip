@@ -145,7 +145,10 @@ struct gpso_ctx {
   std::vector<hipEvent_t> tile_ev;  // start/stop pairs around the leaf-tile kernel, one per chunk
   int tile_pairs = 0;               // pairs recorded by the call in flight
   double last_ms[3] = {0, 0, 0};
-  bool timing = true;  // GPSO_OPT_TIMING: record the event pairs gpso_last_ms reads (two to four HIP calls per entry point)
+  bool timing = true;  // GPSO_OPT_TIMING: does the call in flight record the event pairs gpso_last_ms reads (two to four HIP calls)?
+  int timing_every = 1;  // ... 0: never, 1: every fit / predict-type call, k: every k-th one (the others leave gpso_last_ms alone)
+  long timed_calls = 0;
+  void tick_timing() { timing = timing_every > 0 && (timed_calls++ % timing_every) == 0; }
   // multi-GPU group (gpso_comm_init): one RCCL communicator per context, collectives on ctx->stream
   ncclComm_t comm = nullptr;
   // gpso_comm_abort (callable from another thread): the communicator is gone -- not to be destroyed again, and not to be
@@ -288,6 +291,7 @@ struct EngineT : Engine {
   int small_tile_rows = 8;        // tile rows of the 128-padded linv_p that may be non-zero (8: all / unknown)
   bool linv_b_valid = false;
   std::vector<int64_t> segoff_cache;  // what the device copy of seg_off currently holds
+  double* host_direct = nullptr;      // pinned host memory the arg-max of the call in flight writes its records to
   // predict workspace
   DevBuf leaves_raw, leaves_s, lnorm, pvar, pmean, omean, ovar, oucb, segoff, best, oidx, ovals, grow_key,
       live_cnt, best_pos, gath, wbase, ovals2, bhdr;
@@ -375,7 +379,9 @@ struct EngineT : Engine {
         bf16_fit = value != 0;
         return GPSO_OK;
       case GPSO_OPT_TIMING:
-        if (value != 0 && value != 1) return ctx->fail(GPSO_E_ARG, "timing must be 0 or 1");
+        if (value < 0 || value > 1000000) return ctx->fail(GPSO_E_ARG, "timing must be 0 (off), 1 (every call) or k (every k-th call)");
+        ctx->timing_every = value;
+        ctx->timed_calls = 0;  // (the next fit / predict-type call is a sampled one)
         ctx->timing = value != 0;
         if (!ctx->timing) ctx->last_ms[0] = ctx->last_ms[1] = ctx->last_ms[2] = 0.0;
         return GPSO_OK;
@@ -675,6 +681,7 @@ struct EngineT : Engine {
 
   int fit_eval(int kernel, const double* ls, int n_ls_, double variance, double noise,
                double mean_c, double* nlml, double* grad) override {
+    ctx->tick_timing();
     if (!have_data) return ctx->fail(GPSO_E_STATE, "gpso_fit_eval before gpso_set_data");
     if (!ls) return ctx->fail(GPSO_E_ARG, "lengthscales must not be NULL");
     int rc = ensure_fit_buffers();
@@ -815,9 +822,12 @@ struct EngineT : Engine {
   // ------------------------------------------------------------------------------------------
   // leaves already on the device as raw coordinates (dtype xs_dtype) -> mean/var(/ucb) device arrays.
   // TG = generation type (double unless the context is float-predict with GPSO_GEN_F32).
+  // defer (nullable): the caller's arg-max can finalise the leaves itself (launch_seg_argmax / launch_keyed_argmax with
+  // a LeafFinalize) -- when the batch is ONE chunk the finalize launch is skipped and *defer says what to finalise;
+  // otherwise defer->part_var stays NULL and the leaves are finalised here as before
   template <typename TG>
   int score_leaves_t(const void* xs_dev, int xs_dtype, int64_t m, double varsigma, bool want_ucb,
-                     double* mean_dev, double* var_dev, double* ucb_dev, const int64_t* m_live) {
+                     double* mean_dev, double* var_dev, double* ucb_dev, const int64_t* m_live, LeafFinalize* defer) {
     // row blocks of L^-1 = partial sums per leaf: the split-bf16 kernel always works on 256-row blocks,
     // the native kernels on the shape leaf_tiles_bm picks
     const bool use_bf16 = bf16_usable() && linv_b_valid && bf16_fits(sizeof(TG) == 8);
@@ -881,6 +891,11 @@ struct EngineT : Engine {
       if (rc) return launch_status();
       if (ctx->timing) HIPCHECK(hipEventRecord(ctx->tile_ev[2 * ctx->tile_pairs + 1], s));
       ++ctx->tile_pairs;
+      if (defer != nullptr && nchunk == 1 && want_ucb) {
+        *defer = LeafFinalize{as<double>(pvar), as<double>(pmean), nbi, mp, kp.variance, kp.noise, kp.mean_c, varsigma,
+                              mean_dev, var_dev, ucb_dev};
+        continue;
+      }
       launch_leaf_finalize(s, as<double>(pvar), as<double>(pmean), nbi, mp, mc, kp, varsigma, mean_dev + off,
                            var_dev + off, want_ucb ? ucb_dev + off : nullptr);
     }
@@ -888,15 +903,17 @@ struct EngineT : Engine {
   }
 
   int score_device_leaves(const void* xs_dev, int xs_dtype, int64_t m, double varsigma, bool want_ucb,
-                          double* mean_dev, double* var_dev, double* ucb_dev, const int64_t* m_live = nullptr) {
+                          double* mean_dev, double* var_dev, double* ucb_dev, const int64_t* m_live = nullptr,
+                          LeafFinalize* defer = nullptr) {
+    if (defer != nullptr) *defer = LeafFinalize{};
     if constexpr (kFloatPredict) {
       if (!gen_double()) {
         int rc = ensure_generation_inputs();
         if (rc) return rc;
-        return score_leaves_t<float>(xs_dev, xs_dtype, m, varsigma, want_ucb, mean_dev, var_dev, ucb_dev, m_live);
+        return score_leaves_t<float>(xs_dev, xs_dtype, m, varsigma, want_ucb, mean_dev, var_dev, ucb_dev, m_live, defer);
       }
     }
-    return score_leaves_t<double>(xs_dev, xs_dtype, m, varsigma, want_ucb, mean_dev, var_dev, ucb_dev, m_live);
+    return score_leaves_t<double>(xs_dev, xs_dtype, m, varsigma, want_ucb, mean_dev, var_dev, ucb_dev, m_live, defer);
   }
 
   // after the stream has been synchronised: total leaf-tile kernel time of the call
@@ -1081,6 +1098,7 @@ struct EngineT : Engine {
 
   int predict(const void* xs, int xs_dtype, int xs_mem, int64_t m, double* mean, double* var,
               int out_mem) override {
+    ctx->tick_timing();
     int rc = check_predict_args(xs, xs_dtype, xs_mem, m);
     if (rc) return rc;
     if (m == 0) return GPSO_OK;
@@ -1140,10 +1158,14 @@ struct EngineT : Engine {
       HIPCHECK(hipStreamSynchronize(s));
       segoff_cache = so;
     }
+    LeafFinalize fin{};
     if (m > 0)
-      if ((rc = score_device_leaves(dev, xs_dtype, m, varsigma, true, as<double>(omean), as<double>(ovar), as<double>(oucb)))) return rc;
+      if ((rc = score_device_leaves(dev, xs_dtype, m, varsigma, true, as<double>(omean), as<double>(ovar), as<double>(oucb), nullptr, &fin))) return rc;
+    // (round 4: the leaves of a one-chunk batch are finalised by the arg-max's first stage, and its second stage writes
+    // the winners' records straight into the pinned host memory finish_best reads: two launches and a copy less per call)
+    host_direct = ctx->pinned_scratch((size_t)nseg * 4 + 2);
     launch_seg_argmax(s, as<double>(omean), as<double>(ovar), as<double>(oucb), as<int64_t>(segoff),
-                      nseg, kArgmaxBlocks, best.p, as<double>(ovals));
+                      nseg, argmax_blocks(m, nseg), best.p, as<double>(ovals), fin.part_var ? &fin : nullptr, host_direct);
     ctx->last_count[0] = ctx->last_count[1] = m;
     return launch_status();
   }
@@ -1181,12 +1203,15 @@ struct EngineT : Engine {
     HIPCHECK(hipMemcpyAsync(live_cnt.p, stage + (size_t)nseg * d * 2, 8, hipMemcpyHostToDevice, s));
     launch_grow_unique(s, bdev, nseg, d, depth, row_lo, row_hi, as<double>(leaves_raw), as<int64_t>(grow_key),
                        as<int64_t>(live_cnt));
+    LeafFinalize fin{};
     if (cap > 0)
       if ((rc = score_device_leaves(leaves_raw.p, GPSO_F64, cap, varsigma, true, as<double>(omean), as<double>(ovar),
-                                    as<double>(oucb), as<int64_t>(live_cnt))))
+                                    as<double>(oucb), as<int64_t>(live_cnt), &fin)))
         return rc;
+    host_direct = ctx->pinned_scratch((size_t)nseg * 4 + 2);
     launch_keyed_argmax(s, as<double>(omean), as<double>(ovar), as<double>(oucb), as<int64_t>(grow_key), rows, uniq,
-                        nseg, as<int64_t>(live_cnt), kArgmaxBlocks, best.p, as<int64_t>(best_pos), as<double>(ovals));
+                        nseg, as<int64_t>(live_cnt), argmax_blocks(cap, nseg), best.p, as<int64_t>(best_pos), as<double>(ovals),
+                        fin.part_var ? &fin : nullptr, host_direct);
     ctx->last_count[1] = cap;
     return launch_status();
   }
@@ -1307,7 +1332,10 @@ struct EngineT : Engine {
     const size_t doubles = (size_t)nseg * 4 + (mode == 2 ? 2 : mode);
     double* vals = ctx->pinned_scratch(doubles);
     if (!vals) return ctx->fail(GPSO_E_OOM, "pinned host scratch");
-    HIPCHECK(hipMemcpyAsync(vals, src.p, doubles * 8, hipMemcpyDeviceToHost, s));
+    // (mode 0 / 1: the arg-max's second stage has written the records into this very memory: no copy operation)
+    const bool direct = mode != 2 && host_direct != nullptr && host_direct == vals && src.p == ovals.p;
+    host_direct = nullptr;
+    if (!direct) HIPCHECK(hipMemcpyAsync(vals, src.p, doubles * 8, hipMemcpyDeviceToHost, s));
     if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[3], s));
     HIPCHECK(ctx->wait(s));
     int rc;
@@ -1343,6 +1371,7 @@ struct EngineT : Engine {
 
   int best_ucb(const void* xs, int xs_dtype, int xs_mem, int64_t m, const int64_t* seg_off, int nseg,
                double varsigma, int64_t* idx, double* mean, double* var, double* ucb) override {
+    ctx->tick_timing();
     int rc = check_predict_args(xs, xs_dtype, xs_mem, m);
     if (rc) return rc;
     if (nseg < 1) return ctx->fail(GPSO_E_ARG, "nseg must be >= 1");
@@ -1367,6 +1396,7 @@ struct EngineT : Engine {
   int best_ucb_sharded(const void* xs, int xs_dtype, int xs_mem, int64_t m_local, int64_t m_global,
                        const int64_t* seg_off, int nseg, double varsigma, int64_t* idx, double* mean,
                        double* var, double* ucb) override {
+    ctx->tick_timing();
     int rc = need_comm();
     if (rc) return rc;
     // (arguments every rank passes alike fail alike: no collective has started yet)
@@ -1428,6 +1458,7 @@ struct EngineT : Engine {
   // the result is what gp_eval_best_ucb(leaf.grow(depth)) returns (grow.hip: grow_unique_kernel).
   int best_ucb_grow(const double* bounds, int nseg, int depth, double varsigma, int64_t* idx,
                     double* mean, double* var, double* ucb) override {
+    ctx->tick_timing();
     if (!have_post) return ctx->fail(GPSO_E_STATE, "no posterior resident: call gpso_fit_eval / gpso_set_posterior first");
     int rc = precision_gate();
     if (rc) return rc;
@@ -1441,6 +1472,7 @@ struct EngineT : Engine {
   // (ucb, reference row index) order.  Identical result on every rank, identical to gpso_best_ucb_grow.
   int best_ucb_grow_sharded(const double* bounds, int nseg, int depth, double varsigma, int64_t* idx,
                             double* mean, double* var, double* ucb) override {
+    ctx->tick_timing();
     int rc = need_comm();
     if (rc) return rc;
     if (nseg < 1) return ctx->fail(GPSO_E_ARG, "nseg must be >= 1");
@@ -1462,6 +1494,7 @@ struct EngineT : Engine {
   // `world` ranks computes can be replayed on ONE device, the all-gather replaced by the caller's concatenation ----
   int shard_winners(int rank, int world, const void* xs, int xs_dtype, int xs_mem, int64_t m_local, int64_t m_global,
                     const int64_t* seg_off, int nseg, double varsigma, double* payload) override {
+    ctx->tick_timing();
     if (!payload) return ctx->fail(GPSO_E_ARG, "payload must not be NULL");
     if (world < 1 || rank < 0 || rank >= world) return ctx->fail(GPSO_E_ARG, "rank %d / world %d", rank, world);
     if (nseg < 1) return ctx->fail(GPSO_E_ARG, "nseg must be >= 1");
@@ -1473,6 +1506,7 @@ struct EngineT : Engine {
   }
   int shard_winners_grow(int rank, int world, const double* bounds, int nseg, int depth, double varsigma,
                          double* payload) override {
+    ctx->tick_timing();
     if (!payload) return ctx->fail(GPSO_E_ARG, "payload must not be NULL");
     if (world < 1 || rank < 0 || rank >= world) return ctx->fail(GPSO_E_ARG, "rank %d / world %d", rank, world);
     if (nseg < 1) return ctx->fail(GPSO_E_ARG, "nseg must be >= 1");
@@ -1498,6 +1532,7 @@ struct EngineT : Engine {
   // gpso_shard_winners_grow (global reference row indices)
   int fold_winners(const double* gathered, int world, int64_t m_global, const int64_t* seg_off, int nseg, int64_t* idx,
                    double* mean, double* var, double* ucb) override {
+    ctx->tick_timing();
     if (!gathered) return ctx->fail(GPSO_E_ARG, "gathered must not be NULL");
     if (world < 1 || nseg < 1) return ctx->fail(GPSO_E_ARG, "world %d / nseg %d", world, nseg);
     int rc = ensure_group_buffers(nseg, world);
@@ -1935,6 +1970,7 @@ int gpso_wait_stream(gpso_ctx* ctx, void* producer_stream) {
   ENTER();
   hipStream_t prod = static_cast<hipStream_t>(producer_stream);
   if (prod == ctx->stream) return GPSO_OK;
+  if (hipStreamQuery(prod) == hipSuccess) return GPSO_OK;  // nothing pending there: nothing to wait for (one call, no event)
   HIPCHECK(hipEventRecord(ctx->ev_wait, prod));
   HIPCHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_wait, 0));
   return GPSO_OK;

@@ -61,23 +61,41 @@ int launch_leaf_tiles_bf16(hipStream_t st, int nsplit, const void* linv_b, const
 template <typename TF>
 void launch_pack_linv_f16(hipStream_t st, const TF* linv, int64_t n, int64_t npad, float* scal, void* linv_b,
                           bool have_max = false);
+// what finalising a leaf needs (leaf_finalize_kernel, or fused into the arg-max's first stage: launch_seg_argmax)
+struct LeafFinalize {
+  const double* part_var = nullptr;
+  const double* part_mean = nullptr;
+  int nbi = 0;
+  int64_t mpad = 0;
+  double variance = 0, noise = 0, mean_c = 0, varsigma = 0;
+  double* mean = nullptr;
+  double* var = nullptr;
+  double* ucb = nullptr;
+};
 void launch_leaf_finalize(hipStream_t st, const double* part_var, const double* part_mean, int nbi,
                           int64_t mpad, int64_t m, const KernParams& kp, double varsigma,
                           double* mean, double* var, double* ucb);
 void launch_seg_argmax(hipStream_t st, const double* mean, const double* var, const double* ucb,
                        const int64_t* seg_off_dev, int nseg, int nblk, void* partial_dev,
-                       double* out_vals_dev /* [nseg*4 + 2]: per segment mean, var, ucb, bit-cast int64 index; spare; 0.0 (status slot) */);
+                       double* out_vals_dev /* [nseg*4 + 2]: per segment mean, var, ucb, bit-cast int64 index; spare; 0.0 (status slot) */,
+                       const LeafFinalize* fin = nullptr /* the leaves are still partial sums: finalise them in stage 1 */,
+                       double* host_vals = nullptr /* pinned host copy of out_vals, written by the kernel itself */);
 // arg-max over a de-duplicated, keyed leaf list (grow.hip: launch_grow_unique); out_vals_dev[nseg*4 + 2]:
 // per segment mean, var, ucb, bit-cast reference row index; then the bit-cast live row count; then 0.0 (status slot)
 void launch_keyed_argmax(hipStream_t st, const double* mean, const double* var, const double* ucb,
                          const int64_t* key_dev, int64_t rows, int64_t uniq, int nseg, const int64_t* live_dev,
-                         int nblk, void* partial_dev, int64_t* pos_dev, double* out_vals_dev);
+                         int nblk, void* partial_dev, int64_t* pos_dev, double* out_vals_dev,
+                         const LeafFinalize* fin = nullptr, double* host_vals = nullptr);
 // out_dev[c] = number of live leaves inside chunk c of a batch whose total live count is *live_dev
 void launch_chunk_live(hipStream_t st, const int64_t* live_dev, int64_t chunk, int nchunk, int64_t* out_dev);
 // *acc += sum_i mix(words[i], i, salt)  (64-bit wrap-around sum of a per-word mix: order-independent, so the parallel
 // reduction is deterministic) -- the posterior fingerprint of gpso_posterior_hash
 void launch_hash_words(hipStream_t st, const void* words, size_t nwords, uint64_t salt, unsigned long long* acc);
-constexpr int kArgmaxBlocks = 64;      // stage-1 blocks per segment
+constexpr int kArgmaxBlocks = 256;     // stage-1 blocks per segment, at most (argmax_blocks picks: one pass of 256 leaves per block)
+inline int argmax_blocks(int64_t m, int nseg) {
+  const int64_t per_seg = (m / (nseg > 0 ? nseg : 1) + 255) / 256;
+  return (int)(per_seg < 1 ? 1 : per_seg > kArgmaxBlocks ? kArgmaxBlocks : per_seg);
+}
 constexpr size_t kArgmaxPartialBytes = 16;  // sizeof(Best)
 
 // ---- fit.hip --------------------------------------------------------------------------------------

@@ -938,13 +938,19 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   // Each group is one LDS window addressed as M0 + the instruction's 13-bit immediate offset, which the hardware adds
   // to the global and the LDS address alike (the global base is pre-biased by the same amount): one M0 write and one
   // scalar add per DMA instead of ~25 scalar instructions of address arithmetic.
-  constexpr int FPW = NS * RT / NW;  // fragments of the L^-1 pieces per wave: 4 (two pieces) or 6 (three)
-  static_assert(FPW * NW == NS * RT && FPW * 1024 <= 8192 && RT == 16, "window of a wave's fragments");
+  // DW waves carry the DMA duties.  Fused step, two pieces: waves 0-3 ONLY -- the SIMD's arbiter serves its older wave
+  // first, so waves 0-3 are through a fused step in 3 700 clocks and would wait 1 800 at the barrier for waves 4-7, which
+  // need 5 000 (stamps, tools/micro/leaf_bf16_phases.hip): the DMA issue (~650 clocks per wave when dealt evenly) is the
+  // work that can be moved, and it goes to the waves that have the time.  Otherwise all eight waves share it.
+  constexpr int DW = (FUSED != 0 && NS == 2) ? NW / 2 : NW;
+  constexpr int FPW = NS * RT / DW;  // fragments of the L^-1 pieces per DMA wave: 8 / 4 (two pieces) or 6 (three)
+  static_assert(FPW * DW == NS * RT && FPW * 1024 <= 8192 && RT == 16, "window of a wave's fragments");
+  const bool dma_wave = wave < DW;
   const int lane16 = lane * 16, lane4 = lane * 4;
   const unsigned char* pgb[FPW];
 #pragma unroll
   for (int j = 0; j < FPW; ++j) {
-    const int f = FPW * wave + j, sp = f / RT, rt = f % RT;  // fragment f = piece sp, row tile rt
+    const int f = FPW * (wave % DW) + j, sp = f / RT, rt = f % RT;  // fragment f = piece sp, row tile rt
     pgb[j] = reinterpret_cast<const unsigned char*>(linv_b + ((size_t)sp * npad16 + (bi * RT + rt)) * npad32 * 64) -
              (j * 1024 - FPW * 512);
   }
@@ -957,36 +963,38 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     return reinterpret_cast<const unsigned char*>(((unsigned long long)hi << 32) | lo);
   };
   auto issue_panel = [&](int q, int buf) {
+    if (!dma_wave) return;
     unsigned char* centre = reinterpret_cast<unsigned char*>(panel) + buf * (NS * RT * 1024) + wave * (FPW * 1024) + FPW * 512;
     static_for<0, FPW>([&](auto j_) {
       constexpr int j = decltype(j_)::value;
       glds16_off<j * 1024 - FPW * 512>(uniform(pgb[j] + (size_t)q * 1024) + lane16, centre);
     });
   };
-  // the inputs of a k-step: a ring of three buffers -- waves 4-7 generate step q + 1 during step q.  Piece r of
+  // the inputs of a k-step: a ring of three buffers (step q + 1 is generated during step q).  Piece r of
   // the X fragments is bytes [256 r, 256 r + 256) of the step's contiguous source block and of the buffer alike
-  // (<= 32 pieces: D <= 48 in float, <= 32 in double -- checked at launch); wave w moves pieces w + 8 jj.  Wave 6 also
-  // moves the 32 norms (TG, as 64 dwords; float: lanes 32-63 fetch duplicates into the unused half), wave 7 the 32
-  // alphas 64 TG behind them.
+  // (<= 32 pieces: D <= 48 in float, <= 32 in double -- checked at launch); DMA wave w moves pieces w + DW jj.  The last
+  // but one DMA wave also moves the 32 norms (TG, as 64 dwords; float: lanes 32-63 fetch duplicates into the unused
+  // half), the last one the 32 alphas 64 TG behind them.
   const int xpieces = 2 * dp4 * ((int)sizeof(TG) / 4);
   const unsigned char* xs_bytes = reinterpret_cast<const unsigned char*>(xs_p);
   const size_t xstep = (size_t)2 * dp4 * 64 * sizeof(TG);
-  const int xmine = (xpieces - wave + 7) >> 3;  // how many of the pieces w, w + 8, ... exist
+  const int xmine = dma_wave ? (xpieces - wave + DW - 1) / DW : 0;  // how many of the pieces w, w + DW, ... exist
   auto issue_x = [&](int q) {
+    if (!dma_wave) return;
     unsigned char* xd = xsl + (q % 3) * xstride;
     if (xmine > 0) {
       const unsigned char* src = uniform(xs_bytes + (size_t)q * xstep + wave * 256 + 4096);
       unsigned char* centre = xd + wave * 256 + 4096;
-      glds4_off<-4096>(src + lane4, centre);
-      if (xmine > 1) glds4_off<-2048>(src + lane4, centre);
-      if (xmine > 2) glds4_off<0>(src + lane4, centre);
-      if (xmine > 3) glds4_off<2048>(src + lane4, centre);
+      static_for<0, 32 / DW>([&](auto jj_) {
+        constexpr int jj = decltype(jj_)::value;
+        if (xmine > jj) glds4_off<jj * DW * 256 - 4096>(src + lane4, centre);
+      });
     }
     unsigned char* nd = xd + (size_t)xpieces * 256;
-    if (wave == NW - 2) {
+    if (wave == DW - 2) {
       const int nlane = (sizeof(TG) == 8) ? lane4 : (lane & 31) * 4;
       glds4_off<0>(uniform(reinterpret_cast<const unsigned char*>(xnorm + 32 * q)) + nlane, nd);
-    } else if (wave == NW - 1) {
+    } else if (wave == DW - 1) {
       glds4_off<0>(uniform(reinterpret_cast<const unsigned char*>(alpha + 32 * q)) + (lane & 31) * 4, nd + 64 * sizeof(TG));
     }
   };
@@ -1203,6 +1211,26 @@ template void launch_pack_linv_bf16<float>(hipStream_t, int, const float*, int64
 template void launch_pack_linv_bf16<double>(hipStream_t, int, const double*, int64_t, int64_t, void*);
 
 // ---------------------------------------------------------------------------------------------
+// one leaf: sum the row blocks' partials, form mean / var (+ noise) / ucb, store them; returns ucb
+__device__ __forceinline__ double finalize_leaf(const LeafFinalize& f, int64_t j) {
+  double v = 0, mu = 0;
+  for (int b = 0; b < f.nbi; ++b) {
+    v += f.part_var[(int64_t)b * f.mpad + j];
+    mu += f.part_mean[(int64_t)b * f.mpad + j];
+  }
+  // [gpflow base_conditional] fvar = k** - sum A^2 ; predict_y adds the noise variance
+  const double vy = __dadd_rn(__dsub_rn(f.variance, v), f.noise);
+  const double my = __dadd_rn(mu, f.mean_c);
+  f.mean[j] = my;
+  f.var[j] = vy;
+  // gpso/gp_surrogate.py:326  ucb = mean + varsigma * var  (two roundings, as numpy does)
+  double prod = f.varsigma * vy;
+  asm volatile("" : "+v"(prod));  // keep the product rounded on its own: no fma contraction
+  const double u = my + prod;
+  f.ucb[j] = u;
+  return u;
+}
+
 __global__ __launch_bounds__(256) void leaf_finalize_kernel(const double* __restrict__ part_var,
                                                             const double* __restrict__ part_mean,
                                                             int nbi, int64_t mpad, int64_t m,
@@ -1260,17 +1288,20 @@ __device__ __forceinline__ Best block_best(Best mine, Best* sh) {
   return mine;  // valid on thread 0
 }
 
-// stage 1: grid (nblk, nseg); each block scans a strided share of its segment
+// stage 1: grid (nblk, nseg); each block scans a strided share of its segment.  FIN (round 4): the leaves arrive as
+// the tile kernel's partial sums and are FINALISED here (leaf_finalize_kernel's arithmetic, leaf for leaf: every leaf
+// of [0, M) lies in exactly one segment) -- one launch and one pass over mean / var / ucb less per call
+template <bool FIN>
 __global__ __launch_bounds__(256) void seg_argmax_stage1(const double* __restrict__ ucb,
                                                          const int64_t* __restrict__ seg_off,
-                                                         Best* __restrict__ partial) {
+                                                         Best* __restrict__ partial, LeafFinalize fin) {
   __shared__ Best sh[4];
   const int seg = blockIdx.y;
   const int64_t lo = seg_off[seg], hi = seg_off[seg + 1];
   Best mine{0.0, -1};
   for (int64_t j = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < hi;
        j += (int64_t)gridDim.x * blockDim.x) {
-    Best c{ucb[j], j};
+    Best c{FIN ? finalize_leaf(fin, j) : ucb[j], j};
     if (better(c, mine)) mine = c;
   }
   mine = block_best(mine, sh);
@@ -1283,7 +1314,9 @@ __global__ __launch_bounds__(256) void seg_argmax_stage2(const Best* __restrict_
                                                          const double* __restrict__ mean,
                                                          const double* __restrict__ var,
                                                          const double* __restrict__ ucb, int nseg,
-                                                         double* __restrict__ out_vals /*[nseg*4 + 2]*/) {
+                                                         double* __restrict__ out_vals /*[nseg*4 + 2]*/,
+                                                         double* __restrict__ host_vals /* nullable: the same records
+                                                         straight into pinned host memory (no copy operation behind) */) {
   __shared__ Best sh[4];
   const int seg = blockIdx.x;
   if (seg >= nseg) return;
@@ -1306,6 +1339,11 @@ __global__ __launch_bounds__(256) void seg_argmax_stage2(const Best* __restrict_
       out_vals[seg * 4 + 3] = __builtin_bit_cast(double, (int64_t)(mine.i - seg_off[seg]));
     }
     if (seg == 0) out_vals[nseg * 4 + 1] = 0.0;  // status slot of a group payload: this rank's half succeeded
+    if (host_vals != nullptr) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) host_vals[seg * 4 + k] = out_vals[seg * 4 + k];
+      if (seg == 0) host_vals[nseg * 4 + 1] = 0.0;
+    }
   }
 }
 
@@ -1315,12 +1353,14 @@ __global__ __launch_bounds__(256) void seg_argmax_stage2(const Best* __restrict_
 // [seg * uniq, (seg + 1) * uniq) plus those rows of the appended tail [nseg * uniq, *live) whose key
 // falls into it.  The order is np.argmax's on (ucb, reference row index), so the winner and its index
 // are what scoring the full duplicated list would give.
+template <bool FIN>
 __global__ __launch_bounds__(256) void keyed_argmax_stage1(const double* __restrict__ ucb,
                                                            const int64_t* __restrict__ key, int64_t rows,
                                                            int64_t uniq, int nseg,
                                                            const int64_t* __restrict__ live,
                                                            Best* __restrict__ partial,
-                                                           int64_t* __restrict__ pos /* compact row of each partial */) {
+                                                           int64_t* __restrict__ pos /* compact row of each partial */,
+                                                           LeafFinalize fin) {
   __shared__ Best sh[4];
   __shared__ int64_t shp[4];
   const int seg = blockIdx.y;
@@ -1329,7 +1369,7 @@ __global__ __launch_bounds__(256) void keyed_argmax_stage1(const double* __restr
   Best mine{0.0, -1};
   int64_t mypos = -1;
   for (int64_t j = (int64_t)seg * uniq + t0; j < (int64_t)(seg + 1) * uniq; j += stride) {
-    Best c{ucb[j], key[j]};
+    Best c{FIN ? finalize_leaf(fin, j) : ucb[j], key[j]};
     if (better(c, mine)) {
       mine = c;
       mypos = j;
@@ -1339,7 +1379,7 @@ __global__ __launch_bounds__(256) void keyed_argmax_stage1(const double* __restr
   for (int64_t j = (int64_t)nseg * uniq + t0; j < lv; j += stride) {
     const int64_t kj = key[j];
     if (kj / rows != seg) continue;
-    Best c{ucb[j], kj};
+    Best c{FIN ? finalize_leaf(fin, j) : ucb[j], kj};
     if (better(c, mine)) {
       mine = c;
       mypos = j;
@@ -1379,7 +1419,8 @@ __global__ __launch_bounds__(256) void keyed_argmax_stage2(const Best* __restric
                                                            const double* __restrict__ var,
                                                            const double* __restrict__ ucb,
                                                            const int64_t* __restrict__ live, int nseg,
-                                                           double* __restrict__ out_vals /*[nseg*4 + 2]*/) {
+                                                           double* __restrict__ out_vals /*[nseg*4 + 2]*/,
+                                                           double* __restrict__ host_vals /* nullable, see seg_argmax_stage2 */) {
   __shared__ Best sh[4];
   const int seg = blockIdx.x;
   Best mine{0.0, -1};
@@ -1404,6 +1445,14 @@ __global__ __launch_bounds__(256) void keyed_argmax_stage2(const Best* __restric
     if (seg == 0) {
       out_vals[nseg * 4] = __builtin_bit_cast(double, *live);
       out_vals[nseg * 4 + 1] = 0.0;  // status slot of a group payload
+    }
+    if (host_vals != nullptr) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) host_vals[seg * 4 + k] = out_vals[seg * 4 + k];
+      if (seg == 0) {
+        host_vals[nseg * 4] = out_vals[nseg * 4];
+        host_vals[nseg * 4 + 1] = 0.0;
+      }
     }
   }
 }
@@ -1561,22 +1610,31 @@ void launch_leaf_finalize(hipStream_t st, const double* part_var, const double* 
 
 void launch_seg_argmax(hipStream_t st, const double* mean, const double* var, const double* ucb,
                        const int64_t* seg_off_dev, int nseg, int nblk, void* partial_dev,
-                       double* out_vals_dev) {
-  hipLaunchKernelGGL(seg_argmax_stage1, dim3((unsigned)nblk, (unsigned)nseg), dim3(256), 0, st, ucb,
-                     seg_off_dev, reinterpret_cast<Best*>(partial_dev));
+                       double* out_vals_dev, const LeafFinalize* fin, double* host_vals) {
+  if (fin != nullptr)
+    hipLaunchKernelGGL(seg_argmax_stage1<true>, dim3((unsigned)nblk, (unsigned)nseg), dim3(256), 0, st, ucb,
+                       seg_off_dev, reinterpret_cast<Best*>(partial_dev), *fin);
+  else
+    hipLaunchKernelGGL(seg_argmax_stage1<false>, dim3((unsigned)nblk, (unsigned)nseg), dim3(256), 0, st, ucb,
+                       seg_off_dev, reinterpret_cast<Best*>(partial_dev), LeafFinalize{});
   hipLaunchKernelGGL(seg_argmax_stage2, dim3((unsigned)nseg), dim3(256), 0, st,
                      reinterpret_cast<const Best*>(partial_dev), nblk, seg_off_dev, mean, var, ucb, nseg,
-                     out_vals_dev);
+                     out_vals_dev, host_vals);
 }
 
 void launch_keyed_argmax(hipStream_t st, const double* mean, const double* var, const double* ucb,
                          const int64_t* key_dev, int64_t rows, int64_t uniq, int nseg, const int64_t* live_dev,
-                         int nblk, void* partial_dev, int64_t* pos_dev, double* out_vals_dev) {
-  hipLaunchKernelGGL(keyed_argmax_stage1, dim3((unsigned)nblk, (unsigned)nseg), dim3(256), 0, st, ucb, key_dev,
-                     rows, uniq, nseg, live_dev, reinterpret_cast<Best*>(partial_dev), pos_dev);
+                         int nblk, void* partial_dev, int64_t* pos_dev, double* out_vals_dev, const LeafFinalize* fin,
+                         double* host_vals) {
+  if (fin != nullptr)
+    hipLaunchKernelGGL(keyed_argmax_stage1<true>, dim3((unsigned)nblk, (unsigned)nseg), dim3(256), 0, st, ucb, key_dev,
+                       rows, uniq, nseg, live_dev, reinterpret_cast<Best*>(partial_dev), pos_dev, *fin);
+  else
+    hipLaunchKernelGGL(keyed_argmax_stage1<false>, dim3((unsigned)nblk, (unsigned)nseg), dim3(256), 0, st, ucb, key_dev,
+                       rows, uniq, nseg, live_dev, reinterpret_cast<Best*>(partial_dev), pos_dev, LeafFinalize{});
   hipLaunchKernelGGL(keyed_argmax_stage2, dim3((unsigned)nseg), dim3(256), 0, st,
                      reinterpret_cast<const Best*>(partial_dev), pos_dev, nblk, rows, mean, var, ucb, live_dev,
-                     nseg, out_vals_dev);
+                     nseg, out_vals_dev, host_vals);
 }
 
 void launch_reduce_winners(hipStream_t st, const double* gathered, const int64_t* base, int world, int nseg,

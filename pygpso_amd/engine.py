@@ -107,7 +107,7 @@ class HipGPEngine:
     def set_timing(self, on):
         """GPSO_OPT_TIMING: record the event pairs ``last_ms`` reads (default on); off saves two to four HIP calls per
         entry point -- what a loop of small evaluations wants."""
-        self._check(self._lib.gpso_set_option(self._h, L.OPT_TIMING, 1 if on else 0))
+        self._check(self._lib.gpso_set_option(self._h, L.OPT_TIMING, int(on)))  # (True / 1: every call, k: every k-th)
 
     def set_split_kernel(self, which):
         """GPSO_OPT_SPLIT_KERNEL: "auto" (the fused step) | "two-phase" (round 3's step): same bits, different speed."""

@@ -47,6 +47,13 @@ def worker(args):
                 ks.append(eng.last_ms(0))
             wall = (time.perf_counter() - t0) / args.steps * 1e3
             out[math] = {"kernel_ms": float(np.median(ks)), "step_ms": wall}
+            eng.set_timing(False)  # the same call without the library's event pairs (gpso_last_ms reads 0 then)
+            for _ in range(20):
+                eng.best_ucb(leaves, 2.0)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                eng.best_ucb(leaves, 2.0)
+            out[math]["step_ms_no_events"] = (time.perf_counter() - t0) / args.steps * 1e3
             eng.close()
     elif args.what == "fit":
         for dtype in args.dtype.split(","):
