@@ -286,12 +286,14 @@ struct EngineT : Engine {
   bool gen_decided = false;     // AUTO: has the self-test ruled on this posterior?
   bool gen32_inputs_ok = false; // xs32 / xnorm32 / xs_p32 match the resident posterior
   int split_variant = GPSO_SPLIT_KERNEL_AUTO;  // GPSO_OPT_SPLIT_KERNEL
+  bool small_calls = true;                     // GPSO_OPT_SMALL_CALLS
   int64_t single_level_max = -1;  // < 0: library default
   bool fused_small = true;        // GPSO_OPT_FIT_FUSED_SMALL
   int small_tile_rows = 8;        // tile rows of the 128-padded linv_p that may be non-zero (8: all / unknown)
   bool linv_b_valid = false;
   std::vector<int64_t> segoff_cache;  // what the device copy of seg_off currently holds
   double* host_direct = nullptr;      // pinned host memory the arg-max of the call in flight writes its records to
+  DevBuf extra_cnt;                   // small growth calls: rows appended behind the analytic slots (zero between calls)
   // predict workspace
   DevBuf leaves_raw, leaves_s, lnorm, pvar, pmean, omean, ovar, oucb, segoff, best, oidx, ovals, grow_key,
       live_cnt, best_pos, gath, wbase, ovals2, bhdr;
@@ -306,7 +308,7 @@ struct EngineT : Engine {
                       &work, &kinvb, &linv_p, &white, &alpha_f, &alpha, &logdet, &scal, &gpart, &apart,
                       &kinv_diag, &getter_tmp, &leaves_raw, &leaves_s, &lnorm, &pvar, &pmean, &omean, &ovar,
                       &oucb, &segoff, &best, &oidx, &ovals, &linv_b, &st_mean, &st_var, &st_out, &grow_key, &live_cnt,
-                      &best_pos, &gath, &wbase, &ovals2, &bhdr, &pl_L, &pl_X, &pl_XT, &pl_WT, &amax_rows, &arena, &hash_out})
+                      &best_pos, &gath, &wbase, &ovals2, &bhdr, &pl_L, &pl_X, &pl_XT, &pl_WT, &amax_rows, &arena, &hash_out, &extra_cnt})
       if (b->p && !b->view) (void)hipFree(b->p);
   }
 
@@ -388,6 +390,10 @@ struct EngineT : Engine {
       case GPSO_OPT_FIT_FUSED_SMALL:
         if (value != 0 && value != 1) return ctx->fail(GPSO_E_ARG, "fused small fit must be 0 or 1");
         fused_small = value != 0;
+        return GPSO_OK;
+      case GPSO_OPT_SMALL_CALLS:
+        if (value != 0 && value != 1) return ctx->fail(GPSO_E_ARG, "small calls must be 0 or 1");
+        small_calls = value != 0;
         return GPSO_OK;
       case GPSO_OPT_SPLIT_KERNEL:
         if (value != GPSO_SPLIT_KERNEL_AUTO && value != GPSO_SPLIT_KERNEL_TWO_PHASE) return ctx->fail(GPSO_E_ARG, "unknown split kernel %d", value);
@@ -827,7 +833,8 @@ struct EngineT : Engine {
   // otherwise defer->part_var stays NULL and the leaves are finalised here as before
   template <typename TG>
   int score_leaves_t(const void* xs_dev, int xs_dtype, int64_t m, double varsigma, bool want_ucb,
-                     double* mean_dev, double* var_dev, double* ucb_dev, const int64_t* m_live, LeafFinalize* defer) {
+                     double* mean_dev, double* var_dev, double* ucb_dev, const int64_t* m_live, LeafFinalize* defer,
+                     bool prepared = false /* leaves_s / lnorm already hold the scaled rows (one chunk): no prep launch */) {
     // row blocks of L^-1 = partial sums per leaf: the split-bf16 kernel always works on 256-row blocks,
     // the native kernels on the shape leaf_tiles_bm picks
     const bool use_bf16 = bf16_usable() && linv_b_valid && bf16_fits(sizeof(TG) == 8);
@@ -868,10 +875,13 @@ struct EngineT : Engine {
       const int64_t mp = (mc + kLeafPad - 1) / kLeafPad * kLeafPad;
       const int64_t* m_live_c = (m_live != nullptr && nchunk > 1) ? as<int64_t>(live_cnt) + 1 + off / chunk : m_live;
       const char* src = static_cast<const char*>(xs_dev) + (size_t)off * d * in_elem;
-      if (xs_dtype == GPSO_F64)
+      if (prepared) {
+        if (nchunk != 1) return ctx->fail(GPSO_E_STATE, "internal: prepared leaves in more than one chunk");
+      } else if (xs_dtype == GPSO_F64) {
         launch_prep_leaves<TG, double>(s, reinterpret_cast<const double*>(src), mc, mp, d, dp, ls_dev(), m_live_c, as<TG>(leaves_s), as<TG>(lnorm));
-      else
+      } else {
         launch_prep_leaves<TG, float>(s, reinterpret_cast<const float*>(src), mc, mp, d, dp, ls_dev(), m_live_c, as<TG>(leaves_s), as<TG>(lnorm));
+      }
       while ((int)ctx->tile_ev.size() < 2 * (ctx->tile_pairs + 1)) {
         hipEvent_t e;
         HIPCHECK(hipEventCreate(&e));
@@ -904,16 +914,16 @@ struct EngineT : Engine {
 
   int score_device_leaves(const void* xs_dev, int xs_dtype, int64_t m, double varsigma, bool want_ucb,
                           double* mean_dev, double* var_dev, double* ucb_dev, const int64_t* m_live = nullptr,
-                          LeafFinalize* defer = nullptr) {
+                          LeafFinalize* defer = nullptr, bool prepared = false) {
     if (defer != nullptr) *defer = LeafFinalize{};
     if constexpr (kFloatPredict) {
       if (!gen_double()) {
         int rc = ensure_generation_inputs();
         if (rc) return rc;
-        return score_leaves_t<float>(xs_dev, xs_dtype, m, varsigma, want_ucb, mean_dev, var_dev, ucb_dev, m_live, defer);
+        return score_leaves_t<float>(xs_dev, xs_dtype, m, varsigma, want_ucb, mean_dev, var_dev, ucb_dev, m_live, defer, prepared);
       }
     }
-    return score_leaves_t<double>(xs_dev, xs_dtype, m, varsigma, want_ucb, mean_dev, var_dev, ucb_dev, m_live, defer);
+    return score_leaves_t<double>(xs_dev, xs_dtype, m, varsigma, want_ucb, mean_dev, var_dev, ucb_dev, m_live, defer, prepared);
   }
 
   // after the stream has been synchronised: total leaf-tile kernel time of the call
@@ -1164,8 +1174,20 @@ struct EngineT : Engine {
     // (round 4: the leaves of a one-chunk batch are finalised by the arg-max's first stage, and its second stage writes
     // the winners' records straight into the pinned host memory finish_best reads: two launches and a copy less per call)
     host_direct = ctx->pinned_scratch((size_t)nseg * 4 + 2);
-    launch_seg_argmax(s, as<double>(omean), as<double>(ovar), as<double>(oucb), as<int64_t>(segoff),
-                      nseg, argmax_blocks(m, nseg), best.p, as<double>(ovals), fin.part_var ? &fin : nullptr, host_direct);
+    if (small_calls && fin.part_var != nullptr && m <= kSmallBestMaxRows && nseg <= 64) {
+      // small batch: finalize and both arg-max stages in one launch of one workgroup
+      SmallBest sb{};
+      sb.fin = fin;
+      sb.seg_off = as<int64_t>(segoff);
+      sb.m = m;
+      sb.nseg = nseg;
+      sb.out_vals = as<double>(ovals);
+      sb.host_vals = host_direct;
+      launch_small_best(s, sb, false);
+    } else {
+      launch_seg_argmax(s, as<double>(omean), as<double>(ovar), as<double>(oucb), as<int64_t>(segoff),
+                        nseg, argmax_blocks(m, nseg), best.p, as<double>(ovals), fin.part_var ? &fin : nullptr, host_direct);
+    }
     ctx->last_count[0] = ctx->last_count[1] = m;
     return launch_status();
   }
@@ -1193,6 +1215,48 @@ struct EngineT : Engine {
     if ((rc = ensure(best, (size_t)nseg * kArgmaxBlocks * kArgmaxPartialBytes))) return rc;
     if ((rc = ensure(best_pos, (size_t)nseg * kArgmaxBlocks * 8))) return rc;
     if ((rc = ensure(ovals, (size_t)group_payload_doubles(nseg) * 8))) return rc;
+    // Small calls (the optimiser's exploration levels: a few hundred to a few thousand rows) are launch-bound: boxes by
+    // value, growth + input scaling in one launch, tiles, one-workgroup finalize + arg-max writing pinned host memory --
+    // three launches and no copy operation instead of two copies in, five launches and a copy back
+    if (small_calls && cap > 0 && cap <= kSmallBestMaxRows && nseg <= 64 && (size_t)nseg * d * 2 <= (size_t)kGrowBoxDoubles) {
+      const int64_t cpad = (cap + kLeafPad - 1) / kLeafPad * kLeafPad;
+      const size_t tg = gen_double() ? 8 : 4;
+      if ((rc = ensure(leaves_s, (size_t)cpad * dp * tg))) return rc;
+      if ((rc = ensure(lnorm, (size_t)cpad * tg))) return rc;
+      if (extra_cnt.p == nullptr) {
+        if ((rc = ensure(extra_cnt, 64))) return rc;
+        HIPCHECK(hipMemsetAsync(extra_cnt.p, 0, 64, s));
+      }
+      GrowBoxes gb;
+      std::memcpy(gb.b, bounds, bb);
+      unsigned long long* extra = static_cast<unsigned long long*>(extra_cnt.p);
+      if constexpr (kFloatPredict) {
+        if (!gen_double()) {
+          if ((rc = ensure_generation_inputs())) return rc;
+          launch_grow_unique_prep<float>(s, gb, nseg, d, dp, depth, row_lo, row_hi, ls_dev(), as<float>(leaves_s), as<float>(lnorm), as<int64_t>(grow_key), extra);
+        }
+      }
+      if (gen_double())
+        launch_grow_unique_prep<double>(s, gb, nseg, d, dp, depth, row_lo, row_hi, ls_dev(), as<double>(leaves_s), as<double>(lnorm), as<int64_t>(grow_key), extra);
+      LeafFinalize fin{};
+      if ((rc = score_device_leaves(nullptr, GPSO_F64, cap, varsigma, true, as<double>(omean), as<double>(ovar), as<double>(oucb), nullptr, &fin, true)))
+        return rc;
+      if (fin.part_var == nullptr) return ctx->fail(GPSO_E_STATE, "internal: small growth call was not deferred");
+      host_direct = ctx->pinned_scratch((size_t)nseg * 4 + 2);
+      SmallBest sb{};
+      sb.fin = fin;
+      sb.key = as<int64_t>(grow_key);
+      sb.rows = rows;
+      sb.uniq = uniq;
+      sb.base = (int64_t)nseg * uniq;
+      sb.extra = extra;
+      sb.nseg = nseg;
+      sb.out_vals = as<double>(ovals);
+      sb.host_vals = host_direct;
+      launch_small_best(s, sb, true);
+      ctx->last_count[1] = cap;
+      return launch_status();
+    }
     double* bdev = reinterpret_cast<double*>(static_cast<char*>(leaves_raw.p) + ob);
     double* stage = ctx->pinned_stage((size_t)nseg * d * 2 + 1);
     if (!stage) return ctx->fail(GPSO_E_OOM, "pinned host staging");

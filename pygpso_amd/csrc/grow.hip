@@ -146,6 +146,75 @@ __global__ __launch_bounds__(kGrowThreads) void grow_unique_kernel(const double*
   for (int k = 0; k < d; ++k) o[k] = (lo[k * kGrowThreads + t] + hi[k * kGrowThreads + t]) / 2;
 }
 
+// ---- small calls (round 4): growth AND input scaling in one launch, the boxes passed BY VALUE ---------------------
+// The optimiser's exploration levels score a few hundred to a few thousand rows (gpso/optimisation.py:366-382): the
+// call is launch-bound -- two host-to-device copies (boxes, row count), grow, prep, tiles, two arg-max stages and a
+// copy back were ~100 us for 162 rows at N = 52.  Here the boxes travel as kernel arguments, every thread scales its
+// own row (prep_leaves_kernel's arithmetic, element for element) and stores it where the tile kernel reads; rows that
+// do not repeat their parent bit for bit are appended at base + atomicAdd(extra) -- `extra` is zero between calls (the
+// last kernel of a call resets it).  Rows at or beyond the live count hold whatever the buffer held: the tile kernel
+// computes them, nothing reads them.
+template <typename TG>
+__global__ __launch_bounds__(kGrowThreads) void grow_unique_prep_kernel(GrowBoxes boxes, int d, int dp, int depth,
+                                                                        int64_t rows, int64_t row_lo, int64_t row_hi,
+                                                                        int64_t uniq, int64_t slot_base, int64_t base,
+                                                                        const double* __restrict__ ls,
+                                                                        TG* __restrict__ out_s, TG* __restrict__ norm,
+                                                                        int64_t* __restrict__ key,
+                                                                        unsigned long long* __restrict__ extra) {
+  extern __shared__ double grow_lds[];
+  double* lo = grow_lds;
+  double* hi = grow_lds + (size_t)d * kGrowThreads;
+  const int seg = blockIdx.y, t = threadIdx.x;
+  const int64_t row = row_lo + (int64_t)blockIdx.x * blockDim.x + t;
+  if (row >= row_hi) return;
+  int level;
+  int64_t width, p;
+  grow_locate(row, level, width, p);
+  const double* b = boxes.b + (int64_t)seg * d * 2;
+  for (int k = 0; k < d; ++k) {
+    lo[k * kGrowThreads + t] = b[2 * k];
+    hi[k * kGrowThreads + t] = b[2 * k + 1];
+  }
+  int64_t div = width;
+  for (int s = 0; s + 1 < level; ++s) {
+    div /= 3;
+    grow_split(lo, hi, t, d, (int)((p / div) % 3));
+  }
+  const int child = (level > 0) ? (int)(p % 3) : 0;
+  int64_t slot;
+  if (level == 0) {
+    slot = (int64_t)seg * uniq - slot_base;
+  } else if (child != 1) {
+    grow_split(lo, hi, t, d, child);
+    slot = (int64_t)seg * uniq + (width / 3 + 2 * (p / 3) + (child == 2 ? 1 : 0) - slot_base);
+  } else {
+    int kmax = 0;
+    double wmax = hi[t] - lo[t];
+    for (int k = 1; k < d; ++k) {
+      const double w = hi[k * kGrowThreads + t] - lo[k * kGrowThreads + t];
+      if (w > wmax) {
+        wmax = w;
+        kmax = k;
+      }
+    }
+    const double parent_c = (lo[kmax * kGrowThreads + t] + hi[kmax * kGrowThreads + t]) / 2;
+    grow_split(lo, hi, t, d, 1);
+    const double child_c = (lo[kmax * kGrowThreads + t] + hi[kmax * kGrowThreads + t]) / 2;
+    if (__builtin_bit_cast(long long, parent_c) == __builtin_bit_cast(long long, child_c)) return;
+    slot = base + (int64_t)atomicAdd(extra, 1ull);
+  }
+  key[slot] = (int64_t)seg * rows + row;
+  TG acc = 0;
+  for (int k = 0; k < dp; ++k) {
+    TG v = 0;
+    if (k < d) v = (TG)(((lo[k * kGrowThreads + t] + hi[k * kGrowThreads + t]) / 2) / ls[k]);
+    out_s[slot * dp + k] = v;
+    acc += v * v;
+  }
+  norm[slot] = acc;
+}
+
 static int64_t grow_rows_of(int depth) {
   int64_t rows = 0, w = 1;
   for (int j = 0; j < depth; ++j) {
@@ -193,5 +262,21 @@ void launch_grow_unique(hipStream_t st, const double* bounds_dev, int nseg, int 
                      bounds_dev, d, depth, rows, row_lo, row_hi, uniq, slot_base, out_dev, key_dev,
                      reinterpret_cast<unsigned long long*>(count_dev));
 }
+
+template <typename TG>
+void launch_grow_unique_prep(hipStream_t st, const GrowBoxes& boxes, int nseg, int d, int dp, int depth, int64_t row_lo,
+                             int64_t row_hi, const double* ls_dev, TG* leaves_s, TG* lnorm, int64_t* key_dev,
+                             unsigned long long* extra_dev) {
+  const int64_t rows = grow_rows_of(depth);
+  if (row_hi <= row_lo || nseg == 0) return;
+  const int64_t slot_base = grow_unique_before(row_lo);
+  const int64_t uniq = grow_unique_before(row_hi) - slot_base;
+  const dim3 grid((unsigned)((row_hi - row_lo + kGrowThreads - 1) / kGrowThreads), (unsigned)nseg);
+  hipLaunchKernelGGL((grow_unique_prep_kernel<TG>), grid, dim3(kGrowThreads), (size_t)2 * d * kGrowThreads * 8, st, boxes,
+                     d, dp, depth, rows, row_lo, row_hi, uniq, slot_base, (int64_t)nseg * uniq, ls_dev, leaves_s, lnorm,
+                     key_dev, extra_dev);
+}
+template void launch_grow_unique_prep<float>(hipStream_t, const GrowBoxes&, int, int, int, int, int64_t, int64_t, const double*, float*, float*, int64_t*, unsigned long long*);
+template void launch_grow_unique_prep<double>(hipStream_t, const GrowBoxes&, int, int, int, int, int64_t, int64_t, const double*, double*, double*, int64_t*, unsigned long long*);
 
 }  // namespace gpso

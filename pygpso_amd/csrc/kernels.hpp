@@ -239,6 +239,32 @@ int64_t grow_unique_rows(int depth);
 int64_t grow_unique_before(int64_t row);
 void launch_grow_unique(hipStream_t st, const double* bounds_dev, int nseg, int d, int depth, int64_t row_lo,
                         int64_t row_hi, double* out_dev, int64_t* key_dev, int64_t* count_dev);
+// Small calls (round 4, launch-bound: the optimiser's exploration levels): growth and input scaling in ONE launch with
+// the boxes passed by value -- rows land scaled (x / l in TG, norms) where the tile kernel reads them, keys as above; a
+// row that does not repeat its parent goes to nseg * uniq + atomicAdd(extra); *extra_dev is zero between calls
+constexpr int kGrowBoxDoubles = 96;  // nseg * d * 2 doubles of boxes fit the kernel-argument struct
+struct GrowBoxes {
+  double b[kGrowBoxDoubles];
+};
+template <typename TG>
+void launch_grow_unique_prep(hipStream_t st, const GrowBoxes& boxes, int nseg, int d, int dp, int depth, int64_t row_lo,
+                             int64_t row_hi, const double* ls_dev, TG* leaves_s, TG* lnorm, int64_t* key_dev,
+                             unsigned long long* extra_dev);
+// ... and the whole arg-max of a small batch in ONE launch of one workgroup: finalises every live leaf (LeafFinalize),
+// reduces per segment with np.argmax's rule, writes the records (device and pinned host) and resets *extra_dev
+struct SmallBest {
+  LeafFinalize fin;
+  const int64_t* key = nullptr;       // keyed (grown) batches: reference keys, rows per box, analytic slots per box
+  int64_t rows = 0, uniq = 0, base = 0;
+  unsigned long long* extra = nullptr;
+  const int64_t* seg_off = nullptr;   // plain batches: segment offsets (device), total leaves m
+  int64_t m = 0;
+  int nseg = 0;
+  double* out_vals = nullptr;         // [nseg * 4 + 2]
+  double* host_vals = nullptr;        // nullable pinned host copy
+};
+constexpr int64_t kSmallBestMaxRows = 16384;
+void launch_small_best(hipStream_t st, const SmallBest& a, bool keyed);
 // winners of several ranks -> the global winner per segment, np.argmax order on (ucb, global index):
 // gathered[world][stride], a rank's payload = nseg x (mean, var, ucb, bit-cast index) [, spare, status: stride ==
 // kGroupPayload(nseg)]; base[world][nseg] (nullable) is added to a rank's indices first; out[nseg][4] [, bit-cast rank

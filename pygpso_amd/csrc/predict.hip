@@ -1457,6 +1457,96 @@ __global__ __launch_bounds__(256) void keyed_argmax_stage2(const Best* __restric
   }
 }
 
+// Small batches (round 4): finalize + both arg-max stages in ONE launch of one workgroup.  Every live leaf is finalised
+// exactly once (finalize_leaf), every segment reduced with np.argmax's rule on (ucb, index / reference key): the same
+// records seg_argmax_* / keyed_argmax_* produce, with two launches (and the copy back) less.
+template <bool KEYED>
+__global__ __launch_bounds__(256) void small_best_kernel(SmallBest a) {
+  __shared__ Best sh[4];
+  __shared__ int64_t shp[4];
+  const int tid = threadIdx.x;
+  const int64_t live = KEYED ? a.base + (int64_t)*a.extra : a.m;
+  for (int seg = 0; seg < a.nseg; ++seg) {
+    Best mine{0.0, -1};
+    int64_t mypos = -1;
+    if constexpr (KEYED) {
+      for (int64_t j = (int64_t)seg * a.uniq + tid; j < (int64_t)(seg + 1) * a.uniq; j += 256) {
+        Best c{finalize_leaf(a.fin, j), a.key[j]};
+        if (better(c, mine)) {
+          mine = c;
+          mypos = j;
+        }
+      }
+      for (int64_t j = (int64_t)a.nseg * a.uniq + tid; j < live; j += 256) {
+        const int64_t kj = a.key[j];
+        if (kj / a.rows != seg) continue;
+        Best c{finalize_leaf(a.fin, j), kj};
+        if (better(c, mine)) {
+          mine = c;
+          mypos = j;
+        }
+      }
+    } else {
+      for (int64_t j = a.seg_off[seg] + tid; j < a.seg_off[seg + 1]; j += 256) {
+        Best c{finalize_leaf(a.fin, j), j};
+        if (better(c, mine)) {
+          mine = c;
+          mypos = j;
+        }
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      Best o;
+      o.u = __shfl_xor(mine.u, off);
+      o.i = __shfl_xor(mine.i, off);
+      const int64_t op = __shfl_xor(mypos, off);
+      if (better(o, mine)) {
+        mine = o;
+        mypos = op;
+      }
+    }
+    if ((tid & 63) == 0) {
+      sh[tid >> 6] = mine;
+      shp[tid >> 6] = mypos;
+    }
+    __syncthreads();  // (also: the means / variances stored above are visible to thread 0 below)
+    if (tid == 0) {
+      for (int w = 1; w < 4; ++w)
+        if (better(sh[w], mine)) {
+          mine = sh[w];
+          mypos = shp[w];
+        }
+      double* o = a.out_vals + seg * 4;
+      if (mine.i < 0) {
+        o[0] = o[1] = o[2] = __builtin_nan("");
+        o[3] = __builtin_bit_cast(double, (int64_t)-1);
+      } else {
+        o[0] = a.fin.mean[mypos];
+        o[1] = a.fin.var[mypos];
+        o[2] = a.fin.ucb[mypos];
+        o[3] = __builtin_bit_cast(double, KEYED ? (int64_t)(mine.i - (int64_t)seg * a.rows) : (int64_t)(mine.i - a.seg_off[seg]));
+      }
+      if (a.host_vals != nullptr)
+        for (int k = 0; k < 4; ++k) a.host_vals[seg * 4 + k] = o[k];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    a.out_vals[a.nseg * 4] = __builtin_bit_cast(double, live);
+    a.out_vals[a.nseg * 4 + 1] = 0.0;  // status slot of a group payload: this rank's half succeeded
+    if (a.host_vals != nullptr) {
+      a.host_vals[a.nseg * 4] = __builtin_bit_cast(double, live);
+      a.host_vals[a.nseg * 4 + 1] = 0.0;
+    }
+    if (KEYED) *a.extra = 0ull;  // (zero between calls: the next growth appends from its own base)
+  }
+}
+
+void launch_small_best(hipStream_t st, const SmallBest& a, bool keyed) {
+  if (keyed) hipLaunchKernelGGL(small_best_kernel<true>, dim3(1), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(small_best_kernel<false>, dim3(1), dim3(256), 0, st, a);
+}
+
 // multi-GPU: one thread per segment folds the ranks' winners in rank order with the same rule.  A rank's payload is
 // `stride` doubles: nseg x (mean, var, ucb, bit-cast index), then -- stride == nseg * 4 + 2 -- a spare slot and the
 // rank's STATUS of the call (0 or a negative GPSO_E_* code): the fold also takes the worst status over the ranks

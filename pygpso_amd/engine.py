@@ -113,6 +113,10 @@ class HipGPEngine:
         """GPSO_OPT_SPLIT_KERNEL: "auto" (the fused step) | "two-phase" (round 3's step): same bits, different speed."""
         self._check(self._lib.gpso_set_option(self._h, L.OPT_SPLIT_KERNEL, {"auto": 0, "two-phase": 1}[which]))
 
+    def set_small_calls(self, on):
+        """GPSO_OPT_SMALL_CALLS: the short launch sequence for best-UCB calls on small batches (default on; same bits)."""
+        self._check(self._lib.gpso_set_option(self._h, L.OPT_SMALL_CALLS, 1 if on else 0))
+
     def set_precision_check(self, on):
         self._check(self._lib.gpso_set_option(self._h, L.OPT_PRECISION_CHECK, 1 if on else 0))
 

@@ -900,3 +900,46 @@ def test_fused_step_kernel_gives_the_bits_of_the_two_phase_kernel(dtype, math, g
     post = gpr.posterior(th, X, y)
     mean_ref, var_ref = gpr.predict_y(post, Xs)
     assert np.max(np.abs(a[0] - mean_ref)) <= 2e-3 * max(1.0, np.max(np.abs(y))) and np.max(np.abs(a[1] - var_ref)) <= 2e-4 * th.variance
+
+
+@pytest.mark.parametrize("dtype", ["float64", "mixed", "float32"])
+@pytest.mark.parametrize("n,d,depth", [(52, 2, 5), (30, 4, 7), (100, 6, 9), (128, 3, 8), (300, 5, 6), (7, 1, 9)])
+def test_small_call_sequence_gives_the_bits_of_the_general_one(dtype, n, d, depth):
+    """Round 4: best-UCB calls on small batches run growth + input scaling in ONE launch (boxes by value), the tile
+    kernel, and finalize + arg-max in one workgroup that writes pinned host memory (GPSO_OPT_SMALL_CALLS, default on).
+    Same winners, values, indices and row counts as the general sequence: unit-cube boxes (a third of the rows dropped),
+    arbitrary boxes (near-duplicates appended through the counter, twice in a row: it must be back at zero), plain
+    batches from the host with ragged and empty segments, and the sharded halves."""
+    from pygpso_amd import HipGPEngine
+
+    X, y, th = _problem(n, d, noise=1e-3 if dtype != "float64" else 1e-6, variance=1.3)
+    rng = np.random.default_rng(depth)
+    kids = tree.split_bounds([(0.0, 1.0)] * d)
+    lo = rng.random((2, d)) * 0.5
+    arbitrary = np.stack([lo, lo + 0.1 + 0.4 * rng.random((2, d))], axis=2)
+    res = {}
+    for small in (True, False):
+        eng = HipGPEngine(dtype)
+        eng.set_small_calls(small)
+        _fit(eng, X, y, th, grad=False)
+        out = []
+        for boxes in (np.array([kids[0], kids[2]]), arbitrary, arbitrary, np.array([kids[1]])):
+            out.append(eng.best_ucb_grow(boxes, depth, VS) + (eng.last_count(0), eng.last_count(1)))
+        Xs = synthetic_leaves(700, d, seed=depth)
+        out.append(eng.best_ucb(Xs, VS, np.array([0, 0, 1, 350, 699, 700], dtype=np.int64)))
+        out.append(eng.best_ucb(Xs[:1], VS))
+        out.append(tuple(eng.shard_winners_grow(r, 3, arbitrary, depth, VS) for r in range(3)))
+        res[small] = out
+    for a, b in zip(res[True], res[False]):
+        for p, q in zip(a, b):
+            assert np.array_equal(np.asarray(p), np.asarray(q), equal_nan=True)
+    # and against the full duplicated list scored by predict + numpy (the reference's gp_eval_best_ucb)
+    eng = HipGPEngine(dtype)
+    _fit(eng, X, y, th, grad=False)
+    full = eng.grow(arbitrary, depth)
+    for sgm in range(2):
+        mean, var = eng.predict(full[sgm])
+        ucb = mean + VS * var
+        i = int(np.argmax(ucb))
+        got = res[True][1]
+        assert int(got[0][sgm]) == i and got[3][sgm] == ucb[i] and got[1][sgm] == mean[i] and got[2][sgm] == var[i]
