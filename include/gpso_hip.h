@@ -99,11 +99,14 @@ typedef struct gpso_ctx gpso_ctx;
 #define GPSO_SPLIT_KERNEL_AUTO 0   /*   FUSED step of round 4 (every wave applies step q with the generation of step q+1  */
 #define GPSO_SPLIT_KERNEL_TWO_PHASE 1 /* dealt into its MFMA shadows), 1 round 3's two-phase step.  Both give the SAME    */
                                    /*   BITS (tests/test_gpu_parity.py); the option exists for that comparison            */
-#define GPSO_OPT_SMALL_CALLS 9     /* 1 (default): best-UCB calls on small batches (<= 16384 rows, <= 64 segments) run   */
-                                   /* a short launch sequence -- growth + input scaling in one launch with the boxes by   */
-                                   /* value, the tile kernel, finalize + arg-max in one workgroup writing pinned host      */
-                                   /* memory: 3 launches, no copy operation -- instead of the general one (2 copies in, 5  */
-                                   /* launches, a copy back); 0: always the general sequence.  Same bits (tested)         */
+#define GPSO_OPT_SMALL_CALLS 9     /* best-UCB calls on small batches (<= 16384 rows) are launch-bound.  1 (default): a   */
+                                   /* short sequence -- THREE launches (growth + input scaling with the boxes by value,    */
+                                   /* tiles, one-workgroup finalize + arg-max writing pinned host memory), or ONE where   */
+                                   /* that measures faster (native tile kernel, N_pad = 256: rows made in the kernel's     */
+                                   /* prologue, leaves finalised and reduced in its epilogue, the last workgroup to arrive */
+                                   /* writes the records); no copy operation either way.  2: three launches only; 3: one   */
+                                   /* launch wherever it applies (N_pad = 128 too); 0: always the general sequence (2      */
+                                   /* copies in, 5 launches, a copy back).  Same bits in all (tests/test_gpu_parity.py)    */
 /* floating-point options (gpso_set_option_f64): tolerances of the self-test */
 #define GPSO_OPTF_TOL_VAR 100  /* max |d var| at the training inputs, relative to the kernel variance (default 1e-4; GPSO_F32: 1e-3) */
 #define GPSO_OPTF_TOL_MEAN 101 /* max |d mean| at the training inputs, relative to max |y - c|   (default 1e-4; GPSO_F32: 1e-3) */

@@ -286,7 +286,8 @@ struct EngineT : Engine {
   bool gen_decided = false;     // AUTO: has the self-test ruled on this posterior?
   bool gen32_inputs_ok = false; // xs32 / xnorm32 / xs_p32 match the resident posterior
   int split_variant = GPSO_SPLIT_KERNEL_AUTO;  // GPSO_OPT_SPLIT_KERNEL
-  bool small_calls = true;                     // GPSO_OPT_SMALL_CALLS
+  bool small_calls = true, one_launch = true, one_launch_everywhere = false;  // GPSO_OPT_SMALL_CALLS
+  bool one_refused = false;                    // the one-launch kernel asked for the general sequence (this call only)
   int64_t single_level_max = -1;  // < 0: library default
   bool fused_small = true;        // GPSO_OPT_FIT_FUSED_SMALL
   int small_tile_rows = 8;        // tile rows of the 128-padded linv_p that may be non-zero (8: all / unknown)
@@ -308,7 +309,7 @@ struct EngineT : Engine {
                       &work, &kinvb, &linv_p, &white, &alpha_f, &alpha, &logdet, &scal, &gpart, &apart,
                       &kinv_diag, &getter_tmp, &leaves_raw, &leaves_s, &lnorm, &pvar, &pmean, &omean, &ovar,
                       &oucb, &segoff, &best, &oidx, &ovals, &linv_b, &st_mean, &st_var, &st_out, &grow_key, &live_cnt,
-                      &best_pos, &gath, &wbase, &ovals2, &bhdr, &pl_L, &pl_X, &pl_XT, &pl_WT, &amax_rows, &arena, &hash_out, &extra_cnt})
+                      &best_pos, &gath, &wbase, &ovals2, &bhdr, &pl_L, &pl_X, &pl_XT, &pl_WT, &amax_rows, &arena, &hash_out, &extra_cnt, &one_ctl, &one_partial, &one_ppos})
       if (b->p && !b->view) (void)hipFree(b->p);
   }
 
@@ -392,8 +393,10 @@ struct EngineT : Engine {
         fused_small = value != 0;
         return GPSO_OK;
       case GPSO_OPT_SMALL_CALLS:
-        if (value != 0 && value != 1) return ctx->fail(GPSO_E_ARG, "small calls must be 0 or 1");
+        if (value < 0 || value > 3) return ctx->fail(GPSO_E_ARG, "small calls must be 0 .. 3");
         small_calls = value != 0;
+        one_launch = value == 1 || value == 3;
+        one_launch_everywhere = value == 3;
         return GPSO_OK;
       case GPSO_OPT_SPLIT_KERNEL:
         if (value != GPSO_SPLIT_KERNEL_AUTO && value != GPSO_SPLIT_KERNEL_TWO_PHASE) return ctx->fail(GPSO_E_ARG, "unknown split kernel %d", value);
@@ -1140,6 +1143,91 @@ struct EngineT : Engine {
 
   // ---- best-UCB sequencing: enqueue the local work (winners stay on the device, no host wait) ->
   //      [multi-GPU: all-gather + fold] -> one read-back ------------------------------------------------
+  // ---- one-launch small calls (predict.hip: leaf_tiles_v2_one_kernel) -------------------------------------------------
+  // Applies when the native tile kernel runs this posterior with ONE row block (N_pad = 128 or 256) and the batch is
+  // small.  Returns 0 when the call was enqueued (records on their way to ovals and pinned host memory), 2 when it does
+  // not apply -- the caller goes on with the next-best sequence --, or a negative status.
+  DevBuf one_ctl, one_partial, one_ppos;
+  bool one_pending = false;  // the call in flight is a one-launch call: finish_best looks at its fallback verdict
+  template <typename TG>
+  int try_one_launch_t(OneLaunch& one, int64_t total, int nseg, double varsigma) {
+    const int64_t cpad = (total + kLeafPad - 1) / kLeafPad * kLeafPad;
+    int rc;
+    if ((rc = ensure(leaves_s, (size_t)cpad * dp * sizeof(TG)))) return rc;
+    if ((rc = ensure(lnorm, (size_t)cpad * sizeof(TG)))) return rc;
+    if ((rc = ensure(pvar, (size_t)cpad * 8))) return rc;
+    if ((rc = ensure(pmean, (size_t)cpad * 8))) return rc;
+    if ((rc = ensure(grow_key, (size_t)cpad * 8))) return rc;
+    const size_t wgs = (size_t)(cpad / 64);  // (at most: 64 leaves per workgroup is the smallest tile)
+    if ((rc = ensure(one_partial, wgs * nseg * kArgmaxPartialBytes))) return rc;
+    if ((rc = ensure(one_ppos, wgs * nseg * 8))) return rc;
+    if (one_ctl.p == nullptr) {
+      if ((rc = ensure(one_ctl, 64))) return rc;
+      HIPCHECK(hipMemsetAsync(one_ctl.p, 0, 64, st()));
+    }
+    one.total = total;
+    one.nseg = nseg;
+    one.d = d;
+    one.ls = ls_dev();
+    one.leaves_s = leaves_s.p;
+    one.lnorm = lnorm.p;
+    one.key = as<int64_t>(grow_key);
+    one.fin = LeafFinalize{as<double>(pvar), as<double>(pmean), 1, cpad, kp.variance, kp.noise, kp.mean_c, varsigma,
+                           as<double>(omean), as<double>(ovar), as<double>(oucb)};
+    one.partial = one_partial.p;
+    one.ppos = as<int64_t>(one_ppos);
+    one.ticket = static_cast<unsigned*>(one_ctl.p);
+    one.fallback = static_cast<unsigned*>(one_ctl.p) + 1;
+    one.out_vals = as<double>(ovals);
+    one.host_vals = host_direct = ctx->pinned_scratch((size_t)nseg * 4 + 2);
+    const TG* xsp;
+    const TG* xnr;
+    if constexpr (sizeof(TG) == 8) {
+      xsp = as<double>(xs_p64);
+      xnr = as<double>(xnorm64);
+    } else {
+      xsp = as<float>(xs_p32);
+      xnr = as<float>(xnorm32);
+    }
+    ctx->tile_pairs = 0;
+    while ((int)ctx->tile_ev.size() < 2) {
+      hipEvent_t e;
+      HIPCHECK(hipEventCreate(&e));
+      ctx->tile_ev.push_back(e);
+    }
+    if (ctx->timing) HIPCHECK(hipEventRecord(ctx->tile_ev[0], st()));
+    rc = launch_leaf_tiles_one<TP, TG>(st(), as<TP>(linv_p), xsp, xnr, as<TP>(alpha), as<double>(pvar), as<double>(pmean),
+                                      npad, dp / 4, cpad, kp, one);
+    if (rc == 2) {
+      host_direct = nullptr;
+      return 2;
+    }
+    if (rc) return launch_status();
+    if (ctx->timing) HIPCHECK(hipEventRecord(ctx->tile_ev[1], st()));
+    ctx->tile_pairs = ctx->timing ? 1 : 0;
+    one_pending = true;
+    return launch_status();
+  }
+  int try_one_launch(OneLaunch& one, int64_t total, int nseg, double varsigma) {
+    if (!small_calls || !one_launch || total <= 0 || total > kSmallBestMaxRows || nseg > 16) return 2;
+    if (npad != 128 && npad != 256) return 2;
+    // measured (tools/micro/one_dbg.py, float64, same box; wall us per best_ucb_grow call, one | three launches):
+    // N = 52 / 162 rows 56.3 | 54.1, N = 100 / 1458 rows 61.0 | 59.8, N = 128 / 13122 rows 91.5 | 88.6, N = 256 / 4374 rows
+    // 78.4 | 85.7 -- the two agent-scope fences of the last-arriver fold cost what the two launch boundaries they replace
+    // cost; the single launch only pays at N_pad = 256
+    if (npad == 128 && !one_launch_everywhere) return 2;
+    if (math_in_use() != GPSO_MATH_NATIVE || !linv_p_valid) return 2;
+    if (leaf_tiles_nbi<TP>(npad, dp / 4) != 1) return 2;
+    if constexpr (kFloatPredict) {
+      if (!gen_double()) {
+        int rc = ensure_generation_inputs();
+        if (rc) return rc;
+        return try_one_launch_t<float>(one, total, nseg, varsigma);
+      }
+    }
+    return try_one_launch_t<double>(one, total, nseg, varsigma);
+  }
+
   // per segment (mean, var, ucb, bit-cast index relative to the segment start) -> ovals; seg_off: host,
   // nseg + 1 entries over [0, m]
   int enqueue_best_leaves(const void* dev, int xs_dtype, int64_t m, const int64_t* seg_off, int nseg,
@@ -1167,6 +1255,17 @@ struct EngineT : Engine {
       HIPCHECK(hipMemcpyAsync(segoff.p, so.data(), (size_t)(nseg + 1) * 8, hipMemcpyHostToDevice, s));
       HIPCHECK(hipStreamSynchronize(s));
       segoff_cache = so;
+    }
+    if (m > 0) {  // one launch for the whole call where it applies
+      OneLaunch one{};
+      one.mode = 2;
+      one.raw = dev;
+      one.raw_f64 = xs_dtype == GPSO_F64 ? 1 : 0;
+      one.seg_off = as<int64_t>(segoff);
+      if ((rc = try_one_launch(one, m, nseg, varsigma)) != 2) {
+        ctx->last_count[0] = ctx->last_count[1] = m;
+        return rc;
+      }
     }
     LeafFinalize fin{};
     if (m > 0)
@@ -1219,6 +1318,18 @@ struct EngineT : Engine {
     // value, growth + input scaling in one launch, tiles, one-workgroup finalize + arg-max writing pinned host memory --
     // three launches and no copy operation instead of two copies in, five launches and a copy back
     if (small_calls && cap > 0 && cap <= kSmallBestMaxRows && nseg <= 64 && (size_t)nseg * d * 2 <= (size_t)kGrowBoxDoubles) {
+      if (row_lo == 0 && row_hi == rows && !one_refused) {  // one launch for the whole call where it applies
+        OneLaunch one{};
+        one.mode = 1;
+        std::memcpy(one.boxes.b, bounds, bb);
+        one.depth = depth;
+        one.rows = rows;
+        one.uniq = uniq;
+        if ((rc = try_one_launch(one, (int64_t)nseg * uniq, nseg, varsigma)) != 2) {
+          ctx->last_count[1] = cap;
+          return rc;
+        }
+      }
       const int64_t cpad = (cap + kLeafPad - 1) / kLeafPad * kLeafPad;
       const size_t tg = gen_double() ? 8 : 4;
       if ((rc = ensure(leaves_s, (size_t)cpad * dp * tg))) return rc;
@@ -1353,7 +1464,10 @@ struct EngineT : Engine {
     if (rc) return rc;
     int64_t lo, hi;
     shard_range(gpso_grow_rows(depth), rank, world, &lo, &hi);
-    return enqueue_best_grow(bounds, nseg, depth, lo, hi, varsigma);
+    one_refused = true;  // (a group payload has no way to ask for a re-run: the sequences with the append counter)
+    rc = enqueue_best_grow(bounds, nseg, depth, lo, hi, varsigma);
+    one_refused = false;
+    return rc;
   }
   // after the local half: on failure replace whatever it left in ovals by "no winner" rows and the status
   // (on success the arg-max kernels have written the status slot themselves: no host step on the fast path)
@@ -1393,7 +1507,9 @@ struct EngineT : Engine {
   int finish_best(const DevBuf& src, int nseg, int mode, int64_t* idx, double* mean, double* var, double* ucb,
                   int* verdict_out = nullptr, int64_t* who = nullptr) {
     hipStream_t s = st();
-    const size_t doubles = (size_t)nseg * 4 + (mode == 2 ? 2 : mode);
+    const bool one = one_pending;
+    one_pending = false;
+    const size_t doubles = (size_t)nseg * 4 + ((mode == 2 || one) ? 2 : mode);
     double* vals = ctx->pinned_scratch(doubles);
     if (!vals) return ctx->fail(GPSO_E_OOM, "pinned host scratch");
     // (mode 0 / 1: the arg-max's second stage has written the records into this very memory: no copy operation)
@@ -1407,6 +1523,7 @@ struct EngineT : Engine {
     collect_tile_ms();
     float ms = 0;
     if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ms[1] = ms;
+    if (one && vals[4 * nseg + 1] != 0.0) return 1;  // (a centre child does not repeat its parent: the caller re-runs)
     if (mode == 2) {
       const int verdict = (int)vals[4 * nseg + 1];
       if (verdict_out) *verdict_out = verdict;
@@ -1528,7 +1645,15 @@ struct EngineT : Engine {
     if (rc) return rc;
     if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[2], st()));
     if ((rc = enqueue_best_grow(bounds, nseg, depth, 0, gpso_grow_rows(depth), varsigma))) return rc;
-    return finish_best(ovals, nseg, 1, idx, mean, var, ucb);
+    rc = finish_best(ovals, nseg, 1, idx, mean, var, ucb);
+    if (rc == 1) {  // the one-launch kernel met a near-duplicate it has no slot for: the sequence with the append counter
+      one_refused = true;
+      rc = enqueue_best_grow(bounds, nseg, depth, 0, gpso_grow_rows(depth), varsigma);
+      one_refused = false;
+      if (rc) return rc;
+      rc = finish_best(ovals, nseg, 1, idx, mean, var, ucb);
+    }
+    return rc;
   }
 
   // The same on a group: every rank generates and scores the reference rows shard_range(rows, rank, world)

@@ -11,45 +11,13 @@
 // This translation unit MUST be compiled with -ffp-contract=off (see Makefile): a fused
 // multiply-add in `lo + i * delta` would change the last bit and with it arg-max ties downstream.
 #include "common.hpp"
+#include "grow_device.hpp"
 #include "kernels.hpp"
 
 namespace gpso {
 
 // Per-thread box state lives in LDS as [dimension][thread] (conflict-free, no scratch: a per-thread
-// double lo[64], hi[64] array spills): one wave per block, 2 * d * 64 doubles of dynamic LDS.
-constexpr int kGrowThreads = 64;
-
-// level j and position p of a row: rows of level j start at (3^j - 1) / 2
-__device__ __forceinline__ void grow_locate(int64_t row, int& level, int64_t& width, int64_t& p) {
-  level = 0;
-  int64_t start = 0;
-  width = 1;  // 3^level
-  while (start + width <= row) {
-    start += width;
-    width *= 3;
-    ++level;
-  }
-  p = row - start;
-}
-
-// one ternary split of the box held in (lo, hi)[k * kGrowThreads + t]: child 0 = l, 1 = c, 2 = r
-__device__ __forceinline__ void grow_split(double* lo, double* hi, int t, int d, int child) {
-  int kmax = 0;
-  double wmax = hi[t] - lo[t];
-  for (int k = 1; k < d; ++k) {
-    const double w = hi[k * kGrowThreads + t] - lo[k * kGrowThreads + t];
-    if (w > wmax) {  // first maximum wins, as np.argmax
-      wmax = w;
-      kmax = k;
-    }
-  }
-  const double delta = wmax / 3;
-  const double base = lo[kmax * kGrowThreads + t];
-  const double c0 = base + (double)child * delta;
-  const double c1 = base + (double)(child + 1) * delta;
-  lo[kmax * kGrowThreads + t] = c0;
-  hi[kmax * kGrowThreads + t] = c1;
-}
+// double lo[64], hi[64] array spills): one wave per block, 2 * d * 64 doubles of dynamic LDS (grow_device.hpp).
 
 __global__ __launch_bounds__(kGrowThreads) void grow_kernel(const double* __restrict__ bounds, int d,
                                                             int depth, int64_t rows,

@@ -263,6 +263,33 @@ struct SmallBest {
   double* out_vals = nullptr;         // [nseg * 4 + 2]
   double* host_vals = nullptr;        // nullable pinned host copy
 };
+// ... and, where ONE row block covers L^-1 (N_pad = 128 or 256) and the native tile kernel runs, the whole call in ONE
+// launch (predict.hip: leaf_tiles_v2_one_kernel): rows made in the prologue, leaves finalised and reduced in the epilogue,
+// the last workgroup to arrive writes the records
+struct OneLaunch {
+  int mode = 0;  // 1: rows grown from `boxes` (all reference rows of every box), 2: raw rows at `raw`
+  GrowBoxes boxes;
+  int nseg = 0, d = 0, depth = 0, raw_f64 = 0;
+  int64_t rows = 0, uniq = 0;  // grown: reference rows and analytic slots per box
+  int64_t total = 0;           // live rows: nseg * uniq (grown) or m (raw)
+  const void* raw = nullptr;
+  const int64_t* seg_off = nullptr;  // raw: segment offsets (device)
+  const double* ls = nullptr;        // lengthscale per dimension (device)
+  void* leaves_s = nullptr;          // [mpad * dp] TG: the scaled rows (written by the prologue, read by the tile code)
+  void* lnorm = nullptr;             // [mpad] TG
+  int64_t* key = nullptr;            // [mpad]: reference keys of grown rows
+  LeafFinalize fin;
+  void* partial = nullptr;           // [grid * nseg] winners per workgroup (ucb, id)
+  int64_t* ppos = nullptr;           // [grid * nseg] their rows
+  unsigned* ticket = nullptr;        // arrival counter, zero between calls
+  unsigned* fallback = nullptr;      // raised when a centre child does not repeat its parent; zero between calls
+  double* out_vals = nullptr;        // [nseg * 4 + 2]: records, live rows (bit-cast), status (1.0 = fallback wanted)
+  double* host_vals = nullptr;       // nullable pinned host copy
+};
+template <typename T, typename TG>
+int launch_leaf_tiles_one(hipStream_t st, const T* linv_p, const TG* xs_p, const TG* xnorm, const T* alpha,
+                          double* part_var, double* part_mean, int64_t npad, int dp4, int64_t mpad, const KernParams& kp,
+                          const OneLaunch& one);
 constexpr int64_t kSmallBestMaxRows = 16384;
 void launch_small_best(hipStream_t st, const SmallBest& a, bool keyed);
 // winners of several ranks -> the global winner per segment, np.argmax order on (ucb, global index):

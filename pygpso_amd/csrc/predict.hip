@@ -18,9 +18,45 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "grow_device.hpp"
 #include "kernels.hpp"
 
 namespace gpso {
+
+
+// np.argmax semantics: first maximum wins; NaN counts as the maximum (first NaN wins)
+struct Best {
+  double u;
+  int64_t i;
+};
+__device__ __forceinline__ bool better(const Best& a, const Best& b) {
+  if (a.i < 0) return false;
+  if (b.i < 0) return true;
+  const bool an = a.u != a.u, bn = b.u != b.u;
+  if (an != bn) return an;
+  if (!an && a.u != b.u) return a.u > b.u;
+  return a.i < b.i;
+}
+
+// one leaf: sum the row blocks' partials, form mean / var (+ noise) / ucb, store them; returns ucb
+__device__ __forceinline__ double finalize_leaf(const LeafFinalize& f, int64_t j) {
+  double v = 0, mu = 0;
+  for (int b = 0; b < f.nbi; ++b) {
+    v += f.part_var[(int64_t)b * f.mpad + j];
+    mu += f.part_mean[(int64_t)b * f.mpad + j];
+  }
+  // [gpflow base_conditional] fvar = k** - sum A^2 ; predict_y adds the noise variance
+  const double vy = __dadd_rn(__dsub_rn(f.variance, v), f.noise);
+  const double my = __dadd_rn(mu, f.mean_c);
+  f.mean[j] = my;
+  f.var[j] = vy;
+  // gpso/gp_surrogate.py:326  ucb = mean + varsigma * var  (two roundings, as numpy does)
+  double prod = f.varsigma * vy;
+  asm volatile("" : "+v"(prod));  // keep the product rounded on its own: no fma contraction
+  const double u = my + prod;
+  f.ucb[j] = u;
+  return u;
+}
 
 
 // ---------------------------------------------------------------------------------------------
@@ -232,12 +268,218 @@ inline size_t leaf_v2_lds_bytes(int rt, int dp4) {
 // m_live (nullable): device count of live leaves; workgroups whose first leaf is at or beyond it
 // exit at once (on-device growth sizes its launch for the worst case, see grow.hip).
 // =============================================================================================
-template <typename T, typename TG, int BM, int CT, int KERNEL>
-__global__ __launch_bounds__(256, 2) void leaf_tiles_v2_kernel(
+// ---- ONE-LAUNCH small calls (round 4) ---------------------------------------------------------------------------------
+// When a single row block covers all of L^-1 (N_pad = BM: the optimiser's regime, N <= 128 -- and N <= 256), a workgroup's
+// leaves are finished inside the workgroup.  leaf_tiles_v2_one_kernel then is the whole best-UCB call: its prologue makes
+// the workgroup's rows (replays the ternary geometry for its compact slots -- the inverse of grow_unique_kernel's
+// row -> slot map -- or takes raw rows, and scales them: prep_leaves_kernel's arithmetic), the tile code runs unchanged,
+// the epilogue finalises the leaves (finalize_leaf), reduces them per segment with np.argmax's rule, and the LAST
+// workgroup to arrive (one ticket counter, agent-scope fences around it) folds the workgroups' winners and writes the
+// records to device and pinned host memory.  A centre child that does NOT repeat its parent bit for bit (never for boxes
+// cut from the unit cube) cannot get a closed-form slot: the kernel raises `fallback` and the host runs the general
+// sequence.  Same arithmetic per leaf as the multi-launch sequences: the SAME BITS (tests/test_gpu_parity.py).
+template <typename TG, int LW>
+__device__ __forceinline__ void one_launch_prologue(const OneLaunch& o, int dp, unsigned char* lds, int tid) {
+  const int64_t slot = (int64_t)blockIdx.x * LW + tid;
+  TG* out_s = static_cast<TG*>(o.leaves_s);
+  TG* norm = static_cast<TG*>(o.lnorm);
+  if (tid >= LW) return;
+  const int d = o.d;
+  if (slot >= o.total) {  // padding rows of the last workgroup: clean zeros
+    for (int k = 0; k < dp; ++k) out_s[slot * dp + k] = 0;
+    norm[slot] = 0;
+    return;
+  }
+  TG acc = 0;
+  if (o.mode == 2) {  // raw rows
+    for (int k = 0; k < dp; ++k) {
+      TG v = 0;
+      if (k < d) {
+        const double x = o.raw_f64 ? static_cast<const double*>(o.raw)[slot * d + k] : (double)static_cast<const float*>(o.raw)[slot * d + k];
+        v = (TG)(x / o.ls[k]);
+      }
+      out_s[slot * dp + k] = v;
+      acc += v * v;
+    }
+    norm[slot] = acc;
+    return;
+  }
+  // grown rows: compact slot -> (box, level, position), the inverse of slot = 3^(j-1) + 2 (p / 3) + (p % 3 == 2)
+  double* lo = reinterpret_cast<double*>(lds);
+  double* hi = lo + (size_t)d * LW;
+  const int seg = (int)(slot / o.uniq);
+  const int64_t sl = slot % o.uniq;
+  int level = 0;
+  int64_t width = 1, p = 0;  // 3^level, position inside the level
+  if (sl > 0) {
+    int64_t w3 = 1;  // 3^(level - 1)
+    level = 1;
+    while (sl >= 3 * w3) {
+      w3 *= 3;
+      ++level;
+    }
+    const int64_t within = sl - w3;
+    p = 3 * (within / 2) + ((within & 1) ? 2 : 0);
+    width = 3 * w3;
+  }
+  const double* b = o.boxes.b + (int64_t)seg * d * 2;
+  for (int k = 0; k < d; ++k) {
+    lo[k * LW + tid] = b[2 * k];
+    hi[k * LW + tid] = b[2 * k + 1];
+  }
+  int64_t div = width;
+  for (int st = 0; st < level; ++st) {
+    div /= 3;
+    grow_split<LW>(lo, hi, tid, d, (int)((p / div) % 3));
+  }
+  const int64_t row = (width - 1) / 2 + p;  // reference row index inside the box
+  o.key[slot] = (int64_t)seg * o.rows + row;
+  for (int k = 0; k < dp; ++k) {
+    TG v = 0;
+    if (k < d) v = (TG)(((lo[k * LW + tid] + hi[k * LW + tid]) / 2) / o.ls[k]);
+    out_s[slot * dp + k] = v;
+    acc += v * v;
+  }
+  norm[slot] = acc;
+  // the chain of centre children below this node (they have no slot of their own): each must repeat its parent's centre
+  for (int lev = level + 1; lev < o.depth; ++lev) {
+    int kmax;
+    const double parent_c = grow_split_centre<LW>(lo, hi, tid, d, &kmax);
+    grow_split<LW>(lo, hi, tid, d, 1);
+    const double child_c = (lo[kmax * LW + tid] + hi[kmax * LW + tid]) / 2;
+    if (__builtin_bit_cast(long long, parent_c) != __builtin_bit_cast(long long, child_c)) atomicOr(o.fallback, 1u);
+  }
+}
+
+template <int LW>
+__device__ __forceinline__ void one_launch_epilogue(const OneLaunch& o, int tid, unsigned char* lds) {
+  // (scratch in the kernel's DYNAMIC LDS -- free by now: static LDS on top of it would break the 160 KB opt-in)
+  Best* sh = reinterpret_cast<Best*>(lds);
+  int64_t* shp = reinterpret_cast<int64_t*>(lds + 64);
+  unsigned& last_flag = *reinterpret_cast<unsigned*>(lds + 96);
+  const int64_t j = (int64_t)blockIdx.x * LW + tid;
+  const bool mine_row = tid < LW && j < o.total;
+  double u = 0;
+  int64_t id = -1;
+  if (mine_row) {
+    u = finalize_leaf(o.fin, j);
+    id = (o.mode == 1) ? o.key[j] : j;
+  }
+  for (int seg = 0; seg < o.nseg; ++seg) {
+    Best mine{0.0, -1};
+    int64_t mypos = -1;
+    if (mine_row) {
+      const bool in = (o.mode == 1) ? (id / o.rows == seg) : (j >= o.seg_off[seg] && j < o.seg_off[seg + 1]);
+      if (in) {
+        mine = Best{u, id};
+        mypos = j;
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      Best c;
+      c.u = __shfl_xor(mine.u, off);
+      c.i = __shfl_xor(mine.i, off);
+      const int64_t cp = __shfl_xor(mypos, off);
+      if (better(c, mine)) {
+        mine = c;
+        mypos = cp;
+      }
+    }
+    if ((tid & 63) == 0) {
+      sh[tid >> 6] = mine;
+      shp[tid >> 6] = mypos;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 4; ++w)
+        if (better(sh[w], mine)) {
+          mine = sh[w];
+          mypos = shp[w];
+        }
+      static_cast<Best*>(o.partial)[(int64_t)blockIdx.x * o.nseg + seg] = mine;
+      o.ppos[(int64_t)blockIdx.x * o.nseg + seg] = mypos;
+    }
+    __syncthreads();
+  }
+  // last arriver folds: this workgroup's stores (leaf values, partials) are released before the ticket, the folding
+  // workgroup acquires behind it
+  if (tid == 0) {
+    __threadfence();
+    const unsigned t = atomicAdd(o.ticket, 1u);
+    last_flag = (t == gridDim.x - 1) ? 1u : 0u;
+    if (last_flag) __threadfence();
+  }
+  __syncthreads();
+  if (!last_flag) return;
+  const int nwg = (int)gridDim.x;
+  for (int seg = 0; seg < o.nseg; ++seg) {
+    Best mine{0.0, -1};
+    int64_t mypos = -1;
+    for (int b = tid; b < nwg; b += 256) {
+      const Best c = static_cast<const Best*>(o.partial)[(int64_t)b * o.nseg + seg];
+      if (better(c, mine)) {
+        mine = c;
+        mypos = o.ppos[(int64_t)b * o.nseg + seg];
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      Best c;
+      c.u = __shfl_xor(mine.u, off);
+      c.i = __shfl_xor(mine.i, off);
+      const int64_t cp = __shfl_xor(mypos, off);
+      if (better(c, mine)) {
+        mine = c;
+        mypos = cp;
+      }
+    }
+    if ((tid & 63) == 0) {
+      sh[tid >> 6] = mine;
+      shp[tid >> 6] = mypos;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 4; ++w)
+        if (better(sh[w], mine)) {
+          mine = sh[w];
+          mypos = shp[w];
+        }
+      double rec[4];
+      if (mine.i < 0) {
+        rec[0] = rec[1] = rec[2] = __builtin_nan("");
+        rec[3] = __builtin_bit_cast(double, (int64_t)-1);
+      } else {
+        rec[0] = o.fin.mean[mypos];
+        rec[1] = o.fin.var[mypos];
+        rec[2] = o.fin.ucb[mypos];
+        rec[3] = __builtin_bit_cast(double, (o.mode == 1) ? (int64_t)(mine.i - (int64_t)seg * o.rows) : (int64_t)(mine.i - o.seg_off[seg]));
+      }
+      for (int k = 0; k < 4; ++k) {
+        o.out_vals[seg * 4 + k] = rec[k];
+        if (o.host_vals != nullptr) o.host_vals[seg * 4 + k] = rec[k];
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const unsigned fb = atomicExch(o.fallback, 0u);  // (read and reset for the next call)
+    const double live = __builtin_bit_cast(double, (int64_t)o.total);
+    const double status = fb ? 1.0 : 0.0;  // 1: a centre child does not repeat its parent -- the host runs the general sequence
+    o.out_vals[o.nseg * 4] = live;
+    o.out_vals[o.nseg * 4 + 1] = status;
+    if (o.host_vals != nullptr) {
+      o.host_vals[o.nseg * 4] = live;
+      o.host_vals[o.nseg * 4 + 1] = status;
+    }
+    *o.ticket = 0u;
+  }
+}
+
+template <typename T, typename TG, int BM, int CT, int KERNEL, bool ONE>
+__device__ __forceinline__ void leaf_tiles_v2_body(
     const T* __restrict__ linv_p, const TG* __restrict__ xs_p, const TG* __restrict__ xnorm,
     const T* __restrict__ alpha, const TG* __restrict__ leaves_s, const TG* __restrict__ lnorm,
     double* __restrict__ part_var, double* __restrict__ part_mean, int dp4, int64_t mpad, int nbi,
-    T variance, const int64_t* __restrict__ m_live) {
+    T variance, const int64_t* __restrict__ m_live, const OneLaunch& one) {
   using M = Mfma<T>;
   using vec4 = typename M::vec4;
   using vecG = typename Mfma<TG>::vec4;
@@ -248,6 +490,10 @@ __global__ __launch_bounds__(256, 2) void leaf_tiles_v2_kernel(
   constexpr TG C2 = (TG)KernScale<KERNEL>::C2;
   extern __shared__ __align__(16) unsigned char lds_raw[];
   if (m_live != nullptr && (int64_t)blockIdx.x * (4 * CT * 16) >= *m_live) return;  // workgroup-uniform
+  if constexpr (ONE) {
+    one_launch_prologue<TG, 4 * CT * 16>(one, dp4 * 4, lds_raw, threadIdx.x);
+    __syncthreads();  // (the rows this workgroup reads below are its own: visible behind the barrier)
+  }
   unsigned char* panel = lds_raw;                              // [2][RT] fragments of FB bytes
   unsigned char* xsl = panel + (size_t)2 * RT * FB;            // [2][dp4] fragments of XB bytes
   const int tid = threadIdx.x, lane = tid & 63;
@@ -415,6 +661,29 @@ __global__ __launch_bounds__(256, 2) void leaf_tiles_v2_kernel(
       part_mean[(int64_t)bi * mpad + col] = mm;
     }
   }
+  if constexpr (ONE) {
+    __syncthreads();  // this workgroup's partial sums are stored
+    one_launch_epilogue<4 * CT * 16>(one, tid, lds_raw);
+  }
+}
+
+template <typename T, typename TG, int BM, int CT, int KERNEL>
+__global__ __launch_bounds__(256, 2) void leaf_tiles_v2_kernel(
+    const T* __restrict__ linv_p, const TG* __restrict__ xs_p, const TG* __restrict__ xnorm,
+    const T* __restrict__ alpha, const TG* __restrict__ leaves_s, const TG* __restrict__ lnorm,
+    double* __restrict__ part_var, double* __restrict__ part_mean, int dp4, int64_t mpad, int nbi,
+    T variance, const int64_t* __restrict__ m_live) {
+  leaf_tiles_v2_body<T, TG, BM, CT, KERNEL, false>(linv_p, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, dp4,
+                                                   mpad, nbi, variance, m_live, OneLaunch{});
+}
+template <typename T, typename TG, int BM, int CT, int KERNEL>
+__global__ __launch_bounds__(256, 2) void leaf_tiles_v2_one_kernel(
+    const T* __restrict__ linv_p, const TG* __restrict__ xs_p, const TG* __restrict__ xnorm,
+    const T* __restrict__ alpha, double* __restrict__ part_var, double* __restrict__ part_mean, int dp4, int64_t mpad,
+    T variance, OneLaunch one) {
+  leaf_tiles_v2_body<T, TG, BM, CT, KERNEL, true>(linv_p, xs_p, xnorm, alpha, static_cast<const TG*>(one.leaves_s),
+                                                  static_cast<const TG*>(one.lnorm), part_var, part_mean, dp4, mpad, 1,
+                                                  variance, nullptr, one);
 }
 
 // =============================================================================================
@@ -876,7 +1145,7 @@ __device__ __forceinline__ void leaf_bf16_fused_step(int q, int q_diag0, int lan
 #define GPSO_BF(SA, SB)                                                                                                   \
   c = F16 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[rt & 1][SA]), __builtin_bit_cast(f16x8, bcur[SB][t]), c, 0, 0, 0) \
           : __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[rt & 1][SA]), bcur[SB][t], c, 0, 0, 0)
-        if (NS == 3) {
+        if constexpr (NS == 3) {
           GPSO_BF(2, 0);
           GPSO_BF(0, 2);
           GPSO_BF(1, 1);
@@ -1211,26 +1480,6 @@ template void launch_pack_linv_bf16<float>(hipStream_t, int, const float*, int64
 template void launch_pack_linv_bf16<double>(hipStream_t, int, const double*, int64_t, int64_t, void*);
 
 // ---------------------------------------------------------------------------------------------
-// one leaf: sum the row blocks' partials, form mean / var (+ noise) / ucb, store them; returns ucb
-__device__ __forceinline__ double finalize_leaf(const LeafFinalize& f, int64_t j) {
-  double v = 0, mu = 0;
-  for (int b = 0; b < f.nbi; ++b) {
-    v += f.part_var[(int64_t)b * f.mpad + j];
-    mu += f.part_mean[(int64_t)b * f.mpad + j];
-  }
-  // [gpflow base_conditional] fvar = k** - sum A^2 ; predict_y adds the noise variance
-  const double vy = __dadd_rn(__dsub_rn(f.variance, v), f.noise);
-  const double my = __dadd_rn(mu, f.mean_c);
-  f.mean[j] = my;
-  f.var[j] = vy;
-  // gpso/gp_surrogate.py:326  ucb = mean + varsigma * var  (two roundings, as numpy does)
-  double prod = f.varsigma * vy;
-  asm volatile("" : "+v"(prod));  // keep the product rounded on its own: no fma contraction
-  const double u = my + prod;
-  f.ucb[j] = u;
-  return u;
-}
-
 __global__ __launch_bounds__(256) void leaf_finalize_kernel(const double* __restrict__ part_var,
                                                             const double* __restrict__ part_mean,
                                                             int nbi, int64_t mpad, int64_t m,
@@ -1258,19 +1507,6 @@ __global__ __launch_bounds__(256) void leaf_finalize_kernel(const double* __rest
   }
 }
 
-// np.argmax semantics: first maximum wins; NaN counts as the maximum (first NaN wins)
-struct Best {
-  double u;
-  int64_t i;
-};
-__device__ __forceinline__ bool better(const Best& a, const Best& b) {
-  if (a.i < 0) return false;
-  if (b.i < 0) return true;
-  const bool an = a.u != a.u, bn = b.u != b.u;
-  if (an != bn) return an;
-  if (!an && a.u != b.u) return a.u > b.u;
-  return a.i < b.i;
-}
 __device__ __forceinline__ Best block_best(Best mine, Best* sh) {
   for (int off = 32; off > 0; off >>= 1) {
     Best o;
@@ -1671,6 +1907,51 @@ static int launch_leaf_tiles_shape(hipStream_t st, const T* linv_p, const TG* xs
     return launch_leaf_tiles_v2<T, TG, 128, 2, KERNEL>(GPSO_ARGS);
   }
 }
+
+// the one-launch small call: N_pad = BM (one row block), see leaf_tiles_v2_one_kernel
+template <typename T, typename TG, int BM, int CT, int KERNEL>
+static int launch_leaf_tiles_one_shape(hipStream_t st, const T* linv_p, const TG* xs_p, const TG* xnorm, const T* alpha,
+                                       double* part_var, double* part_mean, int dp4, int64_t mpad, const KernParams& kp,
+                                       const OneLaunch& one) {
+  constexpr int RT = BM / 16, LW = 4 * CT * 16;
+  const size_t lds = leaf_v2_lds_bytes<T, TG, CT>(RT, dp4);
+  if (one.mode == 1 && (size_t)2 * one.d * LW * 8 > lds) return 2;  // the box state of the prologue does not fit
+  const int rc = ensure_dyn_lds((const void*)leaf_tiles_v2_one_kernel<T, TG, BM, CT, KERNEL>, (int)lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL((leaf_tiles_v2_one_kernel<T, TG, BM, CT, KERNEL>), dim3((unsigned)(mpad / LW)), dim3(256), lds, st,
+                     linv_p, xs_p, xnorm, alpha, part_var, part_mean, dp4, mpad, (T)kp.variance, one);
+  return 0;
+}
+template <typename T, typename TG, int KERNEL>
+static int launch_leaf_tiles_one_k(hipStream_t st, const T* linv_p, const TG* xs_p, const TG* xnorm, const T* alpha,
+                                   double* part_var, double* part_mean, int64_t npad, int dp4, int64_t mpad,
+                                   const KernParams& kp, const OneLaunch& one) {
+#define GPSO_ARGS1 st, linv_p, xs_p, xnorm, alpha, part_var, part_mean, dp4, mpad, kp, one
+  if constexpr (sizeof(T) == 4) {
+    if (npad == 256) return launch_leaf_tiles_one_shape<T, TG, 256, 2, KERNEL>(GPSO_ARGS1);
+    return launch_leaf_tiles_one_shape<T, TG, 128, 4, KERNEL>(GPSO_ARGS1);
+  } else {
+    if (npad == 256) return launch_leaf_tiles_one_shape<T, TG, 256, 1, KERNEL>(GPSO_ARGS1);
+    return launch_leaf_tiles_one_shape<T, TG, 128, 2, KERNEL>(GPSO_ARGS1);
+  }
+#undef GPSO_ARGS1
+}
+// returns 0 (launched), 2 (not applicable: the caller runs another sequence) or a negative status
+template <typename T, typename TG>
+int launch_leaf_tiles_one(hipStream_t st, const T* linv_p, const TG* xs_p, const TG* xnorm, const T* alpha,
+                          double* part_var, double* part_mean, int64_t npad, int dp4, int64_t mpad, const KernParams& kp,
+                          const OneLaunch& one) {
+  if (npad != 128 && npad != 256) return 2;
+  switch (kp.kernel) {
+    case 0: return launch_leaf_tiles_one_k<T, TG, 0>(st, linv_p, xs_p, xnorm, alpha, part_var, part_mean, npad, dp4, mpad, kp, one);
+    case 1: return launch_leaf_tiles_one_k<T, TG, 1>(st, linv_p, xs_p, xnorm, alpha, part_var, part_mean, npad, dp4, mpad, kp, one);
+    case 2: return launch_leaf_tiles_one_k<T, TG, 2>(st, linv_p, xs_p, xnorm, alpha, part_var, part_mean, npad, dp4, mpad, kp, one);
+    default: return launch_leaf_tiles_one_k<T, TG, 3>(st, linv_p, xs_p, xnorm, alpha, part_var, part_mean, npad, dp4, mpad, kp, one);
+  }
+}
+template int launch_leaf_tiles_one<float, float>(hipStream_t, const float*, const float*, const float*, const float*, double*, double*, int64_t, int, int64_t, const KernParams&, const OneLaunch&);
+template int launch_leaf_tiles_one<float, double>(hipStream_t, const float*, const double*, const double*, const float*, double*, double*, int64_t, int, int64_t, const KernParams&, const OneLaunch&);
+template int launch_leaf_tiles_one<double, double>(hipStream_t, const double*, const double*, const double*, const double*, double*, double*, int64_t, int, int64_t, const KernParams&, const OneLaunch&);
 
 template <typename T, typename TG>
 int launch_leaf_tiles(hipStream_t st, const T* linv_p, const TG* xs_p, const TG* xnorm,

@@ -114,8 +114,9 @@ class HipGPEngine:
         self._check(self._lib.gpso_set_option(self._h, L.OPT_SPLIT_KERNEL, {"auto": 0, "two-phase": 1}[which]))
 
     def set_small_calls(self, on):
-        """GPSO_OPT_SMALL_CALLS: the short launch sequence for best-UCB calls on small batches (default on; same bits)."""
-        self._check(self._lib.gpso_set_option(self._h, L.OPT_SMALL_CALLS, 1 if on else 0))
+        """GPSO_OPT_SMALL_CALLS: the short launch sequences for best-UCB calls on small batches (default on; same bits).
+        True / 1: three launches, or one where that measures faster; 2: three only; 3: one wherever it applies; 0: general."""
+        self._check(self._lib.gpso_set_option(self._h, L.OPT_SMALL_CALLS, int(on)))
 
     def set_precision_check(self, on):
         self._check(self._lib.gpso_set_option(self._h, L.OPT_PRECISION_CHECK, 1 if on else 0))

@@ -903,7 +903,7 @@ def test_fused_step_kernel_gives_the_bits_of_the_two_phase_kernel(dtype, math, g
 
 
 @pytest.mark.parametrize("dtype", ["float64", "mixed", "float32"])
-@pytest.mark.parametrize("n,d,depth", [(52, 2, 5), (30, 4, 7), (100, 6, 9), (128, 3, 8), (300, 5, 6), (7, 1, 9)])
+@pytest.mark.parametrize("n,d,depth", [(52, 2, 5), (30, 4, 7), (100, 6, 9), (128, 3, 8), (300, 5, 6), (7, 1, 9), (256, 6, 8), (200, 12, 4)])
 def test_small_call_sequence_gives_the_bits_of_the_general_one(dtype, n, d, depth):
     """Round 4: best-UCB calls on small batches run growth + input scaling in ONE launch (boxes by value), the tile
     kernel, and finalize + arg-max in one workgroup that writes pinned host memory (GPSO_OPT_SMALL_CALLS, default on).
@@ -918,7 +918,7 @@ def test_small_call_sequence_gives_the_bits_of_the_general_one(dtype, n, d, dept
     lo = rng.random((2, d)) * 0.5
     arbitrary = np.stack([lo, lo + 0.1 + 0.4 * rng.random((2, d))], axis=2)
     res = {}
-    for small in (True, False):
+    for small in (3, 1, 2, 0):  # one launch wherever it applies | the default choice | three launches | the general sequence
         eng = HipGPEngine(dtype)
         eng.set_small_calls(small)
         _fit(eng, X, y, th, grad=False)
@@ -930,9 +930,10 @@ def test_small_call_sequence_gives_the_bits_of_the_general_one(dtype, n, d, dept
         out.append(eng.best_ucb(Xs[:1], VS))
         out.append(tuple(eng.shard_winners_grow(r, 3, arbitrary, depth, VS) for r in range(3)))
         res[small] = out
-    for a, b in zip(res[True], res[False]):
-        for p, q in zip(a, b):
-            assert np.array_equal(np.asarray(p), np.asarray(q), equal_nan=True)
+    for other in (3, 1, 2):
+        for a, b in zip(res[other], res[0]):
+            for p, q in zip(a, b):
+                assert np.array_equal(np.asarray(p), np.asarray(q), equal_nan=True), other
     # and against the full duplicated list scored by predict + numpy (the reference's gp_eval_best_ucb)
     eng = HipGPEngine(dtype)
     _fit(eng, X, y, th, grad=False)
@@ -941,5 +942,5 @@ def test_small_call_sequence_gives_the_bits_of_the_general_one(dtype, n, d, dept
         mean, var = eng.predict(full[sgm])
         ucb = mean + VS * var
         i = int(np.argmax(ucb))
-        got = res[True][1]
+        got = res[1][1]
         assert int(got[0][sgm]) == i and got[3][sgm] == ucb[i] and got[1][sgm] == mean[i] and got[2][sgm] == var[i]
