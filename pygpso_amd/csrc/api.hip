@@ -722,11 +722,9 @@ struct EngineT : Engine {
       if ((rc = launch_small_fit<TF, TP>(s, a))) return launch_status();
     } else {
       if ((rc = scale_inputs())) return rc;
-      launch_gram<TF>(s, as<double>(xs64), as<double>(xnorm64), n, npad, dp, kp, as<TF>(K));
-      HIPCHECK(hipMemsetAsync(linv.p, 0, (size_t)npad * npad * sizeof(TF), s));
-      const int imax = INT_MAX;
       int* info_dev = reinterpret_cast<int*>(as<double>(scal) + 1);
-      HIPCHECK(hipMemcpyAsync(info_dev, &imax, sizeof(int), hipMemcpyHostToDevice, s));
+      launch_gram<TF>(s, as<double>(xs64), as<double>(xnorm64), n, npad, dp, kp, as<TF>(K), info_dev);
+      HIPCHECK(hipMemsetAsync(linv.p, 0, (size_t)npad * npad * sizeof(TF), s));
       FitPlanes planes{};
       const FitPlanes* pl = nullptr;
       if constexpr (sizeof(TF) == 4) {
@@ -767,7 +765,11 @@ struct EngineT : Engine {
         launch_gradient<TF>(s, as<TF>(linv), as<TF>(alpha_f), as<double>(xs64), as<double>(xnorm64), n, npad, d, dp,
                             n_ls, ls_dev(), kp, as<TF>(kinvb), (done & 2) != 0, as<double>(gpart),
                             as<double>(scal) + 8, xt_ready ? &planes : nullptr);
-      launch_pack_linv<TF, TP>(s, as<TF>(linv), n, npad, as<TP>(linv_p));  // (alpha's predict-type copy: alpha_sum_kernel)
+      // the packed f32 / f64 copy of L^-1 feeds the NATIVE tile kernel only: a posterior that is going to predict with
+      // split math (the default of float-predict contexts) packs it when -- if ever -- something asks for it
+      // (ensure_linv_p: the self-test walking down GPSO_MATH_AUTO's ladder, a hand-off of all buffers)
+      linv_p_lazy = bf16_usable();
+      if (!linv_p_lazy) launch_pack_linv<TF, TP>(s, as<TF>(linv), n, npad, as<TP>(linv_p));  // (alpha's predict-type copy: alpha_sum_kernel)
       small_tile_rows = 8;
     }
     if ((rc = pack_bf16())) return rc;
@@ -790,8 +792,20 @@ struct EngineT : Engine {
       for (int h = 0; h < n_ls + 3; ++h) grad[h] = host[8 + h];
       have_kinv = true;
     }
-    have_post = chol_valid = st_have = linv_p_valid = true;
+    have_post = chol_valid = st_have = true;
+    linv_p_valid = small || !linv_p_lazy;
+    if (small) linv_p_lazy = false;
     return GPSO_OK;
+  }
+  // the packed native-type L^-1, made on demand from the resident factor's inverse
+  bool linv_p_lazy = false;
+  int ensure_linv_p() {
+    if (linv_p_valid || !linv_p_lazy || !chol_valid) return GPSO_OK;
+    launch_pack_linv<TF, TP>(st(), as<TF>(linv), n, npad, as<TP>(linv_p));
+    small_tile_rows = 8;
+    linv_p_valid = true;
+    linv_p_lazy = false;
+    return launch_status();
   }
 
   int set_posterior(const double* X, const double* L, const double* alpha64, int64_t n_, int d_,
@@ -841,6 +855,10 @@ struct EngineT : Engine {
     // row blocks of L^-1 = partial sums per leaf: the split-bf16 kernel always works on 256-row blocks,
     // the native kernels on the shape leaf_tiles_bm picks
     const bool use_bf16 = bf16_usable() && linv_b_valid && bf16_fits(sizeof(TG) == 8);
+    if (!use_bf16) {
+      int rcp = ensure_linv_p();
+      if (rcp) return rcp;
+    }
     if (!use_bf16 && !linv_p_valid)
       return ctx->fail(GPSO_E_STATE, "this posterior was received with the split pieces of L^-1 only (the sender predicts with "
                                      "split math): the f32 MFMA kernel has nothing to read -- keep the sender's predict math, or "
@@ -1216,7 +1234,8 @@ struct EngineT : Engine {
     // 78.4 | 85.7 -- the two agent-scope fences of the last-arriver fold cost what the two launch boundaries they replace
     // cost; the single launch only pays at N_pad = 256
     if (npad == 128 && !one_launch_everywhere) return 2;
-    if (math_in_use() != GPSO_MATH_NATIVE || !linv_p_valid) return 2;
+    if (math_in_use() != GPSO_MATH_NATIVE) return 2;
+    if (ensure_linv_p() != GPSO_OK || !linv_p_valid) return 2;
     if (leaf_tiles_nbi<TP>(npad, dp / 4) != 1) return 2;
     if constexpr (kFloatPredict) {
       if (!gen_double()) {
@@ -1912,6 +1931,7 @@ struct EngineT : Engine {
     if (rc) return rc;
     if (check && st_have && have_data && (rc = selftest_with_fallback())) return rc;  // settles GPSO_MATH_AUTO
     const bool with_linv_p = !span_only || math_in_use() == GPSO_MATH_NATIVE;
+    if (with_linv_p && (rc = ensure_linv_p())) return rc;
     double* flag = ctx->pinned_scratch(256) + 120;  // (a slot neither the read-backs nor set_theta use)
     *flag = (gen_double() ? 0.0 : 1.0) + (math_native_fallback ? 2.0 : 0.0) + ((bf16_usable() && linv_b_valid) ? 4.0 : 0.0) +
             ((with_linv_p && linv_p_valid) ? 8.0 : 0.0) + 256.0 * math;  // (which split the pieces are: a receiver under GPSO_MATH_AUTO follows)

@@ -117,10 +117,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ xs,
                                                    const double* __restrict__ xnorm, int64_t n,
                                                    int64_t npad, int dp, int kernel, double variance,
-                                                   double noise, T* __restrict__ K) {
+                                                   double noise, T* __restrict__ K, int* __restrict__ info) {
   using vec4 = typename Mfma<T>::vec4;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t blk = blockIdx.x;
+  // (the factorisation's verdict starts at "no failing pivot": set here, not by a host-to-device copy of its own)
+  if (info != nullptr && blk == 0 && threadIdx.x == 0) *info = 0x7fffffff;
   int ti = (int)((__builtin_sqrtf(8.0f * (float)blk + 1.0f) - 1.0f) * 0.5f);
   while ((int64_t)(ti + 1) * (ti + 2) / 2 <= blk) ++ti;
   while ((int64_t)ti * (ti + 1) / 2 > blk) --ti;
@@ -177,14 +179,14 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ xs
 
 template <typename T>
 void launch_gram(hipStream_t st, const double* xs, const double* xnorm, int64_t n, int64_t npad, int dp,
-                 const KernParams& kp, T* K) {
+                 const KernParams& kp, T* K, int* info) {
   const int64_t nt = npad / 64;
   hipLaunchKernelGGL((gram_kernel<T>), dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256),
                      (size_t)2 * 64 * (dp + 1) * sizeof(double), st, xs, xnorm, n, npad, dp, kp.kernel, kp.variance,
-                     kp.noise, K);
+                     kp.noise, K, info);
 }
-template void launch_gram<float>(hipStream_t, const double*, const double*, int64_t, int64_t, int, const KernParams&, float*);
-template void launch_gram<double>(hipStream_t, const double*, const double*, int64_t, int64_t, int, const KernParams&, double*);
+template void launch_gram<float>(hipStream_t, const double*, const double*, int64_t, int64_t, int, const KernParams&, float*, int*);
+template void launch_gram<double>(hipStream_t, const double*, const double*, int64_t, int64_t, int, const KernParams&, double*, int*);
 
 // =============================================================================================
 // 64x64 diagonal block: Cholesky + triangular inverse in LDS, 4 waves, blocked by 16 columns

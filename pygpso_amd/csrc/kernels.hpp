@@ -110,7 +110,7 @@ void launch_gen_inputs_f32(hipStream_t st, const double* xs64, int64_t npad, int
 // always formed in double from the double scaled inputs.
 template <typename T>
 void launch_gram(hipStream_t st, const double* xs, const double* xnorm, int64_t n, int64_t npad, int dp,
-                 const KernParams& kp, T* K);
+                 const KernParams& kp, T* K, int* info = nullptr /* device: set to INT_MAX ("no failing pivot") */);
 // blocked right-looking Cholesky, K (destroyed) -> Lf (lower); also writes the inverted 64x64 diagonal
 // blocks into linv, the unrounded diagonal of L to diag64[npad], and the first failing pivot (or
 // INT_MAX) to info
