@@ -73,7 +73,7 @@ PEAK_BF16_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak; a split product costs 
 # cannot be read from inside the process); the committed record of the latest collection:
 PMC_TRAFFIC = {("c3", "native"): "profiles/r02f_pmc_leaf_tiles_c3.json",
                ("c3", "bf16x6"): "profiles/r02h_pmc_leaf_tiles_bf16x6_c3.json",
-               ("c3", "f16x3"): "profiles/r03_pmc_leaf_tiles_f16x3_c3.json"}
+               ("c3", "f16x3"): "profiles/r04_pmc_leaf_tiles_f16x3_c3.json"}
 
 
 def pmc_traffic(workload, math_mode):
