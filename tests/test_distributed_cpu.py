@@ -350,3 +350,62 @@ def test_group_id_exchange_timeout_names_the_missing_ranks_and_answers_a_retry()
     uid = D.exchange_unique_id(0, 2, addr="127.0.0.1", port=port, timeout=10.0, make_id=lambda: b"y" * 128, grace=1.0)
     t.join()
     assert got == [uid, uid]
+
+
+def test_replicating_group_runs_the_fit_on_every_device_and_compares_fingerprints():
+    """``HipGPEngineGroup(posterior="replicate")`` with two fake devices: set_data / fit_eval reach EVERY engine (no
+    broadcast is ever asked for), the fingerprints are compared before the first predict-type call of a new posterior,
+    and a disagreement raises instead of predicting from two different posteriors."""
+    import threading
+
+    from pygpso_amd import _lib as L
+    from pygpso_amd import distributed as D
+
+    calls = []
+    lock = threading.Lock()
+
+    class Eng:
+        dtype_name, dtype = "float64", 0
+
+        def __init__(self, dtype="float64", device=0, **_):
+            self.device, self.n, self.d = device, 0, 0
+            self.rank, self.world = 0, 1
+            self.hash = 0x1234
+
+        def close(self):
+            pass
+
+        def comm_init(self, rank, world, uid):
+            self.rank, self.world = rank, world
+
+        def set_data(self, X, y):
+            self.n, self.d = X.shape
+            with lock:
+                calls.append(("set_data", self.rank))
+
+        def fit_eval(self, *a, **kw):
+            with lock:
+                calls.append(("fit_eval", self.rank))
+            return 1.5 + self.rank, None  # (rank 0's value is the group's)
+
+        def broadcast_posterior(self, root=0):
+            raise AssertionError("a replicating group must not broadcast")
+
+        def posterior_hash(self):
+            return self.hash
+
+        def best_ucb_sharded(self, local, m_global, varsigma, seg_off=None):
+            return (np.array([self.rank]),) * 4
+
+    grp = D.HipGPEngineGroup("float64", devices=[0, 1], engine_cls=Eng, make_id=lambda: b"r" * 128, posterior="replicate")
+    grp.set_data(np.zeros((5, 2)), np.zeros(5))
+    assert grp.fit_eval("Matern52", [0.5], 1.0, 1e-3, 0.0, want_grad=False)[0] == 1.5
+    assert sorted(calls) == [("fit_eval", 0), ("fit_eval", 1), ("set_data", 0), ("set_data", 1)] and grp.n == 5
+    assert int(grp.best_ucb(np.zeros((4, 2)), 1.0)[0][0]) == 0  # fingerprints agree: the call goes through
+    grp.engines[1].hash = 0x9999
+    grp.fit_eval("Matern52", [0.5], 1.0, 1e-3, 0.0, want_grad=False)
+    with pytest.raises(L.GpsoHipError, match="fingerprints"):
+        grp.best_ucb(np.zeros((4, 2)), 1.0)
+    with pytest.raises(ValueError):
+        D.HipGPEngineGroup("float64", devices=[0], engine_cls=Eng, make_id=lambda: b"r" * 128, posterior="gossip")
+    grp.close()
