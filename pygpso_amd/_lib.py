@@ -33,6 +33,8 @@ OPT_FIT_BF16_SYRK = 6
 OPT_TIMING = 7
 OPT_SPLIT_KERNEL = 8
 OPT_SMALL_CALLS = 9
+OPT_CONTRACTION = 10
+CONTRACTION_AUTO, CONTRACTION_F32, CONTRACTION_F16 = 0, 1, 2
 SPLIT_KERNEL_AUTO, SPLIT_KERNEL_TWO_PHASE = 0, 1
 OPTF_TOL_VAR, OPTF_TOL_MEAN = 100, 101
 GEN_F64, GEN_F32, GEN_AUTO = 0, 1, 2

@@ -264,6 +264,7 @@ struct EngineT : Engine {
   // device buffers.  Fit side: xs64 / xnorm64 (scaled inputs, always double), K, Lf, linv, work, kinvb,
   // white, alpha_f in TF.  Predict side: linv_p, alpha in TP; xs_p64 (+ xnorm64) or xs_p32 / xnorm32
   // in the generation type.
+  DevBuf xs_h16, c16_scal;  // fp16 piece pairs of xs32 in the fp16 contraction's fragment order, and their scale (4 floats)
   DevBuf x64, y64, hyper, xs64, xnorm64, xs_p64, xs32, xnorm32, xs_p32, K, Lf, linv, work, kinvb, linv_p,
       white, alpha_f, alpha, logdet, scal, gpart, apart, kinv_diag, getter_tmp;
   // split-bf16 copy of L^-1 (float predict with GPSO_OPT_PREDICT_MATH != native)
@@ -286,6 +287,16 @@ struct EngineT : Engine {
   bool gen_decided = false;     // AUTO: has the self-test ruled on this posterior?
   bool gen32_inputs_ok = false; // xs32 / xnorm32 / xs_p32 match the resident posterior
   int split_variant = GPSO_SPLIT_KERNEL_AUTO;  // GPSO_OPT_SPLIT_KERNEL
+  int contraction = GPSO_CONTRACTION_AUTO;     // GPSO_OPT_CONTRACTION
+  // the x.x* contraction of the fp16-split kernel runs on the fp16 pipe: float generation, D_pad <= 64 (two chunks of 32
+  // dimensions: one DMA window, LDS for the leaf fragments).  AUTO takes it from D_pad = 12: 12 matrix instructions of
+  // 16 clocks per k-step whatever D <= 32, against D_pad / 4 x 4 of 32 clocks -- measured in one process on one
+  // posterior (tools/c16_check.py, profiles/r04_c16_check.jsonl): D = 6 -0.7 %, 12 +3.3 %, 20 +12 %, 33 +21 %, 40 +25 %
+  bool c16_in_use(bool gen64) const {
+    if (!kFloatPredict || gen64 || !f16_split() || contraction == GPSO_CONTRACTION_F32 || dp > 64) return false;
+    if (contraction == GPSO_CONTRACTION_AUTO && dp < 12) return false;
+    return leaf_bf16_lds_bytes(2, dp / 4, 4, true) <= 160 * 1024;
+  }
   bool small_calls = true, one_launch = true, one_launch_everywhere = false;  // GPSO_OPT_SMALL_CALLS
   bool one_refused = false;                    // the one-launch kernel asked for the general sequence (this call only)
   int64_t single_level_max = -1;  // < 0: library default
@@ -305,7 +316,7 @@ struct EngineT : Engine {
   DevBuf st_mean, st_var, st_out;
 
   ~EngineT() override {
-    for (DevBuf* b : {&x64, &y64, &hyper, &xs64, &xnorm64, &xs_p64, &xs32, &xnorm32, &xs_p32, &K, &Lf, &linv,
+    for (DevBuf* b : {&xs_h16, &c16_scal, &x64, &y64, &hyper, &xs64, &xnorm64, &xs_p64, &xs32, &xnorm32, &xs_p32, &K, &Lf, &linv,
                       &work, &kinvb, &linv_p, &white, &alpha_f, &alpha, &logdet, &scal, &gpart, &apart,
                       &kinv_diag, &getter_tmp, &leaves_raw, &leaves_s, &lnorm, &pvar, &pmean, &omean, &ovar,
                       &oucb, &segoff, &best, &oidx, &ovals, &linv_b, &st_mean, &st_var, &st_out, &grow_key, &live_cnt,
@@ -324,7 +335,9 @@ struct EngineT : Engine {
   // the split-bf16 kernel keeps its leaf fragments in LDS: with double generation they do not fit the
   // 160 KB for D > 24 (bf16x6) / D > 36 (bf16x3) -- those calls run the native f32 kernel instead (accuracy
   // decides the generation type, the kernel follows)
-  bool bf16_fits(bool gen64) const { return leaf_bf16_lds_bytes(nsplit(), dp / 4, gen64 ? 8 : 4) <= 160 * 1024; }
+  bool bf16_fits(bool gen64) const {
+    return c16_in_use(gen64) || leaf_bf16_lds_bytes(nsplit(), dp / 4, gen64 ? 8 : 4) <= 160 * 1024;
+  }
   int nsplit() const { return math == GPSO_MATH_BF16X6 ? 3 : 2; }
   bool f16_split() const { return math == GPSO_MATH_F16X3; }
   // bytes of the split copy of L^-1: the planes and, behind them, one 256-byte slot for the power-of-two scale of the
@@ -397,6 +410,14 @@ struct EngineT : Engine {
         small_calls = value != 0;
         one_launch = value == 1 || value == 3;
         one_launch_everywhere = value == 3;
+        return GPSO_OK;
+      case GPSO_OPT_CONTRACTION:
+        if (value != GPSO_CONTRACTION_AUTO && value != GPSO_CONTRACTION_F32 && value != GPSO_CONTRACTION_F16) return ctx->fail(GPSO_E_ARG, "unknown contraction %d", value);
+        if (value != contraction) {
+          contraction = value;
+          gen_decided = false;  // (other bits: the self-test rules again)
+          st_done = false;
+        }
         return GPSO_OK;
       case GPSO_OPT_SPLIT_KERNEL:
         if (value != GPSO_SPLIT_KERNEL_AUTO && value != GPSO_SPLIT_KERNEL_TWO_PHASE) return ctx->fail(GPSO_E_ARG, "unknown split kernel %d", value);
@@ -516,6 +537,8 @@ struct EngineT : Engine {
       if ((rc = ensure(xs32, (size_t)npad * dp * 4))) return rc;
       if ((rc = ensure(xnorm32, (size_t)npad * 4))) return rc;
       if ((rc = ensure(xs_p32, (size_t)npad * dp * 4))) return rc;
+      if ((rc = ensure(xs_h16, (size_t)(npad / 16) * ((dp + 31) / 32) * 2048))) return rc;
+      if ((rc = ensure(c16_scal, 16))) return rc;
     }
     return GPSO_OK;
   }
@@ -659,6 +682,7 @@ struct EngineT : Engine {
   int ensure_generation_inputs() {
     if (gen_double() || gen32_inputs_ok) return GPSO_OK;
     launch_gen_inputs_f32(st(), as<double>(xs64), npad, dp, as<float>(xs32), as<float>(xnorm32), as<float>(xs_p32));
+    launch_gen_inputs_f16(st(), as<float>(xs32), npad, dp, as<float>(c16_scal), xs_h16.p);
     gen32_inputs_ok = true;
     return GPSO_OK;
   }
@@ -913,7 +937,8 @@ struct EngineT : Engine {
         if constexpr (kFloatPredict)
           rc = launch_leaf_tiles_bf16<TG>(s, nsplit(), split_planes(), xsp, xnr, as<float>(alpha), as<TG>(leaves_s),
                                           as<TG>(lnorm), as<double>(pvar), as<double>(pmean), npad, dp / 4, mp,
-                                          kp, m_live_c, f16_split() ? f16_scale() : nullptr, split_variant);
+                                          kp, m_live_c, f16_split() ? f16_scale() : nullptr, split_variant,
+                                          c16_in_use(sizeof(TG) == 8) ? xs_h16.p : nullptr, as<float>(c16_scal));
       } else {
         rc = launch_leaf_tiles<TP, TG>(s, as<TP>(linv_p), xsp, xnr, as<TP>(alpha), as<TG>(leaves_s),
                                        as<TG>(lnorm), as<double>(pvar), as<double>(pmean), npad, dp / 4, mp, kp,

@@ -44,10 +44,16 @@ void launch_pack_linv_bf16(hipStream_t st, int nsplit, const TF* linv, int64_t n
                            void* linv_b);
 // dynamic LDS of the split-bf16 kernel: A pieces (2 buffers x nsplit x 16 KiB) + 3 X buffers + the 8 waves' leaf
 // fragments, for a generation type of tg_bytes
-inline size_t leaf_bf16_lds_bytes(int nsplit, int dp4, int tg_bytes) {
-  return (size_t)2 * nsplit * 16 * 64 * 16 + (size_t)3 * (2 * dp4 * 64 * tg_bytes + 64 * tg_bytes + 256) +
-         (size_t)8 * 2 * dp4 * 64 * tg_bytes;
+// c16: the contraction runs on the fp16 pipe (float generation only): the X fragments of a k-step and the leaf fragments
+// of a wave are fp16 piece pairs of 32-dimension chunks instead of float groups of four dimensions
+inline int leaf_c16_chunks(int dp4) { return (dp4 + 7) / 8; }
+inline size_t leaf_bf16_lds_bytes(int nsplit, int dp4, int tg_bytes, bool c16 = false) {
+  const size_t xfrag = c16 ? (size_t)leaf_c16_chunks(dp4) * 4096 : (size_t)2 * dp4 * 64 * tg_bytes;
+  return (size_t)2 * nsplit * 16 * 64 * 16 + (size_t)3 * (xfrag + 64 * tg_bytes + 256) + (size_t)8 * xfrag;
 }
+// fp16 piece pairs of the float scaled inputs in the fragment order of the fp16 contraction (predict.hip); scal: 4 device
+// floats ([0] max |x / l|, [1] := 2^sx, [2] := 2^-2sx); xs_h16: npad / 16 * ceil(dp / 32) * 2 KB
+void launch_gen_inputs_f16(hipStream_t st, const float* xs32, int64_t npad, int dp, float* scal, void* xs_h16);
 // f16_inv_scale_a != nullptr: the fp16 split (two pieces, three products; predict.hip) -- linv_b and the scale (device,
 // 2 floats: max |L^-1|, 2^-sa) come from launch_pack_linv_f16
 template <typename TG>
@@ -55,7 +61,8 @@ int launch_leaf_tiles_bf16(hipStream_t st, int nsplit, const void* linv_b, const
                            const TG* xnorm, const float* alpha, const TG* leaves_s,
                            const TG* lnorm, double* part_var, double* part_mean, int64_t npad,
                            int dp4, int64_t mpad, const KernParams& kp, const int64_t* m_live,
-                           const float* f16_inv_scale_a = nullptr, int variant = 0 /* GPSO_OPT_SPLIT_KERNEL: 0 the fused step, 1 the two-phase step */);
+                           const float* f16_inv_scale_a = nullptr, int variant = 0 /* GPSO_OPT_SPLIT_KERNEL: 0 the fused step, 1 the two-phase step */,
+                           const void* xs_h16 = nullptr, const float* c16_scale = nullptr /* both set: the contraction on the fp16 pipe (fp16 split, float generation) */);
 // scal: 2 device floats -- [0] max |L^-1|, [1] := 2^-sa.  have_max false: the maximum is computed here first (memset +
 // absmax_kernel); true: the fit left it in scal[0] (launch_solve_alpha: its own pass over L^-1).
 template <typename TF>

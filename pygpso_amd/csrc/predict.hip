@@ -808,11 +808,134 @@ __global__ __launch_bounds__(256) void pack_linv_f16_kernel(const TF* __restrict
   }
 }
 
-template <typename TG>
+// ---- round 4: the x.x* contraction of the float generation on the fp16 pipe -----------------------------------------
+// In float the contraction is D_pad / 4 v_mfma_f32_16x16x4_f32 per 16 x 16 tile at 32 clocks each: at D = 40 1 280 clocks
+// of a k-step's 3 072-clock apply budget, and the measured fraction of the bound falls with D accordingly (0.455 at D = 6,
+// 0.32 at D = 40 for N = 16 384: profiles/r04_sweep.jsonl).  The same split that carries L^-1 carries the scaled inputs:
+// x / l = h0 + h1 in fp16 (|x / l - h0 - h1| <= 2^-24 |x / l|: float's own rounding), a product = h1 h0' + h0 h1' + h0 h0'
+// on v_mfma_f32_16x16x32_f16 -- 12 ceil(D / 32) matrix instructions of 16 clocks per k-step: 192 clocks up to D = 32,
+// 384 up to D = 64.  Both sides are scaled by 2^sx (exact) with the largest |x / l| of the TRAINING inputs in [2^7, 2^8):
+// a leaf up to 255 times further out than any training input still fits fp16 (beyond that it saturates: its r^2 is
+// dominated by its own norm, which stays float, and the kernel map underflows either way); the combine multiplies the
+// contraction by -2 SC 2^-2sx.  The norms stay float sums of the unsplit values.
+// Fragment order of the training side: block (q, h, cc, piece) of 64 lanes x 16 bytes, lane l element j = row
+// 32 q + 16 h + (l & 15), dimension 32 cc + 8 (l >> 4) + j -- the A operand of the 16x16x32 instruction as it stands.
+// scal: 4 device floats -- [0] max |x / l| (as float bits, atomicMax), [1] := 2^sx, [2] := 2^-2sx
+__global__ __launch_bounds__(256) void absmax_f32_kernel(const float* __restrict__ v, int64_t count,
+                                                         unsigned* __restrict__ out) {
+  float m = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(v[i]));
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(out, __builtin_bit_cast(unsigned, m));
+}
+__global__ __launch_bounds__(256) void pack_xs_f16_kernel(const float* __restrict__ xs, int64_t npad, int dp, int nc,
+                                                          float* __restrict__ scal, u32x4* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // ((q, h), cc, lane)
+  int e = 0;
+  (void)frexpf(fmaxf(scal[0], 1e-30f), &e);  // max = m 2^e, m in [0.5, 1)
+  const float up = ldexpf(1.0f, 8 - e);
+  if (idx == 0) {
+    scal[1] = up;
+    scal[2] = ldexpf(1.0f, 2 * (e - 8));
+  }
+  if (idx >= (npad / 16) * nc * 64) return;
+  const int lane = (int)(idx & 63);
+  const int cc = (int)((idx >> 6) % nc);
+  const int64_t kt = (idx >> 6) / nc;  // 16-row tile = 2 q + h
+  const int64_t row = kt * 16 + (lane & 15);
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 32 * cc + 8 * (lane >> 4) + j;
+    v[j] = k < dp ? xs[row * dp + k] * up : 0.0f;
+  }
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_) {
+    u32x4 f;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) f[h] = f16_split_pair(v[2 * h], v[2 * h + 1]);
+    out[((kt * nc + cc) * 2 + s_) * 64 + lane] = f;
+  }
+}
+void launch_gen_inputs_f16(hipStream_t st, const float* xs32, int64_t npad, int dp, float* scal, void* xs_h16) {
+  const int nc = (dp + 31) / 32;
+  (void)hipMemsetAsync(scal, 0, 4, st);
+  const int64_t count = npad * dp;
+  hipLaunchKernelGGL(absmax_f32_kernel, dim3((unsigned)std::min<int64_t>((count + 255) / 256, 1024)), dim3(256), 0, st,
+                     xs32, count, reinterpret_cast<unsigned*>(scal));
+  const int64_t total = (npad / 16) * nc * 64;
+  hipLaunchKernelGGL(pack_xs_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, xs32, npad, dp, nc,
+                     scal, static_cast<u32x4*>(xs_h16));
+}
+
+template <typename TG, bool C16 = false>
 struct Bf16Lds {
-  // bytes of one X buffer: 2 k-tiles of fragments (TG), 32 norms (TG, padded to 64), 32 alphas (float, padded to 64)
-  static __host__ __device__ constexpr int xbytes(int dp4) { return 2 * dp4 * 64 * (int)sizeof(TG) + 64 * (int)sizeof(TG) + 256; }
+  // bytes of the X fragments of one k-step: 2 k-tiles x D_pad / 4 groups (TG), or 2 k-tiles x chunks of 32 dimensions x
+  // 2 fp16 pieces x 1 KB (C16); a wave's leaf fragments take as much
+  static __host__ __device__ constexpr int xfrag(int dp4) { return C16 ? ((dp4 + 7) / 8) * 4096 : 2 * dp4 * 64 * (int)sizeof(TG); }
+  // bytes of one X buffer: the fragments, 32 norms (TG, padded to 64), 32 alphas (float, padded to 64)
+  static __host__ __device__ constexpr int xbytes(int dp4) { return xfrag(dp4) + 64 * (int)sizeof(TG) + 256; }
 };
+// the x.x* contraction of one k-step of a wave: s[h][t] += (16 training points of half h) x (16 leaves of column tile t).
+// Float / double: software-pipelined over the groups of four dimensions -- the operands of group c + 1 are on their way
+// from LDS while the MFMAs of group c issue.  C16: three fp16 products per chunk of 32 dimensions, small terms first.
+template <typename TG, bool C16, int CT>
+__device__ __forceinline__ void leaf_contract(int lane, int dp4, const unsigned char* xs_b, const TG* xb,
+                                              typename Mfma<TG>::vec4 (&s)[2][CT]) {
+  if constexpr (C16) {
+    static_assert(sizeof(TG) == 4, "the fp16 contraction belongs to float generation");
+    const int nc = (dp4 + 7) >> 3;
+    const u32x4* xa = reinterpret_cast<const u32x4*>(xs_b);  // [h][cc][piece][64]
+    const u32x4* lb = reinterpret_cast<const u32x4*>(xb);    // [t][cc][piece][64]
+    for (int cc = 0; cc < nc; ++cc) {
+      u32x4 a[2][2], b[CT][2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) a[h][pc] = xa[((h * nc + cc) * 2 + pc) * 64 + lane];
+#pragma unroll
+      for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) b[t][pc] = lb[((t * nc + cc) * 2 + pc) * 64 + lane];
+#define GPSO_XX(PA, PB)                                                                                              \
+  _Pragma("unroll") for (int h = 0; h < 2; ++h) _Pragma("unroll") for (int t = 0; t < CT; ++t) s[h][t] =             \
+      __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[h][PA]), __builtin_bit_cast(f16x8, b[t][PB]), s[h][t], 0, 0, 0)
+      GPSO_XX(1, 0);
+      GPSO_XX(0, 1);
+      GPSO_XX(0, 0);
+#undef GPSO_XX
+    }
+  } else {
+    using MG = Mfma<TG>;
+    constexpr int XB = 64 * (int)sizeof(TG);
+    TG x0 = reinterpret_cast<const TG*>(xs_b)[lane];
+    TG x1 = reinterpret_cast<const TG*>(xs_b + dp4 * XB)[lane];
+    TG l[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) l[t] = xb[(t * dp4) * 64 + lane];
+    for (int c = 0; c < dp4; ++c) {
+      TG x0n = x0, x1n = x1, ln[CT];
+#pragma unroll
+      for (int t = 0; t < CT; ++t) ln[t] = l[t];
+      if (c + 1 < dp4) {
+        x0n = reinterpret_cast<const TG*>(xs_b + (c + 1) * XB)[lane];
+        x1n = reinterpret_cast<const TG*>(xs_b + (dp4 + c + 1) * XB)[lane];
+#pragma unroll
+        for (int t = 0; t < CT; ++t) ln[t] = xb[(t * dp4 + c + 1) * 64 + lane];
+      }
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        s[0][t] = MG::mma(x0, l[t], s[0][t]);
+        s[1][t] = MG::mma(x1, l[t], s[1][t]);
+      }
+      x0 = x0n;
+      x1 = x1n;
+#pragma unroll
+      for (int t = 0; t < CT; ++t) l[t] = ln[t];
+    }
+  }
+}
 
 // One k-step (32 training points) of the split-bf16 leaf tile is two stretches of very different kind: the
 // GENERATION of this wave's 32 x 32 cross-Gram values (x.x* contraction, kernel map, split into bf16 pieces:
@@ -861,15 +984,15 @@ __device__ __forceinline__ void gen_poly_coeffs(float variance, float (&vc)[3]) 
   vc[1] = variance * kLn2;
   vc[2] = variance * (kLn2 * kLn2 / 3.0f);
 }
-template <int NS, typename TG, int KERNEL, bool F16, bool DIAG, int CT = 2>
+template <int NS, typename TG, int KERNEL, bool F16, bool DIAG, bool C16 = false, int CT = 2>
 __device__ __forceinline__ void leaf_bf16_gen(int lane, int dp4,
                                               const unsigned char* xs_b /* [2][dp4] X fragments | norms | alpha */,
-                                              const TG* xb, const TG (&nb)[CT] /* SC |x*|^2 */, const float (&vc)[3],
-                                              bf16x8 (&bfrag)[NS][CT], float (&macc)[CT]) {
+                                              const TG* xb, const TG (&nb)[CT] /* SC |x*|^2 */, const TG cm /* -2 SC (C16: x 2^-2sx) */,
+                                              const float (&vc)[3], bf16x8 (&bfrag)[NS][CT], float (&macc)[CT]) {
   using MG = Mfma<TG>;
   using vecG = typename MG::vec4;
-  constexpr int XB = 64 * (int)sizeof(TG);
   constexpr TG SC = (TG)GenScale<KERNEL>::SC;
+  const int XF = Bf16Lds<TG, C16>::xfrag(dp4);
   // ---- generate the two 16-point tiles of this k-step (TG) --------------------------------------
   vecG s[2][CT];
 #pragma unroll
@@ -878,39 +1001,14 @@ __device__ __forceinline__ void leaf_bf16_gen(int lane, int dp4,
     for (int t = 0; t < CT; ++t) s[h][t] = vecG{0, 0, 0, 0};
   // norms and alpha of the 32 points of this k-step arrived in LDS with the panel (no ordinary global
   // load inside the loop: one issued after the LDS-DMA makes hipcc drain the DMA queue at its use)
-  const TG* nrm = reinterpret_cast<const TG*>(xs_b + 2 * dp4 * XB);
-  const float* alp = reinterpret_cast<const float*>(xs_b + 2 * dp4 * XB + 64 * sizeof(TG));
-  // the contraction, software-pipelined over the groups of four dimensions: the operands of group c + 1 (and, in front
-  // of everything, the norms) are on their way from LDS while the MFMAs of group c issue -- a generator wave's step is a
-  // latency chain, not an issue budget (stamps: tools/micro/leaf_spec_phases.hip)
+  const TG* nrm = reinterpret_cast<const TG*>(xs_b + XF);
+  const float* alp = reinterpret_cast<const float*>(xs_b + XF + 64 * sizeof(TG));
+  // the contraction (the norms are fetched in front of it: a generator wave's step is a latency chain, not an issue
+  // budget -- stamps: tools/micro/leaf_spec_phases.hip)
   vecG nav[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) nav[h] = *reinterpret_cast<const vecG*>(nrm + 16 * h + 4 * (lane >> 4));
-  TG x0 = reinterpret_cast<const TG*>(xs_b)[lane];
-  TG x1 = reinterpret_cast<const TG*>(xs_b + dp4 * XB)[lane];
-  TG l[CT];
-#pragma unroll
-  for (int t = 0; t < CT; ++t) l[t] = xb[(t * dp4) * 64 + lane];
-  for (int c = 0; c < dp4; ++c) {
-    TG x0n = x0, x1n = x1, ln[CT];
-#pragma unroll
-    for (int t = 0; t < CT; ++t) ln[t] = l[t];
-    if (c + 1 < dp4) {
-      x0n = reinterpret_cast<const TG*>(xs_b + (c + 1) * XB)[lane];
-      x1n = reinterpret_cast<const TG*>(xs_b + (dp4 + c + 1) * XB)[lane];
-#pragma unroll
-      for (int t = 0; t < CT; ++t) ln[t] = xb[(t * dp4 + c + 1) * 64 + lane];
-    }
-#pragma unroll
-    for (int t = 0; t < CT; ++t) {
-      s[0][t] = MG::mma(x0, l[t], s[0][t]);
-      s[1][t] = MG::mma(x1, l[t], s[1][t]);
-    }
-    x0 = x0n;
-    x1 = x1n;
-#pragma unroll
-    for (int t = 0; t < CT; ++t) l[t] = ln[t];
-  }
+  leaf_contract<TG, C16, CT>(lane, dp4, xs_b, xb, s);
   float p[CT][8];
   // stage 0: u = SC r^2, GPflow's GEMM form combined in TG, rounded to float
 #pragma unroll
@@ -919,7 +1017,7 @@ __device__ __forceinline__ void leaf_bf16_gen(int lane, int dp4,
 #pragma unroll
     for (int t = 0; t < CT; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) p[t][4 * h + r] = (float)fma_t((TG)(TG(-2) * SC), s[h][t][r], na[r] + nb[t]);
+      for (int r = 0; r < 4; ++r) p[t][4 * h + r] = (float)fma_t(cm, s[h][t][r], na[r] + nb[t]);
   }
   __builtin_amdgcn_sched_barrier(0);
   float e[CT][8];
@@ -1030,18 +1128,19 @@ __device__ __forceinline__ void leaf_bf16_apply(int q, int q_diag0, int lane, co
 // stream, one workgroup barrier per step.  Same operations on the same operands as the two-phase step: bit-identical
 // partial sums (tests/test_gpu_parity.py compares the two kernels).
 // GMODE: 0 = nothing to generate (last step), 1 = generate step q + 1, 2 = ... and accumulate its share of k*.alpha
-template <int NS, typename TG, int KERNEL, bool F16, bool ADIAG, int GMODE>
+template <int NS, typename TG, int KERNEL, bool F16, bool ADIAG, int GMODE, bool C16 = false>
 __device__ __forceinline__ void leaf_bf16_fused_step(int q, int q_diag0, int lane, int dp4,
                                                      const u32x4* panel_b /* [NS][16][64]: L^-1 pieces of step q */,
                                                      const unsigned char* xs_n /* inputs of step q + 1 */, const TG* xb,
-                                                     const TG (&nb)[2], const float (&vc)[3], const bf16x8 (&bcur)[NS][2],
-                                                     bf16x8 (&bnxt)[NS][2], f32x4 (&acc)[16][2], float (&macc)[2]) {
+                                                     const TG (&nb)[2], const TG cm, const float (&vc)[3],
+                                                     const bf16x8 (&bcur)[NS][2], bf16x8 (&bnxt)[NS][2],
+                                                     f32x4 (&acc)[16][2], float (&macc)[2]) {
   using MG = Mfma<TG>;
   using vecG = typename MG::vec4;
   constexpr int RT = 16, CT = 2;
-  constexpr int XB = 64 * (int)sizeof(TG);
   constexpr TG SC = (TG)GenScale<KERNEL>::SC;
   constexpr bool GEN = GMODE != 0;
+  const int XF = Bf16Lds<TG, C16>::xfrag(dp4);
   // ---- contraction of step q + 1 (TG), software-pipelined over the groups of four dimensions ------------------------
   vecG s[2][CT];
   vecG nav[2];
@@ -1050,34 +1149,10 @@ __device__ __forceinline__ void leaf_bf16_fused_step(int q, int q_diag0, int lan
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int t = 0; t < CT; ++t) s[h][t] = vecG{0, 0, 0, 0};
-    const TG* nrm = reinterpret_cast<const TG*>(xs_n + 2 * dp4 * XB);
+    const TG* nrm = reinterpret_cast<const TG*>(xs_n + XF);
 #pragma unroll
     for (int h = 0; h < 2; ++h) nav[h] = *reinterpret_cast<const vecG*>(nrm + 16 * h + 4 * (lane >> 4));
-    TG x0 = reinterpret_cast<const TG*>(xs_n)[lane];
-    TG x1 = reinterpret_cast<const TG*>(xs_n + dp4 * XB)[lane];
-    TG l[CT];
-#pragma unroll
-    for (int t = 0; t < CT; ++t) l[t] = xb[(t * dp4) * 64 + lane];
-    for (int c = 0; c < dp4; ++c) {
-      TG x0n = x0, x1n = x1, ln[CT];
-#pragma unroll
-      for (int t = 0; t < CT; ++t) ln[t] = l[t];
-      if (c + 1 < dp4) {
-        x0n = reinterpret_cast<const TG*>(xs_n + (c + 1) * XB)[lane];
-        x1n = reinterpret_cast<const TG*>(xs_n + (dp4 + c + 1) * XB)[lane];
-#pragma unroll
-        for (int t = 0; t < CT; ++t) ln[t] = xb[(t * dp4 + c + 1) * 64 + lane];
-      }
-#pragma unroll
-      for (int t = 0; t < CT; ++t) {
-        s[0][t] = MG::mma(x0, l[t], s[0][t]);
-        s[1][t] = MG::mma(x1, l[t], s[1][t]);
-      }
-      x0 = x0n;
-      x1 = x1n;
-#pragma unroll
-      for (int t = 0; t < CT; ++t) l[t] = ln[t];
-    }
+    leaf_contract<TG, C16, CT>(lane, dp4, xs_n, xb, s);
   }
   // ---- apply of step q, the map of step q + 1 dealt over row tiles 1 .. 15 --------------------------------------------
   // value e = 8 t + j, j = 4 h + r (column tile t, 16-point half h, accumulator register r); ops in stage-major order --
@@ -1092,7 +1167,7 @@ __device__ __forceinline__ void leaf_bf16_fused_step(int q, int q_diag0, int lan
   f32x4 al4[2];
   u32x4 fr[NS][CT];
   if constexpr (GMODE == 2) {
-    const float* alp = reinterpret_cast<const float*>(xs_n + 2 * dp4 * XB + 64 * sizeof(TG));
+    const float* alp = reinterpret_cast<const float*>(xs_n + XF + 64 * sizeof(TG));
 #pragma unroll
     for (int h = 0; h < 2; ++h) al4[h] = *reinterpret_cast<const f32x4*>(alp + 16 * h + 4 * (lane >> 4));
   }
@@ -1102,7 +1177,7 @@ __device__ __forceinline__ void leaf_bf16_fused_step(int q, int q_diag0, int lan
       na[o >> 2][o & 3] = nav[o >> 2][o & 3] * SC;
     } else if constexpr (o < O_SQRT) {
       constexpr int e = o - O_COMB, t = e >> 3, h = (e >> 2) & 1, r = e & 3;
-      p[t][4 * h + r] = (float)fma_t((TG)(TG(-2) * SC), s[h][t][r], na[h][r] + nb[t]);
+      p[t][4 * h + r] = (float)fma_t(cm, s[h][t][r], na[h][r] + nb[t]);
     } else if constexpr (o < O_EXP) {
       constexpr int e = o - O_SQRT, t = e >> 3, j = e & 7;
       if constexpr (sizeof(TG) == 4) p[t][j] = __builtin_amdgcn_sqrtf(__builtin_fabsf(p[t][j]));
@@ -1173,13 +1248,15 @@ __device__ __forceinline__ void leaf_bf16_fused_step(int q, int q_diag0, int lan
 // 2^-sa (device, written by pack_linv_f16_kernel) and inv_scale_b = 2^-sb
 // FUSED: every wave runs the fused step (apply of step q with the generation of step q + 1 in its MFMA shadows, one
 // barrier per step); otherwise round 3's two-phase step with the waves of a SIMD in opposite order
-template <int NS, typename TG, int KERNEL, bool F16 = false, bool FUSED = false>
+// C16: the contraction on the fp16 pipe -- xs_p then points at the fp16 piece pairs of the scaled inputs
+// (pack_xs_f16_kernel's order) and c16_scale at their scale (device: [1] = 2^sx, [2] = 2^-2sx)
+template <int NS, typename TG, int KERNEL, bool F16 = false, bool FUSED = false, bool C16 = false>
 __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     const u32x4* __restrict__ linv_b, const TG* __restrict__ xs_p, const TG* __restrict__ xnorm,
     const float* __restrict__ alpha, const TG* __restrict__ leaves_s,
     const TG* __restrict__ lnorm, double* __restrict__ part_var, double* __restrict__ part_mean,
     int npad16, int dp4, int64_t mpad, int nbi, float variance, const int64_t* __restrict__ m_live,
-    const float* __restrict__ inv_scale_a, float inv_scale_b) {
+    const float* __restrict__ inv_scale_a, float inv_scale_b, const float* __restrict__ c16_scale) {
   constexpr int RT = 16, CT = 2, NW = 8;
   constexpr TG SC = (TG)GenScale<KERNEL>::SC;
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -1188,8 +1265,10 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   unsigned char* xsl = reinterpret_cast<unsigned char*>(panel + 2 * NS * RT * 64);  // [3] X buffers
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int xstride = Bf16Lds<TG>::xbytes(dp4);
-  TG* xb = reinterpret_cast<TG*>(xsl + 3 * xstride) + (size_t)wave * CT * dp4 * 64;  // [CT][dp4][64] per wave
+  const int xstride = Bf16Lds<TG, C16>::xbytes(dp4);
+  const int xfrag = Bf16Lds<TG, C16>::xfrag(dp4);
+  // this wave's leaf fragments: [CT][dp4][64] TG, or (C16) [CT][chunk][piece][64] x 16 bytes
+  TG* xb = reinterpret_cast<TG*>(xsl + 3 * xstride + (size_t)wave * xfrag);
 
   const int bi = nbi - 1 - (int)blockIdx.y;
   const int64_t col0 = ((int64_t)blockIdx.x * NW + wave) * (CT * 16);
@@ -1244,22 +1323,28 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   // (<= 32 pieces: D <= 48 in float, <= 32 in double -- checked at launch); DMA wave w moves pieces w + DW jj.  The last
   // but one DMA wave also moves the 32 norms (TG, as 64 dwords; float: lanes 32-63 fetch duplicates into the unused
   // half), the last one the 32 alphas 64 TG behind them.
-  const int xpieces = 2 * dp4 * ((int)sizeof(TG) / 4);
+  // C16: the fragments are 4 ceil(D / 32) <= 8 pieces of 1 KB, one 16-byte DMA each, dealt the same way.
+  constexpr int XPB = C16 ? 1024 : 256;  // bytes of an X piece
+  const int xpieces = xfrag / XPB;
   const unsigned char* xs_bytes = reinterpret_cast<const unsigned char*>(xs_p);
-  const size_t xstep = (size_t)2 * dp4 * 64 * sizeof(TG);
+  const size_t xstep = (size_t)xfrag;
   const int xmine = dma_wave ? (xpieces - wave + DW - 1) / DW : 0;  // how many of the pieces w, w + DW, ... exist
   auto issue_x = [&](int q) {
     if (!dma_wave) return;
     unsigned char* xd = xsl + (q % 3) * xstride;
     if (xmine > 0) {
-      const unsigned char* src = uniform(xs_bytes + (size_t)q * xstep + wave * 256 + 4096);
-      unsigned char* centre = xd + wave * 256 + 4096;
-      static_for<0, 32 / DW>([&](auto jj_) {
+      const unsigned char* src = uniform(xs_bytes + (size_t)q * xstep + wave * XPB + 4096);
+      unsigned char* centre = xd + wave * XPB + 4096;
+      static_for<0, (C16 ? 8 : 32) / DW>([&](auto jj_) {
         constexpr int jj = decltype(jj_)::value;
-        if (xmine > jj) glds4_off<jj * DW * 256 - 4096>(src + lane4, centre);
+        if constexpr (C16) {
+          if (xmine > jj) glds16_off<jj * DW * 1024 - 4096>(src + lane16, centre);
+        } else {
+          if (xmine > jj) glds4_off<jj * DW * 256 - 4096>(src + lane4, centre);
+        }
       });
     }
-    unsigned char* nd = xd + (size_t)xpieces * 256;
+    unsigned char* nd = xd + xfrag;
     if (wave == DW - 2) {
       const int nlane = (sizeof(TG) == 8) ? lane4 : (lane & 31) * 4;
       glds4_off<0>(uniform(reinterpret_cast<const unsigned char*>(xnorm + 32 * q)) + nlane, nd);
@@ -1271,10 +1356,37 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   issue_panel(0, 0);
   issue_x(0);
   if (1 < q_end) issue_x(1);
-  for (int t = 0; t < CT; ++t)
-    for (int c = 0; c < dp4; ++c)
-      xb[(t * dp4 + c) * 64 + lane] =
-          leaves_s[(col0 + t * 16 + (lane & 15)) * dp + 4 * c + (lane >> 4)];
+  TG cm = TG(-2) * SC;
+  if constexpr (C16) {
+    // the leaves' side of the fp16 contraction: B operand of the 16x16x32 instruction, lane l element j = leaf
+    // col0 + 16 t + (l & 15), dimension 32 cc + 8 (l >> 4) + j, scaled like the training side and split the same way
+    const float up = c16_scale[1];
+    cm *= (TG)c16_scale[2];
+    const int nc = (dp4 + 7) >> 3;
+    u32x4* xb16 = reinterpret_cast<u32x4*>(xb);
+    for (int t = 0; t < CT; ++t)
+      for (int cc = 0; cc < nc; ++cc) {
+        const TG* src = leaves_s + (col0 + t * 16 + (lane & 15)) * dp;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = 32 * cc + 8 * (lane >> 4) + j;
+          v[j] = k < dp ? fminf(fmaxf((float)src[k] * up, -60000.0f), 60000.0f) : 0.0f;
+        }
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+          u32x4 f;
+#pragma unroll
+          for (int h = 0; h < 4; ++h) f[h] = f16_split_pair(v[2 * h], v[2 * h + 1]);
+          xb16[((t * nc + cc) * 2 + pc) * 64 + lane] = f;
+        }
+      }
+  } else {
+    for (int t = 0; t < CT; ++t)
+      for (int c = 0; c < dp4; ++c)
+        xb[(t * dp4 + c) * 64 + lane] =
+            leaves_s[(col0 + t * 16 + (lane & 15)) * dp + 4 * c + (lane >> 4)];
+  }
   TG nb[CT];
 #pragma unroll
   for (int t = 0; t < CT; ++t) nb[t] = lnorm[col0 + t * 16 + (lane & 15)] * SC;
@@ -1298,8 +1410,8 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     // (into the buffer step q - 1 was applied from) and of the inputs of step q + 2 (ring of three) are issued, then
     // the fused step applies step q and generates step q + 1.  Step 0 is generated on its own.
     bf16x8 bnxt[NS][CT];
-    if (q_diag0 == 0) leaf_bf16_gen<NS, TG, KERNEL, F16, true>(lane, dp4, xsl, xb, nb, vc, bfrag, macc);
-    else leaf_bf16_gen<NS, TG, KERNEL, F16, false>(lane, dp4, xsl, xb, nb, vc, bfrag, macc);
+    if (q_diag0 == 0) leaf_bf16_gen<NS, TG, KERNEL, F16, true, C16>(lane, dp4, xsl, xb, nb, cm, vc, bfrag, macc);
+    else leaf_bf16_gen<NS, TG, KERNEL, F16, false, C16>(lane, dp4, xsl, xb, nb, cm, vc, bfrag, macc);
     // Measured and NOT kept (tools/ab_time.py, same box, f16x3 at C3: two-phase 0.850 | this 0.7955 ms): the step's DMAs
     // dealt behind the MFMAs of row tiles 1, 2, ... like the map (+2 %); a ring of THREE buffers of L^-1 pieces with the
     // DMAs of step q + 2 issued at the tail of step q behind a raw s_barrier (0.7973); the SIMD's issue priority handed
@@ -1311,9 +1423,10 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     GPSO_BSTAMP(q, 0);                                                                                                \
     issue_for(q);                                                                                                     \
     GPSO_BSTAMP(q, 1);                                                                                                \
-    leaf_bf16_fused_step<NS, TG, KERNEL, F16, ADIAG, GMODE>(q, q_diag0, lane, dp4, panel + (q & 1) * NS * RT * 64,    \
-                                                            xsl + ((q + 1) % 3) * xstride, xb, nb, vc, bfrag, bnxt,   \
-                                                            acc, macc);                                               \
+    leaf_bf16_fused_step<NS, TG, KERNEL, F16, ADIAG, GMODE, C16>(q, q_diag0, lane, dp4,                               \
+                                                                 panel + (q & 1) * NS * RT * 64,                      \
+                                                                 xsl + ((q + 1) % 3) * xstride, xb, nb, cm, vc,       \
+                                                                 bfrag, bnxt, acc, macc);                             \
     GPSO_BSTAMP(q, 4);                                                                                                \
     __syncthreads();                                                                                                  \
     GPSO_BSTAMP(q, 5);                                                                                                \
@@ -1346,7 +1459,7 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     if (!ahead || q == 0) issue_for(q);                                                                               \
     else if (q >= 2) issue_for(q - 1); /* (this wave's iteration q starts in interval q - 1) */                       \
     GPSO_BSTAMP(q, 1);                                                                                                \
-    leaf_bf16_gen<NS, TG, KERNEL, F16, DIAGF>(lane, dp4, xsl + (q % 3) * xstride, xb, nb, vc, bfrag, macc);           \
+    leaf_bf16_gen<NS, TG, KERNEL, F16, DIAGF, C16>(lane, dp4, xsl + (q % 3) * xstride, xb, nb, cm, vc, bfrag, macc);  \
     GPSO_BSTAMP(q, 2);                                                                                                \
     if (ahead && q > 0) __syncthreads();                                                                              \
     GPSO_BSTAMP(q, 3);                                                                                                \
@@ -1393,16 +1506,17 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   }
 }
 
-template <int NS, typename TG, bool F16 = false>
+template <int NS, typename TG, bool F16 = false, bool C16 = false>
 static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const TG* xs_p,
                                      const TG* xnorm, const float* alpha, const TG* leaves_s,
                                      const TG* lnorm, double* part_var, double* part_mean,
                                      int64_t npad, int dp4, int64_t mpad, const KernParams& kp,
-                                     const int64_t* m_live, const float* inv_scale_a = nullptr, int variant = 0) {
+                                     const int64_t* m_live, const float* inv_scale_a = nullptr, int variant = 0,
+                                     const float* c16_scale = nullptr) {
   const int nbi = (int)(npad / 256);
   const dim3 grid((unsigned)(mpad / 256), (unsigned)nbi);
-  const size_t lds = leaf_bf16_lds_bytes(NS, dp4, (int)sizeof(TG));
-  if (2 * dp4 * (int)(sizeof(TG) / 4) > 32) {  // the X fragments of a k-step are one DMA window of 32 pieces
+  const size_t lds = leaf_bf16_lds_bytes(NS, dp4, (int)sizeof(TG), C16);
+  if (C16 ? leaf_c16_chunks(dp4) > 2 : 2 * dp4 * (int)(sizeof(TG) / 4) > 32) {  // the X fragments of a k-step are one DMA window of 32 pieces (C16: 8)
     note_launch_error("launch_leaf_tiles_bf16: more than 32 X pieces per k-step");
     return 1;
   }
@@ -1414,12 +1528,12 @@ static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const T
   // variant 0 (GPSO_SPLIT_KERNEL_AUTO): the fused step; 1: round 3's two-phase step.  Same bits either way.
 #define GPSO_L2(K, FUSED)                                                                           \
   do {                                                                                              \
-    const int rc = ensure_dyn_lds((const void*)leaf_tiles_bf16_kernel<NS, TG, K, F16, FUSED>, (int)lds); \
+    const int rc = ensure_dyn_lds((const void*)leaf_tiles_bf16_kernel<NS, TG, K, F16, FUSED, C16>, (int)lds); \
     if (rc) return rc;                                                                              \
-    hipLaunchKernelGGL((leaf_tiles_bf16_kernel<NS, TG, K, F16, FUSED>), grid, dim3(512), lds, st,   \
+    hipLaunchKernelGGL((leaf_tiles_bf16_kernel<NS, TG, K, F16, FUSED, C16>), grid, dim3(512), lds, st, \
                        static_cast<const u32x4*>(linv_b), xs_p, xnorm, alpha, leaves_s, lnorm,      \
                        part_var, part_mean, (int)(npad / 16), dp4, mpad, nbi, var_arg, m_live,      \
-                       inv_scale_a, inv_b);                                                         \
+                       inv_scale_a, inv_b, c16_scale);                                              \
   } while (0)
 #define GPSO_L(K)                                                                                   \
   do {                                                                                              \
@@ -1442,15 +1556,20 @@ int launch_leaf_tiles_bf16(hipStream_t st, int nsplit, const void* linv_b, const
                            const TG* xnorm, const float* alpha, const TG* leaves_s,
                            const TG* lnorm, double* part_var, double* part_mean, int64_t npad,
                            int dp4, int64_t mpad, const KernParams& kp, const int64_t* m_live,
-                           const float* f16_inv_scale_a, int variant) {
-  if (f16_inv_scale_a != nullptr)  // fp16 split (nsplit == 2 pieces)
+                           const float* f16_inv_scale_a, int variant, const void* xs_h16, const float* c16_scale) {
+  if (f16_inv_scale_a != nullptr) {  // fp16 split (nsplit == 2 pieces)
+    if constexpr (sizeof(TG) == 4) {
+      if (xs_h16 != nullptr && c16_scale != nullptr)  // ... with the contraction on the fp16 pipe as well
+        return launch_leaf_tiles_bf16_ns<2, TG, true, true>(st, linv_b, static_cast<const TG*>(xs_h16), xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, variant, c16_scale);
+    }
     return launch_leaf_tiles_bf16_ns<2, TG, true>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, variant);
+  }
   if (nsplit == 3)
     return launch_leaf_tiles_bf16_ns<3, TG>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, nullptr, variant);
   return launch_leaf_tiles_bf16_ns<2, TG>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, nullptr, variant);
 }
-template int launch_leaf_tiles_bf16<float>(hipStream_t, int, const void*, const float*, const float*, const float*, const float*, const float*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*, const float*, int);
-template int launch_leaf_tiles_bf16<double>(hipStream_t, int, const void*, const double*, const double*, const float*, const double*, const double*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*, const float*, int);
+template int launch_leaf_tiles_bf16<float>(hipStream_t, int, const void*, const float*, const float*, const float*, const float*, const float*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*, const float*, int, const void*, const float*);
+template int launch_leaf_tiles_bf16<double>(hipStream_t, int, const void*, const double*, const double*, const float*, const double*, const double*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*, const float*, int, const void*, const float*);
 
 template <typename TF>
 void launch_pack_linv_bf16(hipStream_t st, int nsplit, const TF* linv, int64_t n, int64_t npad,

@@ -113,6 +113,11 @@ class HipGPEngine:
         """GPSO_OPT_SPLIT_KERNEL: "auto" (the fused step) | "two-phase" (round 3's step): same bits, different speed."""
         self._check(self._lib.gpso_set_option(self._h, L.OPT_SPLIT_KERNEL, {"auto": 0, "two-phase": 1}[which]))
 
+    def set_contraction(self, which):
+        """GPSO_OPT_CONTRACTION: "auto" (the x.x* contraction of the fp16-split kernel on the fp16 pipe where that is
+        faster: 8 < D <= 64) | "f32" (always the f32 matrix instruction) | "f16" (the fp16 pipe wherever it applies)."""
+        self._check(self._lib.gpso_set_option(self._h, L.OPT_CONTRACTION, {"auto": 0, "f32": 1, "f16": 2}[which]))
+
     def set_small_calls(self, on):
         """GPSO_OPT_SMALL_CALLS: the short launch sequences for best-UCB calls on small batches (default on; same bits).
         True / 1: three launches, or one where that measures faster; 2: three only; 3: one wherever it applies; 0: general."""

@@ -691,8 +691,13 @@ def test_config_C5_one_gpu_share_at_size(noise):
     assert np.max(np.abs(mt - y[:512])) < 0.5 and np.all(vt < 4 * th.noise + 1e-3)
     # the mean never goes through the split: identical in both split modes
     assert np.array_equal(results["bf16x6"][0], results["bf16x3"][0])
-    # (the fp16 split scales the generated tile by a power of two -- exact -- and undoes it on the partial sums in double)
-    assert np.max(np.abs(results["f16x3"][0] - results["bf16x6"][0])) <= 1e-12 * ys
+    # (the fp16 split scales the generated tile by a power of two -- exact -- and undoes it on the partial sums in double:
+    # with the same contraction its mean is the bf16 modes'; by default it contracts x.x* on the fp16 pipe: float class)
+    assert np.max(np.abs(results["f16x3"][0] - results["bf16x6"][0])) <= 2 * bm * ys
+    eng.set_predict_math("f16x3")
+    eng.set_contraction("f32")
+    assert np.max(np.abs(eng.predict(Xs)[0] - results["bf16x6"][0])) <= 1e-12 * ys
+    eng.set_contraction("auto")
     assert np.max(np.abs(results["bf16x6"][1] - results["native"][1])) <= 5e-5
     assert np.max(np.abs(results["f16x3"][1] - results["native"][1])) <= 5e-5
     assert np.max(np.abs(results["bf16x3"][1] - results["native"][1])) <= 2e-4
@@ -864,16 +869,19 @@ def test_run_to_run_determinism_c3_g7(math, tol_var):
         eng.close()
 
 
-@pytest.mark.parametrize("dtype,math,gen", [("float32", "f16x3", "float32"), ("mixed", "f16x3", "float64"), ("float32", "bf16x3", "float32"),
-                                            ("mixed", "bf16x3", "float64"), ("float32", "bf16x6", "float32"), ("mixed", "bf16x6", "float64")])
+@pytest.mark.parametrize("dtype,math,gen,contraction",
+                         [("float32", "f16x3", "float32", "auto"), ("float32", "f16x3", "float32", "f32"), ("float32", "f16x3", "float32", "f16"),
+                          ("mixed", "f16x3", "float64", "auto"), ("float32", "bf16x3", "float32", "auto"), ("mixed", "bf16x3", "float64", "auto"),
+                          ("float32", "bf16x6", "float32", "auto"), ("mixed", "bf16x6", "float64", "auto")])
 @pytest.mark.parametrize("n,d,m,kernel", [(256, 6, 1000, "Matern52"), (2048, 12, 4096, "Matern52"), (768, 3, 700, "Matern32"),
                                           (512, 24, 513, "SquaredExponential"), (1024, 40, 300, "Matern12"), (512, 1, 257, "Matern52")])
-def test_fused_step_kernel_gives_the_bits_of_the_two_phase_kernel(dtype, math, gen, n, d, m, kernel):
+def test_fused_step_kernel_gives_the_bits_of_the_two_phase_kernel(dtype, math, gen, contraction, n, d, m, kernel):
     """Round 4: the split kernels run the FUSED step (every wave applies step q with the generation of step q + 1 dealt
     into its MFMA shadows, one barrier per step) instead of round 3's two-phase step (generation and apply as two
     stretches, the waves of a SIMD in opposite order).  Same operations on the same operands in the same order --
     means, variances and winners must be the SAME BITS, for float and double generation, every kernel family, ragged
-    leaf counts, several row blocks, segments and on-device growth."""
+    leaf counts, several row blocks, segments and on-device growth; with the x.x* contraction of the fp16 split on the
+    f32 matrix instruction and on the fp16 pipe (GPSO_OPT_CONTRACTION)."""
     from pygpso_amd import HipGPEngine
 
     X, y, th = _problem(n, d, kernel, noise=1e-3, variance=1.7)
@@ -882,6 +890,7 @@ def test_fused_step_kernel_gives_the_bits_of_the_two_phase_kernel(dtype, math, g
     for which in ("auto", "two-phase"):
         eng = HipGPEngine(dtype, predict_math=math, generation=gen, precision_check=False)
         eng.set_split_kernel(which)
+        eng.set_contraction(contraction)
         _fit(eng, X, y, th, grad=False)
         if n % 256 == 0 and not (gen == "float64" and d >= (24 if math == "bf16x6" else 36)):
             assert eng.precision_info()["predict_math"] == math  # (the split kernel really runs)
@@ -900,6 +909,42 @@ def test_fused_step_kernel_gives_the_bits_of_the_two_phase_kernel(dtype, math, g
     post = gpr.posterior(th, X, y)
     mean_ref, var_ref = gpr.predict_y(post, Xs)
     assert np.max(np.abs(a[0] - mean_ref)) <= 2e-3 * max(1.0, np.max(np.abs(y))) and np.max(np.abs(a[1] - var_ref)) <= 2e-4 * th.variance
+
+
+@pytest.mark.parametrize("n,d,m,kernel", [(256, 6, 1000, "Matern52"), (2048, 12, 4096, "Matern52"), (768, 20, 700, "Matern32"),
+                                          (512, 33, 513, "SquaredExponential"), (1024, 40, 300, "Matern52"), (512, 48, 257, "Matern52"),
+                                          (256, 2, 300, "Matern52")])
+def test_fp16_contraction_is_in_the_float_class_and_survives_far_leaves(n, d, m, kernel):
+    """Round 4: under float generation the fp16-split kernel contracts x.x* on the fp16 pipe (the scaled inputs split
+    into fp16 piece pairs like L^-1; GPSO_OPT_CONTRACTION).  Against the float64 oracle its error is in the class of the
+    f32 contraction's (within 2x + a floor, both inside the bounds the fused-step test uses); the option is live (other
+    bits); and leaves far outside the training range -- where
+    the scaled leaf saturates fp16 -- come back finite with the prior's variance, as from the f32 contraction."""
+    from pygpso_amd import HipGPEngine
+
+    X, y, th = _problem(n, d, kernel, noise=1e-3, variance=1.7)
+    Xs = synthetic_leaves(m, d, seed=5)
+    far = np.concatenate([Xs[:64] * 300.0, -Xs[:64] * 1e4, Xs[:64] + 3.0])
+    post = gpr.posterior(th, X, y)
+    mean_ref, var_ref = gpr.predict_y(post, Xs)
+    mean_far, var_far = gpr.predict_y(post, far)
+    res = {}
+    for which in ("f16", "f32"):
+        eng = HipGPEngine("float32", predict_math="f16x3", generation="float32", precision_check=False)
+        eng.set_contraction(which)
+        _fit(eng, X, y, th, grad=False)
+        assert eng.precision_info()["predict_math"] == "f16x3"
+        res[which] = eng.predict(Xs) + eng.predict(far)
+        eng.close()
+    err = {w: (np.max(np.abs(r[0] - mean_ref)), np.max(np.abs(r[1] - var_ref))) for w, r in res.items()}
+    ymax = max(1.0, np.max(np.abs(y)))
+    for w in err:
+        assert err[w][0] <= 2e-3 * ymax and err[w][1] <= 2e-4 * th.variance, (w, err)
+    assert err["f16"][0] <= 2 * err["f32"][0] + 2e-5 * ymax and err["f16"][1] <= 2 * err["f32"][1] + 2e-6 * th.variance, err
+    assert not np.array_equal(res["f16"][1], res["f32"][1]), "the option changes the arithmetic"
+    for w, r in res.items():
+        assert np.all(np.isfinite(r[2])) and np.all(np.isfinite(r[3])), w
+        assert np.max(np.abs(r[2] - mean_far)) <= 2e-3 * ymax and np.max(np.abs(r[3] - var_far)) <= 2e-4 * th.variance, w
 
 
 @pytest.mark.parametrize("dtype", ["float64", "mixed", "float32"])
