@@ -108,9 +108,9 @@ typedef struct gpso_ctx gpso_ctx;
                                    /* launch wherever it applies (N_pad = 128 too); 0: always the general sequence (2      */
                                    /* copies in, 5 launches, a copy back).  Same bits in all (tests/test_gpu_parity.py)    */
 #define GPSO_OPT_CONTRACTION 10    /* the x.x* contraction of the fp16-split kernel (GPSO_MATH_F16X3) under float         */
-#define GPSO_CONTRACTION_AUTO 0    /*   generation: 0 (default) on the fp16 pipe where that is faster (8 < D <= 64) -- the */
-#define GPSO_CONTRACTION_F32 1     /*   scaled inputs split into fp16 piece pairs like L^-1, three products; 1: always the */
-#define GPSO_CONTRACTION_F16 2     /*   f32 matrix instruction; 2: the fp16 pipe wherever it applies (D <= 64).  Different */
+#define GPSO_CONTRACTION_AUTO 0    /*   generation: 0 (default) on the fp16 pipe -- the scaled inputs split into fp16      */
+#define GPSO_CONTRACTION_F32 1     /*   piece pairs like L^-1, three products, the training input's norm riding in a spare */
+#define GPSO_CONTRACTION_F16 2     /*   slot; 1: the f32 matrix instruction (rounds 1-3); 2: same as 0 today.  Different  */
                                    /*   roundings of r^2, both inside the float class: the self-test rules on whichever    */
                                    /*   runs                                                                                */
 /* floating-point options (gpso_set_option_f64): tolerances of the self-test */

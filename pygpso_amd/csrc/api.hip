@@ -288,13 +288,11 @@ struct EngineT : Engine {
   bool gen32_inputs_ok = false; // xs32 / xnorm32 / xs_p32 match the resident posterior
   int split_variant = GPSO_SPLIT_KERNEL_AUTO;  // GPSO_OPT_SPLIT_KERNEL
   int contraction = GPSO_CONTRACTION_AUTO;     // GPSO_OPT_CONTRACTION
-  // the x.x* contraction of the fp16-split kernel runs on the fp16 pipe: float generation, D_pad <= 64 (two chunks of 32
-  // dimensions: one DMA window, LDS for the leaf fragments).  AUTO takes it from D_pad = 12: 12 matrix instructions of
-  // 16 clocks per k-step whatever D <= 32, against D_pad / 4 x 4 of 32 clocks -- measured in one process on one
-  // posterior (tools/c16_check.py, profiles/r04_c16_check.jsonl): D = 6 -0.7 %, 12 +3.3 %, 20 +12 %, 33 +21 %, 40 +25 %
+  // the x.x* contraction of the fp16-split kernel runs on the fp16 pipe under float generation (D_pad + 1 slots in at most
+  // two chunks of 32: every D this library accepts).  Measured in one process on one posterior (tools/c16_check.py,
+  // profiles/r04_c16_check.jsonl), fp16 pipe against the f32 instruction: D = 6 +4 %, 12 +8 %, 20 +17 %, 33 +28 %, 40 +30 %
   bool c16_in_use(bool gen64) const {
-    if (!kFloatPredict || gen64 || !f16_split() || contraction == GPSO_CONTRACTION_F32 || dp > 64) return false;
-    if (contraction == GPSO_CONTRACTION_AUTO && dp < 12) return false;
+    if (!kFloatPredict || gen64 || !f16_split() || contraction == GPSO_CONTRACTION_F32 || leaf_c16_chunks(dp / 4) > 2) return false;
     return leaf_bf16_lds_bytes(2, dp / 4, 4, true) <= 160 * 1024;
   }
   bool small_calls = true, one_launch = true, one_launch_everywhere = false;  // GPSO_OPT_SMALL_CALLS
@@ -537,7 +535,7 @@ struct EngineT : Engine {
       if ((rc = ensure(xs32, (size_t)npad * dp * 4))) return rc;
       if ((rc = ensure(xnorm32, (size_t)npad * 4))) return rc;
       if ((rc = ensure(xs_p32, (size_t)npad * dp * 4))) return rc;
-      if ((rc = ensure(xs_h16, (size_t)(npad / 16) * ((dp + 31) / 32) * 2048))) return rc;
+      if ((rc = ensure(xs_h16, (size_t)(npad / 16) * leaf_c16_chunks(dp / 4) * 2048))) return rc;
       if ((rc = ensure(c16_scal, 16))) return rc;
     }
     return GPSO_OK;
@@ -682,7 +680,7 @@ struct EngineT : Engine {
   int ensure_generation_inputs() {
     if (gen_double() || gen32_inputs_ok) return GPSO_OK;
     launch_gen_inputs_f32(st(), as<double>(xs64), npad, dp, as<float>(xs32), as<float>(xnorm32), as<float>(xs_p32));
-    launch_gen_inputs_f16(st(), as<float>(xs32), npad, dp, as<float>(c16_scal), xs_h16.p);
+    launch_gen_inputs_f16(st(), as<float>(xs32), as<float>(xnorm32), npad, dp, as<float>(c16_scal), xs_h16.p);
     gen32_inputs_ok = true;
     return GPSO_OK;
   }

@@ -46,14 +46,15 @@ void launch_pack_linv_bf16(hipStream_t st, int nsplit, const TF* linv, int64_t n
 // fragments, for a generation type of tg_bytes
 // c16: the contraction runs on the fp16 pipe (float generation only): the X fragments of a k-step and the leaf fragments
 // of a wave are fp16 piece pairs of 32-dimension chunks instead of float groups of four dimensions
-inline int leaf_c16_chunks(int dp4) { return (dp4 + 7) / 8; }
+inline int leaf_c16_chunks(int dp4) { return (dp4 + 8) / 8; }  // D_pad inputs + the norm slot, 32 slots per chunk
 inline size_t leaf_bf16_lds_bytes(int nsplit, int dp4, int tg_bytes, bool c16 = false) {
   const size_t xfrag = c16 ? (size_t)leaf_c16_chunks(dp4) * 4096 : (size_t)2 * dp4 * 64 * tg_bytes;
   return (size_t)2 * nsplit * 16 * 64 * 16 + (size_t)3 * (xfrag + 64 * tg_bytes + 256) + (size_t)8 * xfrag;
 }
 // fp16 piece pairs of the float scaled inputs in the fragment order of the fp16 contraction (predict.hip); scal: 4 device
-// floats ([0] max |x / l|, [1] := 2^sx, [2] := 2^-2sx); xs_h16: npad / 16 * ceil(dp / 32) * 2 KB
-void launch_gen_inputs_f16(hipStream_t st, const float* xs32, int64_t npad, int dp, float* scal, void* xs_h16);
+// floats ([0] max |x / l|, [1] := 2^sx, [2] := 2^-2sx); xs_h16: npad / 16 * leaf_c16_chunks * 2 KB
+void launch_gen_inputs_f16(hipStream_t st, const float* xs32, const float* xnorm32, int64_t npad, int dp, float* scal,
+                           void* xs_h16);
 // f16_inv_scale_a != nullptr: the fp16 split (two pieces, three products; predict.hip) -- linv_b and the scale (device,
 // 2 floats: max |L^-1|, 2^-sa) come from launch_pack_linv_f16
 template <typename TG>

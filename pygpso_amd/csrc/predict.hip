@@ -817,9 +817,14 @@ __global__ __launch_bounds__(256) void pack_linv_f16_kernel(const TF* __restrict
 // 384 up to D = 64.  Both sides are scaled by 2^sx (exact) with the largest |x / l| of the TRAINING inputs in [2^7, 2^8):
 // a leaf up to 255 times further out than any training input still fits fp16 (beyond that it saturates: its r^2 is
 // dominated by its own norm, which stays float, and the kernel map underflows either way); the combine multiplies the
-// contraction by -2 SC 2^-2sx.  The norms stay float sums of the unsplit values.
+// contraction by -2 SC 2^-2sx.
+// The TRAINING input's norm rides in the contraction: the chunks hold D_pad + 1 <= 32 C16 slots, slot D_pad of a training
+// row is -|x / l|^2 2^2sx / 2^8 (the float norm, scaled by powers of two, split like every other entry; below 2^14 for
+// D_pad <= 48) and slot D_pad of every leaf is 2^7 (exact in the first piece), so the accumulator arrives as
+// 2^2sx (x.x* - |x|^2 / 2) and the combine is ONE fma per value, u = (-2 SC 2^-2sx) s + SC |x*|^2 -- no norm fetch, no norm
+// scaling, no addition.  The leaf's norm stays a float outside the contraction: its range is not known at packing time.
 // Fragment order of the training side: block (q, h, cc, piece) of 64 lanes x 16 bytes, lane l element j = row
-// 32 q + 16 h + (l & 15), dimension 32 cc + 8 (l >> 4) + j -- the A operand of the 16x16x32 instruction as it stands.
+// 32 q + 16 h + (l & 15), slot 32 cc + 8 (l >> 4) + j -- the A operand of the 16x16x32 instruction as it stands.
 // scal: 4 device floats -- [0] max |x / l| (as float bits, atomicMax), [1] := 2^sx, [2] := 2^-2sx
 __global__ __launch_bounds__(256) void absmax_f32_kernel(const float* __restrict__ v, int64_t count,
                                                          unsigned* __restrict__ out) {
@@ -829,8 +834,9 @@ __global__ __launch_bounds__(256) void absmax_f32_kernel(const float* __restrict
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
   if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(out, __builtin_bit_cast(unsigned, m));
 }
-__global__ __launch_bounds__(256) void pack_xs_f16_kernel(const float* __restrict__ xs, int64_t npad, int dp, int nc,
-                                                          float* __restrict__ scal, u32x4* __restrict__ out) {
+__global__ __launch_bounds__(256) void pack_xs_f16_kernel(const float* __restrict__ xs, const float* __restrict__ xnorm,
+                                                          int64_t npad, int dp, int nc, float* __restrict__ scal,
+                                                          u32x4* __restrict__ out) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // ((q, h), cc, lane)
   int e = 0;
   (void)frexpf(fmaxf(scal[0], 1e-30f), &e);  // max = m 2^e, m in [0.5, 1)
@@ -848,7 +854,7 @@ __global__ __launch_bounds__(256) void pack_xs_f16_kernel(const float* __restric
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int k = 32 * cc + 8 * (lane >> 4) + j;
-    v[j] = k < dp ? xs[row * dp + k] * up : 0.0f;
+    v[j] = k < dp ? xs[row * dp + k] * up : (k == dp ? -((xnorm[row] * up) * up) * (1.0f / 256.0f) : 0.0f);
   }
 #pragma unroll
   for (int s_ = 0; s_ < 2; ++s_) {
@@ -858,36 +864,38 @@ __global__ __launch_bounds__(256) void pack_xs_f16_kernel(const float* __restric
     out[((kt * nc + cc) * 2 + s_) * 64 + lane] = f;
   }
 }
-void launch_gen_inputs_f16(hipStream_t st, const float* xs32, int64_t npad, int dp, float* scal, void* xs_h16) {
-  const int nc = (dp + 31) / 32;
+void launch_gen_inputs_f16(hipStream_t st, const float* xs32, const float* xnorm32, int64_t npad, int dp, float* scal,
+                           void* xs_h16) {
+  const int nc = leaf_c16_chunks(dp / 4);
   (void)hipMemsetAsync(scal, 0, 4, st);
   const int64_t count = npad * dp;
   hipLaunchKernelGGL(absmax_f32_kernel, dim3((unsigned)std::min<int64_t>((count + 255) / 256, 1024)), dim3(256), 0, st,
                      xs32, count, reinterpret_cast<unsigned*>(scal));
   const int64_t total = (npad / 16) * nc * 64;
-  hipLaunchKernelGGL(pack_xs_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, xs32, npad, dp, nc,
-                     scal, static_cast<u32x4*>(xs_h16));
+  hipLaunchKernelGGL(pack_xs_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, xs32, xnorm32, npad,
+                     dp, nc, scal, static_cast<u32x4*>(xs_h16));
 }
 
-template <typename TG, bool C16 = false>
+template <typename TG, int C16 = 0 /* chunks of 32 slots of the fp16 contraction; 0: the contraction in TG */>
 struct Bf16Lds {
   // bytes of the X fragments of one k-step: 2 k-tiles x D_pad / 4 groups (TG), or 2 k-tiles x chunks of 32 dimensions x
   // 2 fp16 pieces x 1 KB (C16); a wave's leaf fragments take as much
-  static __host__ __device__ constexpr int xfrag(int dp4) { return C16 ? ((dp4 + 7) / 8) * 4096 : 2 * dp4 * 64 * (int)sizeof(TG); }
+  static __host__ __device__ constexpr int xfrag(int dp4) { return C16 ? C16 * 4096 : 2 * dp4 * 64 * (int)sizeof(TG); }
   // bytes of one X buffer: the fragments, 32 norms (TG, padded to 64), 32 alphas (float, padded to 64)
   static __host__ __device__ constexpr int xbytes(int dp4) { return xfrag(dp4) + 64 * (int)sizeof(TG) + 256; }
 };
 // the x.x* contraction of one k-step of a wave: s[h][t] += (16 training points of half h) x (16 leaves of column tile t).
 // Float / double: software-pipelined over the groups of four dimensions -- the operands of group c + 1 are on their way
 // from LDS while the MFMAs of group c issue.  C16: three fp16 products per chunk of 32 dimensions, small terms first.
-template <typename TG, bool C16, int CT>
+template <typename TG, int C16, int CT>
 __device__ __forceinline__ void leaf_contract(int lane, int dp4, const unsigned char* xs_b, const TG* xb,
                                               typename Mfma<TG>::vec4 (&s)[2][CT]) {
-  if constexpr (C16) {
+  if constexpr (C16 != 0) {
     static_assert(sizeof(TG) == 4, "the fp16 contraction belongs to float generation");
-    const int nc = (dp4 + 7) >> 3;
+    constexpr int nc = C16;
     const u32x4* xa = reinterpret_cast<const u32x4*>(xs_b);  // [h][cc][piece][64]
     const u32x4* lb = reinterpret_cast<const u32x4*>(xb);    // [t][cc][piece][64]
+#pragma unroll
     for (int cc = 0; cc < nc; ++cc) {
       u32x4 a[2][2], b[CT][2];
 #pragma unroll
@@ -955,7 +963,7 @@ __device__ __forceinline__ void leaf_contract(int lane, int dp4, const unsigned 
 //   * float generation takes sqrt(|u|) (a source modifier) instead of clamping: a GEMM-form r^2 that rounds to -1e-6
 //     is as wrong as one that rounds to +1e-6, and the map's error is the same second-order term either way
 //     (double generation keeps GPflow's clamp: its r^2 is exact to 1e-15);
-//   * the remainders of the fp16 split come from v_fma_mix_f32 (a - (float)h in one instruction, exact);
+//   * the second piece of the fp16 split comes from v_fma_mixlo / mixhi_f16 (a - (float)h, exact, rounded once to fp16);
 //   * stage-major order: all combines, all square roots, all exponentials, all polynomials -- no instruction waits
 //     on the one in front of it.
 // 9 vector instructions per value instead of 14.
@@ -964,17 +972,14 @@ struct GenScale {
   static constexpr double kLog2e = 1.44269504088896340736;
   static constexpr double SC = (KERNEL == 3) ? 0.5 * kLog2e : KernScale<KERNEL>::C2 * kLog2e * kLog2e;
 };
-// (a, b) -> packed fp16 pair (round to nearest even); a, b are replaced by the remainders a - (float)h: exact, so the
-// same bits as f16_split_pair, two instructions fewer per pair
-__device__ __forceinline__ unsigned f16_split_pair_mix(float& a, float& b) {
+// (a, b) -> the packed fp16 pair AND the packed pair of the remainders' fp16 roundings (the second piece of a two-piece
+// split): v_fma_mixlo / mixhi_f16 form a - (float)h exactly and round it once to fp16 into the low / high half -- the
+// bits of f16_split_pair applied twice, three instructions per pair instead of four
+__device__ __forceinline__ void f16_split_pair_both(float a, float b, unsigned& h, unsigned& l) {
   const f32x2 v = {a, b};
-  const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
-  float ra, rb;
-  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(h), "v"(a));
-  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(h), "v"(b));
-  a = ra;
-  b = rb;
-  return h;
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+  asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(a));
+  asm("v_fma_mixhi_f16 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(b));
 }
 // vc: sigma^2 (x 2^sb under the fp16 split) times the polynomial's coefficients in t' (see above)
 template <int KERNEL>
@@ -984,7 +989,7 @@ __device__ __forceinline__ void gen_poly_coeffs(float variance, float (&vc)[3]) 
   vc[1] = variance * kLn2;
   vc[2] = variance * (kLn2 * kLn2 / 3.0f);
 }
-template <int NS, typename TG, int KERNEL, bool F16, bool DIAG, bool C16 = false, int CT = 2>
+template <int NS, typename TG, int KERNEL, bool F16, bool DIAG, int C16 = 0, int CT = 2>
 __device__ __forceinline__ void leaf_bf16_gen(int lane, int dp4,
                                               const unsigned char* xs_b /* [2][dp4] X fragments | norms | alpha */,
                                               const TG* xb, const TG (&nb)[CT] /* SC |x*|^2 */, const TG cm /* -2 SC (C16: x 2^-2sx) */,
@@ -1006,18 +1011,27 @@ __device__ __forceinline__ void leaf_bf16_gen(int lane, int dp4,
   // the contraction (the norms are fetched in front of it: a generator wave's step is a latency chain, not an issue
   // budget -- stamps: tools/micro/leaf_spec_phases.hip)
   vecG nav[2];
+  if constexpr (C16 == 0) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h) nav[h] = *reinterpret_cast<const vecG*>(nrm + 16 * h + 4 * (lane >> 4));
+    for (int h = 0; h < 2; ++h) nav[h] = *reinterpret_cast<const vecG*>(nrm + 16 * h + 4 * (lane >> 4));
+  }
   leaf_contract<TG, C16, CT>(lane, dp4, xs_b, xb, s);
   float p[CT][8];
   // stage 0: u = SC r^2, GPflow's GEMM form combined in TG, rounded to float
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const vecG na = nav[h] * SC;
+    if constexpr (C16 != 0) {  // (the training input's norm arrived inside the contraction)
 #pragma unroll
-    for (int t = 0; t < CT; ++t)
+      for (int t = 0; t < CT; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) p[t][4 * h + r] = (float)fma_t(cm, s[h][t][r], na[r] + nb[t]);
+        for (int r = 0; r < 4; ++r) p[t][4 * h + r] = (float)fma_t(cm, s[h][t][r], nb[t]);
+    } else {
+      const vecG na = nav[h] * SC;
+#pragma unroll
+      for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[t][4 * h + r] = (float)fma_t(cm, s[h][t][r], na[r] + nb[t]);
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
   float e[CT][8];
@@ -1065,17 +1079,28 @@ __device__ __forceinline__ void leaf_bf16_gen(int lane, int dp4,
   }
   // ---- split into bf16 / fp16 pieces: B operands --------------------------------------------------
 #pragma unroll
-  for (int t = 0; t < CT; ++t)
-#pragma unroll
-    for (int sp = 0; sp < NS; ++sp) {
-      u32x4 f;
+  for (int t = 0; t < CT; ++t) {
+    if constexpr (F16) {
+      u32x4 f0, f1;
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
-        if constexpr (F16) f[h] = (sp + 1 < NS) ? f16_split_pair_mix(p[t][2 * h], p[t][2 * h + 1]) : f16_split_pair(p[t][2 * h], p[t][2 * h + 1]);
-        else f[h] = bf16_split_pair(p[t][2 * h], p[t][2 * h + 1]);
+        unsigned hh, ll;
+        f16_split_pair_both(p[t][2 * h], p[t][2 * h + 1], hh, ll);
+        f0[h] = hh;
+        f1[h] = ll;
       }
-      bfrag[sp][t] = __builtin_bit_cast(bf16x8, f);  // (fp16 pieces travel in the same 16-byte registers)
+      bfrag[0][t] = __builtin_bit_cast(bf16x8, f0);  // (fp16 pieces travel in the same 16-byte registers)
+      bfrag[1][t] = __builtin_bit_cast(bf16x8, f1);
+    } else {
+#pragma unroll
+      for (int sp = 0; sp < NS; ++sp) {
+        u32x4 f;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) f[h] = bf16_split_pair(p[t][2 * h], p[t][2 * h + 1]);
+        bfrag[sp][t] = __builtin_bit_cast(bf16x8, f);
+      }
     }
+  }
 }
 
 // apply: acc[rt][t] += sum over the kept piece products, small terms first.  DIAG: k-steps of the diagonal block --
@@ -1102,7 +1127,7 @@ __device__ __forceinline__ void leaf_bf16_apply(int q, int q_diag0, int lane, co
 #define GPSO_BF(SA, SB)                                                                                                   \
   c = F16 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[rt & 1][SA]), __builtin_bit_cast(f16x8, bfrag[SB][t]), c, 0, 0, 0) \
           : __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[rt & 1][SA]), bfrag[SB][t], c, 0, 0, 0)
-      if (NS == 3) {
+      if constexpr (NS == 3) {
         GPSO_BF(2, 0);
         GPSO_BF(0, 2);
         GPSO_BF(1, 1);
@@ -1128,7 +1153,11 @@ __device__ __forceinline__ void leaf_bf16_apply(int q, int q_diag0, int lane, co
 // stream, one workgroup barrier per step.  Same operations on the same operands as the two-phase step: bit-identical
 // partial sums (tests/test_gpu_parity.py compares the two kernels).
 // GMODE: 0 = nothing to generate (last step), 1 = generate step q + 1, 2 = ... and accumulate its share of k*.alpha
-template <int NS, typename TG, int KERNEL, bool F16, bool ADIAG, int GMODE, bool C16 = false>
+// ASKIP: the first ASKIP row tiles of step q are all zero (step j of the diagonal block: 2 j tiles above the diagonal) --
+// a compile-time count: the eight steps of the diagonal block are eight straight-line copies.  With the skip as a
+// run-time test per row tile the compiler kept the accumulators of skipped tiles alive through 74 register-pair moves
+// per step (disassembly), in the steps that already have the least matrix work to hide them behind.
+template <int NS, typename TG, int KERNEL, bool F16, int ASKIP, int GMODE, int C16 = 0>
 __device__ __forceinline__ void leaf_bf16_fused_step(int q, int q_diag0, int lane, int dp4,
                                                      const u32x4* panel_b /* [NS][16][64]: L^-1 pieces of step q */,
                                                      const unsigned char* xs_n /* inputs of step q + 1 */, const TG* xb,
@@ -1149,9 +1178,11 @@ __device__ __forceinline__ void leaf_bf16_fused_step(int q, int q_diag0, int lan
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int t = 0; t < CT; ++t) s[h][t] = vecG{0, 0, 0, 0};
-    const TG* nrm = reinterpret_cast<const TG*>(xs_n + XF);
+    if constexpr (C16 == 0) {
+      const TG* nrm = reinterpret_cast<const TG*>(xs_n + XF);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) nav[h] = *reinterpret_cast<const vecG*>(nrm + 16 * h + 4 * (lane >> 4));
+      for (int h = 0; h < 2; ++h) nav[h] = *reinterpret_cast<const vecG*>(nrm + 16 * h + 4 * (lane >> 4));
+    }
     leaf_contract<TG, C16, CT>(lane, dp4, xs_n, xb, s);
   }
   // ---- apply of step q, the map of step q + 1 dealt over row tiles 1 .. 15 --------------------------------------------
@@ -1160,7 +1191,7 @@ __device__ __forceinline__ void leaf_bf16_fused_step(int q, int q_diag0, int lan
   //   norms x SC (8) | combine (16) | sqrt (16; none for the squared exponential) | exp2 (16) | polynomial x exponential
   //   (16) | k*.alpha (16; GMODE 2) | split of pair (t, j) (8)
   constexpr int E = 16;
-  constexpr int O_COMB = 8, O_SQRT = O_COMB + E, O_EXP = O_SQRT + (KERNEL == 3 ? 0 : E), O_POLY = O_EXP + E,
+  constexpr int O_COMB = C16 != 0 ? 0 : 8, O_SQRT = O_COMB + E, O_EXP = O_SQRT + (KERNEL == 3 ? 0 : E), O_POLY = O_EXP + E,
                 O_MEAN = O_POLY + E, O_SPLIT = O_MEAN + (GMODE == 2 ? E : 0), NOPS = O_SPLIT + 8;
   float p[CT][8], ex[CT][8];
   TG na[2][4];
@@ -1177,7 +1208,8 @@ __device__ __forceinline__ void leaf_bf16_fused_step(int q, int q_diag0, int lan
       na[o >> 2][o & 3] = nav[o >> 2][o & 3] * SC;
     } else if constexpr (o < O_SQRT) {
       constexpr int e = o - O_COMB, t = e >> 3, h = (e >> 2) & 1, r = e & 3;
-      p[t][4 * h + r] = (float)fma_t(cm, s[h][t][r], na[h][r] + nb[t]);
+      if constexpr (C16 != 0) p[t][4 * h + r] = (float)fma_t(cm, s[h][t][r], nb[t]);
+      else p[t][4 * h + r] = (float)fma_t(cm, s[h][t][r], na[h][r] + nb[t]);
     } else if constexpr (o < O_EXP) {
       constexpr int e = o - O_SQRT, t = e >> 3, j = e & 7;
       if constexpr (sizeof(TG) == 4) p[t][j] = __builtin_amdgcn_sqrtf(__builtin_fabsf(p[t][j]));
@@ -1196,24 +1228,29 @@ __device__ __forceinline__ void leaf_bf16_fused_step(int q, int q_diag0, int lan
       asm volatile("" : "+v"(macc[t]));  // the two tiles' means stay in separate registers (see leaf_bf16_gen)
     } else {
       constexpr int e = o - O_SPLIT, t = e >> 2, j = e & 3;
+      if constexpr (F16) {
+        unsigned hh, ll;
+        f16_split_pair_both(p[t][2 * j], p[t][2 * j + 1], hh, ll);
+        fr[0][t][j] = hh;
+        fr[1][t][j] = ll;
+      } else {
 #pragma unroll
-      for (int sp = 0; sp < NS; ++sp) {
-        if constexpr (F16) fr[sp][t][j] = (sp + 1 < NS) ? f16_split_pair_mix(p[t][2 * j], p[t][2 * j + 1]) : f16_split_pair(p[t][2 * j], p[t][2 * j + 1]);
-        else fr[sp][t][j] = bf16_split_pair(p[t][2 * j], p[t][2 * j + 1]);
+        for (int sp = 0; sp < NS; ++sp) fr[sp][t][j] = bf16_split_pair(p[t][2 * j], p[t][2 * j + 1]);
       }
     }
   };
+  static_assert(ASKIP >= 0 && ASKIP < RT, "at least one live row tile");
   u32x4 a[2][NS];
 #pragma unroll
-  for (int sp = 0; sp < NS; ++sp) a[0][sp] = panel_b[(sp * RT + 0) * 64 + lane];
+  for (int sp = 0; sp < NS; ++sp) a[ASKIP & 1][sp] = panel_b[(sp * RT + ASKIP) * 64 + lane];
   static_for<0, RT>([&](auto rt_) {
     constexpr int rt = decltype(rt_)::value;
-    if constexpr (rt + 1 < RT) {
+    if constexpr (rt + 1 < RT && rt + 1 > ASKIP) {
 #pragma unroll
       for (int sp = 0; sp < NS; ++sp) a[(rt + 1) & 1][sp] = panel_b[(sp * RT + rt + 1) * 64 + lane];
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (!(ADIAG && 2 * (q - q_diag0) > rt)) {  // (diagonal block: all-zero tiles above the diagonal)
+    if constexpr (rt >= ASKIP) {  // (diagonal block: all-zero tiles above the diagonal)
 #pragma unroll
       for (int t = 0; t < CT; ++t) {
         f32x4 c = acc[rt][t];
@@ -1250,7 +1287,7 @@ __device__ __forceinline__ void leaf_bf16_fused_step(int q, int q_diag0, int lan
 // barrier per step); otherwise round 3's two-phase step with the waves of a SIMD in opposite order
 // C16: the contraction on the fp16 pipe -- xs_p then points at the fp16 piece pairs of the scaled inputs
 // (pack_xs_f16_kernel's order) and c16_scale at their scale (device: [1] = 2^sx, [2] = 2^-2sx)
-template <int NS, typename TG, int KERNEL, bool F16 = false, bool FUSED = false, bool C16 = false>
+template <int NS, typename TG, int KERNEL, bool F16 = false, bool FUSED = false, int C16 = 0>
 __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     const u32x4* __restrict__ linv_b, const TG* __restrict__ xs_p, const TG* __restrict__ xnorm,
     const float* __restrict__ alpha, const TG* __restrict__ leaves_s,
@@ -1323,7 +1360,8 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   // (<= 32 pieces: D <= 48 in float, <= 32 in double -- checked at launch); DMA wave w moves pieces w + DW jj.  The last
   // but one DMA wave also moves the 32 norms (TG, as 64 dwords; float: lanes 32-63 fetch duplicates into the unused
   // half), the last one the 32 alphas 64 TG behind them.
-  // C16: the fragments are 4 ceil(D / 32) <= 8 pieces of 1 KB, one 16-byte DMA each, dealt the same way.
+  // C16: the fragments are 4 C16 <= 8 pieces of 1 KB, one 16-byte DMA each, dealt the same way; no norms (they ride in
+  // the contraction).
   constexpr int XPB = C16 ? 1024 : 256;  // bytes of an X piece
   const int xpieces = xfrag / XPB;
   const unsigned char* xs_bytes = reinterpret_cast<const unsigned char*>(xs_p);
@@ -1345,7 +1383,7 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
       });
     }
     unsigned char* nd = xd + xfrag;
-    if (wave == DW - 2) {
+    if (wave == DW - 2 && C16 == 0) {
       const int nlane = (sizeof(TG) == 8) ? lane4 : (lane & 31) * 4;
       glds4_off<0>(uniform(reinterpret_cast<const unsigned char*>(xnorm + 32 * q)) + nlane, nd);
     } else if (wave == DW - 1) {
@@ -1362,7 +1400,7 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     // col0 + 16 t + (l & 15), dimension 32 cc + 8 (l >> 4) + j, scaled like the training side and split the same way
     const float up = c16_scale[1];
     cm *= (TG)c16_scale[2];
-    const int nc = (dp4 + 7) >> 3;
+    constexpr int nc = C16;
     u32x4* xb16 = reinterpret_cast<u32x4*>(xb);
     for (int t = 0; t < CT; ++t)
       for (int cc = 0; cc < nc; ++cc) {
@@ -1371,7 +1409,7 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int k = 32 * cc + 8 * (lane >> 4) + j;
-          v[j] = k < dp ? fminf(fmaxf((float)src[k] * up, -60000.0f), 60000.0f) : 0.0f;
+          v[j] = k < dp ? fminf(fmaxf((float)src[k] * up, -60000.0f), 60000.0f) : (k == dp ? 128.0f : 0.0f);
         }
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) {
@@ -1418,12 +1456,12 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     // from waves 0-3 to waves 4-7 in the middle of every step (s_setprio; 0.8042 -- the arbiter serves the older wave
     // first: stamps show waves 0-3 through a step in 3 700 clocks and waiting 1 800 at the barrier for waves 4-7, which
     // need 5 000; flipping the priority flips who waits, the sum grows).
-#define GPSO_FUSED_STEP(ADIAG, GMODE)                                                                                 \
+#define GPSO_FUSED_STEP(ASKIP, GMODE)                                                                                 \
   {                                                                                                                   \
     GPSO_BSTAMP(q, 0);                                                                                                \
     issue_for(q);                                                                                                     \
     GPSO_BSTAMP(q, 1);                                                                                                \
-    leaf_bf16_fused_step<NS, TG, KERNEL, F16, ADIAG, GMODE, C16>(q, q_diag0, lane, dp4,                               \
+    leaf_bf16_fused_step<NS, TG, KERNEL, F16, ASKIP, GMODE, C16>(q, q_diag0, lane, dp4,                               \
                                                                  panel + (q & 1) * NS * RT * 64,                      \
                                                                  xsl + ((q + 1) % 3) * xstride, xb, nb, cm, vc,       \
                                                                  bfrag, bnxt, acc, macc);                             \
@@ -1436,13 +1474,17 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     }                                                                                                                 \
   }
     int q = 0;
-    for (; q + 1 < q_diag0; ++q) GPSO_FUSED_STEP(false, 1)
+    for (; q + 1 < q_diag0; ++q) GPSO_FUSED_STEP(0, 1)
     if (q < q_diag0) {  // the last step below the diagonal block generates the block's first step: with its k*.alpha
-      GPSO_FUSED_STEP(false, 2)
+      GPSO_FUSED_STEP(0, 2)
       ++q;
     }
-    for (; q + 1 < q_end; ++q) GPSO_FUSED_STEP(true, 2)
-    GPSO_FUSED_STEP(true, 0)
+    static_for<0, RT / 2>([&](auto j_) {  // the diagonal block: step j skips its 2 j all-zero row tiles
+      constexpr int j = decltype(j_)::value;
+      if constexpr (j + 1 < RT / 2) GPSO_FUSED_STEP(2 * j, 2)
+      else GPSO_FUSED_STEP(2 * j, 0)
+      ++q;
+    });
 #undef GPSO_FUSED_STEP
   } else {
   // Interval k (between workgroup barriers k - 1 and k): waves 0-3 generate and apply step k; waves 4-7 apply step
@@ -1506,7 +1548,7 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   }
 }
 
-template <int NS, typename TG, bool F16 = false, bool C16 = false>
+template <int NS, typename TG, bool F16 = false, int C16 = 0>
 static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const TG* xs_p,
                                      const TG* xnorm, const float* alpha, const TG* leaves_s,
                                      const TG* lnorm, double* part_var, double* part_mean,
@@ -1515,8 +1557,8 @@ static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const T
                                      const float* c16_scale = nullptr) {
   const int nbi = (int)(npad / 256);
   const dim3 grid((unsigned)(mpad / 256), (unsigned)nbi);
-  const size_t lds = leaf_bf16_lds_bytes(NS, dp4, (int)sizeof(TG), C16);
-  if (C16 ? leaf_c16_chunks(dp4) > 2 : 2 * dp4 * (int)(sizeof(TG) / 4) > 32) {  // the X fragments of a k-step are one DMA window of 32 pieces (C16: 8)
+  const size_t lds = leaf_bf16_lds_bytes(NS, dp4, (int)sizeof(TG), C16 != 0);
+  if (C16 ? leaf_c16_chunks(dp4) != C16 : 2 * dp4 * (int)(sizeof(TG) / 4) > 32) {  // the X fragments of a k-step are one DMA window of 32 pieces (C16: 8)
     note_launch_error("launch_leaf_tiles_bf16: more than 32 X pieces per k-step");
     return 1;
   }
@@ -1559,8 +1601,11 @@ int launch_leaf_tiles_bf16(hipStream_t st, int nsplit, const void* linv_b, const
                            const float* f16_inv_scale_a, int variant, const void* xs_h16, const float* c16_scale) {
   if (f16_inv_scale_a != nullptr) {  // fp16 split (nsplit == 2 pieces)
     if constexpr (sizeof(TG) == 4) {
-      if (xs_h16 != nullptr && c16_scale != nullptr)  // ... with the contraction on the fp16 pipe as well
-        return launch_leaf_tiles_bf16_ns<2, TG, true, true>(st, linv_b, static_cast<const TG*>(xs_h16), xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, variant, c16_scale);
+      if (xs_h16 != nullptr && c16_scale != nullptr) {  // ... with the contraction on the fp16 pipe as well
+        if (leaf_c16_chunks(dp4) == 1)
+          return launch_leaf_tiles_bf16_ns<2, TG, true, 1>(st, linv_b, static_cast<const TG*>(xs_h16), xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, variant, c16_scale);
+        return launch_leaf_tiles_bf16_ns<2, TG, true, 2>(st, linv_b, static_cast<const TG*>(xs_h16), xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, variant, c16_scale);
+      }
     }
     return launch_leaf_tiles_bf16_ns<2, TG, true>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, variant);
   }

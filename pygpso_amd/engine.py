@@ -114,8 +114,8 @@ class HipGPEngine:
         self._check(self._lib.gpso_set_option(self._h, L.OPT_SPLIT_KERNEL, {"auto": 0, "two-phase": 1}[which]))
 
     def set_contraction(self, which):
-        """GPSO_OPT_CONTRACTION: "auto" (the x.x* contraction of the fp16-split kernel on the fp16 pipe where that is
-        faster: 8 < D <= 64) | "f32" (always the f32 matrix instruction) | "f16" (the fp16 pipe wherever it applies)."""
+        """GPSO_OPT_CONTRACTION: "auto" / "f16" (the x.x* contraction of the fp16-split kernel on the fp16 pipe under
+        float generation) | "f32" (the f32 matrix instruction, as in rounds 1-3)."""
         self._check(self._lib.gpso_set_option(self._h, L.OPT_CONTRACTION, {"auto": 0, "f32": 1, "f16": 2}[which]))
 
     def set_small_calls(self, on):
