@@ -179,8 +179,10 @@ def split_bf16_report(eng, leaves_dev, leaves_all, varsigma, m_total, flops_per_
     sample = leaves_all[:2048]
     ref = gpr.predict_y(post, sample) if post is not None else None
     time.sleep(0.5)  # let the BLAS worker threads of the CPU-baseline leg stop spinning
-    for mode in ("native", "bf16x6", "f16x3", "bf16x3"):
-        eng.set_predict_math(mode)
+    for mode in ("native", "bf16x6", "f16x3", "f16x3+f32-contraction", "bf16x3"):
+        # (f16x3 contracts x.x* on the fp16 pipe by default; "+f32-contraction" is rounds 1-3's f32 matrix instruction)
+        eng.set_predict_math(mode.split("+")[0])
+        eng.set_contraction("f32" if "+" in mode else "auto")
         for _ in range(3):
             eng.best_ucb(leaves_dev, varsigma)
         t0 = time.perf_counter()
@@ -190,7 +192,7 @@ def split_bf16_report(eng, leaves_dev, leaves_all, varsigma, m_total, flops_per_
             ks.append(eng.last_ms(0))
         dt = time.perf_counter() - t0
         tfl = flops_per_leaf * m_total / (np.mean(ks) * 1e-3) / 1e12
-        bound = PEAK_TFLOPS["float32"] if mode == "native" else PEAK_BF16_TFLOPS / int(mode[-1])
+        bound = PEAK_TFLOPS["float32"] if mode == "native" else PEAK_BF16_TFLOPS / int(mode.split("+")[0][-1])
         entry = {"value": m_total * steps / dt, "unit": "predictions/s", "kernel_ms": float(np.mean(ks)),
                  "algorithmic_tflops": tfl, "bound_tflops": bound, "frac_of_bound": tfl / bound}
         if ref is not None:
@@ -198,6 +200,7 @@ def split_bf16_report(eng, leaves_dev, leaves_all, varsigma, m_total, flops_per_
             entry["max_abs_err_mean_vs_f64_oracle"] = float(np.max(np.abs(mean - ref[0])))
             entry["max_abs_err_var_vs_f64_oracle"] = float(np.max(np.abs(var - ref[1])))
         rep[mode] = entry
+    eng.set_contraction("auto")
     eng.set_predict_math("auto")
     return rep
 
