@@ -823,6 +823,7 @@ __global__ __launch_bounds__(256) void pack_linv_f16_kernel(const TF* __restrict
 // D_pad <= 48) and slot D_pad of every leaf is 2^7 (exact in the first piece), so the accumulator arrives as
 // 2^2sx (x.x* - |x|^2 / 2) and the combine is ONE fma per value, u = (-2 SC 2^-2sx) s + SC |x*|^2 -- no norm fetch, no norm
 // scaling, no addition.  The leaf's norm stays a float outside the contraction: its range is not known at packing time.
+// Both norms are sums over the values the PIECES represent (h0 + h1), not over the floats they came from.
 // Fragment order of the training side: block (q, h, cc, piece) of 64 lanes x 16 bytes, lane l element j = row
 // 32 q + 16 h + (l & 15), slot 32 cc + 8 (l >> 4) + j -- the A operand of the 16x16x32 instruction as it stands.
 // scal: 4 device floats -- [0] max |x / l| (as float bits, atomicMax), [1] := 2^sx, [2] := 2^-2sx
@@ -854,7 +855,22 @@ __global__ __launch_bounds__(256) void pack_xs_f16_kernel(const float* __restric
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int k = 32 * cc + 8 * (lane >> 4) + j;
-    v[j] = k < dp ? xs[row * dp + k] * up : (k == dp ? -((xnorm[row] * up) * up) * (1.0f / 256.0f) : 0.0f);
+    v[j] = k < dp ? xs[row * dp + k] * up : 0.0f;
+    if (k == dp) {
+      // the norm slot: |x / l|^2 of the row AS THE PIECES REPRESENT IT (h0 + h1 differs from the float by up to 2^-22
+      // relative).  With the float norm against the pieces' products, r^2 of a leaf AT a training input came out 3x
+      // further from zero than with the f32 contraction (self-test readings, tools/micro/gen_readings.py); with norms
+      // and products of the same numbers the distance of a point to itself is 2 h1.h1' = 2^-23 |x|^2 and the error at
+      // general leaves drops below the f32 contraction's (profiles/r04_c16_check.jsonl)
+      float acc = 0.0f;
+      for (int kk = 0; kk < dp; ++kk) {
+        const float a = xs[row * dp + kk] * up;
+        const float h0 = (float)(_Float16)a;
+        const float vp = h0 + (float)(_Float16)(a - h0);
+        acc += vp * vp;
+      }
+      v[j] = -acc * (1.0f / 256.0f);
+    }
   }
 #pragma unroll
   for (int s_ = 0; s_ < 2; ++s_) {
@@ -1395,6 +1411,7 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   issue_x(0);
   if (1 < q_end) issue_x(1);
   TG cm = TG(-2) * SC;
+  float nb_c16[CT] = {0, 0};
   if constexpr (C16) {
     // the leaves' side of the fp16 contraction: B operand of the 16x16x32 instruction, lane l element j = leaf
     // col0 + 16 t + (l & 15), dimension 32 cc + 8 (l >> 4) + j, scaled like the training side and split the same way
@@ -1402,7 +1419,8 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     cm *= (TG)c16_scale[2];
     constexpr int nc = C16;
     u32x4* xb16 = reinterpret_cast<u32x4*>(xb);
-    for (int t = 0; t < CT; ++t)
+    for (int t = 0; t < CT; ++t) {
+      float nrm2 = 0.0f;  // |x* / l|^2 2^2sx of the pieces (see pack_xs_f16_kernel: norms and products of the same numbers)
       for (int cc = 0; cc < nc; ++cc) {
         const TG* src = leaves_s + (col0 + t * 16 + (lane & 15)) * dp;
         float v[8];
@@ -1410,6 +1428,14 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
         for (int j = 0; j < 8; ++j) {
           const int k = 32 * cc + 8 * (lane >> 4) + j;
           v[j] = k < dp ? fminf(fmaxf((float)src[k] * up, -60000.0f), 60000.0f) : (k == dp ? 128.0f : 0.0f);
+        }
+        // (the norm from scalar conversions of the values, ahead of the split: summed from bit casts of the packed pieces
+        // hipcc 7.2 added element (0, e) of the first pair for every pair -- disassembly; wrong norms, caught by the tests)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float h0 = (float)(_Float16)v[j];
+          const float vp = h0 + (float)(_Float16)(v[j] - h0);
+          if (32 * cc + 8 * (lane >> 4) + j < dp) nrm2 += vp * vp;
         }
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) {
@@ -1419,6 +1445,10 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
           xb16[((t * nc + cc) * 2 + pc) * 64 + lane] = f;
         }
       }
+      nrm2 += __shfl_xor(nrm2, 16);  // the four lane groups hold a row's slots 8 g .. 8 g + 7 of every chunk
+      nrm2 += __shfl_xor(nrm2, 32);
+      nb_c16[t] = nrm2 * c16_scale[2];
+    }
   } else {
     for (int t = 0; t < CT; ++t)
       for (int c = 0; c < dp4; ++c)
@@ -1427,7 +1457,10 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   }
   TG nb[CT];
 #pragma unroll
-  for (int t = 0; t < CT; ++t) nb[t] = lnorm[col0 + t * 16 + (lane & 15)] * SC;
+  for (int t = 0; t < CT; ++t) {
+    if constexpr (C16 != 0) nb[t] = (TG)nb_c16[t] * SC;
+    else nb[t] = lnorm[col0 + t * 16 + (lane & 15)] * SC;
+  }
   f32x4 acc[RT][CT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
@@ -1455,7 +1488,9 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     // DMAs of step q + 2 issued at the tail of step q behind a raw s_barrier (0.7973); the SIMD's issue priority handed
     // from waves 0-3 to waves 4-7 in the middle of every step (s_setprio; 0.8042 -- the arbiter serves the older wave
     // first: stamps show waves 0-3 through a step in 3 700 clocks and waiting 1 800 at the barrier for waves 4-7, which
-    // need 5 000; flipping the priority flips who waits, the sum grows).
+    // need 5 000; flipping the priority flips who waits, the sum grows); with the fp16 contraction (a third fewer vector
+    // instructions per step) the DMA duties dealt over all eight waves again (0.6976 against 0.6897 ms); a fourth product
+    // h1 h1' in the fp16 contraction (self-test readings 20 % lower, kernel +2.5 %).
 #define GPSO_FUSED_STEP(ASKIP, GMODE)                                                                                 \
   {                                                                                                                   \
     GPSO_BSTAMP(q, 0);                                                                                                \

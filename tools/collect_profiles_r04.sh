@@ -19,6 +19,11 @@ for pat in "$KPAT" "leaf_tiles_bf16_kernel<3" "leaf_tiles_v2_kernel" potrf_step 
 python3 $R/tools/pmc_traffic_json.py $O/pmc_leaf_tiles_f16x3_c3.json c3 "$KPAT" "leaf_tiles_bf16_kernel<2, float, 0, true, true, 1> (fp16 split x3, fused step, fp16 contraction: first rung of GPSO_MATH_AUTO)" $O/pmc1 $O/pmc2 $O/pmc3 > /dev/null
 rm -rf $O/prof $O/pmc1 $O/pmc2 $O/pmc3
 echo "bench profile done"
+rocprofv3 --kernel-trace --output-format csv -d $O/steptrace -- python3 $R/bench.py --steps 60 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+python3 $R/tools/step_timeline.py $O/steptrace > $O/step_timeline.txt 2>&1; rm -rf $O/steptrace
+python3 $R/tools/c16_check.py > $O/c16_check.jsonl 2>/dev/null
+python3 $R/tools/sweep.py 2>/dev/null | grep "^{" > $O/sweep.jsonl
+echo "timeline, contraction check, sweep done"
 fi
 if [ $PART = a ]; then exit 0; fi
 for cfg in "2048 12 c3" "8192 20 c4" "16384 40 c5"; do
@@ -30,4 +35,5 @@ done
 for a in "2 5 50" "4 7 80" "6 9 60"; do set -- $a; python3 $R/tools/loop_bench.py --dim $1 --depth $2 --budget $3; done > $O/loop_bench.jsonl 2>/dev/null
 python3 $R/tools/host_overhead.py 52 2 2>/dev/null | grep -E "wall|device" > $O/host_overhead.txt
 for s in 41 42 43; do FUZZ_CASES=80 FUZZ_SEED=$s python3 $R/tools/fuzz_gpu.py > $O/fuzz_seed$s.log 2>&1; tail -1 $O/fuzz_seed$s.log; done
+(cd $R && python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_distributed.py -q -m gpu -s 2>/dev/null | grep "|d mean|" > $O/float_errors_raw.txt)
 ls -la $O
