@@ -291,8 +291,9 @@ struct EngineT : Engine {
   // the x.x* contraction of the fp16-split kernel runs on the fp16 pipe under float generation (D_pad + 1 slots in at most
   // two chunks of 32: every D this library accepts).  Measured in one process on one posterior (tools/c16_check.py,
   // profiles/r04_c16_check.jsonl), fp16 pipe against the f32 instruction: D = 6 +4 %, 12 +8 %, 20 +17 %, 33 +28 %, 40 +30 %
+  bool c16_fallback = false;  // this posterior's float generation keeps the f32 contraction (decide_generation)
   bool c16_in_use(bool gen64) const {
-    if (!kFloatPredict || gen64 || !f16_split() || contraction == GPSO_CONTRACTION_F32 || leaf_c16_chunks(dp / 4) > 2) return false;
+    if (!kFloatPredict || gen64 || c16_fallback || !f16_split() || contraction == GPSO_CONTRACTION_F32 || leaf_c16_chunks(dp / 4) > 2) return false;
     return leaf_bf16_lds_bytes(2, dp / 4, 4, true) <= 160 * 1024;
   }
   bool small_calls = true, one_launch = true, one_launch_everywhere = false;  // GPSO_OPT_SMALL_CALLS
@@ -673,6 +674,7 @@ struct EngineT : Engine {
     gen_eff32 = kFloatPredict && gen_mode != GPSO_GEN_F64;
     gen_decided = false;
     gen32_inputs_ok = false;
+    c16_fallback = false;
     st_done = false;
   }
   // float copies of the scaled inputs, made when a float-generation predict first needs them, from the
@@ -1052,6 +1054,7 @@ struct EngineT : Engine {
       double r32[6];
       std::copy(st_vals, st_vals + 6, r32);
       const bool pass32 = st_pass();
+      const bool was_c16 = c16_in_use(false);
       if (pass32 && bf16_usable() && linv_b_valid && !bf16_fits(true)) {
         // the split-bf16 kernel the caller opted into cannot hold double fragments at this D: double
         // generation would also mean the (slower) native kernel.  Inside the tolerances: stay.
@@ -1068,6 +1071,23 @@ struct EngineT : Engine {
       if (pass32 && finite64 && r32[0] <= 1.5 * st_vals[0] && r32[1] <= 1.5 * st_vals[1]) {
         gen_eff32 = true;
         std::copy(r32, r32 + 6, st_vals);
+      } else if (was_c16 && finite64) {
+        // float generation with the contraction on the fp16 pipe is not as good as double here: before paying for double
+        // generation (the f64 matrix instruction: 1.3x the kernel time at C3's shape), a look at float generation with
+        // the f32 contraction of rounds 1-3 -- its r^2 AT a training input is closer to zero (same floats in the norms
+        // and the products), which is where this test looks
+        double r64[6];
+        std::copy(st_vals, st_vals + 6, r64);
+        c16_fallback = true;
+        gen_eff32 = true;
+        st_done = false;
+        if ((rc = run_selftest())) return rc;
+        // (kept on the terms it is kept on when it runs first: comfortably inside the tolerances, or as good as double)
+        if (!(st_pass(kAutoMargin) || (st_pass() && st_vals[0] <= 1.5 * r64[0] && st_vals[1] <= 1.5 * r64[1]))) {
+          c16_fallback = false;
+          gen_eff32 = false;
+          std::copy(r64, r64 + 6, st_vals);
+        }
       }
     }
     gen_decided = true;
@@ -1945,7 +1965,7 @@ struct EngineT : Engine {
   // settled on the f32 MFMA kernel for this posterior) is float generation.
   // settle the posterior's arithmetic choices (generation, GPSO_MATH_AUTO's rung) and write them into slot 7 of the
   // hyper block, which travels: 1 = float generation, 2 = GPSO_MATH_AUTO settled on the f32 MFMA kernel, 4 = the split
-  // pieces are built, 8 = the packed L^-1 travels too, 256 x the predict math
+  // pieces are built, 8 = the packed L^-1 travels too, 16 = float generation keeps the f32 contraction, 256 x the predict math
   // (span_only: the flag describes the contiguous range of posterior_span -- the packed L^-1 is part of it only when the
   // posterior runs the f32 / f64 MFMA kernel; otherwise every buffer travels)
   int settle_and_flag(bool span_only) {
@@ -1957,7 +1977,7 @@ struct EngineT : Engine {
     if (with_linv_p && (rc = ensure_linv_p())) return rc;
     double* flag = ctx->pinned_scratch(256) + 120;  // (a slot neither the read-backs nor set_theta use)
     *flag = (gen_double() ? 0.0 : 1.0) + (math_native_fallback ? 2.0 : 0.0) + ((bf16_usable() && linv_b_valid) ? 4.0 : 0.0) +
-            ((with_linv_p && linv_p_valid) ? 8.0 : 0.0) + 256.0 * math;  // (which split the pieces are: a receiver under GPSO_MATH_AUTO follows)
+            ((with_linv_p && linv_p_valid) ? 8.0 : 0.0) + (c16_fallback ? 16.0 : 0.0) + 256.0 * math;  // (which split the pieces are: a receiver under GPSO_MATH_AUTO follows)
     HIPCHECK(hipMemcpyAsync(as<double>(hyper) + 7, flag, 8, hipMemcpyHostToDevice, st()));
     HIPCHECK(hipStreamSynchronize(st()));  // callers copy these buffers on streams of their own
     return GPSO_OK;
@@ -2080,6 +2100,7 @@ struct EngineT : Engine {
     gen_eff32 = kFloatPredict && (gen_mode == GPSO_GEN_F32 || (gen_mode == GPSO_GEN_AUTO && (sender & 1) != 0));
     gen_decided = true;
     gen32_inputs_ok = false;
+    c16_fallback = (sender & 16) != 0;  // (the sender's float generation kept the f32 contraction: same arithmetic here)
     return GPSO_OK;
   }
 };

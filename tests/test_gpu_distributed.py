@@ -112,6 +112,30 @@ def test_posterior_span_is_one_contiguous_range_and_enough_to_predict(dtype, mat
         dst.posterior_span_at(off + 1, nb)
 
 
+def test_posterior_handoff_carries_the_contraction_choice():
+    """A posterior whose self-test kept float generation with the f32 contraction (the second rung of GPSO_GEN_AUTO:
+    tests/test_gpu_parity.py::test_generation_choice_*) says so in its hyper block: the receiver of its span predicts
+    with the same arithmetic -- the same bits -- not with its own default."""
+    from pygpso_amd import HipGPEngine
+
+    n, d = 512, 4
+    X, y = synthetic_problem(n, d, seed=0)
+    src = HipGPEngine("float32")
+    src.set_data(X, y)
+    src.fit_eval("Matern52", [0.25 * np.sqrt(d)], 1.0, 1e-3, float(y.mean()), want_grad=False)
+    Xs = synthetic_leaves(900, d, seed=2)
+    exp = src.predict(Xs)
+    forced = HipGPEngine("float32", generation="float32")
+    forced.set_contraction("f16")
+    forced.set_data(X, y)
+    forced.fit_eval("Matern52", [0.25 * np.sqrt(d)], 1.0, 1e-3, float(y.mean()), want_grad=False)
+    assert not np.array_equal(forced.predict(Xs)[1], exp[1])  # (the sender is NOT on the default contraction)
+    dst = HipGPEngine("float32")
+    _handoff_span(src, dst)
+    got = dst.predict(Xs)
+    assert np.array_equal(exp[0], got[0]) and np.array_equal(exp[1], got[1])
+
+
 @pytest.mark.parametrize("dtype,math", [("float64", None), ("float32", "auto"), ("mixed", "bf16x6"), ("float32", "native")])
 def test_posterior_fingerprints_agree_between_replicated_fits(dtype, math):
     """gpso_posterior_hash: two contexts that ran the same fit hold the same fingerprint (the fit is bit-deterministic:

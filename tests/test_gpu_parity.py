@@ -947,6 +947,41 @@ def test_fp16_contraction_is_in_the_float_class_and_survives_far_leaves(n, d, m,
         assert np.max(np.abs(r[2] - mean_far)) <= 2e-3 * ymax and np.max(np.abs(r[3] - var_far)) <= 2e-4 * th.variance, w
 
 
+@pytest.mark.parametrize("n,d", [(512, 4), (2048, 3), (2048, 6), (2048, 12), (1024, 20)])
+def test_generation_choice_walks_fp16_contraction_then_f32_contraction_then_double(n, d):
+    """GPSO_GEN_AUTO (float32 context, default options): the posterior's self-test picks the generation arithmetic --
+    float with the contraction on the fp16 pipe where that is comfortably inside the tolerances or as good as double
+    generation; else float with the f32 contraction of rounds 1-3 on the same terms (its r^2 AT a training input, where
+    the test looks, is closer to zero); else double.  Whatever it picks, the predictions are the BITS of an engine
+    pinned to that arithmetic, and at these shapes (round 3 kept float generation on all of them) it is never double."""
+    from pygpso_amd import HipGPEngine
+
+    X, y = synthetic_problem(n, d, seed=0)
+    th = gpr.Theta("Matern52", 0.25 * np.sqrt(d) * np.ones(1), 1.0, 1e-3, float(y.mean()))
+    Xs = synthetic_leaves(777, d, seed=2)
+
+    def run(generation=None, contraction=None):
+        eng = HipGPEngine("float32", **({} if generation is None else {"generation": generation}))
+        if contraction is not None:
+            eng.set_contraction(contraction)
+        _fit(eng, X, y, th, grad=False)
+        info = eng.precision_info()
+        out = eng.predict(Xs)
+        eng.close()
+        return info, out
+
+    info, auto = run()
+    assert info["passed"] and info["predict_math"] == "f16x3"
+    pinned = {"fp16 contraction": run("float32", "f16")[1], "f32 contraction": run("float32", "f32")[1], "double": run("float64")[1]}
+    same = [k for k, v in pinned.items() if np.array_equal(v[0], auto[0]) and np.array_equal(v[1], auto[1])]
+    print(f"generation choice N={n} D={d}: {same}")
+    assert len(same) >= 1 and same[0] != "double" and info["generation"] == "float32", (same, info)
+    if (n, d) == (512, 4):
+        assert same == ["f32 contraction"]  # (the second rung: measured -- the fp16 contraction reads 1.9x double's variance error here)
+    if (n, d) == (2048, 12):
+        assert same == ["fp16 contraction"]  # (C3's shape keeps the fast path)
+
+
 @pytest.mark.parametrize("dtype", ["float64", "mixed", "float32"])
 @pytest.mark.parametrize("n,d,depth", [(52, 2, 5), (30, 4, 7), (100, 6, 9), (128, 3, 8), (300, 5, 6), (7, 1, 9), (256, 6, 8), (200, 12, 4)])
 def test_small_call_sequence_gives_the_bits_of_the_general_one(dtype, n, d, depth):
