@@ -1,0 +1,9 @@
+// The split predict kernels for double generation: one translation unit per generation type, so that the two halves
+// of leaf_split.hpp's instantiations compile in parallel.
+#include <hip/hip_runtime.h>
+
+#include "leaf_split.hpp"
+
+namespace gpso {
+template int launch_leaf_tiles_bf16<double>(hipStream_t, int, const void*, const double*, const double*, const float*, const double*, const double*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*, const float*, int, const void*, const float*);
+}  // namespace gpso
