@@ -138,8 +138,9 @@ const char* gpso_last_error(const gpso_ctx* ctx);
 int gpso_set_stream(gpso_ctx* ctx, void* hip_stream);
 int gpso_synchronize(gpso_ctx* ctx);
 /* No counterpart in the reference (GPflow computes in float64 throughout): selects how the
- * predict path multiplies by L^-1.  The split-bf16 modes need N padded to a multiple of 256
- * (otherwise the native kernel runs) and keep an extra nsplit * N^2 bf16 copy of L^-1. */
+ * predict path multiplies by L^-1.  The split modes work on row blocks of 256: GPSO_F32 / GPSO_MIXED
+ * contexts pad N > 128 to a multiple of 256 for them (GPSO_F64 contexts and N <= 128 pad to 128
+ * and run the native kernel), and keep an extra nsplit * N_pad^2 16-bit copy of L^-1. */
 int gpso_set_option(gpso_ctx* ctx, int option, int value);
 int gpso_set_option_f64(gpso_ctx* ctx, int option, double value);
 /* Order the context's stream behind everything already queued on producer_stream (a hipStream_t, e.g.
@@ -280,7 +281,8 @@ int gpso_fold_winners(gpso_ctx* ctx, const double* gathered, int world, int64_t 
 
 /* ---- introspection ------------------------------------------------------------------------- */
 
-/* padded problem size the device works with (multiple of 128), 0 before gpso_set_data */
+/* padded problem size the device works with (a multiple of 128; of 256 in float-predict contexts above
+ * N = 128), 0 before gpso_set_data */
 int64_t gpso_padded_n(const gpso_ctx* ctx);
 /* N and D of the problem the context currently holds (0, 0 before any data / posterior arrived) */
 int gpso_problem_shape(const gpso_ctx* ctx, int64_t* n, int* d);

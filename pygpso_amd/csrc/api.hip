@@ -526,7 +526,12 @@ struct EngineT : Engine {
     if (n_ > 65536) return ctx->fail(GPSO_E_ARG, "n=%lld above the supported 65536", (long long)n_);
     n = n_;
     d = d_;
-    npad = (n + kPadN - 1) / kPadN * kPadN;
+    // Float-predict contexts pad N > 128 to a multiple of 256, the row block of the split predict kernels: with a pad of
+    // 128 every N in (256 k + 128, 256 k + 256] ran them and every N in (256 k, 256 k + 128] fell to the f32 MFMA kernel
+    // (3.2x the time per flop) -- half of all N.  The padding rows are identity rows of the factor: the blocked
+    // factorisation does the same operations on the real rows, up to two 64-column steps more on the padding.
+    const int64_t pad = (kFloatPredict && n > kPadN) ? 2 * kPadN : kPadN;
+    npad = (n + pad - 1) / pad * pad;
     dp = (d + 3) / 4 * 4;
     int rc;
     if ((rc = ensure(x64, (size_t)n * d * 8))) return rc;

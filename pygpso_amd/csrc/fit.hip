@@ -1946,7 +1946,10 @@ int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t
                  double* diag64, int* info, int64_t single_max, const FitPlanes* planes) {
   const bool single = npad <= (single_max >= 0 ? single_max : kSingleLevelMax<T>);
   if (single) {
-    potrf_block<T>(st, K, Lf, linv, work, kinv, npad, (int)(npad / kFitBlock), 0, n, diag64, info);
+    // only the 64-row blocks that hold training rows: a block of padding alone is an identity block of the factor and
+    // of its inverse, nothing downstream reads it (every consumer of L, L^-1, K^-1 and the diagonal stops at row n), and
+    // its step would be a whole link of the launch chain (15 us) -- float-predict contexts pad N to 256
+    potrf_block<T>(st, K, Lf, linv, work, kinv, npad, (int)((n + kFitBlock - 1) / kFitBlock), 0, n, diag64, info);
     return 1 | (kinv != nullptr ? 2 : 0);
   }
   // two-level, by kOuterPanel = fit_outer_panel(npad)-wide diagonal blocks:

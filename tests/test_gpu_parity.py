@@ -947,6 +947,40 @@ def test_fp16_contraction_is_in_the_float_class_and_survives_far_leaves(n, d, m,
         assert np.max(np.abs(r[2] - mean_far)) <= 2e-3 * ymax and np.max(np.abs(r[3] - var_far)) <= 2e-4 * th.variance, w
 
 
+@pytest.mark.parametrize("n", [130, 300, 321, 600, 1100])
+def test_float_predict_contexts_pad_to_the_split_kernels_row_block(n):
+    """Float-predict contexts pad N > 128 to a multiple of 256 (the row block of the split kernels), so the fp16 split
+    runs at EVERY N -- with a pad of 128 half of all N fell to the f32 MFMA kernel (N = 1100: 0.89 -> 0.30 ms per 65 536
+    leaves).  The single-level factorisation only steps over the 64-row blocks that hold training rows, so the padding
+    costs the fit nothing; a double fit on the larger pad (mixed) is the float64 context's fit BIT FOR BIT (factor,
+    inverse, alpha, loss, gradient), and the predictions keep their tolerances."""
+    from pygpso_amd import HipGPEngine
+    from pygpso_amd import _lib as L
+
+    d = 5
+    X, y, th = _problem(n, d, noise=1e-3, variance=1.3)
+    Xs = synthetic_leaves(1000, d, seed=4)
+    post = gpr.posterior(th, X, y)
+    mean_ref, var_ref = gpr.predict_y(post, Xs)
+    out = {}
+    for dtype in ("float64", "mixed", "float32"):
+        eng = HipGPEngine(dtype)
+        f, g = _fit(eng, X, y, th, grad=True)
+        assert eng.padded_n == (-(-n // 128) * 128 if dtype == "float64" else -(-n // 256) * 256)
+        out[dtype] = (f, g, eng.get_matrix(L.MAT_CHOL), eng.get_matrix(L.MAT_LINV), eng.get_vector(L.VEC_ALPHA), eng.predict(Xs))
+        if dtype != "float64":
+            assert eng.precision_info()["predict_math"] == "f16x3"
+        eng.close()
+    a, b = out["float64"], out["mixed"]
+    assert a[0] == b[0] and np.array_equal(a[1], b[1])
+    assert all(np.array_equal(p, q) for p, q in zip(a[2:5], b[2:5]))
+    assert np.max(np.abs(a[5][0] - mean_ref)) < 1e-9 and np.max(np.abs(a[5][1] - var_ref)) < 1e-9
+    ymax = max(1.0, np.max(np.abs(y)))
+    for dtype in ("mixed", "float32"):
+        mean, var = out[dtype][5]
+        assert np.max(np.abs(mean - mean_ref)) <= SMALL_FLOAT_BOUNDS[0] * ymax and np.max(np.abs(var - var_ref)) <= SMALL_FLOAT_BOUNDS[1] * th.variance, dtype
+
+
 @pytest.mark.parametrize("n,d", [(512, 4), (2048, 3), (2048, 6), (2048, 12), (1024, 20)])
 def test_generation_choice_walks_fp16_contraction_then_f32_contraction_then_double(n, d):
     """GPSO_GEN_AUTO (float32 context, default options): the posterior's self-test picks the generation arithmetic --
