@@ -753,7 +753,9 @@ struct EngineT : Engine {
       if ((rc = scale_inputs())) return rc;
       int* info_dev = reinterpret_cast<int*>(as<double>(scal) + 1);
       launch_gram<TF>(s, as<double>(xs64), as<double>(xnorm64), n, npad, dp, kp, as<TF>(K), info_dev);
-      HIPCHECK(hipMemsetAsync(linv.p, 0, (size_t)npad * npad * sizeof(TF), s));
+      // (the single-level factorisation writes all of L^-1 that is ever read: no 4 N_pad^2-byte zero fill -- 10 us at C3)
+      if (!potrf_is_single_level<TF>(npad, single_level_max))
+        HIPCHECK(hipMemsetAsync(linv.p, 0, (size_t)npad * npad * sizeof(TF), s));
       FitPlanes planes{};
       const FitPlanes* pl = nullptr;
       if constexpr (sizeof(TF) == 4) {

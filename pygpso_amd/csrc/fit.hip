@@ -289,7 +289,9 @@ __device__ __forceinline__ void lower_cols_to_global(const double* S, T* __restr
 // all 256 threads: lower part of a 64x64 f64 LDS tile (stride kDS) -> global T tile (the destination's
 // upper part must be pre-zeroed or unused); a thread owns 16 (or 32) consecutive columns of one row (16-byte stores)
 // (NT = 256: all threads, 16 columns each; NT = 128: t in [0, 128), 32 columns each)
-template <typename T, int NT = 256>
+// ZERO_ABOVE: the groups above the diagonal are written as zeros as well -- the destination then needs no zero fill
+// (role D's diagonal tile of L^-1 is read WHOLE by the products of the later steps)
+template <typename T, int NT = 256, bool ZERO_ABOVE = false>
 __device__ __forceinline__ void lower_tile_to_global(const double* S, T* __restrict__ dst, int64_t ld, int t) {
   using vec4 = typename Mfma<T>::vec4;
   constexpr int kPerRow = NT / kFitBlock, kCols = kFitBlock / kPerRow;
@@ -297,7 +299,7 @@ __device__ __forceinline__ void lower_tile_to_global(const double* S, T* __restr
   T* o = dst + (int64_t)r * ld + cb;
 #pragma unroll
   for (int v = 0; v < kCols / 4; ++v) {
-    if (cb + 4 * v <= r) {  // groups entirely above the diagonal: destination is pre-zeroed / never read
+    if (ZERO_ABOVE || cb + 4 * v <= r) {  // groups entirely above the diagonal: destination is pre-zeroed / never read
       vec4 x;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -1808,7 +1810,7 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(T* __restrict__ K, T* _
     if (tid < kFitBlock) diag64[row_base + k0 + tid] = Ls[tid * kDS + tid];
     GPSO_STAMP(7);
     trinv64_lds<true, T, true>(Ls, Xs, Ts, Lf + k0 * ld + k0, ld);
-    lower_tile_to_global<T>(Xs, linv + k0 * ld + k0, ld, tid);
+    lower_tile_to_global<T, 256, true>(Xs, linv + k0 * ld + k0, ld, tid);
     GPSO_STAMP(16);
     return;
   }
@@ -1942,9 +1944,16 @@ static void potrf_block(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, 
 }
 
 template <typename T>
+bool potrf_is_single_level(int64_t npad, int64_t single_max) {
+  return npad <= (single_max >= 0 ? single_max : kSingleLevelMax<T>);
+}
+template bool potrf_is_single_level<float>(int64_t, int64_t);
+template bool potrf_is_single_level<double>(int64_t, int64_t);
+
+template <typename T>
 int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t n, int64_t npad,
                  double* diag64, int* info, int64_t single_max, const FitPlanes* planes) {
-  const bool single = npad <= (single_max >= 0 ? single_max : kSingleLevelMax<T>);
+  const bool single = potrf_is_single_level<T>(npad, single_max);
   if (single) {
     // only the 64-row blocks that hold training rows: a block of padding alone is an identity block of the factor and
     // of its inverse, nothing downstream reads it (every consumer of L, L^-1, K^-1 and the diagonal stops at row n), and

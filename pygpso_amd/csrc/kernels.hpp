@@ -140,6 +140,10 @@ struct FitPlanes {
 inline size_t fit_plane_set_bytes(int64_t npad) { return (size_t)3 * (size_t)npad * (size_t)npad * 2; }
 // planes (float fits, nullable): with them the TRSM GEMMs also emit L into planes->L and the rank-W trailing
 // updates run on the bf16 matrix cores
+// does launch_potrf take the single-level path at this size?  (It then writes every entry of L^-1 that anything reads --
+// the lower 64-tiles, diagonal tiles whole -- and linv needs no zero fill; the two-level path's GEMMs read whole panels.)
+template <typename T>
+bool potrf_is_single_level(int64_t npad, int64_t single_level_max /* < 0: default */);
 template <typename T>
 int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t n, int64_t npad,
                  double* diag64, int* info, int64_t single_level_max /* < 0: default */, const FitPlanes* planes);

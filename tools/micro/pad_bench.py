@@ -3,7 +3,7 @@ sys.path.insert(0, "/root/repo")
 import numpy as np, torch
 from pygpso_amd import HipGPEngine
 from tests.helpers import synthetic_leaves, synthetic_problem
-for n in (300, 600, 1100, 2100):
+for n in ([int(v) for v in sys.argv[1:]] or [300, 600, 1100, 2100]):
     d, m = 8, 65536
     X, y = synthetic_problem(n, d, seed=0)
     leaves = torch.from_numpy(synthetic_leaves(m, d).astype(np.float32)).cuda()
