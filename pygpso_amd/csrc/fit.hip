@@ -2390,8 +2390,12 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(const T* __restrict__ ki
                                                         double variance,
                                                         double* __restrict__ partial) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  double* xi = reinterpret_cast<double*>(lds_raw);  // [64][dp]
-  double* xj = xi + 64 * dp;                        // [64][dp]
+  // rows of the two 64-point blocks at an ODD stride (in doubles): a wave reads xj[jj][k] for 64 consecutive jj -- at
+  // stride D_pad (a multiple of 4) the 64 lanes fell on 8 (D_pad = 12) or 4 (D_pad = 40) distinct bank pairs, an 8- to
+  // 16-way conflict on every operand of the distance loop (C5: 5.4 ms of a 32 ms NLML + gradient evaluation)
+  const int ds = dp | 1;
+  double* xi = reinterpret_cast<double*>(lds_raw);  // [64][ds]
+  double* xj = xi + 64 * ds;                        // [64][ds]
   __shared__ double red[4];
   // 1-D grid over the lower tiles only (a 2-D grid with the upper half exiting at once leaves the 8
   // XCDs unevenly loaded): blk -> (ti, tj <= ti), row-major
@@ -2402,8 +2406,9 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(const T* __restrict__ ki
   const int tj = (int)(blk - (int64_t)ti * (ti + 1) / 2);
   const int H = n_ls + 2;
   for (int e = threadIdx.x; e < 64 * dp; e += 256) {
-    xi[e] = xs[(int64_t)ti * 64 * dp + e];
-    xj[e] = xs[(int64_t)tj * 64 * dp + e];
+    const int r = e / dp, c = e - r * dp;
+    xi[r * ds + c] = xs[(int64_t)ti * 64 * dp + e];
+    xj[r * ds + c] = xs[(int64_t)tj * 64 * dp + e];
   }
   __syncthreads();
   double g_var = 0.0, g_noise = 0.0, g_iso = 0.0;
@@ -2419,8 +2424,8 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(const T* __restrict__ ki
     double s = 0;
     double r2d = 0.0;  // squared distance from direct differences: >= 0 and free of cancellation
     for (int k = 0; k < dp; ++k) {
-      s += xi[ii * dp + k] * xj[jj * dp + k];
-      const double df = xi[ii * dp + k] - xj[jj * dp + k];
+      s += xi[ii * ds + k] * xj[jj * ds + k];
+      const double df = xi[ii * ds + k] - xj[jj * ds + k];
       r2d = fma(df, df, r2d);
     }
     const double r2 = -2.0 * s + (xnorm[i] + xnorm[j]);  // GEMM form (in double, as gram_kernel): the K the loss saw
@@ -2455,7 +2460,7 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(const T* __restrict__ ki
       for (int p = 0; p < 16; ++p) {
         const int idx = threadIdx.x + 256 * p;
         const int ii = idx >> 6, jj = idx & 63;
-        const double df = xi[ii * dp + d] - xj[jj * dp + d];
+        const double df = xi[ii * ds + d] - xj[jj * ds + d];
         acc += base[p] * (-2.0 * df * df);
       }
       const double sd = block_sum(acc) / ls[d];
@@ -2523,7 +2528,7 @@ void launch_gradient(hipStream_t st, const T* linv, const T* alpha, const double
     launch_gemm<T>(st, g);
   }
   const int nt = (int)(npad / 64);
-  const size_t lds = (size_t)2 * 64 * dp * sizeof(double);
+  const size_t lds = (size_t)2 * 64 * (dp | 1) * sizeof(double);
   const int64_t nblk = (int64_t)nt * (nt + 1) / 2;
   hipLaunchKernelGGL((grad_tile_kernel<T>), dim3((unsigned)nblk), dim3(256), lds, st,
                      kinv, alpha, xs, xnorm, n, npad, dp, n_ls, ls, kp.kernel, kp.variance, partial);
