@@ -302,6 +302,7 @@ struct EngineT : Engine {
   bool fused_small = true;        // GPSO_OPT_FIT_FUSED_SMALL
   int small_tile_rows = 8;        // tile rows of the 128-padded linv_p that may be non-zero (8: all / unknown)
   bool linv_b_valid = false;
+  bool linv_b_pending = false;  // the split pieces of the resident L^-1 are still to be packed (a fit that returned a gradient)
   std::vector<int64_t> segoff_cache;  // what the device copy of seg_off currently holds
   double* host_direct = nullptr;      // pinned host memory the arg-max of the call in flight writes its records to
   DevBuf extra_cnt;                   // small growth calls: rows appended behind the analytic slots (zero between calls)
@@ -365,9 +366,19 @@ struct EngineT : Engine {
   }
   bool bf16_usable() const { return kFloatPredict && math != GPSO_MATH_NATIVE && !math_native_fallback && npad > 0 && npad % 256 == 0; }
 
+  // An evaluation WITH gradient is a step of the hyper-parameter search: the next call is another evaluation, not a
+  // prediction, and its 16-bit pieces of L^-1 (10 us at C3, 0.5 ms at C5) would be packed for nothing.  They are packed
+  // when something first asks for them: every predict-type call, the self-test and the hand-off paths come through
+  // decide_generation(), which calls this.
+  int ensure_split_pieces() {
+    if (!linv_b_pending) return GPSO_OK;
+    linv_b_pending = false;
+    return chol_valid ? pack_bf16() : GPSO_OK;
+  }
   // (re)build the bf16 pieces of L^-1 from the fit-type L^-1 resident in `linv`
   int pack_bf16() {
     linv_b_valid = false;
+    linv_b_pending = false;
     if (!bf16_usable()) return GPSO_OK;
     int rc = ensure(linv_b, split_bytes());
     if (rc) return rc;
@@ -803,7 +814,12 @@ struct EngineT : Engine {
       if (!linv_p_lazy) launch_pack_linv<TF, TP>(s, as<TF>(linv), n, npad, as<TP>(linv_p));  // (alpha's predict-type copy: alpha_sum_kernel)
       small_tile_rows = 8;
     }
-    if ((rc = pack_bf16())) return rc;
+    if (grad && !small) {  // (see ensure_split_pieces)
+      linv_b_valid = false;
+      linv_b_pending = bf16_usable();
+    } else if ((rc = pack_bf16())) {
+      return rc;
+    }
     if ((rc = launch_status())) return rc;
     if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[5], s));
     constexpr size_t kHostDoubles = 8 + kGradMaxLs + 3;
@@ -1038,6 +1054,7 @@ struct EngineT : Engine {
   // GPSO_GEN_AUTO: let the self-test choose the generation arithmetic of this posterior.  Without a
   // self-test (switched off, or a posterior installed from outside: no targets) the choice is double.
   int decide_generation() {
+    if (int rcp = ensure_split_pieces()) return rcp;
     if (!kFloatPredict || gen_decided) return GPSO_OK;
     if (gen_mode != GPSO_GEN_AUTO) {
       gen_decided = true;
@@ -2103,6 +2120,7 @@ struct EngineT : Engine {
     if (math_auto && kFloatPredict && (sender_math == GPSO_MATH_F16X3 || sender_math == GPSO_MATH_BF16X6)) math = sender_math;
     // the split pieces the sender actually built travel with it (and are the split this context runs)
     linv_b_valid = bf16_usable() && (sender & 4) != 0 && sender_math == math;
+    linv_b_pending = false;
     linv_p_valid = (sender & 8) != 0;
     gen_eff32 = kFloatPredict && (gen_mode == GPSO_GEN_F32 || (gen_mode == GPSO_GEN_AUTO && (sender & 1) != 0));
     gen_decided = true;
