@@ -2413,6 +2413,25 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(const T* __restrict__ ki
   __syncthreads();
   double g_var = 0.0, g_noise = 0.0, g_iso = 0.0;
   double base[16];  // w * W * dk/dr2 per entry, for the ARD passes
+  // A thread's 16 entries share their column (jj = lane) and take the rows wave, wave + 4, ...: the distance loop runs
+  // over the dimensions ONCE for all of them -- one read of xj[jj][k] and sixteen wave-uniform (broadcast) reads of
+  // xi[.][k] per dimension instead of thirty-two reads; every entry's sums run over k in the same order as before.
+  double s_all[16], r2d_all[16];  // x.x' and the squared distance from direct differences (>= 0, free of cancellation)
+#pragma unroll
+  for (int p = 0; p < 16; ++p) s_all[p] = r2d_all[p] = 0.0;
+  {
+    const int jj = threadIdx.x & 63, i0 = threadIdx.x >> 6;
+    for (int k = 0; k < dp; ++k) {
+      const double b = xj[jj * ds + k];
+#pragma unroll
+      for (int p = 0; p < 16; ++p) {
+        const double a = xi[(i0 + 4 * p) * ds + k];
+        s_all[p] += a * b;
+        const double df = a - b;
+        r2d_all[p] = fma(df, df, r2d_all[p]);
+      }
+    }
+  }
 #pragma unroll
   for (int p = 0; p < 16; ++p) {
     const int idx = threadIdx.x + 256 * p;
@@ -2421,13 +2440,7 @@ __global__ __launch_bounds__(256) void grad_tile_kernel(const T* __restrict__ ki
     base[p] = 0.0;
     if (i >= n || j >= n || j > i) continue;
     const double w = (i == j) ? 1.0 : 2.0;
-    double s = 0;
-    double r2d = 0.0;  // squared distance from direct differences: >= 0 and free of cancellation
-    for (int k = 0; k < dp; ++k) {
-      s += xi[ii * ds + k] * xj[jj * ds + k];
-      const double df = xi[ii * ds + k] - xj[jj * ds + k];
-      r2d = fma(df, df, r2d);
-    }
+    const double s = s_all[p], r2d = r2d_all[p];
     const double r2 = -2.0 * s + (xnorm[i] + xnorm[j]);  // GEMM form (in double, as gram_kernel): the K the loss saw
     const double ai = (double)alpha[i], aj = (double)alpha[j];
     const double W = 0.5 * ((double)kinv[i * npad + j] - ai * aj);
