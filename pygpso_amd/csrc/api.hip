@@ -961,7 +961,7 @@ struct EngineT : Engine {
           rc = launch_leaf_tiles_bf16<TG>(s, nsplit(), split_planes(), xsp, xnr, as<float>(alpha), as<TG>(leaves_s),
                                           as<TG>(lnorm), as<double>(pvar), as<double>(pmean), npad, dp / 4, mp,
                                           kp, m_live_c, f16_split() ? f16_scale() : nullptr, split_variant,
-                                          c16_in_use(sizeof(TG) == 8) ? xs_h16.p : nullptr, as<float>(c16_scal));
+                                          c16_in_use(sizeof(TG) == 8) ? xs_h16.p : nullptr, as<float>(c16_scal), n);
       } else {
         rc = launch_leaf_tiles<TP, TG>(s, as<TP>(linv_p), xsp, xnr, as<TP>(alpha), as<TG>(leaves_s),
                                        as<TG>(lnorm), as<double>(pvar), as<double>(pmean), npad, dp / 4, mp, kp,

@@ -63,7 +63,8 @@ int launch_leaf_tiles_bf16(hipStream_t st, int nsplit, const void* linv_b, const
                            const TG* lnorm, double* part_var, double* part_mean, int64_t npad,
                            int dp4, int64_t mpad, const KernParams& kp, const int64_t* m_live,
                            const float* f16_inv_scale_a = nullptr, int variant = 0 /* GPSO_OPT_SPLIT_KERNEL: 0 the fused step, 1 the two-phase step */,
-                           const void* xs_h16 = nullptr, const float* c16_scale = nullptr /* both set: the contraction on the fp16 pipe (fp16 split, float generation) */);
+                           const void* xs_h16 = nullptr, const float* c16_scale = nullptr /* both set: the contraction on the fp16 pipe (fp16 split, float generation) */,
+                           int64_t n_rows = 0 /* N (0: unknown): the fused step stops at the k-steps that hold padding points only */);
 // scal: 2 device floats -- [0] max |L^-1|, [1] := 2^-sa.  have_max false: the maximum is computed here first (memset +
 // absmax_kernel); true: the fit left it in scal[0] (launch_solve_alpha: its own pass over L^-1).
 template <typename TF>

@@ -494,7 +494,7 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     const float* __restrict__ alpha, const TG* __restrict__ leaves_s,
     const TG* __restrict__ lnorm, double* __restrict__ part_var, double* __restrict__ part_mean,
     int npad16, int dp4, int64_t mpad, int nbi, float variance, const int64_t* __restrict__ m_live,
-    const float* __restrict__ inv_scale_a, float inv_scale_b, const float* __restrict__ c16_scale) {
+    const float* __restrict__ inv_scale_a, float inv_scale_b, const float* __restrict__ c16_scale, int q_max) {
   constexpr int RT = 16, CT = 2, NW = 8;
   constexpr TG SC = (TG)GenScale<KERNEL>::SC;
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -513,6 +513,10 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   const int dp = dp4 * 4;
   const int npad32 = npad16 / 2;
   const int q_diag0 = bi * (RT / 2), q_end = q_diag0 + RT / 2;
+  // q_max = ceil(N / 32): the k-steps from there on hold padding points only -- all-zero columns of L^-1.  The fused
+  // loop stops applying there (the last row block of an N that is not a multiple of 256; adding exact zeros or not adding
+  // them: the same partial sums).  q_diag0 < q_max always: a row block has at least one training row.
+  const int q_lim = FUSED ? min(q_end, q_max) : q_end;
 
   // ---- LDS-DMA duties, dealt EVENLY over the eight waves (round 4) -------------------------------------------
   // A step's DMAs are NS x 16 fragments of the L^-1 pieces (1 KB each), the X fragments of the step (256-byte pieces)
@@ -658,8 +662,8 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   __syncthreads();
 
   auto issue_for = [&](int k) {
-    if (k + 1 < q_end) issue_panel(k + 1, (k + 1) & 1);
-    if (k + 2 < q_end) issue_x(k + 2);
+    if (k + 1 < q_lim) issue_panel(k + 1, (k + 1) & 1);
+    if (k + 2 < q_end && k + 2 <= q_lim) issue_x(k + 2);  // (step q_lim is still GENERATED by step q_lim - 1: padding points, alpha = 0)
   };
   if constexpr (FUSED) {
     // Interval q (between workgroup barriers q - 1 and q), every wave alike: the DMAs of the L^-1 pieces of step q + 1
@@ -701,8 +705,10 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     }
     static_for<0, RT / 2>([&](auto j_) {  // the diagonal block: step j skips its 2 j all-zero row tiles
       constexpr int j = decltype(j_)::value;
-      if constexpr (j + 1 < RT / 2) GPSO_FUSED_STEP(2 * j, 2)
-      else GPSO_FUSED_STEP(2 * j, 0)
+      if (q < q_lim) {  // (workgroup-uniform)
+        if constexpr (j + 1 < RT / 2) GPSO_FUSED_STEP(2 * j, 2)
+        else GPSO_FUSED_STEP(2 * j, 0)
+      }
       ++q;
     });
 #undef GPSO_FUSED_STEP
@@ -774,7 +780,7 @@ static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const T
                                      const TG* lnorm, double* part_var, double* part_mean,
                                      int64_t npad, int dp4, int64_t mpad, const KernParams& kp,
                                      const int64_t* m_live, const float* inv_scale_a = nullptr, int variant = 0,
-                                     const float* c16_scale = nullptr) {
+                                     const float* c16_scale = nullptr, int64_t n_rows = 0) {
   const int nbi = (int)(npad / 256);
   const dim3 grid((unsigned)(mpad / 256), (unsigned)nbi);
   const size_t lds = leaf_bf16_lds_bytes(NS, dp4, (int)sizeof(TG), C16 != 0);
@@ -787,6 +793,7 @@ static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const T
   (void)frexp(kp.variance, &eb);
   const float var_arg = F16 ? (float)ldexp(kp.variance, 14 - eb) : (float)kp.variance;
   const float inv_b = F16 ? (float)ldexp(1.0, eb - 14) : 1.0f;
+  const int q_max = n_rows > 0 ? (int)((n_rows + 31) / 32) : (int)(npad / 32);
   // variant 0 (GPSO_SPLIT_KERNEL_AUTO): the fused step; 1: round 3's two-phase step.  Same bits either way.
 #define GPSO_L2(K, FUSED)                                                                           \
   do {                                                                                              \
@@ -795,7 +802,7 @@ static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const T
     hipLaunchKernelGGL((leaf_tiles_bf16_kernel<NS, TG, K, F16, FUSED, C16>), grid, dim3(512), lds, st, \
                        static_cast<const u32x4*>(linv_b), xs_p, xnorm, alpha, leaves_s, lnorm,      \
                        part_var, part_mean, (int)(npad / 16), dp4, mpad, nbi, var_arg, m_live,      \
-                       inv_scale_a, inv_b, c16_scale);                                              \
+                       inv_scale_a, inv_b, c16_scale, q_max);                                       \
   } while (0)
 #define GPSO_L(K)                                                                                   \
   do {                                                                                              \
@@ -818,19 +825,20 @@ int launch_leaf_tiles_bf16(hipStream_t st, int nsplit, const void* linv_b, const
                            const TG* xnorm, const float* alpha, const TG* leaves_s,
                            const TG* lnorm, double* part_var, double* part_mean, int64_t npad,
                            int dp4, int64_t mpad, const KernParams& kp, const int64_t* m_live,
-                           const float* f16_inv_scale_a, int variant, const void* xs_h16, const float* c16_scale) {
+                           const float* f16_inv_scale_a, int variant, const void* xs_h16, const float* c16_scale,
+                           int64_t n_rows) {
   if (f16_inv_scale_a != nullptr) {  // fp16 split (nsplit == 2 pieces)
     if constexpr (sizeof(TG) == 4) {
       if (xs_h16 != nullptr && c16_scale != nullptr) {  // ... with the contraction on the fp16 pipe as well
         if (leaf_c16_chunks(dp4) == 1)
-          return launch_leaf_tiles_bf16_ns<2, TG, true, 1>(st, linv_b, static_cast<const TG*>(xs_h16), xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, variant, c16_scale);
-        return launch_leaf_tiles_bf16_ns<2, TG, true, 2>(st, linv_b, static_cast<const TG*>(xs_h16), xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, variant, c16_scale);
+          return launch_leaf_tiles_bf16_ns<2, TG, true, 1>(st, linv_b, static_cast<const TG*>(xs_h16), xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, variant, c16_scale, n_rows);
+        return launch_leaf_tiles_bf16_ns<2, TG, true, 2>(st, linv_b, static_cast<const TG*>(xs_h16), xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, variant, c16_scale, n_rows);
       }
     }
-    return launch_leaf_tiles_bf16_ns<2, TG, true>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, variant);
+    return launch_leaf_tiles_bf16_ns<2, TG, true>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, variant, nullptr, n_rows);
   }
   if (nsplit == 3)
-    return launch_leaf_tiles_bf16_ns<3, TG>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, nullptr, variant);
-  return launch_leaf_tiles_bf16_ns<2, TG>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, nullptr, variant);
+    return launch_leaf_tiles_bf16_ns<3, TG>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, nullptr, variant, nullptr, n_rows);
+  return launch_leaf_tiles_bf16_ns<2, TG>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, nullptr, variant, nullptr, n_rows);
 }
 }  // namespace gpso

@@ -5,5 +5,5 @@
 #include "leaf_split.hpp"
 
 namespace gpso {
-template int launch_leaf_tiles_bf16<double>(hipStream_t, int, const void*, const double*, const double*, const float*, const double*, const double*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*, const float*, int, const void*, const float*);
+template int launch_leaf_tiles_bf16<double>(hipStream_t, int, const void*, const double*, const double*, const float*, const double*, const double*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*, const float*, int, const void*, const float*, int64_t);
 }  // namespace gpso
