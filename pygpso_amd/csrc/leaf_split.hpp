@@ -358,7 +358,9 @@ __device__ __forceinline__ void leaf_bf16_apply(int q, int q_diag0, int lane, co
 // a compile-time count: the eight steps of the diagonal block are eight straight-line copies.  With the skip as a
 // run-time test per row tile the compiler kept the accumulators of skipped tiles alive through 74 register-pair moves
 // per step (disassembly), in the steps that already have the least matrix work to hide them behind.
-template <int NS, typename TG, int KERNEL, bool F16, int ASKIP, int GMODE, int C16 = 0>
+// RTL: row tiles of the block that hold training rows (16, or 8 for a LAST row block with <= 128 of them: the tiles
+// beyond are all zero and are not applied; the map of the next step is then dealt over row tiles 1 .. RTL - 1)
+template <int NS, typename TG, int KERNEL, bool F16, int ASKIP, int GMODE, int C16 = 0, int RTL = 16>
 __device__ __forceinline__ void leaf_bf16_fused_step(int q, int q_diag0, int lane, int dp4,
                                                      const u32x4* panel_b /* [NS][16][64]: L^-1 pieces of step q */,
                                                      const unsigned char* xs_n /* inputs of step q + 1 */, const TG* xb,
@@ -440,13 +442,13 @@ __device__ __forceinline__ void leaf_bf16_fused_step(int q, int q_diag0, int lan
       }
     }
   };
-  static_assert(ASKIP >= 0 && ASKIP < RT, "at least one live row tile");
+  static_assert(ASKIP >= 0 && ASKIP < RTL && RTL <= RT, "at least one live row tile");
   u32x4 a[2][NS];
 #pragma unroll
   for (int sp = 0; sp < NS; ++sp) a[ASKIP & 1][sp] = panel_b[(sp * RT + ASKIP) * 64 + lane];
-  static_for<0, RT>([&](auto rt_) {
+  static_for<0, RTL>([&](auto rt_) {
     constexpr int rt = decltype(rt_)::value;
-    if constexpr (rt + 1 < RT && rt + 1 > ASKIP) {
+    if constexpr (rt + 1 < RTL && rt + 1 > ASKIP) {
 #pragma unroll
       for (int sp = 0; sp < NS; ++sp) a[(rt + 1) & 1][sp] = panel_b[(sp * RT + rt + 1) * 64 + lane];
     }
@@ -470,8 +472,8 @@ __device__ __forceinline__ void leaf_bf16_fused_step(int q, int q_diag0, int lan
         acc[rt][t] = c;
       }
     }
-    if constexpr (GEN && rt >= 1) {  // this row tile's share of the map: ops [(rt - 1) NOPS / 15, rt NOPS / 15)
-      static_for<(rt - 1) * NOPS / (RT - 1), rt * NOPS / (RT - 1)>(op);
+    if constexpr (GEN && rt >= 1) {  // this row tile's share of the map: ops [(rt - 1) NOPS / (RTL - 1), rt NOPS / (RTL - 1))
+      static_for<(rt - 1) * NOPS / (RTL - 1), rt * NOPS / (RTL - 1)>(op);
     }
   });
   if constexpr (GEN) {
@@ -685,7 +687,7 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     GPSO_BSTAMP(q, 0);                                                                                                \
     issue_for(q);                                                                                                     \
     GPSO_BSTAMP(q, 1);                                                                                                \
-    leaf_bf16_fused_step<NS, TG, KERNEL, F16, ASKIP, GMODE, C16>(q, q_diag0, lane, dp4,                               \
+    leaf_bf16_fused_step<NS, TG, KERNEL, F16, ASKIP, GMODE, C16, RTL>(q, q_diag0, lane, dp4,                          \
                                                                  panel + (q & 1) * NS * RT * 64,                      \
                                                                  xsl + ((q + 1) % 3) * xstride, xb, nb, cm, vc,       \
                                                                  bfrag, bnxt, acc, macc);                             \
@@ -697,20 +699,27 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
         for (int t = 0; t < CT; ++t) bfrag[sp][t] = bnxt[sp][t];                                                      \
     }                                                                                                                 \
   }
-    int q = 0;
-    for (; q + 1 < q_diag0; ++q) GPSO_FUSED_STEP(0, 1)
-    if (q < q_diag0) {  // the last step below the diagonal block generates the block's first step: with its k*.alpha
-      GPSO_FUSED_STEP(0, 2)
-      ++q;
-    }
-    static_for<0, RT / 2>([&](auto j_) {  // the diagonal block: step j skips its 2 j all-zero row tiles
-      constexpr int j = decltype(j_)::value;
-      if (q < q_lim) {  // (workgroup-uniform)
-        if constexpr (j + 1 < RT / 2) GPSO_FUSED_STEP(2 * j, 2)
-        else GPSO_FUSED_STEP(2 * j, 0)
+    auto fused_loops = [&](auto rtl_) {
+      constexpr int RTL = decltype(rtl_)::value;
+      int q = 0;
+      for (; q + 1 < q_diag0; ++q) GPSO_FUSED_STEP(0, 1)
+      if (q < q_diag0) {  // the last step below the diagonal block generates the block's first step: with its k*.alpha
+        GPSO_FUSED_STEP(0, 2)
+        ++q;
       }
-      ++q;
-    });
+      static_for<0, RTL / 2>([&](auto j_) {  // the diagonal block: step j skips its 2 j all-zero row tiles
+        constexpr int j = decltype(j_)::value;
+        if (q < q_lim) {  // (workgroup-uniform)
+          if constexpr (j + 1 < RT / 2) GPSO_FUSED_STEP(2 * j, 2)
+          else GPSO_FUSED_STEP(2 * j, 0)
+        }
+        ++q;
+      });
+    };
+    // a LAST row block with at most 128 training rows (q_max <= q_diag0 + 4): its row tiles 8 .. 15 are padding -- a
+    // second copy of the loops that applies row tiles 0 .. 7 only (N = 1100: 76 rows in the fifth block)
+    if (q_max <= q_diag0 + RT / 4) fused_loops(std::integral_constant<int, RT / 2>{});
+    else fused_loops(std::integral_constant<int, RT>{});
 #undef GPSO_FUSED_STEP
   } else {
   // Interval k (between workgroup barriers k - 1 and k): waves 0-3 generate and apply step k; waves 4-7 apply step
