@@ -57,14 +57,30 @@ void launch_gen_inputs_f16(hipStream_t st, const float* xs32, const float* xnorm
                            void* xs_h16);
 // f16_inv_scale_a != nullptr: the fp16 split (two pieces, three products; predict.hip) -- linv_b and the scale (device,
 // 2 floats: max |L^-1|, 2^-sa) come from launch_pack_linv_f16
+// FUSED: the fused step (round 4) or round 3's two-phase step -- same bits; one explicit instantiation per slice
+// (TG, FUSED, KS) in predict_split_*.hip
+template <typename TG, bool FUSED, int KS /* kernel families 0-1 | 2-3 */>
+int launch_leaf_tiles_bf16_v(hipStream_t st, int nsplit, const void* linv_b, const TG* xs_p,
+                             const TG* xnorm, const float* alpha, const TG* leaves_s,
+                             const TG* lnorm, double* part_var, double* part_mean, int64_t npad,
+                             int dp4, int64_t mpad, const KernParams& kp, const int64_t* m_live,
+                             const float* f16_inv_scale_a, const void* xs_h16, const float* c16_scale, int64_t n_rows);
+// variant: GPSO_OPT_SPLIT_KERNEL (0 the fused step, 1 the two-phase step); xs_h16 and c16_scale both set: the contraction
+// on the fp16 pipe (fp16 split, float generation); n_rows: N (0: unknown) -- the fused step stops at the k-steps that
+// hold padding points only
 template <typename TG>
-int launch_leaf_tiles_bf16(hipStream_t st, int nsplit, const void* linv_b, const TG* xs_p,
-                           const TG* xnorm, const float* alpha, const TG* leaves_s,
-                           const TG* lnorm, double* part_var, double* part_mean, int64_t npad,
-                           int dp4, int64_t mpad, const KernParams& kp, const int64_t* m_live,
-                           const float* f16_inv_scale_a = nullptr, int variant = 0 /* GPSO_OPT_SPLIT_KERNEL: 0 the fused step, 1 the two-phase step */,
-                           const void* xs_h16 = nullptr, const float* c16_scale = nullptr /* both set: the contraction on the fp16 pipe (fp16 split, float generation) */,
-                           int64_t n_rows = 0 /* N (0: unknown): the fused step stops at the k-steps that hold padding points only */);
+inline int launch_leaf_tiles_bf16(hipStream_t st, int nsplit, const void* linv_b, const TG* xs_p,
+                                  const TG* xnorm, const float* alpha, const TG* leaves_s,
+                                  const TG* lnorm, double* part_var, double* part_mean, int64_t npad,
+                                  int dp4, int64_t mpad, const KernParams& kp, const int64_t* m_live,
+                                  const float* f16_inv_scale_a = nullptr, int variant = 0, const void* xs_h16 = nullptr,
+                                  const float* c16_scale = nullptr, int64_t n_rows = 0) {
+#define GPSO_V(FUSED, KS) launch_leaf_tiles_bf16_v<TG, FUSED, KS>(st, nsplit, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, xs_h16, c16_scale, n_rows)
+  const bool low = kp.kernel == 0 || kp.kernel == 1;
+  const int rc = variant == 0 ? (low ? GPSO_V(true, 0) : GPSO_V(true, 1)) : (low ? GPSO_V(false, 0) : GPSO_V(false, 1));
+#undef GPSO_V
+  return rc;
+}
 // scal: 2 device floats -- [0] max |L^-1|, [1] := 2^-sa.  have_max false: the maximum is computed here first (memset +
 // absmax_kernel); true: the fit left it in scal[0] (launch_solve_alpha: its own pass over L^-1).
 template <typename TF>

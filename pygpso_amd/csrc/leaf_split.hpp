@@ -783,12 +783,15 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   }
 }
 
-template <int NS, typename TG, bool F16 = false, int C16 = 0>
+// FUSED and KS (kernel families 0-1: Matern-5/2, -3/2 | 2-3: Matern-1/2, squared exponential) are template parameters of
+// the launchers: each (TG, FUSED, KS) slice of the kernels is instantiated in a translation unit of its own
+// (launch_leaf_tiles_bf16_v<TG, FUSED, KS>, predict_split_*.hip), and the slices compile in parallel
+template <bool FUSED, int KS, int NS, typename TG, bool F16 = false, int C16 = 0>
 static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const TG* xs_p,
                                      const TG* xnorm, const float* alpha, const TG* leaves_s,
                                      const TG* lnorm, double* part_var, double* part_mean,
                                      int64_t npad, int dp4, int64_t mpad, const KernParams& kp,
-                                     const int64_t* m_live, const float* inv_scale_a = nullptr, int variant = 0,
+                                     const int64_t* m_live, const float* inv_scale_a = nullptr,
                                      const float* c16_scale = nullptr, int64_t n_rows = 0) {
   const int nbi = (int)(npad / 256);
   const dim3 grid((unsigned)(mpad / 256), (unsigned)nbi);
@@ -803,8 +806,8 @@ static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const T
   const float var_arg = F16 ? (float)ldexp(kp.variance, 14 - eb) : (float)kp.variance;
   const float inv_b = F16 ? (float)ldexp(1.0, eb - 14) : 1.0f;
   const int q_max = n_rows > 0 ? (int)((n_rows + 31) / 32) : (int)(npad / 32);
-  // variant 0 (GPSO_SPLIT_KERNEL_AUTO): the fused step; 1: round 3's two-phase step.  Same bits either way.
-#define GPSO_L2(K, FUSED)                                                                           \
+  // FUSED (GPSO_SPLIT_KERNEL_AUTO): the fused step; otherwise round 3's two-phase step.  Same bits either way.
+#define GPSO_L(K)                                                                                   \
   do {                                                                                              \
     const int rc = ensure_dyn_lds((const void*)leaf_tiles_bf16_kernel<NS, TG, K, F16, FUSED, C16>, (int)lds); \
     if (rc) return rc;                                                                              \
@@ -813,41 +816,36 @@ static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const T
                        part_var, part_mean, (int)(npad / 16), dp4, mpad, nbi, var_arg, m_live,      \
                        inv_scale_a, inv_b, c16_scale, q_max);                                       \
   } while (0)
-#define GPSO_L(K)                                                                                   \
-  do {                                                                                              \
-    if (variant == 0) GPSO_L2(K, true);                                                             \
-    else GPSO_L2(K, false);                                                                         \
-  } while (0)
-  switch (kp.kernel) {
-    case 0: GPSO_L(0); break;
-    case 1: GPSO_L(1); break;
-    case 2: GPSO_L(2); break;
-    default: GPSO_L(3); break;
+  if constexpr (KS == 0) {
+    if (kp.kernel == 0) GPSO_L(0);
+    else GPSO_L(1);
+  } else {
+    if (kp.kernel == 2) GPSO_L(2);
+    else GPSO_L(3);
   }
-#undef GPSO_L2
 #undef GPSO_L
   return 0;
 }
 
-template <typename TG>
-int launch_leaf_tiles_bf16(hipStream_t st, int nsplit, const void* linv_b, const TG* xs_p,
+template <typename TG, bool FUSED, int KS>
+int launch_leaf_tiles_bf16_v(hipStream_t st, int nsplit, const void* linv_b, const TG* xs_p,
                            const TG* xnorm, const float* alpha, const TG* leaves_s,
                            const TG* lnorm, double* part_var, double* part_mean, int64_t npad,
                            int dp4, int64_t mpad, const KernParams& kp, const int64_t* m_live,
-                           const float* f16_inv_scale_a, int variant, const void* xs_h16, const float* c16_scale,
+                           const float* f16_inv_scale_a, const void* xs_h16, const float* c16_scale,
                            int64_t n_rows) {
   if (f16_inv_scale_a != nullptr) {  // fp16 split (nsplit == 2 pieces)
     if constexpr (sizeof(TG) == 4) {
       if (xs_h16 != nullptr && c16_scale != nullptr) {  // ... with the contraction on the fp16 pipe as well
         if (leaf_c16_chunks(dp4) == 1)
-          return launch_leaf_tiles_bf16_ns<2, TG, true, 1>(st, linv_b, static_cast<const TG*>(xs_h16), xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, variant, c16_scale, n_rows);
-        return launch_leaf_tiles_bf16_ns<2, TG, true, 2>(st, linv_b, static_cast<const TG*>(xs_h16), xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, variant, c16_scale, n_rows);
+          return launch_leaf_tiles_bf16_ns<FUSED, KS, 2, TG, true, 1>(st, linv_b, static_cast<const TG*>(xs_h16), xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, c16_scale, n_rows);
+        return launch_leaf_tiles_bf16_ns<FUSED, KS, 2, TG, true, 2>(st, linv_b, static_cast<const TG*>(xs_h16), xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, c16_scale, n_rows);
       }
     }
-    return launch_leaf_tiles_bf16_ns<2, TG, true>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, variant, nullptr, n_rows);
+    return launch_leaf_tiles_bf16_ns<FUSED, KS, 2, TG, true>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, nullptr, n_rows);
   }
   if (nsplit == 3)
-    return launch_leaf_tiles_bf16_ns<3, TG>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, nullptr, variant, nullptr, n_rows);
-  return launch_leaf_tiles_bf16_ns<2, TG>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, nullptr, variant, nullptr, n_rows);
+    return launch_leaf_tiles_bf16_ns<FUSED, KS, 3, TG>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, nullptr, nullptr, n_rows);
+  return launch_leaf_tiles_bf16_ns<FUSED, KS, 2, TG>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, nullptr, nullptr, n_rows);
 }
 }  // namespace gpso

@@ -1,0 +1,10 @@
+// The split predict kernels, double generation, round 3's two-phase step: one translation unit per slice of leaf_split.hpp's
+// instantiations, so that they compile in parallel.
+#include <hip/hip_runtime.h>
+
+#include "leaf_split.hpp"
+
+namespace gpso {
+template int launch_leaf_tiles_bf16_v<double, false, 0>(hipStream_t, int, const void*, const double*, const double*, const float*, const double*, const double*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*, const float*, const void*, const float*, int64_t);
+template int launch_leaf_tiles_bf16_v<double, false, 1>(hipStream_t, int, const void*, const double*, const double*, const float*, const double*, const double*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*, const float*, const void*, const float*, int64_t);
+}  // namespace gpso
