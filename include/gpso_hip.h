@@ -176,6 +176,22 @@ int gpso_fit_eval(gpso_ctx* ctx, int kernel, const double* lengthscales, int n_l
 int gpso_fit_eval_u(gpso_ctx* ctx, int kernel, const double* u, int n_ls, int train_mean, double mean_c_fixed,
                     double* nlml, double* grad_u, double* theta_out);
 
+/* Replaces: `model.data = (x, y)` at gpso/gp_surrogate.py:496-498 for an update that KEEPS the hyper-parameters (the
+ * reference always re-optimises right after, :500-503, and so refactorises from scratch although N grew by 1-7 points
+ * per iteration, gpso/optimisation.py:324-329).  With the posterior of the N points resident at theta
+ * (after gpso_fit_eval), the k new points Xnew[k*D], ynew[k] (host float64) extend L, L^-1, alpha, the NLML and the
+ * predict-ready copies of L^-1 IN PLACE: L21 = K21 L11^-T from one pass over the resident L^-1, L22 = chol(K22 + noise I -
+ * L21 L21^T) in one workgroup, the new rows of L^-1 = -L22^-1 L21 L11^-1 from a second pass -- O(N^2 k) and N^2 s bytes
+ * instead of O(N^3); arithmetic in double whatever the context's matrix type.  *nlml (nullable) receives the NLML of
+ * the N + k points at theta.
+ * Returns GPSO_OK (extended in place); 1 when the posterior of the N + k points was instead REFITTED from scratch at
+ * theta -- k > 64, N + k above the padded size (gpso_padded_n: every buffer's layout changes), or N + k <= 128 (the
+ * one-launch fit is the shorter exact update there) -- gpso_last_error then says which; GPSO_E_NOTPD with the failing
+ * pivot (N + p) when the appended block is not positive definite: the posterior of the N points then stays resident
+ * unchanged; GPSO_E_STATE without a posterior fitted on this context.  The gradient-side K^-1 (GPSO_MAT_KINV) is not
+ * extended.  The precision self-test runs again before the next prediction of a float-predict context. */
+int gpso_append(gpso_ctx* ctx, const double* Xnew, const double* ynew, int64_t k, double* nlml);
+
 /* Interop / debug: install a posterior computed elsewhere (host float64: X[N*D], L[N*N] row-major
  * lower, alpha[N]) -- the device still derives L^-1 and its tile packing itself.  Mirrors loading
  * saved GPflow parameters into a placeholder model (gpso/gp_surrogate.py:463-473). */

@@ -72,6 +72,7 @@ SIGNATURES = {
                                 C.c_double, _c_double_p, _c_double_p]),
     "gpso_fit_eval_u": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, C.c_int, C.c_int, C.c_double, _c_double_p,
                                   _c_double_p, _c_double_p]),
+    "gpso_append": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, C.c_int64, _c_double_p]),
     "gpso_set_posterior": (C.c_int, [C.c_void_p, _c_double_p, _c_double_p, _c_double_p, C.c_int64,
                                      C.c_int, C.c_int, _c_double_p, C.c_int, C.c_double, C.c_double,
                                      C.c_double]),

@@ -77,6 +77,7 @@ struct Engine {
   virtual int set_posterior(const double* X, const double* L, const double* alpha, int64_t n, int d,
                             int kernel, const double* ls, int n_ls, double variance, double noise,
                             double mean_c) = 0;
+  virtual int append(const double* Xnew, const double* ynew, int64_t k, double* nlml) = 0;
   virtual int predict(const void* xs, int xs_dtype, int xs_mem, int64_t m, double* mean,
                       double* var, int out_mem) = 0;
   virtual int best_ucb(const void* xs, int xs_dtype, int xs_mem, int64_t m, const int64_t* seg_off,
@@ -270,6 +271,8 @@ struct EngineT : Engine {
   // split-bf16 copy of L^-1 (float predict with GPSO_OPT_PREDICT_MATH != native)
   DevBuf linv_b;
   DevBuf pl_L, pl_X, pl_XT, pl_WT;  // bf16 plane sets of the two-level float fit (kernels.hpp: FitPlanes)
+  DevBuf app;                       // scratch of gpso_append (kernels.hpp: append_scratch_doubles)
+  std::vector<double> x_host, y_host;  // host mirror of the training data (gpso_append's refit path needs all of it)
   bool bf16_fit = true;             // GPSO_OPT_FIT_BF16_SYRK
   // predict math: the OPTION (math_auto: GPSO_MATH_AUTO) and what the resident posterior uses (math, and
   // math_native_fallback when the self-test preferred the f32 MFMA kernel for it)
@@ -320,7 +323,7 @@ struct EngineT : Engine {
                       &work, &kinvb, &linv_p, &white, &alpha_f, &alpha, &logdet, &scal, &gpart, &apart,
                       &kinv_diag, &getter_tmp, &leaves_raw, &leaves_s, &lnorm, &pvar, &pmean, &omean, &ovar,
                       &oucb, &segoff, &best, &oidx, &ovals, &linv_b, &st_mean, &st_var, &st_out, &grow_key, &live_cnt,
-                      &best_pos, &gath, &wbase, &ovals2, &bhdr, &pl_L, &pl_X, &pl_XT, &pl_WT, &amax_rows, &arena, &hash_out, &extra_cnt, &one_ctl, &one_partial, &one_ppos})
+                      &best_pos, &gath, &wbase, &ovals2, &bhdr, &pl_L, &pl_X, &pl_XT, &pl_WT, &app, &amax_rows, &arena, &hash_out, &extra_cnt, &one_ctl, &one_partial, &one_ppos})
       if (b->p && !b->view) (void)hipFree(b->p);
   }
 
@@ -545,8 +548,9 @@ struct EngineT : Engine {
     npad = (n + pad - 1) / pad * pad;
     dp = (d + 3) / 4 * 4;
     int rc;
-    if ((rc = ensure(x64, (size_t)n * d * 8))) return rc;
-    if ((rc = ensure(y64, (size_t)n * 8))) return rc;
+    // (room for the padded size: gpso_append adds rows in place)
+    if ((rc = ensure(x64, (size_t)npad * d * 8))) return rc;
+    if ((rc = ensure(y64, (size_t)npad * 8))) return rc;
     if ((rc = carve_posterior())) return rc;
     if (kFloatPredict) {
       if ((rc = ensure(xs32, (size_t)npad * dp * 4))) return rc;
@@ -722,6 +726,8 @@ struct EngineT : Engine {
       HIPCHECK(hipMemcpyAsync(y64.p, y, (size_t)n * 8, hipMemcpyHostToDevice, st()));
       HIPCHECK(hipStreamSynchronize(st()));
     }
+    if (X != x_host.data()) x_host.assign(X, X + (size_t)n * d);
+    if (y != y_host.data()) y_host.assign(y, y + (size_t)n);
     have_data = true;
     have_post = have_kinv = chol_valid = linv_p_valid = false;
     st_done = st_have = false;
@@ -854,6 +860,99 @@ struct EngineT : Engine {
     linv_p_lazy = false;
     return launch_status();
   }
+
+  // ---- rank-k append at the resident hyper-parameters (append.hip) ------------------------------------------------------
+  // Returns GPSO_OK when the resident factor was extended in place, 1 when the posterior of the n + k points was refitted
+  // from scratch at the same hyper-parameters instead (gpso_last_error says why), or a negative status.
+  int append(const double* Xn, const double* yn, int64_t k, double* nlml) override {
+    ctx->tick_timing();
+    if (!Xn || !yn) return ctx->fail(GPSO_E_ARG, "Xnew / ynew must not be NULL");
+    if (k < 1) return ctx->fail(GPSO_E_ARG, "need at least one new point (k=%lld)", (long long)k);
+    if (!have_data || !have_post || !chol_valid || (int64_t)y_host.size() != n)
+      return ctx->fail(GPSO_E_STATE, "gpso_append needs a posterior fitted on this context (gpso_set_data + gpso_fit_eval)");
+    const int64_t n_new = n + k;
+    if (n_new > 65536) return ctx->fail(GPSO_E_ARG, "n=%lld above the supported 65536", (long long)n_new);
+    const char* refit = nullptr;
+    if (k > kAppendMax) refit = "more than 64 new points in one call";
+    else if (n_new > npad) refit = "the padded size grows: every buffer changes its layout";
+    else if (fused_small && small_fit_eligible(n_new, dp)) refit = "N <= 128: the one-launch fit is the shorter exact update";
+    if (refit != nullptr) {
+      std::vector<double> X(x_host), y(y_host), ls(ls_host);
+      X.insert(X.end(), Xn, Xn + (size_t)k * d);
+      y.insert(y.end(), yn, yn + (size_t)k);
+      const KernParams th = kp;
+      const int nls = n_ls, d_ = d;
+      int rc = set_data(X.data(), y.data(), n_new, d_);
+      if (rc) return rc;
+      if ((rc = fit_eval(th.kernel, ls.data(), nls, th.variance, th.noise, th.mean_c, nlml, nullptr))) return rc;
+      ctx->fail(1, "gpso_append: posterior of the %lld points refitted from scratch at the resident hyper-parameters (%s)",
+                (long long)n_new, refit);
+      return 1;
+    }
+    hipStream_t s = st();
+    int rc;
+    const int kpad = append_kp((int)k);
+    if ((rc = ensure(app, append_scratch_doubles(npad, kpad) * 8))) return rc;
+    double* stage = ctx->pinned_stage((size_t)k * d + (size_t)k);  // (waits for the stream)
+    double* host = ctx->pinned_scratch(8);
+    if (!stage || !host) return ctx->fail(GPSO_E_OOM, "pinned host staging");
+    if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[4], s));
+    std::memcpy(stage, Xn, (size_t)k * d * 8);
+    std::memcpy(stage + (size_t)k * d, yn, (size_t)k * 8);
+    HIPCHECK(hipMemcpyAsync(as<double>(x64) + (size_t)n * d, stage, (size_t)k * d * 8, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(as<double>(y64) + (size_t)n, stage + (size_t)k * d, (size_t)k * 8, hipMemcpyHostToDevice, s));
+    AppendArgs a{};
+    a.x64 = as<double>(x64); a.y64 = as<double>(y64); a.ls = ls_dev();
+    a.n = n; a.npad = npad; a.k = (int)k; a.d = d; a.dp = dp; a.kernel = kp.kernel;
+    a.variance = kp.variance; a.noise = kp.noise; a.mean_c = kp.mean_c;
+    a.xs64 = as<double>(xs64); a.xnorm64 = as<double>(xnorm64); a.xs_p64 = as<double>(xs_p64);
+    a.diag64 = as<double>(logdet); a.nlml = as<double>(scal); a.kinv_diag = as<double>(kinv_diag);
+    a.alpha_p = alpha.p; a.hyper = as<double>(hyper); a.host_out = host;
+    // the fp16 split's scale follows max |L^-1|: the slot holds it when the pieces are built, or when the fit's solve
+    // handed it over for a packing still to come
+    const bool f16_max_live = kFloatPredict && f16_split() && bf16_usable() &&
+                              (linv_b_valid || (linv_b_pending && f16_handed_at != nullptr && f16_handed_at == f16_scale()));
+    a.f16_scal = f16_max_live ? f16_scale() : nullptr;
+    host[0] = host[1] = 0.0;
+    launch_append<TF, TP>(s, a, app.p, as<TF>(linv), as<TF>(Lf), as<TF>(white), as<TF>(alpha_f));
+    // the 16-row tiles that hold new rows, in whichever predict-ready copies of L^-1 are built (the others are made on
+    // demand from the extended matrix)
+    const int64_t rt0 = n / 16;
+    auto repack = [&](int64_t rows) {
+      if (linv_b_valid) {
+        if (f16_split()) launch_pack_linv_f16<TF>(s, as<TF>(linv), rows, npad, f16_scale(), split_planes(), true, rt0);
+        else launch_pack_linv_bf16<TF>(s, nsplit(), as<TF>(linv), rows, npad, split_planes(), rt0);
+      }
+      if (linv_p_valid) launch_pack_linv<TF, TP>(s, as<TF>(linv), rows, npad, as<TP>(linv_p), rt0);
+    };
+    repack(n_new);
+    if ((rc = launch_status())) return rc;
+    if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[5], s));
+    HIPCHECK(ctx->wait(s));
+    float ms = 0;
+    if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->last_ms[2] = ms;
+    if (host[1] != 1.0) {
+      // K22 + noise I - L21 L21^T is not positive definite: the posterior of the n points is still what the device holds
+      // (append_cols_kernel did not run); the tiles just repacked and the scaled-input rows go back to their padding state
+      const int pivot = (int)host[2];
+      repack(n);
+      (void)scale_inputs();
+      gen32_inputs_ok = false;
+      HIPCHECK(hipStreamSynchronize(s));
+      return ctx->fail(GPSO_E_NOTPD, "K + noise*I is not positive definite: the appended block's Cholesky failed at pivot %d "
+                       "(the posterior of the first %lld points is unchanged)", pivot, (long long)n);
+    }
+    x_host.insert(x_host.end(), Xn, Xn + (size_t)k * d);
+    y_host.insert(y_host.end(), yn, yn + (size_t)k);
+    n = n_new;
+    if (nlml) *nlml = host[0];
+    have_kinv = false;
+    st_done = false;           // the self-test looks at the extended posterior before the next prediction
+    gen32_inputs_ok = false;   // float / fp16 copies of the scaled inputs: derived again from the extended double ones
+    small_tile_rows = 8;
+    return GPSO_OK;
+  }
+
 
   int set_posterior(const double* X, const double* L, const double* alpha64, int64_t n_, int d_,
                     int kernel, const double* ls, int n_ls_, double variance, double noise,
@@ -2306,6 +2405,11 @@ int gpso_fit_eval_u(gpso_ctx* ctx, int kernel, const double* u, int n_ls, int tr
   return GPSO_OK;
 }
 
+int gpso_append(gpso_ctx* ctx, const double* Xnew, const double* ynew, int64_t k, double* nlml) {
+  ENTER();
+  return ctx->eng->append(Xnew, ynew, k, nlml);
+}
+
 int gpso_set_posterior(gpso_ctx* ctx, const double* X, const double* L, const double* alpha,
                        int64_t n, int d, int kernel, const double* lengthscales, int n_ls,
                        double variance, double noise, double mean_c) {
@@ -2528,6 +2632,6 @@ int64_t gpso_last_count(gpso_ctx* ctx, int what) {
   return ctx->last_count[what];
 }
 
-const char* gpso_version(void) { return "gpso-hip 0.4.0 (gfx950)"; }
+const char* gpso_version(void) { return "gpso-hip 0.5.0 (gfx950)"; }
 
 }  // extern "C"

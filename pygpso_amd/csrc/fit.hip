@@ -2158,9 +2158,9 @@ template void launch_trtri<double>(hipStream_t, const double*, double*, double*,
 // this buffer and the multi-GPU broadcast of it.)  TF = fit type, TP = predict type.
 template <typename TF, typename TP>
 __global__ __launch_bounds__(256) void pack_linv_kernel(const TF* __restrict__ linv, int64_t n,
-                                                        int64_t npad, TP* __restrict__ linv_p) {
+                                                        int64_t npad, TP* __restrict__ linv_p, int64_t tile0) {
   using vec4 = typename Mfma<TP>::vec4;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (tile, lane)
+  const int64_t idx = tile0 * 64 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (tile, lane)
   const int64_t npad16 = npad / 16;
   if (idx >= npad16 * (npad16 + 1) / 2 * 64) return;
   const int lane = (int)(idx & 63);
@@ -2181,14 +2181,16 @@ __global__ __launch_bounds__(256) void pack_linv_kernel(const TF* __restrict__ l
 }
 
 template <typename TF, typename TP>
-void launch_pack_linv(hipStream_t st, const TF* linv, int64_t n, int64_t npad, TP* linv_p) {
-  const int64_t total = (npad / 16) * (npad / 16 + 1) / 2 * 64;
+void launch_pack_linv(hipStream_t st, const TF* linv, int64_t n, int64_t npad, TP* linv_p, int64_t rt0) {
+  const int64_t tile0 = rt0 * (rt0 + 1) / 2;  // tiles are stored row-major over the triangle: tile row rt0 starts here
+  const int64_t total = ((npad / 16) * (npad / 16 + 1) / 2 - tile0) * 64;
+  if (total <= 0) return;
   hipLaunchKernelGGL((pack_linv_kernel<TF, TP>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                     linv, n, npad, linv_p);
+                     linv, n, npad, linv_p, tile0);
 }
-template void launch_pack_linv<float, float>(hipStream_t, const float*, int64_t, int64_t, float*);
-template void launch_pack_linv<double, double>(hipStream_t, const double*, int64_t, int64_t, double*);
-template void launch_pack_linv<double, float>(hipStream_t, const double*, int64_t, int64_t, float*);
+template void launch_pack_linv<float, float>(hipStream_t, const float*, int64_t, int64_t, float*, int64_t);
+template void launch_pack_linv<double, double>(hipStream_t, const double*, int64_t, int64_t, double*, int64_t);
+template void launch_pack_linv<double, float>(hipStream_t, const double*, int64_t, int64_t, float*, int64_t);
 
 // =============================================================================================
 // single-RHS solves through L^-1 and the NLML

@@ -39,9 +39,10 @@ int launch_leaf_tiles(hipStream_t st, const T* linv_p, const TG* xs_p, const TG*
                       const int64_t* m_live);
 // split-bf16 apply (float contexts): nsplit = 2 -> bf16x3, 3 -> bf16x6; needs npad % 256 == 0.
 // linv_b = nsplit * npad * npad bf16, produced by launch_pack_linv_bf16 from the fit-type L^-1
+// rt0 > 0: only the 16-row tiles from rt0 on are (re)packed -- the rows a gpso_append wrote
 template <typename TF>
 void launch_pack_linv_bf16(hipStream_t st, int nsplit, const TF* linv, int64_t n, int64_t npad,
-                           void* linv_b);
+                           void* linv_b, int64_t rt0 = 0);
 // dynamic LDS of the split-bf16 kernel: A pieces (2 buffers x nsplit x 16 KiB) + 3 X buffers + the 8 waves' leaf
 // fragments, for a generation type of tg_bytes
 // c16: the contraction runs on the fp16 pipe (float generation only): the X fragments of a k-step and the leaf fragments
@@ -83,9 +84,12 @@ inline int launch_leaf_tiles_bf16(hipStream_t st, int nsplit, const void* linv_b
 }
 // scal: 2 device floats -- [0] max |L^-1|, [1] := 2^-sa.  have_max false: the maximum is computed here first (memset +
 // absmax_kernel); true: the fit left it in scal[0] (launch_solve_alpha: its own pass over L^-1).
+// rt0 > 0 (after a gpso_append; scal[0] already holds the new maximum, scal[3] the 2^-sa the resident pieces were packed
+// with): only the 16-row tiles from rt0 on are repacked -- unless the maximum crossed a power of two, which the kernel
+// sees on the device and then repacks everything
 template <typename TF>
 void launch_pack_linv_f16(hipStream_t st, const TF* linv, int64_t n, int64_t npad, float* scal, void* linv_b,
-                          bool have_max = false);
+                          bool have_max = false, int64_t rt0 = 0);
 // what finalising a leaf needs (leaf_finalize_kernel, or fused into the arg-max's first stage: launch_seg_argmax)
 struct LeafFinalize {
   const double* part_var = nullptr;
@@ -180,7 +184,7 @@ void launch_trtri(hipStream_t st, const T* L, T* linv, T* work, int64_t npad, in
 // zero rows/cols >= n and re-tile the lower 16x16 tiles of L^-1 into the MFMA fragment-major layout
 // the predict kernel reads: npad16 (npad16 + 1) / 2 tiles of 256 elements
 template <typename TF, typename TP>
-void launch_pack_linv(hipStream_t st, const TF* linv, int64_t n, int64_t npad, TP* linv_p);
+void launch_pack_linv(hipStream_t st, const TF* linv, int64_t n, int64_t npad, TP* linv_p, int64_t rt0 = 0 /* first 16-row tile row to pack */);
 inline size_t packed_linv_elems(int64_t npad) { return (size_t)(npad / 16) * (size_t)(npad / 16 + 1) / 2 * 256; }
 // a = L^-1 (y - c), alpha = L^-T a, nlml = 1/2 a.a + sum log diag64 + n/2 log 2pi  (double accumulators);
 // kinv_diag[npad] = squared column norms of L^-1 = diag((K + noise I)^-1)
@@ -253,6 +257,35 @@ void launch_convert_out(hipStream_t st, const T* src, int64_t ld_src, double* ds
 // install L (row-major lower, n x n float64 on device) into the padded T buffer + invert diagonal blocks
 template <typename T>
 void launch_install_chol(hipStream_t st, const double* L64, int64_t n, int64_t npad, T* K, T* linv);
+
+// ---- append.hip: rank-k append at fixed hyper-parameters ----------------------------------------------------------------
+// The posterior of the first n points is resident; k <= kAppendMax new points (already copied behind the old ones in
+// x64 / y64) extend L, L^-1, a, alpha, diag(K_y^-1), the NLML and the scaled inputs in place: two passes over L^-1
+// (append.hip).  Everything below lives on the device; scratch = append_scratch_doubles(npad, append_kp(k)) doubles.
+constexpr int kAppendMax = 64;
+struct AppendArgs {
+  const double* x64;   // [(n + k) * d] raw inputs, new rows included
+  const double* y64;   // [n + k]
+  const double* ls;    // lengthscale per input dimension (device)
+  int64_t n, npad;
+  int k, kp, d, dp, kernel;
+  double variance, noise, mean_c;
+  double *xs64, *xnorm64, *xs_p64;  // scaled inputs (rows n .. n + k - 1 are written)
+  double *Kc, *Bm, *part, *sm;      // scratch (carved by launch_append)
+  int* info;                        // scratch: INT_MAX, or the first failing pivot (n + p)
+  double* diag64;                   // [npad] diagonal of L
+  double* nlml;                     // device scalar: the resident NLML, updated in place
+  double* kinv_diag;                // [npad] squared column norms of L^-1
+  void* alpha_p;                    // [npad] predict-type copy of alpha
+  double* hyper;                    // hyper block: slot 0 (n) is updated
+  float* f16_scal;                  // nullable: scale slot of the fp16 split ([0] max |L^-1| grows by atomicMax, [3] := [1])
+  double* host_out;                 // pinned host: [0] the new NLML, [1] 1.0 = extended / 2.0 = not positive definite, [2] pivot
+};
+int append_kp(int k);
+size_t append_scratch_doubles(int64_t npad, int kp);
+const int* append_info_ptr(void* scratch, int64_t npad, int k);
+template <typename TF, typename TP>
+void launch_append(hipStream_t st, AppendArgs a, void* scratch, TF* linv, TF* Lf, TF* white, TF* alpha_f);
 
 // ---- grow.hip -------------------------------------------------------------------------------------
 // centres of the ternary subtree (levels 0..depth-1) under each box; out[nseg*rows*d] float64

@@ -661,9 +661,9 @@ __global__ __launch_bounds__(256, 2) void leaf_tiles_v2_one_kernel(
 // full-precision value)
 template <int NS, typename TF>
 __global__ __launch_bounds__(256) void pack_linv_bf16_kernel(const TF* __restrict__ linv, int64_t n,
-                                                             int64_t npad, u32x4* __restrict__ out) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (rt, kq, lane)
+                                                             int64_t npad, u32x4* __restrict__ out, int64_t rt0) {
   const int64_t npad16 = npad / 16, npad32 = npad / 32;
+  const int64_t idx = rt0 * npad32 * 64 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (rt, kq, lane)
   if (idx >= npad16 * npad32 * 64) return;
   const int lane = (int)(idx & 63);
   const int64_t kq = (idx >> 6) % npad32, rt = (idx >> 6) / npad32;
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const TF* __restrict__ linv
 // the fit's own pass over L^-1: fit.hip white_kernel / alpha_sum_kernel), scal[1] := 2^-sa (read by the predict kernel's epilogue)
 template <typename TF>
 __global__ __launch_bounds__(256) void pack_linv_f16_kernel(const TF* __restrict__ linv, int64_t n, int64_t npad,
-                                                            float* __restrict__ scal, u32x4* __restrict__ out) {
+                                                            float* __restrict__ scal, u32x4* __restrict__ out, int64_t rt0) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (rt, kq, lane)
   const int64_t npad16 = npad / 16, npad32 = npad / 32;
   int e = 0;
@@ -727,6 +727,9 @@ __global__ __launch_bounds__(256) void pack_linv_f16_kernel(const TF* __restrict
   if (idx >= npad16 * npad32 * 64) return;
   const int lane = (int)(idx & 63);
   const int64_t kq = (idx >> 6) % npad32, rt = (idx >> 6) / npad32;
+  // after a gpso_append: the tile rows above rt0 keep their pieces as long as the scale they were packed with
+  // (scal[3], read-only here) is still the scale (workgroup-uniform up to the tile row)
+  if (rt < rt0 && scal[3] == ldexpf(1.0f, e - 14)) return;
   const int64_t row = rt * 16 + (lane & 15);
   float v[8];
 #pragma unroll
@@ -831,17 +834,18 @@ void launch_gen_inputs_f16(hipStream_t st, const float* xs32, const float* xnorm
 
 template <typename TF>
 void launch_pack_linv_bf16(hipStream_t st, int nsplit, const TF* linv, int64_t n, int64_t npad,
-                           void* linv_b) {
-  const int64_t total = (npad / 16) * (npad / 32) * 64;
+                           void* linv_b, int64_t rt0) {
+  const int64_t total = (npad / 16 - rt0) * (npad / 32) * 64;
+  if (total <= 0) return;
   const dim3 grid((unsigned)((total + 255) / 256));
   if (nsplit == 3)
-    hipLaunchKernelGGL((pack_linv_bf16_kernel<3, TF>), grid, dim3(256), 0, st, linv, n, npad, static_cast<u32x4*>(linv_b));
+    hipLaunchKernelGGL((pack_linv_bf16_kernel<3, TF>), grid, dim3(256), 0, st, linv, n, npad, static_cast<u32x4*>(linv_b), rt0);
   else
-    hipLaunchKernelGGL((pack_linv_bf16_kernel<2, TF>), grid, dim3(256), 0, st, linv, n, npad, static_cast<u32x4*>(linv_b));
+    hipLaunchKernelGGL((pack_linv_bf16_kernel<2, TF>), grid, dim3(256), 0, st, linv, n, npad, static_cast<u32x4*>(linv_b), rt0);
 }
 template <typename TF>
 void launch_pack_linv_f16(hipStream_t st, const TF* linv, int64_t n, int64_t npad, float* scal, void* linv_b,
-                          bool have_max) {
+                          bool have_max, int64_t rt0) {
   if (!have_max) {
     (void)hipMemsetAsync(scal, 0, 4, st);
     hipLaunchKernelGGL((absmax_kernel<TF>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, linv, n, npad,
@@ -849,12 +853,12 @@ void launch_pack_linv_f16(hipStream_t st, const TF* linv, int64_t n, int64_t npa
   }
   const int64_t total = (npad / 16) * (npad / 32) * 64;
   hipLaunchKernelGGL((pack_linv_f16_kernel<TF>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, linv, n, npad,
-                     scal, static_cast<u32x4*>(linv_b));
+                     scal, static_cast<u32x4*>(linv_b), rt0);
 }
-template void launch_pack_linv_f16<float>(hipStream_t, const float*, int64_t, int64_t, float*, void*, bool);
-template void launch_pack_linv_f16<double>(hipStream_t, const double*, int64_t, int64_t, float*, void*, bool);
-template void launch_pack_linv_bf16<float>(hipStream_t, int, const float*, int64_t, int64_t, void*);
-template void launch_pack_linv_bf16<double>(hipStream_t, int, const double*, int64_t, int64_t, void*);
+template void launch_pack_linv_f16<float>(hipStream_t, const float*, int64_t, int64_t, float*, void*, bool, int64_t);
+template void launch_pack_linv_f16<double>(hipStream_t, const double*, int64_t, int64_t, float*, void*, bool, int64_t);
+template void launch_pack_linv_bf16<float>(hipStream_t, int, const float*, int64_t, int64_t, void*, int64_t);
+template void launch_pack_linv_bf16<double>(hipStream_t, int, const double*, int64_t, int64_t, void*, int64_t);
 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void leaf_finalize_kernel(const double* __restrict__ part_var,

@@ -281,6 +281,13 @@ class HipGPEngineGroup:
         self._stale = True
         return self._fitters(lambda e: e.fit_eval_u(*a, **kw))
 
+    def append(self, Xnew, ynew):
+        """``HipGPEngine.append`` on the fitting rank(s); the peers get the extended posterior like a fitted one."""
+        out = self._fitters(lambda e: e.append(Xnew, ynew))
+        self.n = self.engines[0].n
+        self._stale = True
+        return out
+
     def set_posterior(self, *a, **kw):
         self._fitters(lambda e: e.set_posterior(*a, **kw))
         self.n, self.d = self.engines[0].n, self.engines[0].d

@@ -220,6 +220,22 @@ class HipGPEngine:
             self._check(rc)
         return nl.value, ga.copy(), ta.copy()
 
+    def append(self, Xnew, ynew):
+        """``gpso_append``: k new training points extend the resident posterior at its hyper-parameters (two passes over
+        L^-1 instead of a factorisation).  Returns (nlml of the N + k points, in_place): ``in_place`` False when the
+        library refitted from scratch instead (pad crossing, k > 64, N + k <= 128: ``last_message()`` says which)."""
+        Xn = L.as_f64(np.atleast_2d(Xnew))
+        if Xn.ndim != 2 or Xn.shape[1] != self.d:
+            raise ValueError(f"Xnew must be [k, {self.d}]")
+        yn = L.as_f64(np.asarray(ynew).reshape(-1), (Xn.shape[0],))
+        nlml = C.c_double()
+        rc = self._check(self._lib.gpso_append(self._h, L.dptr(Xn), L.dptr(yn), Xn.shape[0], C.byref(nlml)))
+        self.n += Xn.shape[0]
+        return nlml.value, rc == L.OK
+
+    def last_message(self):
+        return self._lib.gpso_last_error(self._h).decode()
+
     def set_posterior(self, X, Lchol, alpha, kernel, lengthscales, variance, noise, mean_c):
         X = L.as_f64(X)
         n, d = X.shape

@@ -122,6 +122,25 @@ class HipGPR:
         self._resident = False
         self._device_theta = None  # hyper-parameters of the posterior on the device (None: none / unknown)
 
+    def append_data(self, x_new, y_new):
+        """Extend the training data by ``x_new [k, D]``, ``y_new [k]`` or ``[k, 1]`` WITHOUT touching the hyper-parameters
+        (``gpso_append``): when the posterior on the device is the one of the current hyper-parameters it is extended in
+        place -- O(N^2 k) -- instead of refactorised.  Returns True when the device posterior was extended (or refitted at
+        the same hyper-parameters by the library: pad crossing, N <= 128), False for engines without ``append``."""
+        x_new = np.ascontiguousarray(np.atleast_2d(x_new), dtype=np.float64)
+        y_new = np.ascontiguousarray(y_new, dtype=np.float64).reshape(-1, 1)
+        assert x_new.shape[0] == y_new.shape[0] and x_new.shape[1] == self._data[0].shape[1]
+        x = np.concatenate([self._data[0], x_new])
+        y = np.concatenate([self._data[1], y_new])
+        if not hasattr(self.engine, "append"):
+            self.data = (x, y)
+            return False
+        self._ensure_resident()  # the posterior of the data so far at the current hyper-parameters (a fit only if it is not there)
+        self._data = (x, y)
+        self._last_nlml, _ = self.engine.append(x_new, y_new[:, 0])
+        self._resident = True
+        return True
+
     # -- hyper-parameters ---------------------------------------------------------------------
     @property
     def n_ls(self):

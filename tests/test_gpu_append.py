@@ -1,0 +1,260 @@
+"""
+GPU parity tests of ``gpso_append`` (the rank-k append at FIXED hyper-parameters): the posterior
+extended in place on the device against the ORACLE's from-scratch posterior on the N + k points.
+
+Stated tolerances
+  float64 ..... mean, var, NLML, L, L^-1, alpha <= 1e-9 relative (the tolerances of the from-scratch fit)
+  mixed ....... factor as float64; predictions in the float class of tests/test_gpu_parity.py (SMALL_FLOAT_BOUNDS)
+  float32 ..... the float-fit bounds of the from-scratch fit: NLML 2e-5 relative, predictions FLOAT_BOUNDS-class
+"""
+import numpy as np
+import pytest
+
+from oracle import gpr
+from tests.helpers import synthetic_leaves, synthetic_problem
+
+pytestmark = pytest.mark.gpu
+
+VS = gpr.VARSIGMA_DEFAULT
+
+
+def _engine(dtype="float64", **kw):
+    from pygpso_amd import HipGPEngine
+
+    return HipGPEngine(dtype, **kw)
+
+
+def _theta(d, y, kernel="Matern52", noise=1e-3, ard=False, variance=1.3):
+    ls = 0.25 * np.sqrt(d) * (np.linspace(0.8, 1.3, d) if ard else np.ones(1))
+    return gpr.Theta(kernel, ls, variance, noise, float(y.mean()))
+
+
+def _fit(eng, X, y, th, grad=False):
+    eng.set_data(X, y)
+    return eng.fit_eval(th.kernel, th.lengthscales, th.variance, th.noise, th.mean_c, want_grad=grad)
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(1e-300, np.max(np.abs(b))))
+
+
+@pytest.mark.parametrize("k", [1, 7, 64])
+@pytest.mark.parametrize("n,d,ard", [(130, 2, False), (300, 5, True), (2048 - 64, 12, False)])
+def test_append_fp64_matches_the_oracles_from_scratch_posterior(n, d, ard, k):
+    from pygpso_amd import _lib as L
+
+    X, y = synthetic_problem(n + k, d, seed=3)
+    th = _theta(d, y, ard=ard)
+    post = gpr.posterior(th, X, y)  # the N + k points, from scratch
+    f_ref, _ = gpr.nlml_and_grad(th, X, y)
+    eng = _engine()
+    _fit(eng, X[:n], y[:n], th, grad=(k == 7))  # (an evaluation with gradient leaves the same factor)
+    f, in_place = eng.append(X[n:], y[n:])
+    assert in_place, eng.last_message()
+    assert eng.n == n + k
+    assert abs(f - f_ref) <= 1e-9 * abs(f_ref)
+    Linv_ref = np.linalg.inv(post.L)
+    assert _rel(eng.get_matrix(L.MAT_CHOL), post.L) < 1e-9
+    assert _rel(eng.get_matrix(L.MAT_LINV), Linv_ref) < 1e-8
+    assert _rel(eng.get_vector(L.VEC_ALPHA), post.alpha) < 1e-8
+    assert _rel(eng.get_vector(L.VEC_WHITE), Linv_ref @ (y - th.mean_c)) < 1e-8
+    Xs = synthetic_leaves(1500, d)
+    mean, var = eng.predict(Xs)
+    mean_ref, var_ref = gpr.predict_y(post, Xs)
+    scale = max(1.0, float(np.max(np.abs(y))))
+    assert np.max(np.abs(mean - mean_ref)) <= 1e-9 * scale
+    assert np.max(np.abs(var - var_ref)) <= 1e-9 * th.variance
+    idx, mu, vv, ucb = eng.best_ucb(Xs, VS)
+    i_ref = gpr.best_ucb(post, Xs)[0]
+    assert int(idx[0]) == i_ref
+    # ... and a fit from scratch on the same context afterwards sees the same N + k points
+    f2, _ = eng.fit_eval(th.kernel, th.lengthscales, th.variance, th.noise, th.mean_c, want_grad=False)
+    assert abs(f2 - f_ref) <= 1e-9 * abs(f_ref)
+
+
+@pytest.mark.parametrize("kernel", ["Matern32", "Matern12", "SquaredExponential"])
+def test_append_fp64_other_kernels(kernel):
+    n, d, k = 200, 3, 5
+    tol = 1e-5 if kernel == "Matern12" else 1e-9
+    X, y = synthetic_problem(n + k, d, seed=5)
+    th = _theta(d, y, kernel=kernel)
+    post = gpr.posterior(th, X, y)
+    f_ref, _ = gpr.nlml_and_grad(th, X, y)
+    eng = _engine()
+    _fit(eng, X[:n], y[:n], th)
+    f, in_place = eng.append(X[n:], y[n:])
+    assert in_place
+    assert abs(f - f_ref) <= tol * abs(f_ref)
+    Xs = synthetic_leaves(500, d)
+    mean, var = eng.predict(Xs)
+    mean_ref, var_ref = gpr.predict_y(post, Xs)
+    assert np.max(np.abs(mean - mean_ref)) <= tol * 10 * max(1.0, float(np.max(np.abs(y))))
+    assert np.max(np.abs(var - var_ref)) <= tol * 10 * th.variance
+
+
+def test_a_chain_of_twenty_appends_equals_one_fit_fp64():
+    n0, d = 150, 4
+    ks = [1, 2, 7, 3, 1, 5, 1, 1, 4, 6, 2, 1, 7, 1, 3, 2, 1, 1, 5, 4]
+    n1 = n0 + sum(ks)
+    X, y = synthetic_problem(n1, d, seed=7)
+    th = _theta(d, y)
+    eng = _engine()
+    _fit(eng, X[:n0], y[:n0], th)
+    lo = n0
+    for k in ks:
+        f, in_place = eng.append(X[lo:lo + k], y[lo:lo + k])
+        assert in_place
+        lo += k
+    post = gpr.posterior(th, X, y)
+    f_ref, _ = gpr.nlml_and_grad(th, X, y)
+    assert abs(f - f_ref) <= 1e-9 * abs(f_ref)
+    Xs = synthetic_leaves(800, d)
+    mean, var = eng.predict(Xs)
+    mean_ref, var_ref = gpr.predict_y(post, Xs)
+    assert np.max(np.abs(mean - mean_ref)) <= 1e-9 * max(1.0, float(np.max(np.abs(y))))
+    assert np.max(np.abs(var - var_ref)) <= 1e-9 * th.variance
+    # the same chain on a second context gives the same bits (deterministic reductions)
+    eng2 = _engine()
+    _fit(eng2, X[:n0], y[:n0], th)
+    lo = n0
+    for k in ks:
+        eng2.append(X[lo:lo + k], y[lo:lo + k])
+        lo += k
+    m2, v2 = eng2.predict(Xs)
+    assert np.array_equal(mean, m2) and np.array_equal(var, v2)
+
+
+def test_pad_crossing_small_problems_and_wide_blocks_refit_and_say_so():
+    d = 3
+    X, y = synthetic_problem(400, d, seed=9)
+    th = _theta(d, y)
+    for n, k, why in [(126, 5, "padded size"), (40, 6, "one-launch"), (200, 70, "more than 64")]:
+        eng = _engine()
+        _fit(eng, X[:n], y[:n], th)
+        f, in_place = eng.append(X[n:n + k], y[n:n + k])
+        assert not in_place and why in eng.last_message(), eng.last_message()
+        post = gpr.posterior(th, X[:n + k], y[:n + k])
+        f_ref, _ = gpr.nlml_and_grad(th, X[:n + k], y[:n + k])
+        assert abs(f - f_ref) <= 1e-9 * abs(f_ref)
+        Xs = synthetic_leaves(300, d)
+        mean, var = eng.predict(Xs)
+        mean_ref, var_ref = gpr.predict_y(post, Xs)
+        assert np.max(np.abs(mean - mean_ref)) <= 1e-9 * max(1.0, float(np.max(np.abs(y))))
+        assert np.max(np.abs(var - var_ref)) <= 1e-9 * th.variance
+    # float-predict contexts pad to 256: the crossing is there
+    eng = _engine("mixed")
+    _fit(eng, X[:250], y[:250], th)
+    _, in_place = eng.append(X[250:257], y[250:257])
+    assert not in_place and "padded size" in eng.last_message()
+
+
+def test_a_block_that_is_not_positive_definite_leaves_the_posterior_alone():
+    n, d = 300, 3
+    X, y = synthetic_problem(n, d, seed=11)
+    th = _theta(d, y, noise=1e-6)
+    eng = _engine()
+    _fit(eng, X, y, th)
+    Xs = synthetic_leaves(400, d)
+    before = eng.predict(Xs)
+    bad = np.vstack([X[:2], np.full((1, d), np.nan)])  # a NaN input: the Schur complement cannot be factorised
+    with pytest.raises(np.linalg.LinAlgError) as err:
+        eng.append(bad, np.zeros(3))
+    assert "pivot" in str(err.value)
+    assert eng.n == n
+    after = eng.predict(Xs)
+    assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
+    # state errors: no posterior yet
+    eng2 = _engine()
+    eng2.set_data(X, y)
+    from pygpso_amd import _lib as L
+
+    with pytest.raises(L.GpsoHipError):
+        eng2.append(X[:1], y[:1])
+
+
+@pytest.mark.parametrize("math", ["f16x3", "bf16x6", "native"])
+@pytest.mark.parametrize("dtype", ["mixed", "float32"])
+def test_append_in_float_contexts_repacks_only_the_new_tile_rows(dtype, math):
+    """The 16-bit pieces / the packed f32 tiles of the rows an append wrote are packed in place; everything a from-scratch
+    fit of the same context type would be held to is held here: the float bounds of tests/test_gpu_parity.py."""
+    n, d, k = 2048 - 40, 12, 7
+    X, y = synthetic_problem(n + 3 * k, d, seed=13)
+    th = gpr.Theta("Matern52", np.array([0.25 * np.sqrt(d)]), 1.0, 1e-3, float(y.mean()))
+    Xs = synthetic_leaves(4096, d)
+    eng = _engine(dtype, predict_math=math)
+    _fit(eng, X[:n], y[:n], th)
+    eng.predict(Xs[:256])  # (the self-test has ruled and the pieces are built before the first append)
+    lo = n
+    for _ in range(3):
+        f, in_place = eng.append(X[lo:lo + k], y[lo:lo + k])
+        assert in_place, eng.last_message()
+        lo += k
+    post = gpr.posterior(th, X, y)
+    f_ref, _ = gpr.nlml_and_grad(th, X, y)
+    assert abs(f - f_ref) <= (2e-5 if dtype == "float32" else 1e-9) * abs(f_ref)
+    mean, var = eng.predict(Xs)
+    assert eng.precision_info()["predict_math"] == math
+    mean_ref, var_ref = gpr.predict_y(post, Xs)
+    em = float(np.max(np.abs(mean - mean_ref)) / np.max(np.abs(y)))
+    ev = float(np.max(np.abs(var - var_ref)) / th.variance)
+    print(f"append {dtype}/{math}: |d mean| {em:.2e} max|y|, |d var| {ev:.2e} sigma^2")
+    assert em <= 1.8e-4 and ev <= 1.3e-5  # FLOAT_BOUNDS["C3"] of tests/test_gpu_parity.py
+    # against a from-scratch fit of the same context type on the same points: the same class of error
+    ref = _engine(dtype, predict_math=math)
+    _fit(ref, X, y, th)
+    m2, v2 = ref.predict(Xs)
+    em2 = float(np.max(np.abs(m2 - mean_ref)) / np.max(np.abs(y)))
+    ev2 = float(np.max(np.abs(v2 - var_ref)) / th.variance)
+    assert em <= 4 * em2 + 1e-6 and ev <= 4 * ev2 + 1e-7, (em, em2, ev, ev2)
+
+
+def test_append_when_the_fp16_scale_crosses_a_power_of_two():
+    """A new point almost on top of an old one makes |L^-1|'s largest entry jump (1 / sqrt of a tiny Schur complement):
+    the fp16 pieces of EVERY row are then repacked with the new scale (decided on the device)."""
+    n, d = 500, 2
+    X, y = synthetic_problem(n + 1, d, seed=17)
+    X[n] = X[3] + 1e-7
+    y[n] = y[3]
+    th = gpr.Theta("Matern52", np.array([0.3]), 1.0, 1e-4, float(y.mean()))
+    eng = _engine("mixed", predict_math="f16x3", precision_check=False)
+    _fit(eng, X[:n], y[:n], th)
+    Xs = synthetic_leaves(2000, d)
+    eng.predict(Xs[:256])
+    _, in_place = eng.append(X[n:], y[n:])
+    assert in_place
+    post = gpr.posterior(th, X, y)
+    mean, var = eng.predict(Xs)
+    mean_ref, var_ref = gpr.predict_y(post, Xs)
+    assert np.max(np.abs(mean - mean_ref)) <= 6e-4 * np.max(np.abs(y))
+    assert np.max(np.abs(var - var_ref)) <= 1e-4 * th.variance
+
+
+def test_append_data_on_the_model_and_refit_every_on_the_surrogate():
+    from pygpso_amd import GPRSurrogate
+    from pygpso_amd.kernels import Constant, Matern52
+
+    n, d = 160, 2
+    X, y = synthetic_problem(n + 12, d, seed=19)
+    surr = GPRSurrogate(gp_kernel=Matern52(lengthscales=0.25, variance=1.0), gp_meanf=Constant(0.0), refit_every=3)
+    surr.append(X[:n], y[:n])
+    surr.gp_update()  # update 0: hyper-parameters optimised
+    model = surr.gpflow_model
+    evals0 = model.num_loss_evals
+    theta0 = model.parameter_dict()
+    for step in range(1, 4):
+        lo = n + 4 * (step - 1)
+        surr.append(X[lo:lo + 4], y[lo:lo + 4])
+        surr.gp_update()
+        if step < 3:  # appended at the kept hyper-parameters: no loss evaluation
+            assert model.num_loss_evals == evals0
+            assert all(np.array_equal(theta0[k], v) for k, v in model.parameter_dict().items())
+            th = gpr.Theta("Matern52", np.atleast_1d(theta0[".kernel.lengthscales"]), float(theta0[".kernel.variance"]),
+                           float(theta0[".likelihood.variance"]), float(theta0[".mean_function.c"]))
+            post = gpr.posterior(th, X[:lo + 4], y[:lo + 4])
+            Xs = synthetic_leaves(200, d)
+            mean, var = model.predict_y(Xs)
+            mean_ref, var_ref = gpr.predict_y(post, Xs)
+            assert np.max(np.abs(mean[:, 0] - mean_ref)) <= 1e-8 * max(1.0, float(np.max(np.abs(y))))
+            assert np.max(np.abs(var[:, 0] - var_ref)) <= 1e-8 * th.variance
+        else:  # the third update re-optimises
+            assert model.num_loss_evals > evals0
