@@ -185,8 +185,9 @@ int gpso_fit_eval_u(gpso_ctx* ctx, int kernel, const double* u, int n_ls, int tr
  * instead of O(N^3); arithmetic in double whatever the context's matrix type.  *nlml (nullable) receives the NLML of
  * the N + k points at theta.
  * Returns GPSO_OK (extended in place); 1 when the posterior of the N + k points was instead REFITTED from scratch at
- * theta -- k > 64, N + k above the padded size (gpso_padded_n: every buffer's layout changes), or N + k <= 128 (the
- * one-launch fit is the shorter exact update there) -- gpso_last_error then says which; GPSO_E_NOTPD with the failing
+ * theta -- k > 64 (k > 32 below a padded size of 4096, where the refit is as fast), N + k above the padded size
+ * (gpso_padded_n: every buffer's layout changes), or N + k <= 128 (the one-launch fit is the shorter exact update
+ * there) -- gpso_last_error then says which; GPSO_E_NOTPD with the failing
  * pivot (N + p) when the appended block is not positive definite: the posterior of the N points then stays resident
  * unchanged; GPSO_E_STATE without a posterior fitted on this context.  The gradient-side K^-1 (GPSO_MAT_KINV) is not
  * extended.  The precision self-test runs again before the next prediction of a float-predict context. */

@@ -876,6 +876,9 @@ struct EngineT : Engine {
     if (k > kAppendMax) refit = "more than 64 new points in one call";
     else if (n_new > npad) refit = "the padded size grows: every buffer changes its layout";
     else if (fused_small && small_fit_eligible(n_new, dp)) refit = "N <= 128: the one-launch fit is the shorter exact update";
+    // (measured, float, N = 2048: append of 64 points 0.55 ms, of 7 points 0.06 ms, posterior fit 0.52 ms -- the k x k corner
+    // is factorised by one workgroup; at N = 8192 the same 64 points take 1.1 ms against 4.2: profiles/r05_append_bench.jsonl)
+    else if (k > 32 && npad < 4096) refit = "more than 32 new points beside fewer than 4096: the refit is as fast";
     if (refit != nullptr) {
       std::vector<double> X(x_host), y(y_host), ls(ls_host);
       X.insert(X.end(), Xn, Xn + (size_t)k * d);

@@ -16,14 +16,14 @@
 //   append_cross_kernel      K12 (n x k) and K22 + noise I (k x k) from the scaled inputs; the new rows' scaled inputs,
 //                            norms and MFMA fragments land where the fit leaves them (same formulas as scale_x_kernel /
 //                            gram_kernel: GEMM-form r^2 in double)
-//   append_rows_kernel       B[r][:] = sum_{c <= r} X11[r][c] K12[c][:]          one wave per row, coalesced row reads
-//   append_gram_part_kernel  partial [B | a1]^T [B | a1] per 64-row chunk          (L21 L21^T and L21 a1 in one go)
+//   append_pass_kernel<.., false>  row pass, tile by tile: B[r][:] = sum_{c <= r} X11[r][c] K12[c][:]  (partials per tile chunk)
+//   append_gram_part_kernel  B from its chunks; partial [B | a1]^T [B | a1] per 64-row block  (L21 L21^T and L21 a1 in one go)
 //   append_chol_kernel       ONE workgroup: S, its Cholesky (first failing pivot -> info = n + p), L22^-1, a2, nlml
-//   append_cols_kernel       W[:, c] = sum_{r >= c} B[r][:] X11[r][c] per 64-column strip (B blocks through LDS), then
-//                            R = -L22^-1 W: the new rows of L^-1 and L, alpha1 += R^T a2, diag(K_y^-1) += sum R^2,
+//   append_pass_kernel<.., true>   column pass: W[:, c] = sum_{r >= c} B[r][:] X11[r][c]
+//   append_finish_kernel     R = -L22^-1 W: the new rows of L^-1 and L, alpha1 += R^T a2, diag(K_y^-1) += sum R^2,
 //                            max |new entries| for the fp16 split's scale; one extra workgroup writes the k x k corner
 //
-// A failed pivot leaves the resident posterior of the n points untouched (append_cols_kernel exits on info).
+// A failed pivot leaves the resident posterior of the n points untouched (append_finish_kernel exits on info).
 #include <climits>
 
 #include "common.hpp"
@@ -65,85 +65,163 @@ __global__ __launch_bounds__(256) void append_cross_kernel(AppendArgs a) {
       if (a.f16_scal != nullptr) a.f16_scal[3] = a.f16_scal[1];  // the scale the resident pieces were packed with
     }
   }
-  const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+  // 64 rows per workgroup, staged in LDS (odd stride); thread = (row, j mod 4): the k kernel values of a row are dealt to
+  // four threads.  (First version: one thread per row reading its scaled inputs from global memory k times: 13 - 22 us.)
+  __shared__ double xr[64 * 49];
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  const int st = dp + 1;
+  for (int e = tid; e < 64 * dp; e += 256) {
+    const int rr = e / dp, kk = e - rr * dp;
+    const int64_t i = r0 + rr;
+    xr[rr * st + kk] = (i < n) ? a.xs64[i * dp + kk] : (i < n + k ? xn[(i - n) * dp + kk] : 0.0);
+  }
+  __syncthreads();
+  const int rr = tid & 63, jg = tid >> 6;
+  const int64_t i = r0 + rr;
   if (i >= n + k) return;
+  const double ni = (i < n) ? a.xnorm64[i] : nn[i - n];
   double* out = a.Kc + i * KP;
-  if (i < n) {
-    const double* xi = a.xs64 + i * dp;
-    const double ni = a.xnorm64[i];
-    for (int j = 0; j < k; ++j) {
+  for (int j = jg; j < KP; j += 4) {
+    double kv = 0.0;
+    if (j < k) {
       double s = 0.0;
-      for (int kk = 0; kk < dp; ++kk) s = fma(xi[kk], xn[j * dp + kk], s);
-      out[j] = kern_from_r2_lean(a.kernel, fma(-2.0, s, ni + nn[j]), a.variance);
+      for (int kk = 0; kk < dp; ++kk) s = fma(xr[rr * st + kk], xn[j * dp + kk], s);
+      kv = kern_from_r2_lean(a.kernel, fma(-2.0, s, ni + nn[j]), a.variance);
+      if (i - n == j) kv += a.noise;
     }
+    out[j] = kv;
+  }
+}
+
+// ---- 2. / 5a. the two passes over L^-1, tile by tile ----------------------------------------------------------------
+// One workgroup = one 64-row block of L^-1 (row pass: B = X11 K12) or one 64-column block (column pass: W = X11^T B) times
+// a chunk of `ct` of its 64x64 tiles; grid (tiles per side, nq <= 8).  A tile arrives with 16-byte loads (the next one is
+// in flight while this one is used), is masked to the lower triangle / the first n rows and staged in LDS beside the 64
+// operand rows (K12 / B) of its contraction index; the product runs on the f64 matrix instruction (16x16x4: wave g owns 16
+// rows / columns of the block, the k <= 64 right-hand sides are its 16-wide column blocks), accumulators live across the
+// chunk's tiles.  Partial sums per chunk go to part[q][index][KP]; the consumer adds the chunks in order (deterministic).
+// (First versions, profiles/r05_append_experiments.txt: one wave per row re-reading K12 from the L2 for every row -- 8.6 TB
+// of L2 traffic at N = 16 384 -- and one workgroup per column strip: 0.71 + 1.98 ms at C5, 14 + 183 us at C3; then vector
+// FMAs with scalar operand loads in the inner loop, latency-chained: 0.61 + 0.39 ms, 34 + 36 us.)
+template <int KP>
+struct PassShape {
+  static constexpr int NB = KP <= 16 ? 1 : KP / 16;  // 16-wide blocks of right-hand sides (KP = 8: half a block is padding)
+  static constexpr int UW = 16 * NB;
+};
+template <typename TF, int KP>
+constexpr int append_pass_lds_bytes() { return 64 * 65 * (int)sizeof(TF) + 64 * PassShape<KP>::UW * 8; }
+
+template <typename TF, int KP, bool COLS>
+__global__ __launch_bounds__(256) void append_pass_kernel(const TF* __restrict__ linv, int64_t n, int64_t npad,
+                                                          const double* __restrict__ U, double* __restrict__ part, int ct) {
+  constexpr int EV = 16 / (int)sizeof(TF);  // elements per 16-byte load
+  constexpr int VPR = 64 / EV;              // loads per tile row
+  constexpr int RPP = 256 / VPR;            // tile rows per pass of the workgroup
+  constexpr int NP = 64 / RPP;              // passes
+  constexpr int NB = PassShape<KP>::NB, UW = PassShape<KP>::UW;
+  constexpr int NU = 64 * KP / 256;         // operand doubles per thread and tile
+  constexpr int LD = 65;
+  typedef TF vecT __attribute__((ext_vector_type(EV)));
+  extern __shared__ __align__(16) unsigned char pass_lds[];
+  TF* T = reinterpret_cast<TF*>(pass_lds);                                      // the tile, masked, [64][65]
+  double* Us = reinterpret_cast<double*>(pass_lds + 64 * LD * sizeof(TF));      // the operand rows, [64][UW]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tb = blockIdx.x, q = blockIdx.y;
+  const int ntile = (int)((n + 63) / 64);
+  int lo, hi;  // range of the other tile index
+  if (!COLS) {
+    lo = q * ct;
+    hi = min((q + 1) * ct, tb + 1);
   } else {
-    const int t = (int)(i - n);
-    for (int j = 0; j < k; ++j) {
-      double s = 0.0;
-      for (int kk = 0; kk < dp; ++kk) s = fma(xn[t * dp + kk], xn[j * dp + kk], s);
-      double kv = kern_from_r2_lean(a.kernel, fma(-2.0, s, nn[t] + nn[j]), a.variance);
-      if (t == j) kv += a.noise;
-      out[j] = kv;
-    }
+    lo = max(tb, q * ct);
+    hi = min((q + 1) * ct, ntile);
   }
-  for (int j = k; j < KP; ++j) out[j] = 0.0;
-}
-
-// ---- 2. row pass: B = X11 K12 ---------------------------------------------------------------------------------------
-template <typename TF, int KP>
-__global__ __launch_bounds__(256) void append_rows_kernel(const TF* __restrict__ linv, int64_t n, int64_t npad,
-                                                          const double* __restrict__ Kc, double* __restrict__ Bm) {
-  const int lane = threadIdx.x & 63;
-  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= n) return;
-  double acc[KP];
+  if (lo >= hi) return;  // (the consumer knows which chunks exist)
+  if (KP < UW)
+    for (int e = tid; e < 64 * (UW - KP); e += 256) Us[(e / (UW - KP)) * UW + KP + e % (UW - KP)] = 0.0;  // padding columns
+  const int vrow = tid / VPR, vcol = (tid % VPR) * EV;
+  vecT v[NP];
+  double uu[NU];
+  auto fetch = [&](int o) {
+    const int64_t R0 = (COLS ? o : tb) * 64, C0 = (COLS ? tb : o) * 64;
 #pragma unroll
-  for (int j = 0; j < KP; ++j) acc[j] = 0.0;
-  const TF* row = linv + r * npad;
-  int64_t c = lane;
-  if constexpr (KP <= 16) {
-    // (two steps in flight: one row per wave, nothing else hides the latency)
-    for (; c + 64 <= r; c += 128) {
-      const double l0 = (double)row[c], l1 = (double)row[c + 64];
-      double k0[KP], k1[KP];
+    for (int p = 0; p < NP; ++p) v[p] = *reinterpret_cast<const vecT*>(linv + (R0 + p * RPP + vrow) * npad + C0 + vcol);
+    // the operand rows of the contraction index: K12 rows of the tile's columns (row pass) / B rows of its rows (column pass)
+    const int64_t X0 = COLS ? R0 : C0;
 #pragma unroll
-      for (int j = 0; j < KP; ++j) {
-        k0[j] = Kc[c * KP + j];
-        k1[j] = Kc[(c + 64) * KP + j];
+    for (int w = 0; w < NU; ++w) {
+      const int idx = w * 256 + tid;  // (x, j) = (idx / KP, idx % KP)
+      uu[w] = (X0 + idx / KP < n) ? U[X0 * KP + idx] : 0.0;
+    }
+  };
+  f64x4 acc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) acc[b] = f64x4{0, 0, 0, 0};
+  fetch(lo);
+  for (int o = lo; o < hi; ++o) {
+    const int64_t R0 = (COLS ? o : tb) * 64, C0 = (COLS ? tb : o) * 64;
+    __syncthreads();  // (the previous tile has been read)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int64_t gr = R0 + p * RPP + vrow;
+#pragma unroll
+      for (int x = 0; x < EV; ++x) {
+        const int64_t gc = C0 + vcol + x;
+        T[(p * RPP + vrow) * LD + vcol + x] = (gr < n && gc <= gr) ? v[p][x] : (TF)0;
       }
+    }
 #pragma unroll
-      for (int j = 0; j < KP; ++j) acc[j] = fma(l1, k1[j], fma(l0, k0[j], acc[j]));
+    for (int w = 0; w < NU; ++w) {
+      const int idx = w * 256 + tid;
+      Us[(idx / KP) * UW + idx % KP] = uu[w];
+    }
+    if (o + 1 < hi) fetch(o + 1);
+    __syncthreads();
+    // 16 k-steps of the f64 matrix instruction: D[i][j] += A[i][kk] B[kk][j], A = the tile (row pass: i = row, kk = column;
+    // column pass: i = column, kk = row) for this wave's 16 rows / columns, B = the operand rows
+    const int i = lane & 15, kk = lane >> 4;
+#pragma unroll 4
+    for (int s4 = 0; s4 < 16; ++s4) {
+      const double a = COLS ? (double)T[(4 * s4 + kk) * LD + 16 * g + i] : (double)T[(16 * g + i) * LD + 4 * s4 + kk];
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Us[(4 * s4 + kk) * UW + 16 * b + i], acc[b], 0, 0, 0);
     }
   }
-  for (; c <= r; c += 64) {
-    const double l = (double)row[c];
+  // accumulator register r of lane l: index 16 g + (l >> 4) + 4 r of the block, right-hand side 16 b + (l & 15)
 #pragma unroll
-    for (int j = 0; j < KP; ++j) acc[j] = fma(l, Kc[c * KP + j], acc[j]);
-  }
-  double mine = 0.0;
+  for (int b = 0; b < NB; ++b) {
+    const int j = 16 * b + (lane & 15);
+    if (j < KP) {
 #pragma unroll
-  for (int j = 0; j < KP; ++j) {
-    const double s = wave_sum(acc[j]);
-    if (lane == j) mine = s;
+      for (int r = 0; r < 4; ++r)
+        part[((int64_t)q * npad + (int64_t)tb * 64 + 16 * g + (lane >> 4) + 4 * r) * KP + j] = acc[b][r];
+    }
   }
-  if (lane < KP) Bm[r * KP + lane] = mine;
 }
 
-// ---- 3. partial Gram of [B | a1] per 64-row chunk -------------------------------------------------------------------
+// ---- 3. B from its chunks; partial Gram of [B | a1] per 64-row block -----------------------------------------------------
 template <typename TF, int KP>
-__global__ __launch_bounds__(256) void append_gram_part_kernel(const double* __restrict__ Bm, const TF* __restrict__ white,
+__global__ __launch_bounds__(256) void append_gram_part_kernel(const double* __restrict__ bpart, int ct, int64_t npad,
+                                                               double* __restrict__ Bm, const TF* __restrict__ white,
                                                                int64_t n, double* __restrict__ part) {
   constexpr int W = KP + 1, LD = KP + 2;
   __shared__ double tile[64 * LD];
   const int tid = threadIdx.x;
   const int64_t r0 = (int64_t)blockIdx.x * 64;
-  for (int e = tid; e < 64 * W; e += 256) {
-    const int rr = e / W, j = e - rr * W;
+  const int nq = (int)blockIdx.x / ct + 1;  // chunks of the row pass that hold tiles of this row block
+  for (int e = tid; e < 64 * KP; e += 256) {
+    const int rr = e / KP, j = e - rr * KP;
     const int64_t r = r0 + rr;
     double v = 0.0;
-    if (r < n) v = (j < KP) ? Bm[r * KP + j] : (double)white[r];
+    if (r < n) {
+      for (int q = 0; q < nq; ++q) v += bpart[((int64_t)q * npad + r) * KP + j];
+      Bm[r * KP + j] = v;
+    }
     tile[rr * LD + j] = v;
   }
+  if (tid < 64) tile[tid * LD + KP] = (r0 + tid < n) ? (double)white[r0 + tid] : 0.0;
   __syncthreads();
   double* out = part + (int64_t)blockIdx.x * W * W;
   for (int e = tid; e < W * W; e += 256) {
@@ -169,12 +247,34 @@ __global__ __launch_bounds__(256) void append_chol_kernel(AppendArgs a, int nchu
   const int tid = threadIdx.x, k = a.k;
   const int64_t n = a.n;
   if (tid == 0) bad = INT_MAX;
-  // S = K22 + noise I - sum over the chunks of B^T B (fixed order: deterministic); v = B^T a1
-  for (int e = tid; e < W * W; e += 256) {
+  // S = K22 + noise I - sum over the chunks of B^T B; v = B^T a1.  PARTS threads share an entry (chunks p, p + PARTS, ..),
+  // their sums are added in order: deterministic
+  constexpr int EP = 1 << (32 - __builtin_clz((unsigned)(W * W - 1)));  // entries, rounded up to a power of two
+  constexpr int PARTS = EP >= 256 ? 1 : 256 / EP;
+  __shared__ double psum[PARTS > 1 ? 256 : 1];
+  for (int e0 = 0; e0 < W * W; e0 += 256 / PARTS) {
+    const int e = e0 + tid % (256 / PARTS), p = tid / (256 / PARTS);
     const int i = e / W, j = e - i * W;
-    if (i > j || i >= k) continue;
+    const bool live = e < W * W && i <= j && i < k;
     double g = 0.0;
-    for (int c = 0; c < nchunk; ++c) g += a.part[(int64_t)c * W * W + e];
+    if (live) {
+      int c = p;
+      for (; c + 3 * PARTS < nchunk; c += 4 * PARTS) {
+        const double g0 = a.part[(int64_t)c * W * W + e], g1 = a.part[(int64_t)(c + PARTS) * W * W + e];
+        const double g2 = a.part[(int64_t)(c + 2 * PARTS) * W * W + e], g3 = a.part[(int64_t)(c + 3 * PARTS) * W * W + e];
+        g += (g0 + g1) + (g2 + g3);
+      }
+      for (; c < nchunk; c += PARTS) g += a.part[(int64_t)c * W * W + e];
+    }
+    if (PARTS > 1) {
+      __syncthreads();
+      psum[tid] = g;
+      __syncthreads();
+      g = 0.0;
+      if (p == 0)
+        for (int pp = 0; pp < PARTS; ++pp) g += psum[pp * (256 / PARTS) + tid];
+    }
+    if (!live || p != 0) continue;
     if (j == KP) {
       v[i] = g;
     } else if (j < k) {
@@ -256,23 +356,18 @@ __device__ __forceinline__ void store_alpha_p(void* alpha_p, int64_t i, double v
   static_cast<TP*>(alpha_p)[i] = (TP)v;
 }
 
+// ---- 5b. the new rows: R = -L22^-1 W per column, alpha, diag(K_y^-1), the k x k corner ------------------------------------
 template <typename TF, typename TP, int KP>
-__global__ __launch_bounds__(256) void append_cols_kernel(AppendArgs a, TF* __restrict__ linv, TF* __restrict__ Lf,
-                                                          TF* __restrict__ white, TF* __restrict__ alpha_f) {
+__global__ __launch_bounds__(256) void append_finish_kernel(AppendArgs a, const double* __restrict__ wpart, int ct,
+                                                            TF* __restrict__ linv, TF* __restrict__ Lf,
+                                                            TF* __restrict__ white, TF* __restrict__ alpha_f) {
   if (*a.info != INT_MAX) return;  // S was not positive definite: the resident posterior stays as it is
-  constexpr int LDB = KP;  // (rows of the block are read wave-uniformly: LDS broadcasts, no padding needed)
-  constexpr int JW = KP < 16 ? KP : 16;
-  constexpr int kBufDoubles = 64 * KP > 3 * JW * 64 ? 64 * KP : 3 * JW * 64;
-  __shared__ double buf[kBufDoubles];   // a 64-row block of B; afterwards the cross-wave reduction, JW accumulators at a time
-  __shared__ double Xs[64 * 65 / 2];    // L22^-1, lower triangle packed by rows
+  __shared__ double Xs[64 * 65 / 2];  // L22^-1, lower triangle packed by rows
   __shared__ double a2s[64];
-  double* Bs = buf;
-  double (*red)[JW][64] = reinterpret_cast<double (*)[JW][64]>(buf);
   const int tid = threadIdx.x, lane = tid & 63;
-  const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int k = a.k;
   const int64_t n = a.n, npad = a.npad;
-  const int nstrip = (int)((n + 63) / 64);
+  const int nblk = (int)((n + 255) / 256);
   for (int e = tid; e < k * k; e += 256) {
     const int i = e / k, j = e - i * k;
     if (j <= i) Xs[i * (i + 1) / 2 + j] = a.sm[4096 + i * 64 + j];
@@ -280,7 +375,7 @@ __global__ __launch_bounds__(256) void append_cols_kernel(AppendArgs a, TF* __re
   if (tid < k) a2s[tid] = a.sm[8192 + tid];
   __syncthreads();
 
-  if ((int)blockIdx.x == nstrip) {
+  if ((int)blockIdx.x == nblk) {
     // the k x k corner: rows n .. n + k - 1, columns n .. (end of the 64-column block that holds n + k - 1)
     const int64_t cend = min(npad, (n + k + 63) / 64 * 64);
     const int wcols = (int)(cend - n);
@@ -317,67 +412,39 @@ __global__ __launch_bounds__(256) void append_cols_kernel(AppendArgs a, TF* __re
     return;
   }
 
-  const int64_t c = (int64_t)blockIdx.x * 64 + lane;
-  double w[KP];
-#pragma unroll
-  for (int j = 0; j < KP; ++j) w[j] = 0.0;
-  const int nrb = nstrip;
-  for (int rb = (int)blockIdx.x; rb < nrb; ++rb) {
-    const int64_t r0 = (int64_t)rb * 64;
-    __syncthreads();
-    for (int e = tid; e < 64 * KP; e += 256) {
-      const int rr = e / KP, j = e - rr * KP;
-      Bs[rr * LDB + j] = (r0 + rr < n) ? a.Bm[(r0 + rr) * KP + j] : 0.0;
-    }
-    // this wave's 16 rows of the block: the loads first, then the updates
-    double l[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int64_t r = r0 + g + 4 * u;
-      l[u] = (r < n && r >= c) ? (double)linv[r * npad + c] : 0.0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const double* brow = Bs + (g + 4 * u) * LDB;
-#pragma unroll
-      for (int j = 0; j < KP; ++j) w[j] = fma(l[u], brow[j], w[j]);
-    }
-  }
-  // sum the four waves' partial columns (fixed order), 16 accumulators at a time; wave 0 keeps the totals
-#pragma unroll
-  for (int j0 = 0; j0 < KP; j0 += JW) {
-    __syncthreads();
-    if (g > 0) {
-#pragma unroll
-      for (int j = 0; j < JW; ++j) red[g - 1][j][lane] = w[j0 + j];
-    }
-    __syncthreads();
-    if (g == 0) {
-#pragma unroll
-      for (int j = 0; j < JW; ++j) w[j0 + j] = (w[j0 + j] + red[0][j][lane]) + (red[1][j][lane] + red[2][j][lane]);
-    }
-  }
-  if (g != 0 || c >= n) return;
-  // R = -L22^-1 W: the new rows of L^-1 at this column; L's new rows are B^T
-  double al = 0.0, sq = 0.0;
+  const int64_t c = (int64_t)blockIdx.x * 256 + tid;
   float m = 0.0f;
-  for (int t = 0; t < k; ++t) {
-    double s = 0.0;
+  if (c < n) {
+    // W[:, c]: the chunks of the column pass that hold tiles of this column block, in order
+    const int ntile = (int)((n + 63) / 64);
+    const int q0 = (int)(c / 64) / ct, q1 = (ntile - 1) / ct;
+    double w[KP];
 #pragma unroll
-    for (int j = 0; j < KP; ++j)
-      if (j <= t) s = fma(Xs[t * (t + 1) / 2 + j], w[j], s);
-    const TF rv = (TF)(-s);
-    linv[(n + t) * npad + c] = rv;
-    Lf[(n + t) * npad + c] = (TF)a.Bm[c * KP + t];
-    al = fma((double)rv, a2s[t], al);
-    sq = fma((double)rv, (double)rv, sq);
-    m = fmaxf(m, fabsf((float)rv));
+    for (int j = 0; j < KP; ++j) w[j] = 0.0;
+    for (int q = q0; q <= q1; ++q) {
+      const double* src = wpart + ((int64_t)q * npad + c) * KP;
+#pragma unroll
+      for (int j = 0; j < KP; ++j) w[j] += src[j];
+    }
+    // R = -L22^-1 W: the new rows of L^-1 at this column; L's new rows are B^T
+    double al = 0.0, sq = 0.0;
+    for (int t = 0; t < k; ++t) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < KP; ++j)
+        if (j <= t) s = fma(Xs[t * (t + 1) / 2 + j], w[j], s);
+      const TF rv = (TF)(-s);
+      linv[(n + t) * npad + c] = rv;
+      Lf[(n + t) * npad + c] = (TF)a.Bm[c * KP + t];
+      al = fma((double)rv, a2s[t], al);
+      sq = fma((double)rv, (double)rv, sq);
+      m = fmaxf(m, fabsf((float)rv));
+    }
+    const TF alf = (TF)((double)alpha_f[c] + al);
+    alpha_f[c] = alf;
+    store_alpha_p<TP>(a.alpha_p, c, (double)alf);
+    a.kinv_diag[c] += sq;
   }
-  const TF alf = (TF)((double)alpha_f[c] + al);
-  alpha_f[c] = alf;
-  store_alpha_p<TP>(a.alpha_p, c, (double)alf);
-  a.kinv_diag[c] += sq;
   if (a.f16_scal != nullptr) {
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
     if (lane == 0 && m > 0.0f) atomicMax(reinterpret_cast<unsigned*>(a.f16_scal), __builtin_bit_cast(unsigned, m));
@@ -386,20 +453,32 @@ __global__ __launch_bounds__(256) void append_cols_kernel(AppendArgs a, TF* __re
 
 // ---- launcher ---------------------------------------------------------------------------------------------------------
 int append_kp(int k) { return k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : 64; }
-size_t append_scratch_doubles(int64_t npad, int kp) {
-  const size_t chunks = (size_t)(npad + 63) / 64;
-  return (size_t)(npad + kAppendMax) * kp + (size_t)npad * kp + chunks * (size_t)(kp + 1) * (kp + 1) + 8192 + 64 + 8;
-}
+constexpr int kAppendChunks = 8;  // chunks of tiles per block row / column of a pass, at most
+static size_t append_off_bm(int64_t npad, int kp) { return (size_t)(npad + kAppendMax) * kp; }
+static size_t append_off_pass(int64_t npad, int kp) { return append_off_bm(npad, kp) + (size_t)npad * kp; }
+static size_t append_off_part(int64_t npad, int kp) { return append_off_pass(npad, kp) + (size_t)kAppendChunks * npad * kp; }
+static size_t append_off_sm(int64_t npad, int kp) { return append_off_part(npad, kp) + (size_t)((npad + 63) / 64) * (kp + 1) * (kp + 1); }
+static size_t append_off_info(int64_t npad, int kp) { return append_off_sm(npad, kp) + 8192 + 64; }
+size_t append_scratch_doubles(int64_t npad, int kp) { return append_off_info(npad, kp) + 8; }
 
 template <typename TF, typename TP, int KP>
-static void launch_append_kp(hipStream_t st, AppendArgs a, TF* linv, TF* Lf, TF* white, TF* alpha_f) {
+static void launch_append_kp(hipStream_t st, AppendArgs a, double* pass, TF* linv, TF* Lf, TF* white, TF* alpha_f) {
   const int64_t n = a.n;
-  const int nchunk = (int)((n + 63) / 64);
-  hipLaunchKernelGGL(append_cross_kernel, dim3((unsigned)((n + a.k + 255) / 256)), dim3(256), 0, st, a);
-  hipLaunchKernelGGL((append_rows_kernel<TF, KP>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, linv, n, a.npad, a.Kc, a.Bm);
-  hipLaunchKernelGGL((append_gram_part_kernel<TF, KP>), dim3((unsigned)nchunk), dim3(256), 0, st, a.Bm, white, n, a.part);
-  hipLaunchKernelGGL((append_chol_kernel<KP>), dim3(1), dim3(256), 0, st, a, nchunk);
-  hipLaunchKernelGGL((append_cols_kernel<TF, TP, KP>), dim3((unsigned)nchunk + 1), dim3(256), 0, st, a, linv, Lf, white, alpha_f);
+  const int ntile = (int)((n + 63) / 64);
+  const int ct = (ntile + kAppendChunks - 1) / kAppendChunks, nq = (ntile + ct - 1) / ct;
+  hipLaunchKernelGGL(append_cross_kernel, dim3((unsigned)((n + a.k + 63) / 64)), dim3(256), 0, st, a);
+  constexpr int lds = append_pass_lds_bytes<TF, KP>();
+  if (ensure_dyn_lds(reinterpret_cast<const void*>(&append_pass_kernel<TF, KP, false>), lds) ||
+      ensure_dyn_lds(reinterpret_cast<const void*>(&append_pass_kernel<TF, KP, true>), lds))
+    return;  // (recorded with note_launch_error)
+  hipLaunchKernelGGL((append_pass_kernel<TF, KP, false>), dim3((unsigned)ntile, (unsigned)nq), dim3(256), lds, st, linv, n, a.npad,
+                     a.Kc, pass, ct);
+  hipLaunchKernelGGL((append_gram_part_kernel<TF, KP>), dim3((unsigned)ntile), dim3(256), 0, st, pass, ct, a.npad, a.Bm, white, n, a.part);
+  hipLaunchKernelGGL((append_chol_kernel<KP>), dim3(1), dim3(256), 0, st, a, ntile);
+  hipLaunchKernelGGL((append_pass_kernel<TF, KP, true>), dim3((unsigned)ntile, (unsigned)nq), dim3(256), lds, st, linv, n, a.npad,
+                     a.Bm, pass, ct);
+  hipLaunchKernelGGL((append_finish_kernel<TF, TP, KP>), dim3((unsigned)((n + 255) / 256) + 1), dim3(256), 0, st, a, pass, ct, linv,
+                     Lf, white, alpha_f);
 }
 
 template <typename TF, typename TP>
@@ -408,25 +487,17 @@ void launch_append(hipStream_t st, AppendArgs a, void* scratch, TF* linv, TF* Lf
   a.kp = kp;
   double* q = static_cast<double*>(scratch);
   a.Kc = q;
-  q += (size_t)(a.npad + kAppendMax) * kp;
-  a.Bm = q;
-  q += (size_t)a.npad * kp;
-  a.part = q;
-  q += (size_t)((a.npad + 63) / 64) * (kp + 1) * (kp + 1);
-  a.sm = q;
-  q += 8192 + 64;
-  a.info = reinterpret_cast<int*>(q);
+  a.Bm = q + append_off_bm(a.npad, kp);
+  double* pass = q + append_off_pass(a.npad, kp);
+  a.part = q + append_off_part(a.npad, kp);
+  a.sm = q + append_off_sm(a.npad, kp);
+  a.info = reinterpret_cast<int*>(q + append_off_info(a.npad, kp));
   switch (kp) {
-    case 8: launch_append_kp<TF, TP, 8>(st, a, linv, Lf, white, alpha_f); break;
-    case 16: launch_append_kp<TF, TP, 16>(st, a, linv, Lf, white, alpha_f); break;
-    case 32: launch_append_kp<TF, TP, 32>(st, a, linv, Lf, white, alpha_f); break;
-    default: launch_append_kp<TF, TP, 64>(st, a, linv, Lf, white, alpha_f); break;
+    case 8: launch_append_kp<TF, TP, 8>(st, a, pass, linv, Lf, white, alpha_f); break;
+    case 16: launch_append_kp<TF, TP, 16>(st, a, pass, linv, Lf, white, alpha_f); break;
+    case 32: launch_append_kp<TF, TP, 32>(st, a, pass, linv, Lf, white, alpha_f); break;
+    default: launch_append_kp<TF, TP, 64>(st, a, pass, linv, Lf, white, alpha_f); break;
   }
-}
-const int* append_info_ptr(void* scratch, int64_t npad, int k) {
-  const int kp = append_kp(k);
-  const size_t off = (size_t)(npad + kAppendMax) * kp + (size_t)npad * kp + (size_t)((npad + 63) / 64) * (kp + 1) * (kp + 1) + 8192 + 64;
-  return reinterpret_cast<const int*>(static_cast<double*>(scratch) + off);
 }
 template void launch_append<float, float>(hipStream_t, AppendArgs, void*, float*, float*, float*, float*);
 template void launch_append<double, float>(hipStream_t, AppendArgs, void*, double*, double*, double*, double*);

@@ -283,7 +283,6 @@ struct AppendArgs {
 };
 int append_kp(int k);
 size_t append_scratch_doubles(int64_t npad, int kp);
-const int* append_info_ptr(void* scratch, int64_t npad, int k);
 template <typename TF, typename TP>
 void launch_append(hipStream_t st, AppendArgs a, void* scratch, TF* linv, TF* Lf, TF* white, TF* alpha_f);
 

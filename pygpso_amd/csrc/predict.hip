@@ -717,33 +717,35 @@ __global__ __launch_bounds__(256) void absmax_kernel(const TF* __restrict__ linv
 // the fit's own pass over L^-1: fit.hip white_kernel / alpha_sum_kernel), scal[1] := 2^-sa (read by the predict kernel's epilogue)
 template <typename TF>
 __global__ __launch_bounds__(256) void pack_linv_f16_kernel(const TF* __restrict__ linv, int64_t n, int64_t npad,
-                                                            float* __restrict__ scal, u32x4* __restrict__ out, int64_t rt0) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (rt, kq, lane)
+                                                            float* __restrict__ scal, u32x4* __restrict__ out, int64_t rt_lo,
+                                                            int64_t rt_hi, int only_if_rescaled) {
   const int64_t npad16 = npad / 16, npad32 = npad / 32;
   int e = 0;
   (void)frexpf(fmaxf(scal[0], 1e-30f), &e);  // max = m 2^e, m in [0.5, 1)
   const float up = ldexpf(1.0f, 14 - e);
-  if (idx == 0) scal[1] = ldexpf(1.0f, e - 14);
-  if (idx >= npad16 * npad32 * 64) return;
-  const int lane = (int)(idx & 63);
-  const int64_t kq = (idx >> 6) % npad32, rt = (idx >> 6) / npad32;
-  // after a gpso_append: the tile rows above rt0 keep their pieces as long as the scale they were packed with
-  // (scal[3], read-only here) is still the scale (workgroup-uniform up to the tile row)
-  if (rt < rt0 && scal[3] == ldexpf(1.0f, e - 14)) return;
-  const int64_t row = rt * 16 + (lane & 15);
-  float v[8];
+  // after a gpso_append the tile rows above the appended ones keep their pieces as long as the scale they were packed
+  // with (scal[3], read-only here) is still the scale: that launch (a small grid, grid-stride) exits at once
+  if (only_if_rescaled && scal[3] == ldexpf(1.0f, e - 14)) return;
+  if (!only_if_rescaled && blockIdx.x == 0 && threadIdx.x == 0) scal[1] = ldexpf(1.0f, e - 14);
+  const int64_t total = (rt_hi - rt_lo) * npad32 * 64;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {  // (rt, kq, lane)
+    const int lane = (int)(idx & 63);
+    const int64_t kq = (idx >> 6) % npad32, rt = rt_lo + (idx >> 6) / npad32;
+    const int64_t row = rt * 16 + (lane & 15);
+    float v[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int64_t col = kq * 32 + (j >> 2) * 16 + 4 * (lane >> 4) + (j & 3);
-    // (a double L^-1 is rounded to float first: the two fp16 pieces hold 22 bits, float's 24 are enough)
-    v[j] = (row < n && col <= row) ? (float)linv[row * npad + col] * up : 0.0f;
-  }
+    for (int j = 0; j < 8; ++j) {
+      const int64_t col = kq * 32 + (j >> 2) * 16 + 4 * (lane >> 4) + (j & 3);
+      // (a double L^-1 is rounded to float first: the two fp16 pieces hold 22 bits, float's 24 are enough)
+      v[j] = (row < n && col <= row) ? (float)linv[row * npad + col] * up : 0.0f;
+    }
 #pragma unroll
-  for (int s_ = 0; s_ < 2; ++s_) {
-    u32x4 f;
+    for (int s_ = 0; s_ < 2; ++s_) {
+      u32x4 f;
 #pragma unroll
-    for (int h = 0; h < 4; ++h) f[h] = f16_split_pair(v[2 * h], v[2 * h + 1]);
-    out[((int64_t)s_ * npad16 + rt) * npad32 * 64 + kq * 64 + lane] = f;
+      for (int h = 0; h < 4; ++h) f[h] = f16_split_pair(v[2 * h], v[2 * h + 1]);
+      out[((int64_t)s_ * npad16 + rt) * npad32 * 64 + kq * 64 + lane] = f;
+    }
   }
 }
 
@@ -851,9 +853,13 @@ void launch_pack_linv_f16(hipStream_t st, const TF* linv, int64_t n, int64_t npa
     hipLaunchKernelGGL((absmax_kernel<TF>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, linv, n, npad,
                        reinterpret_cast<unsigned*>(scal));
   }
-  const int64_t total = (npad / 16) * (npad / 32) * 64;
-  hipLaunchKernelGGL((pack_linv_f16_kernel<TF>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, linv, n, npad,
-                     scal, static_cast<u32x4*>(linv_b), rt0);
+  const int64_t npad16 = npad / 16, per_rt = (npad / 32) * 64;
+  if (rt0 > 0)  // (the tile rows above the appended ones: only when the scale changed -- decided on the device)
+    hipLaunchKernelGGL((pack_linv_f16_kernel<TF>), dim3((unsigned)std::min<int64_t>((rt0 * per_rt + 255) / 256, 4096)), dim3(256), 0, st,
+                       linv, n, npad, scal, static_cast<u32x4*>(linv_b), (int64_t)0, rt0, 1);
+  if (npad16 > rt0)
+    hipLaunchKernelGGL((pack_linv_f16_kernel<TF>), dim3((unsigned)(((npad16 - rt0) * per_rt + 255) / 256)), dim3(256), 0, st, linv, n, npad,
+                       scal, static_cast<u32x4*>(linv_b), rt0, npad16, 0);
 }
 template void launch_pack_linv_f16<float>(hipStream_t, const float*, int64_t, int64_t, float*, void*, bool, int64_t);
 template void launch_pack_linv_f16<double>(hipStream_t, const double*, int64_t, int64_t, float*, void*, bool, int64_t);

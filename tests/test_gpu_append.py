@@ -39,7 +39,7 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("k", [1, 7, 64])
-@pytest.mark.parametrize("n,d,ard", [(130, 2, False), (300, 5, True), (2048 - 64, 12, False)])
+@pytest.mark.parametrize("n,d,ard", [(130, 2, False), (300, 5, True), (2048 - 64, 12, False), (4096 - 64, 6, False)])
 def test_append_fp64_matches_the_oracles_from_scratch_posterior(n, d, ard, k):
     from pygpso_amd import _lib as L
 
@@ -50,7 +50,8 @@ def test_append_fp64_matches_the_oracles_from_scratch_posterior(n, d, ard, k):
     eng = _engine()
     _fit(eng, X[:n], y[:n], th, grad=(k == 7))  # (an evaluation with gradient leaves the same factor)
     f, in_place = eng.append(X[n:], y[n:])
-    assert in_place, eng.last_message()
+    # (more than 32 points beside a factor below 4096 rows: the library refits instead -- the k x k corner is one workgroup's)
+    assert in_place == (not (k > 32 and eng.padded_n < 4096)), eng.last_message()
     assert eng.n == n + k
     assert abs(f - f_ref) <= 1e-9 * abs(f_ref)
     Linv_ref = np.linalg.inv(post.L)
