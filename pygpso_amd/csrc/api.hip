@@ -797,6 +797,10 @@ struct EngineT : Engine {
                                         grad ? as<TF>(kinvb) : nullptr, n, npad, as<double>(logdet), info_dev,
                                         single_level_max, pl);
       bool inv_done = (done & 1) != 0, xt_ready = false;
+      // (the single-level path leaves the padding blocks of L^-1 unwritten; the K^-1 = L^-T L^-1 GEMM of launch_gradient
+      // would read them -- that path always builds K^-1 beside the factorisation: hold it to that)
+      if (grad && potrf_is_single_level<TF>(npad, single_level_max) && (done & 2) == 0)
+        return ctx->fail(GPSO_E_STATE, "internal: the single-level factorisation did not leave K^-1 for the gradient");
       if constexpr (sizeof(TF) == 4) {
         if (!inv_done && pl != nullptr && trtri_bf16_applies(npad, fit_outer_panel(npad))) {
           launch_trtri_bf16(s, as<float>(linv), planes, npad, fit_outer_panel(npad), grad);
@@ -1396,7 +1400,7 @@ struct EngineT : Engine {
     return launch_status();
   }
   int try_one_launch(OneLaunch& one, int64_t total, int nseg, double varsigma) {
-    if (!small_calls || !one_launch || total <= 0 || total > kSmallBestMaxRows || nseg > 16) return 2;
+    if (!small_calls || !one_launch || one_refused || total <= 0 || total > kSmallBestMaxRows || nseg > 16) return 2;
     if (npad != 128 && npad != 256) return 2;
     // measured (tools/micro/one_dbg.py, float64, same box; wall us per best_ucb_grow call, one | three launches):
     // N = 52 / 162 rows 56.3 | 54.1, N = 100 / 1458 rows 61.0 | 59.8, N = 128 / 13122 rows 91.5 | 88.6, N = 256 / 4374 rows
@@ -1421,6 +1425,8 @@ struct EngineT : Engine {
   int enqueue_best_leaves(const void* dev, int xs_dtype, int64_t m, const int64_t* seg_off, int nseg,
                           double varsigma) {
     int rc;
+    one_pending = false;  // (a call whose result was never read -- gpso_shard_winners -- leaves nothing behind)
+    host_direct = nullptr;
     hipStream_t s = st();
     if ((rc = ensure(omean, (size_t)m * 8))) return rc;
     if ((rc = ensure(ovar, (size_t)m * 8))) return rc;
@@ -1487,6 +1493,8 @@ struct EngineT : Engine {
     if (nseg < 1) return ctx->fail(GPSO_E_ARG, "nseg must be >= 1");
     if (depth < 0 || depth > 16) return ctx->fail(GPSO_E_ARG, "depth %d outside [0, 16]", depth);
     int rc;
+    one_pending = false;
+    host_direct = nullptr;
     hipStream_t s = st();
     const int64_t rows = gpso_grow_rows(depth);
     const int64_t uniq = grow_unique_before(row_hi) - grow_unique_before(row_lo);
@@ -1644,7 +1652,10 @@ struct EngineT : Engine {
     for (int i = 0; i <= nseg; ++i) sl[i] = std::min(std::max(so[i], lo), hi) - lo;
     const void* dev = nullptr;
     if (m_local > 0 && (rc = stage_leaves(xs, xs_dtype, xs_mem, m_local, &dev))) return rc;
-    return enqueue_best_leaves(dev, xs_dtype, m_local, sl.data(), nseg, varsigma);
+    one_refused = true;  // (the status slot of a group payload belongs to the group's verdict: the general sequences)
+    rc = enqueue_best_leaves(dev, xs_dtype, m_local, sl.data(), nseg, varsigma);
+    one_refused = false;
+    return rc;
   }
   int sharded_local_grow(int rank, int world, const double* bounds, int nseg, int depth, double varsigma) {
     if (!have_post) return ctx->fail(GPSO_E_STATE, "no posterior resident: call gpso_broadcast_posterior first");
@@ -1711,7 +1722,9 @@ struct EngineT : Engine {
     collect_tile_ms();
     float ms = 0;
     if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ms[1] = ms;
-    if (one && vals[4 * nseg + 1] != 0.0) return 1;  // (a centre child does not repeat its parent: the caller re-runs)
+    // (a centre child does not repeat its parent: the caller re-runs.  Only where a re-run exists -- a folded group
+    // payload keeps the GROUP's verdict in this slot, and its half was enqueued with the one-launch kernel refused)
+    if (one && mode != 2 && vals[4 * nseg + 1] != 0.0) return 1;
     if (mode == 2) {
       const int verdict = (int)vals[4 * nseg + 1];
       if (verdict_out) *verdict_out = verdict;
@@ -1894,6 +1907,8 @@ struct EngineT : Engine {
     return payload_out(nseg, local, payload);
   }
   int payload_out(int nseg, int local, double* payload) {
+    one_pending = false;
+    host_direct = nullptr;
     const std::string local_msg = ctx->err;
     int rc = publish_local(nseg, local);
     if (rc) return rc;

@@ -618,7 +618,10 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int k = 32 * cc + 8 * (lane >> 4) + j;
-          v[j] = k < dp ? fminf(fmaxf((float)src[k] * up, -60000.0f), 60000.0f) : (k == dp ? 128.0f : 0.0f);
+          // (clamped into fp16's range; a NaN coordinate stays NaN -- fminf / fmaxf would turn it into -60000 and the
+          // leaf into a far-away point with the prior's mean and variance, unlike every other predict path)
+          const float xv = (float)src[k < dp ? k : 0] * up;
+          v[j] = k < dp ? (xv != xv ? xv : fminf(fmaxf(xv, -60000.0f), 60000.0f)) : (k == dp ? 128.0f : 0.0f);
         }
         // (the norm from scalar conversions of the values, ahead of the split: summed from bit casts of the packed pieces
         // hipcc 7.2 added element (0, e) of the first pair for every pair -- disassembly; wrong norms, caught by the tests)

@@ -361,10 +361,10 @@ __device__ __forceinline__ void one_launch_epilogue(const OneLaunch& o, int tid,
     __threadfence();
     const unsigned t = atomicAdd(o.ticket, 1u);
     last_flag = (t == gridDim.x - 1) ? 1u : 0u;
-    if (last_flag) __threadfence();
   }
   __syncthreads();
   if (!last_flag) return;
+  __threadfence();  // EVERY thread of the folding workgroup acquires before it reads the other workgroups' partials and leaves
   const int nwg = (int)gridDim.x;
   for (int seg = 0; seg < o.nseg; ++seg) {
     Best mine{0.0, -1};

@@ -103,15 +103,20 @@ def exchange_unique_id(rank, world, addr=None, port=None, timeout=120.0, make_id
                         continue
             # every rank has been answered once; an answer may still have been lost on the way, so the port stays
             # open for a short grace period and a rank that asks again is answered again
-            srv.settimeout(grace)
+            # (ONE deadline for the whole grace period: a client that keeps reconnecting cannot hold rank 0 back)
+            grace_deadline = time.monotonic() + grace
             while True:
+                left = grace_deadline - time.monotonic()
+                if left <= 0:
+                    break
+                srv.settimeout(left)
                 try:
                     conn, _peer = srv.accept()
                 except (socket.timeout, OSError):
                     break
                 with conn:
                     try:
-                        conn.settimeout(2.0)
+                        conn.settimeout(max(0.05, min(2.0, grace_deadline - time.monotonic())))
                         r, n = struct.unpack("<II", _recv_exact(conn, 8))
                         if n <= 64 and _recv_exact(conn, n) == token and 1 <= r < world:
                             conn.sendall(struct.pack("<I", len(uid)) + uid)

@@ -390,13 +390,17 @@ def test_fold_kernel_against_the_host_rule(world):
     assert int(idx[0]) == 1000 - (world - 1) and mean[0] == 0.1 * (world - 1)
 
 
-def test_a_failed_half_reaches_every_rank():
+@pytest.mark.parametrize("n", [300, 200])
+def test_a_failed_half_reaches_every_rank(n):
     """Collective safety: a rank whose half fails still produces a payload (no winners, its status in the last
-    slot) and the fold hands that status to every rank -- here a shard of the wrong size on one rank."""
+    slot) and the fold hands that status to every rank -- here a shard of the wrong size on one rank.  N = 200 pads to
+    256: the shape at which plain best-UCB calls take the ONE-launch kernel, whose fallback flag shares the payload's
+    status slot -- a group half must never be enqueued with it, and nothing of it may outlive a call whose result was
+    only copied out (round-4 advice: finish_best read the group's verdict as that flag)."""
     from pygpso_amd import _lib as L
     from pygpso_amd.distributed import shard_range
 
-    eng = _fitted("float64")
+    eng = _fitted("float64", n=n)
     Xs = synthetic_leaves(1000, 5)
     good = eng.shard_winners(0, 2, Xs[slice(*shard_range(1000, 0, 2))], 1000, VS)
     n_pay = good.shape[0]
@@ -409,6 +413,12 @@ def test_a_failed_half_reaches_every_rank():
     # and the healthy group still folds afterwards
     ok = eng.shard_winners(1, 2, Xs[slice(*shard_range(1000, 1, 2))], 1000, VS)
     assert all(np.array_equal(a, b) for a, b in zip(eng.fold_winners([good, ok], 1, 1000), eng.best_ucb(Xs, VS)))
+    # a growth call right behind payload-only calls is the plain call's (no stale one-launch state)
+    box = np.array([[[0.1, 0.4]] * 5])
+    eng.shard_winners(0, 2, Xs[slice(*shard_range(1000, 0, 2))], 1000, VS)
+    got = eng.best_ucb_grow(box, 5, VS)
+    ref = _fitted("float64", n=n).best_ucb_grow(box, 5, VS)
+    assert all(np.array_equal(a, b) for a, b in zip(got, ref))
 
 
 def test_precision_failure_is_a_group_verdict():

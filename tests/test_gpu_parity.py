@@ -83,6 +83,57 @@ def test_fit_stages_fp64(kernel, n, d, ard):
     assert np.max(np.abs(g - g_ref) / np.maximum(1.0, np.abs(g_ref))) < tol * 10
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_a_smaller_fit_after_a_larger_one_at_the_same_padded_size(dtype):
+    """The single-level fit writes only the 64-row blocks that hold training rows: after a fit at N = 1000 a fit at
+    N = 900 on the same context (both pad to 1024; its 64-row blocks end at 960) finds the old factor's rows in the padding
+    block of L^-1.  Nothing
+    may read them: NLML, gradient, L, L^-1 and K^-1 are the oracle's (round-4 advice)."""
+    from pygpso_amd import _lib as L
+
+    d = 4
+    X, y, th = _problem(1000, d, variance=1.0)
+    eng = _engine(dtype)
+    _fit(eng, X, y, th)
+    n = 900
+    Xs_, ys_ = X[:n], y[:n]
+    f, g = _fit(eng, Xs_, ys_, th)
+    assert eng.padded_n == 1024
+    post = gpr.posterior(th, Xs_, ys_)
+    f_ref, g_ref = gpr.nlml_and_grad(th, Xs_, ys_)
+    tol = 1e-9 if dtype == "float64" else 2e-5
+    assert abs(f - f_ref) <= tol * abs(f_ref)
+    assert np.max(np.abs(g - g_ref) / np.maximum(1.0, np.abs(g_ref))) < (1e-8 if dtype == "float64" else 5e-3)
+    if dtype == "float64":
+        Linv_ref = np.linalg.inv(post.L)
+        assert _rel(eng.get_matrix(L.MAT_CHOL), post.L) < 1e-9
+        assert _rel(eng.get_matrix(L.MAT_LINV), Linv_ref) < 1e-8
+        assert _rel(eng.get_matrix(L.MAT_KINV), Linv_ref.T @ Linv_ref) < 1e-8
+    fresh = _engine(dtype)
+    f2, g2 = _fit(fresh, Xs_, ys_, th)
+    assert f == f2 and np.array_equal(g, g2)  # the bits of a context that never held the larger problem
+    Xl = synthetic_leaves(700, d)
+    assert all(np.array_equal(a, b) for a, b in zip(eng.predict(Xl), fresh.predict(Xl)))
+
+
+def test_a_nan_leaf_stays_nan_in_every_predict_math():
+    """A NaN coordinate propagates to the leaf's mean and variance whatever runs the prediction (the fp16 contraction's
+    clamp used to turn it into a far-away point with the prior's mean and variance: round-4 advice)."""
+    n, d = 600, 5
+    X, y, th = _problem(n, d, variance=1.0)
+    Xl = synthetic_leaves(512, d)
+    Xl[17, 2] = np.nan
+    for dtype, math, contraction in [("float64", None, None), ("mixed", "native", None), ("mixed", "bf16x6", None),
+                                     ("mixed", "f16x3", "f16"), ("mixed", "f16x3", "f32")]:
+        eng = _engine(dtype) if math is None else __import__("pygpso_amd").HipGPEngine(dtype, predict_math=math)
+        if contraction:
+            eng.set_contraction(contraction)
+        _fit(eng, X, y, th, grad=False)
+        mean, var = eng.predict(Xl)
+        assert np.isnan(mean[17]) and np.isnan(var[17]), (dtype, math, contraction, mean[17], var[17])
+        assert np.all(np.isfinite(np.delete(mean, 17))) and np.all(np.isfinite(np.delete(var, 17)))
+
+
 @pytest.mark.parametrize("n,d,m", [(1, 2, 7), (5, 2, 121), (64, 1, 1), (128, 4, 256), (129, 3, 257),
                                    (256, 6, 4096), (300, 12, 1000), (200, 40, 300), (77, 48, 33)])
 def test_predict_fp64(n, d, m):
