@@ -85,10 +85,13 @@ typedef struct gpso_ctx gpso_ctx;
 #define GPSO_OPT_FIT_FUSED_SMALL 5 /* 1 (default): N <= 128 is fitted by the single-launch, single-workgroup     */
                                    /* kernel; 0: the general multi-launch path (test hook: results agree to     */
                                    /* rounding)                                                                 */
-#define GPSO_OPT_FIT_BF16_SYRK 6   /* GPSO_F32 contexts, N above the single-level limit: 1 (default) the large products */
-                                   /* of the fit (rank-W trailing updates, level-doubling inverse) run on the bf16    */
-                                   /* matrix cores as 3-way split products (6 bf16 MFMAs per product, f32             */
-                                   /* accumulation: f32-class accuracy; 4 x 6 N^2 bytes of bf16 planes); 0: f32 MFMA   */
+#define GPSO_OPT_FIT_BF16_SYRK 6   /* GPSO_F32 contexts, N above the single-level limit: the large products of the fit     */
+                                   /* (rank-W trailing updates, level-doubling inverse, K^-1) run on the 16-bit matrix     */
+                                   /* cores as split products with f32 accumulation.  2 (default): TWO fp16 pieces of the  */
+                                   /* power-of-two scaled operands, three MFMAs per product (the dropped low x low term is */
+                                   /* 2^-22 relative) -- where the hyper-parameters keep every operand in fp16's range      */
+                                   /* (noise / variance above ~1e-9), else as 1; 1: THREE bf16 pieces, six MFMAs per       */
+                                   /* product (round 3-4; f32-class entry by entry); 0: f32 MFMA                            */
 #define GPSO_OPT_TIMING 7          /* 1 (default): every fit / predict-type entry point records the event pairs           */
                                    /* gpso_last_ms reads (two to four HIP calls + an elapsed-time query: 10-25 us of a     */
                                    /* call); 0: none, gpso_last_ms returns 0 -- for callers in a loop of small evaluations */

@@ -273,7 +273,7 @@ struct EngineT : Engine {
   DevBuf pl_L, pl_X, pl_XT, pl_WT;  // bf16 plane sets of the two-level float fit (kernels.hpp: FitPlanes)
   DevBuf app;                       // scratch of gpso_append (kernels.hpp: append_scratch_doubles)
   std::vector<double> x_host, y_host;  // host mirror of the training data (gpso_append's refit path needs all of it)
-  bool bf16_fit = true;             // GPSO_OPT_FIT_BF16_SYRK
+  int fit_planes_mode = 2;          // GPSO_OPT_FIT_BF16_SYRK: 0 f32 MFMA | 1 bf16 pieces (6 MFMAs per product) | 2 fp16 pieces (3) where representable
   // predict math: the OPTION (math_auto: GPSO_MATH_AUTO) and what the resident posterior uses (math, and
   // math_native_fallback when the self-test preferred the f32 MFMA kernel for it)
   // GPSO_MATH_AUTO walks the ladder fp16 split (3 MFMAs per product) -> bf16x6 -> f32 MFMA kernel, one rung down each
@@ -404,8 +404,8 @@ struct EngineT : Engine {
         single_level_max = value;
         return GPSO_OK;
       case GPSO_OPT_FIT_BF16_SYRK:
-        if (value != 0 && value != 1) return ctx->fail(GPSO_E_ARG, "bf16 SYRK must be 0 or 1");
-        bf16_fit = value != 0;
+        if (value < 0 || value > 2) return ctx->fail(GPSO_E_ARG, "fit plane mode must be 0 (f32 MFMA), 1 (bf16 pieces) or 2 (fp16 pieces)");
+        fit_planes_mode = value;
         return GPSO_OK;
       case GPSO_OPT_TIMING:
         if (value < 0 || value > 1000000) return ctx->fail(GPSO_E_ARG, "timing must be 0 (off), 1 (every call) or k (every k-th call)");
@@ -776,7 +776,7 @@ struct EngineT : Engine {
       FitPlanes planes{};
       const FitPlanes* pl = nullptr;
       if constexpr (sizeof(TF) == 4) {
-        if (bf16_fit && npad > (single_level_max >= 0 ? single_level_max : 3584)) {
+        if (fit_planes_mode != 0 && npad > (single_level_max >= 0 ? single_level_max : 3584)) {
           for (DevBuf* b : {&pl_L, &pl_X, &pl_XT, &pl_WT})
             if ((rc = ensure(*b, fit_plane_set_bytes(npad)))) return rc;
           planes = FitPlanes{static_cast<unsigned short*>(pl_L.p), static_cast<unsigned short*>(pl_X.p),
@@ -790,6 +790,9 @@ struct EngineT : Engine {
           planes.side = ctx->side_stream;
           planes.ev_col = ctx->ev_col;
           planes.ev_chain = ctx->ev_chain;
+          // fp16 pieces (three MFMAs per product) when the hyper-parameters leave every plane set inside fp16's range
+          // after its power-of-two scaling; bf16 pieces (six) otherwise -- the fallback rung
+          if (fit_planes_mode == 2) (void)fit_plane_scales(variance, noise, planes);
           pl = &planes;
         }
       }
@@ -1078,11 +1081,11 @@ struct EngineT : Engine {
       ++ctx->tile_pairs;
       if (defer != nullptr && nchunk == 1 && want_ucb) {
         *defer = LeafFinalize{as<double>(pvar), as<double>(pmean), nbi, mp, kp.variance, kp.noise, kp.mean_c, varsigma,
-                              mean_dev, var_dev, ucb_dev};
+                              mean_dev, var_dev, ucb_dev, lnorm.p, sizeof(TG) == 8};
         continue;
       }
       launch_leaf_finalize(s, as<double>(pvar), as<double>(pmean), nbi, mp, mc, kp, varsigma, mean_dev + off,
-                           var_dev + off, want_ucb ? ucb_dev + off : nullptr);
+                           var_dev + off, want_ucb ? ucb_dev + off : nullptr, lnorm.p, sizeof(TG) == 8);
     }
     return launch_status();  // (no host wait here: the kernel time is read after the call's final sync)
   }
@@ -1364,7 +1367,7 @@ struct EngineT : Engine {
     one.lnorm = lnorm.p;
     one.key = as<int64_t>(grow_key);
     one.fin = LeafFinalize{as<double>(pvar), as<double>(pmean), 1, cpad, kp.variance, kp.noise, kp.mean_c, varsigma,
-                           as<double>(omean), as<double>(ovar), as<double>(oucb)};
+                           as<double>(omean), as<double>(ovar), as<double>(oucb), lnorm.p, sizeof(TG) == 8};
     one.partial = one_partial.p;
     one.ppos = as<int64_t>(one_ppos);
     one.ticket = static_cast<unsigned*>(one_ctl.p);

@@ -305,6 +305,17 @@ __device__ __forceinline__ unsigned bf16_split_pair(float& a, float& b) {
   return u;
 }
 
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// (a, b) -> packed fp16 pair (round to nearest even); a, b are replaced by the remainders
+__device__ __forceinline__ unsigned f16_split_pair(float& a, float& b) {
+  const f32x2 v = {a, b};
+  const f16x2 h = __builtin_convertvector(v, f16x2);
+  a -= (float)h[0];
+  b -= (float)h[1];
+  return __builtin_bit_cast(unsigned, h);
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

@@ -674,6 +674,8 @@ struct GemmDesc {
   int64_t split_stride;  // bf16 elements between planes
   int split_nkb;         // 32-column blocks per row of the plane layout
   int64_t split_row0, split_col0;  // position of C's (0, 0) in the planes
+  int split_np;          // 3: bf16 pieces | 2: fp16 pieces of value * split_scale (a power of two)
+  float split_scale;
 };
 
 // =============================================================================================
@@ -939,8 +941,15 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmDesc g) {
           for (int b = 0; b < WT; b += 2) {
             float x0 = v[b], x1 = v[b + 1];
             unsigned short* dst = g.split + syrk_plane_offset(g.split_row0 + row, (int)g.split_col0 + col + b, g.split_nkb);
+            if (g.split_np == 2) {
+              x0 *= g.split_scale;
+              x1 *= g.split_scale;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(dst + p * g.split_stride) = bf16_split_pair(x0, x1);
+              for (int p = 0; p < 2; ++p) *reinterpret_cast<unsigned*>(dst + p * g.split_stride) = f16_split_pair(x0, x1);
+            } else {
+#pragma unroll
+              for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(dst + p * g.split_stride) = bf16_split_pair(x0, x1);
+            }
           }
         }
       }
@@ -1015,6 +1024,7 @@ struct Bf16Planes {
   unsigned short* p;  // plane 0 (nullptr: absent)
   int64_t stride;     // bf16 elements between planes
   int nkb;
+  float scale = 1.0f;  // fp16 pieces (GemmBf16Desc::np == 2): the planes hold value * scale, a power of two
 };
 // super-tile: tile rows x tile columns that one XCD works on at a time (square for the triangular enumeration);
 // filled by launch_gemm_bf16.  mg_*: q = n / d as __umulhi(n, mg) (exact for n < 2^20, 1 < d <= 4096).
@@ -1043,11 +1053,15 @@ struct GemmBf16Desc {
   Bf16Planes out, out_t;
   int64_t o_row0, o_col0, ot_row0, ot_col0;
   BfTiling tl;
+  // pieces per value: 3 = bf16 (six MFMAs per product, h0h0 + h0h1 + h1h0 + h1h1 + h0h2 + h2h0), 2 = fp16 pieces of the
+  // scaled values (THREE MFMAs per product, h1h0 + h0h1 + h0h0; the dropped h1h1 is 2^-22 relative): round 5.  alpha
+  // is the caller's; the kernel divides the scales of A and B out (exact: powers of two)
+  int np;
 };
 constexpr int kSyrkBf16MinRows = 3072;  // below: too few 128-tiles for one workgroup per CU to pay (measured)
 constexpr int kSyrkNbuf = 3;
-constexpr int kSyrkStepBytes = 2 * 3 * 8 * 1024;  // [operand][piece][row tile] x 1 KB
-constexpr int kSyrkLdsBytes = kSyrkNbuf * kSyrkStepBytes + 4 * 1024;  // + a spare KB per wave (C prefetch target)
+constexpr int syrk_step_bytes(int np) { return 2 * np * 8 * 1024; }  // [operand][piece][row tile] x 1 KB
+constexpr int syrk_lds_bytes(int np) { return kSyrkNbuf * syrk_step_bytes(np) + 4 * 1024; }  // + a spare KB per wave (C prefetch target)
 
 #ifndef GPSO_GSTAMP
 #define GPSO_GSTAMP(tile, i)  // tools/micro/syrk_bench.hip defines this to record s_memtime stamps per tile
@@ -1095,8 +1109,12 @@ __device__ __forceinline__ void bf16_wait() {
 //    12 DMA instructions of a step occupy the CU's address path for ~770 clocks, and issued in one burst they
 //    stalled the wave for ~600 of the ~1540 clocks of its MFMAs).  Items e + 1 .. e + 3 may belong to the NEXT
 //    tile: its first three steps are in flight while this tile's accumulators are stored.
+template <int NP>
 __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel(GemmBf16Desc g) {
   typedef float vecW __attribute__((ext_vector_type(4)));
+  constexpr int kSyrkStepBytes = syrk_step_bytes(NP);
+  constexpr int ND = 4 * NP;  // DMA instructions per wave and step (12 | 8)
+  constexpr int NR = 8 * NP;  // fragment reads per wave and step (24 | 16)
   extern __shared__ __align__(16) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1143,11 +1161,11 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel(GemmBf16Desc g) {
   // tile = 4 (64-row strip of the 128 rows) + x: 1 KB of contiguous memory each.  Source of piece s = the
   // cursor's per-operand base (a scalar register pair that advances 1 KB per step) + voff[s], a per-lane
   // 32-bit offset that never changes (plane, tile and lane; three planes of a 16384^2 matrix span 1.5 GB).
-  unsigned voff[12];
-  int dst[12];
+  unsigned voff[ND];
+  int dst[ND];
 #pragma unroll
-  for (int s = 0; s < 12; ++s) {
-    const int q = wave + 4 * s, op = q / 24, p = (q % 24) / 8, tile = q % 8;
+  for (int s = 0; s < ND; ++s) {
+    const int q = wave + 4 * s, op = q / (8 * NP), p = (q % (8 * NP)) / 8, tile = q % 8;
     const Bf16Planes& P = (op == 0) ? g.A : g.B;
     voff[s] = (unsigned)(((int64_t)p * P.stride + (int64_t)tile * P.nkb * 512) * 2) + (unsigned)lane * 16u;
     dst[s] = q * 1024;
@@ -1173,17 +1191,17 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel(GemmBf16Desc g) {
     asm volatile("s_mov_b32 m0, %0" ::"s"(a) : "memory");
   };
   auto dma_go = [&](int s) {
-    asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(voff[s]), "s"(src[s / 6]) : "memory");
+    asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(voff[s]), "s"(src[s / (2 * NP)]) : "memory");
   };
 
-  u32x4 F[2][2][4][3];  // fragments: [set][operand][tile][piece]
-  auto frag_ptr = [&](int buf, int r) {  // read r of a step: operand r / 12, tile (r % 12) / 3, piece r % 3
-    const int op = r / 12, x = (r % 12) / 3, p = r % 3;
-    return reinterpret_cast<const u32x4*>(lds + buf * kSyrkStepBytes + ((op * 3 + p) * 8 + (op == 0 ? wr : wc) * 4 + x) * 1024 + lane * 16);
+  u32x4 F[2][2][4][NP];  // fragments: [set][operand][tile][piece]
+  auto frag_ptr = [&](int buf, int r) {  // read r of a step: operand r / (4 NP), tile (r % (4 NP)) / NP, piece r % NP
+    const int op = r / (4 * NP), x = (r % (4 * NP)) / NP, p = r % NP;
+    return reinterpret_cast<const u32x4*>(lds + buf * kSyrkStepBytes + ((op * NP + p) * 8 + (op == 0 ? wr : wc) * 4 + x) * 1024 + lane * 16);
   };
   auto wait_groups = [&](int newer) {  // every DMA group of this wave but the newest `newer`, and every LDS read
-    if (newer >= 2) bf16_wait<24>();
-    else if (newer == 1) bf16_wait<12>();
+    if (newer >= 2) bf16_wait<2 * ND>();
+    else if (newer == 1) bf16_wait<ND>();
     else bf16_wait<0>();
   };
 
@@ -1198,17 +1216,18 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel(GemmBf16Desc g) {
 #pragma unroll
   for (int d = 0; d < kSyrkNbuf; ++d)
 #pragma unroll
-    for (int s = 0; s < 12; ++s) {
+    for (int s = 0; s < ND; ++s) {
       dma_m0(s, d);
       asm volatile("s_nop 0");
       dma_go(s);
-      if (s == 11) src[0] += 1024, src[1] += 1024;
+      if (s == ND - 1) src[0] += 1024, src[1] += 1024;
     }
   wait_groups(2);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 #pragma unroll
-  for (int r = 0; r < 24; ++r) F[0][r / 12][(r % 12) / 3][r % 3] = *frag_ptr(0, r);
+  for (int r = 0; r < NR; ++r) F[0][r / (4 * NP)][(r % (4 * NP)) / NP][r % NP] = *frag_ptr(0, r);
+  const float alpha_eff = g.alpha / (g.A.scale * g.B.scale);  // (scales are powers of two: exact)
 
   f32x4 acc[4][4];
   float* c_base = nullptr;
@@ -1230,7 +1249,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel(GemmBf16Desc g) {
     // item e + 1 has landed (the reads below need it); the fragments of this item, read during the last one, are
     // in registers on every wave once all have passed the barrier, so its buffer may be overwritten.  (Step 0 of
     // a later tile: that wait was made before the stores of the previous tile's epilogue, see below.)
-    if (kSteady) bf16_wait<12>();
+    if (kSteady) bf16_wait<ND>();
     else if (st == 0 && !first_tile) bf16_wait<63>();
     else wait_groups(ahead - 1);
     __builtin_amdgcn_s_barrier();
@@ -1246,35 +1265,51 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel(GemmBf16Desc g) {
     }
     const int buf_rd = (buf + 1 == kSyrkNbuf) ? 0 : buf + 1;
     auto read_frag = [&](int r) {
-      if (do_rd) F[1 - S][r / 12][(r % 12) / 3][r % 3] = *frag_ptr(buf_rd, r);
+      if (do_rd) F[1 - S][r / (4 * NP)][(r % (4 * NP)) / NP][r % NP] = *frag_ptr(buf_rd, r);
     };
-#define GPSO_SY(PA, PB) \
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, F[S][0][a][PA]), __builtin_bit_cast(bf16x8, F[S][1][b][PB]), c, 0, 0, 0)
+#define GPSO_SY(PA, PB)                                                                                                                \
+  c = NP == 2 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, F[S][0][a][PA]), __builtin_bit_cast(f16x8, F[S][1][b][PB]), c, 0, 0, 0) \
+              : __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, F[S][0][a][PA]), __builtin_bit_cast(bf16x8, F[S][1][b][PB]), c, 0, 0, 0)
 #define GPSO_SLOT __builtin_amdgcn_sched_barrier(0)
 #pragma unroll
     for (int ch = 0; ch < 16; ++ch) {  // one MFMA, then at most one other instruction: nothing else ever queues up
       const int a = ch / 4, b = ch % 4;
       f32x4 c = acc[a][b];
-      GPSO_SY(2, 0);
-      GPSO_SLOT;
-      if (ch < 12 && do_dma) dma_m0(ch, buf);
-      GPSO_SLOT;
-      GPSO_SY(0, 2);
-      GPSO_SLOT;
-      if (ch < 12 && do_dma) dma_go(ch);
-      GPSO_SLOT;
-      GPSO_SY(1, 1);
-      GPSO_SLOT;
-      read_frag(ch);  // reads 0..15, one per group
-      GPSO_SLOT;
-      GPSO_SY(1, 0);
-      GPSO_SLOT;
-      if (ch < 8) read_frag(16 + ch);  // reads 16..23
-      GPSO_SLOT;
-      GPSO_SY(0, 1);
-      GPSO_SLOT;
-      GPSO_SY(0, 0);
-      GPSO_SLOT;
+      if constexpr (NP == 3) {
+        GPSO_SY(NP - 1, 0);
+        GPSO_SLOT;
+        if (ch < 12 && do_dma) dma_m0(ch, buf);
+        GPSO_SLOT;
+        GPSO_SY(0, NP - 1);
+        GPSO_SLOT;
+        if (ch < 12 && do_dma) dma_go(ch);
+        GPSO_SLOT;
+        GPSO_SY(1, 1);
+        GPSO_SLOT;
+        read_frag(ch);  // reads 0..15, one per group
+        GPSO_SLOT;
+        GPSO_SY(1, 0);
+        GPSO_SLOT;
+        if (ch < 8) read_frag(16 + ch);  // reads 16..23
+        GPSO_SLOT;
+        GPSO_SY(0, 1);
+        GPSO_SLOT;
+        GPSO_SY(0, 0);
+        GPSO_SLOT;
+      } else {  // fp16 pieces: three products, small terms first; 8 DMAs and 16 reads per step in the 48 gaps
+        GPSO_SY(1, 0);
+        GPSO_SLOT;
+        if (ch < ND && do_dma) dma_m0(ch, buf);
+        GPSO_SLOT;
+        GPSO_SY(0, 1);
+        GPSO_SLOT;
+        if (ch < ND && do_dma) dma_go(ch);
+        GPSO_SLOT;
+        GPSO_SY(0, 0);
+        GPSO_SLOT;
+        read_frag(ch);  // reads 0..15
+        GPSO_SLOT;
+      }
       acc[a][b] = c;
     }
 #undef GPSO_SLOT
@@ -1330,27 +1365,28 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_kernel(GemmBf16Desc g) {
       for (int r = 0; r < 4; ++r) {
         vecW v;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) v[b] = g.alpha * acc[a][b][r] + (with_c ? cin[a][r][b] : 0.0f);
+        for (int b = 0; b < 4; ++b) v[b] = alpha_eff * acc[a][b][r] + (with_c ? cin[a][r][b] : 0.0f);
         if (c_base != nullptr) *reinterpret_cast<vecW*>(c_ptr(a, r)) = v;
         const int64_t row = row_w + 4 * (4 * (lane >> 4) + r) + a;  // (row, col_w .. col_w + 3) of the result
         if (g.out.p != nullptr) {
 #pragma unroll
           for (int b = 0; b < 4; b += 2) {
-            float x0 = v[b], x1 = v[b + 1];
+            float x0 = v[b] * g.out.scale, x1 = v[b + 1] * g.out.scale;
             unsigned short* d = g.out.p + syrk_plane_offset(g.o_row0 + zs + row, (int)(g.o_col0 + zs) + col_w + b, g.out.nkb);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(d + p * g.out.stride) = bf16_split_pair(x0, x1);
+            for (int p = 0; p < NP; ++p)
+              *reinterpret_cast<unsigned*>(d + p * g.out.stride) = NP == 2 ? f16_split_pair(x0, x1) : bf16_split_pair(x0, x1);
           }
         }
         if (g.out_t.p != nullptr) {  // element (row, col) of the result is element (col, row) of the transpose
 #pragma unroll
           for (int b = 0; b < 4; b += 2) {
-            float x0 = v[b], x1 = v[b + 1];
+            float x0 = v[b] * g.out_t.scale, x1 = v[b + 1] * g.out_t.scale;
             unsigned short* d0 = g.out_t.p + syrk_plane_offset(g.ot_row0 + zs + col_w + b, (int)(g.ot_col0 + zs + row), g.out_t.nkb);
             unsigned short* d1 = g.out_t.p + syrk_plane_offset(g.ot_row0 + zs + col_w + b + 1, (int)(g.ot_col0 + zs + row), g.out_t.nkb);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-              const unsigned u = bf16_split_pair(x0, x1);
+            for (int p = 0; p < NP; ++p) {
+              const unsigned u = NP == 2 ? f16_split_pair(x0, x1) : bf16_split_pair(x0, x1);
               d0[p * g.out_t.stride] = (unsigned short)(u & 0xffffu);
               d1[p * g.out_t.stride] = (unsigned short)(u >> 16);
             }
@@ -1379,11 +1415,30 @@ static int bf16_gemm_grid(int total_slots) {
 // reserve_cus: compute units left to another stream (a workgroup of this kernel fills a CU's LDS, so that many
 // CUs stay free for whatever else is in flight)
 static void launch_gemm_bf16(hipStream_t st, GemmBf16Desc g, int reserve_cus = 0) {
-  if (ensure_dyn_lds(reinterpret_cast<const void*>(&gemm_bf16_kernel), kSyrkLdsBytes)) return;
+  if (g.np != 2) g.np = 3;
+  const int lds = syrk_lds_bytes(g.np);
+  const void* fn = g.np == 2 ? reinterpret_cast<const void*>(&gemm_bf16_kernel<2>) : reinterpret_cast<const void*>(&gemm_bf16_kernel<3>);
+  if (ensure_dyn_lds(fn, lds)) return;
   g.tl = bf16_tiling(g);
   int grid = bf16_gemm_grid(g.tl.total_slots);
   if (reserve_cus > 0) grid = std::max(8, std::min(grid, (bf16_gemm_grid(INT_MAX) - reserve_cus) / 8 * 8));
-  hipLaunchKernelGGL(gemm_bf16_kernel, dim3((unsigned)grid), dim3(256), kSyrkLdsBytes, st, g);
+  if (g.np == 2) hipLaunchKernelGGL(gemm_bf16_kernel<2>, dim3((unsigned)grid), dim3(256), lds, st, g);
+  else hipLaunchKernelGGL(gemm_bf16_kernel<3>, dim3((unsigned)grid), dim3(256), lds, st, g);
+}
+bool fit_plane_scales(double variance, double noise, FitPlanes& pl) {
+  // scaled bound 2^13; the scale itself must leave a typical entry's SECOND piece (2^-11 of it) a normal fp16 number
+  auto scale_for = [](double bound) { return std::ldexp(1.0, 13 - (int)std::ceil(std::log2(std::max(bound, 1e-300)))); };
+  if (!(variance > 0.0) || !(noise > 0.0)) return false;
+  const double sl = scale_for(std::sqrt(variance + noise)), sx = scale_for(1.0 / std::sqrt(noise)),
+               sw = scale_for(std::sqrt((variance + noise) / noise));
+  // typical entries: |L| ~ sqrt(variance), |L^-1| and the W blocks ~ 1 / sqrt(variance) and up
+  const double lo = std::ldexp(1.0, -2), hi = std::ldexp(1.0, 40);
+  if (sl * std::sqrt(variance) < lo || sx / std::sqrt(variance) < lo || sw < lo * 0.25 || sl > hi || sx > hi || sw > hi) return false;
+  pl.sL = (float)sl;
+  pl.sX = (float)sx;
+  pl.sW = (float)sw;
+  pl.np = 2;
+  return true;
 }
 
 // a float block (rows x cols at src, leading dimension ld) -> planes at (row0, col0) and / or its transpose at
@@ -1391,7 +1446,7 @@ static void launch_gemm_bf16(hipStream_t st, GemmBf16Desc g, int reserve_cus = 0
 __global__ __launch_bounds__(256) void block_to_planes_kernel(const float* __restrict__ src, int64_t ld, int rows,
                                                               int cols, int64_t batch_src, int64_t batch_shift,
                                                               Bf16Planes out, int64_t row0, int64_t col0,
-                                                              Bf16Planes out_t, int64_t trow0, int64_t tcol0) {
+                                                              Bf16Planes out_t, int64_t trow0, int64_t tcol0, int np) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // pair index inside a block
   const int per_row = cols / 2;
   if (idx >= (int64_t)rows * per_row) return;
@@ -1400,9 +1455,15 @@ __global__ __launch_bounds__(256) void block_to_planes_kernel(const float* __res
   const int c = 2 * (int)(idx % per_row);
   const float* s = src + (int64_t)blockIdx.y * batch_src + r * ld + c;
   float a = s[0], b = s[1];
+  if (np == 2) {  // (both plane sets of a call share their scale)
+    const float sc = out.p != nullptr ? out.scale : out_t.scale;
+    a *= sc;
+    b *= sc;
+  }
 #pragma unroll
   for (int p = 0; p < 3; ++p) {
-    const unsigned u = bf16_split_pair(a, b);
+    if (p >= np) break;
+    const unsigned u = np == 2 ? f16_split_pair(a, b) : bf16_split_pair(a, b);
     if (out.p != nullptr)
       *reinterpret_cast<unsigned*>(out.p + p * out.stride + syrk_plane_offset(row0 + zs + r, (int)(col0 + zs) + c, out.nkb)) = u;
     if (out_t.p != nullptr) {
@@ -2005,12 +2066,15 @@ int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t
       t.split_nkb = planes->nkb;
       t.split_row0 = r1;
       t.split_col0 = c0;
+      t.split_np = planes->np;
+      t.split_scale = planes->sL;
     }
     launch_gemm<T>(st, t);
     if (have_planes && m2 >= kSyrkBf16MinRows) {
       if constexpr (sizeof(T) == 4) {
         GemmBf16Desc sy{};
-        sy.A = sy.B = Bf16Planes{planes->L, planes->stride, planes->nkb};
+        sy.A = sy.B = Bf16Planes{planes->L, planes->stride, planes->nkb, planes->sL};
+        sy.np = planes->np;
         sy.a_row0 = sy.b_row0 = r1;
         sy.a_col0 = sy.b_col0 = c0;
         sy.C = reinterpret_cast<float*>(K + r1 * npad + r1);
@@ -2105,18 +2169,19 @@ void launch_trtri(hipStream_t st, const T* L, T* linv, T* work, int64_t npad, in
 // is what the next level reads.  The diagonal blocks of L^-1 (float, from the step kernels) enter X / XT first.
 void launch_trtri_bf16(hipStream_t st, float* linv, const FitPlanes& pl, int64_t npad, int64_t first_level,
                        bool keep_xt) {
-  const Bf16Planes L{pl.L, pl.stride, pl.nkb}, X{pl.X, pl.stride, pl.nkb}, XT{pl.XT, pl.stride, pl.nkb},
-      WT{pl.WT, pl.stride, pl.nkb}, none{nullptr, 0, 0};
+  const Bf16Planes L{pl.L, pl.stride, pl.nkb, pl.sL}, X{pl.X, pl.stride, pl.nkb, pl.sX}, XT{pl.XT, pl.stride, pl.nkb, pl.sX},
+      WT{pl.WT, pl.stride, pl.nkb, pl.sW}, none{nullptr, 0, 0, 1.0f};
   {
     const int fl = (int)first_level, nb = (int)(npad / first_level);
     const int64_t pairs = (int64_t)fl * fl / 2;
     hipLaunchKernelGGL(block_to_planes_kernel, dim3((unsigned)((pairs + 255) / 256), (unsigned)nb), dim3(256), 0, st, linv,
                        npad, fl, fl, (int64_t)fl * npad + fl, (int64_t)fl, X, (int64_t)0, (int64_t)0, XT, (int64_t)0,
-                       (int64_t)0);
+                       (int64_t)0, pl.np);
   }
   for (int64_t s = first_level; s < npad; s *= 2) {
     const int nb = (int)(npad / (2 * s));
     GemmBf16Desc a{};  // WT[A,B]
+    a.np = pl.np;
     a.A = XT; a.a_row0 = 0; a.a_col0 = 0;
     a.B = L; a.b_row0 = s; a.b_col0 = 0;
     a.C = nullptr; a.ldc = npad;
@@ -2127,6 +2192,7 @@ void launch_trtri_bf16(hipStream_t st, float* linv, const FitPlanes& pl, int64_t
     a.out_t = none;
     launch_gemm_bf16(st, a);
     GemmBf16Desc b{};  // Linv[B,A]
+    b.np = pl.np;
     b.A = X; b.a_row0 = s; b.a_col0 = s;
     b.B = WT; b.b_row0 = 0; b.b_col0 = s;
     b.C = linv + s * npad; b.ldc = npad;
@@ -2521,7 +2587,8 @@ void launch_gradient(hipStream_t st, const T* linv, const T* alpha, const double
     // Kinv = L^-T (L^-T)^T is a product of k-contiguous rows of them (lower tiles, k >= 128 ti)
     if constexpr (sizeof(T) == 4) {
       GemmBf16Desc g{};
-      g.A = g.B = Bf16Planes{xt_planes->XT, xt_planes->stride, xt_planes->nkb};
+      g.A = g.B = Bf16Planes{xt_planes->XT, xt_planes->stride, xt_planes->nkb, xt_planes->sX};
+      g.np = xt_planes->np;
       g.C = reinterpret_cast<float*>(kinv);
       g.ldc = npad;
       g.m = g.n = g.k = (int)npad;

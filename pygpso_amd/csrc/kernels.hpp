@@ -100,10 +100,15 @@ struct LeafFinalize {
   double* mean = nullptr;
   double* var = nullptr;
   double* ucb = nullptr;
+  // nullable: the leaves' squared norms (generation type: float | double).  A leaf with a NaN coordinate has a NaN norm
+  // and gets NaN mean / var / ucb -- what GPflow returns for it (and np.argmax then picks it); the kernel map's clamp
+  // max(r^2, 1e-36) would otherwise turn its r^2 into 0 against every training point (finite garbage, negative variance)
+  const void* lnorm = nullptr;
+  int lnorm_f64 = 0;
 };
 void launch_leaf_finalize(hipStream_t st, const double* part_var, const double* part_mean, int nbi,
                           int64_t mpad, int64_t m, const KernParams& kp, double varsigma,
-                          double* mean, double* var, double* ucb);
+                          double* mean, double* var, double* ucb, const void* lnorm = nullptr, int lnorm_f64 = 0);
 void launch_seg_argmax(hipStream_t st, const double* mean, const double* var, const double* ucb,
                        const int64_t* seg_off_dev, int nseg, int nblk, void* partial_dev,
                        double* out_vals_dev /* [nseg*4 + 2]: per segment mean, var, ucb, bit-cast int64 index; spare; 0.0 (status slot) */,
@@ -151,14 +156,24 @@ void launch_gram(hipStream_t st, const double* xs, const double* xnorm, int64_t 
 // matrices (fit_plane_set_bytes(npad) each): L, X = L^-1, XT = X^T, WT = scratch (fit.hip: gemm_bf16_kernel).
 struct FitPlanes {
   unsigned short *L, *X, *XT, *WT;
-  int64_t stride;  // bf16 elements between the three planes of a set
+  int64_t stride;  // 16-bit elements between the planes of a set
   int nkb;         // npad / 32
+  // Round 5: the planes hold either three bf16 pieces per value (np = 3: six MFMAs per product) or TWO fp16 pieces of the
+  // value times a power of two (np = 2: three MFMAs per product -- the split that carries the predict path): fp16 has 5
+  // exponent bits, so every plane set is scaled into its range by a bound known on the host -- |L| <= sqrt(s2 + noise),
+  // |L^-1| <= 1 / sqrt(noise), |L[B,A] L^-1[A,A]| <= sqrt((s2 + noise) / noise) -- with 2^13 as the scaled bound (a factor
+  // of 8 below fp16's largest number); fit_plane_scales() fills them
+  int np = 3;
+  float sL = 1.0f, sX = 1.0f, sW = 1.0f;
   // look-ahead (all three set, or none): the next diagonal block is factored on `side` while the rest of the
   // current rank-W update runs on the caller's stream; ev_col / ev_chain order the two streams
   hipStream_t side = nullptr;
   hipEvent_t ev_col = nullptr, ev_chain = nullptr;
 };
 inline size_t fit_plane_set_bytes(int64_t npad) { return (size_t)3 * (size_t)npad * (size_t)npad * 2; }
+// power-of-two scales of the fp16 planes for hyper-parameters (variance, noise); false: a scale leaves the range in which
+// the second piece of a typical entry is still a normal fp16 number (noise / variance below ~1e-9): keep bf16 pieces
+bool fit_plane_scales(double variance, double noise, FitPlanes& pl);
 // planes (float fits, nullable): with them the TRSM GEMMs also emit L into planes->L and the rank-W trailing
 // updates run on the bf16 matrix cores
 // does launch_potrf take the single-level path at this size?  (It then writes every entry of L^-1 that anything reads --

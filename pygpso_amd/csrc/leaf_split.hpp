@@ -62,16 +62,7 @@ __device__ __forceinline__ void glds4(const void* gsrc_lane, void* lds_wave_base
 // An entry 2^-28 below its operand's maximum is still a normal fp16 number; below that the ABSOLUTE error per entry
 // stays under 2^-25 of the scaled maximum -- far inside the 2^-22 the dropped product costs.  Accumulation is f32 as
 // everywhere; the epilogue undoes the scales (sum of squares x 2^-2(sa+sb), mean x 2^-sb).
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-// (a, b) -> packed fp16 pair (round to nearest even); a, b are replaced by the remainders
-__device__ __forceinline__ unsigned f16_split_pair(float& a, float& b) {
-  const f32x2 v = {a, b};
-  const f16x2 h = __builtin_convertvector(v, f16x2);
-  a -= (float)h[0];
-  b -= (float)h[1];
-  return __builtin_bit_cast(unsigned, h);
-}
+// (f16x2 / f16x8 and f16_split_pair: common.hpp -- the fit's fp16 planes use them too)
 
 #ifndef GPSO_BSTAMP
 #define GPSO_BSTAMP(q, i)  // tools/micro/leaf_bf16_phases.hip defines this to record s_memtime stamps

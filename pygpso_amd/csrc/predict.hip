@@ -39,6 +39,15 @@ __device__ __forceinline__ bool better(const Best& a, const Best& b) {
   return a.i < b.i;
 }
 
+__device__ __forceinline__ bool leaf_norm_is_nan(const void* lnorm, int f64, int64_t j) {
+  if (lnorm == nullptr) return false;
+  if (f64) {
+    const double q = static_cast<const double*>(lnorm)[j];
+    return q != q;
+  }
+  const float q = static_cast<const float*>(lnorm)[j];
+  return q != q;
+}
 // one leaf: sum the row blocks' partials, form mean / var (+ noise) / ucb, store them; returns ucb
 __device__ __forceinline__ double finalize_leaf(const LeafFinalize& f, int64_t j) {
   double v = 0, mu = 0;
@@ -46,6 +55,7 @@ __device__ __forceinline__ double finalize_leaf(const LeafFinalize& f, int64_t j
     v += f.part_var[(int64_t)b * f.mpad + j];
     mu += f.part_mean[(int64_t)b * f.mpad + j];
   }
+  if (leaf_norm_is_nan(f.lnorm, f.lnorm_f64, j)) v = mu = __builtin_nan("");  // (a NaN coordinate: NaN out, as the reference)
   // [gpflow base_conditional] fvar = k** - sum A^2 ; predict_y adds the noise variance
   const double vy = __dadd_rn(__dsub_rn(f.variance, v), f.noise);
   const double my = __dadd_rn(mu, f.mean_c);
@@ -873,7 +883,8 @@ __global__ __launch_bounds__(256) void leaf_finalize_kernel(const double* __rest
                                                             KernParams kp, double varsigma,
                                                             double* __restrict__ mean,
                                                             double* __restrict__ var,
-                                                            double* __restrict__ ucb) {
+                                                            double* __restrict__ ucb, const void* __restrict__ lnorm,
+                                                            int lnorm_f64) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= m) return;
   double v = 0, mu = 0;
@@ -881,6 +892,7 @@ __global__ __launch_bounds__(256) void leaf_finalize_kernel(const double* __rest
     v += part_var[(int64_t)b * mpad + j];
     mu += part_mean[(int64_t)b * mpad + j];
   }
+  if (leaf_norm_is_nan(lnorm, lnorm_f64, j)) v = mu = __builtin_nan("");
   // [gpflow base_conditional] fvar = k** - sum A^2 ; predict_y adds the noise variance
   const double vy = __dadd_rn(__dsub_rn(kp.variance, v), kp.noise);
   const double my = __dadd_rn(mu, kp.mean_c);
@@ -1359,11 +1371,11 @@ template int launch_leaf_tiles<double, double>(hipStream_t, const double*, const
 
 void launch_leaf_finalize(hipStream_t st, const double* part_var, const double* part_mean, int nbi,
                           int64_t mpad, int64_t m, const KernParams& kp, double varsigma,
-                          double* mean, double* var, double* ucb) {
+                          double* mean, double* var, double* ucb, const void* lnorm, int lnorm_f64) {
   const int64_t blocks = (m + 255) / 256;
   if (blocks == 0) return;
   hipLaunchKernelGGL(leaf_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part_var,
-                     part_mean, nbi, mpad, m, kp, varsigma, mean, var, ucb);
+                     part_mean, nbi, mpad, m, kp, varsigma, mean, var, ucb, lnorm, lnorm_f64);
 }
 
 void launch_seg_argmax(hipStream_t st, const double* mean, const double* var, const double* ucb,
