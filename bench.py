@@ -437,6 +437,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     eng.set_timing(1)
+    # the same K steps through the non-blocking pair, two deep (gpso_best_ucb_begin / _end): the device work of step i + 1
+    # is queued before the host reads the result of step i, so the GPU does not idle over the host's round trip.  Reported
+    # BESIDE the headline (which keeps the synchronous protocol above); single-GPU runs only (the sharded call is a
+    # collective and stays blocking).
+    pipelined_ms = None
+    if not use_dist:
+        for _ in range(3):
+            eng.best_ucb_end(eng.best_ucb_begin(leaves_dev, varsigma))
+        torch.cuda.synchronize()
+        t0p = time.perf_counter()
+        tk = eng.best_ucb_begin(leaves_dev, varsigma)
+        for _ in range(args.steps - 1):
+            tk2 = eng.best_ucb_begin(leaves_dev, varsigma)
+            pw = eng.best_ucb_end(tk)
+            tk = tk2
+        pw = eng.best_ucb_end(tk)
+        torch.cuda.synchronize()
+        pipelined_ms = (time.perf_counter() - t0p) / args.steps * 1e3
+        assert int(pw[0][0]) == winner[0], (pw, winner)
 
     if rank == 0:
         kern_ms = float(np.mean(tile_ms))
@@ -452,6 +471,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_pipelined": pipelined_ms,  # two calls in flight (gpso_best_ucb_begin / _end); the headline is synchronous
+            "value_pipelined": (m_total / (pipelined_ms * 1e-3)) if pipelined_ms else None,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -219,6 +219,20 @@ int gpso_best_ucb(gpso_ctx* ctx, const void* xs, int xs_dtype, int xs_mem, int64
                   const int64_t* seg_off, int nseg, double varsigma, int64_t* idx, double* mean,
                   double* var, double* ucb);
 
+/* The same calls as a non-blocking pair (round 5).  _begin checks and enqueues the call on the context's stream and
+ * returns a ticket (0 or 1) without waiting, or a negative status; gpso_best_ucb_end(ticket) waits for THAT call and fills
+ * the outputs (nseg each, nullable).  Two calls may be in flight on a context: the device work of the second queues up
+ * behind the first while the host still reads the first's result, so the GPU does not idle over the host's round trip.
+ * The reference's loop (gpso/optimisation.py:366-382) is synchronous -- the blocking calls above are _begin + _end --;
+ * callers with several independent batches (conditional grids, one batch per tree level of several trees) overlap them.
+ * Between a _begin and its _end the leaves buffer (GPSO_MEM_DEVICE) must stay untouched; host leaves are copied before
+ * _begin returns.  nseg <= 1024.  Any call that changes the posterior while a ticket is open leaves that ticket's
+ * result undefined.  gpso_last_ms is not updated by asynchronous calls. */
+int gpso_best_ucb_begin(gpso_ctx* ctx, const void* xs, int xs_dtype, int xs_mem, int64_t m, const int64_t* seg_off,
+                        int nseg, double varsigma);
+int gpso_best_ucb_grow_begin(gpso_ctx* ctx, const double* bounds, int nseg, int depth, double varsigma);
+int gpso_best_ucb_end(gpso_ctx* ctx, int ticket, int64_t* idx, double* mean, double* var, double* ucb);
+
 /* ---- ternary geometry on device (LeafNode.grow, gpso/param_space.py:175-200,257-307) -------- */
 
 /* Centres of levels 0..depth-1 of the ternary subtree under each of nseg boxes, generated on the

@@ -81,6 +81,9 @@ SIGNATURES = {
     "gpso_best_ucb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, _c_int64_p,
                                 C.c_int, C.c_double, _c_int64_p, _c_double_p, _c_double_p,
                                 _c_double_p]),
+    "gpso_best_ucb_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, _c_int64_p, C.c_int, C.c_double]),
+    "gpso_best_ucb_grow_begin": (C.c_int, [C.c_void_p, _c_double_p, C.c_int, C.c_int, C.c_double]),
+    "gpso_best_ucb_end": (C.c_int, [C.c_void_p, C.c_int, _c_int64_p, _c_double_p, _c_double_p, _c_double_p]),
     "gpso_grow_rows": (C.c_int64, [C.c_int]),
     "gpso_grow": (C.c_int, [C.c_void_p, _c_double_p, C.c_int, C.c_int, C.c_int, _c_double_p]),
     "gpso_best_ucb_grow": (C.c_int, [C.c_void_p, _c_double_p, C.c_int, C.c_int, C.c_double,

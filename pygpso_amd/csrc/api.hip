@@ -83,6 +83,9 @@ struct Engine {
   virtual int best_ucb(const void* xs, int xs_dtype, int xs_mem, int64_t m, const int64_t* seg_off,
                        int nseg, double varsigma, int64_t* idx, double* mean, double* var,
                        double* ucb) = 0;
+  virtual int best_ucb_begin(const void* xs, int xs_dtype, int xs_mem, int64_t m, const int64_t* seg_off, int nseg,
+                             double varsigma, const double* bounds, int depth) = 0;
+  virtual int best_ucb_end(int ticket, int64_t* idx, double* mean, double* var, double* ucb) = 0;
   virtual int grow(const double* bounds, int nseg, int d, int depth, double* out) = 0;
   virtual int best_ucb_grow(const double* bounds, int nseg, int depth, double varsigma,
                             int64_t* idx, double* mean, double* var, double* ucb) = 0;
@@ -166,6 +169,15 @@ struct gpso_ctx {
   size_t pinned_doubles = 0;
   double* stage = nullptr;       // pinned staging of small host inputs (training data, bounds)
   size_t stage_doubles = 0;
+  // gpso_best_ucb_begin / _end: two calls may be in flight; each has a pinned result slot of its own and a completion event
+  static constexpr int kSlots = 2;
+  static constexpr size_t kSlotDoubles = 4 * 1024 + 2;  // nseg <= 1024 per asynchronous call
+  double* slot_host = nullptr;   // [kSlots][kSlotDoubles], pinned
+  hipEvent_t slot_ev[kSlots] = {};
+  int slot_nseg[kSlots] = {0, 0};  // > 0: the slot holds a call that has not been ended
+  int slot_mode[kSlots] = {0, 0};
+  int slot_next = 0;
+  int slots_busy() const { return (slot_nseg[0] > 0) + (slot_nseg[1] > 0); }
 
   // Wait for everything queued on s.  hipStreamSynchronize parks the thread on an interrupt and costs
   // tens of microseconds to wake up -- as much as the device work of a small fit.  The calling thread
@@ -308,6 +320,8 @@ struct EngineT : Engine {
   bool linv_b_pending = false;  // the split pieces of the resident L^-1 are still to be packed (a fit that returned a gradient)
   std::vector<int64_t> segoff_cache;  // what the device copy of seg_off currently holds
   double* host_direct = nullptr;      // pinned host memory the arg-max of the call in flight writes its records to
+  double* result_slot = nullptr;      // asynchronous call being enqueued: its own pinned slot instead of the shared scratch
+  double* result_host(size_t doubles) { return result_slot != nullptr ? result_slot : ctx->pinned_scratch(doubles); }
   DevBuf extra_cnt;                   // small growth calls: rows appended behind the analytic slots (zero between calls)
   // predict workspace
   DevBuf leaves_raw, leaves_s, lnorm, pvar, pmean, omean, ovar, oucb, segoff, best, oidx, ovals, grow_key,
@@ -1373,7 +1387,7 @@ struct EngineT : Engine {
     one.ticket = static_cast<unsigned*>(one_ctl.p);
     one.fallback = static_cast<unsigned*>(one_ctl.p) + 1;
     one.out_vals = as<double>(ovals);
-    one.host_vals = host_direct = ctx->pinned_scratch((size_t)nseg * 4 + 2);
+    one.host_vals = host_direct = result_host((size_t)nseg * 4 + 2);
     const TG* xsp;
     const TG* xnr;
     if constexpr (sizeof(TG) == 8) {
@@ -1469,7 +1483,7 @@ struct EngineT : Engine {
       if ((rc = score_device_leaves(dev, xs_dtype, m, varsigma, true, as<double>(omean), as<double>(ovar), as<double>(oucb), nullptr, &fin))) return rc;
     // (round 4: the leaves of a one-chunk batch are finalised by the arg-max's first stage, and its second stage writes
     // the winners' records straight into the pinned host memory finish_best reads: two launches and a copy less per call)
-    host_direct = ctx->pinned_scratch((size_t)nseg * 4 + 2);
+    host_direct = result_host((size_t)nseg * 4 + 2);
     if (small_calls && fin.part_var != nullptr && m <= kSmallBestMaxRows && nseg <= 64) {
       // small batch: finalize and both arg-max stages in one launch of one workgroup
       SmallBest sb{};
@@ -1552,7 +1566,7 @@ struct EngineT : Engine {
       if ((rc = score_device_leaves(nullptr, GPSO_F64, cap, varsigma, true, as<double>(omean), as<double>(ovar), as<double>(oucb), nullptr, &fin, true)))
         return rc;
       if (fin.part_var == nullptr) return ctx->fail(GPSO_E_STATE, "internal: small growth call was not deferred");
-      host_direct = ctx->pinned_scratch((size_t)nseg * 4 + 2);
+      host_direct = result_host((size_t)nseg * 4 + 2);
       SmallBest sb{};
       sb.fin = fin;
       sb.key = as<int64_t>(grow_key);
@@ -1582,7 +1596,7 @@ struct EngineT : Engine {
       if ((rc = score_device_leaves(leaves_raw.p, GPSO_F64, cap, varsigma, true, as<double>(omean), as<double>(ovar),
                                     as<double>(oucb), as<int64_t>(live_cnt), &fin)))
         return rc;
-    host_direct = ctx->pinned_scratch((size_t)nseg * 4 + 2);
+    host_direct = result_host((size_t)nseg * 4 + 2);
     launch_keyed_argmax(s, as<double>(omean), as<double>(ovar), as<double>(oucb), as<int64_t>(grow_key), rows, uniq,
                         nseg, as<int64_t>(live_cnt), argmax_blocks(cap, nseg), best.p, as<int64_t>(best_pos), as<double>(ovals),
                         fin.part_var ? &fin : nullptr, host_direct);
@@ -1765,6 +1779,79 @@ struct EngineT : Engine {
     if (m > 0 && (rc = stage_leaves(xs, xs_dtype, xs_mem, m, &dev))) return rc;
     if ((rc = enqueue_best_leaves(dev, xs_dtype, m, seg_off, nseg, varsigma))) return rc;
     return finish_best(ovals, nseg, 0, idx, mean, var, ucb);
+  }
+
+  // ---- the non-blocking pair (round 5): gpso_best_ucb_begin / gpso_best_ucb_grow_begin enqueue a call and return a
+  // ticket; gpso_best_ucb_end waits for THAT call and reads its records.  Two calls may be in flight: the device work of
+  // the second is queued while the first still runs, so the GPU never idles over the host's round trip (pinned-memory
+  // read, ctypes, Python: 42 us of a 0.77 ms step at C3, profiles/r04_step_timeline.txt).  Every call has its own pinned
+  // result slot -- the arg-max kernels write their records there -- and a completion event; the device-side scratch is
+  // shared and ordered by the stream.  No timing events, no one-launch kernel (it may ask for a re-run).
+  int best_ucb_begin(const void* xs, int xs_dtype, int xs_mem, int64_t m, const int64_t* seg_off, int nseg, double varsigma,
+                     const double* bounds, int depth) override {
+    const bool grown = bounds != nullptr;
+    if (!have_post) return ctx->fail(GPSO_E_STATE, "no posterior resident: call gpso_fit_eval / gpso_set_posterior first");
+    if (nseg < 1 || (size_t)nseg * 4 + 2 > gpso_ctx::kSlotDoubles) return ctx->fail(GPSO_E_ARG, "nseg must be in [1, 1024] for an asynchronous call");
+    int rc = grown ? precision_gate() : check_predict_args(xs, xs_dtype, xs_mem, m);
+    if (rc) return rc;
+    const int k = ctx->slot_next;
+    if (ctx->slot_nseg[k] > 0)
+      return ctx->fail(GPSO_E_STATE, "two asynchronous best-UCB calls are already in flight: end one (gpso_best_ucb_end) first");
+    if (ctx->slot_host == nullptr) {
+      if (hipHostMalloc(reinterpret_cast<void**>(&ctx->slot_host), gpso_ctx::kSlots * gpso_ctx::kSlotDoubles * 8, hipHostMallocDefault) != hipSuccess)
+        return ctx->fail(GPSO_E_OOM, "pinned result slots");
+      for (auto& ev : ctx->slot_ev) HIPCHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    const bool timing_was = ctx->timing;
+    ctx->timing = false;
+    result_slot = ctx->slot_host + (size_t)k * gpso_ctx::kSlotDoubles;
+    one_refused = true;
+    if (grown) {
+      rc = enqueue_best_grow(bounds, nseg, depth, 0, gpso_grow_rows(depth), varsigma);
+    } else {
+      const void* dev = nullptr;
+      if (m > 0) rc = stage_leaves(xs, xs_dtype, xs_mem, m, &dev);
+      if (rc == GPSO_OK) rc = enqueue_best_leaves(dev, xs_dtype, m, seg_off, nseg, varsigma);
+    }
+    one_refused = false;
+    result_slot = nullptr;
+    host_direct = nullptr;
+    ctx->timing = timing_was;
+    if (rc) return rc;
+    if (xs_mem == GPSO_MEM_HOST && !grown && m > 0) HIPCHECK(hipStreamSynchronize(st()));  // (the caller's host leaves are free again on return)
+    HIPCHECK(hipEventRecord(ctx->slot_ev[k], st()));
+    ctx->slot_nseg[k] = nseg;
+    ctx->slot_mode[k] = grown ? 1 : 0;
+    ctx->slot_next = (k + 1) % gpso_ctx::kSlots;
+    return k;
+  }
+  int best_ucb_end(int ticket, int64_t* idx, double* mean, double* var, double* ucb) override {
+    if (ticket < 0 || ticket >= gpso_ctx::kSlots || ctx->slot_nseg[ticket] <= 0)
+      return ctx->fail(GPSO_E_ARG, "ticket %d names no asynchronous call in flight", ticket);
+    const int nseg = ctx->slot_nseg[ticket];
+    ctx->slot_nseg[ticket] = 0;
+    // spin on the call's own event (the thread is blocked here anyway), then block
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int it = 0;; ++it) {
+      const hipError_t e = hipEventQuery(ctx->slot_ev[ticket]);
+      if (e == hipSuccess) break;
+      if (e != hipErrorNotReady) return ctx->fail(GPSO_E_HIP, "hipEventQuery failed: %s", hipGetErrorString(e));
+      if ((it & 63) == 63 && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 20.0) {
+        HIPCHECK(hipEventSynchronize(ctx->slot_ev[ticket]));
+        break;
+      }
+    }
+    int rc;
+    if ((rc = launch_status())) return rc;
+    const double* vals = ctx->slot_host + (size_t)ticket * gpso_ctx::kSlotDoubles;
+    for (int i = 0; i < nseg; ++i) {
+      if (idx) std::memcpy(&idx[i], &vals[4 * i + 3], 8);
+      if (mean) mean[i] = vals[4 * i];
+      if (var) var[i] = vals[4 * i + 1];
+      if (ucb) ucb[i] = vals[4 * i + 2];
+    }
+    if (ctx->slot_mode[ticket] == 1) std::memcpy(&ctx->last_count[0], &vals[4 * nseg], 8);
+    return GPSO_OK;
   }
 
   int need_comm() {
@@ -2326,6 +2413,9 @@ void gpso_destroy(gpso_ctx* ctx) {
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->stage) (void)hipHostFree(ctx->stage);
+  if (ctx->slot_host) (void)hipHostFree(ctx->slot_host);
+  for (auto& ev : ctx->slot_ev)
+    if (ev) (void)hipEventDestroy(ev);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -2450,6 +2540,23 @@ int gpso_best_ucb(gpso_ctx* ctx, const void* xs, int xs_dtype, int xs_mem, int64
                   double* var, double* ucb) {
   ENTER();
   return ctx->eng->best_ucb(xs, xs_dtype, xs_mem, m, seg_off, nseg, varsigma, idx, mean, var, ucb);
+}
+
+int gpso_best_ucb_begin(gpso_ctx* ctx, const void* xs, int xs_dtype, int xs_mem, int64_t m, const int64_t* seg_off, int nseg,
+                        double varsigma) {
+  ENTER();
+  return ctx->eng->best_ucb_begin(xs, xs_dtype, xs_mem, m, seg_off, nseg, varsigma, nullptr, 0);
+}
+
+int gpso_best_ucb_grow_begin(gpso_ctx* ctx, const double* bounds, int nseg, int depth, double varsigma) {
+  ENTER();
+  if (!bounds) return ctx->fail(GPSO_E_ARG, "bounds must not be NULL");
+  return ctx->eng->best_ucb_begin(nullptr, GPSO_F64, GPSO_MEM_DEVICE, 0, nullptr, nseg, varsigma, bounds, depth);
+}
+
+int gpso_best_ucb_end(gpso_ctx* ctx, int ticket, int64_t* idx, double* mean, double* var, double* ucb) {
+  ENTER();
+  return ctx->eng->best_ucb_end(ticket, idx, mean, var, ucb);
 }
 
 int64_t gpso_grow_rows(int depth) {

@@ -317,6 +317,42 @@ class HipGPEngine:
                                             L.i64ptr(idx), L.dptr(mean), L.dptr(var), L.dptr(ucb)))
         return idx, mean, var, ucb
 
+    def best_ucb_begin(self, xs, varsigma, seg_off=None):
+        """Non-blocking ``best_ucb``: enqueues the call and returns a ticket for ``best_ucb_end``; two calls may be in
+        flight (``gpso_best_ucb_begin``).  The leaves must stay untouched until the call is ended."""
+        ptr, dt, mem, m, keep = self._leaf_args(xs)
+        if seg_off is None:
+            nseg, so_ptr = 1, None
+        else:
+            so = np.ascontiguousarray(seg_off, dtype=np.int64)
+            nseg, so_ptr = int(so.shape[0] - 1), L.i64ptr(so)
+        ticket = self._check(self._lib.gpso_best_ucb_begin(self._h, ptr, dt, mem, m, so_ptr, nseg, float(varsigma)))
+        self._open_tickets = getattr(self, "_open_tickets", {})
+        self._open_tickets[ticket] = (nseg, keep)
+        return ticket
+
+    def best_ucb_grow_begin(self, bounds, depth, varsigma):
+        b = L.as_f64(bounds)
+        if b.ndim == 2:
+            b = b[None]
+        nseg, d, _ = b.shape
+        if d != self.d:
+            raise ValueError(f"bounds have D={d}, model has D={self.d}")
+        ticket = self._check(self._lib.gpso_best_ucb_grow_begin(self._h, L.dptr(b), nseg, int(depth), float(varsigma)))
+        self._open_tickets = getattr(self, "_open_tickets", {})
+        self._open_tickets[ticket] = (nseg, None)
+        return ticket
+
+    def best_ucb_end(self, ticket):
+        """Wait for the call behind ``ticket`` -> (idx, mean, var, ucb) arrays of length nseg."""
+        nseg, _keep = self._open_tickets.pop(ticket)
+        idx = np.empty(nseg, dtype=np.int64)
+        mean = np.empty(nseg, dtype=np.float64)
+        var = np.empty(nseg, dtype=np.float64)
+        ucb = np.empty(nseg, dtype=np.float64)
+        self._check(self._lib.gpso_best_ucb_end(self._h, int(ticket), L.i64ptr(idx), L.dptr(mean), L.dptr(var), L.dptr(ucb)))
+        return idx, mean, var, ucb
+
     # -- ternary geometry ------------------------------------------------------------------------
     def grow_rows(self, depth):
         return int(self._lib.gpso_grow_rows(int(depth)))

@@ -1125,3 +1125,45 @@ def test_small_call_sequence_gives_the_bits_of_the_general_one(dtype, n, d, dept
         i = int(np.argmax(ucb))
         got = res[1][1]
         assert int(got[0][sgm]) == i and got[3][sgm] == ucb[i] and got[1][sgm] == mean[i] and got[2][sgm] == var[i]
+
+
+@pytest.mark.parametrize("dtype", ["float64", "mixed"])
+def test_the_non_blocking_pair_gives_the_blocking_calls_bits(dtype):
+    """gpso_best_ucb_begin / _grow_begin / _end: two calls in flight, ended in order or out of order, return what the
+    blocking calls return, bit for bit; a third begin is refused; a ticket is good for one end."""
+    from pygpso_amd import HipGPEngine, _lib as L
+
+    n, d = 700, 4
+    X, y, th = _problem(n, d, variance=1.0)
+    eng = HipGPEngine(dtype)
+    _fit(eng, X, y, th, grad=False)
+    A, B = synthetic_leaves(5000, d, seed=3), synthetic_leaves(30000, d, seed=4)
+    seg = np.array([0, 1000, 1000, 30000])
+    ref_a, ref_b = eng.best_ucb(A, VS), eng.best_ucb(B, VS, seg)
+    box = np.array([[[0.2, 0.5]] * d, [[0.0, 1.0 / 3.0]] * d])
+    ref_g = eng.best_ucb_grow(box, 6, VS)
+    for order in ("in order", "reversed"):
+        ta = eng.best_ucb_begin(A, VS)
+        tb = eng.best_ucb_begin(B, VS, seg)
+        with pytest.raises(L.GpsoHipError, match="already in flight"):
+            eng.best_ucb_begin(A, VS)
+        if order == "in order":
+            got_a, got_b = eng.best_ucb_end(ta), eng.best_ucb_end(tb)
+        else:
+            got_b, got_a = eng.best_ucb_end(tb), eng.best_ucb_end(ta)
+        assert all(np.array_equal(u, v) for u, v in zip(got_a, ref_a))
+        assert all(np.array_equal(u, v, equal_nan=True) for u, v in zip(got_b, ref_b))
+    tg = eng.best_ucb_grow_begin(box, 6, VS)
+    ta = eng.best_ucb_begin(A, VS)
+    assert all(np.array_equal(u, v) for u, v in zip(eng.best_ucb_end(tg), ref_g))
+    assert all(np.array_equal(u, v) for u, v in zip(eng.best_ucb_end(ta), ref_a))
+    rc = eng._lib.gpso_best_ucb_end(eng._h, ta, None, None, None, None)
+    assert rc == L.E_ARG  # (ended already)
+    # a long pipeline: K calls, two deep
+    t = eng.best_ucb_begin(A, VS)
+    for _ in range(20):
+        t2 = eng.best_ucb_begin(A, VS)
+        assert all(np.array_equal(u, v) for u, v in zip(eng.best_ucb_end(t), ref_a))
+        t = t2
+    assert all(np.array_equal(u, v) for u, v in zip(eng.best_ucb_end(t), ref_a))
+    assert all(np.array_equal(u, v, equal_nan=True) for u, v in zip(eng.best_ucb(B, VS, seg), ref_b))  # the blocking call behind it

@@ -7,6 +7,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 LOG=${1:-$R/profiles/r05_asan_cpu.log}
 RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
 make -C $R/pygpso_amd/csrc asan -j8 > /dev/null 2>&1 || { echo "asan build failed"; exit 1; }
+trap "rm -rf $R/pygpso_amd/libgpso_hip_asan.so $R/pygpso_amd/csrc/build_asan" EXIT  # (71 MB that would travel to the GPU box with every gpurun call)
 cd $R
 {
   echo "# host-side ASan + UBSan run of the CPU suites (tools/run_asan_cpu.sh); library: pygpso_amd/libgpso_hip_asan.so"
