@@ -370,7 +370,8 @@ int gpso_precision_info(gpso_ctx* ctx, double* out);
 
 /* last-call device timings in milliseconds measured with HIP events on the context's stream:
  * what = 0: dominant predict kernel (leaf tiles) of the last predict/best_ucb call,
- *        1: whole last predict/best_ucb call, 2: whole last gpso_fit_eval call. */
+ *        1: whole last predict/best_ucb call, 2: whole last gpso_fit_eval / gpso_append call,
+ *        3: the collective of the last gpso_best_ucb*_sharded call (ncclAllGather of the winners + the fold kernel). */
 double gpso_last_ms(gpso_ctx* ctx, int what);
 
 /* leaf counts of the last predict / best_ucb / best_ucb_grow call: what = 0: rows the predict kernels

@@ -145,10 +145,10 @@ struct gpso_ctx {
   int dtype = GPSO_F64;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[6] = {};
+  hipEvent_t ev[8] = {};  // [0..1] spare, [2..3] predict-type call, [4..5] fit, [6..7] the collective of a sharded call
   std::vector<hipEvent_t> tile_ev;  // start/stop pairs around the leaf-tile kernel, one per chunk
   int tile_pairs = 0;               // pairs recorded by the call in flight
-  double last_ms[3] = {0, 0, 0};
+  double last_ms[4] = {0, 0, 0, 0};
   bool timing = true;  // GPSO_OPT_TIMING: does the call in flight record the event pairs gpso_last_ms reads (two to four HIP calls)?
   int timing_every = 1;  // ... 0: never, 1: every fit / predict-type call, k: every k-th one (the others leave gpso_last_ms alone)
   long timed_calls = 0;
@@ -426,7 +426,7 @@ struct EngineT : Engine {
         ctx->timing_every = value;
         ctx->timed_calls = 0;  // (the next fit / predict-type call is a sampled one)
         ctx->timing = value != 0;
-        if (!ctx->timing) ctx->last_ms[0] = ctx->last_ms[1] = ctx->last_ms[2] = 0.0;
+        if (!ctx->timing) ctx->last_ms[0] = ctx->last_ms[1] = ctx->last_ms[2] = ctx->last_ms[3] = 0.0;
         return GPSO_OK;
       case GPSO_OPT_FIT_FUSED_SMALL:
         if (value != 0 && value != 1) return ctx->fail(GPSO_E_ARG, "fused small fit must be 0 or 1");
@@ -1357,6 +1357,7 @@ struct EngineT : Engine {
   // not apply -- the caller goes on with the next-best sequence --, or a negative status.
   DevBuf one_ctl, one_partial, one_ppos;
   bool one_pending = false;  // the call in flight is a one-launch call: finish_best looks at its fallback verdict
+  bool coll_timed = false;   // the call in flight recorded the event pair around its collective (all-gather + fold)
   template <typename TG>
   int try_one_launch_t(OneLaunch& one, int64_t total, int nseg, double varsigma) {
     const int64_t cpad = (total + kLeafPad - 1) / kLeafPad * kLeafPad;
@@ -1711,9 +1712,12 @@ struct EngineT : Engine {
     RcclApi& R = RcclApi::get();
     hipStream_t s = st();
     const int pd = group_payload_doubles(nseg);
+    if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[6], s));
     RCCLCHECK(R.AllGather(ovals.p, gath.p, (size_t)pd, ncclDouble, ctx->comm, s));
     launch_reduce_winners(s, as<double>(gath), with_base ? as<int64_t>(wbase) : nullptr, ctx->world, nseg, pd,
                           as<double>(ovals2));
+    if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[7], s));
+    coll_timed = ctx->timing;
     return launch_status();
   }
 
@@ -1739,6 +1743,8 @@ struct EngineT : Engine {
     collect_tile_ms();
     float ms = 0;
     if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_ms[1] = ms;
+    if (coll_timed && hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]) == hipSuccess) ctx->last_ms[3] = ms;
+    coll_timed = false;
     // (a centre child does not repeat its parent: the caller re-runs.  Only where a re-run exists -- a folded group
     // payload keeps the GROUP's verdict in this slot, and its half was enqueued with the one-launch kernel refused)
     if (one && mode != 2 && vals[4 * nseg + 1] != 0.0) return 1;
@@ -2637,7 +2643,7 @@ int gpso_adopt_posterior(gpso_ctx* ctx) {
 }
 
 double gpso_last_ms(gpso_ctx* ctx, int what) {
-  if (!ctx || what < 0 || what > 2) return -1.0;
+  if (!ctx || what < 0 || what > 3) return -1.0;
   return ctx->last_ms[what];
 }
 

@@ -29,3 +29,13 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_terminal_summary(terminalreporter):
+    from tests import helpers
+
+    c = helpers.WINNER_CENSUS
+    if c["exact"] + c["gap"]:
+        terminalreporter.write_line(
+            f"float winner rule: {c['exact']} winners were the oracle's arg-max, {c['gap']} were accepted through the gap branch "
+            f"(largest gap used: {c['largest_gap_used']:.2e} of max(1, |ucb|); allowed 2e-5)")

@@ -99,3 +99,21 @@ def g8_run_resume_save_resume(make_optimiser, optimiser_cls, tmp_folder, goldens
         assert got[1] == exp["highest_score"]
         assert abs(got[2] - exp["highest_ucb"]) < 1e-8
     return opt2
+
+
+# float32 engines: the winner is the oracle's arg-max, or a leaf whose ORACLE ucb lies within the rounding of a float
+# prediction of it (gap x max(1, |ucb_max|)).  Every application of the rule is counted: the GPU run's terminal summary
+# (tests/conftest.py) says how often the winner was the oracle's own arg-max and how often the gap branch was needed.
+WINNER_CENSUS = {"exact": 0, "gap": 0, "largest_gap_used": 0.0}
+
+
+def winner_is_the_oracles(idx, ucb_ref, gap, what=""):
+    idx = int(idx)
+    best = int(np.argmax(ucb_ref))
+    if idx == best:
+        WINNER_CENSUS["exact"] += 1
+        return
+    used = float(ucb_ref.max() - ucb_ref[idx]) / max(1.0, abs(float(ucb_ref.max())))
+    assert used <= gap, (what, idx, best, used)
+    WINNER_CENSUS["gap"] += 1
+    WINNER_CENSUS["largest_gap_used"] = max(WINNER_CENSUS["largest_gap_used"], used)

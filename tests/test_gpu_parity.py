@@ -51,10 +51,9 @@ WINNER_GAP = 2e-5
 
 
 def _winner_is_the_oracles(best, mean_ref, var_ref, gap=WINNER_GAP):
-    idx = int(best[0][0])
-    ucb_ref = mean_ref + VS * var_ref
-    assert idx == int(np.argmax(ucb_ref)) or ucb_ref.max() - ucb_ref[idx] <= gap * max(1.0, abs(ucb_ref.max())), \
-        (idx, int(np.argmax(ucb_ref)), float(ucb_ref.max() - ucb_ref[idx]))
+    from tests.helpers import winner_is_the_oracles
+
+    winner_is_the_oracles(best[0][0], mean_ref + VS * var_ref, gap, "test_gpu_parity")
 
 
 def _rel(a, b):

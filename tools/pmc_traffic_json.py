@@ -27,7 +27,7 @@ for r in rows:
     if int(r.get("Grid_Size", 0) or 0) == big:
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 rec = {"workload": workload, "kernel": desc, "grid_threads": big,
-       "source": "rocprofv3 --pmc, separate passes (tools/collect_profiles_r04.sh), mean over the full-size dispatches only",
+       "source": "rocprofv3 --pmc, separate passes (tools/collect_profiles.sh), mean over the full-size dispatches only",
        "dispatches_averaged": {k: len(v) for k, v in acc.items()}}
 for k, v in sorted(acc.items()):
     rec[k + ("_KB" if k in ("FETCH_SIZE", "WRITE_SIZE") else "")] = sum(v) / len(v)
