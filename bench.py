@@ -111,13 +111,13 @@ def cpu_baseline(X, y, theta, leaves, varsigma, budget_s=12.0):
         fits.append(time.perf_counter() - t0)
     fit_s = float(np.median(fits))
     # The oracle's predict pass is numpy elementwise work (the kernel map) around two BLAS calls: one Python thread uses ONE
-    # core for most of it.  The stated baseline runs the 16k-leaf chunks of SURVEY 8d on a thread pool (numpy and BLAS
+    # core for most of it.  The stated baseline runs leaf chunks (SURVEY 8d processes leaves in chunks) on a thread pool (numpy and BLAS
     # release the GIL) with BLAS held to one thread per worker, so that every host core works; the per-chunk winners are
     # folded with np.argmax's rule.
     from concurrent.futures import ThreadPoolExecutor
 
     workers = max(1, min(os.cpu_count() or 1, 64))
-    chunk = 16384
+    chunk = 1024  # (small chunks: 64 of them in a 65 536-leaf batch, so that every worker has one)
 
     def best_of(lo):
         i, mu, var, ucb = gpr.best_ucb(post, leaves[lo:lo + chunk], varsigma)
@@ -161,7 +161,7 @@ def cpu_baseline(X, y, theta, leaves, varsigma, budget_s=12.0):
         "fit_gflops": (X.shape[0] ** 3 / 3 + X.shape[0] ** 2 * X.shape[1] + 10 * X.shape[0] ** 2) / fit_s / 1e9,
         "predict_threads": int(min(workers, n_chunks)),
         "note": "the numpy/scipy restatement of the reference's algorithm, not a tuned CPU implementation: the predict pass "
-                "runs its 16k-leaf chunks on a thread pool (one BLAS thread per worker; numpy's elementwise kernel map is "
+                "runs 1024-leaf chunks on a thread pool (one BLAS thread per worker; numpy's elementwise kernel map is "
                 "single-threaded per chunk), the fit (LAPACK potrf / trsm) uses the BLAS's own threads; fit time is the "
                 "median of 3 warm calls",
     }, post
