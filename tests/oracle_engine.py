@@ -32,6 +32,14 @@ class OracleEngine:
         self.post = gpr.posterior(th, self.X, self.y)
         return f, g
 
+    def append(self, Xnew, ynew):
+        """What ``HipGPEngine.append`` answers: the posterior of the old + new points at the resident hyper-parameters
+        (here simply refitted by the oracle) -> (nlml, in_place)."""
+        th = self.post.theta
+        self.set_data(np.vstack([self.X, np.atleast_2d(Xnew)]), np.concatenate([self.y, np.asarray(ynew).reshape(-1)]))
+        self.post = gpr.posterior(th, self.X, self.y)
+        return self.post.nlml, True
+
     def predict(self, xs, out=None):
         return gpr.predict_y(self.post, np.asarray(xs, dtype=np.float64))
 

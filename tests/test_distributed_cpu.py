@@ -250,6 +250,15 @@ def test_engine_group_threads_with_two_fake_devices():
     grp.fit_eval("Matern52", [0.5], 1.2, 1e-3, 0.1, want_grad=False)
     ref.fit_eval("Matern52", [0.5], 1.2, 1e-3, 0.1, want_grad=False)
     assert np.array_equal(grp.best_ucb(Xs, VS)[0], ref.best_ucb(Xs, VS)[0])
+    # gpso_append through the group: the fitting rank extends its posterior at the kept hyper-parameters, the peers are
+    # stale again and get the extended posterior before the next sharded call
+    Xn, yn = synthetic_problem(5, 3, seed=9)
+    f_grp, in_place = grp.append(Xn, yn)
+    f_ref, _ = ref.append(Xn, yn)
+    assert in_place and f_grp == f_ref and grp.n == 75 and grp._stale
+    got, exp = grp.best_ucb(Xs, VS, seg), ref.best_ucb(Xs, VS, seg)
+    assert np.array_equal(got[0], exp[0])
+    np.testing.assert_allclose(np.array(got[1:]), np.array(exp[1:]), rtol=1e-12, atol=1e-13, equal_nan=True)
     grp.close()
 
 

@@ -420,3 +420,54 @@ def test_direct_lbfgsb_driver_is_scipy_minimize_bit_for_bit():
                                 method="L-BFGS-B").x))
     s2._gp_train(x=x, y=y[:, np.newaxis])
     assert np.array_equal(theta_direct, s2.gpflow_model._pack())
+
+
+def test_refit_every_appends_between_reoptimisations_on_the_host_side():
+    """``GPRSurrogate(refit_every=3)`` (opt-in, not the reference's behaviour): updates 1 and 2 after a fit keep the
+    hyper-parameters and call ``engine.append`` with exactly the new rows; update 3 re-optimises.  CPU: the engine is the
+    oracle-backed test double, so the host logic (what counts as "the same points plus new ones", the counters, the
+    model's data) is what is tested; the device arithmetic of gpso_append: tests/test_gpu_append.py."""
+    import numpy as np
+
+    from pygpso_amd import GPRSurrogate
+    from pygpso_amd.kernels import Constant, Matern52
+    from tests.helpers import synthetic_problem
+    from tests.oracle_engine import OracleEngine
+
+    calls = []
+
+    class Eng(OracleEngine):
+        dtype_name = "float64"
+
+        def append(self, Xn, yn):
+            calls.append(np.array(Xn).shape[0])
+            return super().append(Xn, yn)
+
+        def set_timing(self, on):
+            pass
+
+    X, y = synthetic_problem(40, 2, seed=4)
+    surr = GPRSurrogate(gp_kernel=Matern52(lengthscales=0.25, variance=1.0), gp_meanf=Constant(0.0), refit_every=3)
+    surr.engine_factory = Eng
+    surr.append(X[:30], y[:30])
+    surr.gp_update()
+    model = surr.gpflow_model
+    model.fused_transforms = False  # (the double has no fit_eval_u)
+    evals = model.num_loss_evals
+    theta = {k: np.array(v) for k, v in model.parameter_dict().items()}
+    for step, (lo, hi) in enumerate([(30, 33), (33, 34), (34, 40)], start=1):
+        surr.append(X[lo:hi], y[lo:hi])
+        surr.gp_update()
+        assert model.data[0].shape[0] == hi
+        if step < 3:
+            assert calls[-1] == hi - lo and model.num_loss_evals == evals
+            assert all(np.array_equal(theta[k], v) for k, v in model.parameter_dict().items())
+        else:
+            assert len(calls) == 2 and model.num_loss_evals > evals
+    # the default surrogate never appends
+    plain = GPRSurrogate(gp_kernel=Matern52(lengthscales=0.25, variance=1.0), gp_meanf=Constant(0.0))
+    plain.engine_factory = Eng
+    plain.append(X[:30], y[:30]); plain.gp_update()
+    plain.gpflow_model.fused_transforms = False
+    plain.append(X[30:33], y[30:33]); plain.gp_update()
+    assert len(calls) == 2
