@@ -1644,13 +1644,17 @@ struct EngineT : Engine {
     }
     return GPSO_OK;
   }
+  std::vector<int64_t> wbase_cache;  // what the device copy of the bases holds (they change with the batch shape only)
   int upload_base(const std::vector<int64_t>& base) {
+    if (wbase.p != nullptr && base == wbase_cache) return GPSO_OK;
+    wbase_cache.clear();
     int rc = ensure(wbase, base.size() * 8);
     if (rc) return rc;
     double* stage = ctx->pinned_stage(base.size());
     if (!stage) return ctx->fail(GPSO_E_OOM, "pinned host staging");
     std::memcpy(stage, base.data(), base.size() * 8);
     HIPCHECK(hipMemcpyAsync(wbase.p, stage, base.size() * 8, hipMemcpyHostToDevice, st()));
+    wbase_cache = base;
     return GPSO_OK;
   }
   // local half of gpso_best_ucb_sharded for (rank, world): rows shard_range(m_global, rank, world) of the batch ->
@@ -1714,8 +1718,10 @@ struct EngineT : Engine {
     const int pd = group_payload_doubles(nseg);
     if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[6], s));
     RCCLCHECK(R.AllGather(ovals.p, gath.p, (size_t)pd, ncclDouble, ctx->comm, s));
+    // (the fold writes the group's records straight into the pinned memory finish_best reads: no copy operation behind it)
+    host_direct = result_host((size_t)nseg * 4 + 2);
     launch_reduce_winners(s, as<double>(gath), with_base ? as<int64_t>(wbase) : nullptr, ctx->world, nseg, pd,
-                          as<double>(ovals2));
+                          as<double>(ovals2), host_direct);
     if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[7], s));
     coll_timed = ctx->timing;
     return launch_status();
@@ -1733,7 +1739,7 @@ struct EngineT : Engine {
     double* vals = ctx->pinned_scratch(doubles);
     if (!vals) return ctx->fail(GPSO_E_OOM, "pinned host scratch");
     // (mode 0 / 1: the arg-max's second stage has written the records into this very memory: no copy operation)
-    const bool direct = mode != 2 && host_direct != nullptr && host_direct == vals && src.p == ovals.p;
+    const bool direct = host_direct != nullptr && host_direct == vals && src.p == (mode == 2 ? ovals2.p : ovals.p);
     host_direct = nullptr;
     if (!direct) HIPCHECK(hipMemcpyAsync(vals, src.p, doubles * 8, hipMemcpyDeviceToHost, s));
     if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[3], s));
@@ -2036,8 +2042,9 @@ struct EngineT : Engine {
     }
     const int pd = group_payload_doubles(nseg);
     HIPCHECK(hipMemcpyAsync(gath.p, gathered, (size_t)world * pd * 8, hipMemcpyHostToDevice, s));
+    host_direct = result_host((size_t)nseg * 4 + 2);
     launch_reduce_winners(s, as<double>(gath), with_base ? as<int64_t>(wbase) : nullptr, world, nseg, pd,
-                          as<double>(ovals2));
+                          as<double>(ovals2), host_direct);
     if ((rc = launch_status())) return rc;
     int64_t who = -1;
     int verdict = GPSO_OK;

@@ -373,7 +373,7 @@ void launch_small_best(hipStream_t st, const SmallBest& a, bool keyed);
 // kGroupPayload(nseg)]; base[world][nseg] (nullable) is added to a rank's indices first; out[nseg][4] [, bit-cast rank
 // of the worst status, worst status]
 void launch_reduce_winners(hipStream_t st, const double* gathered, const int64_t* base, int world, int nseg,
-                           int stride, double* out);
+                           int stride, double* out, double* host_out = nullptr /* pinned host copy of out, written by the kernel */);
 // doubles of one rank's group payload: the winners, the live row count of a growth call (bit-cast), the status
 inline int group_payload_doubles(int nseg) { return nseg * 4 + 2; }
 

@@ -1188,7 +1188,8 @@ void launch_small_best(hipStream_t st, const SmallBest& a, bool keyed) {
 // (out[nseg * 4 + 1], and the rank it came from bit-cast into out[nseg * 4]), so that every rank of a group returns the
 // same verdict and none is left inside a collective by a peer that failed locally.
 __global__ void reduce_winners_kernel(const double* __restrict__ gathered, const int64_t* __restrict__ base,
-                                      int world, int nseg, int stride, double* __restrict__ out) {
+                                      int world, int nseg, int stride, double* __restrict__ out,
+                                      double* __restrict__ host_out /* nullable: the same records into pinned host memory */) {
   const int seg = blockIdx.x * blockDim.x + threadIdx.x;
   if (seg == 0 && stride >= nseg * 4 + 2) {
     double worst = 0.0;
@@ -1205,6 +1206,10 @@ __global__ void reduce_winners_kernel(const double* __restrict__ gathered, const
     }
     out[nseg * 4] = __builtin_bit_cast(double, who);
     out[nseg * 4 + 1] = worst;
+    if (host_out != nullptr) {
+      host_out[nseg * 4] = __builtin_bit_cast(double, who);
+      host_out[nseg * 4 + 1] = worst;
+    }
   }
   if (seg >= nseg) return;
   Best best{0.0, -1};
@@ -1229,6 +1234,10 @@ __global__ void reduce_winners_kernel(const double* __restrict__ gathered, const
     o[1] = row[1];
     o[2] = row[2];
     o[3] = __builtin_bit_cast(double, best.i);
+  }
+  if (host_out != nullptr) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) host_out[(int64_t)seg * 4 + k] = o[k];
   }
 }
 
@@ -1408,9 +1417,9 @@ void launch_keyed_argmax(hipStream_t st, const double* mean, const double* var, 
 }
 
 void launch_reduce_winners(hipStream_t st, const double* gathered, const int64_t* base, int world, int nseg,
-                           int stride, double* out) {
+                           int stride, double* out, double* host_out) {
   hipLaunchKernelGGL(reduce_winners_kernel, dim3((unsigned)((nseg + 63) / 64)), dim3(64), 0, st, gathered, base,
-                     world, nseg, stride, out);
+                     world, nseg, stride, out, host_out);
 }
 
 // splitmix64-style finaliser of (word, position, salt); summed with wrap-around
