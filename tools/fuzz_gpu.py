@@ -119,6 +119,32 @@ for case in range(N_CASES):
             b = tree.split_bounds(b)[int(rng.integers(3))]
         depth = int(rng.integers(1, 7))
         ok &= np.array_equal(eng.grow(np.array(b), depth), tree.grow(b, depth))
+    # ... and (round 5) gpso_append: k more points at the same hyper-parameters against the oracle's from-scratch posterior
+    # of the n + k points, held to the tolerances of the fit above.  Its random draws come from a generator of their own so
+    # that the cases of the earlier rounds' seeds stay what they were.
+    rng_a = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1234")) * 1000003 + case)
+    if n >= 2 and rng_a.random() < 0.6:
+        k_new = int(rng_a.choice([1, 2, 3, 7, 20]))
+        X2, y2 = synthetic_problem(k_new, d, seed=int(rng_a.integers(1 << 30)))
+        Xa, ya = np.vstack([X, X2]), np.concatenate([y, y2])
+        try:
+            post_a = gpr.posterior(th, Xa, ya)
+            f_a, in_place = eng.append(X2, y2)
+            mean_a, var_a = eng.predict(Xs)
+            mean_ar, var_ar = gpr.predict_y(post_a, Xs)
+            ysa = max(1.0, float(np.max(np.abs(ya - th.mean_c))))
+            scale_m = ysa if dtype == "float64" else 1.0
+            e_ma = (base * amp * ysa) if dtype == "float64" else 4e-4 * ysa
+            errs["app_nlml"] = abs(f_a - post_a.nlml) / max(1.0, abs(post_a.nlml))
+            errs["app_mean"] = float(np.max(np.abs(mean_a - mean_ar)))
+            errs["app_var"] = float(np.max(np.abs(var_a - var_ar)))
+            # (the extended matrix may be worse conditioned than the first: the allowance follows the first's, x 4)
+            ok &= errs["app_nlml"] <= 4 * e_f and errs["app_mean"] <= 4 * e_ma and errs["app_var"] <= 4 * e_v
+            tag += f" +{k_new}{'' if in_place else 'r'}"
+        except (GpsoPrecisionError, np.linalg.LinAlgError):
+            tag += f" +{k_new}x"  # (a refusal / loss of positive definiteness after the append: the fit's rule above applies)
+            refused += dtype != "float64"
+            ok &= dtype != "float64"
     status = "ok " if ok else "BAD"
     bad += (not ok)
     print(f"{status} {tag} " + " ".join(f"{k_}={v:.1e}" for k_, v in errs.items()))
