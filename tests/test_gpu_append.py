@@ -259,3 +259,59 @@ def test_append_data_on_the_model_and_refit_every_on_the_surrogate():
             assert np.max(np.abs(var[:, 0] - var_ref)) <= 1e-8 * th.variance
         else:  # the third update re-optimises
             assert model.num_loss_evals > evals0
+
+
+@pytest.mark.parametrize("dtype", ["mixed", "float32"])
+def test_append_behind_an_evaluation_with_gradient_and_a_wide_block(dtype):
+    """(a) An evaluation WITH gradient defers the packing of the 16-bit pieces: an append behind it must leave the later
+    packing the right maximum (the fp16 scale) and the right N.  (b) k = 40 runs the 64-wide instantiation of the passes in a
+    float context (N_pad = 4096: below that a block this wide is refitted)."""
+    n, d, k = 4096 - 47, 6, 40
+    X, y = synthetic_problem(n + k + 7, d, seed=23)
+    th = gpr.Theta("Matern52", np.array([0.25 * np.sqrt(d)]), 1.0, 1e-3, float(y.mean()))
+    eng = _engine(dtype)
+    _fit(eng, X[:n], y[:n], th, grad=True)          # pieces pending
+    f1, in_place = eng.append(X[n:n + 7], y[n:n + 7])
+    assert in_place, eng.last_message()
+    f2, in_place = eng.append(X[n + 7:], y[n + 7:])  # k = 40 -> KP = 64
+    assert in_place, eng.last_message()
+    post = gpr.posterior(th, X, y)
+    assert abs(f2 - post.nlml) <= (2e-5 if dtype == "float32" else 1e-9) * abs(post.nlml)
+    Xs = synthetic_leaves(2048, d)
+    mean, var = eng.predict(Xs)
+    mean_ref, var_ref = gpr.predict_y(post, Xs)
+    em = float(np.max(np.abs(mean - mean_ref)) / np.max(np.abs(y)))
+    ev = float(np.max(np.abs(var - var_ref)) / th.variance)
+    print(f"append behind a gradient, k = 7 + 40, {dtype}: |d mean| {em:.2e} max|y|, |d var| {ev:.2e} sigma^2")
+    assert em <= 3.3e-4 and ev <= 2.4e-5  # the C4-class float bounds of tests/test_gpu_parity.py (N = 4096 .. 8192)
+
+
+def test_an_appended_posterior_travels_like_a_fitted_one():
+    """The extended posterior is handed to a second context as ONE span copy (what gpso_broadcast_posterior moves): the
+    receiver adopts N + k points and predicts the sender's bits; fingerprints of two contexts that ran the same fit + append
+    agree (a replicating group appends on every rank)."""
+    import torch
+
+    from tests.test_gpu_distributed import _DeviceBytes
+
+    n, d, k = 600, 4, 5
+    X, y = synthetic_problem(n + k, d, seed=29)
+    th = gpr.Theta("Matern52", np.array([0.5]), 1.0, 1e-3, float(y.mean()))
+    Xs = synthetic_leaves(3000, d)
+    for dtype in ("float64", "mixed"):
+        a, b, c = _engine(dtype), _engine(dtype), _engine(dtype)
+        for e in (a, c):
+            _fit(e, X[:n], y[:n], th)
+            e.append(X[n:], y[n:])
+        assert a.posterior_hash() == c.posterior_hash()
+        ptr, off, nb = a.posterior_span()
+        b.alloc_posterior(a.n, a.d)
+        dst = b.posterior_span_at(off, nb)
+        torch.as_tensor(_DeviceBytes(dst, nb), device="cuda").copy_(torch.as_tensor(_DeviceBytes(ptr, nb), device="cuda"))
+        torch.cuda.synchronize()
+        b.adopt_posterior()
+        assert b.n == n + k
+        ra, rb = a.best_ucb(Xs, VS), b.best_ucb(Xs, VS)
+        assert all(np.array_equal(u, v) for u, v in zip(ra, rb))
+        ma, mb = a.predict(Xs), b.predict(Xs)
+        assert np.array_equal(ma[0], mb[0]) and np.array_equal(ma[1], mb[1])
