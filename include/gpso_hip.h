@@ -226,8 +226,9 @@ int gpso_best_ucb(gpso_ctx* ctx, const void* xs, int xs_dtype, int xs_mem, int64
  * The reference's loop (gpso/optimisation.py:366-382) is synchronous -- the blocking calls above are _begin + _end --;
  * callers with several independent batches (conditional grids, one batch per tree level of several trees) overlap them.
  * Between a _begin and its _end the leaves buffer (GPSO_MEM_DEVICE) must stay untouched; host leaves are copied before
- * _begin returns.  nseg <= 1024.  Any call that changes the posterior while a ticket is open leaves that ticket's
- * result undefined.  gpso_last_ms is not updated by asynchronous calls. */
+ * _begin returns.  nseg <= 1024.  Calls that replace or change the posterior (gpso_set_data, gpso_fit_eval, gpso_append,
+ * gpso_set_posterior, gpso_alloc_posterior) return GPSO_E_STATE while a ticket is open.  gpso_last_ms is not updated by
+ * asynchronous calls. */
 int gpso_best_ucb_begin(gpso_ctx* ctx, const void* xs, int xs_dtype, int xs_mem, int64_t m, const int64_t* seg_off,
                         int nseg, double varsigma);
 int gpso_best_ucb_grow_begin(gpso_ctx* ctx, const double* bounds, int nseg, int depth, double varsigma);

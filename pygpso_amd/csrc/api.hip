@@ -503,6 +503,12 @@ struct EngineT : Engine {
   }
 
   hipStream_t st() const { return ctx->stream; }
+  // calls that replace or change the posterior are refused while an asynchronous best-UCB call is open: its kernels
+  // may still be reading what the call would overwrite
+  int refuse_if_async(const char* what) {
+    if (ctx->slots_busy() == 0) return GPSO_OK;
+    return ctx->fail(GPSO_E_STATE, "%s while %d asynchronous best-UCB call(s) are open: gpso_best_ucb_end them first", what, ctx->slots_busy());
+  }
   double* ls_dev() const { return static_cast<double*>(hyper.p) + kHyperHeader; }
   template <typename U>
   U* as(const DevBuf& b) const { return static_cast<U*>(b.p); }
@@ -724,7 +730,9 @@ struct EngineT : Engine {
   // ------------------------------------------------------------------------------------------
   int set_data(const double* X, const double* y, int64_t n_, int d_) override {
     if (!X || !y) return ctx->fail(GPSO_E_ARG, "X / y must not be NULL");
-    int rc = shape(n_, d_);
+    int rc = refuse_if_async("gpso_set_data");
+    if (rc) return rc;
+    rc = shape(n_, d_);
     if (rc) return rc;
     // small problems (the optimiser loop: N <= a few hundred) are staged through pinned memory so that
     // the call needs no stream synchronisation; large ones copy straight from the caller's pages
@@ -753,7 +761,9 @@ struct EngineT : Engine {
     ctx->tick_timing();
     if (!have_data) return ctx->fail(GPSO_E_STATE, "gpso_fit_eval before gpso_set_data");
     if (!ls) return ctx->fail(GPSO_E_ARG, "lengthscales must not be NULL");
-    int rc = ensure_fit_buffers();
+    int rc = refuse_if_async("gpso_fit_eval");
+    if (rc) return rc;
+    rc = ensure_fit_buffers();
     if (rc) return rc;
     const bool small = fused_small && small_fit_eligible(n, dp);
     if ((rc = set_theta(kernel, ls, n_ls_, variance, noise, mean_c, !small))) return rc;
@@ -889,6 +899,7 @@ struct EngineT : Engine {
     ctx->tick_timing();
     if (!Xn || !yn) return ctx->fail(GPSO_E_ARG, "Xnew / ynew must not be NULL");
     if (k < 1) return ctx->fail(GPSO_E_ARG, "need at least one new point (k=%lld)", (long long)k);
+    if (int rca = refuse_if_async("gpso_append")) return rca;
     if (!have_data || !have_post || !chol_valid || (int64_t)y_host.size() != n)
       return ctx->fail(GPSO_E_STATE, "gpso_append needs a posterior fitted on this context (gpso_set_data + gpso_fit_eval)");
     const int64_t n_new = n + k;
@@ -982,7 +993,9 @@ struct EngineT : Engine {
                     int kernel, const double* ls, int n_ls_, double variance, double noise,
                     double mean_c) override {
     if (!X || !L || !alpha64 || !ls) return ctx->fail(GPSO_E_ARG, "NULL argument");
-    int rc = shape(n_, d_);
+    int rc = refuse_if_async("gpso_set_posterior");
+    if (rc) return rc;
+    rc = shape(n_, d_);
     if (rc) return rc;
     if ((rc = ensure_fit_buffers())) return rc;
     if ((rc = set_theta(kernel, ls, n_ls_, variance, noise, mean_c))) return rc;
@@ -2307,7 +2320,9 @@ struct EngineT : Engine {
   }
 
   int alloc_posterior(int64_t n_, int d_) override {
-    int rc = shape(n_, d_);
+    int rc = refuse_if_async("gpso_alloc_posterior");
+    if (rc) return rc;
+    rc = shape(n_, d_);
     if (rc) return rc;
     have_data = have_post = have_kinv = chol_valid = linv_p_valid = false;
     st_done = st_have = false;

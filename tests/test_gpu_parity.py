@@ -1153,6 +1153,8 @@ def test_the_non_blocking_pair_gives_the_blocking_calls_bits(dtype):
         assert all(np.array_equal(u, v) for u, v in zip(got_a, ref_a))
         assert all(np.array_equal(u, v, equal_nan=True) for u, v in zip(got_b, ref_b))
     tg = eng.best_ucb_grow_begin(box, 6, VS)
+    with pytest.raises(L.GpsoHipError, match="asynchronous"):  # the posterior cannot change under an open ticket
+        eng.fit_eval(th.kernel, th.lengthscales, th.variance, th.noise, th.mean_c, want_grad=False)
     ta = eng.best_ucb_begin(A, VS)
     assert all(np.array_equal(u, v) for u, v in zip(eng.best_ucb_end(tg), ref_g))
     assert all(np.array_equal(u, v) for u, v in zip(eng.best_ucb_end(ta), ref_a))
