@@ -25,21 +25,30 @@ def main():
     ap.add_argument("--dim", type=int, default=4)
     ap.add_argument("--depth", type=int, default=7)
     ap.add_argument("--budget", type=int, default=80)
+    ap.add_argument("--refit-every", type=int, default=1,
+                    help="c > 1 (opt-in, not the reference's behaviour): the surrogate re-optimises its hyper-parameters on every "
+                         "c-th update only and extends the device posterior by the new points in between (gpso_append)")
+    ap.add_argument("--skip-cpu", action="store_true", help="do not run the CPU oracle loop beside it")
     a = ap.parse_args()
     bounds = [[-1.0, 1.0]] * a.dim
 
     from oracle import gpso_loop
-    from pygpso_amd import GPSOptimiser, ParameterSpace
+    from pygpso_amd import GPRSurrogate, GPSOptimiser, ParameterSpace
+
+    def surrogate():
+        surr = GPRSurrogate.default()
+        surr.refit_every = max(1, a.refit_every)
+        return surr
 
     # first pass: includes the one-off costs (library + code-object load, context creation, allocations)
     t0 = time.perf_counter()
     space = ParameterSpace(parameter_names=[f"p{i}" for i in range(a.dim)], parameter_bounds=bounds)
-    GPSOptimiser(space, exploration_depth=a.depth, budget=a.budget).run(objective)
+    GPSOptimiser(space, gp_surrogate=surrogate(), exploration_depth=a.depth, budget=a.budget).run(objective)
     t_cold = time.perf_counter() - t0
 
     t0 = time.perf_counter()
     space = ParameterSpace(parameter_names=[f"p{i}" for i in range(a.dim)], parameter_bounds=bounds)
-    opt = GPSOptimiser(space, exploration_depth=a.depth, budget=a.budget)
+    opt = GPSOptimiser(space, gp_surrogate=surrogate(), exploration_depth=a.depth, budget=a.budget)
     phases = {"_gp_update": 0.0, "_tree_explore": 0.0, "_tree_select": 0.0}
     for name in phases:
         fn = getattr(opt, name)
@@ -56,6 +65,12 @@ def main():
     t_gpu = time.perf_counter() - t0
     model = opt.gp_surr.gpflow_model
 
+    if a.skip_cpu or a.refit_every > 1:  # (the oracle loop restates the reference: it always re-optimises)
+        print(json.dumps({"dim": a.dim, "depth": a.depth, "budget": a.budget, "refit_every": a.refit_every,
+                          "evaluations": opt.n_eval_counter, "iterations": opt.iterations,
+                          "gp_loss_evaluations": model.num_loss_evals, "hip_seconds": t_gpu, "hip_phase_seconds": phases,
+                          "best_score_hip": best.score_mu, "training_points": int(model.data[0].shape[0])}))
+        return
     t0 = time.perf_counter()
     st = gpso_loop.LoopState(bounds, depth=a.depth, budget=a.budget)
     best_ref = gpso_loop.run(st, objective)
