@@ -116,6 +116,9 @@ typedef struct gpso_ctx gpso_ctx;
 #define GPSO_CONTRACTION_F16 2     /*   slot; 1: the f32 matrix instruction (rounds 1-3); 2: same as 0 today.  Different  */
                                    /*   roundings of r^2, both inside the float class: the self-test rules on whichever    */
                                    /*   runs                                                                                */
+#define GPSO_OPT_FUSED_PREP 11     /* 1 (default): float leaves (GPSO_F32) of a one-chunk batch are scaled by the lengthscales in  */
+                                   /* the fp16-contraction kernel's own prologue -- no prep launch in front of it; 0: the separate */
+                                   /* prep kernel.  Same bits (tests/test_gpu_parity.py); the option exists for that comparison     */
 /* floating-point options (gpso_set_option_f64): tolerances of the self-test */
 #define GPSO_OPTF_TOL_VAR 100  /* max |d var| at the training inputs, relative to the kernel variance (default 1e-4; GPSO_F32: 1e-3) */
 #define GPSO_OPTF_TOL_MEAN 101 /* max |d mean| at the training inputs, relative to max |y - c|   (default 1e-4; GPSO_F32: 1e-3) */

@@ -60,12 +60,21 @@ void launch_gen_inputs_f16(hipStream_t st, const float* xs32, const float* xnorm
 // 2 floats: max |L^-1|, 2^-sa) come from launch_pack_linv_f16
 // FUSED: the fused step (round 4) or round 3's two-phase step -- same bits; one explicit instantiation per slice
 // (TG, FUSED, KS) in predict_split_*.hip
+// the caller's unscaled float leaves for the fp16-contraction kernels, whose prologue can scale them itself (round 5: the
+// prep launch and the dependency gap behind it are 12 us of a 740 us step at C3); x == nullptr: leaves_s / lnorm are read
+struct RawLeaves {
+  const float* x = nullptr;
+  const double* ls = nullptr;  // lengthscale per input dimension (device)
+  int64_t m = 0;
+  int d = 0;
+};
 template <typename TG, bool FUSED, int KS /* kernel families 0-1 | 2-3 */>
 int launch_leaf_tiles_bf16_v(hipStream_t st, int nsplit, const void* linv_b, const TG* xs_p,
                              const TG* xnorm, const float* alpha, const TG* leaves_s,
                              const TG* lnorm, double* part_var, double* part_mean, int64_t npad,
                              int dp4, int64_t mpad, const KernParams& kp, const int64_t* m_live,
-                             const float* f16_inv_scale_a, const void* xs_h16, const float* c16_scale, int64_t n_rows);
+                             const float* f16_inv_scale_a, const void* xs_h16, const float* c16_scale, int64_t n_rows,
+                             const RawLeaves& rawl);
 // variant: GPSO_OPT_SPLIT_KERNEL (0 the fused step, 1 the two-phase step); xs_h16 and c16_scale both set: the contraction
 // on the fp16 pipe (fp16 split, float generation); n_rows: N (0: unknown) -- the fused step stops at the k-steps that
 // hold padding points only
@@ -75,8 +84,8 @@ inline int launch_leaf_tiles_bf16(hipStream_t st, int nsplit, const void* linv_b
                                   const TG* lnorm, double* part_var, double* part_mean, int64_t npad,
                                   int dp4, int64_t mpad, const KernParams& kp, const int64_t* m_live,
                                   const float* f16_inv_scale_a = nullptr, int variant = 0, const void* xs_h16 = nullptr,
-                                  const float* c16_scale = nullptr, int64_t n_rows = 0) {
-#define GPSO_V(FUSED, KS) launch_leaf_tiles_bf16_v<TG, FUSED, KS>(st, nsplit, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, xs_h16, c16_scale, n_rows)
+                                  const float* c16_scale = nullptr, int64_t n_rows = 0, const RawLeaves& rawl = RawLeaves{}) {
+#define GPSO_V(FUSED, KS) launch_leaf_tiles_bf16_v<TG, FUSED, KS>(st, nsplit, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, xs_h16, c16_scale, n_rows, rawl)
   const bool low = kp.kernel == 0 || kp.kernel == 1;
   const int rc = variant == 0 ? (low ? GPSO_V(true, 0) : GPSO_V(true, 1)) : (low ? GPSO_V(false, 0) : GPSO_V(false, 1));
 #undef GPSO_V

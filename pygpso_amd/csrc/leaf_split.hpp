@@ -487,7 +487,10 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     const float* __restrict__ alpha, const TG* __restrict__ leaves_s,
     const TG* __restrict__ lnorm, double* __restrict__ part_var, double* __restrict__ part_mean,
     int npad16, int dp4, int64_t mpad, int nbi, float variance, const int64_t* __restrict__ m_live,
-    const float* __restrict__ inv_scale_a, float inv_scale_b, const float* __restrict__ c16_scale, int q_max) {
+    const float* __restrict__ inv_scale_a, float inv_scale_b, const float* __restrict__ c16_scale, int q_max,
+    const float* __restrict__ raw /* nullable (C16 only): the caller's UNSCALED float leaves [raw_m][raw_d] -- the prologue
+    scales them itself ((float)(x / l), rows beyond raw_m are padding): no prep launch in front of this kernel */,
+    const double* __restrict__ raw_ls, int64_t raw_m, int raw_d) {
   constexpr int RT = 16, CT = 2, NW = 8;
   constexpr TG SC = (TG)GenScale<KERNEL>::SC;
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -611,7 +614,15 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
           const int k = 32 * cc + 8 * (lane >> 4) + j;
           // (clamped into fp16's range; a NaN coordinate stays NaN -- fminf / fmaxf would turn it into -60000 and the
           // leaf into a far-away point with the prior's mean and variance, unlike every other predict path)
-          const float xv = (float)src[k < dp ? k : 0] * up;
+          float xv;
+          if (raw != nullptr) {  // (workgroup-uniform) the arithmetic of prep_leaves_kernel<float, float>, bit for bit
+            const int64_t jrow = col0 + t * 16 + (lane & 15);
+            const int kk = k < dp ? k : 0;
+            xv = (jrow < raw_m && kk < raw_d) ? (float)((double)raw[jrow * raw_d + kk] / raw_ls[kk]) : 0.0f;
+            xv *= up;
+          } else {
+            xv = (float)src[k < dp ? k : 0] * up;
+          }
           v[j] = k < dp ? (xv != xv ? xv : fminf(fmaxf(xv, -60000.0f), 60000.0f)) : (k == dp ? 128.0f : 0.0f);
         }
         // (the norm from scalar conversions of the values, ahead of the split: summed from bit casts of the packed pieces
@@ -786,7 +797,7 @@ static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const T
                                      const TG* lnorm, double* part_var, double* part_mean,
                                      int64_t npad, int dp4, int64_t mpad, const KernParams& kp,
                                      const int64_t* m_live, const float* inv_scale_a = nullptr,
-                                     const float* c16_scale = nullptr, int64_t n_rows = 0) {
+                                     const float* c16_scale = nullptr, int64_t n_rows = 0, const RawLeaves& rawl = RawLeaves{}) {
   const int nbi = (int)(npad / 256);
   const dim3 grid((unsigned)(mpad / 256), (unsigned)nbi);
   const size_t lds = leaf_bf16_lds_bytes(NS, dp4, (int)sizeof(TG), C16 != 0);
@@ -808,7 +819,7 @@ static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const T
     hipLaunchKernelGGL((leaf_tiles_bf16_kernel<NS, TG, K, F16, FUSED, C16>), grid, dim3(512), lds, st, \
                        static_cast<const u32x4*>(linv_b), xs_p, xnorm, alpha, leaves_s, lnorm,      \
                        part_var, part_mean, (int)(npad / 16), dp4, mpad, nbi, var_arg, m_live,      \
-                       inv_scale_a, inv_b, c16_scale, q_max);                                       \
+                       inv_scale_a, inv_b, c16_scale, q_max, C16 ? rawl.x : nullptr, rawl.ls, rawl.m, rawl.d); \
   } while (0)
   if constexpr (KS == 0) {
     if (kp.kernel == 0) GPSO_L(0);
@@ -827,13 +838,13 @@ int launch_leaf_tiles_bf16_v(hipStream_t st, int nsplit, const void* linv_b, con
                            const TG* lnorm, double* part_var, double* part_mean, int64_t npad,
                            int dp4, int64_t mpad, const KernParams& kp, const int64_t* m_live,
                            const float* f16_inv_scale_a, const void* xs_h16, const float* c16_scale,
-                           int64_t n_rows) {
+                           int64_t n_rows, const RawLeaves& rawl) {
   if (f16_inv_scale_a != nullptr) {  // fp16 split (nsplit == 2 pieces)
     if constexpr (sizeof(TG) == 4) {
       if (xs_h16 != nullptr && c16_scale != nullptr) {  // ... with the contraction on the fp16 pipe as well
         if (leaf_c16_chunks(dp4) == 1)
-          return launch_leaf_tiles_bf16_ns<FUSED, KS, 2, TG, true, 1>(st, linv_b, static_cast<const TG*>(xs_h16), xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, c16_scale, n_rows);
-        return launch_leaf_tiles_bf16_ns<FUSED, KS, 2, TG, true, 2>(st, linv_b, static_cast<const TG*>(xs_h16), xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, c16_scale, n_rows);
+          return launch_leaf_tiles_bf16_ns<FUSED, KS, 2, TG, true, 1>(st, linv_b, static_cast<const TG*>(xs_h16), xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, c16_scale, n_rows, rawl);
+        return launch_leaf_tiles_bf16_ns<FUSED, KS, 2, TG, true, 2>(st, linv_b, static_cast<const TG*>(xs_h16), xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, c16_scale, n_rows, rawl);
       }
     }
     return launch_leaf_tiles_bf16_ns<FUSED, KS, 2, TG, true>(st, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, nullptr, n_rows);

@@ -5,6 +5,6 @@
 #include "leaf_split.hpp"
 
 namespace gpso {
-template int launch_leaf_tiles_bf16_v<float, false, 0>(hipStream_t, int, const void*, const float*, const float*, const float*, const float*, const float*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*, const float*, const void*, const float*, int64_t);
-template int launch_leaf_tiles_bf16_v<float, false, 1>(hipStream_t, int, const void*, const float*, const float*, const float*, const float*, const float*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*, const float*, const void*, const float*, int64_t);
+template int launch_leaf_tiles_bf16_v<float, false, 0>(hipStream_t, int, const void*, const float*, const float*, const float*, const float*, const float*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*, const float*, const void*, const float*, int64_t, const RawLeaves&);
+template int launch_leaf_tiles_bf16_v<float, false, 1>(hipStream_t, int, const void*, const float*, const float*, const float*, const float*, const float*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*, const float*, const void*, const float*, int64_t, const RawLeaves&);
 }  // namespace gpso

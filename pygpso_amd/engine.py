@@ -29,6 +29,9 @@ def _producer_stream(x):
     torch = sys.modules.get("torch")
     if torch is None or not isinstance(x, torch.Tensor):
         return None
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # (the pointer without a Stream object: this sits in every call)
+    if raw is not None and x.device.index is not None:
+        return int(raw(x.device.index))
     return int(torch.cuda.current_stream(x.device).cuda_stream)
 
 

@@ -1168,3 +1168,29 @@ def test_the_non_blocking_pair_gives_the_blocking_calls_bits(dtype):
         t = t2
     assert all(np.array_equal(u, v) for u, v in zip(eng.best_ucb_end(t), ref_a))
     assert all(np.array_equal(u, v, equal_nan=True) for u, v in zip(eng.best_ucb(B, VS, seg), ref_b))  # the blocking call behind it
+
+
+@pytest.mark.parametrize("n,d", [(2048, 12), (700, 33), (300, 5)])
+def test_leaves_scaled_in_the_kernels_prologue_give_the_prep_kernels_bits(n, d):
+    """Float leaves of a one-chunk batch are scaled by the lengthscales in the fp16-contraction kernel's own prologue
+    (GPSO_OPT_FUSED_PREP, default on): the same bits as with the separate prep kernel, and as float64 leaves holding the
+    same values (which always go through the prep kernel) -- host and device leaves, predict and best-UCB."""
+    import torch
+
+    from pygpso_amd import HipGPEngine, _lib as L
+
+    X, y, th = _problem(n, d, variance=1.0)
+    Xs = synthetic_leaves(5000, d).astype(np.float32)
+    res = []
+    for fused in (1, 0):
+        eng = HipGPEngine("mixed", predict_math="f16x3")
+        eng._check(eng._lib.gpso_set_option(eng._h, L.OPT_FUSED_PREP, fused))
+        _fit(eng, X, y, th, grad=False)
+        assert eng.precision_info()["predict_math"] == "f16x3"
+        dev = torch.from_numpy(Xs).cuda()
+        res.append((eng.predict(Xs), eng.predict(dev), eng.best_ucb(dev, VS, np.array([0, 17, 4000, 5000])), eng.predict(Xs.astype(np.float64))))
+    for a, b in zip(res[0], res[1]):
+        assert all(np.array_equal(u, v) for u, v in zip(a, b))
+    assert all(np.array_equal(u, v) for u, v in zip(res[0][0], res[0][3]))  # float leaves == the same values as doubles
+    mean_ref, var_ref = gpr.predict_y(gpr.posterior(th, X, y), Xs.astype(np.float64))
+    assert np.max(np.abs(res[0][0][1] - var_ref)) <= 2e-5 * th.variance
