@@ -171,7 +171,8 @@ struct gpso_ctx {
   size_t stage_doubles = 0;
   // gpso_best_ucb_begin / _end: two calls may be in flight; each has a pinned result slot of its own and a completion event
   static constexpr int kSlots = 2;
-  static constexpr size_t kSlotDoubles = 4 * 1024 + 2;  // nseg <= 1024 per asynchronous call
+  static constexpr size_t kSlotDoubles = 4 * 1024 + 4;  // nseg <= 1024 per asynchronous call (+ the completion token)
+  double slot_token[kSlots] = {0, 0};
   double* slot_host = nullptr;   // [kSlots][kSlotDoubles], pinned
   hipEvent_t slot_ev[kSlots] = {};
   int slot_nseg[kSlots] = {0, 0};  // > 0: the slot holds a call that has not been ended
@@ -202,9 +203,29 @@ struct gpso_ctx {
       pinned_doubles = 0;
       const size_t want = std::max<size_t>(doubles, 256);
       if (hipHostMalloc(reinterpret_cast<void**>(&pinned), want * 8, hipHostMallocDefault) != hipSuccess) return nullptr;
+      std::memset(pinned, 0, want * 8);  // (no stale completion token)
       pinned_doubles = want;
     }
     return pinned;
+  }
+  // Completion tokens (round 5): where the last kernel of a call is a single workgroup it writes a sequence number behind
+  // its records in pinned host memory and the host spins on THAT word -- no event to record, no driver call per poll.  A
+  // token that does not arrive within kSpinMs falls back to a blocking wait (where a failed launch surfaces as before).
+  uint64_t seq = 0;
+  double next_token() { return (double)(++seq); }  // (exact in a double for 2^53 calls)
+  hipError_t wait_token(const double* word, double token, hipStream_t s) {
+    constexpr double kSpinMs = 20.0;
+    const volatile double* w = word;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int it = 0;; ++it) {
+      if (*w == token) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return hipSuccess;
+      }
+      if ((it & 1023) == 1023 &&
+          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > kSpinMs)
+        return hipStreamSynchronize(s);
+    }
   }
 
   // staging buffer for host -> device copies that must not force a stream synchronisation.  It is
@@ -322,7 +343,16 @@ struct EngineT : Engine {
   std::vector<int64_t> segoff_cache;  // what the device copy of seg_off currently holds
   double* host_direct = nullptr;      // pinned host memory the arg-max of the call in flight writes its records to
   double* result_slot = nullptr;      // asynchronous call being enqueued: its own pinned slot instead of the shared scratch
-  double* result_host(size_t doubles) { return result_slot != nullptr ? result_slot : ctx->pinned_scratch(doubles); }
+  double* result_host(size_t doubles) { return result_slot != nullptr ? result_slot : ctx->pinned_scratch(doubles + 1); }  // (+ the token's slot)
+  double call_token = 0.0;  // the completion token the LAST kernel of the call in flight writes (0: none -- wait for the event)
+  // a fresh token for the kernel about to be launched as the call's last one, or 0 where the call is timed (events needed)
+  // or that kernel is not a single workgroup
+  double arm_token(bool single_workgroup, int nseg) {
+    call_token = (single_workgroup && !ctx->timing && host_direct != nullptr) ? ctx->next_token() : 0.0;
+    // (whatever an earlier call left in the token's word -- a record of a call with more segments -- cannot pass for it)
+    if (call_token != 0.0) host_direct[4 * nseg + 2] = 0.0;
+    return call_token;
+  }
   DevBuf extra_cnt;                   // small growth calls: rows appended behind the analytic slots (zero between calls)
   // predict workspace
   DevBuf leaves_raw, leaves_s, lnorm, pvar, pmean, omean, ovar, oucb, segoff, best, oidx, ovals, grow_key,
@@ -776,6 +806,7 @@ struct EngineT : Engine {
     st_done = st_have = false;
     reset_generation();
     hipStream_t s = st();
+    double fit_token = 0.0;
     if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[4], s));
     if (grad && (rc = ensure(kinvb, (size_t)npad * npad * sizeof(TF)))) return rc;
     if (small) {
@@ -794,6 +825,9 @@ struct EngineT : Engine {
       // the loss, the factorisation's verdict and the gradient land in pinned host memory straight from the kernel
       a.scal_host = ctx->pinned_scratch(8 + kGradMaxLs + 3);
       if (!a.scal_host) return ctx->fail(GPSO_E_OOM, "pinned host scratch");
+      fit_token = ctx->timing ? 0.0 : ctx->next_token();  // (slot 7 of the scalars: unused by the layout)
+      a.scal_host[7] = 0.0;
+      a.done_token = fit_token;
       if ((rc = launch_small_fit<TF, TP>(s, a))) return launch_status();
     } else {
       if ((rc = scale_inputs())) return rc;
@@ -868,7 +902,8 @@ struct EngineT : Engine {
     double* host = ctx->pinned_scratch(kHostDoubles);
     if (!host) return ctx->fail(GPSO_E_OOM, "pinned host scratch");
     if (!small) HIPCHECK(hipMemcpyAsync(host, scal.p, kHostDoubles * 8, hipMemcpyDeviceToHost, s));
-    HIPCHECK(ctx->wait(s));
+    if (small && fit_token != 0.0 && !ctx->timing) HIPCHECK(ctx->wait_token(&host[7], fit_token, s));
+    else HIPCHECK(ctx->wait(s));
     float ms = 0;
     if (ctx->timing && hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) ctx->last_ms[2] = ms;
     int info;
@@ -1423,6 +1458,7 @@ struct EngineT : Engine {
     one.fallback = static_cast<unsigned*>(one_ctl.p) + 1;
     one.out_vals = as<double>(ovals);
     one.host_vals = host_direct = result_host((size_t)nseg * 4 + 2);
+    one.done_token = arm_token(true, nseg);  // (the last-arriving workgroup's thread 0 writes every host record, then the token)
     const TG* xsp;
     const TG* xnr;
     if constexpr (sizeof(TG) == 8) {
@@ -1479,6 +1515,7 @@ struct EngineT : Engine {
     int rc;
     one_pending = false;  // (a call whose result was never read -- gpso_shard_winners -- leaves nothing behind)
     host_direct = nullptr;
+    call_token = 0.0;
     hipStream_t s = st();
     if ((rc = ensure(omean, (size_t)m * 8))) return rc;
     if ((rc = ensure(ovar, (size_t)m * 8))) return rc;
@@ -1528,10 +1565,12 @@ struct EngineT : Engine {
       sb.nseg = nseg;
       sb.out_vals = as<double>(ovals);
       sb.host_vals = host_direct;
+      sb.done_token = arm_token(true, nseg);
       launch_small_best(s, sb, false);
     } else {
       launch_seg_argmax(s, as<double>(omean), as<double>(ovar), as<double>(oucb), as<int64_t>(segoff),
-                        nseg, argmax_blocks(m, nseg), best.p, as<double>(ovals), fin.part_var ? &fin : nullptr, host_direct);
+                        nseg, argmax_blocks(m, nseg), best.p, as<double>(ovals), fin.part_var ? &fin : nullptr, host_direct,
+                        arm_token(nseg == 1, nseg));
     }
     ctx->last_count[0] = ctx->last_count[1] = m;
     return launch_status();
@@ -1547,6 +1586,7 @@ struct EngineT : Engine {
     int rc;
     one_pending = false;
     host_direct = nullptr;
+    call_token = 0.0;
     hipStream_t s = st();
     const int64_t rows = gpso_grow_rows(depth);
     const int64_t uniq = grow_unique_before(row_hi) - grow_unique_before(row_lo);
@@ -1612,6 +1652,7 @@ struct EngineT : Engine {
       sb.nseg = nseg;
       sb.out_vals = as<double>(ovals);
       sb.host_vals = host_direct;
+      sb.done_token = arm_token(true, nseg);
       launch_small_best(s, sb, true);
       ctx->last_count[1] = cap;
       return launch_status();
@@ -1634,7 +1675,7 @@ struct EngineT : Engine {
     host_direct = result_host((size_t)nseg * 4 + 2);
     launch_keyed_argmax(s, as<double>(omean), as<double>(ovar), as<double>(oucb), as<int64_t>(grow_key), rows, uniq,
                         nseg, as<int64_t>(live_cnt), argmax_blocks(cap, nseg), best.p, as<int64_t>(best_pos), as<double>(ovals),
-                        fin.part_var ? &fin : nullptr, host_direct);
+                        fin.part_var ? &fin : nullptr, host_direct, arm_token(nseg == 1, nseg));
     ctx->last_count[1] = cap;
     return launch_status();
   }
@@ -1755,7 +1796,7 @@ struct EngineT : Engine {
     // (the fold writes the group's records straight into the pinned memory finish_best reads: no copy operation behind it)
     host_direct = result_host((size_t)nseg * 4 + 2);
     launch_reduce_winners(s, as<double>(gath), with_base ? as<int64_t>(wbase) : nullptr, ctx->world, nseg, pd,
-                          as<double>(ovals2), host_direct);
+                          as<double>(ovals2), host_direct, arm_token(nseg <= 64, nseg));
     if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[7], s));
     coll_timed = ctx->timing;
     return launch_status();
@@ -1777,7 +1818,10 @@ struct EngineT : Engine {
     host_direct = nullptr;
     if (!direct) HIPCHECK(hipMemcpyAsync(vals, src.p, doubles * 8, hipMemcpyDeviceToHost, s));
     if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[3], s));
-    HIPCHECK(ctx->wait(s));
+    const double token = call_token;
+    call_token = 0.0;
+    if (direct && token != 0.0 && !ctx->timing) HIPCHECK(ctx->wait_token(&vals[4 * nseg + 2], token, s));
+    else HIPCHECK(ctx->wait(s));
     int rc;
     if ((rc = launch_status())) return rc;
     collect_tile_ms();
@@ -1837,7 +1881,7 @@ struct EngineT : Engine {
                      const double* bounds, int depth) override {
     const bool grown = bounds != nullptr;
     if (!have_post) return ctx->fail(GPSO_E_STATE, "no posterior resident: call gpso_fit_eval / gpso_set_posterior first");
-    if (nseg < 1 || (size_t)nseg * 4 + 2 > gpso_ctx::kSlotDoubles) return ctx->fail(GPSO_E_ARG, "nseg must be in [1, 1024] for an asynchronous call");
+    if (nseg < 1 || (size_t)nseg * 4 + 3 > gpso_ctx::kSlotDoubles) return ctx->fail(GPSO_E_ARG, "nseg must be in [1, 1024] for an asynchronous call");
     int rc = grown ? precision_gate() : check_predict_args(xs, xs_dtype, xs_mem, m);
     if (rc) return rc;
     const int k = ctx->slot_next;
@@ -1846,6 +1890,7 @@ struct EngineT : Engine {
     if (ctx->slot_host == nullptr) {
       if (hipHostMalloc(reinterpret_cast<void**>(&ctx->slot_host), gpso_ctx::kSlots * gpso_ctx::kSlotDoubles * 8, hipHostMallocDefault) != hipSuccess)
         return ctx->fail(GPSO_E_OOM, "pinned result slots");
+      std::memset(ctx->slot_host, 0, gpso_ctx::kSlots * gpso_ctx::kSlotDoubles * 8);
       for (auto& ev : ctx->slot_ev) HIPCHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
     const bool timing_was = ctx->timing;
@@ -1862,6 +1907,8 @@ struct EngineT : Engine {
     one_refused = false;
     result_slot = nullptr;
     host_direct = nullptr;
+    ctx->slot_token[k] = call_token;
+    call_token = 0.0;
     ctx->timing = timing_was;
     if (rc) return rc;
     if (xs_mem == GPSO_MEM_HOST && !grown && m > 0) HIPCHECK(hipStreamSynchronize(st()));  // (the caller's host leaves are free again on return)
@@ -1876,8 +1923,13 @@ struct EngineT : Engine {
       return ctx->fail(GPSO_E_ARG, "ticket %d names no asynchronous call in flight", ticket);
     const int nseg = ctx->slot_nseg[ticket];
     ctx->slot_nseg[ticket] = 0;
-    // spin on the call's own event (the thread is blocked here anyway), then block
+    const double* vals = ctx->slot_host + (size_t)ticket * gpso_ctx::kSlotDoubles;
+    // the call's completion token where its last kernel writes one, else its own event: spin (the thread is blocked here
+    // anyway), then block
     const auto t0 = std::chrono::steady_clock::now();
+    if (ctx->slot_token[ticket] != 0.0) {
+      HIPCHECK(ctx->wait_token(&vals[4 * nseg + 2], ctx->slot_token[ticket], st()));
+    } else
     for (int it = 0;; ++it) {
       const hipError_t e = hipEventQuery(ctx->slot_ev[ticket]);
       if (e == hipSuccess) break;
@@ -1889,7 +1941,6 @@ struct EngineT : Engine {
     }
     int rc;
     if ((rc = launch_status())) return rc;
-    const double* vals = ctx->slot_host + (size_t)ticket * gpso_ctx::kSlotDoubles;
     for (int i = 0; i < nseg; ++i) {
       if (idx) std::memcpy(&idx[i], &vals[4 * i + 3], 8);
       if (mean) mean[i] = vals[4 * i];
@@ -2045,6 +2096,7 @@ struct EngineT : Engine {
   int payload_out(int nseg, int local, double* payload) {
     one_pending = false;
     host_direct = nullptr;
+    call_token = 0.0;
     const std::string local_msg = ctx->err;
     int rc = publish_local(nseg, local);
     if (rc) return rc;
@@ -2078,7 +2130,7 @@ struct EngineT : Engine {
     HIPCHECK(hipMemcpyAsync(gath.p, gathered, (size_t)world * pd * 8, hipMemcpyHostToDevice, s));
     host_direct = result_host((size_t)nseg * 4 + 2);
     launch_reduce_winners(s, as<double>(gath), with_base ? as<int64_t>(wbase) : nullptr, world, nseg, pd,
-                          as<double>(ovals2), host_direct);
+                          as<double>(ovals2), host_direct, arm_token(nseg <= 64, nseg));
     if ((rc = launch_status())) return rc;
     int64_t who = -1;
     int verdict = GPSO_OK;

@@ -2936,6 +2936,10 @@ __global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs g) {
       g.scal_host[0] = nl;
       *reinterpret_cast<int*>(g.scal_host + 1) = atomicMin(info, INT_MAX);  // (the factorisation's verdict, as the device holds it)
       if (g.want_grad) g.scal_host[8 + g.n_ls + 2] = gc;
+      if (!g.want_grad && g.done_token != 0.0) {  // (the last host store of an evaluation without gradient: this thread's)
+        __threadfence_system();
+        *reinterpret_cast<volatile double*>(g.scal_host + 7) = g.done_token;
+      }
     }
   }
   GPSO_SSTAMP(10);
@@ -3030,6 +3034,11 @@ __global__ __launch_bounds__(256) void small_fit_kernel(SmallFitArgs g) {
     if (tid < g.n_ls) v /= g.ls[g.n_ls == 1 ? 0 : tid];
     g.scal[8 + tid] = v;
     if (g.scal_host != nullptr) g.scal_host[8 + tid] = v;
+  }
+  if (g.scal_host != nullptr && g.done_token != 0.0) {  // every writer releases at system scope, then the token
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) *reinterpret_cast<volatile double*>(g.scal_host + 7) = g.done_token;
   }
   GPSO_SSTAMP(11);
 }

@@ -122,13 +122,14 @@ void launch_seg_argmax(hipStream_t st, const double* mean, const double* var, co
                        const int64_t* seg_off_dev, int nseg, int nblk, void* partial_dev,
                        double* out_vals_dev /* [nseg*4 + 2]: per segment mean, var, ucb, bit-cast int64 index; spare; 0.0 (status slot) */,
                        const LeafFinalize* fin = nullptr /* the leaves are still partial sums: finalise them in stage 1 */,
-                       double* host_vals = nullptr /* pinned host copy of out_vals, written by the kernel itself */);
+                       double* host_vals = nullptr /* pinned host copy of out_vals, written by the kernel itself */,
+                       double done_token = 0.0 /* nseg == 1 only: host_vals[nseg * 4 + 2] := token behind the records */);
 // arg-max over a de-duplicated, keyed leaf list (grow.hip: launch_grow_unique); out_vals_dev[nseg*4 + 2]:
 // per segment mean, var, ucb, bit-cast reference row index; then the bit-cast live row count; then 0.0 (status slot)
 void launch_keyed_argmax(hipStream_t st, const double* mean, const double* var, const double* ucb,
                          const int64_t* key_dev, int64_t rows, int64_t uniq, int nseg, const int64_t* live_dev,
                          int nblk, void* partial_dev, int64_t* pos_dev, double* out_vals_dev,
-                         const LeafFinalize* fin = nullptr, double* host_vals = nullptr);
+                         const LeafFinalize* fin = nullptr, double* host_vals = nullptr, double done_token = 0.0);
 // out_dev[c] = number of live leaves inside chunk c of a batch whose total live count is *live_dev
 void launch_chunk_live(hipStream_t st, const int64_t* live_dev, int64_t chunk, int nchunk, int64_t* out_dev);
 // *acc += sum_i mix(words[i], i, salt)  (64-bit wrap-around sum of a per-word mix: order-independent, so the parallel
@@ -256,6 +257,7 @@ struct SmallFitArgs {
   double* scal;    // [0] nlml, [1] info (int), [8 ..] gradient (ls..., variance, noise, c)
   double* scal_host;  // nullable: pinned host memory (device-visible) that receives the same scalars straight from the
                       // kernel -- the evaluation then needs no device-to-host copy operation behind it either
+  double done_token;  // != 0: scal_host[7] := token behind the scalars (system-scope release; the host spins on it)
 };
 
 bool small_fit_eligible(int64_t n, int dp);
@@ -347,6 +349,8 @@ struct SmallBest {
   int nseg = 0;
   double* out_vals = nullptr;         // [nseg * 4 + 2]
   double* host_vals = nullptr;        // nullable pinned host copy
+  double done_token = 0.0;            // != 0: written to host_vals[nseg * 4 + 2] behind the records (system-scope release):
+                                      // the host spins on it instead of polling an event (round 5)
 };
 // ... and, where ONE row block covers L^-1 (N_pad = 128 or 256) and the native tile kernel runs, the whole call in ONE
 // launch (predict.hip: leaf_tiles_v2_one_kernel): rows made in the prologue, leaves finalised and reduced in the epilogue,
@@ -370,6 +374,7 @@ struct OneLaunch {
   unsigned* fallback = nullptr;      // raised when a centre child does not repeat its parent; zero between calls
   double* out_vals = nullptr;        // [nseg * 4 + 2]: records, live rows (bit-cast), status (1.0 = fallback wanted)
   double* host_vals = nullptr;       // nullable pinned host copy
+  double done_token = 0.0;           // as SmallBest::done_token
 };
 template <typename T, typename TG>
 int launch_leaf_tiles_one(hipStream_t st, const T* linv_p, const TG* xs_p, const TG* xnorm, const T* alpha,
@@ -382,7 +387,8 @@ void launch_small_best(hipStream_t st, const SmallBest& a, bool keyed);
 // kGroupPayload(nseg)]; base[world][nseg] (nullable) is added to a rank's indices first; out[nseg][4] [, bit-cast rank
 // of the worst status, worst status]
 void launch_reduce_winners(hipStream_t st, const double* gathered, const int64_t* base, int world, int nseg,
-                           int stride, double* out, double* host_out = nullptr /* pinned host copy of out, written by the kernel */);
+                           int stride, double* out, double* host_out = nullptr /* pinned host copy of out, written by the kernel */,
+                           double done_token = 0.0 /* nseg <= 64 (one workgroup): host_out[nseg * 4 + 2] := token behind the records */);
 // doubles of one rank's group payload: the winners, the live row count of a growth call (bit-cast), the status
 inline int group_payload_doubles(int nseg) { return nseg * 4 + 2; }
 

@@ -25,6 +25,16 @@
 namespace gpso {
 
 
+// Completion token (round 5): the LAST kernel of a call, where it is a single workgroup, writes a sequence number behind its
+// records in pinned host memory; the host spins on that word instead of recording and polling an event (a few microseconds
+// of every call; what a 50 us call of the optimiser's regime notices).  The caller has made every record store of the
+// workgroup happen-before this one (one writer thread, or a system-scope fence per writer + a workgroup barrier).
+__device__ __forceinline__ void publish_done(double* host_vals, int slot, double token) {
+  if (host_vals == nullptr || token == 0.0) return;
+  __threadfence_system();
+  *reinterpret_cast<volatile double*>(host_vals + slot) = token;
+}
+
 // np.argmax semantics: first maximum wins; NaN counts as the maximum (first NaN wins)
 struct Best {
   double u;
@@ -435,6 +445,7 @@ __device__ __forceinline__ void one_launch_epilogue(const OneLaunch& o, int tid,
       o.host_vals[o.nseg * 4 + 1] = status;
     }
     *o.ticket = 0u;
+    publish_done(o.host_vals, o.nseg * 4 + 2, o.done_token);  // (thread 0 wrote every host record itself)
   }
 }
 
@@ -951,7 +962,8 @@ __global__ __launch_bounds__(256) void seg_argmax_stage2(const Best* __restrict_
                                                          const double* __restrict__ ucb, int nseg,
                                                          double* __restrict__ out_vals /*[nseg*4 + 2]*/,
                                                          double* __restrict__ host_vals /* nullable: the same records
-                                                         straight into pinned host memory (no copy operation behind) */) {
+                                                         straight into pinned host memory (no copy operation behind) */,
+                                                         double done_token) {
   __shared__ Best sh[4];
   const int seg = blockIdx.x;
   if (seg >= nseg) return;
@@ -978,6 +990,7 @@ __global__ __launch_bounds__(256) void seg_argmax_stage2(const Best* __restrict_
 #pragma unroll
       for (int k = 0; k < 4; ++k) host_vals[seg * 4 + k] = out_vals[seg * 4 + k];
       if (seg == 0) host_vals[nseg * 4 + 1] = 0.0;
+      if (nseg == 1) publish_done(host_vals, nseg * 4 + 2, done_token);  // (one workgroup, one writer)
     }
   }
 }
@@ -1055,7 +1068,8 @@ __global__ __launch_bounds__(256) void keyed_argmax_stage2(const Best* __restric
                                                            const double* __restrict__ ucb,
                                                            const int64_t* __restrict__ live, int nseg,
                                                            double* __restrict__ out_vals /*[nseg*4 + 2]*/,
-                                                           double* __restrict__ host_vals /* nullable, see seg_argmax_stage2 */) {
+                                                           double* __restrict__ host_vals /* nullable, see seg_argmax_stage2 */,
+                                                           double done_token) {
   __shared__ Best sh[4];
   const int seg = blockIdx.x;
   Best mine{0.0, -1};
@@ -1088,6 +1102,7 @@ __global__ __launch_bounds__(256) void keyed_argmax_stage2(const Best* __restric
         host_vals[nseg * 4] = out_vals[nseg * 4];
         host_vals[nseg * 4 + 1] = 0.0;
       }
+      if (nseg == 1) publish_done(host_vals, nseg * 4 + 2, done_token);
     }
   }
 }
@@ -1174,6 +1189,7 @@ __global__ __launch_bounds__(256) void small_best_kernel(SmallBest a) {
       a.host_vals[a.nseg * 4 + 1] = 0.0;
     }
     if (KEYED) *a.extra = 0ull;  // (zero between calls: the next growth appends from its own base)
+    publish_done(a.host_vals, a.nseg * 4 + 2, a.done_token);  // (thread 0 wrote every host record itself)
   }
 }
 
@@ -1189,7 +1205,8 @@ void launch_small_best(hipStream_t st, const SmallBest& a, bool keyed) {
 // same verdict and none is left inside a collective by a peer that failed locally.
 __global__ void reduce_winners_kernel(const double* __restrict__ gathered, const int64_t* __restrict__ base,
                                       int world, int nseg, int stride, double* __restrict__ out,
-                                      double* __restrict__ host_out /* nullable: the same records into pinned host memory */) {
+                                      double* __restrict__ host_out /* nullable: the same records into pinned host memory */,
+                                      double done_token) {
   const int seg = blockIdx.x * blockDim.x + threadIdx.x;
   if (seg == 0 && stride >= nseg * 4 + 2) {
     double worst = 0.0;
@@ -1211,7 +1228,7 @@ __global__ void reduce_winners_kernel(const double* __restrict__ gathered, const
       host_out[nseg * 4 + 1] = worst;
     }
   }
-  if (seg >= nseg) return;
+  if (seg < nseg) {
   Best best{0.0, -1};
   int from = -1;
   for (int r = 0; r < world; ++r) {
@@ -1238,6 +1255,12 @@ __global__ void reduce_winners_kernel(const double* __restrict__ gathered, const
   if (host_out != nullptr) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) host_out[(int64_t)seg * 4 + k] = o[k];
+  }
+  }
+  if (host_out != nullptr && done_token != 0.0 && gridDim.x == 1) {  // one workgroup: every writer releases, then the token
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) publish_done(host_out, nseg * 4 + 2, done_token);
   }
 }
 
@@ -1389,7 +1412,7 @@ void launch_leaf_finalize(hipStream_t st, const double* part_var, const double* 
 
 void launch_seg_argmax(hipStream_t st, const double* mean, const double* var, const double* ucb,
                        const int64_t* seg_off_dev, int nseg, int nblk, void* partial_dev,
-                       double* out_vals_dev, const LeafFinalize* fin, double* host_vals) {
+                       double* out_vals_dev, const LeafFinalize* fin, double* host_vals, double done_token) {
   if (fin != nullptr)
     hipLaunchKernelGGL(seg_argmax_stage1<true>, dim3((unsigned)nblk, (unsigned)nseg), dim3(256), 0, st, ucb,
                        seg_off_dev, reinterpret_cast<Best*>(partial_dev), *fin);
@@ -1398,13 +1421,13 @@ void launch_seg_argmax(hipStream_t st, const double* mean, const double* var, co
                        seg_off_dev, reinterpret_cast<Best*>(partial_dev), LeafFinalize{});
   hipLaunchKernelGGL(seg_argmax_stage2, dim3((unsigned)nseg), dim3(256), 0, st,
                      reinterpret_cast<const Best*>(partial_dev), nblk, seg_off_dev, mean, var, ucb, nseg,
-                     out_vals_dev, host_vals);
+                     out_vals_dev, host_vals, done_token);
 }
 
 void launch_keyed_argmax(hipStream_t st, const double* mean, const double* var, const double* ucb,
                          const int64_t* key_dev, int64_t rows, int64_t uniq, int nseg, const int64_t* live_dev,
                          int nblk, void* partial_dev, int64_t* pos_dev, double* out_vals_dev, const LeafFinalize* fin,
-                         double* host_vals) {
+                         double* host_vals, double done_token) {
   if (fin != nullptr)
     hipLaunchKernelGGL(keyed_argmax_stage1<true>, dim3((unsigned)nblk, (unsigned)nseg), dim3(256), 0, st, ucb, key_dev,
                        rows, uniq, nseg, live_dev, reinterpret_cast<Best*>(partial_dev), pos_dev, *fin);
@@ -1413,13 +1436,13 @@ void launch_keyed_argmax(hipStream_t st, const double* mean, const double* var, 
                        rows, uniq, nseg, live_dev, reinterpret_cast<Best*>(partial_dev), pos_dev, LeafFinalize{});
   hipLaunchKernelGGL(keyed_argmax_stage2, dim3((unsigned)nseg), dim3(256), 0, st,
                      reinterpret_cast<const Best*>(partial_dev), pos_dev, nblk, rows, mean, var, ucb, live_dev,
-                     nseg, out_vals_dev, host_vals);
+                     nseg, out_vals_dev, host_vals, done_token);
 }
 
 void launch_reduce_winners(hipStream_t st, const double* gathered, const int64_t* base, int world, int nseg,
-                           int stride, double* out, double* host_out) {
+                           int stride, double* out, double* host_out, double done_token) {
   hipLaunchKernelGGL(reduce_winners_kernel, dim3((unsigned)((nseg + 63) / 64)), dim3(64), 0, st, gathered, base,
-                     world, nseg, stride, out, host_out);
+                     world, nseg, stride, out, host_out, done_token);
 }
 
 // splitmix64-style finaliser of (word, position, salt); summed with wrap-around
