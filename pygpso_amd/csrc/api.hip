@@ -202,7 +202,9 @@ struct gpso_ctx {
       pinned = nullptr;
       pinned_doubles = 0;
       const size_t want = std::max<size_t>(doubles, 256);
-      if (hipHostMalloc(reinterpret_cast<void**>(&pinned), want * 8, hipHostMallocDefault) != hipSuccess) return nullptr;
+      // (fine-grained -- hipHostMallocCoherent --: kernels write their records and the completion token here WHILE they run,
+      // and the host reads them behind a system-scope release; coarse-grained host memory is only coherent at kernel boundaries)
+      if (hipHostMalloc(reinterpret_cast<void**>(&pinned), want * 8, hipHostMallocCoherent) != hipSuccess) return nullptr;
       std::memset(pinned, 0, want * 8);  // (no stale completion token)
       pinned_doubles = want;
     }
@@ -1888,7 +1890,7 @@ struct EngineT : Engine {
     if (ctx->slot_nseg[k] > 0)
       return ctx->fail(GPSO_E_STATE, "two asynchronous best-UCB calls are already in flight: end one (gpso_best_ucb_end) first");
     if (ctx->slot_host == nullptr) {
-      if (hipHostMalloc(reinterpret_cast<void**>(&ctx->slot_host), gpso_ctx::kSlots * gpso_ctx::kSlotDoubles * 8, hipHostMallocDefault) != hipSuccess)
+      if (hipHostMalloc(reinterpret_cast<void**>(&ctx->slot_host), gpso_ctx::kSlots * gpso_ctx::kSlotDoubles * 8, hipHostMallocCoherent) != hipSuccess)
         return ctx->fail(GPSO_E_OOM, "pinned result slots");
       std::memset(ctx->slot_host, 0, gpso_ctx::kSlots * gpso_ctx::kSlotDoubles * 8);
       for (auto& ev : ctx->slot_ev) HIPCHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
