@@ -19,6 +19,11 @@ Order of a run: fit (timed by the library's events: ``fit_ms``) -> [broadcast] -
 with 20 / 5 steps the kernel otherwise runs at start-up clocks: 0.93 ms against 0.86) -> W untimed warm-up steps ->
 barrier + synchronize -> EXACTLY K timed steps -> synchronize + barrier -> CPU baseline and accuracy report (untimed).
 
+Beside the contract's fields the line carries (round 5) ``ms_per_step_pipelined`` / ``value_pipelined`` (the same K steps with two
+calls in flight through gpso_best_ucb_begin / _end; the headline ``value`` keeps the synchronous protocol), ``fit_ms`` =
+{posterior, nlml_grad, append_k7 (gpso_append of 7 points), hyperopt (one warm-started L-BFGS-B fit: wall / device ms,
+evaluations)} with ``roofline_fit``, and for N > 1 ``allgather_us`` (the winners' all-gather + fold per step on rank 0).
+
 Rank 0 prints ONE JSON line.  ``roofline`` is for the dominant kernel (leaf_tiles_kernel):
 achieved = algorithmic FLOPs per launch (N^2 + 2ND + 20N per leaf) / its average
 duration measured with HIP events on the library's stream inside the timed region.

@@ -416,6 +416,7 @@ class GPRSurrogate(GPSurrogate):
             "gp_likelihood": self.gp_lik_sigma,
             "optimiser": [type(self.optimiser).__name__],
             "dtype": self.dtype,
+            "refit_every": self.refit_every,  # (not in the reference's schema: an extra key; 1 = the reference's behaviour)
         }
         with open(os.path.join(folder, self.GPR_INFO), "w") as fh:
             fh.write(json.dumps(info))
@@ -442,4 +443,4 @@ class GPRSurrogate(GPSurrogate):
         return cls(gp_kernel=kernel, gp_meanf=meanf, optimiser=Scipy(),
                    gauss_likelihood_sigma=info["gp_likelihood"], varsigma=info["gp_varsigma"],
                    points=points, gpflow_model=model, dtype=info.get("dtype", "float64"), device=device,
-                   devices=devices)
+                   devices=devices, refit_every=info.get("refit_every", 1))
