@@ -67,6 +67,7 @@ class HipGPEngine:
         self.d = 0
         self.rank, self.world = 0, 1
         self._u_bufs = {}
+        self._win_bufs = {}
         if predict_math is not None and not (predict_math in ("native", "f32") and self.dtype == L.F64):
             self.set_predict_math(predict_math)
         if generation is not None:
@@ -250,6 +251,18 @@ class HipGPEngine:
         self.n, self.d = n, d
 
     # -- predict -----------------------------------------------------------------------------
+    def _winner_bufs(self, nseg):
+        """Output arrays of a best-UCB call and their ctypes pointers, made once per segment count: these calls are the
+        optimiser's inner loop (the arrays are copied out, so callers may keep what they get)."""
+        bufs = self._win_bufs.get(nseg)
+        if bufs is None:
+            idx = np.empty(nseg, dtype=np.int64)
+            mean = np.empty(nseg, dtype=np.float64)
+            var = np.empty(nseg, dtype=np.float64)
+            ucb = np.empty(nseg, dtype=np.float64)
+            bufs = self._win_bufs[nseg] = (idx, mean, var, ucb, L.i64ptr(idx), L.dptr(mean), L.dptr(var), L.dptr(ucb))
+        return bufs
+
     def _leaf_args(self, xs):
         """-> (pointer, xs_dtype, xs_mem, M, keepalive)"""
         if _is_device_tensor(xs):
@@ -312,13 +325,11 @@ class HipGPEngine:
         else:
             so = np.ascontiguousarray(seg_off, dtype=np.int64)
             nseg, so_ptr = int(so.shape[0] - 1), L.i64ptr(so)
-        idx = np.empty(nseg, dtype=np.int64)
-        mean = np.empty(nseg, dtype=np.float64)
-        var = np.empty(nseg, dtype=np.float64)
-        ucb = np.empty(nseg, dtype=np.float64)
-        self._check(self._lib.gpso_best_ucb(self._h, ptr, dt, mem, m, so_ptr, nseg, float(varsigma),
-                                            L.i64ptr(idx), L.dptr(mean), L.dptr(var), L.dptr(ucb)))
-        return idx, mean, var, ucb
+        idx, mean, var, ucb, pi, pm, pv, pu = self._winner_bufs(nseg)
+        rc = self._lib.gpso_best_ucb(self._h, ptr, dt, mem, m, so_ptr, nseg, float(varsigma), pi, pm, pv, pu)
+        if rc < 0:
+            self._check(rc)
+        return idx.copy(), mean.copy(), var.copy(), ucb.copy()
 
     def best_ucb_begin(self, xs, varsigma, seg_off=None):
         """Non-blocking ``best_ucb``: enqueues the call and returns a ticket for ``best_ucb_end``; two calls may be in
@@ -380,13 +391,11 @@ class HipGPEngine:
         nseg, d, _ = b.shape
         if d != self.d:
             raise ValueError(f"bounds have D={d}, model has D={self.d}")
-        idx = np.empty(nseg, dtype=np.int64)
-        mean = np.empty(nseg, dtype=np.float64)
-        var = np.empty(nseg, dtype=np.float64)
-        ucb = np.empty(nseg, dtype=np.float64)
-        self._check(self._lib.gpso_best_ucb_grow(self._h, L.dptr(b), nseg, int(depth), float(varsigma),
-                                                 L.i64ptr(idx), L.dptr(mean), L.dptr(var), L.dptr(ucb)))
-        return idx, mean, var, ucb
+        idx, mean, var, ucb, pi, pm, pv, pu = self._winner_bufs(nseg)
+        rc = self._lib.gpso_best_ucb_grow(self._h, L.dptr(b), nseg, int(depth), float(varsigma), pi, pm, pv, pu)
+        if rc < 0:
+            self._check(rc)
+        return idx.copy(), mean.copy(), var.copy(), ucb.copy()
 
     # -- multi-GPU group (RCCL behind the C-ABI; see pygpso_amd/distributed.py) ------------------
     def comm_init(self, rank, world, unique_id):
