@@ -213,8 +213,12 @@ struct gpso_ctx {
   // Completion tokens (round 5): where the last kernel of a call is a single workgroup it writes a sequence number behind
   // its records in pinned host memory and the host spins on THAT word -- no event to record, no driver call per poll.  A
   // token that does not arrive within kSpinMs falls back to a blocking wait (where a failed launch surfaces as before).
-  uint64_t seq = 0;
-  double next_token() { return (double)(++seq); }  // (exact in a double for 2^53 calls)
+  // (process-wide: a pinned buffer handed on by a destroyed context -- ContextPool -- never holds a number a later call waits for)
+  static std::atomic<uint64_t>& seq_counter() {
+    static std::atomic<uint64_t> c{0};
+    return c;
+  }
+  double next_token() { return (double)(seq_counter().fetch_add(1) + 1); }  // (exact in a double for 2^53 calls)
   hipError_t wait_token(const double* word, double token, hipStream_t s) {
     constexpr double kSpinMs = 20.0;
     const volatile double* w = word;
@@ -254,6 +258,41 @@ struct gpso_ctx {
     va_end(ap);
     err = buf;
     return code;
+  }
+};
+
+// Host-side resources of a context -- its stream, its events, its pinned buffers -- cost ~2 ms to create and ~1 ms to
+// destroy (tools/context_cost.py), a sixth of a whole 50-evaluation GPSO run whose surrogate lives for 32 ms.  gpso_destroy
+// hands them to a small per-device pool and gpso_create takes them from there (at most kKeep sets per device are kept; they
+// are released at process exit by the runtime).  Device memory is not pooled.
+struct ContextPool {
+  struct Set {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_wait = nullptr, ev[8] = {};
+    double *pinned = nullptr, *stage = nullptr;
+    size_t pinned_doubles = 0, stage_doubles = 0;
+  };
+  static constexpr int kKeep = 4, kDevices = 64;
+  std::mutex mu;
+  std::vector<Set> free_sets[kDevices];
+  static ContextPool& get() {
+    static ContextPool* p = new ContextPool();  // (never destroyed: no HIP calls from a static destructor)
+    return *p;
+  }
+  bool take(int device, Set& out) {
+    if (device < 0 || device >= kDevices) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    if (free_sets[device].empty()) return false;
+    out = free_sets[device].back();
+    free_sets[device].pop_back();
+    return true;
+  }
+  bool give(int device, const Set& s) {
+    if (device < 0 || device >= kDevices) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    if ((int)free_sets[device].size() >= kKeep) return false;
+    free_sets[device].push_back(s);
+    return true;
   }
 };
 
@@ -2473,6 +2512,18 @@ int gpso_create(gpso_ctx** out, int device, int dtype) {
   gpso_ctx* ctx = new gpso_ctx();
   ctx->device = device;
   ctx->dtype = dtype;
+  ContextPool::Set pooled;
+  if (ContextPool::get().take(device, pooled)) {  // a destroyed context's stream, events and pinned buffers
+    ctx->own_stream = pooled.stream;
+    ctx->ev_wait = pooled.ev_wait;
+    for (int i = 0; i < 8; ++i) ctx->ev[i] = pooled.ev[i];
+    ctx->pinned = pooled.pinned;
+    ctx->pinned_doubles = pooled.pinned_doubles;
+    ctx->stage = pooled.stage;
+    ctx->stage_doubles = pooled.stage_doubles;
+    if (ctx->pinned) std::memset(ctx->pinned, 0, ctx->pinned_doubles * 8);
+    ctx->stream = ctx->own_stream;
+  } else {
   if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) {
     g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
     delete ctx;
@@ -2490,6 +2541,7 @@ int gpso_create(gpso_ctx** out, int device, int dtype) {
       gpso_destroy(ctx);
       return GPSO_E_HIP;
     }
+  }
   if (dtype == GPSO_F64)
     ctx->eng = new EngineT<double, double>(ctx);
   else if (dtype == GPSO_F32)
@@ -2506,20 +2558,36 @@ void gpso_destroy(gpso_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->comm && !ctx->comm_aborted) (void)RcclApi::get().CommDestroy(ctx->comm);
   delete ctx->eng;
-  for (auto& ev : ctx->ev)
-    if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : ctx->tile_ev) (void)hipEventDestroy(ev);
-  if (ctx->ev_wait) (void)hipEventDestroy(ctx->ev_wait);
   if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
   if (ctx->ev_col) (void)hipEventDestroy(ctx->ev_col);
   if (ctx->ev_chain) (void)hipEventDestroy(ctx->ev_chain);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
-  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-  if (ctx->stage) (void)hipHostFree(ctx->stage);
   if (ctx->slot_host) (void)hipHostFree(ctx->slot_host);
   for (auto& ev : ctx->slot_ev)
     if (ev) (void)hipEventDestroy(ev);
-  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  // stream, events and pinned buffers go to the pool when they are complete and the pool has room (ContextPool)
+  bool complete = ctx->own_stream != nullptr && ctx->ev_wait != nullptr;
+  for (auto& ev : ctx->ev) complete = complete && ev != nullptr;
+  ContextPool::Set give;
+  if (complete) {
+    (void)hipStreamSynchronize(ctx->own_stream);
+    give.stream = ctx->own_stream;
+    give.ev_wait = ctx->ev_wait;
+    for (int i = 0; i < 8; ++i) give.ev[i] = ctx->ev[i];
+    give.pinned = ctx->pinned;
+    give.pinned_doubles = ctx->pinned_doubles;
+    give.stage = ctx->stage;
+    give.stage_doubles = ctx->stage_doubles;
+  }
+  if (!complete || !ContextPool::get().give(ctx->device, give)) {
+    for (auto& ev : ctx->ev)
+      if (ev) (void)hipEventDestroy(ev);
+    if (ctx->ev_wait) (void)hipEventDestroy(ctx->ev_wait);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->stage) (void)hipHostFree(ctx->stage);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  }
   delete ctx;
 }
 
