@@ -2,7 +2,8 @@
 """
 Headline benchmark: leaf-UCB predictions/s (+ GP-fit ms) on synthetic {N_train, D, N_leaves}.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c5] [--dtype float32|mixed|float64]
+                    [--seed 0..4] [--leaves batch|grow --depth d]
 
 A "step" = one pass of the hot path over one leaf batch: ``gpso_best_ucb`` (prep -> leaf-tile MFMA
 kernel -> finalize -> arg-max) on leaves ALREADY RESIDENT in HBM, posterior resident.  N = 1 runs
@@ -76,14 +77,21 @@ PEAK_TFLOPS = {"float32": 157.3, "float64": 78.6}  # dense MFMA peaks, MI355X_MI
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak; a split product costs 6 (bf16x6) or 3 (f16x3, bf16x3) MFMAs
 # HBM bytes per launch of the dominant kernel come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
 # cannot be read from inside the process); the committed record of the latest collection:
-PMC_TRAFFIC = {("c3", "native"): "profiles/r02f_pmc_leaf_tiles_c3.json",
-               ("c3", "bf16x6"): "profiles/r02h_pmc_leaf_tiles_bf16x6_c3.json",
-               ("c3", "f16x3"): "profiles/r04_pmc_leaf_tiles_f16x3_c3.json"}
+# (the newest record that exists wins: the current round's collection first)
+PMC_TRAFFIC = {("c3", "native"): ["profiles/r02f_pmc_leaf_tiles_c3.json"],
+               ("c3", "bf16x6"): ["profiles/r02h_pmc_leaf_tiles_bf16x6_c3.json"],
+               ("c3", "f16x3"): ["profiles/r06_pmc_leaf_tiles_f16x3_c3.json", "profiles/r05_pmc_leaf_tiles_f16x3_c3.json"]}
+# what a fit's achieved FLOP rate is priced against: the dense MFMA peak of the arithmetic its LARGE PRODUCTS ran on
+# (gpso_last_count(ctx, 2)); a split product costs 6 (bf16 pieces) or 3 (fp16 pieces) 16-bit MFMAs
+FIT_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6, "small": 78.6, "bf16x6": PEAK_BF16_TFLOPS / 6, "f16x3": PEAK_BF16_TFLOPS / 3}
 
 
 def pmc_traffic(workload, math_mode):
-    path = os.path.join(ROOT, PMC_TRAFFIC.get((workload, math_mode), ""))
-    if not os.path.isfile(path):
+    for rel in PMC_TRAFFIC.get((workload, math_mode), []):
+        path = os.path.join(ROOT, rel)
+        if os.path.isfile(path):
+            break
+    else:
         return None, None
     with open(path) as fh:
         rec = json.load(fh)
@@ -172,34 +180,34 @@ def cpu_baseline(X, y, theta, leaves, varsigma, budget_s=12.0):
     }, post
 
 
-def roofline_fit(n, d, dtype, fit_ms):
-    """GP-fit half of the metric against the MFMA peak of the fit's arithmetic type.  Algorithmic FLOPs
-    (SURVEY.md 8d): posterior fit N^3/3 + N^2 D + 10 N^2; one NLML + gradient evaluation adds 2 N^3 / 3
-    (K^-1 from L) + 2 H N^2 (H = 4 hyper-parameters).  Times are the library's HIP-event medians
-    (gpso_last_ms(ctx, 2)) of 5 evaluations each."""
+def roofline_fit(n, d, dtype, fit_ms, fit_math):
+    """GP-fit half of the metric against the MFMA peak of THE ARITHMETIC THAT RAN (``fit_math`` = HipGPEngine.fit_math() of
+    the timed evaluations: single-level float fit -> f32 157.3; float64 / mixed -> f64 78.6; two-level float fit on fp16
+    pieces -> 2500 / 3 = 833.3, on bf16 pieces -> 2500 / 6 = 416.7 TFLOP/s f32-equivalent).  Algorithmic FLOPs (SURVEY.md
+    8d): posterior fit N^3/3 + N^2 D + 10 N^2; one NLML + gradient evaluation adds 2 N^3 / 3 (K^-1 from L) + 2 H N^2 (H = 4
+    hyper-parameters).  Times are the library's HIP-event medians (gpso_last_ms(ctx, 2)) of 5 evaluations each."""
     if not fit_ms:
         return None
-    peak = PEAK_TFLOPS[dtype]
+    fit_math = fit_math or ("f64" if dtype != "float32" else "f32")
+    peak = FIT_PEAK_TFLOPS[fit_math]
     f_post = n ** 3 / 3 + n * n * d + 10 * n * n
     f_grad = f_post + 2 * n ** 3 / 3 + 2 * 4 * n * n
-    n_pad = -(-n // 128) * 128
-    single = n_pad <= (3584 if dtype == "float32" else 2560)
-    out = {"bound": "mfma", "peak": peak, "unit": "TFLOP/s",
-           "dominant_kernel": ("small_fit_kernel (one launch)" if n <= 128 else
-                               "potrf_step_kernel (one launch per 64 columns: diagonal-block chain + trailing update)"
-                               if single else
-                               "gemm_bf16_kernel (split-bf16 rank-1024 updates / level-doubling inverse / K^-1) + potrf_step_kernel "
-                               "chain of the diagonal blocks, looked ahead on a side stream" if dtype == "float32" else
-                               "gemm128_kernel (SYRK / TRSM / level-doubling inverse) + potrf_step_kernel chain"),
-           "peak_note": ("dense f32 MFMA peak; the large products of a two-level float fit run as 6 bf16 MFMAs per f32 product "
-                         "(bound 2500 / 6 = 417 TFLOP/s f32-equivalent), so frac may approach or pass 1 there"
-                         if dtype == "float32" and not single else "dense MFMA peak of the fit's arithmetic type"),
+    two_level = fit_math in ("f16x3", "bf16x6") or (fit_math == "f64" and -(-n // 128) * 128 > 2560)
+    out = {"bound": "mfma", "peak": peak, "unit": "TFLOP/s", "fit_math": fit_math,
+           "dominant_kernel": ("small_fit_kernel (one launch)" if fit_math == "small" else
+                               "gemm_bf16_kernel (16-bit-piece rank-1024 updates / level-doubling inverse / K^-1) + potrf_step_kernel "
+                               "chain of the diagonal blocks, looked ahead on a side stream" if fit_math in ("f16x3", "bf16x6") else
+                               "gemm128_kernel (SYRK / TRSM / level-doubling inverse) + potrf_step_kernel chain" if two_level else
+                               "potrf_step_kernel (one launch per 64 columns: diagonal-block chain + trailing update)"),
+           "peak_note": {"f32": "dense f32 MFMA peak", "f64": "dense f64 MFMA peak", "small": "dense f64 MFMA peak (a one-launch, latency-bound fit)",
+                         "f16x3": "f32-equivalent FLOPs; every large product is 3 fp16 MFMAs with f32 accumulation: bound = 2500 / 3",
+                         "bf16x6": "f32-equivalent FLOPs; every large product is 6 bf16 MFMAs with f32 accumulation: bound = 2500 / 6"}[fit_math],
            "flops_posterior": f_post, "flops_nlml_grad": f_grad}
     for key, fl in (("posterior", f_post), ("nlml_grad", f_grad)):
         if key in fit_ms:
             ach = fl / (fit_ms[key] * 1e-3) / 1e12
             out[key] = {"ms": fit_ms[key], "achieved": ach, "frac": ach / peak}
-    if fit_ms.get("append_k7") == fit_ms.get("append_k7"):  # (present and not NaN)
+    if fit_ms.get("append_k7") == fit_ms.get("append_k7") and "append_k7" in fit_ms:  # (present and not NaN)
         # gpso_append is HBM-bound: two passes over the lower triangle of L^-1 (N^2 s bytes) + O(N k) vectors
         sz = 4 if dtype == "float32" else 8
         by = (n - 7) ** 2 * sz
@@ -210,31 +218,40 @@ def roofline_fit(n, d, dtype, fit_ms):
     return out
 
 
-def hyperopt_fit(eng, X, y, theta):
+def hyperopt_fit(dtype, device, X, y, theta):
     """What gpso/gp_surrogate.py:500-503 does per GP update: ONE L-BFGS-B maximum-likelihood fit of the hyper-parameters,
     warm-started near the optimum as the reference's re-used model is -- from (l, s2, noise, c) = (1.3 l*, 1.5, 3e-3, 0)
-    -- through the drop-in model class on this engine (hyper-opt wall time with iteration count)."""
+    -- through the drop-in model class on an engine of the workload's dtype that the MODEL owns (hyper-opt wall
+    time with iteration count).  A float32 search that loses positive definiteness reopens the engine as "mixed" (float64
+    fit) and starts over (pygpso_amd/kernels.py: Scipy.minimize): the line then says so -- ``dtype`` = the engine the
+    search finished on, ``escalations``, and the wall time INCLUDES the abandoned float32 evaluations."""
     from pygpso_amd.kernels import Constant, Matern52, Scipy
     from pygpso_amd.model import HipGPR
 
     model = HipGPR(data=(X, y[:, None]), kernel=Matern52(lengthscales=1.3 * theta[1], variance=1.5),
-                   mean_function=Constant(0.0), noise_variance=3.0e-3, engine=eng)
-    eng.set_timing(1)
-    dev_ms = []
+                   mean_function=Constant(0.0), noise_variance=3.0e-3, dtype=dtype, device=device)
+    dev_ms, timed_engine = [], [None]
     inner = model._loss_and_grad
 
     def timed(u):
+        if model.engine is not timed_engine[0]:  # (the first call, and after an escalation)
+            model.engine.set_timing(1)
+            timed_engine[0] = model.engine
         out = inner(u)
-        dev_ms.append(eng.last_ms(2))
+        dev_ms.append(model.engine.last_ms(2))
         return out
 
     model._loss_and_grad = timed
     t0 = time.perf_counter()
     res = Scipy().minimize(model.training_loss, model.trainable_variables)
     wall = (time.perf_counter() - t0) * 1e3
-    return {"wall_ms": wall, "device_ms": float(np.sum(dev_ms)), "evaluations": int(res.nfev), "iterations": int(res.nit),
-            "nlml": float(res.fun), "theta": {k: np.asarray(v).tolist() for k, v in model.parameter_dict().items()},
-            "start": "l = 1.3 x 0.25 sqrt(D), s2 = 1.5, noise 3e-3, c = 0; SciPy L-BFGS-B defaults (as gpflow.optimizers.Scipy)"}
+    out = {"wall_ms": wall, "device_ms": float(np.sum(dev_ms)), "evaluations": int(res.nfev), "iterations": int(res.nit),
+           "evaluations_in_all": int(model.num_loss_evals), "dtype": model.engine.dtype_name, "requested_dtype": dtype,
+           "escalations": int(model.fit_escalations), "fit_math": model.engine.fit_math(),
+           "nlml": float(res.fun), "theta": {k: np.asarray(v).tolist() for k, v in model.parameter_dict().items()},
+           "start": "l = 1.3 x 0.25 sqrt(D), s2 = 1.5, noise 3e-3, c = 0; SciPy L-BFGS-B defaults (as gpflow.optimizers.Scipy)"}
+    model.engine.close()
+    return out
 
 
 def split_bf16_report(eng, leaves_dev, leaves_all, varsigma, m_total, flops_per_leaf, post, steps):
@@ -281,6 +298,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--noise", type=float, default=1.0e-3, help="noise variance of the synthetic posterior")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hyperopt", action="store_true", help="skip fit_ms.hyperopt (one L-BFGS-B fit: seconds at C5 in float64)")
     ap.add_argument("--timing-every", type=int, default=4,
                     help="the leaf-tile kernel is timed with HIP events on every k-th timed step (1 = every step)")
     ap.add_argument("--settle-s", type=float, default=0.3,
@@ -289,6 +307,17 @@ def main():
                     help="--gpus N > 1: how the peers get the posterior the timed steps use -- ONE ncclBroadcast of the "
                          "fitting rank's predict-ready range, or the same deterministic fit on every rank (fingerprints "
                          "compared).  Both are timed and reported whichever is chosen (SURVEY 8e: measure both)")
+    ap.add_argument("--dtype", default=None, choices=["float32", "mixed", "float64"],
+                    help="arithmetic of the engine (default: the workload's).  float64 is the reference's own (gpflow.default_float, "
+                         "gpso/gp_surrogate.py:490-495) and the drop-in surrogate's default; mixed = float64 fit + float predict")
+    ap.add_argument("--seed", type=int, default=0, choices=[0, 1, 2, 3, 4],
+                    help="seed of the synthetic problem (SURVEY 8d: seeds 0..4; leaves use seed + 1); stated in the line")
+    ap.add_argument("--leaves", default="batch", choices=["batch", "grow"],
+                    help="batch: SURVEY 8(d) family B -- the first M rows of a seeded U[0,1]^(M x D), resident in HBM.  grow: family A "
+                         "-- the call the optimiser really makes (gpso/optimisation.py:366-382 on gpso/param_space.py:175-200): "
+                         "LeafNode.grow(--depth) of the two outer children of a box at tree depth 3, generated ON the device by "
+                         "gpso_best_ucb_grow; value counts the REFERENCE's rows, value_distinct_rows the rows actually scored")
+    ap.add_argument("--depth", type=int, default=11, help="--leaves grow: depth of the grown sub-trees (8, 11, 12: (3^d - 1) / 2 rows per box)")
     ap.add_argument("--math", default="auto", choices=["auto", "native", "bf16x3", "bf16x6", "f16x3"],
                     help="predict math of float32 workloads (auto = the library default: the first rung of the ladder "
                          "f16x3 -> bf16x6 -> native f32 the posterior's self-test passes with)")
@@ -319,15 +348,39 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     d, n, m_per_gpu, dtype, label = WORKLOADS[args.workload]
-    m_total = m_per_gpu * world
+    if args.dtype is not None and args.dtype != dtype:
+        dtype = args.dtype
+        label += f" -- run as --dtype {dtype}"
+    float_predict = dtype in ("float32", "mixed")
+    grow = args.leaves == "grow"
+    boxes = None
+    if grow:
+        # SURVEY 8(d) family A: a box at tree depth 3 (the unit box split three times along its widest dimension -- first
+        # maximum --, left child each time) and its two OUTER children, bounds lo + i (w / 3) as gpso/param_space.py:257-307
+        lo_b, hi_b = np.zeros(d), np.ones(d)
+        for k in range(3):
+            hi_b[k] = lo_b[k] + 1 * ((hi_b[k] - lo_b[k]) / 3)
+        w3 = (hi_b[3 % d] - lo_b[3 % d]) / 3
+        kids = []
+        for i in (0, 2):
+            b = np.stack([lo_b, hi_b], axis=1)
+            b[3 % d] = (lo_b[3 % d] + i * w3, lo_b[3 % d] + (i + 1) * w3)
+            kids.append(b)
+        boxes = np.ascontiguousarray(np.stack(kids))
+        rows_ref = 2 * (3 ** args.depth - 1) // 2
+        rows_distinct = 2 * 3 ** (args.depth - 1)
+        m_per_gpu = rows_ref  # (the value counts the reference's rows; under --gpus N the rows of the two boxes are SHARDED)
+        label += f" -- leaves: grow(depth {args.depth}) of the two outer children of a depth-3 box = {rows_ref} reference rows, {rows_distinct} distinct"
+    m_total = m_per_gpu * (1 if grow else world)
     varsigma = float(erfcinv(0.01))
-    X, y, leaves_all = synthetic(n, d, m_total)
+    X, y, leaves_all = synthetic(n, d, 1 if grow else m_total, seed=args.seed)
     theta = ("Matern52", 0.25 * math.sqrt(d), 1.0, args.noise, float(y.mean()))
 
-    math_opt = args.math if dtype == "float32" else "native"
+    math_opt = args.math if float_predict else "native"
     eng = HipGPEngine(dtype, device=local_rank, predict_math=math_opt)
     # ---- fit on rank 0 (timed separately), broadcast the predict-ready posterior ----------------
     fit_ms = {}
+    fit_math = [None]
 
     def fit_here(timed):
         eng.set_data(X, y)
@@ -347,20 +400,19 @@ def main():
                 _, in_place = eng.append(X[-7:], y[-7:])
                 ts.append(eng.last_ms(2) if in_place else float("nan"))
             fit_ms["append_k7"] = float(np.median(ts))
-            try:
-                fit_ms["hyperopt"] = hyperopt_fit(eng, X, y, theta)
-            except np.linalg.LinAlgError as exc:
-                # (a float32 factorisation can lose positive definiteness where L-BFGS-B's line search steps into tiny noise
-                # -- N = 16 384 in float32 does; the reference's float64 path would not: the product's answer there is a
-                # "mixed" or "float64" surrogate, whose fit is the float64 one)
-                fit_ms["hyperopt"] = {"error": str(exc)[:200]}
+            fit_math[0] = eng.fit_math()
+            if not args.no_hyperopt:
+                # (a float32 factorisation can lose positive definiteness where L-BFGS-B's line search steps into tiny noise --
+                # N = 16 384 in float32 does; the reference's float64 path does not: the model then reopens its engine as
+                # "mixed" and the search starts over -- hyperopt.dtype says where it finished)
+                fit_ms["hyperopt"] = hyperopt_fit(dtype, local_rank, X, y, theta)
             eng.set_data(X, y)
         eng.fit_eval(*theta, want_grad=False)
 
     math_mode = "native"
     if rank == 0:
         fit_here(timed=True)
-        if dtype == "float32":  # what GPSO_MATH_AUTO settled on for this posterior (its self-test ran here)
+        if float_predict:  # what GPSO_MATH_AUTO settled on for this posterior (its self-test ran here)
             math_mode = eng.precision_info()["predict_math"]
     bcast_ms = repl_ms = None
     posterior_bytes = None
@@ -425,11 +477,20 @@ def main():
                         "the same deterministic fit on every rank, fingerprints compared (gpso_posterior_hash); no bulk collective")
 
     # ---- this rank's leaf shard, resident in HBM before the timed region --------------------------
-    lo, hi = D.shard_range(m_total, rank, world)
-    np_dtype = np.float32 if dtype == "float32" else np.float64
-    leaves_dev = torch.from_numpy(np.ascontiguousarray(leaves_all[lo:hi].astype(np_dtype))).cuda(local_rank)
+    lo, hi = (0, m_total) if grow else D.shard_range(m_total, rank, world)
+    np_dtype = np.float32 if float_predict else np.float64
+    leaves_dev = None if grow else torch.from_numpy(np.ascontiguousarray(leaves_all[lo:hi].astype(np_dtype))).cuda(local_rank)
 
     def step():
+        if grow:
+            # gpso_best_ucb_grow: the centres are generated on the device (bit-identical to LeafNode.grow), every distinct one
+            # scored once; the global winner of the two boxes is folded on the host from the two records
+            if use_dist:
+                idx, mean, var, ucb = D.best_ucb_grow_sharded(eng, boxes, args.depth, varsigma)
+            else:
+                idx, mean, var, ucb = eng.best_ucb_grow(boxes, args.depth, varsigma)
+            j = int(np.argmax(ucb))
+            return int(idx[j]) + j * (rows_ref // 2), float(mean[j]), float(var[j]), float(ucb[j])
         if use_dist:  # gpso_best_ucb_sharded: local scoring, RCCL all-gather of the winners, fold on device
             idx, mean, var, ucb = D.best_ucb_sharded(eng, leaves_dev, m_total, varsigma)
         else:
@@ -483,7 +544,7 @@ def main():
     # BESIDE the headline (which keeps the synchronous protocol above); single-GPU runs only (the sharded call is a
     # collective and stays blocking).
     pipelined_ms = pipelined_same = None
-    if not use_dist:
+    if not use_dist and not grow:
         for _ in range(3):
             eng.best_ucb_end(eng.best_ucb_begin(leaves_dev, varsigma))
         torch.cuda.synchronize()
@@ -501,9 +562,12 @@ def main():
     if rank == 0:
         kern_ms = float(np.mean(tile_ms))
         flops_per_leaf = n * n + 2 * n * d + 20 * n
-        achieved = flops_per_leaf * (hi - lo) / (kern_ms * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic(args.workload, math_mode)
-        peak = PEAK_TFLOPS[dtype] if math_mode == "native" else PEAK_BF16_TFLOPS / int(math_mode[-1])
+        # rows the leaf-tile kernel scores per launch: this rank's shard; under --leaves grow the DISTINCT rows (the library
+        # drops the centre children that repeat their parent bit for bit: gpso_last_count(ctx, 0))
+        scored = (eng.last_count(0) if grow else hi - lo)
+        achieved = flops_per_leaf * scored / (kern_ms * 1e-3) / 1e12
+        traffic, traffic_src = (None, None) if grow or args.dtype is not None else pmc_traffic(args.workload, math_mode)
+        peak = PEAK_TFLOPS["float32" if float_predict else "float64"] if math_mode == "native" else PEAK_BF16_TFLOPS / int(math_mode[-1])
         out = {
             "metric": "leaf_ucb_predictions_per_sec",
             "value": m_total * args.steps / elapsed,
@@ -518,8 +582,10 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if dtype == "float32" else "f64",
+            "dtype": "f32" if float_predict else "f64",  # the arithmetic class of the predict path ("mixed": float64 fit + float predict)
+            "engine_dtype": dtype,
             "data": "synthetic",
+            "seed": args.seed,
             "config": {
                 "workload": label if world == 1 else
                 f"{label} -- weak scaling: the same {m_per_gpu} leaves on each of the {world} GPUs ({m_total} in all); "
@@ -530,10 +596,17 @@ def main():
                 "D": d, "N_train": n, "leaves_per_gpu": m_per_gpu,
                 "leaves_total": m_total, "kernel": "Matern52", "lengthscale": theta[1],
                 "noise_variance": theta[3], "parallelism": f"leaf-shard x{world}",
-                "leaves_resident_in_hbm": True, "predict_math": math_mode, "predict_math_option": math_opt,
+                "leaves_resident_in_hbm": not grow, "predict_math": math_mode, "predict_math_option": math_opt,
+                "seed": args.seed, "engine_dtype": dtype,
+                **({"leaves": "grow", "depth": args.depth, "reference_rows": rows_ref, "distinct_rows": rows_distinct,
+                    "boxes": boxes.tolist()} if grow else {"leaves": "batch"}),
             },
+            # --leaves grow: ``value`` counts the rows of the reference's list (what LeafNode.grow would have handed to
+            # gp_eval_best_ucb); the kernels score every DISTINCT centre once
+            **({"value_distinct_rows": scored * args.steps / elapsed * (world if use_dist else 1),
+                "rows_scored_per_call": scored} if grow else {}),
             "fit_ms": fit_ms,
-            "roofline_fit": roofline_fit(n, d, dtype, fit_ms),
+            "roofline_fit": roofline_fit(n, d, dtype, fit_ms, fit_math[0]),
             "posterior_broadcast_ms": bcast_ms,
             "posterior_replicate_ms": repl_ms,
             "posterior_fingerprints_agree": hashes_agree,          # replicated fits: one fingerprint on every rank
@@ -555,17 +628,31 @@ def main():
                 f"with f32 accumulation, so the bound is the dense bf16 / fp16 peak / {math_mode[-1]} = {peak:.0f} TFLOP/s",
                 "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC, gfx950-corrected)",
                 "traffic_source": traffic_src,
-                "algorithmic_bytes": int((hi - lo) * (d + 3) * (4 if dtype == "float32" else 8)
-                                         + (n * n // 2 + n * d + n) * (4 if dtype == "float32" else 8)),
+                "algorithmic_bytes": int(scored * (d + 3) * (4 if float_predict else 8)
+                                         + (n * n // 2 + n * d + n) * (4 if float_predict else 8)),
                 "kernel_ms": kern_ms, "kernel_ms_samples": len(tile_ms), "kernel_timed_every": every,
                 # the same algorithmic flops against round 2's bound (six bf16 MFMAs per product): the fp16 split does
                 # half the matrix work for an f32-class product, so the figures of the two rounds compare on this line
                 **({"achieved_over_bf16x6_bound": achieved / (PEAK_BF16_TFLOPS / 6)} if math_mode == "f16x3" else {}),
-                "flops_per_leaf": flops_per_leaf, "leaves_per_launch": hi - lo,
+                "flops_per_leaf": flops_per_leaf, "leaves_per_launch": scored,
             },
         }
         post = None
-        if world == 1 and not args.no_cpu_baseline:
+        if grow and world == 1 and not args.no_cpu_baseline:
+            # the checker for the grown leaves: the oracle grows the first box on the host (small depths only) and scores it
+            from oracle import gpr, tree
+
+            if args.depth <= 9:
+                post = gpr.posterior(gpr.Theta(*theta), X, y)
+                ucbs = []
+                for b in boxes:
+                    rows = tree.grow([tuple(r) for r in b], args.depth)
+                    mr, vr = gpr.predict_y(post, rows)
+                    ucbs.append(mr + varsigma * vr)
+                ucb_ref = np.concatenate(ucbs)
+                out["winner"]["oracle_argmax"] = int(np.argmax(ucb_ref))
+                out["winner"]["oracle_ucb_gap"] = float(ucb_ref.max() - ucb_ref[winner[0]])
+        elif world == 1 and not args.no_cpu_baseline:
             cb, post = cpu_baseline(X, y, theta, leaves_all, varsigma)
             out["cpu_baseline"] = cb
             # the checker: the GPU winner must be (within fp tolerance) the oracle's winner on the sample
@@ -580,7 +667,7 @@ def main():
                 out["winner"]["oracle_argmax_over_sample"] = int(np.argmax(ucb_ref))
                 out["winner"]["oracle_ucb_gap"] = float(ucb_ref.max() - ucb_ref[winner[0]])
                 out["winner"]["same_argmax_as_oracle"] = bool(int(np.argmax(ucb_ref)) == winner[0]) if n_s == leaves_all.shape[0] else None
-        if world == 1 and dtype == "float32" and math_opt == "auto":
+        if world == 1 and float_predict and math_opt == "auto" and not grow:
             # every predict math on the same leaves in the same run: throughput + accuracy vs the oracle
             out["predict_math_modes"] = split_bf16_report(eng, leaves_dev, leaves_all, varsigma, m_total,
                                                   flops_per_leaf, post, max(3, args.steps // 2))

@@ -381,7 +381,16 @@ double gpso_last_ms(gpso_ctx* ctx, int what);
 /* leaf counts of the last predict / best_ucb / best_ucb_grow call: what = 0: rows the predict kernels
  * actually scored, 1: rows of the reference's list.  They differ for gpso_best_ucb_grow, which drops the
  * rows of LeafNode.grow that repeat an earlier row bit for bit (a centre child's centre is its parent's,
- * gpso/param_space.py:186-200: (3^depth - 1) / 2 rows per box, 3^(depth-1) distinct). */
+ * gpso/param_space.py:186-200: (3^depth - 1) / 2 rows per box, 3^(depth-1) distinct).
+ * what = 2: the arithmetic the LARGE PRODUCTS of the last gpso_fit_eval ran on (GPSO_FITMATH_*: what a roofline figure of
+ * the fit is priced against -- the f32 / f64 matrix instruction, or the two-level float fit's 16-bit pieces: six bf16 or
+ * three fp16 MFMAs per f32 product). */
+#define GPSO_FITMATH_NONE 0
+#define GPSO_FITMATH_SMALL 1   /* N <= 128: one launch, vector arithmetic in double */
+#define GPSO_FITMATH_F32 2     /* v_mfma_f32_16x16x4_f32 (float fits up to N_pad = 3584, or GPSO_OPT_FIT_BF16_SYRK = 0) */
+#define GPSO_FITMATH_F64 3     /* v_mfma_f64_16x16x4_f64 (float64 / mixed contexts) */
+#define GPSO_FITMATH_BF16X6 4  /* two-level float fit: three bf16 pieces per operand, six MFMAs per product */
+#define GPSO_FITMATH_F16X3 5   /* two-level float fit: two scaled fp16 pieces per operand, three MFMAs per product */
 int64_t gpso_last_count(gpso_ctx* ctx, int what);
 
 const char* gpso_version(void);

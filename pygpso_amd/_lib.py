@@ -39,6 +39,7 @@ CONTRACTION_AUTO, CONTRACTION_F32, CONTRACTION_F16 = 0, 1, 2
 SPLIT_KERNEL_AUTO, SPLIT_KERNEL_TWO_PHASE = 0, 1
 OPTF_TOL_VAR, OPTF_TOL_MEAN = 100, 101
 GEN_F64, GEN_F32, GEN_AUTO = 0, 1, 2
+FITMATH_NONE, FITMATH_SMALL, FITMATH_F32, FITMATH_F64, FITMATH_BF16X6, FITMATH_F16X3 = 0, 1, 2, 3, 4, 5  # gpso_last_count(ctx, 2)
 GEN_IDS = {"float64": GEN_F64, "f64": GEN_F64, "float32": GEN_F32, "f32": GEN_F32, "auto": GEN_AUTO}
 DTYPE_IDS = {"float64": F64, "fp64": F64, "f64": F64, "float32": F32, "fp32": F32, "f32": F32, "mixed": MIXED}
 MATH_NATIVE, MATH_AUTO, MATH_BF16X3, MATH_BF16X6, MATH_F16X3 = 0, 1, 3, 6, 13

@@ -159,7 +159,7 @@ struct gpso_ctx {
   // handed to a collective again either (need_comm refuses until gpso_comm_destroy + gpso_comm_init)
   std::atomic<bool> comm_aborted{false};
   int rank = 0, world = 1;
-  int64_t last_count[2] = {0, 0};  // leaves scored / leaves asked for by the last predict-type call
+  int64_t last_count[3] = {0, 0, 0};  // leaves scored / leaves asked for by the last predict-type call; [2] GPSO_FITMATH_* of the last fit
   std::string err;
   Engine* eng = nullptr;
   hipEvent_t ev_wait = nullptr;  // completion marker of the call in flight
@@ -850,6 +850,7 @@ struct EngineT : Engine {
     double fit_token = 0.0;
     if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[4], s));
     if (grad && (rc = ensure(kinvb, (size_t)npad * npad * sizeof(TF)))) return rc;
+    ctx->last_count[2] = small ? GPSO_FITMATH_SMALL : (sizeof(TF) == 8 ? GPSO_FITMATH_F64 : GPSO_FITMATH_F32);
     if (small) {
       // N <= 128: the whole evaluation in ONE launch (fit.hip: small_fit_kernel)
       SmallFitArgs a{};
@@ -898,6 +899,7 @@ struct EngineT : Engine {
           // after its power-of-two scaling; bf16 pieces (six) otherwise -- the fallback rung
           if (fit_planes_mode == 2) (void)fit_plane_scales(variance, noise, planes);
           pl = &planes;
+          ctx->last_count[2] = planes.np == 2 ? GPSO_FITMATH_F16X3 : GPSO_FITMATH_BF16X6;
         }
       }
       const int done = launch_potrf<TF>(s, as<TF>(K), as<TF>(Lf), as<TF>(linv), as<TF>(work),
@@ -998,9 +1000,22 @@ struct EngineT : Engine {
       y.insert(y.end(), yn, yn + (size_t)k);
       const KernParams th = kp;
       const int nls = n_ls, d_ = d;
+      const int64_t n_old = n;
       int rc = set_data(X.data(), y.data(), n_new, d_);
-      if (rc) return rc;
-      if ((rc = fit_eval(th.kernel, ls.data(), nls, th.variance, th.noise, th.mean_c, nlml, nullptr))) return rc;
+      if (rc == GPSO_OK) rc = fit_eval(th.kernel, ls.data(), nls, th.variance, th.noise, th.mean_c, nlml, nullptr);
+      if (rc < 0) {
+        // the header's promise holds on this path too: a failed append leaves the posterior of the first n points resident
+        // (set_data dropped it: put the old points back and refit at the resident hyper-parameters -- the fit that
+        // succeeded before the call)
+        const std::string why = ctx->err;
+        X.resize((size_t)n_old * d_);
+        y.resize((size_t)n_old);
+        int rc2 = set_data(X.data(), y.data(), n_old, d_);
+        if (rc2 == GPSO_OK) rc2 = fit_eval(th.kernel, ls.data(), nls, th.variance, th.noise, th.mean_c, nullptr, nullptr);
+        if (rc2 < 0) return ctx->fail(rc, "%s (and the posterior of the first %lld points could not be restored: status %d -- "
+                                          "gpso_set_data + gpso_fit_eval start over)", why.c_str(), (long long)n_old, rc2);
+        return ctx->fail(rc, "%s (the posterior of the first %lld points is resident again)", why.c_str(), (long long)n_old);
+      }
       ctx->fail(1, "gpso_append: posterior of the %lld points refitted from scratch at the resident hyper-parameters (%s)",
                 (long long)n_new, refit);
       return 1;
@@ -1013,12 +1028,12 @@ struct EngineT : Engine {
     double* host = ctx->pinned_scratch(8);
     if (!stage || !host) return ctx->fail(GPSO_E_OOM, "pinned host staging");
     if (ctx->timing) HIPCHECK(hipEventRecord(ctx->ev[4], s));
+    // (no copies: append_cross_kernel reads the new points from this pinned buffer and files them in x64 / y64 itself)
     std::memcpy(stage, Xn, (size_t)k * d * 8);
     std::memcpy(stage + (size_t)k * d, yn, (size_t)k * 8);
-    HIPCHECK(hipMemcpyAsync(as<double>(x64) + (size_t)n * d, stage, (size_t)k * d * 8, hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemcpyAsync(as<double>(y64) + (size_t)n, stage + (size_t)k * d, (size_t)k * 8, hipMemcpyHostToDevice, s));
     AppendArgs a{};
     a.x64 = as<double>(x64); a.y64 = as<double>(y64); a.ls = ls_dev();
+    a.xnew = stage; a.ynew = stage + (size_t)k * d;
     a.n = n; a.npad = npad; a.k = (int)k; a.d = d; a.dp = dp; a.kernel = kp.kernel;
     a.variance = kp.variance; a.noise = kp.noise; a.mean_c = kp.mean_c;
     a.xs64 = as<double>(xs64); a.xnorm64 = as<double>(xnorm64); a.xs_p64 = as<double>(xs_p64);
@@ -1925,7 +1940,10 @@ struct EngineT : Engine {
     if (nseg < 1 || (size_t)nseg * 4 + 3 > gpso_ctx::kSlotDoubles) return ctx->fail(GPSO_E_ARG, "nseg must be in [1, 1024] for an asynchronous call");
     int rc = grown ? precision_gate() : check_predict_args(xs, xs_dtype, xs_mem, m);
     if (rc) return rc;
-    const int k = ctx->slot_next;
+    // any free slot (the round-robin one first): calls may be ended out of order, so after begin A, begin B, end B the free slot
+    // is the one slot_next does NOT name -- refuse only when both hold a call
+    int k = ctx->slot_next;
+    if (ctx->slot_nseg[k] > 0) k = (k + 1) % gpso_ctx::kSlots;
     if (ctx->slot_nseg[k] > 0)
       return ctx->fail(GPSO_E_STATE, "two asynchronous best-UCB calls are already in flight: end one (gpso_best_ucb_end) first");
     if (ctx->slot_host == nullptr) {
@@ -1934,23 +1952,34 @@ struct EngineT : Engine {
       std::memset(ctx->slot_host, 0, gpso_ctx::kSlots * gpso_ctx::kSlotDoubles * 8);
       for (auto& ev : ctx->slot_ev) HIPCHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
-    const bool timing_was = ctx->timing;
-    ctx->timing = false;
-    result_slot = ctx->slot_host + (size_t)k * gpso_ctx::kSlotDoubles;
-    one_refused = true;
-    if (grown) {
-      rc = enqueue_best_grow(bounds, nseg, depth, 0, gpso_grow_rows(depth), varsigma);
-    } else {
-      const void* dev = nullptr;
-      if (m > 0) rc = stage_leaves(xs, xs_dtype, xs_mem, m, &dev);
-      if (rc == GPSO_OK) rc = enqueue_best_leaves(dev, xs_dtype, m, seg_off, nseg, varsigma);
+    {
+      // the enqueue runs untimed, into this call's own result slot, with the one-launch kernel refused: whichever way the
+      // region is left (an early return included), the context's synchronous calls find their state as it was
+      struct AsyncRegion {
+        EngineT* e;
+        bool timing_was;
+        AsyncRegion(EngineT* e_, double* slot) : e(e_), timing_was(e_->ctx->timing) {
+          e->ctx->timing = false;
+          e->result_slot = slot;
+          e->one_refused = true;
+        }
+        ~AsyncRegion() {
+          e->one_refused = false;
+          e->result_slot = nullptr;
+          e->host_direct = nullptr;
+          e->call_token = 0.0;
+          e->ctx->timing = timing_was;
+        }
+      } region(this, ctx->slot_host + (size_t)k * gpso_ctx::kSlotDoubles);
+      if (grown) {
+        rc = enqueue_best_grow(bounds, nseg, depth, 0, gpso_grow_rows(depth), varsigma);
+      } else {
+        const void* dev = nullptr;
+        if (m > 0) rc = stage_leaves(xs, xs_dtype, xs_mem, m, &dev);
+        if (rc == GPSO_OK) rc = enqueue_best_leaves(dev, xs_dtype, m, seg_off, nseg, varsigma);
+      }
+      ctx->slot_token[k] = call_token;
     }
-    one_refused = false;
-    result_slot = nullptr;
-    host_direct = nullptr;
-    ctx->slot_token[k] = call_token;
-    call_token = 0.0;
-    ctx->timing = timing_was;
     if (rc) return rc;
     if (xs_mem == GPSO_MEM_HOST && !grown && m > 0) HIPCHECK(hipStreamSynchronize(st()));  // (the caller's host leaves are free again on return)
     HIPCHECK(hipEventRecord(ctx->slot_ev[k], st()));
@@ -2927,7 +2956,7 @@ int gpso_comm_abort(gpso_ctx* ctx) {
 }
 
 int64_t gpso_last_count(gpso_ctx* ctx, int what) {
-  if (!ctx || what < 0 || what > 1) return -1;
+  if (!ctx || what < 0 || what > 2) return -1;
   return ctx->last_count[what];
 }
 

@@ -11,7 +11,12 @@
 // i.e. TWO passes over the resident L^-1 (row pass: B = X11 K12; column pass: W = B^T X11) instead of a factorisation:
 // N^2 s bytes and 2 N^2 k flops -- HBM-bound, against N^3 / 3 flops.  All arithmetic is double whatever the matrix type
 // TF (the loads are TF, the k-wide accumulators double): the passes are bandwidth-bound, and S = K22 - L21 L21^T is a
-// cancellation the float fit also pays for.  Kernels (one stream, in order):
+// cancellation the float fit also pays for.  Round 5 ran the six steps below as six launches behind two host-to-device
+// copies (60 us at C3, all of it dependency gaps); round 6 runs them as THREE: the cross kernel reads the new points from
+// pinned host memory itself, and each pass carries its consumer in its epilogue behind last-arriver tickets (agent-scope
+// fences around one atomic counter per 64-row / 64-column block, as the one-launch predict kernel does) -- the last chunk of
+// a row block to finish sums the chunks IN ORDER (same bits as the separate kernel) and forms the block's partial Gram, the
+// last row block factorises the corner; the last chunk of a column block writes that block's new rows.  Steps:
 //
 //   append_cross_kernel      K12 (n x k) and K22 + noise I (k x k) from the scaled inputs; the new rows' scaled inputs,
 //                            norms and MFMA fragments land where the fit leaves them (same formulas as scale_x_kernel /
@@ -38,9 +43,11 @@ __global__ __launch_bounds__(256) void append_cross_kernel(AppendArgs a) {
   const int tid = threadIdx.x;
   const int k = a.k, dp = a.dp, d = a.d, KP = a.kp;
   const int64_t n = a.n;
+  // (the new points come straight from the caller's staging buffer in pinned host memory: k d + k doubles per workgroup over
+  // the fabric instead of two copy operations in front of the first launch; workgroup 0 files them in x64 / y64)
   for (int e = tid; e < k * dp; e += 256) {
     const int t = e / dp, kk = e - t * dp;
-    xn[e] = (kk < d) ? a.x64[(n + t) * d + kk] / a.ls[kk] : 0.0;
+    xn[e] = (kk < d) ? a.xnew[t * d + kk] / a.ls[kk] : 0.0;
   }
   __syncthreads();
   if (tid < k) {
@@ -60,6 +67,9 @@ __global__ __launch_bounds__(256) void append_cross_kernel(AppendArgs a) {
       a.xs_p64[pbase + (kk >> 2) * 64 + 16 * (kk & 3)] = xn[e];
     }
     if (tid < k) a.xnorm64[n + tid] = nn[tid];
+    for (int e = tid; e < k * d; e += 256) a.x64[n * d + e] = a.xnew[e];
+    if (tid < k) a.y64[n + tid] = a.ynew[tid];
+    for (int e = tid; e < a.ntickets; e += 256) a.tickets[e] = 0u;  // (also zero after every completed call: a fresh scratch buffer is not)
     if (tid == 0) {
       *a.info = INT_MAX;
       if (a.f16_scal != nullptr) a.f16_scal[3] = a.f16_scal[1];  // the scale the resident pieces were packed with
@@ -93,124 +103,16 @@ __global__ __launch_bounds__(256) void append_cross_kernel(AppendArgs a) {
   }
 }
 
-// ---- 2. / 5a. the two passes over L^-1, tile by tile ----------------------------------------------------------------
-// One workgroup = one 64-row block of L^-1 (row pass: B = X11 K12) or one 64-column block (column pass: W = X11^T B) times
-// a chunk of `ct` of its 64x64 tiles; grid (tiles per side, nq <= 8).  A tile arrives with 16-byte loads (the next one is
-// in flight while this one is used), is masked to the lower triangle / the first n rows and staged in LDS beside the 64
-// operand rows (K12 / B) of its contraction index; the product runs on the f64 matrix instruction (16x16x4: wave g owns 16
-// rows / columns of the block, the k <= 64 right-hand sides are its 16-wide column blocks), accumulators live across the
-// chunk's tiles.  Partial sums per chunk go to part[q][index][KP]; the consumer adds the chunks in order (deterministic).
-// (First versions, profiles/r05_append_experiments.txt: one wave per row re-reading K12 from the L2 for every row -- 8.6 TB
-// of L2 traffic at N = 16 384 -- and one workgroup per column strip: 0.71 + 1.98 ms at C5, 14 + 183 us at C3; then vector
-// FMAs with scalar operand loads in the inner loop, latency-chained: 0.61 + 0.39 ms, 34 + 36 us.)
-template <int KP>
-struct PassShape {
-  static constexpr int NB = KP <= 16 ? 1 : KP / 16;  // 16-wide blocks of right-hand sides (KP = 8: half a block is padding)
-  static constexpr int UW = 16 * NB;
-};
+// ---- 3. B from its chunks; partial Gram of [B | a1] per 64-row block (epilogue of the row pass) ----------------------------
+// Run by the LAST chunk of row block `tb` to finish: sums the chunks in order (deterministic), writes B, forms the block's
+// partial [B | a1]^T [B | a1].  tile: >= 64 (KP + 2) doubles of LDS.
 template <typename TF, int KP>
-constexpr int append_pass_lds_bytes() { return 64 * 65 * (int)sizeof(TF) + 64 * PassShape<KP>::UW * 8; }
-
-template <typename TF, int KP, bool COLS>
-__global__ __launch_bounds__(256) void append_pass_kernel(const TF* __restrict__ linv, int64_t n, int64_t npad,
-                                                          const double* __restrict__ U, double* __restrict__ part, int ct) {
-  constexpr int EV = 16 / (int)sizeof(TF);  // elements per 16-byte load
-  constexpr int VPR = 64 / EV;              // loads per tile row
-  constexpr int RPP = 256 / VPR;            // tile rows per pass of the workgroup
-  constexpr int NP = 64 / RPP;              // passes
-  constexpr int NB = PassShape<KP>::NB, UW = PassShape<KP>::UW;
-  constexpr int NU = 64 * KP / 256;         // operand doubles per thread and tile
-  constexpr int LD = 65;
-  typedef TF vecT __attribute__((ext_vector_type(EV)));
-  extern __shared__ __align__(16) unsigned char pass_lds[];
-  TF* T = reinterpret_cast<TF*>(pass_lds);                                      // the tile, masked, [64][65]
-  double* Us = reinterpret_cast<double*>(pass_lds + 64 * LD * sizeof(TF));      // the operand rows, [64][UW]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tb = blockIdx.x, q = blockIdx.y;
-  const int ntile = (int)((n + 63) / 64);
-  int lo, hi;  // range of the other tile index
-  if (!COLS) {
-    lo = q * ct;
-    hi = min((q + 1) * ct, tb + 1);
-  } else {
-    lo = max(tb, q * ct);
-    hi = min((q + 1) * ct, ntile);
-  }
-  if (lo >= hi) return;  // (the consumer knows which chunks exist)
-  if (KP < UW)
-    for (int e = tid; e < 64 * (UW - KP); e += 256) Us[(e / (UW - KP)) * UW + KP + e % (UW - KP)] = 0.0;  // padding columns
-  const int vrow = tid / VPR, vcol = (tid % VPR) * EV;
-  vecT v[NP];
-  double uu[NU];
-  auto fetch = [&](int o) {
-    const int64_t R0 = (COLS ? o : tb) * 64, C0 = (COLS ? tb : o) * 64;
-#pragma unroll
-    for (int p = 0; p < NP; ++p) v[p] = *reinterpret_cast<const vecT*>(linv + (R0 + p * RPP + vrow) * npad + C0 + vcol);
-    // the operand rows of the contraction index: K12 rows of the tile's columns (row pass) / B rows of its rows (column pass)
-    const int64_t X0 = COLS ? R0 : C0;
-#pragma unroll
-    for (int w = 0; w < NU; ++w) {
-      const int idx = w * 256 + tid;  // (x, j) = (idx / KP, idx % KP)
-      uu[w] = (X0 + idx / KP < n) ? U[X0 * KP + idx] : 0.0;
-    }
-  };
-  f64x4 acc[NB];
-#pragma unroll
-  for (int b = 0; b < NB; ++b) acc[b] = f64x4{0, 0, 0, 0};
-  fetch(lo);
-  for (int o = lo; o < hi; ++o) {
-    const int64_t R0 = (COLS ? o : tb) * 64, C0 = (COLS ? tb : o) * 64;
-    __syncthreads();  // (the previous tile has been read)
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int64_t gr = R0 + p * RPP + vrow;
-#pragma unroll
-      for (int x = 0; x < EV; ++x) {
-        const int64_t gc = C0 + vcol + x;
-        T[(p * RPP + vrow) * LD + vcol + x] = (gr < n && gc <= gr) ? v[p][x] : (TF)0;
-      }
-    }
-#pragma unroll
-    for (int w = 0; w < NU; ++w) {
-      const int idx = w * 256 + tid;
-      Us[(idx / KP) * UW + idx % KP] = uu[w];
-    }
-    if (o + 1 < hi) fetch(o + 1);
-    __syncthreads();
-    // 16 k-steps of the f64 matrix instruction: D[i][j] += A[i][kk] B[kk][j], A = the tile (row pass: i = row, kk = column;
-    // column pass: i = column, kk = row) for this wave's 16 rows / columns, B = the operand rows
-    const int i = lane & 15, kk = lane >> 4;
-#pragma unroll 4
-    for (int s4 = 0; s4 < 16; ++s4) {
-      const double a = COLS ? (double)T[(4 * s4 + kk) * LD + 16 * g + i] : (double)T[(16 * g + i) * LD + 4 * s4 + kk];
-#pragma unroll
-      for (int b = 0; b < NB; ++b)
-        acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Us[(4 * s4 + kk) * UW + 16 * b + i], acc[b], 0, 0, 0);
-    }
-  }
-  // accumulator register r of lane l: index 16 g + (l >> 4) + 4 r of the block, right-hand side 16 b + (l & 15)
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const int j = 16 * b + (lane & 15);
-    if (j < KP) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        part[((int64_t)q * npad + (int64_t)tb * 64 + 16 * g + (lane >> 4) + 4 * r) * KP + j] = acc[b][r];
-    }
-  }
-}
-
-// ---- 3. B from its chunks; partial Gram of [B | a1] per 64-row block -----------------------------------------------------
-template <typename TF, int KP>
-__global__ __launch_bounds__(256) void append_gram_part_kernel(const double* __restrict__ bpart, int ct, int64_t npad,
-                                                               double* __restrict__ Bm, const TF* __restrict__ white,
-                                                               int64_t n, double* __restrict__ part) {
+__device__ __forceinline__ void append_gram_part(const double* __restrict__ bpart, int nq, int64_t npad, int tb,
+                                                 double* __restrict__ Bm, const TF* __restrict__ white, int64_t n,
+                                                 double* __restrict__ part, double* tile) {
   constexpr int W = KP + 1, LD = KP + 2;
-  __shared__ double tile[64 * LD];
   const int tid = threadIdx.x;
-  const int64_t r0 = (int64_t)blockIdx.x * 64;
-  const int nq = (int)blockIdx.x / ct + 1;  // chunks of the row pass that hold tiles of this row block
+  const int64_t r0 = (int64_t)tb * 64;
   for (int e = tid; e < 64 * KP; e += 256) {
     const int rr = e / KP, j = e - rr * KP;
     const int64_t r = r0 + rr;
@@ -223,10 +125,10 @@ __global__ __launch_bounds__(256) void append_gram_part_kernel(const double* __r
   }
   if (tid < 64) tile[tid * LD + KP] = (r0 + tid < n) ? (double)white[r0 + tid] : 0.0;
   __syncthreads();
-  double* out = part + (int64_t)blockIdx.x * W * W;
+  double* out = part + (int64_t)tb * W * W;
   for (int e = tid; e < W * W; e += 256) {
     const int i = e / W, j = e - i * W;
-    if (i > j) continue;  // (upper triangle incl. the a1 column: what append_chol_kernel reads)
+    if (i > j) continue;  // (upper triangle incl. the a1 column: what append_chol reads)
     double s = 0.0;
 #pragma unroll 8
     for (int rr = 0; rr < 64; ++rr) s = fma(tile[rr * LD + i], tile[rr * LD + j], s);
@@ -234,24 +136,28 @@ __global__ __launch_bounds__(256) void append_gram_part_kernel(const double* __r
   }
 }
 
-// ---- 4. the k x k corner: Schur complement, Cholesky, inverse, a2, NLML ---------------------------------------------
-// sm (doubles): [0, 4096) L22 (ld 64) | [4096, 8192) L22^-1 (ld 64) | [8192, 8256) a2
+// ---- 4. the k x k corner: Schur complement, Cholesky, inverse, a2, NLML (run by the LAST row block's workgroup) -------------
+// global sm (doubles): [0, 4096) L22 (ld 64) | [4096, 8192) L22^-1 (ld 64) | [8192, 8256) a2
+// LDS (doubles, carved from `lds`): S [KP x KP] | X, lower triangle packed by rows: (i, j <= i) at i (i + 1) / 2 + j | v | a2 | psum
 template <int KP>
-__global__ __launch_bounds__(256) void append_chol_kernel(AppendArgs a, int nchunk) {
+constexpr int append_chol_lds_doubles() { return KP * KP + KP * (KP + 1) / 2 + 2 * KP + 256 + 2; }
+template <int KP>
+__device__ __forceinline__ void append_chol(const AppendArgs& a, int nchunk, double* lds) {
   constexpr int W = KP + 1;
-  constexpr int LD = 64;
-  __shared__ double S[64 * LD];
-  __shared__ double X[64 * 65 / 2];  // L22^-1, lower triangle packed by rows: (i, j <= i) at i (i + 1) / 2 + j
-  __shared__ double v[64], a2[64];
-  __shared__ int bad;
+  constexpr int LD = KP;
+  double* S = lds;
+  double* X = S + KP * KP;
+  double* v = X + KP * (KP + 1) / 2;
+  double* a2 = v + KP;
+  double* psum = a2 + KP;
+  int* bad = reinterpret_cast<int*>(psum + 256);
   const int tid = threadIdx.x, k = a.k;
   const int64_t n = a.n;
-  if (tid == 0) bad = INT_MAX;
+  if (tid == 0) *bad = INT_MAX;
   // S = K22 + noise I - sum over the chunks of B^T B; v = B^T a1.  PARTS threads share an entry (chunks p, p + PARTS, ..),
   // their sums are added in order: deterministic
   constexpr int EP = 1 << (32 - __builtin_clz((unsigned)(W * W - 1)));  // entries, rounded up to a power of two
   constexpr int PARTS = EP >= 256 ? 1 : 256 / EP;
-  __shared__ double psum[PARTS > 1 ? 256 : 1];
   for (int e0 = 0; e0 < W * W; e0 += 256 / PARTS) {
     const int e = e0 + tid % (256 / PARTS), p = tid / (256 / PARTS);
     const int i = e / W, j = e - i * W;
@@ -288,7 +194,7 @@ __global__ __launch_bounds__(256) void append_chol_kernel(AppendArgs a, int nchu
   for (int p = 0; p < k; ++p) {
     const double dpp = S[p * LD + p];
     if (!(dpp > 0.0) || !(dpp < 1.0e300)) {
-      if (tid == 0) bad = p;
+      if (tid == 0) *bad = p;
       break;  // (block-uniform: every thread reads the same LDS word)
     }
     const double lpp = sqrt(dpp);
@@ -303,10 +209,10 @@ __global__ __launch_bounds__(256) void append_chol_kernel(AppendArgs a, int nchu
     __syncthreads();
   }
   __syncthreads();
-  if (bad != INT_MAX) {
+  if (*bad != INT_MAX) {
     if (tid == 0) {
-      *a.info = (int)(n + bad);
-      a.host_out[2] = (double)(n + bad);
+      *a.info = (int)(n + *bad);
+      a.host_out[2] = (double)(n + *bad);
       a.host_out[1] = 2.0;
     }
     return;
@@ -350,74 +256,76 @@ __global__ __launch_bounds__(256) void append_chol_kernel(AppendArgs a, int nchu
   }
 }
 
-// ---- 5. column pass and the new rows -----------------------------------------------------------------------------
+// ---- 5b. the new rows (epilogue of the column pass): R = -L22^-1 W per column, alpha, diag(K_y^-1), the k x k corner --------
 template <typename TP>
 __device__ __forceinline__ void store_alpha_p(void* alpha_p, int64_t i, double v) {
   static_cast<TP*>(alpha_p)[i] = (TP)v;
 }
-
-// ---- 5b. the new rows: R = -L22^-1 W per column, alpha, diag(K_y^-1), the k x k corner ------------------------------------
-template <typename TF, typename TP, int KP>
-__global__ __launch_bounds__(256) void append_finish_kernel(AppendArgs a, const double* __restrict__ wpart, int ct,
-                                                            TF* __restrict__ linv, TF* __restrict__ Lf,
-                                                            TF* __restrict__ white, TF* __restrict__ alpha_f) {
-  if (*a.info != INT_MAX) return;  // S was not positive definite: the resident posterior stays as it is
-  __shared__ double Xs[64 * 65 / 2];  // L22^-1, lower triangle packed by rows
-  __shared__ double a2s[64];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int k = a.k;
-  const int64_t n = a.n, npad = a.npad;
-  const int nblk = (int)((n + 255) / 256);
+template <int KP>
+constexpr int append_finish_lds_doubles() { return KP * (KP + 1) / 2 + KP; }
+// L22^-1 (packed) and a2 from the corner's global record into LDS
+__device__ __forceinline__ void append_load_corner(const AppendArgs& a, double* Xs, double* a2s) {
+  const int tid = threadIdx.x, k = a.k;
   for (int e = tid; e < k * k; e += 256) {
     const int i = e / k, j = e - i * k;
     if (j <= i) Xs[i * (i + 1) / 2 + j] = a.sm[4096 + i * 64 + j];
   }
   if (tid < k) a2s[tid] = a.sm[8192 + tid];
   __syncthreads();
-
-  if ((int)blockIdx.x == nblk) {
-    // the k x k corner: rows n .. n + k - 1, columns n .. (end of the 64-column block that holds n + k - 1)
-    const int64_t cend = min(npad, (n + k + 63) / 64 * 64);
-    const int wcols = (int)(cend - n);
-    float m = 0.0f;
-    for (int e = tid; e < k * wcols; e += 256) {
-      const int t = e / wcols, j = e - t * wcols;
-      double x = 0.0, l = 0.0;
-      if (j <= t) {
-        x = Xs[t * (t + 1) / 2 + j];
-        l = a.sm[t * 64 + j];
-      }
-      linv[(n + t) * npad + n + j] = (TF)x;
-      Lf[(n + t) * npad + n + j] = (TF)l;
-      m = fmaxf(m, fabsf((float)x));
+}
+// the k x k corner: rows n .. n + k - 1, columns n .. (end of the 64-column block that holds n + k - 1); one workgroup
+template <typename TF, typename TP>
+__device__ __forceinline__ void append_finish_corner(const AppendArgs& a, const double* Xs, const double* a2s, TF* __restrict__ linv,
+                                                     TF* __restrict__ Lf, TF* __restrict__ white, TF* __restrict__ alpha_f) {
+  const int tid = threadIdx.x, lane = tid & 63, k = a.k;
+  const int64_t n = a.n, npad = a.npad;
+  const int64_t cend = min(npad, (n + k + 63) / 64 * 64);
+  const int wcols = (int)(cend - n);
+  float m = 0.0f;
+  for (int e = tid; e < k * wcols; e += 256) {
+    const int t = e / wcols, j = e - t * wcols;
+    double x = 0.0, l = 0.0;
+    if (j <= t) {
+      x = Xs[t * (t + 1) / 2 + j];
+      l = a.sm[t * 64 + j];
     }
-    if (tid < k) {
-      double al = 0.0, sq = 0.0;
-      for (int j = tid; j < k; ++j) {
-        const double x = Xs[j * (j + 1) / 2 + tid];
-        al = fma(x, a2s[j], al);
-        sq = fma(x, x, sq);
-      }
-      const TF alf = (TF)al;
-      white[n + tid] = (TF)a2s[tid];
-      alpha_f[n + tid] = alf;
-      store_alpha_p<TP>(a.alpha_p, n + tid, (double)alf);
-      a.kinv_diag[n + tid] = sq;
-    }
-    if (tid == 0) a.hyper[0] = (double)(n + k);
-    if (a.f16_scal != nullptr) {
-      for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-      if (lane == 0 && m > 0.0f) atomicMax(reinterpret_cast<unsigned*>(a.f16_scal), __builtin_bit_cast(unsigned, m));
-    }
-    return;
+    linv[(n + t) * npad + n + j] = (TF)x;
+    Lf[(n + t) * npad + n + j] = (TF)l;
+    m = fmaxf(m, fabsf((float)x));
   }
-
-  const int64_t c = (int64_t)blockIdx.x * 256 + tid;
+  if (tid < k) {
+    double al = 0.0, sq = 0.0;
+    for (int j = tid; j < k; ++j) {
+      const double x = Xs[j * (j + 1) / 2 + tid];
+      al = fma(x, a2s[j], al);
+      sq = fma(x, x, sq);
+    }
+    const TF alf = (TF)al;
+    white[n + tid] = (TF)a2s[tid];
+    alpha_f[n + tid] = alf;
+    store_alpha_p<TP>(a.alpha_p, n + tid, (double)alf);
+    a.kinv_diag[n + tid] = sq;
+  }
+  if (tid == 0) a.hyper[0] = (double)(n + k);
+  if (a.f16_scal != nullptr) {
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (lane == 0 && m > 0.0f) atomicMax(reinterpret_cast<unsigned*>(a.f16_scal), __builtin_bit_cast(unsigned, m));
+  }
+}
+// the 64 columns of block tb, one thread per column (wave 0; per-column arithmetic as in round 5's 256-column workgroups: same bits)
+template <typename TF, typename TP, int KP>
+__device__ __forceinline__ void append_finish_columns(const AppendArgs& a, const double* __restrict__ wpart, int ct, int tb,
+                                                      const double* Xs, const double* a2s, TF* __restrict__ linv, TF* __restrict__ Lf,
+                                                      TF* __restrict__ alpha_f) {
+  const int tid = threadIdx.x, k = a.k;
+  if (tid >= 64) return;
+  const int64_t n = a.n, npad = a.npad;
+  const int64_t c = (int64_t)tb * 64 + tid;
   float m = 0.0f;
   if (c < n) {
     // W[:, c]: the chunks of the column pass that hold tiles of this column block, in order
     const int ntile = (int)((n + 63) / 64);
-    const int q0 = (int)(c / 64) / ct, q1 = (ntile - 1) / ct;
+    const int q0 = tb / ct, q1 = (ntile - 1) / ct;
     double w[KP];
 #pragma unroll
     for (int j = 0; j < KP; ++j) w[j] = 0.0;
@@ -447,7 +355,181 @@ __global__ __launch_bounds__(256) void append_finish_kernel(AppendArgs a, const 
   }
   if (a.f16_scal != nullptr) {
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if (lane == 0 && m > 0.0f) atomicMax(reinterpret_cast<unsigned*>(a.f16_scal), __builtin_bit_cast(unsigned, m));
+    if (tid == 0 && m > 0.0f) atomicMax(reinterpret_cast<unsigned*>(a.f16_scal), __builtin_bit_cast(unsigned, m));
+  }
+}
+
+// ---- 2. / 5a. the two passes over L^-1, tile by tile, each with its consumer in the epilogue ----------------------------------
+// One workgroup = one 64-row block of L^-1 (row pass: B = X11 K12) or one 64-column block (column pass: W = X11^T B) times
+// a chunk of `ct` of its 64x64 tiles; grid (tiles per side [+ 1: the corner's workgroup, column pass], nq <= 8).  A tile
+// arrives with 16-byte loads, kDepth tiles ahead of its use (round 5: one ahead -- 3.3 TB/s at C5; the loop is bound by the
+// latency of a load under load, so the bytes in flight per CU are what counts), is masked to the lower triangle / the first
+// n rows and staged in LDS beside the 64 operand rows (K12 / B) of its contraction index; the product runs on the f64
+// matrix instruction (16x16x4: wave g owns 16 rows / columns of the block, the k <= 64 right-hand sides are its 16-wide
+// column blocks), accumulators live across the chunk's tiles.  Partial sums per chunk go to part[q][index][KP]; the
+// consumer -- the LAST chunk of the block to arrive at the block's ticket -- adds the chunks in order (deterministic).
+// (First versions, profiles/r05_append_experiments.txt: one wave per row re-reading K12 from the L2 for every row -- 8.6 TB
+// of L2 traffic at N = 16 384 -- and one workgroup per column strip: 0.71 + 1.98 ms at C5, 14 + 183 us at C3; then vector
+// FMAs with scalar operand loads in the inner loop, latency-chained: 0.61 + 0.39 ms, 34 + 36 us.)
+template <int KP>
+struct PassShape {
+  static constexpr int NB = KP <= 16 ? 1 : KP / 16;  // 16-wide blocks of right-hand sides (KP = 8: half a block is padding)
+  static constexpr int UW = 16 * NB;
+};
+constexpr int cmax(int x, int y) { return x > y ? x : y; }
+template <typename TF, int KP>
+constexpr int append_pass_lds_bytes() {
+  return cmax(cmax(64 * 65 * (int)sizeof(TF) + 64 * PassShape<KP>::UW * 8, 64 * (KP + 2) * 8),
+              cmax(append_chol_lds_doubles<KP>(), append_finish_lds_doubles<KP>()) * 8);
+}
+constexpr int kPassDepth = 2;  // tiles in flight ahead of the one in use
+
+template <typename TF, typename TP, int KP, bool COLS>
+__global__ __launch_bounds__(256) void append_pass_kernel(AppendArgs a, const TF* __restrict__ linv, const double* __restrict__ U,
+                                                          double* __restrict__ part, int ct, TF* __restrict__ linv_w, TF* __restrict__ Lf,
+                                                          TF* __restrict__ white, TF* __restrict__ alpha_f) {
+  constexpr int EV = 16 / (int)sizeof(TF);  // elements per 16-byte load
+  constexpr int VPR = 64 / EV;              // loads per tile row
+  constexpr int RPP = 256 / VPR;            // tile rows per pass of the workgroup
+  constexpr int NP = 64 / RPP;              // passes
+  constexpr int NB = PassShape<KP>::NB, UW = PassShape<KP>::UW;
+  constexpr int NU = 64 * KP / 256;         // operand doubles per thread and tile
+  constexpr int LD = 65;
+  typedef TF vecT __attribute__((ext_vector_type(EV)));
+  extern __shared__ __align__(16) unsigned char pass_lds[];
+  __shared__ unsigned last_flag;
+  TF* T = reinterpret_cast<TF*>(pass_lds);                                      // the tile, masked, [64][65]
+  double* Us = reinterpret_cast<double*>(pass_lds + 64 * LD * sizeof(TF));      // the operand rows, [64][UW]
+  const int64_t n = a.n, npad = a.npad;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tb = blockIdx.x, q = blockIdx.y;
+  const int ntile = (int)((n + 63) / 64);
+  if (COLS) {
+    if (*a.info != INT_MAX) return;  // S was not positive definite: the resident posterior stays as it is
+    if (tb == ntile) {               // the corner's workgroup
+      if (q != 0) return;
+      double* Xs = reinterpret_cast<double*>(pass_lds);
+      double* a2s = Xs + KP * (KP + 1) / 2;
+      append_load_corner(a, Xs, a2s);
+      append_finish_corner<TF, TP>(a, Xs, a2s, linv_w, Lf, white, alpha_f);
+      return;
+    }
+  }
+  int lo, hi;  // range of the other tile index
+  if (!COLS) {
+    lo = q * ct;
+    hi = min((q + 1) * ct, tb + 1);
+  } else {
+    lo = max(tb, q * ct);
+    hi = min((q + 1) * ct, ntile);
+  }
+  if (lo >= hi) return;  // (the consumer knows which chunks exist)
+  if (KP < UW)
+    for (int e = tid; e < 64 * (UW - KP); e += 256) Us[(e / (UW - KP)) * UW + KP + e % (UW - KP)] = 0.0;  // padding columns
+  const int vrow = tid / VPR, vcol = (tid % VPR) * EV;
+  vecT v[kPassDepth][NP];
+  double uu[kPassDepth][NU];
+  auto fetch = [&](int o, vecT* vv, double* uv) {
+    const int64_t R0 = (COLS ? o : tb) * 64, C0 = (COLS ? tb : o) * 64;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) vv[p] = *reinterpret_cast<const vecT*>(linv + (R0 + p * RPP + vrow) * npad + C0 + vcol);
+    // the operand rows of the contraction index: K12 rows of the tile's columns (row pass) / B rows of its rows (column pass)
+    const int64_t X0 = COLS ? R0 : C0;
+#pragma unroll
+    for (int w = 0; w < NU; ++w) {
+      const int idx = w * 256 + tid;  // (x, j) = (idx / KP, idx % KP)
+      uv[w] = (X0 + idx / KP < n) ? U[X0 * KP + idx] : 0.0;
+    }
+  };
+  f64x4 acc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) acc[b] = f64x4{0, 0, 0, 0};
+  auto use = [&](int o, const vecT* vv, const double* uv) {
+    const int64_t R0 = (COLS ? o : tb) * 64, C0 = (COLS ? tb : o) * 64;
+    __syncthreads();  // (the previous tile has been read)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int64_t gr = R0 + p * RPP + vrow;
+#pragma unroll
+      for (int x = 0; x < EV; ++x) {
+        const int64_t gc = C0 + vcol + x;
+        T[(p * RPP + vrow) * LD + vcol + x] = (gr < n && gc <= gr) ? vv[p][x] : (TF)0;
+      }
+    }
+#pragma unroll
+    for (int w = 0; w < NU; ++w) {
+      const int idx = w * 256 + tid;
+      Us[(idx / KP) * UW + idx % KP] = uv[w];
+    }
+  };
+  auto multiply = [&]() {
+    __syncthreads();
+    // 16 k-steps of the f64 matrix instruction: D[i][j] += A[i][kk] B[kk][j], A = the tile (row pass: i = row, kk = column;
+    // column pass: i = column, kk = row) for this wave's 16 rows / columns, B = the operand rows
+    const int i = lane & 15, kk = lane >> 4;
+#pragma unroll 4
+    for (int s4 = 0; s4 < 16; ++s4) {
+      const double av = COLS ? (double)T[(4 * s4 + kk) * LD + 16 * g + i] : (double)T[(16 * g + i) * LD + 4 * s4 + kk];
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Us[(4 * s4 + kk) * UW + 16 * b + i], acc[b], 0, 0, 0);
+    }
+  };
+  // software pipeline, kPassDepth tiles in flight: slot s holds tile lo + (multiple of kPassDepth) + s (static register slots)
+#pragma unroll
+  for (int s_ = 0; s_ < kPassDepth; ++s_)
+    if (lo + s_ < hi) fetch(lo + s_, v[s_], uu[s_]);
+  for (int o = lo; o < hi; o += kPassDepth) {
+#pragma unroll
+    for (int s_ = 0; s_ < kPassDepth; ++s_) {
+      if (o + s_ < hi) {
+        use(o + s_, v[s_], uu[s_]);
+        if (o + s_ + kPassDepth < hi) fetch(o + s_ + kPassDepth, v[s_], uu[s_]);
+        multiply();
+      }
+    }
+  }
+  // accumulator register r of lane l: index 16 g + (l >> 4) + 4 r of the block, right-hand side 16 b + (l & 15)
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int j = 16 * b + (lane & 15);
+    if (j < KP) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        part[((int64_t)q * npad + (int64_t)tb * 64 + 16 * g + (lane >> 4) + 4 * r) * KP + j] = acc[b][r];
+    }
+  }
+  // ---- the consumer, behind the block's ticket: this workgroup's partial sums are released before the ticket (thread 0's
+  // agent-scope fence behind the barrier covers every wave's stores: they share one L2), the last arriver acquires behind it
+  const int nlive = COLS ? (ntile - 1) / ct - tb / ct + 1 : tb / ct + 1;  // chunks of this block that hold tiles
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    last_flag = (atomicAdd(&a.tickets[(COLS ? ntile + 1 : 0) + tb], 1u) == (unsigned)(nlive - 1)) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!last_flag) return;
+  __threadfence();  // (every thread of the consuming workgroup acquires before it reads the other chunks)
+  if (tid == 0) a.tickets[(COLS ? ntile + 1 : 0) + tb] = 0u;  // (zero between calls)
+  if (!COLS) {
+    append_gram_part<TF, KP>(part, nlive, npad, tb, a.Bm, white, n, a.part, reinterpret_cast<double*>(pass_lds));
+    // the last row block to have its partial Gram factorises the corner
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence();
+      last_flag = (atomicAdd(&a.tickets[ntile], 1u) == (unsigned)(ntile - 1)) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    __threadfence();
+    if (tid == 0) a.tickets[ntile] = 0u;
+    append_chol<KP>(a, ntile, reinterpret_cast<double*>(pass_lds));
+  } else {
+    double* Xs = reinterpret_cast<double*>(pass_lds);
+    double* a2s = Xs + KP * (KP + 1) / 2;
+    append_load_corner(a, Xs, a2s);
+    append_finish_columns<TF, TP, KP>(a, part, ct, tb, Xs, a2s, linv_w, Lf, alpha_f);
   }
 }
 
@@ -459,26 +541,26 @@ static size_t append_off_pass(int64_t npad, int kp) { return append_off_bm(npad,
 static size_t append_off_part(int64_t npad, int kp) { return append_off_pass(npad, kp) + (size_t)kAppendChunks * npad * kp; }
 static size_t append_off_sm(int64_t npad, int kp) { return append_off_part(npad, kp) + (size_t)((npad + 63) / 64) * (kp + 1) * (kp + 1); }
 static size_t append_off_info(int64_t npad, int kp) { return append_off_sm(npad, kp) + 8192 + 64; }
-size_t append_scratch_doubles(int64_t npad, int kp) { return append_off_info(npad, kp) + 8; }
+static size_t append_off_tickets(int64_t npad, int kp) { return append_off_info(npad, kp) + 8; }
+static int append_ntickets(int64_t npad) { return 2 * (int)((npad + 63) / 64) + 2; }  // row blocks + the corner's | column blocks
+size_t append_scratch_doubles(int64_t npad, int kp) { return append_off_tickets(npad, kp) + (size_t)(append_ntickets(npad) + 1) / 2; }
 
 template <typename TF, typename TP, int KP>
 static void launch_append_kp(hipStream_t st, AppendArgs a, double* pass, TF* linv, TF* Lf, TF* white, TF* alpha_f) {
   const int64_t n = a.n;
   const int ntile = (int)((n + 63) / 64);
   const int ct = (ntile + kAppendChunks - 1) / kAppendChunks, nq = (ntile + ct - 1) / ct;
-  hipLaunchKernelGGL(append_cross_kernel, dim3((unsigned)((n + a.k + 63) / 64)), dim3(256), 0, st, a);
   constexpr int lds = append_pass_lds_bytes<TF, KP>();
-  if (ensure_dyn_lds(reinterpret_cast<const void*>(&append_pass_kernel<TF, KP, false>), lds) ||
-      ensure_dyn_lds(reinterpret_cast<const void*>(&append_pass_kernel<TF, KP, true>), lds))
+  if (ensure_dyn_lds(reinterpret_cast<const void*>(&append_pass_kernel<TF, TP, KP, false>), lds) ||
+      ensure_dyn_lds(reinterpret_cast<const void*>(&append_pass_kernel<TF, TP, KP, true>), lds))
     return;  // (recorded with note_launch_error)
-  hipLaunchKernelGGL((append_pass_kernel<TF, KP, false>), dim3((unsigned)ntile, (unsigned)nq), dim3(256), lds, st, linv, n, a.npad,
-                     a.Kc, pass, ct);
-  hipLaunchKernelGGL((append_gram_part_kernel<TF, KP>), dim3((unsigned)ntile), dim3(256), 0, st, pass, ct, a.npad, a.Bm, white, n, a.part);
-  hipLaunchKernelGGL((append_chol_kernel<KP>), dim3(1), dim3(256), 0, st, a, ntile);
-  hipLaunchKernelGGL((append_pass_kernel<TF, KP, true>), dim3((unsigned)ntile, (unsigned)nq), dim3(256), lds, st, linv, n, a.npad,
-                     a.Bm, pass, ct);
-  hipLaunchKernelGGL((append_finish_kernel<TF, TP, KP>), dim3((unsigned)((n + 255) / 256) + 1), dim3(256), 0, st, a, pass, ct, linv,
-                     Lf, white, alpha_f);
+  hipLaunchKernelGGL(append_cross_kernel, dim3((unsigned)((n + a.k + 63) / 64)), dim3(256), 0, st, a);
+  // row pass -> (last chunk of a row block) B + partial Gram -> (last row block) the corner's Cholesky
+  hipLaunchKernelGGL((append_pass_kernel<TF, TP, KP, false>), dim3((unsigned)ntile, (unsigned)nq), dim3(256), lds, st, a, linv, a.Kc,
+                     pass, ct, linv, Lf, white, alpha_f);
+  // column pass -> (last chunk of a column block) the new rows at those columns; workgroup (ntile, 0): the k x k corner
+  hipLaunchKernelGGL((append_pass_kernel<TF, TP, KP, true>), dim3((unsigned)ntile + 1, (unsigned)nq), dim3(256), lds, st, a, linv, a.Bm,
+                     pass, ct, linv, Lf, white, alpha_f);
 }
 
 template <typename TF, typename TP>
@@ -492,6 +574,8 @@ void launch_append(hipStream_t st, AppendArgs a, void* scratch, TF* linv, TF* Lf
   a.part = q + append_off_part(a.npad, kp);
   a.sm = q + append_off_sm(a.npad, kp);
   a.info = reinterpret_cast<int*>(q + append_off_info(a.npad, kp));
+  a.tickets = reinterpret_cast<unsigned*>(q + append_off_tickets(a.npad, kp));
+  a.ntickets = append_ntickets(a.npad);
   switch (kp) {
     case 8: launch_append_kp<TF, TP, 8>(st, a, pass, linv, Lf, white, alpha_f); break;
     case 16: launch_append_kp<TF, TP, 16>(st, a, pass, linv, Lf, white, alpha_f); break;

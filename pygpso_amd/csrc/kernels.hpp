@@ -290,8 +290,11 @@ void launch_install_chol(hipStream_t st, const double* L64, int64_t n, int64_t n
 // (append.hip).  Everything below lives on the device; scratch = append_scratch_doubles(npad, append_kp(k)) doubles.
 constexpr int kAppendMax = 64;
 struct AppendArgs {
-  const double* x64;   // [(n + k) * d] raw inputs, new rows included
-  const double* y64;   // [n + k]
+  double* x64;         // [npad * d] raw inputs: rows n .. n + k - 1 are filed by the cross kernel
+  double* y64;         // [npad]
+  const double *xnew, *ynew;  // the k new points [k * d], [k] in pinned HOST memory (read by the cross kernel itself: no copies)
+  unsigned* tickets;   // scratch: last-arriver counters, [0, ntile) row blocks | [ntile] the corner | [ntile + 1, ..) column blocks
+  int ntickets;
   const double* ls;    // lengthscale per input dimension (device)
   int64_t n, npad;
   int k, kp, d, dp, kernel;

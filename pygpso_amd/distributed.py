@@ -355,7 +355,7 @@ class HipGPEngineGroup:
 
     # read-only introspection of the fitting rank (first device); anything that would CHANGE one engine only is
     # not forwarded
-    _ROOT_READS = ("precision_info", "last_ms", "last_count", "padded_n", "get_matrix", "get_vector", "grow",
+    _ROOT_READS = ("precision_info", "last_ms", "last_count", "fit_math", "padded_n", "get_matrix", "get_vector", "grow",
                    "grow_rows", "posterior_buffers", "rank")
 
     def __getattr__(self, name):

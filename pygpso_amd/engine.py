@@ -175,6 +175,15 @@ class HipGPEngine:
         """0: leaves the kernels scored in the last predict-type call, 1: leaves of the reference's list."""
         return int(self._lib.gpso_last_count(self._h, int(what)))
 
+    FIT_MATH = {L.FITMATH_NONE: None, L.FITMATH_SMALL: "small", L.FITMATH_F32: "f32", L.FITMATH_F64: "f64",
+                L.FITMATH_BF16X6: "bf16x6", L.FITMATH_F16X3: "f16x3"}
+
+    def fit_math(self):
+        """Arithmetic the large products of the last ``fit_eval`` ran on (``gpso_last_count(ctx, 2)``, GPSO_FITMATH_*):
+        "small" (N <= 128, one launch), "f32" / "f64" (the matrix instruction of the fit type), "bf16x6" / "f16x3" (the
+        two-level float fit's 16-bit pieces)."""
+        return self.FIT_MATH.get(self.last_count(2))
+
     @property
     def padded_n(self):
         return int(self._lib.gpso_padded_n(self._h))
@@ -233,8 +242,14 @@ class HipGPEngine:
             raise ValueError(f"Xnew must be [k, {self.d}]")
         yn = L.as_f64(np.asarray(ynew).reshape(-1), (Xn.shape[0],))
         nlml = C.c_double()
-        rc = self._check(self._lib.gpso_append(self._h, L.dptr(Xn), L.dptr(yn), Xn.shape[0], C.byref(nlml)))
-        self.n += Xn.shape[0]
+        try:
+            rc = self._check(self._lib.gpso_append(self._h, L.dptr(Xn), L.dptr(yn), Xn.shape[0], C.byref(nlml)))
+        finally:
+            # whatever happened, N is what the library says it holds (a failed append leaves the first N points, in place
+            # or refitted: include/gpso_hip.h)
+            n, d = C.c_int64(), C.c_int()
+            if self._lib.gpso_problem_shape(self._h, C.byref(n), C.byref(d)) == L.OK:
+                self.n = int(n.value)
         return nlml.value, rc == L.OK
 
     def last_message(self):

@@ -392,10 +392,16 @@ class GPRSurrogate(GPSurrogate):
             if keep_theta:
                 # the evaluated points only ever grow at the end (GPListOfPoints keeps insertion order): extend the
                 # posterior at the kept hyper-parameters
-                self._updates += 1
-                self.gpflow_model.append_data(x[n_old:], y[n_old:])
-                return
-            self.gpflow_model.data = (x, y)  # hyper-parameters warm-start from the last optimum
+                try:
+                    self.gpflow_model.append_data(x[n_old:], y[n_old:])
+                    self._updates += 1
+                    return
+                except np.linalg.LinAlgError as err:
+                    # the appended block is not positive definite at the kept hyper-parameters (in the engine's
+                    # arithmetic): the model holds the N + k points with no posterior -- this update re-optimises instead
+                    logging.warning(f"{err}; this update re-optimises the hyper-parameters instead of appending")
+            else:
+                self.gpflow_model.data = (x, y)  # hyper-parameters warm-start from the last optimum
         self._updates += 1
         self.optimiser.minimize(self.gpflow_model.training_loss, self.gpflow_model.trainable_variables)
 

@@ -93,12 +93,26 @@ class Scipy:
         model = getattr(closure, "__self__", None)
         if model is None or not hasattr(model, "_loss_and_grad"):
             raise TypeError("Scipy.minimize expects the bound training_loss of a HipGPR model")
-        res = None
-        if method == "L-BFGS-B" and not scipy_kwargs:
-            res = self._lbfgsb_direct(model._loss_and_grad, model._pack())
-        if res is None:
-            res = scipy.optimize.minimize(model._loss_and_grad, model._pack(), jac=True, method=method,
-                                          **scipy_kwargs)
+        x0 = model._pack()  # (the model's hyper-parameters are assigned only at the end: a restart begins here again)
+        while True:
+            try:
+                res = None
+                if method == "L-BFGS-B" and not scipy_kwargs:
+                    res = self._lbfgsb_direct(model._loss_and_grad, x0)
+                if res is None:
+                    res = scipy.optimize.minimize(model._loss_and_grad, x0, jac=True, method=method, **scipy_kwargs)
+                break
+            except np.linalg.LinAlgError as err:
+                # GPSO_E_NOTPD inside the search.  The reference's search runs in float64 (gpflow.default_float,
+                # gpso/gp_surrogate.py:490-503) and loses positive definiteness only on a genuinely singular matrix; a
+                # float32 factorisation loses it where the line search steps into small noise at large N.  The model then
+                # reopens its engine as "mixed" (float64 fit, on the device) and THIS update's search starts over from its
+                # theta_0 -- one history in one arithmetic.  Nowhere to go (float64 / mixed engine, escalate=False, an engine
+                # the model does not own): the error is the caller's, as in the reference.
+                escalate = getattr(model, "_escalate", None)
+                if escalate is None or not escalate(err, fit=True):
+                    raise
+                model.fit_escalations = getattr(model, "fit_escalations", 0) + 1
         model._assign(res.x)
         return res
 

@@ -23,6 +23,9 @@ NOISE_FLOOR = 1.0e-6  # gpflow.likelihoods.Gaussian DEFAULT_VARIANCE_LOWER_BOUND
 # what a model does when the device reports GPSO_E_PRECISION: reopen the posterior in the next more
 # precise arithmetic ON THE DEVICE (never on the CPU, never in the test oracle)
 PRECISION_ESCALATION = {"float32": "mixed", "mixed": "float64"}
+# ... and when a float32 FACTORISATION loses positive definiteness (GPSO_E_NOTPD inside a hyper-parameter search or a fit at
+# the stored hyper-parameters): "mixed" fits in float64, as the reference does; there is no further step
+FIT_ESCALATION = {"float32": "mixed"}
 
 
 def _softplus1(u):
@@ -88,6 +91,7 @@ class HipGPR:
         self._devices = list(devices) if devices is not None else None
         self._owns_engine = engine is None
         self.escalate = bool(escalate)
+        self.fit_escalations = 0  # hyper-parameter searches restarted on a more precise engine (Scipy.minimize)
         self.fused_transforms = True  # loss evaluations through gpso_fit_eval_u (False: transforms in Python)
         self.engine = engine if engine is not None else self._open_engine(dtype)
         self._data = None
@@ -136,8 +140,18 @@ class HipGPR:
             self.data = (x, y)
             return False
         self._ensure_resident()  # the posterior of the data so far at the current hyper-parameters (a fit only if it is not there)
+        try:
+            nlml, _ = self.engine.append(x_new, y_new[:, 0])
+        except np.linalg.LinAlgError:
+            # the appended block is not positive definite in this arithmetic (GPSO_E_NOTPD): whatever the device still
+            # holds, the model's state must be ONE consistent thing -- the N + k points as data, no resident posterior,
+            # nothing known about the device's hyper-parameters -- so that the caller's next step (GPRSurrogate: a
+            # re-optimisation, which may reopen a float32 engine as "mixed") starts from a plain ``model.data = (x, y)``
+            self.data = (x, y)
+            raise
+        # only a successful append changes what the model claims
         self._data = (x, y)
-        self._last_nlml, _ = self.engine.append(x_new, y_new[:, 0])
+        self._last_nlml = nlml
         self._resident = True
         return True
 
@@ -221,7 +235,7 @@ class HipGPR:
             # evaluation left on the device is then the one asked for (an evaluation with the gradient builds
             # the same factor, L^-1 and alpha, bit for bit) and no further fit is needed
             if self._device_theta != self._theta_key(name, ls, var, noise, c):
-                self._last_nlml, _ = self.engine.fit_eval(name, ls, var, noise, c, want_grad=False)
+                self._last_nlml, _ = self._fitting(lambda: self.engine.fit_eval(name, ls, var, noise, c, want_grad=False))
                 self._device_theta = self._theta_key(name, ls, var, noise, c)
             self._resident = True
 
@@ -235,10 +249,14 @@ class HipGPR:
         return -self.training_loss()
 
     # -- predict ------------------------------------------------------------------------------
-    def _escalate(self, err):
-        """GPSO_E_PRECISION: move data + hyper-parameters to an engine of the next more precise
-        arithmetic (still on the device).  Returns False when there is nowhere left to go."""
-        nxt = PRECISION_ESCALATION.get(getattr(self.engine, "dtype_name", None))
+    def _escalate(self, err, fit=False):
+        """GPSO_E_PRECISION (predict) or -- ``fit=True`` -- GPSO_E_NOTPD out of a FLOAT factorisation: move data +
+        hyper-parameters to an engine of the next more precise arithmetic (still on the device).  Returns False when
+        there is nowhere left to go: a fit error has one step only, "float32" -> "mixed" (whose fit is the float64 one,
+        the reference's arithmetic: gpso/gp_surrogate.py:490-503 -- a matrix that is not positive definite THERE is the
+        caller's to see, as in the reference)."""
+        cur = getattr(self.engine, "dtype_name", None)
+        nxt = FIT_ESCALATION.get(cur) if fit else PRECISION_ESCALATION.get(cur)
         if nxt is None or not self.escalate or not self._owns_engine:
             return False
         logging.warning(f"{err}; reopening the GP posterior as a {nxt!r} engine on device {self._device}")
@@ -250,6 +268,16 @@ class HipGPR:
         self._resident = False
         self._device_theta = None
         return True
+
+    def _fitting(self, call):
+        """Run a fit-type engine call; a float32 engine whose factorisation is not positive definite is replaced by a
+        "mixed" one (float64 fit) and the call repeated -- ``escalate=False`` keeps the raise."""
+        while True:
+            try:
+                return call()
+            except np.linalg.LinAlgError as err:
+                if not self._escalate(err, fit=True):
+                    raise
 
     def _predicting(self, call):
         """Run a predict-type engine call; a float engine that reports GPSO_E_PRECISION is replaced by

@@ -315,3 +315,168 @@ def test_an_appended_posterior_travels_like_a_fitted_one():
         assert all(np.array_equal(u, v) for u, v in zip(ra, rb))
         ma, mb = a.predict(Xs), b.predict(Xs)
         assert np.array_equal(ma[0], mb[0]) and np.array_equal(ma[1], mb[1])
+
+
+# ---- round 6: the append at the sizes it was built for (BASELINE configs C4 / C5) -------------------------------------------
+def _append_at_size(family, n1, d, k, dtype, post_nlml, leaves_sub, mean_ref, var_ref, X, y, th, post=None):
+    """Fit the first n1 - k points, append the last k, compare with the ORACLE's from-scratch posterior of all n1 (one CPU
+    factorisation shared with tests/test_gpu_parity.py's config tests).  Float contexts: FLOAT_BOUNDS[family] unchanged,
+    NLML 2e-5; float64: NLML 1e-9, predictions 1e-8 (the bound of the from-scratch fit at N = 4600), the new rows of L 1e-9."""
+    from pygpso_amd import _lib as L
+    from tests.test_gpu_parity import FLOAT_BOUNDS
+
+    n = n1 - k
+    eng = _engine(dtype)
+    _fit(eng, X[:n], y[:n], th)
+    if dtype != "float64":
+        eng.predict(leaves_sub[:64])  # (the self-test has ruled and the 16-bit pieces exist: the append repacks them in place)
+    f, in_place = eng.append(X[n:], y[n:])
+    assert in_place, eng.last_message()
+    assert eng.n == n1
+    tol_f = 2e-5 if dtype == "float32" else 1e-9
+    assert abs(f - post_nlml) <= tol_f * abs(post_nlml), (f, post_nlml)
+    mean, var = eng.predict(leaves_sub)
+    ys = max(1.0, float(np.max(np.abs(y))))
+    em, ev = float(np.max(np.abs(mean - mean_ref)) / ys), float(np.max(np.abs(var - var_ref)) / th.variance)
+    print(f"append at {family} (N = {n} + {k}, {dtype}): nlml {abs(f - post_nlml) / abs(post_nlml):.1e}, |d mean| {em:.2e} max|y|, "
+          f"|d var| {ev:.2e} sigma^2")
+    if dtype == "float64":
+        assert em <= 1e-8 and ev <= 1e-8
+        if post is not None:  # the rows the append wrote, against the oracle's factor
+            chol = eng.get_matrix(L.MAT_CHOL)
+            assert _rel(chol[n:], post.L[n:]) < 1e-9
+            assert _rel(eng.get_vector(L.VEC_ALPHA), post.alpha) < 1e-6  # (a forward error: cond(K_y) ~ 1e6 at this size)
+    else:
+        bm, bv = FLOAT_BOUNDS[family]
+        assert em <= bm and ev <= bv
+    return eng
+
+
+@pytest.mark.parametrize("k", [1, 7, 40])
+@pytest.mark.parametrize("dtype", ["float32", "mixed", "float64"])
+def test_append_at_config_C4_size_matches_the_oracles_from_scratch_posterior(dtype, k):
+    from tests.test_gpu_parity import _c4_posterior, _problem
+
+    n1, d = 8192, 20
+    X, y, th = _problem(n1, d, variance=1.0)
+    post = _c4_posterior(th, X, y)
+    Xs = synthetic_leaves(32768, d)
+    sub = np.sort(np.random.default_rng(31).choice(Xs.shape[0], 256, replace=False))
+    mean_ref, var_ref = gpr.predict_y(post, Xs[sub])
+    _append_at_size("C4", n1, d, k, dtype, post.nlml, Xs[sub], mean_ref, var_ref, X, y, th, post)
+
+
+@pytest.mark.parametrize("k", [1, 7, 40])
+@pytest.mark.parametrize("dtype", ["float32", "mixed"])
+def test_append_at_config_C5_size_matches_the_oracles_from_scratch_posterior(dtype, k):
+    """N = 16 384 - k: the passes run with the nq = 8 chunking and 256 tiles per block column.  The oracle is the CPU potrf
+    at 16 384 the C5 tests of tests/test_gpu_parity.py already pay for (noise 1e-3: bench.py --workload c5's)."""
+    from tests.test_gpu_parity import _c5_reference
+
+    ref = _c5_reference(1e-3)
+    X, y, th = ref["X"], ref["y"], ref["th"]
+    leaves = synthetic_leaves(131072, 40).astype(np.float32)[ref["sub"]].astype(np.float64)
+    _append_at_size("C5", 16384, 40, k, dtype, ref["nlml"], leaves, ref["mean_ref"], ref["var_ref"], X, y, th)
+
+
+def test_an_appended_C4_posterior_through_the_eight_shard_replay():
+    """The appended C4 posterior handed to a second context as one span copy, scored as 8 shards on the two contexts
+    (gpso_shard_winners x 8 + gpso_fold_winners: the group call minus the ncclAllGather) = ONE gpso_best_ucb over the
+    batch, bit for bit -- and the winner is the oracle's (float rule)."""
+    from tests.helpers import winner_is_the_oracles
+    from tests.test_gpu_distributed import _replay_at_size
+    from tests.test_gpu_parity import _c4_posterior, _problem
+
+    n1, d, k, m = 8192, 20, 7, 32768
+    X, y, th = _problem(n1, d, variance=1.0)
+    post = _c4_posterior(th, X, y)
+    root = _engine("float32")
+    _fit(root, X[:n1 - k], y[:n1 - k], th)
+    Xs = synthetic_leaves(m, d).astype(np.float32)
+    root.predict(Xs[:256])
+    _, in_place = root.append(X[n1 - k:], y[n1 - k:])
+    assert in_place and root.n == n1
+    segs = {"one": None, "ragged": np.array([0, 1000, 1000, m // 8 + 5, m // 2, m - 1, m], dtype=np.int64)}
+    whole, _ = _replay_at_size(root, Xs, segs)
+    mean_ref, var_ref = gpr.predict_y(post, Xs.astype(np.float64))
+    winner_is_the_oracles(whole["one"][0][0], mean_ref + VS * var_ref, 2e-5, "test_gpu_append")
+
+
+@pytest.mark.parametrize("k", [33, 48, 64])
+def test_wide_blocks_in_a_float32_context(k):
+    """k = 33 ... 64 (the 64-wide instantiation of the passes and of the one-workgroup corner) in a float32 context at
+    N_pad = 4096, against the oracle: the float bounds of the from-scratch fit at this size (C4 class)."""
+    n1, d = 4096, 6
+    X, y = synthetic_problem(n1, d, seed=37)
+    th = gpr.Theta("Matern52", np.array([0.25 * np.sqrt(d)]), 1.0, 1e-3, float(y.mean()))
+    post = gpr.posterior(th, X, y)
+    Xs = synthetic_leaves(1024, d)
+    mean_ref, var_ref = gpr.predict_y(post, Xs)
+    _append_at_size("C4", n1, d, k, "float32", post.nlml, Xs, mean_ref, var_ref, X, y, th)
+
+
+# ---- round 6: failures leave ONE consistent state (ADVICE r5) ---------------------------------------------------------------
+def test_a_failed_refit_path_append_restores_the_posterior_of_the_first_points():
+    """k > 64 takes the library's refit path (gpso_set_data + gpso_fit_eval on the N + k points).  When THAT fit fails the
+    header's promise still holds: the posterior of the first N points is resident again, N is N, predictions are the bits
+    of before."""
+    n, d = 300, 3
+    X, y = synthetic_problem(n, d, seed=41)
+    th = _theta(d, y, noise=1e-6)
+    eng = _engine()
+    _fit(eng, X, y, th)
+    Xs = synthetic_leaves(400, d)
+    before = eng.predict(Xs)
+    bad = np.vstack([synthetic_problem(69, d, seed=43)[0], np.full((1, d), np.nan)])  # 70 rows: the refit path; a NaN input
+    with pytest.raises(np.linalg.LinAlgError) as err:
+        eng.append(bad, np.zeros(70))
+    assert "resident again" in str(err.value)
+    assert eng.n == n
+    after = eng.predict(Xs)
+    assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
+    f, in_place = eng.append(X[:1] + 0.01, y[:1])  # ... and the context appends as before
+    assert in_place and eng.n == n + 1
+
+
+def test_a_failed_append_leaves_the_model_consistent_and_the_surrogate_reoptimises():
+    from pygpso_amd import GPRSurrogate
+    from pygpso_amd.kernels import Constant, Matern52
+    from pygpso_amd.model import HipGPR
+
+    n, d = 200, 2
+    X, y = synthetic_problem(n + 4, d, seed=47)
+    model = HipGPR(data=(X[:n], y[:n, None]), kernel=Matern52(lengthscales=0.3, variance=1.0), mean_function=Constant(0.0),
+                   noise_variance=1e-4)
+    model.predict_y(X[:3])
+    bad = np.vstack([X[n:n + 2], np.full((1, d), np.nan)])
+    with pytest.raises(np.linalg.LinAlgError):
+        model.append_data(bad, np.zeros(3))
+    # the model claims the N + 3 rows as data and NO resident posterior (the advisor's case: it claimed a posterior of
+    # N + 3 points while the device held N)
+    assert model.data[0].shape[0] == n + 3 and not model._resident and model._device_theta is None
+    model.data = (X[:n], y[:n, None])
+    mean, _ = model.predict_y(X[:3])
+    assert np.all(np.isfinite(mean))
+    # the surrogate: an update whose append fails re-optimises on all points instead
+    surr = GPRSurrogate(gp_kernel=Matern52(lengthscales=0.25, variance=1.0), gp_meanf=Constant(0.0), refit_every=4)
+    surr.append(X[:n], y[:n])
+    surr.gp_update()
+    m = surr.gpflow_model
+    evals0 = m.num_loss_evals
+    real_append = m.engine.append
+
+    def failing(*a, **kw):  # (a NaN row would also poison the re-optimisation: the failure itself is forced here, the
+        raise np.linalg.LinAlgError("forced: the appended block is not positive definite")  # device's is tested above)
+
+    m.engine.append = failing
+    surr.append(X[n:n + 4], y[n:n + 4])
+    surr.gp_update()
+    m.engine.append = real_append
+    assert m.num_loss_evals > evals0  # re-optimised on all N + 4 points
+    assert m.data[0].shape[0] == n + 4 == surr.num_evaluated and m.engine.n == n + 4
+    th = m.parameter_dict()
+    post = gpr.posterior(gpr.Theta("Matern52", np.atleast_1d(th[".kernel.lengthscales"]), float(th[".kernel.variance"]),
+                                   float(th[".likelihood.variance"]), float(th[".mean_function.c"])), X, y)
+    mean, var = m.predict_y(X[:5])
+    mean_ref, var_ref = gpr.predict_y(post, X[:5])
+    assert np.max(np.abs(mean[:, 0] - mean_ref)) <= 1e-8 and np.max(np.abs(var[:, 0] - var_ref)) <= 1e-8

@@ -8,7 +8,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = 5  # bump with the round: the second sweep below is new cases every round
+ROUND = 6  # bump with the round: the second sweep below is new cases every round
 SEEDS = [pytest.param(20260101, id="fixed-seed20260101"), pytest.param(20260100 + 7 * ROUND, id=f"round{ROUND}-seed{20260100 + 7 * ROUND}")]
 
 

@@ -175,3 +175,66 @@ def test_G6_replay_in_float_arithmetic(dtype, math, caplog):
         t, exp = opt.gp_surr.gpflow_model, G["G6"]["final_theta"]
         assert abs(float(t.kernel.lengthscales) - exp["lengthscale"]) <= 6e-6 * exp["lengthscale"]
         assert abs(t.kernel.variance - exp["variance"]) <= 6e-6 * exp["variance"]
+
+
+# ---- round 6: a float32 hyper-parameter search that loses positive definiteness (VERDICT r5 missing 2) -----------------------
+def test_notpd_inside_a_float32_search_escalates_to_a_mixed_engine_and_ends_where_the_oracle_does(caplog):
+    """The reference's search runs in float64 (gpflow.default_float; gpso/gp_surrogate.py:490-503) and does not lose positive
+    definiteness for arithmetic reasons.  A float32 factorisation does: on this recipe (N = 4600, D = 8, start (1.3 l*, 1.5,
+    3e-3, 0); tools/hyperopt_notpd_probe.py) L-BFGS-B's ninth evaluation fails at pivot 4165.  ``escalate=False`` keeps that
+    raise; by default the model reopens its engine as "mixed" (float64 fit) and the search starts over from theta_0.
+
+    Stated tolerances.  Against a float64 ENGINE's search from the same start: the same bits (one history, one arithmetic).
+    Against the ORACLE's ``gpr.fit`` (tests/golden/oracle_hyperopt_n4600_d8.json -- 100 CPU evaluations, 159 s, generated
+    on the GPU box by the committed probe): NLML within 1e-8 relative; theta within 5e-3 relative -- the optimum sits on the
+    noise floor (1e-6) with s2 ~ 6300, cond(K_y) ~ 1e10: a flat valley in which two float64 implementations of the same
+    search stop 1.6e-3 apart in s2 (measured) at NLMLs that agree to 1.7e-9.  And the oracle, evaluated HERE at the device's
+    theta, must agree with the device's NLML to 1e-9 and be no worse than its own optimum by more than 1e-8."""
+    import json
+    import os
+
+    from pygpso_amd.kernels import Constant, Matern52, Scipy
+    from pygpso_amd.model import HipGPR
+    from tests.helpers import GOLDEN_DIR
+
+    with open(os.path.join(GOLDEN_DIR, "oracle_hyperopt_n4600_d8.json")) as fh:
+        gold = json.load(fh)
+    n, d = gold["recipe"]["n"], gold["recipe"]["d"]
+    X, y = synthetic_problem(n, d, seed=0)
+    st = gold["recipe"]["start"]
+
+    def model(dtype, **kw):
+        return HipGPR(data=(X, y[:, None]), kernel=Matern52(lengthscales=st["ls"], variance=st["variance"]),
+                      mean_function=Constant(st["c"]), noise_variance=st["noise"], dtype=dtype, **kw)
+
+    plain = model("float32", escalate=False)
+    with pytest.raises(np.linalg.LinAlgError, match="pivot"):
+        Scipy().minimize(plain.training_loss, plain.trainable_variables)
+    assert plain.engine.dtype_name == "float32" and plain.kernel.variance == st["variance"]  # nothing assigned, nothing reopened
+    plain.engine.close()
+
+    m = model("float32")
+    with caplog.at_level(logging.WARNING):
+        res = Scipy().minimize(m.training_loss, m.trainable_variables)
+    assert m.engine.dtype_name == "mixed" and m.fit_escalations == 1
+    assert "reopening the GP posterior as a 'mixed' engine" in caplog.text
+    ref = model("float64")
+    res64 = Scipy().minimize(ref.training_loss, ref.trainable_variables)
+    assert res.nfev == res64.nfev and np.array_equal(res.x, res64.x) and res.fun == res64.fun
+    got = np.array([float(m.kernel.lengthscales), m.kernel.variance, m.likelihood.variance, m.mean_function.c])
+    want = np.array(gold["oracle"]["theta"])
+    rel = np.abs(got - want) / np.abs(want)
+    print(f"escalated float32 search: {res.nfev} evaluations (+ {m.num_loss_evals - res.nfev} abandoned in float32); theta vs the "
+          f"oracle's fit: rel {rel}, nlml rel {abs(res.fun - gold['oracle']['nlml']) / abs(gold['oracle']['nlml']):.1e}")
+    assert np.all(rel <= 5e-3), (got, want)
+    assert abs(res.fun - gold["oracle"]["nlml"]) <= 1e-8 * abs(gold["oracle"]["nlml"])
+    th = gpr.Theta("Matern52", np.array([got[0]]), got[1], got[2], got[3])
+    f_here = gpr.posterior(th, X, y).nlml  # the oracle at the device's optimum
+    assert abs(f_here - res.fun) <= 1e-9 * abs(f_here)
+    assert f_here <= gold["oracle"]["nlml"] + 1e-8 * abs(gold["oracle"]["nlml"])
+    # the model goes on predicting from the engine it ended on
+    Xs = synthetic_leaves(256, d)
+    mean, var = m.predict_y(Xs)
+    mean_ref, var_ref = gpr.predict_y(gpr.posterior(th, X, y), Xs)
+    assert np.max(np.abs(mean[:, 0] - mean_ref)) <= 2e-3 * max(1.0, float(np.max(np.abs(y))))
+    assert np.max(np.abs(var[:, 0] - var_ref)) <= 1e-3 * th.variance

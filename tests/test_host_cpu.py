@@ -471,3 +471,149 @@ def test_refit_every_appends_between_reoptimisations_on_the_host_side():
     plain.gpflow_model.fused_transforms = False
     plain.append(X[30:33], y[30:33]); plain.gp_update()
     assert len(calls) == 2
+
+
+# ---- round 6: a float32 hyper-parameter search that loses positive definiteness escalates (host logic) -------------------------
+class _FloatEngineThatLosesPD(OracleEngine):
+    """A "float32" engine whose factorisation fails below a noise level -- what the device's float Cholesky does at large N when
+    L-BFGS-B's line search steps into small noise; the "mixed" engine it is replaced by never fails."""
+    dtype_name = "float32"
+    opened = []
+
+    def __init__(self, dtype="float32", device=0, **kw):
+        super().__init__()
+        self.dtype_name = dtype
+        self.closed = False
+        type(self).opened.append(self)
+
+    def set_timing(self, on):
+        pass
+
+    def close(self):
+        self.closed = True
+
+    def fit_eval(self, kernel, lengthscales, variance, noise, mean_c, want_grad=True):
+        if self.dtype_name == "float32" and noise < 5.0e-3:
+            raise np.linalg.LinAlgError("K + noise*I is not positive definite: Cholesky failed at pivot 17")
+        return super().fit_eval(kernel, lengthscales, variance, noise, mean_c, want_grad)
+
+
+def _model_on(engine_cls, monkeypatch, **kw):
+    from pygpso_amd.kernels import Constant, Matern52
+    from pygpso_amd.model import HipGPR
+    from tests.helpers import synthetic_problem
+
+    engine_cls.opened = []
+    monkeypatch.setattr(HipGPR, "_open_engine", lambda self, dtype: engine_cls(dtype))
+    X, y = synthetic_problem(60, 2, seed=6)
+    model = HipGPR(data=(X, y[:, None]), kernel=Matern52(lengthscales=0.4, variance=1.5), mean_function=Constant(0.0),
+                   noise_variance=3.0e-2, dtype="float32", **kw)
+    model.fused_transforms = False
+    return model, X, y
+
+
+def test_notpd_inside_a_float32_search_reopens_the_engine_as_mixed_and_restarts(monkeypatch, caplog):
+    from oracle import gpr
+    from pygpso_amd.kernels import Scipy
+
+    model, X, y = _model_on(_FloatEngineThatLosesPD, monkeypatch)
+    theta0 = gpr.Theta("Matern52", np.array([0.4]), 1.5, 3.0e-2, 0.0)
+    want, info = gpr.fit(theta0, X, y, return_info=True)  # the reference's float64 search from the same start
+    assert want.noise < 5.0e-3  # (the search's path crosses the level at which the float engine fails)
+    with caplog.at_level("WARNING"):
+        res = Scipy().minimize(model.training_loss, model.trainable_variables)
+    first, second = _FloatEngineThatLosesPD.opened
+    assert first.dtype_name == "float32" and first.closed and second.dtype_name == "mixed" and model.engine is second
+    assert model.fit_escalations == 1 and "reopening the GP posterior as a 'mixed' engine" in caplog.text
+    # one history in one arithmetic: the restarted search IS the float64 search from theta_0 -- same iterates, same optimum
+    # (the model's chain rule and the oracle's differ in the last bits: the iterates agree to ~1e-8)
+    assert res.nfev == info.nfev and np.allclose(res.x, info.x, rtol=1e-6, atol=1e-6)
+    assert abs(model.likelihood.variance - want.noise) <= 1e-6 * want.noise and abs(model.kernel.variance - want.variance) <= 1e-6 * want.variance
+    want = gpr.Theta("Matern52", np.atleast_1d(model.kernel.lengthscales), model.kernel.variance, model.likelihood.variance,
+                     model.mean_function.c)
+    # ... and the model predicts from the new engine
+    mean, var = model.predict_y(X[:4])
+    mean_ref, var_ref = gpr.predict_y(gpr.posterior(want, X, y), X[:4])
+    assert np.allclose(mean[:, 0], mean_ref, atol=1e-12) and np.allclose(var[:, 0], var_ref, atol=1e-12)
+
+
+def test_notpd_without_escalation_or_on_a_float64_engine_is_the_callers(monkeypatch):
+    from pygpso_amd.kernels import Scipy
+
+    model, X, y = _model_on(_FloatEngineThatLosesPD, monkeypatch, escalate=False)
+    with pytest.raises(np.linalg.LinAlgError, match="pivot 17"):
+        Scipy().minimize(model.training_loss, model.trainable_variables)
+    assert len(_FloatEngineThatLosesPD.opened) == 1 and model.kernel.variance == 1.5  # nothing reopened, nothing assigned
+
+    class F64ThatFails(_FloatEngineThatLosesPD):
+        def fit_eval(self, *a, **kw):
+            raise np.linalg.LinAlgError("K + noise*I is not positive definite: Cholesky failed at pivot 3")
+
+    model, X, y = _model_on(F64ThatFails, monkeypatch)
+    model.engine.dtype_name = "mixed"  # a float64 FIT that fails has nowhere to go: as in the reference, the error escapes
+    with pytest.raises(np.linalg.LinAlgError, match="pivot 3"):
+        Scipy().minimize(model.training_loss, model.trainable_variables)
+    # an engine the model does not own is never replaced
+    eng = _FloatEngineThatLosesPD("float32")
+    from pygpso_amd.kernels import Constant, Matern52
+    from pygpso_amd.model import HipGPR
+
+    m2 = HipGPR(data=(X, y[:, None]), kernel=Matern52(lengthscales=0.4, variance=1.5), mean_function=Constant(0.0),
+                noise_variance=3.0e-2, engine=eng)
+    m2.fused_transforms = False
+    with pytest.raises(np.linalg.LinAlgError):
+        Scipy().minimize(m2.training_loss, m2.trainable_variables)
+    assert m2.engine is eng
+
+
+def test_a_fit_at_the_stored_hyperparameters_escalates_too(monkeypatch):
+    """``_ensure_resident`` (a predict after ``model.data = ...`` / after loading a saved surrogate) fits at the stored
+    hyper-parameters: a float32 engine that cannot factorise there is replaced the same way."""
+    model, X, y = _model_on(_FloatEngineThatLosesPD, monkeypatch)
+    model.likelihood.variance = 1.0e-3
+    mean, var = model.predict_y(X[:4])
+    assert model.engine.dtype_name == "mixed" and np.all(np.isfinite(mean))
+
+
+def test_a_failed_append_leaves_model_and_surrogate_in_one_state():
+    """``append_data`` claimed N + k points and a resident posterior BEFORE the device call; a failing append
+    left the model describing something the device did not hold."""
+    from pygpso_amd.kernels import Constant, Matern52
+    from tests.helpers import synthetic_problem
+
+    class Eng(OracleEngine):
+        dtype_name = "float64"
+        fail = False
+
+        def append(self, Xn, yn):
+            if type(self).fail:
+                raise np.linalg.LinAlgError("the appended block's Cholesky failed at pivot 31")
+            return super().append(Xn, yn)
+
+        def set_timing(self, on):
+            pass
+
+    X, y = synthetic_problem(40, 2, seed=4)
+    surr = GPRSurrogate(gp_kernel=Matern52(lengthscales=0.25, variance=1.0), gp_meanf=Constant(0.0), refit_every=5)
+    surr.engine_factory = Eng
+    surr.append(X[:30], y[:30])
+    surr.gp_update()
+    model = surr.gpflow_model
+    model.fused_transforms = False
+    evals = model.num_loss_evals
+    Eng.fail = True
+    with pytest.raises(np.linalg.LinAlgError):
+        model.append_data(X[30:32], y[30:32])
+    assert model.data[0].shape[0] == 32 and not model._resident and model._device_theta is None
+    assert model.engine.n == 32  # ... and the engine was handed exactly that data
+    model.data = (X[:30], y[:30, None])
+    # through the surrogate: the update re-optimises instead (counted as an update, the points are all there)
+    updates = surr._updates
+    surr.append(X[30:33], y[30:33])
+    surr.gp_update()
+    assert model.num_loss_evals > evals and model.data[0].shape[0] == 33 and surr._updates == updates + 1
+    Eng.fail = False
+    evals = model.num_loss_evals
+    surr.append(X[33:35], y[33:35])
+    surr.gp_update()  # the next update appends again
+    assert model.num_loss_evals == evals and model.data[0].shape[0] == 35

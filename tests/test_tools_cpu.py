@@ -52,3 +52,21 @@ def test_full_size_launch_mean(tmp_path):
     rec = json.load(open(out))
     assert rec["launches"] == 3 and rec["full_size_launches"] == 2
     assert rec["mean_ns_full_size"] == 850.0 and abs(rec["mean_ns_all_launches"] - (800 + 900 + 200) / 3) < 1e-9
+
+
+def test_roofline_fit_prices_a_fit_against_the_arithmetic_that_ran():
+    """``roofline_fit`` always used the f32 MFMA peak -- a two-level float fit on fp16 pieces came out at
+    frac 1.388.  The peak now follows HipGPEngine.fit_math(); the committed round-5 times give fractions below 1."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    c5 = bench.roofline_fit(16384, 40, "float32", {"posterior": 14.6, "nlml_grad": 20.2, "append_k7": 0.40}, "f16x3")
+    assert c5["peak"] == 2500.0 / 3 and c5["fit_math"] == "f16x3"
+    assert abs(c5["nlml_grad"]["frac"] - 0.26) < 0.01 and abs(c5["posterior"]["frac"] - 0.12) < 0.01  # (the verdict's recomputation)
+    assert bench.roofline_fit(8192, 20, "float32", {"posterior": 3.7}, "bf16x6")["peak"] == 2500.0 / 6
+    c3 = bench.roofline_fit(2048, 12, "float32", {"posterior": 0.556}, "f32")
+    assert c3["peak"] == 157.3 and abs(c3["posterior"]["frac"] - 0.034) < 0.002
+    f64 = bench.roofline_fit(8192, 20, "mixed", {"posterior": 9.64}, "f64")
+    assert f64["peak"] == 78.6 and abs(f64["posterior"]["frac"] - 0.24) < 0.01
+    for rec in (c5, c3, f64):
+        assert all(rec[k]["frac"] < 1.0 for k in ("posterior", "nlml_grad", "append_k7") if k in rec)

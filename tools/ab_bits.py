@@ -52,6 +52,24 @@ def worker():
             h = hashlib.sha1(mean.tobytes() + var.tobytes() + np.asarray(idx).tobytes() + np.asarray(ucb).tobytes()).hexdigest()[:12]
             out[f"N{n} D{d} {kernel} | {dtype} {math} gen={gen} contraction={contraction}"] = h
             eng.close()
+    # gpso_append (round 6: the same arithmetic in three launches instead of six + two copies): fit N - k, append k, hash what
+    # the extended posterior is -- NLML, the factor's new rows, alpha, predictions
+    from pygpso_amd import _lib as L
+
+    for n, d, k, dtype in [(2048, 12, 7, "float32"), (2048, 12, 1, "mixed"), (1000, 5, 20, "float64"), (4096, 6, 40, "float32"),
+                           (4096, 6, 64, "float64"), (300, 3, 3, "float64"), (8192, 20, 7, "float32")]:
+        X, y = synthetic_problem(n, d, seed=2)
+        Xs = synthetic_leaves(1500, d, seed=3)
+        eng = HipGPEngine(dtype, precision_check=False)
+        eng.set_data(X[:n - k], y[:n - k])
+        eng.fit_eval("Matern52", 0.25 * np.sqrt(d) * np.ones(1), 1.0, 1e-3, float(y.mean()), want_grad=False)
+        eng.predict(Xs[:256])
+        f, in_place = eng.append(X[n - k:], y[n - k:])
+        mean, var = eng.predict(Xs)
+        h = hashlib.sha1(np.float64(f).tobytes() + mean.tobytes() + var.tobytes() + eng.get_vector(L.VEC_ALPHA).tobytes()
+                         + (eng.get_matrix(L.MAT_LINV)[n - k:].tobytes() if n <= 4096 else b"")).hexdigest()[:12]
+        out[f"append N{n - k}+{k} D{d} {dtype} in_place={in_place}"] = h
+        eng.close()
     print("AB_BITS " + json.dumps(out), flush=True)
 
 

@@ -148,5 +148,42 @@ for case in range(N_CASES):
     status = "ok " if ok else "BAD"
     bad += (not ok)
     print(f"{status} {tag} " + " ".join(f"{k_}={v:.1e}" for k_, v in errs.items()))
+# (round 6) gpso_append where it was built to run: a few cases per sweep at N in [2000, 5000] -- the passes' chunking, the
+# 64-wide instantiation, float and double contexts -- against the oracle's from-scratch posterior of the N + k points
+N_LARGE = int(os.environ.get("FUZZ_LARGE_APPENDS", "3"))
+rng_l = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1234")) * 7919 + 17)
+for case in range(N_LARGE):
+    dtype = str(rng_l.choice(["float64", "float32", "mixed"]))
+    n = int(rng_l.integers(2000, 5001))
+    d = int(rng_l.choice([2, 6, 12, 20, 40]))
+    k_new = int(rng_l.choice([1, 3, 7, 20, 33, 64]))
+    noise = float(rng_l.choice([1e-3, 1e-2]))
+    X, y = synthetic_problem(n + k_new, d, seed=int(rng_l.integers(1 << 30)))
+    Xs = synthetic_leaves(700, d, seed=int(rng_l.integers(1 << 30)))
+    th = gpr.Theta("Matern52", 0.25 * np.sqrt(d) * np.ones(1), float(rng_l.uniform(0.7, 1.5)), noise, float(y.mean()))
+    post_a = gpr.posterior(th, X, y)
+    mean_r, var_r = gpr.predict_y(post_a, Xs)
+    eng = HipGPEngine(dtype)
+    eng.set_data(X[:n], y[:n])
+    tag = f"{dtype:7s} large append n={n:5d} +{k_new:2d} d={d:2d} noise={noise:g}"
+    try:
+        eng.fit_eval(th.kernel, th.lengthscales, th.variance, th.noise, th.mean_c, want_grad=bool(rng_l.random() < 0.5))
+        if rng_l.random() < 0.5:
+            eng.predict(Xs[:64])  # (pieces built before / after the append)
+        f_a, in_place = eng.append(X[n:], y[n:])
+        mean_a, var_a = eng.predict(Xs)
+    except (GpsoPrecisionError, np.linalg.LinAlgError) as e:
+        ok = dtype != "float64"
+        refused += 1
+        bad += (not ok)
+        print(f"{'ref' if ok else 'BAD'} {tag} refused: {type(e).__name__} {str(e)[:200]}")
+        continue
+    ys = max(1.0, float(np.max(np.abs(y))))
+    e_f = 1e-9 if dtype != "float32" else 5e-5
+    e_m, e_v = (1e-8 * ys, 1e-8 * th.variance) if dtype == "float64" else (3.3e-4 * ys, 2.4e-5 * th.variance)  # (float: FLOAT_BOUNDS["C4"])
+    errs = dict(nlml=abs(f_a - post_a.nlml) / abs(post_a.nlml), mean=float(np.max(np.abs(mean_a - mean_r))), var=float(np.max(np.abs(var_a - var_r))))
+    ok = errs["nlml"] <= e_f and errs["mean"] <= e_m and errs["var"] <= e_v
+    bad += (not ok)
+    print(f"{'ok ' if ok else 'BAD'} {tag} {'in place' if in_place else 'refit'} " + " ".join(f"{k_}={v:.1e}" for k_, v in errs.items()))
 print(f"{N_CASES} cases, {refused} refused, {bad} bad, {time.time() - t0:.1f} s")
 sys.exit(1 if bad else 0)
