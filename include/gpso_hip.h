@@ -277,6 +277,25 @@ void gpso_shard_range(int64_t m, int rank, int world, int64_t* lo, int64_t* hi);
 /* collective: the posterior resident on `root` (after gpso_fit_eval / gpso_set_posterior) becomes
  * resident on every rank -- one RCCL broadcast per buffer of gpso_posterior_buffers, device to device */
 int gpso_broadcast_posterior(gpso_ctx* ctx, int root);
+/* After gpso_append on the root: bring the peers up to date moving ONLY what the appends wrote -- the new rows of the scaled
+ * inputs and of each predict-ready copy of L^-1 (whole 16-row tile rows), alpha, the hyper block: ~1.1 MB instead of the 1.07
+ * GB of gpso_broadcast_posterior for 7 new points at N = 16 384 (the reference re-creates its model on every update,
+ * gpso/gp_surrogate.py:496-498; there is no hand-off to replace).  Collective, same header / verdict protocol: the root
+ * offers rows when its posterior is the one of the last hand-off extended in place (same predict math, same fp16 scale);
+ * every rank says whether it holds that base; if all do, the ranges travel (one ncclBroadcast each, grouped) and the call
+ * returns GPSO_OK -- otherwise EVERY rank takes the whole range as gpso_broadcast_posterior does and the call returns 1.
+ * gpso_last_count(ctx, 0) = the bytes that travelled. */
+int gpso_broadcast_posterior_rows(gpso_ctx* ctx, int root);
+/* The same decision without a communicator (hand-offs by plain device copies: several contexts of one process, tests): the
+ * ranges [offsets[i], offsets[i] + nbytes[i]) of the posterior arena -- offsets as gpso_posterior_span reports them, valid on
+ * every context of the same shape and type (gpso_posterior_span_at) -- that a peer holding the posterior of the last
+ * hand-off lacks.  Returns their number (<= 9; cap >= 10): 0 = the peer is up to date; when rows do not apply, ONE range: the
+ * whole span.  After copying them the receiver calls gpso_adopt_posterior, the sender gpso_posterior_mark_synced (which
+ * gpso_broadcast_posterior / _rows do themselves on every rank, and a receiver's gpso_adopt_posterior does not: a receiver
+ * that becomes a sender marks explicitly). */
+int gpso_posterior_dirty_ranges(gpso_ctx* ctx, int64_t* offsets, int64_t* nbytes, int cap);
+int gpso_posterior_mark_synced(gpso_ctx* ctx);
+
 /* collective gpso_best_ucb: xs holds THIS rank's rows gpso_shard_range(m_global, rank, world) of the
  * batch (m_local of them); seg_off[nseg+1] (host, NULL = one segment) is in GLOBAL rows; idx is relative
  * to the global segment start.  Outputs are identical on every rank. */

@@ -103,6 +103,9 @@ struct Engine {
   virtual int set_option_f64(int option, double value) = 0;
   virtual int precision_info(double* out) = 0;
   virtual int broadcast_posterior(int root) = 0;
+  virtual int broadcast_posterior_rows(int root) = 0;
+  virtual int posterior_dirty_ranges(int64_t* offsets, int64_t* nbytes, int cap) = 0;
+  virtual int posterior_mark_synced() = 0;
   virtual int best_ucb_sharded(const void* xs, int xs_dtype, int xs_mem, int64_t m_local, int64_t m_global,
                                const int64_t* seg_off, int nseg, double varsigma, int64_t* idx, double* mean,
                                double* var, double* ucb) = 0;
@@ -726,6 +729,55 @@ struct EngineT : Engine {
   }
   bool linv_p_valid = false;  // the packed f32 / f64 L^-1 of the resident posterior is here (a receiver of a split posterior: no)
 
+  // ---- what the peers of a group hold of THIS posterior (round 6: gpso_broadcast_posterior_rows) --------------------------------
+  // A hand-off (gpso_broadcast_posterior, or a span copy followed by gpso_posterior_mark_synced / gpso_adopt_posterior)
+  // records the rows the other side then holds; gpso_append extends the posterior in place and leaves the record alone, so
+  // the NEXT hand-off may move only what the appends wrote -- the new rows of the scaled inputs and of each predict-ready
+  // copy of L^-1, alpha, the hyper block -- instead of the whole range (C5: ~1.1 MB instead of 1.07 GB for 7 points).
+  // Anything that makes another posterior (gpso_set_data, gpso_fit_eval, gpso_set_posterior, a new shape) clears it.
+  int64_t sync_n = -1;      // rows the peers hold; -1: unknown
+  int sync_math = -1;       // predict math in use then (the ladder may move: other pieces)
+  float sync_scale = 0.0f;  // fp16 split: the scale the peers' planes were packed with (an append that crosses a power of two repacks all rows)
+  void forget_peers() { sync_n = -1; }
+  // the scale slot's [1] (2^-sa) of the fp16 split as the device holds it now; 0 where it does not apply
+  int current_split_scale(float* out) {
+    *out = 0.0f;
+    if (!(kFloatPredict && f16_split() && bf16_usable() && linv_b_valid)) return GPSO_OK;
+    float* h = reinterpret_cast<float*>(ctx->pinned_scratch(256) + 124);  // (a slot of the scratch nothing else reads)
+    HIPCHECK(hipMemcpyAsync(h, f16_scale() + 1, 4, hipMemcpyDeviceToHost, st()));
+    HIPCHECK(hipStreamSynchronize(st()));
+    *out = *h;
+    return GPSO_OK;
+  }
+  // ranges of the arena (offset, bytes) that differ between the posterior of the first n0 rows and this one of n rows at the
+  // same hyper-parameters, predict math and fp16 scale -- the same list on every rank (a function of n0, n, the layout)
+  void rows_ranges(int64_t n0, std::vector<std::pair<int64_t, int64_t>>& out) const {
+    out.clear();
+    const char* base = static_cast<const char*>(arena.p);
+    auto rel = [&](const DevBuf& b, size_t off, size_t bytes) {
+      if (bytes) out.push_back({(int64_t)(static_cast<const char*>(b.p) - base + off), (int64_t)bytes});
+    };
+    const int64_t rt0 = n0 / 16, rt1 = (n - 1) / 16, npad16 = npad / 16;
+    rel(hyper, 0, (size_t)(kHyperHeader + kMaxD) * 8);
+    rel(xs64, (size_t)n0 * dp * 8, (size_t)(n - n0) * dp * 8);
+    rel(xs_p64, (size_t)rt0 * dp * 16 * 8, (size_t)(rt1 + 1 - rt0) * dp * 16 * 8);  // MFMA fragments: 16-row groups
+    rel(xnorm64, (size_t)n0 * 8, (size_t)(n - n0) * 8);
+    rel(alpha, 0, (size_t)npad * sizeof(TP));  // alpha_1 += R^T a_2: every entry moved
+    if (math_in_use() != GPSO_MATH_NATIVE) {
+      rel(linv_b, 0, 256);  // the scale slot
+      for (int s_ = 0; s_ < nsplit(); ++s_)  // plane s: tile row rt at ((s npad16 + rt) npad 32) bytes behind the slot
+        rel(linv_b, 256 + ((size_t)s_ * npad16 + rt0) * npad * 32, (size_t)(rt1 + 1 - rt0) * npad * 32);
+    } else {
+      const size_t t0 = (size_t)rt0 * (rt0 + 1) / 2, t1 = (size_t)(rt1 + 1) * (rt1 + 2) / 2;  // tiles row-major over the triangle
+      rel(linv_p, t0 * 256 * sizeof(TP), (t1 - t0) * 256 * sizeof(TP));
+    }
+  }
+  // can the peers be brought up to date by rows?  (root side; scale = current_split_scale)
+  bool rows_apply(float scale) const {
+    return have_post && sync_n >= 0 && sync_n <= n && sync_math == math_in_use() && scale == sync_scale &&
+           (sync_n == n || sync_n / 16 <= (n - 1) / 16);
+  }
+
   int ensure_fit_buffers() {
     int rc;
     const size_t s = sizeof(TF);
@@ -829,6 +881,7 @@ struct EngineT : Engine {
     have_data = true;
     have_post = have_kinv = chol_valid = linv_p_valid = false;
     st_done = st_have = false;
+    forget_peers();
     return GPSO_OK;
   }
 
@@ -845,6 +898,7 @@ struct EngineT : Engine {
     if ((rc = set_theta(kernel, ls, n_ls_, variance, noise, mean_c, !small))) return rc;
     have_post = have_kinv = chol_valid = false;
     st_done = st_have = false;
+    forget_peers();
     reset_generation();
     hipStream_t s = st();
     double fit_token = 0.0;
@@ -1104,6 +1158,7 @@ struct EngineT : Engine {
     have_data = false;  // y unknown: a later fit needs gpso_set_data
     have_post = have_kinv = chol_valid = false;
     st_done = st_have = false;
+    forget_peers();
     reset_generation();
     if ((rc = scale_inputs())) return rc;
     HIPCHECK(hipMemsetAsync(linv.p, 0, (size_t)npad * npad * sizeof(TF), s));
@@ -2311,9 +2366,121 @@ struct EngineT : Engine {
     }
     RCCLCHECK(R.Broadcast(span_ptr, span_ptr, (size_t)span_bytes, ncclChar, root, ctx->comm, s));
     ctx->last_count[0] = ctx->last_count[1] = span_bytes;  // (gpso_last_count after a broadcast: the bytes that travelled)
-    if (!is_root) return adopt_posterior();  // (synchronises the stream)
-    HIPCHECK(ctx->wait(s));
+    if (!is_root) {
+      if ((rc = adopt_posterior())) return rc;  // (synchronises the stream)
+    } else {
+      HIPCHECK(ctx->wait(s));
+    }
+    return posterior_mark_synced();  // every rank: the group holds these n rows in this math at this scale
+  }
+
+  // ---- the peers of a group brought up to date after gpso_append: only what the appends wrote travels -----------------------
+  int posterior_mark_synced() override {
+    if (!have_post) return ctx->fail(GPSO_E_STATE, "no posterior resident");
+    float scale = 0.0f;
+    int rc = current_split_scale(&scale);
+    if (rc) return rc;
+    sync_n = n;
+    sync_math = math_in_use();
+    sync_scale = scale;
     return GPSO_OK;
+  }
+  // the ranges (offsets into the posterior arena: the same on every context of this shape and type) that a peer holding the
+  // posterior as of the last hand-off lacks; returns their number, 0 when the peer is up to date, and -- when rows do not
+  // apply (another posterior since, another predict math, the fp16 scale crossed a power of two) -- ONE range: the whole span
+  int posterior_dirty_ranges(int64_t* offsets, int64_t* nbytes, int cap) override {
+    if (!offsets || !nbytes || cap < 10) return ctx->fail(GPSO_E_ARG, "need room for 10 ranges");
+    void* span_ptr = nullptr;
+    int64_t span_off = 0, span_bytes = 0;
+    int rc = posterior_span(&span_ptr, &span_off, &span_bytes);  // (settles the arithmetic choices, builds pending pieces)
+    if (rc) return rc;
+    float scale = 0.0f;
+    if ((rc = current_split_scale(&scale))) return rc;
+    if (!rows_apply(scale)) {
+      offsets[0] = span_off;
+      nbytes[0] = span_bytes;
+      return 1;
+    }
+    if (sync_n == n) return 0;
+    std::vector<std::pair<int64_t, int64_t>> rr;
+    rows_ranges(sync_n, rr);
+    for (size_t i = 0; i < rr.size(); ++i) {
+      offsets[i] = rr[i].first;
+      nbytes[i] = rr[i].second;
+    }
+    return (int)rr.size();
+  }
+  // Collective.  Returns GPSO_OK when only rows travelled, 1 when the whole range did (any rank that cannot take rows -- it
+  // never received this posterior, holds another shape / math / scale -- makes every rank take the whole), < 0 on error;
+  // gpso_last_count(ctx, 0) = the bytes that travelled.  Same header / verdict protocol as gpso_broadcast_posterior.
+  int broadcast_posterior_rows(int root) override {
+    int rc = need_comm();
+    if (rc) return rc;
+    RcclApi& R = RcclApi::get();
+    if (root < 0 || root >= ctx->world) return ctx->fail(GPSO_E_ARG, "root %d outside the group of %d", root, ctx->world);
+    hipStream_t s = st();
+    const bool is_root = ctx->rank == root;
+    if ((rc = ensure(bhdr, 256))) return rc;
+    int64_t* hd = as<int64_t>(bhdr);
+    int64_t* host = reinterpret_cast<int64_t*>(ctx->pinned_scratch(32));
+    if (!host) return ctx->fail(GPSO_E_OOM, "pinned host scratch");
+    // the root says what it can offer: rows since n_base in (math, scale), or nothing but the whole range (n_base = -1; also
+    // when anything is wrong on the root: the full call then reports it on every rank)
+    int64_t n_base = -1, n_now = 0, mth = 0, scale_bits = 0;
+    if (is_root) {
+      void* span_ptr = nullptr;
+      int64_t span_off = 0, span_bytes = 0;
+      float scale = 0.0f;
+      if (have_post && posterior_span(&span_ptr, &span_off, &span_bytes) == GPSO_OK && current_split_scale(&scale) == GPSO_OK &&
+          rows_apply(scale) && !(check && st_have && have_data && !st_pass())) {
+        n_base = sync_n;
+        n_now = n;
+        mth = math_in_use();
+        scale_bits = (int64_t)__builtin_bit_cast(unsigned, scale);
+      }
+      host[0] = n_base; host[1] = n_now; host[2] = mth; host[3] = scale_bits; host[4] = npad; host[5] = dp; host[6] = host[7] = 0;
+      HIPCHECK(hipMemcpyAsync(hd, host, 64, hipMemcpyHostToDevice, s));
+    }
+    RCCLCHECK(R.Broadcast(hd, hd, 64, ncclChar, root, ctx->comm, s));
+    HIPCHECK(hipMemcpyAsync(host, hd, 64, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    n_base = host[0]; n_now = host[1]; mth = host[2]; scale_bits = host[3];
+    const int64_t r_npad = host[4], r_dp = host[5];
+    // can THIS rank take rows?  (the peers' record is what the last hand-off left on them)
+    int64_t mine = 1;
+    if (n_base < 0) mine = 0;
+    else if (!is_root)
+      mine = (have_post && arena.p != nullptr && sync_n == n_base && n == n_base && npad == r_npad && dp == r_dp && math_in_use() == (int)mth &&
+              (int64_t)__builtin_bit_cast(unsigned, sync_scale) == scale_bits && n_now <= npad) ? 1 : 0;
+    int64_t agreed = 0;
+    if ((rc = agree_min(hd + 8, host + 8, mine, &agreed))) return rc;
+    if (agreed != 1) {
+      rc = broadcast_posterior(root);
+      return rc == GPSO_OK ? 1 : rc;
+    }
+    int64_t moved = 0;
+    if (n_now > n_base) {
+      const int64_t n_keep = n;
+      n = n_now;  // (rows_ranges describes the posterior of n_now rows)
+      std::vector<std::pair<int64_t, int64_t>> rr;
+      rows_ranges(n_base, rr);
+      n = n_keep;
+      char* base = static_cast<char*>(arena.p);
+      RCCLCHECK(R.GroupStart());
+      for (const auto& r : rr) {
+        RCCLCHECK(R.Broadcast(base + r.first, base + r.first, (size_t)r.second, ncclChar, root, ctx->comm, s));
+        moved += r.second;
+      }
+      RCCLCHECK(R.GroupEnd());
+    }
+    ctx->last_count[0] = ctx->last_count[1] = moved;
+    if (!is_root) {
+      n = n_now;
+      if ((rc = adopt_posterior())) return rc;  // (reads the hyper block that just arrived; synchronises the stream)
+    } else {
+      HIPCHECK(ctx->wait(s));
+    }
+    return posterior_mark_synced();
   }
 
   // ------------------------------------------------------------------------------------------
@@ -2469,6 +2636,7 @@ struct EngineT : Engine {
     if (rc) return rc;
     have_data = have_post = have_kinv = chol_valid = linv_p_valid = false;
     st_done = st_have = false;
+    forget_peers();
     return GPSO_OK;
   }
 
@@ -2478,9 +2646,13 @@ struct EngineT : Engine {
     if (!h) return ctx->fail(GPSO_E_OOM, "pinned host scratch");
     HIPCHECK(hipMemcpyAsync(h, hyper.p, (size_t)(kHyperHeader + kMaxD) * 8, hipMemcpyDeviceToHost, st()));
     HIPCHECK(hipStreamSynchronize(st()));
-    if ((int64_t)h[0] != n || (int)h[1] != d)
+    // (a posterior EXTENDED by gpso_append on the sender arrives with more rows than the buffers were announced for: the
+    // layout is a function of the padded size, which an in-place append cannot change)
+    const int64_t hn = (int64_t)h[0];
+    if ((int)h[1] != d || hn < n || hn > npad)
       return ctx->fail(GPSO_E_ARG, "received posterior is for n=%lld d=%d, buffers were sized for n=%lld d=%d",
                        (long long)h[0], (int)h[1], (long long)n, d);
+    n = hn;
     kp.kernel = (int)h[2];
     n_ls = (int)h[3];
     kp.variance = h[4];
@@ -2906,6 +3078,21 @@ void gpso_shard_range(int64_t m, int rank, int world, int64_t* lo, int64_t* hi) 
 int gpso_broadcast_posterior(gpso_ctx* ctx, int root) {
   ENTER();
   return ctx->eng->broadcast_posterior(root);
+}
+
+int gpso_broadcast_posterior_rows(gpso_ctx* ctx, int root) {
+  ENTER();
+  return ctx->eng->broadcast_posterior_rows(root);
+}
+
+int gpso_posterior_dirty_ranges(gpso_ctx* ctx, int64_t* offsets, int64_t* nbytes, int cap) {
+  ENTER();
+  return ctx->eng->posterior_dirty_ranges(offsets, nbytes, cap);
+}
+
+int gpso_posterior_mark_synced(gpso_ctx* ctx) {
+  ENTER();
+  return ctx->eng->posterior_mark_synced();
 }
 
 int gpso_best_ucb_sharded(gpso_ctx* ctx, const void* xs, int xs_dtype, int xs_mem, int64_t m_local,

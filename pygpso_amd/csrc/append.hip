@@ -11,12 +11,9 @@
 // i.e. TWO passes over the resident L^-1 (row pass: B = X11 K12; column pass: W = B^T X11) instead of a factorisation:
 // N^2 s bytes and 2 N^2 k flops -- HBM-bound, against N^3 / 3 flops.  All arithmetic is double whatever the matrix type
 // TF (the loads are TF, the k-wide accumulators double): the passes are bandwidth-bound, and S = K22 - L21 L21^T is a
-// cancellation the float fit also pays for.  Round 5 ran the six steps below as six launches behind two host-to-device
-// copies (60 us at C3, all of it dependency gaps); round 6 runs them as THREE: the cross kernel reads the new points from
-// pinned host memory itself, and each pass carries its consumer in its epilogue behind last-arriver tickets (agent-scope
-// fences around one atomic counter per 64-row / 64-column block, as the one-launch predict kernel does) -- the last chunk of
-// a row block to finish sums the chunks IN ORDER (same bits as the separate kernel) and forms the block's partial Gram, the
-// last row block factorises the corner; the last chunk of a column block writes that block's new rows.  Steps:
+// cancellation the float fit also pays for.  Kernels (one stream, in order; round 6: the new points are read from pinned host
+// memory by the cross kernel itself -- no copies in front of the first launch -- and the repack of the predict-ready copies is one
+// launch instead of two):
 //
 //   append_cross_kernel      K12 (n x k) and K22 + noise I (k x k) from the scaled inputs; the new rows' scaled inputs,
 //                            norms and MFMA fragments land where the fit leaves them (same formulas as scale_x_kernel /
@@ -69,7 +66,6 @@ __global__ __launch_bounds__(256) void append_cross_kernel(AppendArgs a) {
     if (tid < k) a.xnorm64[n + tid] = nn[tid];
     for (int e = tid; e < k * d; e += 256) a.x64[n * d + e] = a.xnew[e];
     if (tid < k) a.y64[n + tid] = a.ynew[tid];
-    for (int e = tid; e < a.ntickets; e += 256) a.tickets[e] = 0u;  // (also zero after every completed call: a fresh scratch buffer is not)
     if (tid == 0) {
       *a.info = INT_MAX;
       if (a.f16_scal != nullptr) a.f16_scal[3] = a.f16_scal[1];  // the scale the resident pieces were packed with
@@ -103,9 +99,9 @@ __global__ __launch_bounds__(256) void append_cross_kernel(AppendArgs a) {
   }
 }
 
-// ---- 3. B from its chunks; partial Gram of [B | a1] per 64-row block (epilogue of the row pass) ----------------------------
-// Run by the LAST chunk of row block `tb` to finish: sums the chunks in order (deterministic), writes B, forms the block's
-// partial [B | a1]^T [B | a1].  tile: >= 64 (KP + 2) doubles of LDS.
+// ---- 3. B from its chunks; partial Gram of [B | a1] per 64-row block -----------------------------------------------------
+// sums the chunks of row block `tb` in order (deterministic), writes B, forms the block's partial [B | a1]^T [B | a1].
+// tile: 64 (KP + 2) doubles of LDS.
 template <typename TF, int KP>
 __device__ __forceinline__ void append_gram_part(const double* __restrict__ bpart, int nq, int64_t npad, int tb,
                                                  double* __restrict__ Bm, const TF* __restrict__ white, int64_t n,
@@ -136,7 +132,7 @@ __device__ __forceinline__ void append_gram_part(const double* __restrict__ bpar
   }
 }
 
-// ---- 4. the k x k corner: Schur complement, Cholesky, inverse, a2, NLML (run by the LAST row block's workgroup) -------------
+// ---- 4. the k x k corner: Schur complement, Cholesky, inverse, a2, NLML (ONE workgroup) --------------------------------------
 // global sm (doubles): [0, 4096) L22 (ld 64) | [4096, 8192) L22^-1 (ld 64) | [8192, 8256) a2
 // LDS (doubles, carved from `lds`): S [KP x KP] | X, lower triangle packed by rows: (i, j <= i) at i (i + 1) / 2 + j | v | a2 | psum
 template <int KP>
@@ -256,13 +252,11 @@ __device__ __forceinline__ void append_chol(const AppendArgs& a, int nchunk, dou
   }
 }
 
-// ---- 5b. the new rows (epilogue of the column pass): R = -L22^-1 W per column, alpha, diag(K_y^-1), the k x k corner --------
+// ---- 5b. the new rows: R = -L22^-1 W per column, alpha, diag(K_y^-1), the k x k corner ------------------------------------
 template <typename TP>
 __device__ __forceinline__ void store_alpha_p(void* alpha_p, int64_t i, double v) {
   static_cast<TP*>(alpha_p)[i] = (TP)v;
 }
-template <int KP>
-constexpr int append_finish_lds_doubles() { return KP * (KP + 1) / 2 + KP; }
 // L22^-1 (packed) and a2 from the corner's global record into LDS
 __device__ __forceinline__ void append_load_corner(const AppendArgs& a, double* Xs, double* a2s) {
   const int tid = threadIdx.x, k = a.k;
@@ -312,20 +306,18 @@ __device__ __forceinline__ void append_finish_corner(const AppendArgs& a, const 
     if (lane == 0 && m > 0.0f) atomicMax(reinterpret_cast<unsigned*>(a.f16_scal), __builtin_bit_cast(unsigned, m));
   }
 }
-// the 64 columns of block tb, one thread per column (wave 0; per-column arithmetic as in round 5's 256-column workgroups: same bits)
+// one thread per column c: R = -L22^-1 W at that column, alpha, diag(K_y^-1); the wave's largest |new entry| for the fp16 scale
 template <typename TF, typename TP, int KP>
-__device__ __forceinline__ void append_finish_columns(const AppendArgs& a, const double* __restrict__ wpart, int ct, int tb,
+__device__ __forceinline__ void append_finish_columns(const AppendArgs& a, const double* __restrict__ wpart, int ct, int64_t c,
                                                       const double* Xs, const double* a2s, TF* __restrict__ linv, TF* __restrict__ Lf,
                                                       TF* __restrict__ alpha_f) {
-  const int tid = threadIdx.x, k = a.k;
-  if (tid >= 64) return;
+  const int k = a.k;
   const int64_t n = a.n, npad = a.npad;
-  const int64_t c = (int64_t)tb * 64 + tid;
   float m = 0.0f;
   if (c < n) {
     // W[:, c]: the chunks of the column pass that hold tiles of this column block, in order
     const int ntile = (int)((n + 63) / 64);
-    const int q0 = tb / ct, q1 = (ntile - 1) / ct;
+    const int q0 = (int)(c / 64) / ct, q1 = (ntile - 1) / ct;
     double w[KP];
 #pragma unroll
     for (int j = 0; j < KP; ++j) w[j] = 0.0;
@@ -355,19 +347,18 @@ __device__ __forceinline__ void append_finish_columns(const AppendArgs& a, const
   }
   if (a.f16_scal != nullptr) {
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if (tid == 0 && m > 0.0f) atomicMax(reinterpret_cast<unsigned*>(a.f16_scal), __builtin_bit_cast(unsigned, m));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(reinterpret_cast<unsigned*>(a.f16_scal), __builtin_bit_cast(unsigned, m));
   }
 }
 
-// ---- 2. / 5a. the two passes over L^-1, tile by tile, each with its consumer in the epilogue ----------------------------------
+// ---- 2. / 5a. the two passes over L^-1, tile by tile ----------------------------------------------------------------------------
 // One workgroup = one 64-row block of L^-1 (row pass: B = X11 K12) or one 64-column block (column pass: W = X11^T B) times
-// a chunk of `ct` of its 64x64 tiles; grid (tiles per side [+ 1: the corner's workgroup, column pass], nq <= 8).  A tile
-// arrives with 16-byte loads, kDepth tiles ahead of its use (round 5: one ahead -- 3.3 TB/s at C5; the loop is bound by the
-// latency of a load under load, so the bytes in flight per CU are what counts), is masked to the lower triangle / the first
+// a chunk of `ct` of its 64x64 tiles; grid (tiles per side, nq <= 8).  A tile
+// arrives with 16-byte loads, kPassDepth tiles ahead of its use, is masked to the lower triangle / the first
 // n rows and staged in LDS beside the 64 operand rows (K12 / B) of its contraction index; the product runs on the f64
 // matrix instruction (16x16x4: wave g owns 16 rows / columns of the block, the k <= 64 right-hand sides are its 16-wide
 // column blocks), accumulators live across the chunk's tiles.  Partial sums per chunk go to part[q][index][KP]; the
-// consumer -- the LAST chunk of the block to arrive at the block's ticket -- adds the chunks in order (deterministic).
+// consumer adds the chunks in order (deterministic).
 // (First versions, profiles/r05_append_experiments.txt: one wave per row re-reading K12 from the L2 for every row -- 8.6 TB
 // of L2 traffic at N = 16 384 -- and one workgroup per column strip: 0.71 + 1.98 ms at C5, 14 + 183 us at C3; then vector
 // FMAs with scalar operand loads in the inner loop, latency-chained: 0.61 + 0.39 ms, 34 + 36 us.)
@@ -376,18 +367,16 @@ struct PassShape {
   static constexpr int NB = KP <= 16 ? 1 : KP / 16;  // 16-wide blocks of right-hand sides (KP = 8: half a block is padding)
   static constexpr int UW = 16 * NB;
 };
-constexpr int cmax(int x, int y) { return x > y ? x : y; }
 template <typename TF, int KP>
-constexpr int append_pass_lds_bytes() {
-  return cmax(cmax(64 * 65 * (int)sizeof(TF) + 64 * PassShape<KP>::UW * 8, 64 * (KP + 2) * 8),
-              cmax(append_chol_lds_doubles<KP>(), append_finish_lds_doubles<KP>()) * 8);
-}
-constexpr int kPassDepth = 2;  // tiles in flight ahead of the one in use
+constexpr int append_pass_lds_bytes() { return 64 * 65 * (int)sizeof(TF) + 64 * PassShape<KP>::UW * 8; }
+#ifndef GPSO_PASS_DEPTH
+#define GPSO_PASS_DEPTH 2
+#endif
+constexpr int kPassDepth = GPSO_PASS_DEPTH;  // tiles in flight ahead of the one in use
 
-template <typename TF, typename TP, int KP, bool COLS>
-__global__ __launch_bounds__(256) void append_pass_kernel(AppendArgs a, const TF* __restrict__ linv, const double* __restrict__ U,
-                                                          double* __restrict__ part, int ct, TF* __restrict__ linv_w, TF* __restrict__ Lf,
-                                                          TF* __restrict__ white, TF* __restrict__ alpha_f) {
+template <typename TF, int KP, bool COLS>
+__global__ __launch_bounds__(256) void append_pass_kernel(const TF* __restrict__ linv, int64_t n, int64_t npad,
+                                                          const double* __restrict__ U, double* __restrict__ part, int ct) {
   constexpr int EV = 16 / (int)sizeof(TF);  // elements per 16-byte load
   constexpr int VPR = 64 / EV;              // loads per tile row
   constexpr int RPP = 256 / VPR;            // tile rows per pass of the workgroup
@@ -397,25 +386,12 @@ __global__ __launch_bounds__(256) void append_pass_kernel(AppendArgs a, const TF
   constexpr int LD = 65;
   typedef TF vecT __attribute__((ext_vector_type(EV)));
   extern __shared__ __align__(16) unsigned char pass_lds[];
-  __shared__ unsigned last_flag;
   TF* T = reinterpret_cast<TF*>(pass_lds);                                      // the tile, masked, [64][65]
   double* Us = reinterpret_cast<double*>(pass_lds + 64 * LD * sizeof(TF));      // the operand rows, [64][UW]
-  const int64_t n = a.n, npad = a.npad;
   const int tid = threadIdx.x, lane = tid & 63;
   const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tb = blockIdx.x, q = blockIdx.y;
   const int ntile = (int)((n + 63) / 64);
-  if (COLS) {
-    if (*a.info != INT_MAX) return;  // S was not positive definite: the resident posterior stays as it is
-    if (tb == ntile) {               // the corner's workgroup
-      if (q != 0) return;
-      double* Xs = reinterpret_cast<double*>(pass_lds);
-      double* a2s = Xs + KP * (KP + 1) / 2;
-      append_load_corner(a, Xs, a2s);
-      append_finish_corner<TF, TP>(a, Xs, a2s, linv_w, Lf, white, alpha_f);
-      return;
-    }
-  }
   int lo, hi;  // range of the other tile index
   if (!COLS) {
     lo = q * ct;
@@ -500,37 +476,38 @@ __global__ __launch_bounds__(256) void append_pass_kernel(AppendArgs a, const TF
         part[((int64_t)q * npad + (int64_t)tb * 64 + 16 * g + (lane >> 4) + 4 * r) * KP + j] = acc[b][r];
     }
   }
-  // ---- the consumer, behind the block's ticket: this workgroup's partial sums are released before the ticket (thread 0's
-  // agent-scope fence behind the barrier covers every wave's stores: they share one L2), the last arriver acquires behind it
-  const int nlive = COLS ? (ntile - 1) / ct - tb / ct + 1 : tb / ct + 1;  // chunks of this block that hold tiles
-  __syncthreads();
-  if (tid == 0) {
-    __threadfence();
-    last_flag = (atomicAdd(&a.tickets[(COLS ? ntile + 1 : 0) + tb], 1u) == (unsigned)(nlive - 1)) ? 1u : 0u;
-  }
-  __syncthreads();
-  if (!last_flag) return;
-  __threadfence();  // (every thread of the consuming workgroup acquires before it reads the other chunks)
-  if (tid == 0) a.tickets[(COLS ? ntile + 1 : 0) + tb] = 0u;  // (zero between calls)
-  if (!COLS) {
-    append_gram_part<TF, KP>(part, nlive, npad, tb, a.Bm, white, n, a.part, reinterpret_cast<double*>(pass_lds));
-    // the last row block to have its partial Gram factorises the corner
-    __syncthreads();
-    if (tid == 0) {
-      __threadfence();
-      last_flag = (atomicAdd(&a.tickets[ntile], 1u) == (unsigned)(ntile - 1)) ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!last_flag) return;
-    __threadfence();
-    if (tid == 0) a.tickets[ntile] = 0u;
-    append_chol<KP>(a, ntile, reinterpret_cast<double*>(pass_lds));
-  } else {
-    double* Xs = reinterpret_cast<double*>(pass_lds);
-    double* a2s = Xs + KP * (KP + 1) / 2;
-    append_load_corner(a, Xs, a2s);
-    append_finish_columns<TF, TP, KP>(a, part, ct, tb, Xs, a2s, linv_w, Lf, alpha_f);
-  }
+}
+
+// ---- the consumers as kernels of their own ------------------------------------------------------------------------------------
+// (Round 6 measured the alternative the round-5 verdict asked for -- each pass carrying its consumer in its epilogue behind
+// last-arriver tickets, agent-scope fences around one atomic counter per block: 8 launches -> 5, same bits -- and it is SLOWER
+// on this chip: the fused row pass took 31 us at C3 against 7.5 + 7.9 + 11.2 us for pass + Gram + corner as three launches, and
+// at C5 the streaming itself fell from 147 to 244 us per pass with 1 150 workgroups each writing back / invalidating its XCD's L2
+// at its end.  A launch boundary is the cheaper grid-wide synchronisation here: profiles/r06_append_experiments.txt.)
+template <typename TF, int KP>
+__global__ __launch_bounds__(256) void append_gram_part_kernel(const double* __restrict__ bpart, int ct, int64_t npad,
+                                                               double* __restrict__ Bm, const TF* __restrict__ white,
+                                                               int64_t n, double* __restrict__ part) {
+  __shared__ double tile[64 * (KP + 2)];
+  append_gram_part<TF, KP>(bpart, (int)blockIdx.x / ct + 1, npad, (int)blockIdx.x, Bm, white, n, part, tile);
+}
+template <int KP>
+__global__ __launch_bounds__(256) void append_chol_kernel(AppendArgs a, int nchunk) {
+  __shared__ double lds[append_chol_lds_doubles<KP>()];
+  append_chol<KP>(a, nchunk, lds);
+}
+// grid: column blocks of 256 (four 64-column blocks, one wave each) + one workgroup for the k x k corner
+template <typename TF, typename TP, int KP>
+__global__ __launch_bounds__(256) void append_finish_kernel(AppendArgs a, const double* __restrict__ wpart, int ct,
+                                                            TF* __restrict__ linv, TF* __restrict__ Lf,
+                                                            TF* __restrict__ white, TF* __restrict__ alpha_f) {
+  if (*a.info != INT_MAX) return;  // S was not positive definite: the resident posterior stays as it is
+  __shared__ double Xs[KP * (KP + 1) / 2];  // L22^-1, lower triangle packed by rows
+  __shared__ double a2s[KP];
+  append_load_corner(a, Xs, a2s);
+  const int nblk = (int)((a.n + 255) / 256);
+  if ((int)blockIdx.x == nblk) append_finish_corner<TF, TP>(a, Xs, a2s, linv, Lf, white, alpha_f);
+  else append_finish_columns<TF, TP, KP>(a, wpart, ct, (int64_t)blockIdx.x * 256 + threadIdx.x, Xs, a2s, linv, Lf, alpha_f);
 }
 
 // ---- launcher ---------------------------------------------------------------------------------------------------------
@@ -541,9 +518,7 @@ static size_t append_off_pass(int64_t npad, int kp) { return append_off_bm(npad,
 static size_t append_off_part(int64_t npad, int kp) { return append_off_pass(npad, kp) + (size_t)kAppendChunks * npad * kp; }
 static size_t append_off_sm(int64_t npad, int kp) { return append_off_part(npad, kp) + (size_t)((npad + 63) / 64) * (kp + 1) * (kp + 1); }
 static size_t append_off_info(int64_t npad, int kp) { return append_off_sm(npad, kp) + 8192 + 64; }
-static size_t append_off_tickets(int64_t npad, int kp) { return append_off_info(npad, kp) + 8; }
-static int append_ntickets(int64_t npad) { return 2 * (int)((npad + 63) / 64) + 2; }  // row blocks + the corner's | column blocks
-size_t append_scratch_doubles(int64_t npad, int kp) { return append_off_tickets(npad, kp) + (size_t)(append_ntickets(npad) + 1) / 2; }
+size_t append_scratch_doubles(int64_t npad, int kp) { return append_off_info(npad, kp) + 8; }
 
 template <typename TF, typename TP, int KP>
 static void launch_append_kp(hipStream_t st, AppendArgs a, double* pass, TF* linv, TF* Lf, TF* white, TF* alpha_f) {
@@ -551,16 +526,18 @@ static void launch_append_kp(hipStream_t st, AppendArgs a, double* pass, TF* lin
   const int ntile = (int)((n + 63) / 64);
   const int ct = (ntile + kAppendChunks - 1) / kAppendChunks, nq = (ntile + ct - 1) / ct;
   constexpr int lds = append_pass_lds_bytes<TF, KP>();
-  if (ensure_dyn_lds(reinterpret_cast<const void*>(&append_pass_kernel<TF, TP, KP, false>), lds) ||
-      ensure_dyn_lds(reinterpret_cast<const void*>(&append_pass_kernel<TF, TP, KP, true>), lds))
+  if (ensure_dyn_lds(reinterpret_cast<const void*>(&append_pass_kernel<TF, KP, false>), lds) ||
+      ensure_dyn_lds(reinterpret_cast<const void*>(&append_pass_kernel<TF, KP, true>), lds))
     return;  // (recorded with note_launch_error)
   hipLaunchKernelGGL(append_cross_kernel, dim3((unsigned)((n + a.k + 63) / 64)), dim3(256), 0, st, a);
-  // row pass -> (last chunk of a row block) B + partial Gram -> (last row block) the corner's Cholesky
-  hipLaunchKernelGGL((append_pass_kernel<TF, TP, KP, false>), dim3((unsigned)ntile, (unsigned)nq), dim3(256), lds, st, a, linv, a.Kc,
-                     pass, ct, linv, Lf, white, alpha_f);
-  // column pass -> (last chunk of a column block) the new rows at those columns; workgroup (ntile, 0): the k x k corner
-  hipLaunchKernelGGL((append_pass_kernel<TF, TP, KP, true>), dim3((unsigned)ntile + 1, (unsigned)nq), dim3(256), lds, st, a, linv, a.Bm,
-                     pass, ct, linv, Lf, white, alpha_f);
+  hipLaunchKernelGGL((append_pass_kernel<TF, KP, false>), dim3((unsigned)ntile, (unsigned)nq), dim3(256), lds, st, linv, n, a.npad,
+                     a.Kc, pass, ct);
+  hipLaunchKernelGGL((append_gram_part_kernel<TF, KP>), dim3((unsigned)ntile), dim3(256), 0, st, pass, ct, a.npad, a.Bm, white, n, a.part);
+  hipLaunchKernelGGL((append_chol_kernel<KP>), dim3(1), dim3(256), 0, st, a, ntile);
+  hipLaunchKernelGGL((append_pass_kernel<TF, KP, true>), dim3((unsigned)ntile, (unsigned)nq), dim3(256), lds, st, linv, n, a.npad,
+                     a.Bm, pass, ct);
+  hipLaunchKernelGGL((append_finish_kernel<TF, TP, KP>), dim3((unsigned)((n + 255) / 256) + 1), dim3(256), 0, st, a, pass, ct, linv,
+                     Lf, white, alpha_f);
 }
 
 template <typename TF, typename TP>
@@ -574,8 +551,6 @@ void launch_append(hipStream_t st, AppendArgs a, void* scratch, TF* linv, TF* Lf
   a.part = q + append_off_part(a.npad, kp);
   a.sm = q + append_off_sm(a.npad, kp);
   a.info = reinterpret_cast<int*>(q + append_off_info(a.npad, kp));
-  a.tickets = reinterpret_cast<unsigned*>(q + append_off_tickets(a.npad, kp));
-  a.ntickets = append_ntickets(a.npad);
   switch (kp) {
     case 8: launch_append_kp<TF, TP, 8>(st, a, pass, linv, Lf, white, alpha_f); break;
     case 16: launch_append_kp<TF, TP, 16>(st, a, pass, linv, Lf, white, alpha_f); break;

@@ -293,8 +293,7 @@ struct AppendArgs {
   double* x64;         // [npad * d] raw inputs: rows n .. n + k - 1 are filed by the cross kernel
   double* y64;         // [npad]
   const double *xnew, *ynew;  // the k new points [k * d], [k] in pinned HOST memory (read by the cross kernel itself: no copies)
-  unsigned* tickets;   // scratch: last-arriver counters, [0, ntile) row blocks | [ntile] the corner | [ntile + 1, ..) column blocks
-  int ntickets;
+
   const double* ls;    // lengthscale per input dimension (device)
   int64_t n, npad;
   int k, kp, d, dp, kernel;

@@ -736,20 +736,26 @@ __global__ __launch_bounds__(256) void absmax_kernel(const TF* __restrict__ linv
 
 // fp16 pieces of L^-1 2^sa in the fragment order of pack_linv_bf16_kernel<2>; scal[0] = max |L^-1| (absmax_kernel, or
 // the fit's own pass over L^-1: fit.hip white_kernel / alpha_sum_kernel), scal[1] := 2^-sa (read by the predict kernel's epilogue)
+// One launch, two block ranges (round 6; two launches before: the first one's 4 us were a launch that exits at once):
+// blocks [0, nb_above) -- the tile rows [0, rt_split) ABOVE the rows a gpso_append wrote, grid-stride, and only when the
+// scale they were packed with (scal[3], read-only here) is no longer the scale; blocks [nb_above, ..) -- the tile rows
+// [rt_split, rt_hi), one (rt, kq, lane) per thread.  A full packing is rt_split = 0, nb_above = 0.
 template <typename TF>
 __global__ __launch_bounds__(256) void pack_linv_f16_kernel(const TF* __restrict__ linv, int64_t n, int64_t npad,
-                                                            float* __restrict__ scal, u32x4* __restrict__ out, int64_t rt_lo,
-                                                            int64_t rt_hi, int only_if_rescaled) {
+                                                            float* __restrict__ scal, u32x4* __restrict__ out, int64_t rt_split,
+                                                            int64_t rt_hi, int nb_above) {
   const int64_t npad16 = npad / 16, npad32 = npad / 32;
   int e = 0;
   (void)frexpf(fmaxf(scal[0], 1e-30f), &e);  // max = m 2^e, m in [0.5, 1)
   const float up = ldexpf(1.0f, 14 - e);
-  // after a gpso_append the tile rows above the appended ones keep their pieces as long as the scale they were packed
-  // with (scal[3], read-only here) is still the scale: that launch (a small grid, grid-stride) exits at once
-  if (only_if_rescaled && scal[3] == ldexpf(1.0f, e - 14)) return;
-  if (!only_if_rescaled && blockIdx.x == 0 && threadIdx.x == 0) scal[1] = ldexpf(1.0f, e - 14);
-  const int64_t total = (rt_hi - rt_lo) * npad32 * 64;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {  // (rt, kq, lane)
+  const bool above = (int)blockIdx.x < nb_above;
+  if (above && scal[3] == ldexpf(1.0f, e - 14)) return;
+  if (!above && (int)blockIdx.x == nb_above && threadIdx.x == 0) scal[1] = ldexpf(1.0f, e - 14);
+  const int64_t rt_lo = above ? 0 : rt_split;
+  const int64_t total = ((above ? rt_split : rt_hi) - rt_lo) * npad32 * 64;
+  const int64_t first = above ? (int64_t)blockIdx.x * blockDim.x : ((int64_t)blockIdx.x - nb_above) * blockDim.x;
+  const int64_t stride = above ? (int64_t)nb_above * blockDim.x : total;  // (the lower range: one element per thread)
+  for (int64_t idx = first + threadIdx.x; idx < total; idx += stride) {  // (rt, kq, lane)
     const int lane = (int)(idx & 63);
     const int64_t kq = (idx >> 6) % npad32, rt = rt_lo + (idx >> 6) / npad32;
     const int64_t row = rt * 16 + (lane & 15);
@@ -875,12 +881,12 @@ void launch_pack_linv_f16(hipStream_t st, const TF* linv, int64_t n, int64_t npa
                        reinterpret_cast<unsigned*>(scal));
   }
   const int64_t npad16 = npad / 16, per_rt = (npad / 32) * 64;
-  if (rt0 > 0)  // (the tile rows above the appended ones: only when the scale changed -- decided on the device)
-    hipLaunchKernelGGL((pack_linv_f16_kernel<TF>), dim3((unsigned)std::min<int64_t>((rt0 * per_rt + 255) / 256, 4096)), dim3(256), 0, st,
-                       linv, n, npad, scal, static_cast<u32x4*>(linv_b), (int64_t)0, rt0, 1);
-  if (npad16 > rt0)
-    hipLaunchKernelGGL((pack_linv_f16_kernel<TF>), dim3((unsigned)(((npad16 - rt0) * per_rt + 255) / 256)), dim3(256), 0, st, linv, n, npad,
-                       scal, static_cast<u32x4*>(linv_b), rt0, npad16, 0);
+  // (the tile rows above the appended ones: only when the scale changed -- decided on the device; same launch)
+  const int nb_above = rt0 > 0 ? (int)std::min<int64_t>((rt0 * per_rt + 255) / 256, 4096) : 0;
+  const int64_t nb_rows = npad16 > rt0 ? ((npad16 - rt0) * per_rt + 255) / 256 : 0;
+  if (nb_above + nb_rows > 0)
+    hipLaunchKernelGGL((pack_linv_f16_kernel<TF>), dim3((unsigned)(nb_above + nb_rows)), dim3(256), 0, st, linv, n, npad, scal,
+                       static_cast<u32x4*>(linv_b), rt0, npad16, nb_above);
 }
 template void launch_pack_linv_f16<float>(hipStream_t, const float*, int64_t, int64_t, float*, void*, bool, int64_t);
 template void launch_pack_linv_f16<double>(hipStream_t, const double*, int64_t, int64_t, float*, void*, bool, int64_t);

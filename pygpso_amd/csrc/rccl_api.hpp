@@ -19,6 +19,8 @@ struct RcclApi {
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string load_error;
   bool ok = false;
@@ -55,6 +57,8 @@ struct RcclApi {
     Broadcast = reinterpret_cast<decltype(Broadcast)>(sym("ncclBroadcast"));
     AllGather = reinterpret_cast<decltype(AllGather)>(sym("ncclAllGather"));
     AllReduce = reinterpret_cast<decltype(AllReduce)>(sym("ncclAllReduce"));
+    GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+    GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
     GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
     ok = load_error.empty();
   }

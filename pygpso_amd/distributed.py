@@ -204,6 +204,9 @@ class HipGPEngineGroup:
         uid = (make_id or unique_id)()
         self._all(lambda r, e: e.comm_init(r, self.world, uid), collective=True)
         self._stale = False  # peers lag behind the root's posterior?
+        self._stale_rows = False     # ... by appended rows only (gpso_broadcast_posterior_rows applies)
+        self._stale_rows_ok = False  # the peers hold the posterior the next append extends
+        self.last_handoff = None     # ("rows" | "whole", bytes) of the last hand-off
         self.n = self.d = 0
 
     def _all(self, fn, collective=False):
@@ -252,7 +255,7 @@ class HipGPEngineGroup:
         self._broken = False
         uid = (make_id or unique_id)()
         self._all(lambda r, e: e.comm_init(r, self.world, uid), collective=True)
-        self._stale = True
+        self._new_posterior()
 
     def close(self):
         for e in getattr(self, "engines", []):
@@ -273,30 +276,38 @@ class HipGPEngineGroup:
             return self._all(lambda r, e: fn(e))[0]
         return fn(self.engines[0])
 
+    def _new_posterior(self):
+        self._stale = True
+        self._stale_rows = False
+        self._stale_rows_ok = False
+
     def set_data(self, X, y):
         self._fitters(lambda e: e.set_data(X, y))
         self.n, self.d = self.engines[0].n, self.engines[0].d
-        self._stale = True
+        self._new_posterior()
 
     def fit_eval(self, *a, **kw):
-        self._stale = True
+        self._new_posterior()
         return self._fitters(lambda e: e.fit_eval(*a, **kw))
 
     def fit_eval_u(self, *a, **kw):
-        self._stale = True
+        self._new_posterior()
         return self._fitters(lambda e: e.fit_eval_u(*a, **kw))
 
     def append(self, Xnew, ynew):
         """``HipGPEngine.append`` on the fitting rank(s); the peers get the extended posterior like a fitted one."""
         out = self._fitters(lambda e: e.append(Xnew, ynew))
         self.n = self.engines[0].n
+        # "broadcast" groups: the next predict-type call moves only what the append wrote (gpso_broadcast_posterior_rows; the
+        # library falls back to the whole range on every rank when a peer does not hold the base) -- not the whole posterior
         self._stale = True
+        self._stale_rows = self._stale_rows_ok and out[1]
         return out
 
     def set_posterior(self, *a, **kw):
         self._fitters(lambda e: e.set_posterior(*a, **kw))
         self.n, self.d = self.engines[0].n, self.engines[0].d
-        self._stale = True
+        self._new_posterior()
 
     def _sync_posterior(self):
         if self._stale and self.world > 1:
@@ -305,9 +316,15 @@ class HipGPEngineGroup:
                 if len(set(hashes)) != 1:
                     raise L.GpsoHipError(L.E_STATE, "replicated fits disagree: posterior fingerprints "
                                          + ", ".join(f"{h:016x}" for h in hashes))
+            elif self._stale_rows and hasattr(self.engines[0], "broadcast_posterior_rows"):
+                rows = self._all(lambda r, e: e.broadcast_posterior_rows(0), collective=True)
+                self.last_handoff = ("rows" if rows[0] else "whole", self.engines[0].last_count(0))
             else:
                 self._all(lambda r, e: e.broadcast_posterior(0), collective=True)
+                self.last_handoff = ("whole", self.engines[0].last_count(0) if hasattr(self.engines[0], "last_count") else None)
         self._stale = False
+        self._stale_rows = False
+        self._stale_rows_ok = True  # (from here on an append alone can be handed on by rows)
 
     # predict-type calls: sharded
     def predict(self, xs, out=None):
@@ -335,11 +352,11 @@ class HipGPEngineGroup:
     # predict math at the broadcast; generation, self-test and tolerances would silently differ otherwise)
     def set_predict_math(self, mode):
         self._all(lambda r, e: e.set_predict_math(mode))
-        self._stale = True
+        self._new_posterior()
 
     def set_generation(self, mode):
         self._all(lambda r, e: e.set_generation(mode))
-        self._stale = True
+        self._new_posterior()
 
     def set_precision_check(self, on):
         self._all(lambda r, e: e.set_precision_check(on))

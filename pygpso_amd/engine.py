@@ -431,6 +431,28 @@ class HipGPEngine:
         self._check(self._lib.gpso_problem_shape(self._h, C.byref(n), C.byref(d)))
         self.n, self.d = int(n.value), int(d.value)
 
+    def broadcast_posterior_rows(self, root=0):
+        """Collective: after ``append`` on ``root`` only what the appends wrote travels (``gpso_broadcast_posterior_rows``);
+        any rank that cannot take rows makes every rank take the whole range.  Returns True when rows sufficed;
+        ``last_count(0)`` = the bytes that travelled."""
+        rc = self._check(self._lib.gpso_broadcast_posterior_rows(self._h, int(root)))
+        n, d = C.c_int64(), C.c_int()
+        self._check(self._lib.gpso_problem_shape(self._h, C.byref(n), C.byref(d)))
+        self.n, self.d = int(n.value), int(d.value)
+        return rc == L.OK
+
+    def posterior_dirty_ranges(self):
+        """[(offset, nbytes), ...] of the posterior arena that a peer holding the posterior of the last hand-off lacks
+        (``gpso_posterior_dirty_ranges``): [] = up to date; one range = the whole span when rows do not apply."""
+        off = np.zeros(12, dtype=np.int64)
+        nb = np.zeros(12, dtype=np.int64)
+        cnt = self._check(self._lib.gpso_posterior_dirty_ranges(self._h, L.i64ptr(off), L.i64ptr(nb), 12))
+        return [(int(off[i]), int(nb[i])) for i in range(cnt)]
+
+    def posterior_mark_synced(self):
+        """The peers now hold this posterior (after a hand-off by plain copies): the next ``posterior_dirty_ranges`` counts from here."""
+        self._check(self._lib.gpso_posterior_mark_synced(self._h))
+
     def best_ucb_sharded(self, local_leaves, m_global, varsigma, seg_off=None):
         """Collective ``best_ucb``: ``local_leaves`` are this rank's rows
         ``distributed.shard_range(m_global, rank, world)`` of the batch; ``seg_off`` is global.
@@ -556,3 +578,6 @@ class HipGPEngine:
 
     def adopt_posterior(self):
         self._check(self._lib.gpso_adopt_posterior(self._h))
+        n, d = C.c_int64(), C.c_int()  # (a posterior extended by gpso_append on the sender arrives with more rows)
+        self._check(self._lib.gpso_problem_shape(self._h, C.byref(n), C.byref(d)))
+        self.n, self.d = int(n.value), int(d.value)

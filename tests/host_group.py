@@ -44,6 +44,29 @@ class HostGroup:
         state = self._bcast(state, src)
         if self.rank != src:
             self.engine.import_posterior(state)
+        self.engine.sync_n = self.engine.n  # every rank: the group holds these rows (api.hip: posterior_mark_synced)
+        self.last_bytes = sum(np.asarray(v).nbytes for v in state.values() if isinstance(v, np.ndarray))
+
+    def broadcast_posterior_rows(self, src=0):
+        """Host mirror of gpso_broadcast_posterior_rows: the root offers the rows since the last hand-off (or nothing
+        but the whole), every rank says whether it holds that base (min over the ranks), then either the rows travel
+        or -- on EVERY rank -- the whole posterior.  Returns True when rows sufficed."""
+        eng = self.engine
+        offer = None
+        if self.rank == src:
+            offer = (eng.sync_n if (eng.post is not None and 0 <= eng.sync_n <= eng.n) else -1, eng.n)
+        n_base, n_now = self._bcast(offer, src)
+        mine = 1.0 if n_base >= 0 and (self.rank == src or (eng.post is not None and eng.sync_n == n_base and eng.n == n_base)) else 0.0
+        if float(np.min(self._allgather(np.array([mine])))) != 1.0:
+            self.broadcast_posterior(src)
+            return False
+        state = eng.export_rows(n_base) if self.rank == src else None
+        state = self._bcast(state, src)
+        if self.rank != src and n_now > n_base:
+            eng.import_rows(state)
+        eng.sync_n = eng.n
+        self.last_bytes = sum(np.asarray(v).nbytes for v in state.values() if isinstance(v, np.ndarray))
+        return True
 
     def _fold(self, mine):
         """mine [nseg, 4] = (ucb, global idx or -1, mean, var) -> winners [nseg, 4]"""

@@ -16,14 +16,17 @@ class OracleEngine:
         self.n = self.d = 0
         self.post = None
         self._ms = 0.0
+        self.sync_n = -1  # rows the peers of a group hold of this posterior (mirror of api.hip: sync_n); -1: unknown
 
     def set_data(self, X, y):
         self.X = np.ascontiguousarray(X, dtype=np.float64)
         self.y = np.asarray(y, dtype=np.float64).reshape(-1)
         self.n, self.d = self.X.shape
         self.post = None
+        self.sync_n = -1
 
     def fit_eval(self, kernel, lengthscales, variance, noise, mean_c, want_grad=True):
+        self.sync_n = -1
         th = gpr.Theta(kernel, lengthscales, variance, noise, mean_c)
         if want_grad:
             f, g = gpr.nlml_and_grad(th, self.X, self.y)
@@ -36,8 +39,10 @@ class OracleEngine:
         """What ``HipGPEngine.append`` answers: the posterior of the old + new points at the resident hyper-parameters
         (here simply refitted by the oracle) -> (nlml, in_place)."""
         th = self.post.theta
+        keep = self.sync_n  # (an in-place append leaves the record of what the peers hold alone)
         self.set_data(np.vstack([self.X, np.atleast_2d(Xnew)]), np.concatenate([self.y, np.asarray(ynew).reshape(-1)]))
         self.post = gpr.posterior(th, self.X, self.y)
+        self.sync_n = keep
         return self.post.nlml, True
 
     def predict(self, xs, out=None):
@@ -83,6 +88,24 @@ class OracleEngine:
         return dict(kernel=th.kernel, lengthscales=np.array(th.lengthscales), variance=th.variance,
                     noise=th.noise, mean_c=th.mean_c, X=self.post.X.copy(), L=self.post.L.copy(),
                     alpha=self.post.alpha.copy(), y=self.post.y.copy())
+
+    # -- the rows an append wrote (host mirror of gpso_posterior_dirty_ranges / gpso_broadcast_posterior_rows) -----------
+    def export_rows(self, n_base):
+        """What a peer holding the first ``n_base`` rows lacks: the new rows of X, y and L (the old rows of a Cholesky
+        factor do not change when rows are appended), all of alpha."""
+        p = self.post
+        return dict(n_base=int(n_base), X=p.X[n_base:].copy(), y=p.y[n_base:].copy(), L_rows=p.L[n_base:].copy(),
+                    alpha=p.alpha.copy())
+
+    def import_rows(self, st):
+        p, nb = self.post, st["n_base"]
+        assert p.X.shape[0] == nb
+        n1 = nb + st["X"].shape[0]
+        L = np.zeros((n1, n1))
+        L[:nb, :nb] = p.L
+        L[nb:, :] = st["L_rows"]
+        p.X, p.y, p.L, p.alpha = np.vstack([p.X, st["X"]]), np.concatenate([p.y, st["y"]]), L, st["alpha"]
+        self.n = n1
 
     def import_posterior(self, st):
         post = gpr.Posterior()

@@ -62,7 +62,28 @@ def _worker(rank, world, port, case, m, out):
             eng.fit_eval("Matern52", [0.4], 1.0, 1e-3, 0.0, want_grad=False)
         grp = HostGroup(eng, rank, world, *_gloo_transport(dist))
         grp.broadcast_posterior(src=0)
-        if case in ("plain", "dup", "segments"):
+        if case in ("append", "append-lost-base"):
+            # gpso_append on the root, then the rows hand-off: only what the append wrote travels -- unless a rank does not
+            # hold the base (here: rank 1 refitted something else in between), in which case EVERY rank takes the whole
+            Xn, yn = synthetic_problem(6, 3, seed=5)
+            ref.append(Xn, yn)
+            whole_bytes = grp.last_bytes
+            if rank == 0:
+                eng.append(Xn, yn)
+            elif case == "append-lost-base":
+                eng.sync_n = -1
+            rows = grp.broadcast_posterior_rows(src=0)
+            assert rows == (case == "append"), (case, rows)
+            assert eng.n == 86 and eng.sync_n == 86
+            if rows:
+                assert grp.last_bytes < 0.2 * whole_bytes  # 6 new rows of an 86-row posterior
+            rows_again = grp.broadcast_posterior_rows(src=0)  # nothing new: rows, and nothing to move
+            assert rows_again
+            leaves = synthetic_leaves(m, 3, seed=1)
+            lo, hi = D.shard_range(m, rank, world)
+            got = grp.best_ucb_sharded(leaves[lo:hi], m, VS, None)
+            exp = ref.best_ucb(leaves, VS, None)
+        elif case in ("plain", "dup", "segments"):
             leaves = synthetic_leaves(m, 3, seed=1)
             if case == "dup":  # the global winner also appears, later, in the other rank's shard
                 i0 = int(ref.best_ucb(leaves, VS)[0][0])
@@ -84,7 +105,7 @@ def _worker(rank, world, port, case, m, out):
 
 
 @pytest.mark.parametrize("case,m", [("plain", 1001), ("dup", 640), ("plain", 3), ("segments", 900),
-                                    ("grow", 5), ("grow", 1)])
+                                    ("grow", 5), ("grow", 1), ("append", 700), ("append-lost-base", 700)])
 def test_two_ranks_agree_with_single_process(case, m):
     world = 2
     with mp.Manager() as mgr:
@@ -219,6 +240,12 @@ def test_engine_group_threads_with_two_fake_devices():
         def broadcast_posterior(self, root=0):
             self._grp.broadcast_posterior(root)
 
+        def broadcast_posterior_rows(self, root=0):
+            return self._grp.broadcast_posterior_rows(root)
+
+        def last_count(self, what=0):
+            return self._grp.last_bytes
+
         def best_ucb_sharded(self, local, m_global, varsigma, seg_off=None):
             return self._grp.best_ucb_sharded(np.asarray(local), m_global, varsigma, seg_off)
 
@@ -255,10 +282,30 @@ def test_engine_group_threads_with_two_fake_devices():
     Xn, yn = synthetic_problem(5, 3, seed=9)
     f_grp, in_place = grp.append(Xn, yn)
     f_ref, _ = ref.append(Xn, yn)
-    assert in_place and f_grp == f_ref and grp.n == 75 and grp._stale
+    assert in_place and f_grp == f_ref and grp.n == 75 and grp._stale and grp._stale_rows
+    whole = grp.last_handoff
+    assert whole[0] == "whole"
     got, exp = grp.best_ucb(Xs, VS, seg), ref.best_ucb(Xs, VS, seg)
     assert np.array_equal(got[0], exp[0])
     np.testing.assert_allclose(np.array(got[1:]), np.array(exp[1:]), rtol=1e-12, atol=1e-13, equal_nan=True)
+    # ... by ROWS (round 6: gpso_broadcast_posterior_rows): a fraction of the whole posterior's bytes
+    assert grp.last_handoff[0] == "rows" and grp.last_handoff[1] < 0.25 * whole[1], (grp.last_handoff, whole)
+    # two appends before the next predict-type call travel together; a peer that lost the base makes every rank take the whole
+    for seed in (10, 11):
+        Xn, yn = synthetic_problem(3, 3, seed=seed)
+        grp.append(Xn, yn)
+        ref.append(Xn, yn)
+    assert np.array_equal(grp.best_ucb(Xs, VS, seg)[0], ref.best_ucb(Xs, VS, seg)[0]) and grp.last_handoff[0] == "rows"
+    Xn, yn = synthetic_problem(2, 3, seed=12)
+    grp.append(Xn, yn)
+    ref.append(Xn, yn)
+    grp.engines[1].sync_n = -1
+    assert np.array_equal(grp.best_ucb(Xs, VS, seg)[0], ref.best_ucb(Xs, VS, seg)[0]) and grp.last_handoff[0] == "whole"
+    assert grp.engines[1].n == ref.n == 83
+    # a fit in between: the next hand-off is the whole posterior again, an append after it rows
+    grp.fit_eval("Matern52", [0.45], 1.1, 1e-3, 0.0, want_grad=False)
+    ref.fit_eval("Matern52", [0.45], 1.1, 1e-3, 0.0, want_grad=False)
+    assert np.array_equal(grp.best_ucb(Xs, VS)[0], ref.best_ucb(Xs, VS)[0]) and grp.last_handoff[0] == "whole"
     grp.close()
 
 

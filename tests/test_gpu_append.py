@@ -210,19 +210,25 @@ def test_append_in_float_contexts_repacks_only_the_new_tile_rows(dtype, math):
 
 
 def test_append_when_the_fp16_scale_crosses_a_power_of_two():
-    """A new point almost on top of an old one makes |L^-1|'s largest entry jump (1 / sqrt of a tiny Schur complement):
-    the fp16 pieces of EVERY row are then repacked with the new scale (decided on the device)."""
-    n, d = 500, 2
+    """A new point almost on top of an old one beside SPARSE old points (D = 12, short lengthscale: max |L^-1| ~ 1 before,
+    1 / sqrt(2 noise) ~ 70 after): the largest entry jumps six powers of two and the fp16 pieces of EVERY row are repacked
+    with the new scale (decided on the device).  (Round 5's recipe -- D = 2, 500 dense points -- did not cross: among dense
+    points every conditional variance is already ~ noise.  The crossing is now asserted: gpso_posterior_dirty_ranges reports
+    the whole span only when the scale moved.)"""
+    n, d = 300, 12
     X, y = synthetic_problem(n + 1, d, seed=17)
     X[n] = X[3] + 1e-7
     y[n] = y[3]
-    th = gpr.Theta("Matern52", np.array([0.3]), 1.0, 1e-4, float(y.mean()))
+    th = gpr.Theta("Matern52", np.array([0.2]), 1.0, 1e-4, float(y.mean()))
     eng = _engine("mixed", predict_math="f16x3", precision_check=False)
     _fit(eng, X[:n], y[:n], th)
     Xs = synthetic_leaves(2000, d)
     eng.predict(Xs[:256])
+    eng.posterior_mark_synced()
+    assert eng.posterior_dirty_ranges() == []
     _, in_place = eng.append(X[n:], y[n:])
     assert in_place
+    assert len(eng.posterior_dirty_ranges()) == 1  # the scale moved: nothing a peer holds is still valid
     post = gpr.posterior(th, X, y)
     mean, var = eng.predict(Xs)
     mean_ref, var_ref = gpr.predict_y(post, Xs)

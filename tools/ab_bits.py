@@ -79,7 +79,7 @@ def main():
     libs = sys.argv[1:]
     res = []
     for lib in libs:
-        env = dict(os.environ, GPSO_HIP_LIB=os.path.abspath(lib))
+        env = dict(os.environ, GPSO_HIP_LIB=os.path.abspath(lib), GPSO_HIP_LIB_OLDER="1")
         p = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker"], env=env, capture_output=True, text=True)
         line = [l for l in p.stdout.splitlines() if l.startswith("AB_BITS ")]
         if not line:
