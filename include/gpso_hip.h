@@ -119,6 +119,13 @@ typedef struct gpso_ctx gpso_ctx;
 #define GPSO_OPT_FUSED_PREP 11     /* 1 (default): float leaves (GPSO_F32) of a one-chunk batch are scaled by the lengthscales in  */
                                    /* the fp16-contraction kernel's own prologue -- no prep launch in front of it; 0: the separate */
                                    /* prep kernel.  Same bits (tests/test_gpu_parity.py); the option exists for that comparison     */
+#define GPSO_OPT_FIT_OVERLAP 12    /* float64 fits above the single-level limit (N_pad > 2560; the fit of GPSO_F64 and GPSO_MIXED      */
+                                   /* contexts).  Bit 1 (value 2, default): the level-doubling inverse runs on a second stream, pair   */
+                                   /* by pair, as soon as the panels a product reads are final -- beside the rest of the factorisation */
+                                   /* instead of behind it.  Bit 0: the next diagonal block is factored on a side stream beside the    */
+                                   /* trailing update (as the float fit does; measured not to pay in double: the chain's launches need */
+                                   /* whole free CUs and starve behind the update's tiles).  0: round 5's sequential schedule.  The    */
+                                   /* same products in the same order on the same tiles: the same bits whatever the value.             */
 /* floating-point options (gpso_set_option_f64): tolerances of the self-test */
 #define GPSO_OPTF_TOL_VAR 100  /* max |d var| at the training inputs, relative to the kernel variance (default 1e-4; GPSO_F32: 1e-3) */
 #define GPSO_OPTF_TOL_MEAN 101 /* max |d mean| at the training inputs, relative to max |y - c|   (default 1e-4; GPSO_F32: 1e-3) */

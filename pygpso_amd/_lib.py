@@ -35,6 +35,7 @@ OPT_SPLIT_KERNEL = 8
 OPT_SMALL_CALLS = 9
 OPT_CONTRACTION = 10
 OPT_FUSED_PREP = 11
+OPT_FIT_OVERLAP = 12
 CONTRACTION_AUTO, CONTRACTION_F32, CONTRACTION_F16 = 0, 1, 2
 SPLIT_KERNEL_AUTO, SPLIT_KERNEL_TWO_PHASE = 0, 1
 OPTF_TOL_VAR, OPTF_TOL_MEAN = 100, 101

@@ -166,8 +166,10 @@ struct gpso_ctx {
   std::string err;
   Engine* eng = nullptr;
   hipEvent_t ev_wait = nullptr;  // completion marker of the call in flight
-  hipStream_t side_stream = nullptr;  // look-ahead of the two-level float fit (kernels.hpp: FitPlanes)
+  hipStream_t side_stream = nullptr;  // look-ahead of the two-level fits (kernels.hpp: FitPlanes)
   hipEvent_t ev_col = nullptr, ev_chain = nullptr;
+  hipStream_t inv_stream = nullptr;   // the overlapped inverse of the two-level double fit
+  hipEvent_t ev_panel = nullptr, ev_inv = nullptr;
   double* pinned = nullptr;      // pinned host scratch for the small result read-backs
   size_t pinned_doubles = 0;
   double* stage = nullptr;       // pinned staging of small host inputs (training data, bounds)
@@ -350,6 +352,7 @@ struct EngineT : Engine {
   DevBuf pl_L, pl_X, pl_XT, pl_WT;  // bf16 plane sets of the two-level float fit (kernels.hpp: FitPlanes)
   DevBuf app;                       // scratch of gpso_append (kernels.hpp: append_scratch_doubles)
   std::vector<double> x_host, y_host;  // host mirror of the training data (gpso_append's refit path needs all of it)
+  int fit_overlap = 2;              // GPSO_OPT_FIT_OVERLAP (bit 0 look-ahead, bit 1 overlapped inverse: the default): two-level double fits overlap chains, updates and the inverse (0: sequential, round 5)
   int fit_planes_mode = 2;          // GPSO_OPT_FIT_BF16_SYRK: 0 f32 MFMA | 1 bf16 pieces (6 MFMAs per product) | 2 fp16 pieces (3) where representable
   // predict math: the OPTION (math_auto: GPSO_MATH_AUTO) and what the resident posterior uses (math, and
   // math_native_fallback when the self-test preferred the f32 MFMA kernel for it)
@@ -495,6 +498,10 @@ struct EngineT : Engine {
       case GPSO_OPT_FIT_BF16_SYRK:
         if (value < 0 || value > 2) return ctx->fail(GPSO_E_ARG, "fit plane mode must be 0 (f32 MFMA), 1 (bf16 pieces) or 2 (fp16 pieces)");
         fit_planes_mode = value;
+        return GPSO_OK;
+      case GPSO_OPT_FIT_OVERLAP:
+        if (value < 0) return ctx->fail(GPSO_E_ARG, "fit overlap must be >= 0");
+        fit_overlap = value;
         return GPSO_OK;
       case GPSO_OPT_TIMING:
         if (value < 0 || value > 1000000) return ctx->fail(GPSO_E_ARG, "timing must be 0 (off), 1 (every call) or k (every k-th call)");
@@ -954,6 +961,32 @@ struct EngineT : Engine {
           if (fit_planes_mode == 2) (void)fit_plane_scales(variance, noise, planes);
           pl = &planes;
           ctx->last_count[2] = planes.np == 2 ? GPSO_FITMATH_F16X3 : GPSO_FITMATH_BF16X6;
+        }
+      } else {
+        // double fits above the single-level limit (round 6): the diagonal blocks' chains are looked ahead on a side stream
+        // and the level-doubling inverse runs on a third one, pair by pair, as soon as the panels it reads are final
+        // (fit.hip: launch_potrf) -- GPSO_OPT_FIT_OVERLAP = 0 keeps round 5's sequential schedule (same bits either way)
+        if (fit_overlap && !potrf_is_single_level<TF>(npad, single_level_max)) {
+          if (ctx->side_stream == nullptr) {
+            int lo_p = 0, hi_p = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);  // (hi_p = the numerically smallest = highest priority)
+            HIPCHECK(hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, hi_p));
+            HIPCHECK(hipEventCreateWithFlags(&ctx->ev_col, hipEventDisableTiming));
+            HIPCHECK(hipEventCreateWithFlags(&ctx->ev_chain, hipEventDisableTiming));
+          }
+          if (ctx->inv_stream == nullptr) {
+            HIPCHECK(hipStreamCreateWithFlags(&ctx->inv_stream, hipStreamNonBlocking));
+            HIPCHECK(hipEventCreateWithFlags(&ctx->ev_panel, hipEventDisableTiming));
+            HIPCHECK(hipEventCreateWithFlags(&ctx->ev_inv, hipEventDisableTiming));
+          }
+          planes.side = ctx->side_stream;
+          planes.ev_col = ctx->ev_col;
+          planes.ev_chain = ctx->ev_chain;
+          planes.inv = ctx->inv_stream;
+          planes.ev_panel = ctx->ev_panel;
+          planes.ev_inv = ctx->ev_inv;
+          planes.overlap = fit_overlap;
+          pl = &planes;
         }
       }
       const int done = launch_potrf<TF>(s, as<TF>(K), as<TF>(Lf), as<TF>(linv), as<TF>(work),
@@ -2761,9 +2794,11 @@ void gpso_destroy(gpso_ctx* ctx) {
   delete ctx->eng;
   for (auto& ev : ctx->tile_ev) (void)hipEventDestroy(ev);
   if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
-  if (ctx->ev_col) (void)hipEventDestroy(ctx->ev_col);
-  if (ctx->ev_chain) (void)hipEventDestroy(ctx->ev_chain);
+  if (ctx->inv_stream) (void)hipStreamSynchronize(ctx->inv_stream);
+  for (hipEvent_t e : {ctx->ev_col, ctx->ev_chain, ctx->ev_panel, ctx->ev_inv})
+    if (e) (void)hipEventDestroy(e);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+  if (ctx->inv_stream) (void)hipStreamDestroy(ctx->inv_stream);
   if (ctx->slot_host) (void)hipHostFree(ctx->slot_host);
   for (auto& ev : ctx->slot_ev)
     if (ev) (void)hipEventDestroy(ev);

@@ -15,6 +15,9 @@
 // (gpso/gp_surrogate.py:500-503).
 #include <algorithm>
 #include <climits>
+#include <functional>
+#include <utility>
+#include <vector>
 #include <cstdlib>
 
 #include "common.hpp"
@@ -668,6 +671,7 @@ struct GemmDesc {
   double alpha, beta;
   int lower_only;  // only tiles with tj <= ti (needs m == n)
   int kmode;       // 0: all k | 1: k >= TS tj | 2: k >= TS ti | 3: k < TS (ti + 1) | 4: k < TS (tj + 1)
+  int ts_hint;     // 0: tile size by the launch's own tile count | 64 / 128: as the launch this one is a PART of chose (same bits)
   // float only, nullable: also write C (rows / columns relative to C) as three bf16 planes in the layout
   // syrk_bf16_kernel reads (the TRSM of the two-level Cholesky hands its panel to the SYRK this way)
   unsigned short* split;
@@ -974,6 +978,13 @@ static void launch_gemm_dma(hipStream_t st, const GemmDesc& g, bool a_kc, bool b
   else launch_gemm128<T, TS, false, false>(st, g);
 }
 
+// the tile size launch_gemm picks for a launch of these extents (parts of a split launch pass it on as ts_hint)
+static int gemm_tile_choice(int m, int n, int m_last, int k, int nbatch, bool lower_only) {
+  const bool div128 = (m % 128 == 0) && (n % 128 == 0) && (m_last % 128 == 0) && (k % 128 == 0);
+  const int64_t tiles128 = (int64_t)(m / 128) * (n / 128) * nbatch / (lower_only ? 2 : 1);
+  return (div128 && tiles128 >= 512) ? 128 : 64;
+}
+
 template <typename T>
 static void launch_gemm(hipStream_t st, const GemmDesc& g) {
   if (g.m <= 0 || g.n <= 0 || g.nbatch <= 0) return;
@@ -990,7 +1001,7 @@ static void launch_gemm(hipStream_t st, const GemmDesc& g) {
     note_launch_error("launch_gemm: operand strides / sizes the LDS-DMA tile kernel cannot take");
     return;
   }
-  if (div128 && tiles128 >= 512) launch_gemm_dma<T, 128>(st, g, a_kc, b_kc);
+  if (g.ts_hint == 128 ? div128 : (g.ts_hint == 0 && div128 && tiles128 >= 512)) launch_gemm_dma<T, 128>(st, g, a_kc, b_kc);
   else launch_gemm_dma<T, 64>(st, g, a_kc, b_kc);
 }
 
@@ -2036,6 +2047,64 @@ int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t
   // CUs the chain takes 416 us instead of 263, with 32 CUs left to it 307.)
   constexpr int kLookaheadCus = 48;  // measured: 8-16 leave the chain's ~100-workgroup launches crawling; 32-64 within 2 %
   const bool can_look = sizeof(T) == 4 && planes != nullptr && planes->L != nullptr && planes->side != nullptr;
+  // Round 6, double fits (the fit of "float64" and "mixed" contexts).  Measured at C4 (profiles/r06_fit_c4_f64_timeline_before.txt):
+  // 9.75 ms = 2.07 ms of diagonal-block chains with the chip idle + 3.5 ms of TRSM / SYRK products + 3.65 ms of level-doubling
+  // inverse behind them + 0.5 ms.  (a) look-ahead as in the float fit: the next diagonal block is factored on `side` as soon as
+  // its block column of the update is done, beside the rest of the update.  (b) the inverse does not wait for the factorisation:
+  // a block's inverse needs only the panels inside it, so the products of each pair are issued on `inv` the moment both halves
+  // are final -- the FIRST product of a pair, W = L[B,A] Linv[A,A], already when the A half is (the last level's starts at half
+  // time and runs beside the second half's chains, which leave most of the chip idle).  Same products on the same tiles in the
+  // same k order as the sequential schedule: the same bits (ts_hint keeps the tile size a split launch would otherwise lose).
+  const int ov = (sizeof(T) == 8 && planes != nullptr) ? planes->overlap : 0;  // bit 0: look-ahead, bit 1: overlapped inverse
+  const bool look64 = (ov & 1) && planes->side != nullptr && planes->ev_col != nullptr && planes->ev_chain != nullptr;
+  const int64_t npanels = npad / kOuterPanel;
+  const bool dag64 = (ov & 2) && planes->inv != nullptr && planes->ev_panel != nullptr && planes->ev_inv != nullptr &&
+                     npad % kOuterPanel == 0 && npanels >= 2 && (npanels & (npanels - 1)) == 0;
+  // (bits 8..: products of pairs wider than 2^(bits) panels wait for the end of the factorisation -- experiments)
+  const int64_t defer_from = (ov >> 8) > 0 ? (kOuterPanel << ((ov >> 8) - 1)) : npad;
+  std::vector<std::pair<int64_t, int64_t>> deferred_w;  // (lo, s) of first products held back
+  // the products of pair [lo, lo + 2 s) of the inverse's level s (launch_trtri's two GEMMs, one pair each), on `inv`
+  auto pair_w = [&](int64_t lo, int64_t s) {  // W[B,A] = L[B,A] Linv[A,A]
+    GemmDesc a{};
+    const int64_t o = lo * npad + lo;
+    a.A = Lf + o + s * npad; a.sai = npad; a.sak = 1;
+    a.B = linv + o; a.sbk = npad; a.sbj = 1;
+    a.C = work + o + s * npad; a.ldc = npad;
+    a.m = a.n = a.k = a.m_last = (int)s; a.nbatch = 1;
+    a.alpha = 1.0; a.beta = 0.0; a.kmode = 1;
+    a.ts_hint = gemm_tile_choice((int)s, (int)s, (int)s, (int)s, (int)(npad / (2 * s)), false);
+    launch_gemm<T>(planes->inv, a);
+  };
+  auto pair_x = [&](int64_t lo, int64_t s) {  // Linv[B,A] = -Linv[B,B] W[B,A]
+    GemmDesc b{};
+    const int64_t o = lo * npad + lo;
+    b.A = linv + o + s * npad + s; b.sai = npad; b.sak = 1;
+    b.B = work + o + s * npad; b.sbk = npad; b.sbj = 1;
+    b.C = linv + o + s * npad; b.ldc = npad;
+    b.m = b.n = b.k = b.m_last = (int)s; b.nbatch = 1;
+    b.alpha = -1.0; b.beta = 0.0; b.kmode = 3;
+    b.ts_hint = gemm_tile_choice((int)s, (int)s, (int)s, (int)s, (int)(npad / (2 * s)), false);
+    launch_gemm<T>(planes->inv, b);
+  };
+  // block [lo, lo + size) has its inverse complete (in the order of `inv`): an A half starts its parent's first product, a B
+  // half finishes the parent
+  std::function<void(int64_t, int64_t)> complete = [&](int64_t lo, int64_t size) {
+    if (size >= npad) return;
+    const int64_t parent = lo / (2 * size) * (2 * size);
+    if (lo == parent) {
+      if (size >= defer_from) deferred_w.push_back({parent, size});
+      else pair_w(parent, size);
+    } else {
+      for (size_t i = 0; i < deferred_w.size(); ++i)
+        if (deferred_w[i].first == parent && deferred_w[i].second == size) {
+          pair_w(parent, size);
+          deferred_w.erase(deferred_w.begin() + (long)i);
+          break;
+        }
+      pair_x(parent, size);
+      complete(parent, 2 * size);
+    }
+  };
   bool chain_on_side = false;  // the diagonal block of this iteration was launched on the side stream
   for (int64_t c0 = 0; c0 < npad; c0 += kOuterPanel) {
     const int64_t wp = std::min<int64_t>(kOuterPanel, npad - c0);
@@ -2049,7 +2118,16 @@ int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t
     }
     const int64_t r1 = c0 + wp;
     const int m2 = (int)(npad - r1);
-    if (m2 <= 0) break;
+    if (m2 <= 0) {
+      if (dag64) {  // the last panel is final: the remaining products of the inverse, then the caller's stream joins
+        (void)hipEventRecord(planes->ev_panel, st);
+        (void)hipStreamWaitEvent(planes->inv, planes->ev_panel, 0);
+        complete(c0, wp);
+        (void)hipEventRecord(planes->ev_inv, planes->inv);
+        (void)hipStreamWaitEvent(st, planes->ev_inv, 0);
+      }
+      break;
+    }
     GemmDesc t{};  // L21 = A21 X11^T:  opB(k, j) = X11[j][k], zero for k > j
     t.A = K + r1 * npad + c0; t.sai = npad; t.sak = 1;
     t.B = linv + off; t.sbk = 1; t.sbj = npad;
@@ -2115,9 +2193,37 @@ int launch_potrf(hipStream_t st, T* K, T* Lf, T* linv, T* work, T* kinv, int64_t
     u.C = K + r1 * npad + r1; u.ldc = npad;
     u.m = m2; u.n = m2; u.k = (int)wp; u.m_last = m2; u.nbatch = 1;
     u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1;
+    if (dag64) {  // panel c0 is final (its block column of L and its diagonal block's inverse): its part of the inverse
+      (void)hipEventRecord(planes->ev_panel, st);
+      (void)hipStreamWaitEvent(planes->inv, planes->ev_panel, 0);
+      complete(c0, wp);
+    }
+    const int64_t wn = std::min<int64_t>(kOuterPanel, npad - r1);  // the next panel
+    if (look64 && m2 > wn) {
+      const int ts = gemm_tile_choice(m2, m2, m2, (int)wp, 1, true);
+      GemmDesc col = u;  // the next panel's block column first: rows r1 .., columns r1 .. r1 + wn (its upper tiles ride along)
+      col.n = (int)wn;
+      col.lower_only = 0;
+      col.ts_hint = ts;
+      launch_gemm<T>(st, col);
+      (void)hipEventRecord(planes->ev_col, st);
+      GemmDesc rest = u;  // then everything to the right of it, while the next diagonal block is factored on the side stream
+      rest.A = rest.B = Lf + (r1 + wn) * npad + c0;
+      rest.C = K + (r1 + wn) * npad + (r1 + wn);
+      rest.m = rest.n = rest.m_last = (int)(m2 - wn);
+      rest.ts_hint = ts;
+      launch_gemm<T>(st, rest);
+      (void)hipStreamWaitEvent(planes->side, planes->ev_col, 0);
+      const int64_t off1 = r1 * npad + r1;
+      potrf_block<T>(planes->side, K + off1, Lf + off1, linv + off1, work + off1, nullptr, npad, (int)(wn / kFitBlock), r1, n,
+                     diag64, info);
+      (void)hipEventRecord(planes->ev_chain, planes->side);
+      chain_on_side = true;
+      continue;
+    }
     launch_gemm<T>(st, u);
   }
-  return 0;
+  return dag64 ? 1 : 0;
 }
 template int launch_potrf<float>(hipStream_t, float*, float*, float*, float*, float*, int64_t, int64_t, double*, int*, int64_t, const FitPlanes*);
 template int launch_potrf<double>(hipStream_t, double*, double*, double*, double*, double*, int64_t, int64_t, double*, int*, int64_t, const FitPlanes*);

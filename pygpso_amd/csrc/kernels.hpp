@@ -179,6 +179,12 @@ struct FitPlanes {
   // current rank-W update runs on the caller's stream; ev_col / ev_chain order the two streams
   hipStream_t side = nullptr;
   hipEvent_t ev_col = nullptr, ev_chain = nullptr;
+  // Round 6 (double fits; L == nullptr): `side` also carries the look-ahead of the float64 two-level fit, and `inv` (nullable)
+  // the level-doubling inverse, issued pair by pair as soon as the panels it reads are final -- the first product of the last
+  // level starts when HALF of the factorisation is done (launch_potrf); ev_panel / ev_inv order the streams
+  hipStream_t inv = nullptr;
+  hipEvent_t ev_panel = nullptr, ev_inv = nullptr;
+  int overlap = 0;  // double fits: bit 0 look-ahead on `side`, bit 1 the inverse on `inv` (GPSO_OPT_FIT_OVERLAP)
 };
 inline size_t fit_plane_set_bytes(int64_t npad) { return (size_t)3 * (size_t)npad * (size_t)npad * 2; }
 // power-of-two scales of the fp16 planes for hyper-parameters (variance, noise); false: a scale leaves the range in which

@@ -1194,3 +1194,43 @@ def test_leaves_scaled_in_the_kernels_prologue_give_the_prep_kernels_bits(n, d):
     assert all(np.array_equal(u, v) for u, v in zip(res[0][0], res[0][3]))  # float leaves == the same values as doubles
     mean_ref, var_ref = gpr.predict_y(gpr.posterior(th, X, y), Xs.astype(np.float64))
     assert np.max(np.abs(res[0][0][1] - var_ref)) <= 2e-5 * th.variance
+
+
+# ---- round 6: the double two-level fit overlaps chains, updates and the inverse (GPSO_OPT_FIT_OVERLAP) ---------------------
+@pytest.mark.parametrize("n,d,force_two_level", [(2048, 6, True), (1500, 3, True), (4096, 6, False), (3000, 5, False)])
+def test_overlapped_double_fit_gives_the_sequential_schedules_bits(n, d, force_two_level):
+    """float64 / mixed fits above the single-level limit look the diagonal chains ahead on a side stream and issue the
+    level-doubling inverse pair by pair on a third one as soon as its panels are final (fit.hip: launch_potrf).  The same
+    products on the same tiles in the same k order: L, L^-1, alpha, K^-1, NLML and gradient are the sequential schedule's
+    bits -- and the oracle's values to 1e-9.  Panel counts: 4 (a power of two: the overlapped inverse) and 3 (look-ahead
+    only), at the default limit and forced at small sizes."""
+    from pygpso_amd import HipGPEngine, _lib as L
+
+    X, y, th = _problem(n, d, noise=1e-3)
+    res = {}
+    for overlap in (3, 2, 0):  # look-ahead + overlapped inverse | the default (overlapped inverse) | sequential
+        eng = HipGPEngine("float64")
+        eng._check(eng._lib.gpso_set_option(eng._h, L.OPT_FIT_OVERLAP, overlap))
+        if force_two_level:
+            eng.set_fit_single_level_max(0)
+        outs = []
+        for rep in range(2):  # (twice: stream / event reuse across fits of one context)
+            f, g = _fit(eng, X, y, th, grad=True)
+            outs.append((f, g.tobytes(), eng.get_matrix(L.MAT_LINV).tobytes(), eng.get_matrix(L.MAT_CHOL).tobytes(),
+                         eng.get_vector(L.VEC_ALPHA).tobytes(), eng.get_matrix(L.MAT_KINV).tobytes()))
+        assert outs[0] == outs[1]
+        res[overlap] = (outs[0], eng)
+    assert res[3][0] == res[0][0] and res[2][0] == res[0][0]
+    f_ref, g_ref = gpr.nlml_and_grad(th, X, y)
+    post = gpr.posterior(th, X, y)
+    eng = res[3][1]
+    f = res[3][0][0]
+    assert abs(f - f_ref) <= 1e-9 * abs(f_ref)
+    assert _rel(eng.get_matrix(L.MAT_CHOL), post.L) < 1e-9
+    assert _rel(eng.get_matrix(L.MAT_LINV), np.linalg.inv(post.L)) < 1e-8
+    assert _rel(eng.get_vector(L.VEC_ALPHA), post.alpha) < 1e-7
+    g = np.frombuffer(res[3][0][1], dtype=np.float64)
+    assert np.max(np.abs(g - g_ref) / np.maximum(1.0, np.abs(g_ref))) < 1e-7
+    # a posterior fit (no gradient) leaves the same factor
+    f2, _ = _fit(eng, X, y, th, grad=False)
+    assert f2 == f and eng.get_matrix(L.MAT_LINV).tobytes() == res[3][0][2]
