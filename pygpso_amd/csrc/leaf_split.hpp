@@ -64,6 +64,15 @@ __device__ __forceinline__ void glds4(const void* gsrc_lane, void* lds_wave_base
 // everywhere; the epilogue undoes the scales (sum of squares x 2^-2(sa+sb), mean x 2^-sb).
 // (f16x2 / f16x8 and f16_split_pair: common.hpp -- the fit's fp16 planes use them too)
 
+// Round 6: the half-step stagger of waves 4-7 (leaf_bf16_fused_half below) is bit-identical to the shipped step and SLOWER
+// on the same box (tools/ab_time.py, alternating fresh processes: C3 0.7193 | 0.7379 ms, C4 share 5.339 | 5.490 ms; profiles/
+// r06_predict_experiments.txt): the partners are already out of step -- the SIMD's arbiter serves the older wave first, waves
+// 0-3 are through a step in 3 700 clocks and wait for waves 4-7 -- so the delay adds to the slower half's path instead of
+// filling the faster half's wait.  Built only with -DGPSO_LEAF_STAGGER=1.
+#ifndef GPSO_LEAF_STAGGER
+#define GPSO_LEAF_STAGGER 0
+#endif
+constexpr bool kLeafStagger = GPSO_LEAF_STAGGER != 0;
 #ifndef GPSO_BSTAMP
 #define GPSO_BSTAMP(q, i)  // tools/micro/leaf_bf16_phases.hip defines this to record s_memtime stamps
 #endif
@@ -475,6 +484,136 @@ __device__ __forceinline__ void leaf_bf16_fused_step(int q, int q_diag0, int lan
   }
 }
 
+// ---- the fused step in two HALVES (round 6: the stagger) ------------------------------------------------------------------
+// All eight waves run the same fused stream with one barrier per step, two waves per SIMD: partners reach their MFMA
+// bursts, their LDS fragment reads and the barrier together (matrix pipe busy 0.62, the rest is waiting on each other:
+// MI355X_MICROARCH.md, "two waves per SIMD", item 9).  The stagger delays waves 4-7 by HALF a step: the step is cut between
+// row tiles RTL / 2 - 1 and RTL / 2, waves 0-3 meet the barrier at the end of a step, waves 4-7 in its middle -- one copy of
+// the code, only the place of the barrier differs.  Waves 4-7 then read the L^-1 pieces of step q - 1 (second half) and of
+// step q (first half) in the interval in which waves 0-3 issue the DMAs of step q + 1: the pieces live in a ring of THREE
+// buffers.  Same operations on the same operands in the same order per wave: the same bits.
+// The state a step carries from its first half to its second (registers):
+template <int NS, typename TG, int CT = 2>
+struct FusedRegs {
+  typename Mfma<TG>::vec4 s[2][CT];
+  typename Mfma<TG>::vec4 nav[2];
+  float p[CT][8], ex[CT][8];
+  TG na[2][4];
+  f32x4 al4[2];
+  u32x4 fr[NS][CT];
+  u32x4 a[2][NS];
+};
+template <int NS, typename TG, int KERNEL, bool F16, int ASKIP, int GMODE, int C16, int RTL, int HALF>
+__device__ __forceinline__ void leaf_bf16_fused_half(int lane, int dp4, const u32x4* panel_b, const unsigned char* xs_n,
+                                                     const TG* xb, const TG (&nb)[2], const TG cm, const float (&vc)[3],
+                                                     const bf16x8 (&bcur)[NS][2], bf16x8 (&bnxt)[NS][2], f32x4 (&acc)[16][2],
+                                                     float (&macc)[2], FusedRegs<NS, TG>& R) {
+  using MG = Mfma<TG>;
+  using vecG = typename MG::vec4;
+  constexpr int RT = 16, CT = 2;
+  constexpr TG SC = (TG)GenScale<KERNEL>::SC;
+  constexpr bool GEN = GMODE != 0;
+  const int XF = Bf16Lds<TG, C16>::xfrag(dp4);
+  constexpr int E = 16;
+  constexpr int O_COMB = C16 != 0 ? 0 : 8, O_SQRT = O_COMB + E, O_EXP = O_SQRT + (KERNEL == 3 ? 0 : E), O_POLY = O_EXP + E,
+                O_MEAN = O_POLY + E, O_SPLIT = O_MEAN + (GMODE == 2 ? E : 0), NOPS = O_SPLIT + 8;
+  static_assert(ASKIP >= 0 && ASKIP < RTL && RTL <= RT && RTL % 2 == 0, "at least one live row tile");
+  if constexpr (HALF == 0) {
+    if constexpr (GEN) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) R.s[h][t] = vecG{0, 0, 0, 0};
+      if constexpr (C16 == 0) {
+        const TG* nrm = reinterpret_cast<const TG*>(xs_n + XF);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) R.nav[h] = *reinterpret_cast<const vecG*>(nrm + 16 * h + 4 * (lane >> 4));
+      }
+      leaf_contract<TG, C16, CT>(lane, dp4, xs_n, xb, R.s);
+    }
+    if constexpr (GMODE == 2) {
+      const float* alp = reinterpret_cast<const float*>(xs_n + XF + 64 * sizeof(TG));
+#pragma unroll
+      for (int h = 0; h < 2; ++h) R.al4[h] = *reinterpret_cast<const f32x4*>(alp + 16 * h + 4 * (lane >> 4));
+    }
+#pragma unroll
+    for (int sp = 0; sp < NS; ++sp) R.a[ASKIP & 1][sp] = panel_b[(sp * RT + ASKIP) * 64 + lane];
+  }
+  auto op = [&](auto o_) {
+    constexpr int o = decltype(o_)::value;
+    if constexpr (o < O_COMB) {
+      R.na[o >> 2][o & 3] = R.nav[o >> 2][o & 3] * SC;
+    } else if constexpr (o < O_SQRT) {
+      constexpr int e = o - O_COMB, t = e >> 3, h = (e >> 2) & 1, r = e & 3;
+      if constexpr (C16 != 0) R.p[t][4 * h + r] = (float)fma_t(cm, R.s[h][t][r], nb[t]);
+      else R.p[t][4 * h + r] = (float)fma_t(cm, R.s[h][t][r], R.na[h][r] + nb[t]);
+    } else if constexpr (o < O_EXP) {
+      constexpr int e = o - O_SQRT, t = e >> 3, j = e & 7;
+      if constexpr (sizeof(TG) == 4) R.p[t][j] = __builtin_amdgcn_sqrtf(__builtin_fabsf(R.p[t][j]));
+      else R.p[t][j] = __builtin_amdgcn_sqrtf(fmaxf(R.p[t][j], (float)(GenScale<KERNEL>::SC * 1e-36)));
+    } else if constexpr (o < O_POLY) {
+      constexpr int e = o - O_EXP, t = e >> 3, j = e & 7;
+      R.ex[t][j] = __builtin_amdgcn_exp2f(-R.p[t][j]);
+    } else if constexpr (o < O_MEAN) {
+      constexpr int e = o - O_POLY, t = e >> 3, j = e & 7;
+      if constexpr (KERNEL == 0) R.p[t][j] = fmaf(R.p[t][j], fmaf(R.p[t][j], vc[2], vc[1]), vc[0]) * R.ex[t][j];
+      else if constexpr (KERNEL == 1) R.p[t][j] = fmaf(R.p[t][j], vc[1], vc[0]) * R.ex[t][j];
+      else R.p[t][j] = vc[0] * R.ex[t][j];
+    } else if constexpr (o < O_SPLIT) {  // (GMODE 2) k*.alpha in f32, before the split; per column tile in the order j = 0 .. 7
+      constexpr int e = o - O_MEAN, t = e >> 3, j = e & 7;
+      macc[t] = fma_t(R.p[t][j], R.al4[j >> 2][j & 3], macc[t]);
+      asm volatile("" : "+v"(macc[t]));  // the two tiles' means stay in separate registers (see leaf_bf16_gen)
+    } else {
+      constexpr int e = o - O_SPLIT, t = e >> 2, j = e & 3;
+      if constexpr (F16) {
+        unsigned hh, ll;
+        f16_split_pair_both(R.p[t][2 * j], R.p[t][2 * j + 1], hh, ll);
+        R.fr[0][t][j] = hh;
+        R.fr[1][t][j] = ll;
+      } else {
+#pragma unroll
+        for (int sp = 0; sp < NS; ++sp) R.fr[sp][t][j] = bf16_split_pair(R.p[t][2 * j], R.p[t][2 * j + 1]);
+      }
+    }
+  };
+  static_for<HALF * (RTL / 2), (HALF + 1) * (RTL / 2)>([&](auto rt_) {
+    constexpr int rt = decltype(rt_)::value;
+    if constexpr (rt + 1 < RTL && rt + 1 > ASKIP) {
+#pragma unroll
+      for (int sp = 0; sp < NS; ++sp) R.a[(rt + 1) & 1][sp] = panel_b[(sp * RT + rt + 1) * 64 + lane];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (rt >= ASKIP) {  // (diagonal block: all-zero tiles above the diagonal)
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        f32x4 c = acc[rt][t];
+#define GPSO_BF(SA, SB)                                                                                                   \
+  c = F16 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, R.a[rt & 1][SA]), __builtin_bit_cast(f16x8, bcur[SB][t]), c, 0, 0, 0) \
+          : __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, R.a[rt & 1][SA]), bcur[SB][t], c, 0, 0, 0)
+        if constexpr (NS == 3) {
+          GPSO_BF(2, 0);
+          GPSO_BF(0, 2);
+          GPSO_BF(1, 1);
+        }
+        GPSO_BF(1, 0);
+        GPSO_BF(0, 1);
+        GPSO_BF(0, 0);
+#undef GPSO_BF
+        acc[rt][t] = c;
+      }
+    }
+    if constexpr (GEN && rt >= 1) {  // this row tile's share of the map: ops [(rt - 1) NOPS / (RTL - 1), rt NOPS / (RTL - 1))
+      static_for<(rt - 1) * NOPS / (RTL - 1), rt * NOPS / (RTL - 1)>(op);
+    }
+  });
+  if constexpr (GEN && HALF == 1) {
+#pragma unroll
+    for (int sp = 0; sp < NS; ++sp)
+#pragma unroll
+      for (int t = 0; t < CT; ++t) bnxt[sp][t] = __builtin_bit_cast(bf16x8, R.fr[sp][t]);
+  }
+}
+
 // F16: the fp16 split (two pieces, three products); `variance` then arrives multiplied by 2^sb, inv_scale_a[1] is
 // 2^-sa (device, written by pack_linv_f16_kernel) and inv_scale_b = 2^-sb
 // FUSED: every wave runs the fused step (apply of step q with the generation of step q + 1 in its MFMA shadows, one
@@ -495,8 +634,12 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   constexpr TG SC = (TG)GenScale<KERNEL>::SC;
   extern __shared__ __align__(16) unsigned char lds_raw[];
   if (m_live != nullptr && (int64_t)blockIdx.x * (NW * CT * 16) >= *m_live) return;  // workgroup-uniform
-  u32x4* panel = reinterpret_cast<u32x4*>(lds_raw);                 // [2][NS][RT][64]
-  unsigned char* xsl = reinterpret_cast<unsigned char*>(panel + 2 * NS * RT * 64);  // [3] X buffers
+  // STAG (round 6): waves 4-7 run half a step behind waves 0-3 (leaf_bf16_fused_half); the L^-1 pieces then live in a ring of
+  // three buffers -- where that fits the 160 KB (one chunk of the fp16 contraction: D <= 28)
+  constexpr bool STAG = kLeafStagger && FUSED && NS == 2 && F16 && C16 == 1;
+  constexpr int PBUF = STAG ? 3 : 2;
+  u32x4* panel = reinterpret_cast<u32x4*>(lds_raw);                 // [PBUF][NS][RT][64]
+  unsigned char* xsl = reinterpret_cast<unsigned char*>(panel + PBUF * NS * RT * 64);  // [3] X buffers
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int xstride = Bf16Lds<TG, C16>::xbytes(dp4);
@@ -669,7 +812,7 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   __syncthreads();
 
   auto issue_for = [&](int k) {
-    if (k + 1 < q_lim) issue_panel(k + 1, (k + 1) & 1);
+    if (k + 1 < q_lim) issue_panel(k + 1, STAG ? (k + 1) % 3 : (k + 1) & 1);
     if (k + 2 < q_end && k + 2 <= q_lim) issue_x(k + 2);  // (step q_lim is still GENERATED by step q_lim - 1: padding points, alpha = 0)
   };
   if constexpr (FUSED) {
@@ -677,6 +820,10 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     // (into the buffer step q - 1 was applied from) and of the inputs of step q + 2 (ring of three) are issued, then
     // the fused step applies step q and generates step q + 1.  Step 0 is generated on its own.
     bf16x8 bnxt[NS][CT];
+    FusedRegs<NS, TG> fregs;
+    const bool late = wave >= NW / 2;  // (wave-uniform) the staggered half
+    (void)fregs;
+    (void)late;
     if (q_diag0 == 0) leaf_bf16_gen<NS, TG, KERNEL, F16, true, C16>(lane, dp4, xsl, xb, nb, cm, vc, bfrag, macc);
     else leaf_bf16_gen<NS, TG, KERNEL, F16, false, C16>(lane, dp4, xsl, xb, nb, cm, vc, bfrag, macc);
     // Measured and NOT kept (tools/ab_time.py, same box, f16x3 at C3: two-phase 0.850 | this 0.7955 ms): the step's DMAs
@@ -692,12 +839,26 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     GPSO_BSTAMP(q, 0);                                                                                                \
     issue_for(q);                                                                                                     \
     GPSO_BSTAMP(q, 1);                                                                                                \
-    leaf_bf16_fused_step<NS, TG, KERNEL, F16, ASKIP, GMODE, C16, RTL>(q, q_diag0, lane, dp4,                          \
-                                                                 panel + (q & 1) * NS * RT * 64,                      \
-                                                                 xsl + ((q + 1) % 3) * xstride, xb, nb, cm, vc,       \
-                                                                 bfrag, bnxt, acc, macc);                             \
-    GPSO_BSTAMP(q, 4);                                                                                                \
-    __syncthreads();                                                                                                  \
+    if constexpr (STAG) {                                                                                             \
+      leaf_bf16_fused_half<NS, TG, KERNEL, F16, ASKIP, GMODE, C16, RTL, 0>(lane, dp4, panel + (q % 3) * NS * RT * 64, \
+                                                                      xsl + ((q + 1) % 3) * xstride, xb, nb, cm, vc,  \
+                                                                      bfrag, bnxt, acc, macc, fregs);                 \
+      GPSO_BSTAMP(q, 2);                                                                                              \
+      if (late) __syncthreads(); /* waves 4-7 meet the barrier in the middle of their step */                         \
+      GPSO_BSTAMP(q, 3);                                                                                              \
+      leaf_bf16_fused_half<NS, TG, KERNEL, F16, ASKIP, GMODE, C16, RTL, 1>(lane, dp4, panel + (q % 3) * NS * RT * 64, \
+                                                                      xsl + ((q + 1) % 3) * xstride, xb, nb, cm, vc,  \
+                                                                      bfrag, bnxt, acc, macc, fregs);                 \
+      GPSO_BSTAMP(q, 4);                                                                                              \
+      if (!late) __syncthreads();                                                                                     \
+    } else {                                                                                                          \
+      leaf_bf16_fused_step<NS, TG, KERNEL, F16, ASKIP, GMODE, C16, RTL>(q, q_diag0, lane, dp4,                        \
+                                                                   panel + (q & 1) * NS * RT * 64,                    \
+                                                                   xsl + ((q + 1) % 3) * xstride, xb, nb, cm, vc,     \
+                                                                   bfrag, bnxt, acc, macc);                           \
+      GPSO_BSTAMP(q, 4);                                                                                              \
+      __syncthreads();                                                                                                \
+    }                                                                                                                 \
     GPSO_BSTAMP(q, 5);                                                                                                \
     if (GMODE != 0) {                                                                                                 \
       for (int sp = 0; sp < NS; ++sp)                                                                                 \
@@ -800,7 +961,8 @@ static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const T
                                      const float* c16_scale = nullptr, int64_t n_rows = 0, const RawLeaves& rawl = RawLeaves{}) {
   const int nbi = (int)(npad / 256);
   const dim3 grid((unsigned)(mpad / 256), (unsigned)nbi);
-  const size_t lds = leaf_bf16_lds_bytes(NS, dp4, (int)sizeof(TG), C16 != 0);
+  constexpr bool STAG = kLeafStagger && FUSED && NS == 2 && F16 && C16 == 1;
+  const size_t lds = leaf_bf16_lds_bytes(NS, dp4, (int)sizeof(TG), C16 != 0) + (STAG ? (size_t)NS * 16 * 64 * 16 : 0);  // (a third buffer of L^-1 pieces)
   if (C16 ? leaf_c16_chunks(dp4) != C16 : 2 * dp4 * (int)(sizeof(TG) / 4) > 32) {  // the X fragments of a k-step are one DMA window of 32 pieces (C16: 8)
     note_launch_error("launch_leaf_tiles_bf16: more than 32 X pieces per k-step");
     return 1;

@@ -107,7 +107,7 @@ def main():
     res = {lib: [] for lib in args.libs}
     for r in range(args.rounds):
         for lib in args.libs:
-            env = dict(os.environ, GPSO_HIP_LIB=os.path.abspath(lib))
+            env = dict(os.environ, GPSO_HIP_LIB=os.path.abspath(lib), GPSO_HIP_LIB_OLDER="1")
             cmd = [sys.executable, os.path.abspath(__file__), "--worker", "--what", args.what, "--steps", str(args.steps),
                    "--shape", *map(str, args.shape), "--math", args.math, "--dtype", args.dtype]
             p = subprocess.run(cmd, env=env, capture_output=True, text=True)
