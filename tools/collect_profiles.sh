@@ -3,13 +3,17 @@
 # copied into profiles/ as TAG_* (see profiles/README.md).
 #   a = bench lines + kernel stats + PMC passes + step timeline      b = fit timelines, loop bench, host overhead, fuzz, float errors
 #   c = round-5 additions: append bench, fit-plane modes, vendor yardstick
-TAG=${1:-r05}
+TAG=${1:-r06}
 PART=${2:-all}   # a = bench lines + kernel stats + PMC, b = fit timelines, loop bench, host overhead, fuzz
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 KPAT="leaf_tiles_bf16_kernel<2, float, 0, true, true, 1>"   # the fp16 split instantiation (first rung of GPSO_MATH_AUTO)
 if [ $PART = a ] || [ $PART = all ]; then
 python3 $R/bench.py > $O/bench_c3.json 2> $O/bench_c3.err
 for w in c2 c4 c5 c3f64; do python3 $R/bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2>/dev/null; done
+# (round 6) the reference's own dtype and "mixed" at the large shares; SURVEY 8(d) family A leaves (grown on the device)
+for w in c4 c5; do for t in float64 mixed; do python3 $R/bench.py --workload $w --dtype $t --no-cpu-baseline --steps 30 --warmup 5 > $O/bench_${w}_$t.json 2>/dev/null; done; done
+for cfg in "c2 8" "c3 11" "c4 12"; do set -- $cfg; python3 $R/bench.py --workload $1 --leaves grow --depth $2 --steps 100 --no-hyperopt > $O/bench_grow_d$2.json 2>/dev/null; done
+for sd in 1 2 3 4; do python3 $R/bench.py --seed $sd --no-cpu-baseline --no-hyperopt > $O/bench_c3_seed$sd.json 2>/dev/null; done
 for m in native bf16x6; do python3 $R/bench.py --math $m --no-cpu-baseline > $O/bench_c3_$m.json 2>/dev/null; done
 echo "bench lines done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_c3_under_rocprof.json 2>/dev/null
@@ -35,6 +39,9 @@ for cfg in "2048 12 c3" "8192 20 c4" "16384 40 c5"; do
   bash $R/tools/collect_fit_timeline.sh $TAG/fit_$3_grad $1 $2 grad > /dev/null 2>&1
   echo "fit timeline $3 done"
 done
+python3 $R/tools/fit_overlap_ab.py n4096 c4 c5 --modes 0 2 > $O/fit_overlap_ab.jsonl 2>/dev/null
+python3 $R/tools/loop_large_n.py --refit-every 1 5 > $O/loop_large_n.jsonl 2>/dev/null
+python3 $R/tools/loop_large_n.py --refit-every 1 5 --dtype float32 >> $O/loop_large_n.jsonl 2>/dev/null
 for a in "2 5 50" "4 7 80" "6 9 60"; do set -- $a; python3 $R/tools/loop_bench.py --dim $1 --depth $2 --budget $3; done > $O/loop_bench.jsonl 2>/dev/null
 python3 $R/tools/host_overhead.py 52 2 2>/dev/null | grep -E "wall|device" > $O/host_overhead.txt
 for s in 41 42 43; do FUZZ_CASES=80 FUZZ_SEED=$s python3 $R/tools/fuzz_gpu.py > $O/fuzz_seed$s.log 2>&1; tail -1 $O/fuzz_seed$s.log; done

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel time of the split predict kernel at C3 with whatever library GPSO_HIP_LIB names (ablation builds of
 csrc/predict.hip: -DGPSO_ABL_HALFGEN / -DGPSO_ABL_NOGEN; their RESULTS are wrong by construction, only the time counts).
-Round 4: the -DGPSO_ABL_* hooks live in tools/micro/predict_hooks.patch -- `git apply` it before building the ablation
+Round 4: the -DGPSO_ABL_* hooks live in tools/attic/predict_hooks.patch -- `git apply` it before building the ablation
 libraries.  tools/ab_time.py alternates several libraries in one GPU call (boxes differ by up to 10 %)."""
 import os
 import sys

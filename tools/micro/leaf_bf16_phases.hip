@@ -23,7 +23,7 @@ __device__ long long g_cst[2 * 64 * 8];
 #ifndef GPSO_CSTAMP
 #define GPSO_CSTAMP(q, i)
 #endif
-#include "leaf_tiles_wide.hpp"
+#include "../attic/leaf_tiles_wide.hpp"
 #include <cstdio>
 #include <cmath>
 #include <vector>

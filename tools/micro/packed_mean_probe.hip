@@ -6,7 +6,7 @@
 //   packed       hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DGPSO_PROBE_PACKED_MEAN -I pygpso_amd/csrc
 //                  tools/micro/packed_mean_probe.hip -o tools/micro/packed_mean_probe_packed.bin
 // (round 4: the GPSO_PROBE_* hooks the packed / dump builds need are no longer in predict.hip -- git apply
-//  tools/micro/predict_hooks.patch first; the hunt is parked: profiles/r03_packed_mean.txt)
+//  tools/attic/predict_hooks.patch first; the hunt is parked: profiles/r03_packed_mean.txt)
 // (packed: SLP vectorisation on and the empty asm behind the mean updates left out, so the two column tiles' means
 // are accumulated as one chain of dependent v_pk_fma_f32)
 #include "../../pygpso_amd/csrc/predict.hip"

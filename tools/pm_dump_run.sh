@@ -3,7 +3,7 @@
 # processes of the packed build in its original protocol -- and only on a box that shows it the dump build
 # (tools/micro/packed_mean_probe.hip -DGPSO_PROBE_PACKED_MEAN -DGPSO_PROBE_DUMP_MACC): which lanes / links of the
 # first launch differ from a warm launch.
-# (round 4: git apply tools/micro/predict_hooks.patch first -- the GPSO_PROBE_* hooks left predict.hip)
+# (round 4: git apply tools/attic/predict_hooks.patch first -- the GPSO_PROBE_* hooks left predict.hip)
 N=${1:-40}
 M=${2:-200}
 mkdir -p gpurun_out
