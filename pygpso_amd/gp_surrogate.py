@@ -65,10 +65,17 @@ class GPListOfPoints(list):
     not de-duplicate.  ``append`` additionally RETURNS the index the point now lives at (first
     duplicate, or the new last position)."""
 
-    # bucket width of the index on the first coordinate: any two points closer than the duplicate
-    # tolerance (1e-12, L2) differ by at most that in coordinate 0, so a duplicate of x can only sit
-    # in the bucket of x[0] or one of its two neighbours
+    # The index hashes a PROJECTION w.x of the coordinates, bucket width 1e-6: two points closer than the duplicate
+    # tolerance (1e-12, L2) differ by at most |w| x 1e-12 < 1.5e-12 in it, so a duplicate of x can only sit in the bucket of
+    # w.x or one of its two neighbours.  (Rounds 1-5 hashed coordinate 0 alone: the centres of a ternary tree share their
+    # first coordinate -- in D = 12 the tree splits other dimensions for a long time --, nearly every point fell into ONE
+    # bucket and a look-up scanned the whole list in Python: 250 us per look-up at 1 000 points, O(P^2) per gp_update.  With
+    # w_i = 1 / sqrt(i-th prime) distinct grid points have distinct projections.)
     _BUCKET = 1.0e-6
+    _PRIMES = (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67, 71, 73, 79, 83, 89, 97, 101, 103, 107,
+               109, 113, 127, 131, 137, 139, 149, 151, 157, 163, 167, 173, 179, 181, 191, 193, 197, 199, 211, 223, 227, 229,
+               233, 239, 241, 251, 257, 263, 269, 271, 277, 281, 283, 293, 307, 311)
+    _W = tuple(1.0 / math.sqrt(p) for p in _PRIMES)  # |w|^2 = sum 1 / p < 2.1 over these 64
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
@@ -85,12 +92,18 @@ class GPListOfPoints(list):
             self._rows = [tuple(np.asarray(p.normed_coord, dtype=np.float64).reshape(-1).tolist()) for p in self]
             self._buckets = {}
             for i, r in enumerate(self._rows):
-                self._buckets.setdefault(self._bucket_of(r[0]), []).append(i)
+                self._buckets.setdefault(self._bucket_of(r), []).append(i)
             self._dirty = False
 
     @classmethod
-    def _bucket_of(cls, c0):
-        return int(math.floor(float(c0) / cls._BUCKET))
+    def _bucket_of(cls, row):
+        """bucket of the projection w.row (dimensions beyond the 64 weights wrap around: still a valid projection)"""
+        w = cls._W
+        if len(row) <= len(w):
+            proj = sum(a * b for a, b in zip(row, w))
+        else:
+            proj = sum(a * w[i % len(w)] for i, a in enumerate(row))
+        return int(math.floor(proj / cls._BUCKET))
 
     def _matches(self, coords):
         """Indices (ascending) of the stored points within the duplicate tolerance of ``coords`` --
@@ -100,7 +113,7 @@ class GPListOfPoints(list):
         if not self._rows:
             return []
         c = np.asarray(coords, dtype=np.float64).reshape(-1).tolist()
-        b = self._bucket_of(c[0])
+        b = self._bucket_of(c)
         get = self._buckets.get
         cand = get(b - 1, _NONE) + get(b, _NONE) + get(b + 1, _NONE)
         if not cand:
@@ -123,7 +136,7 @@ class GPListOfPoints(list):
         if isinstance(idx, int) and not self._dirty and n == len(self) and -n <= idx < n:
             i = idx % n
             row = tuple(np.asarray(value.normed_coord, dtype=np.float64).reshape(-1).tolist())
-            old_b, new_b = self._bucket_of(self._rows[i][0]), self._bucket_of(row[0])
+            old_b, new_b = self._bucket_of(self._rows[i]), self._bucket_of(row)
             self._rows[i] = row
             if old_b != new_b:
                 self._buckets[old_b].remove(i)
@@ -145,7 +158,7 @@ class GPListOfPoints(list):
         if not self._dirty and len(self._rows) == n:
             row = tuple(np.asarray(point.normed_coord, dtype=np.float64).reshape(-1).tolist())
             self._rows.append(row)
-            self._buckets.setdefault(self._bucket_of(row[0]), []).append(n)
+            self._buckets.setdefault(self._bucket_of(row), []).append(n)
         else:
             self._dirty = True
         return n
@@ -343,7 +356,7 @@ class GPRSurrogate(GPSurrogate):
 
     def __init__(self, gp_kernel, gp_meanf=None, optimiser=None, varsigma=erfcinv(0.01),
                  gauss_likelihood_sigma=1.0e-3, points=None, gpflow_model=None, dtype="float64",
-                 device=0, engine_options=None, devices=None, refit_every=1):
+                 device=0, engine_options=None, devices=None, refit_every=1, refit_guard=2.0):
         """
         :param gauss_likelihood_sigma: initial noise VARIANCE of the Gaussian likelihood (the
             reference passes it as ``noise_variance`` despite the name, gpso/gp_surrogate.py:494)
@@ -351,12 +364,18 @@ class GPRSurrogate(GPSurrogate):
             (gpso/gp_surrogate.py:496-503).  c > 1 (opt-in, NOT the reference's behaviour): only every c-th update
             re-optimises; the updates in between keep the hyper-parameters and extend the device posterior by the new
             points in place (``gpso_append``: O(N^2 k) instead of 10-45 O(N^3) loss evaluations)
+        :param refit_guard: (with ``refit_every`` > 1) how far the kept hyper-parameters may drift before an appended
+            posterior counts as stale: an append's NLML increment per new point is -log p(y_new | data, theta); when it
+            exceeds the fit's own average (NLML / N) by more than ``refit_guard`` nats per point the new points are
+            surprising under theta and THIS update re-optimises instead of waiting for the c-th.  None: no guard
         """
         super().__init__(gp_kernel=gp_kernel, gp_meanf=gp_meanf, optimiser=optimiser,
                          varsigma=varsigma, points=points, gpflow_model=gpflow_model, dtype=dtype,
                          device=device, engine_options=engine_options, devices=devices)
         self.gp_lik_sigma = gauss_likelihood_sigma
         self.refit_every = max(1, int(refit_every))
+        self.refit_guard = None if refit_guard is None else float(refit_guard)
+        self.guard_refits = 0  # updates the guard turned into re-optimisations
         self._updates = 0  # gp_update calls so far (refit_every counts them)
 
     @classmethod
@@ -386,16 +405,29 @@ class GPRSurrogate(GPSurrogate):
                                        engine_options=self.engine_options, devices=self.devices)
         else:
             n_old = self.gpflow_model.data[0].shape[0]
-            keep_theta = (self.refit_every > 1 and self._updates % self.refit_every != 0 and x.shape[0] > n_old
-                          and np.array_equal(x[:n_old], self.gpflow_model.data[0])
-                          and np.array_equal(y[:n_old], self.gpflow_model.data[1]))
-            if keep_theta:
-                # the evaluated points only ever grow at the end (GPListOfPoints keeps insertion order): extend the
-                # posterior at the kept hyper-parameters
+            new_rows = None
+            if self.refit_every > 1 and self._updates % self.refit_every != 0 and x.shape[0] > n_old:
+                new_rows = self._rows_beyond(self.gpflow_model.data, x, y)
+            if new_rows is not None:
+                # the model's points are all still there with their scores: extend the posterior at the kept
+                # hyper-parameters by the others.  (The evaluated points do NOT only grow at the end of the list: an
+                # evaluation of a point that was stored gp-based overwrites that entry in place, gpso/gp_surrogate.py:
+                # 68-101 -- the model then holds the points in ITS order of arrival, a permutation of the list's; the next
+                # re-optimisation sets the list's order again.)
                 try:
-                    self.gpflow_model.append_data(x[n_old:], y[n_old:])
-                    self._updates += 1
-                    return
+                    model = self.gpflow_model
+                    model._ensure_resident()
+                    nlml_before = float(model._last_nlml)
+                    model.append_data(x[new_rows], y[new_rows])
+                    per_new = (float(model._last_nlml) - nlml_before) / (x.shape[0] - n_old)
+                    if self.refit_guard is None or not (per_new > nlml_before / n_old + self.refit_guard):
+                        self._updates += 1
+                        return
+                    # the new points are much less likely under the kept hyper-parameters than the old ones were on
+                    # average: theta has drifted -- re-optimise now (the model already holds all points)
+                    self.guard_refits += 1
+                    logging.info(f"appended points cost {per_new:.2f} nats each against {nlml_before / n_old:.2f} on average: "
+                                 "re-optimising the hyper-parameters on this update")
                 except np.linalg.LinAlgError as err:
                     # the appended block is not positive definite at the kept hyper-parameters (in the engine's
                     # arithmetic): the model holds the N + k points with no posterior -- this update re-optimises instead
@@ -404,6 +436,21 @@ class GPRSurrogate(GPSurrogate):
                 self.gpflow_model.data = (x, y)  # hyper-parameters warm-start from the last optimum
         self._updates += 1
         self.optimiser.minimize(self.gpflow_model.training_loss, self.gpflow_model.trainable_variables)
+
+    @staticmethod
+    def _rows_beyond(data, x, y):
+        """Indices of the rows of (x, y) that the model's data does not hold, when EVERY row of the model's data is among
+        (x, y) bit for bit with its score (any order) -- else None: the update cannot be an append."""
+        old_x, old_y = data
+        if old_x.shape[1] != x.shape[1] or x.shape[0] <= old_x.shape[0]:
+            return None
+        rec = np.dtype([("", np.float64)] * (x.shape[1] + 1))
+        new_v = np.ascontiguousarray(np.hstack([x, y.reshape(-1, 1)]), dtype=np.float64).view(rec).ravel()
+        old_v = np.ascontiguousarray(np.hstack([old_x, old_y.reshape(-1, 1)]), dtype=np.float64).view(rec).ravel()
+        held = np.isin(new_v, old_v)
+        if int(held.sum()) != old_v.shape[0] or np.unique(old_v).shape[0] != old_v.shape[0]:
+            return None
+        return np.flatnonzero(~held)
 
     # -- persistence: points JSON (reference schema) + hyper-parameters as plain JSON ---------------
     def save(self, folder):
@@ -423,6 +470,7 @@ class GPRSurrogate(GPSurrogate):
             "optimiser": [type(self.optimiser).__name__],
             "dtype": self.dtype,
             "refit_every": self.refit_every,  # (not in the reference's schema: an extra key; 1 = the reference's behaviour)
+            "refit_guard": self.refit_guard,
         }
         with open(os.path.join(folder, self.GPR_INFO), "w") as fh:
             fh.write(json.dumps(info))
@@ -449,4 +497,4 @@ class GPRSurrogate(GPSurrogate):
         return cls(gp_kernel=kernel, gp_meanf=meanf, optimiser=Scipy(),
                    gauss_likelihood_sigma=info["gp_likelihood"], varsigma=info["gp_varsigma"],
                    points=points, gpflow_model=model, dtype=info.get("dtype", "float64"), device=device,
-                   devices=devices, refit_every=info.get("refit_every", 1))
+                   devices=devices, refit_every=info.get("refit_every", 1), refit_guard=info.get("refit_guard", 2.0))

@@ -617,3 +617,117 @@ def test_a_failed_append_leaves_model_and_surrogate_in_one_state():
     surr.append(X[33:35], y[33:35])
     surr.gp_update()  # the next update appends again
     assert model.num_loss_evals == evals and model.data[0].shape[0] == 35
+
+
+def test_refit_guard_turns_a_surprising_append_into_a_reoptimisation():
+    """nothing said how far theta may drift before an appended posterior is stale.  The append's NLML
+    increment per new point is -log p(y_new | data, theta): new points far off what theta predicts (here: the function's
+    scale changes) make THIS update re-optimise; ordinary points do not."""
+    from pygpso_amd.kernels import Constant, Matern52
+    from tests.helpers import synthetic_problem
+
+    class Eng(OracleEngine):
+        dtype_name = "float64"
+
+        def set_timing(self, on):
+            pass
+
+    X, y = synthetic_problem(60, 2, seed=4)
+    surr = GPRSurrogate(gp_kernel=Matern52(lengthscales=0.25, variance=1.0), gp_meanf=Constant(0.0), refit_every=10,
+                        refit_guard=2.0)
+    surr.engine_factory = Eng
+    surr.append(X[:40], y[:40])
+    surr.gp_update()
+    model = surr.gpflow_model
+    model.fused_transforms = False
+    evals = model.num_loss_evals
+    surr.append(X[40:44], y[40:44])  # points of the same function: appended at the kept hyper-parameters
+    surr.gp_update()
+    assert model.num_loss_evals == evals and surr.guard_refits == 0
+    surr.append(X[44:48], y[44:48] * 30.0 + 5.0)  # the objective's scale jumps: 4 points the posterior calls impossible
+    surr.gp_update()
+    assert surr.guard_refits == 1 and model.num_loss_evals > evals and model.data[0].shape[0] == 48
+    # without a guard the same update appends
+    plain = GPRSurrogate(gp_kernel=Matern52(lengthscales=0.25, variance=1.0), gp_meanf=Constant(0.0), refit_every=10,
+                         refit_guard=None)
+    plain.engine_factory = Eng
+    plain.append(X[:44], y[:44])
+    plain.gp_update()
+    plain.gpflow_model.fused_transforms = False
+    e0 = plain.gpflow_model.num_loss_evals
+    plain.append(X[44:48], y[44:48] * 30.0 + 5.0)
+    plain.gp_update()
+    assert plain.gpflow_model.num_loss_evals == e0 and plain.guard_refits == 0
+
+
+def test_refit_every_appends_although_an_evaluation_overwrote_a_gp_based_point_in_place():
+    """An evaluated point that duplicates a stored gp-based point overwrites that entry IN PLACE (the reference's rule,
+    gpso/gp_surrogate.py:68-101), so the evaluated points of the list do not only grow at its end.  Round 5's
+    ``refit_every`` compared prefixes and silently re-optimised on most updates of a real run (9 appends of 31 updates at
+    refit_every = 5); the model's points are now matched as a SET and the others appended."""
+    from pygpso_amd.kernels import Constant, Matern52
+    from tests.helpers import synthetic_problem
+
+    class Eng(OracleEngine):
+        dtype_name = "float64"
+
+        def set_timing(self, on):
+            pass
+
+    X, y = synthetic_problem(40, 2, seed=4)
+    surr = GPRSurrogate(gp_kernel=Matern52(lengthscales=0.25, variance=1.0), gp_meanf=Constant(0.0), refit_every=4)
+    surr.engine_factory = Eng
+    surr.append(X[:30], y[:30])
+    surr.gp_update()
+    model = surr.gpflow_model
+    model.fused_transforms = False
+    evals = model.num_loss_evals
+    surr.gp_predict(X[30:33])  # three gp-based points enter the list BEHIND the 30 evaluated ones ...
+    surr.append(X[33:35], y[33:35])  # ... two evaluated points behind those ...
+    surr.append(X[30:31], y[30:31])  # ... and the first gp-based point is evaluated: overwritten in place, in FRONT of them
+    xs, _ = surr.current_training_data
+    assert np.array_equal(xs[30], X[30]) and np.array_equal(xs[31], X[33])  # not a prefix extension of the model's data
+    surr.gp_update()
+    assert model.num_loss_evals == evals  # appended at the kept hyper-parameters all the same
+    assert model.data[0].shape[0] == 33 and np.array_equal(model.data[0][:30], X[:30])
+    assert sorted(map(tuple, model.data[0][30:].tolist())) == sorted(map(tuple, X[[30, 33, 34]].tolist()))
+    # a changed score of an old point is not an append
+    surr.points[0] = surr.points[0]._replace(score_mu=surr.points[0].score_mu + 1.0)
+    surr.append(X[35:36], y[35:36])
+    surr.gp_update()
+    assert model.num_loss_evals > evals
+
+
+def test_point_store_lookup_does_not_degenerate_on_tree_points_and_keeps_the_tolerance_rule():
+    """The centres of a ternary tree share coordinates: hashed on coordinate 0 alone (rounds 1-5) nearly every point of a
+    D = 12 run fell into one bucket and a look-up scanned the list (250 us at 1 000 points, O(P^2) per gp_update).  The
+    store now hashes a projection of all coordinates; the duplicate rule (L2 distance < 1e-12) is unchanged."""
+    import time
+
+    rng = np.random.default_rng(0)
+    d, n = 12, 3000
+    grid = rng.integers(0, 27, size=(n, d)) / 27.0 + 1.0 / 54.0
+    grid[:, 0] = 0.5  # every point shares coordinate 0 (and most share several others)
+    grid = np.unique(grid, axis=0)
+    pts = GPListOfPoints()
+    for row in grid:
+        pts.append(_pt(row))
+    assert len(pts) == grid.shape[0]
+    t0 = time.perf_counter()
+    for i in range(0, grid.shape[0], 3):
+        assert pts.find_index_by_coords(grid[i]) == i
+    per = (time.perf_counter() - t0) / (grid.shape[0] / 3)
+    assert per < 100e-6, f"{per * 1e6:.0f} us per look-up"  # (a linear scan of 3 000 rows of 12 numbers in Python: > 2 ms)
+    assert max(len(v) for v in pts._buckets.values()) <= 3
+    # the tolerance rule at random places, bucket edges of the projection included
+    for _ in range(300):
+        i = int(rng.integers(grid.shape[0]))
+        delta = rng.normal(size=d)
+        delta /= np.linalg.norm(delta)
+        assert pts.find_index_by_coords(grid[i] + 0.9e-12 * delta) == i
+        assert pts.find_index_by_coords(grid[i] + 3.0e-12 * delta) is None
+    w = np.array(GPListOfPoints._W[:d])
+    base = np.full(d, 0.25)
+    base[0] += (np.ceil(w @ base / 1e-6) * 1e-6 - w @ base) / w[0] - 2e-13 / w[0]  # projection 2e-13 below a bucket edge
+    edge = GPListOfPoints([_pt(base)])
+    assert edge.find_index_by_coords(base + 0.6e-12 * w / np.linalg.norm(w)) == 0  # (the duplicate sits in the NEXT bucket)
