@@ -82,7 +82,10 @@ class GPListOfPoints(list):
         assert all(isinstance(p, GPPoint) for p in self)
         self._rows = []      # coordinates of self[i] as a tuple of Python floats
         self._dirty = True
-        self._buckets = {}   # bucket of coordinate 0 -> indices (ascending)
+        self._buckets = {}   # bucket of the projection -> indices (ascending)
+        # every point came in through append(): no two stored points lie within the duplicate tolerance of each other (the
+        # constructor does not de-duplicate, list surgery may break it: cleared by anything but append / score updates)
+        self._unique = len(self) == 0
 
     # -- index kept in sync ------------------------------------------------------------------------
     # (plain Python floats on purpose: a look-up touches one or two candidate rows of D numbers, and the
@@ -132,6 +135,7 @@ class GPListOfPoints(list):
 
     def __setitem__(self, idx, value):
         super().__setitem__(idx, value)
+        self._unique = False  # (arbitrary surgery: the store can no longer vouch for uniqueness; append() keeps it itself)
         n = len(self._rows)
         if isinstance(idx, int) and not self._dirty and n == len(self) and -n <= idx < n:
             i = idx % n
@@ -149,9 +153,11 @@ class GPListOfPoints(list):
         assert isinstance(point, GPPoint)
         hits = self._matches(point.normed_coord)
         if hits:
+            unique = self._unique
             for i in hits:
                 if self[i].label != PointLabels.evaluated:
                     self[i] = point
+            self._unique = unique  # (a point replaced by one within the tolerance of it: uniqueness is kept)
             return hits[0]
         n = len(self)
         super().append(point)
@@ -162,6 +168,19 @@ class GPListOfPoints(list):
         else:
             self._dirty = True
         return n
+
+    def update_scores(self, indices, mean, var, varsigma):
+        """New (mean, var, ucb) for the points at ``indices``, coordinates and labels kept -- what re-appending a point with
+        the SAME coordinates does (it overwrites its own entry), without the look-up.  Only valid while no two stored points
+        are duplicates of each other (``_unique``); returns False otherwise and changes nothing."""
+        if not self._unique:
+            return False
+        setitem = list.__setitem__
+        for i, m, v in zip(indices, mean, var):
+            p = self[i]
+            m, v = float(m), float(v)
+            setitem(self, i, GPPoint(p.normed_coord, m, v, float(m + varsigma * v), p.label))  # (coordinates unchanged: the index stays valid)
+        return True
 
     def find_index_by_coords(self, coords):
         hits = self._matches(coords)
@@ -205,6 +224,7 @@ def _invalidating(name):
 
     def method(self, *args, **kwargs):
         self._dirty = True
+        self._unique = False
         return base(self, *args, **kwargs)
 
     method.__name__ = name
@@ -340,8 +360,17 @@ class GPSurrogate:
         if logging.getLogger().isEnabledFor(logging.DEBUG):  # (formatting the arrays is not free)
             logging.debug(f"Retraining GPR with x data: {x_train}; y data: {y_train}")
         self._gp_train(x=x_train, y=y_train[:, np.newaxis])
-        if self.num_gp_based > 0:
-            self.gp_predict(self.gp_based_coords)
+        # re-predict every gp-based point.  The reference re-appends them (gpso/gp_surrogate.py:341-342): each overwrites its
+        # own entry -- done here by index, one predict call and no look-ups, while the store can vouch that no two points are
+        # duplicates of each other; otherwise the reference's way
+        idx = [i for i, p in enumerate(self.points) if p.label == PointLabels.gp_based]
+        if idx:
+            coords = np.array([self.points[i].normed_coord for i in idx])
+            if getattr(self.points, "_unique", False):
+                mean, var = self.gpflow_model.predict_y(coords)
+                if self.points.update_scores(idx, np.asarray(mean)[:, 0], np.asarray(var)[:, 0], self.gp_varsigma):
+                    return
+            self.gp_predict(coords)
 
     def save(self, folder):
         raise NotImplementedError

@@ -731,3 +731,28 @@ def test_point_store_lookup_does_not_degenerate_on_tree_points_and_keeps_the_tol
     base[0] += (np.ceil(w @ base / 1e-6) * 1e-6 - w @ base) / w[0] - 2e-13 / w[0]  # projection 2e-13 below a bucket edge
     edge = GPListOfPoints([_pt(base)])
     assert edge.find_index_by_coords(base + 0.6e-12 * w / np.linalg.norm(w)) == 0  # (the duplicate sits in the NEXT bucket)
+
+
+def test_gp_update_by_index_equals_the_references_reappending():
+    """gp_update re-predicts every gp-based point; the reference re-appends them (each overwrites its own entry after a
+    look-up), the drop-in updates them by index while the store can vouch for uniqueness.  Same run either way: trace,
+    points, scores."""
+    from pygpso_amd.gp_surrogate import GPListOfPoints as Store
+
+    def run(force_reference_way):
+        space = ParameterSpace(parameter_names=["x", "y"], parameter_bounds=[[-3, 5], [-3, 3]])
+        opt = GPSOptimiser(space, exploration_depth=4, budget=40)
+        if force_reference_way:
+            real = Store.update_scores
+            Store.update_scores = lambda self, *a, **k: False
+        try:
+            best = opt.run(rotated_peaks)
+        finally:
+            if force_reference_way:
+                Store.update_scores = real
+        pts = [(tuple(p.normed_coord), p.score_mu, p.score_sigma, p.score_ucb, p.label) for p in opt.gp_surr.points]
+        return opt.trace, pts, best.score_mu, opt.gp_surr.points._unique
+
+    fast, slow = run(False), run(True)
+    assert fast[3] and fast[0] == slow[0] and fast[2] == slow[2]
+    assert fast[1] == slow[1]
