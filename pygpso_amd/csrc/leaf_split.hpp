@@ -73,6 +73,8 @@ __device__ __forceinline__ void glds4(const void* gsrc_lane, void* lds_wave_base
 #define GPSO_LEAF_STAGGER 0
 #endif
 constexpr bool kLeafStagger = GPSO_LEAF_STAGGER != 0;
+// GPSO_OPT_XCD_MAP (process-wide switch of the split kernels' workgroup assignment; api.hip sets it): predict.hip owns it
+extern int g_leaf_xcd_map;
 #ifndef GPSO_BSTAMP
 #define GPSO_BSTAMP(q, i)  // tools/micro/leaf_bf16_phases.hip defines this to record s_memtime stamps
 #endif
@@ -627,13 +629,37 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     const TG* __restrict__ lnorm, double* __restrict__ part_var, double* __restrict__ part_mean,
     int npad16, int dp4, int64_t mpad, int nbi, float variance, const int64_t* __restrict__ m_live,
     const float* __restrict__ inv_scale_a, float inv_scale_b, const float* __restrict__ c16_scale, int q_max,
+    int xcd_map /* 1: XCD-aware (leaf tile, row block) assignment (see below); 0: rounds 1-5's */,
     const float* __restrict__ raw /* nullable (C16 only): the caller's UNSCALED float leaves [raw_m][raw_d] -- the prologue
     scales them itself ((float)(x / l), rows beyond raw_m are padding): no prep launch in front of this kernel */,
     const double* __restrict__ raw_ls, int64_t raw_m, int raw_d) {
   constexpr int RT = 16, CT = 2, NW = 8;
   constexpr TG SC = (TG)GenScale<KERNEL>::SC;
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  if (m_live != nullptr && (int64_t)blockIdx.x * (NW * CT * 16) >= *m_live) return;  // workgroup-uniform
+  // ---- which (leaf tile, row block) this workgroup computes ------------------------------------------------------------
+  // Default: leaf tile = blockIdx.x, row block = heaviest first over blockIdx.y.  Consecutive workgroups go to the 8 XCDs
+  // round-robin, so all eight work on the SAME row block at any time and each XCD's L2 pulls its own copy of that block's
+  // planes: 89.8 MB of HBM / fabric traffic per launch at C3 against 12.4 MB algorithmic (7.2x).  Round 6 built the obvious
+  // cure (xcd_map != 0, GPSO_OPT_XCD_MAP = 1; needs an even number of row blocks and whole units per XCD): row blocks PAIRED
+  // (g, nbi - 1 - g) -- every pair weighs the same nbi + 1 units --, the (pair, leaf tile) units dealt to the XCDs in contiguous
+  // runs, two workgroups (heavier member first) per unit, so that a pair's planes are fetched by one or two XCDs.  Same tiles,
+  // same bits (tests/test_gpu_parity.py) -- and 54 % SLOWER (C3 0.720 -> 1.106 ms, C4 share 5.34 -> 8.55, C5 92.9 -> 144.2;
+  // profiles/r06_predict_experiments.txt): workgroups are dispatched IN ORDER across the XCDs, so one XCD busy with 64-step
+  // workgroups holds back the dispatch to the others; balanced totals per XCD do not help, every slot of the order would have
+  // to weigh the same on all eight -- which is exactly "all XCDs on the same row block".  The traffic is 127 GB/s: irrelevant to
+  // time.  Off by default; the cure that keeps the order out of the dispatcher's hands is a persistent grid with one work
+  // queue per XCD -- priced, not built.
+  int bi_sel = nbi - 1 - (int)blockIdx.y;
+  int64_t leaf_tile = blockIdx.x;
+  if (xcd_map) {
+    const int64_t ltiles = gridDim.x, w = (int64_t)blockIdx.y * ltiles + blockIdx.x;
+    const int64_t per_xcd = ltiles * (nbi / 2) / 8;  // units per XCD
+    const int64_t unit = (w & 7) * per_xcd + (w >> 4);
+    const int g = (int)(unit / ltiles);
+    leaf_tile = unit - (int64_t)g * ltiles;
+    bi_sel = ((w >> 3) & 1) ? g : nbi - 1 - g;
+  }
+  if (m_live != nullptr && leaf_tile * (NW * CT * 16) >= *m_live) return;  // workgroup-uniform
   // STAG (round 6): waves 4-7 run half a step behind waves 0-3 (leaf_bf16_fused_half); the L^-1 pieces then live in a ring of
   // three buffers -- where that fits the 160 KB (one chunk of the fp16 contraction: D <= 28)
   constexpr bool STAG = kLeafStagger && FUSED && NS == 2 && F16 && C16 == 1;
@@ -647,8 +673,8 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   // this wave's leaf fragments: [CT][dp4][64] TG, or (C16) [CT][chunk][piece][64] x 16 bytes
   TG* xb = reinterpret_cast<TG*>(xsl + 3 * xstride + (size_t)wave * xfrag);
 
-  const int bi = nbi - 1 - (int)blockIdx.y;
-  const int64_t col0 = ((int64_t)blockIdx.x * NW + wave) * (CT * 16);
+  const int bi = bi_sel;
+  const int64_t col0 = (leaf_tile * NW + wave) * (CT * 16);
   const int dp = dp4 * 4;
   const int npad32 = npad16 / 2;
   const int q_diag0 = bi * (RT / 2), q_end = q_diag0 + RT / 2;
@@ -973,6 +999,8 @@ static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const T
   const float var_arg = F16 ? (float)ldexp(kp.variance, 14 - eb) : (float)kp.variance;
   const float inv_b = F16 ? (float)ldexp(1.0, eb - 14) : 1.0f;
   const int q_max = n_rows > 0 ? (int)((n_rows + 31) / 32) : (int)(npad / 32);
+  // the XCD-aware assignment where its arithmetic is exact (an even number of row blocks, whole units per XCD)
+  const int xcd_map = (g_leaf_xcd_map && nbi >= 2 && nbi % 2 == 0 && ((mpad / 256) * (nbi / 2)) % 8 == 0) ? 1 : 0;
   // FUSED (GPSO_SPLIT_KERNEL_AUTO): the fused step; otherwise round 3's two-phase step.  Same bits either way.
 #define GPSO_L(K)                                                                                   \
   do {                                                                                              \
@@ -981,7 +1009,7 @@ static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const T
     hipLaunchKernelGGL((leaf_tiles_bf16_kernel<NS, TG, K, F16, FUSED, C16>), grid, dim3(512), lds, st, \
                        static_cast<const u32x4*>(linv_b), xs_p, xnorm, alpha, leaves_s, lnorm,      \
                        part_var, part_mean, (int)(npad / 16), dp4, mpad, nbi, var_arg, m_live,      \
-                       inv_scale_a, inv_b, c16_scale, q_max, C16 ? rawl.x : nullptr, rawl.ls, rawl.m, rawl.d); \
+                       inv_scale_a, inv_b, c16_scale, q_max, xcd_map, C16 ? rawl.x : nullptr, rawl.ls, rawl.m, rawl.d); \
   } while (0)
   if constexpr (KS == 0) {
     if (kp.kernel == 0) GPSO_L(0);

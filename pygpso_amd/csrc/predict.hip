@@ -23,6 +23,7 @@
 #include "leaf_split.hpp"  // (LDS-DMA helpers, the fp16 pair split; the split kernels themselves: predict_split_*.hip)
 
 namespace gpso {
+int g_leaf_xcd_map = 0;  // (leaf_split.hpp: the XCD-aware workgroup assignment of the split predict kernels; GPSO_OPT_XCD_MAP -- measured SLOWER, off)
 
 
 // Completion token (round 5): the LAST kernel of a call, where it is a single workgroup, writes a sequence number behind its

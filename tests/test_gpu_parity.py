@@ -1234,3 +1234,28 @@ def test_overlapped_double_fit_gives_the_sequential_schedules_bits(n, d, force_t
     # a posterior fit (no gradient) leaves the same factor
     f2, _ = _fit(eng, X, y, th, grad=False)
     assert f2 == f and eng.get_matrix(L.MAT_LINV).tobytes() == res[3][0][2]
+
+
+# ---- round 6: the split kernels' XCD-aware workgroup assignment (GPSO_OPT_XCD_MAP) -----------------------------------------
+@pytest.mark.parametrize("dtype,math", [("float32", "f16x3"), ("float32", "bf16x6"), ("mixed", "f16x3"), ("float32", "bf16x3")])
+@pytest.mark.parametrize("n,d,m", [(2048, 12, 8192), (512, 6, 2048), (1024, 20, 1024), (2040, 12, 4096), (4096, 6, 2048)])
+def test_xcd_aware_assignment_gives_the_same_bits(dtype, math, n, d, m):
+    """GPSO_OPT_XCD_MAP = 1 (an experiment, off by default: a third of the HBM traffic, 54 % slower): row blocks paired heaviest +
+    lightest and dealt to the XCDs in runs -- every workgroup computes the same (leaf tile, row block) it did before, under
+    another number: means, variances and winners are the bits of the default order, segments included."""
+    from pygpso_amd import HipGPEngine
+
+    X, y, th = _problem(n, d, variance=1.0)
+    eng = HipGPEngine(dtype, predict_math=math, precision_check=False)
+    _fit(eng, X, y, th, grad=False)
+    Xs = synthetic_leaves(m, d).astype(np.float32)
+    seg = np.array([0, m // 3, m // 3, m - 5, m], dtype=np.int64)
+    out = {}
+    try:
+        for on in (1, 0, 1):
+            eng.set_xcd_map(on)
+            mean, var = eng.predict(Xs)
+            out[on] = (mean.tobytes(), var.tobytes(), tuple(a.tobytes() for a in eng.best_ucb(Xs, VS, seg)))
+    finally:
+        eng.set_xcd_map(0)
+    assert out[1] == out[0]
