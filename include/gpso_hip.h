@@ -126,11 +126,9 @@ typedef struct gpso_ctx gpso_ctx;
                                    /* trailing update (as the float fit does; measured not to pay in double: the chain's launches need */
                                    /* whole free CUs and starve behind the update's tiles).  0: round 5's sequential schedule.  The    */
                                    /* same products in the same order on the same tiles: the same bits whatever the value.             */
-#define GPSO_OPT_XCD_MAP 13        /* 0 (default): the split predict kernels take (leaf tile, row block) from the grid indices, heaviest */
-                                   /* row blocks first.  1: row blocks paired heaviest + lightest and dealt to the 8 XCDs in runs, so   */
-                                   /* that a row block's planes of L^-1 are fetched by one or two XCDs' L2 instead of all eight: the    */
-                                   /* same tiles and bits, a third of the HBM traffic -- and 54 % slower (in-order dispatch across the  */
-                                   /* XCDs: leaf_split.hpp).  Process-wide; kept for that comparison.                                   */
+#define GPSO_OPT_ROW_LOOP 13       /* 1 (default): a workgroup of the split predict kernels keeps its 256 leaves and loops over row     */
+                                   /* blocks of L^-1 (the leaf prologue once per leaf tile; C3: 256 workgroups of 288 k-steps instead  */
+                                   /* of 2 048 of 8 .. 64); 0: one row block per workgroup (rounds 1-5).  Process-wide.  Same bits.     */
 /* floating-point options (gpso_set_option_f64): tolerances of the self-test */
 #define GPSO_OPTF_TOL_VAR 100  /* max |d var| at the training inputs, relative to the kernel variance (default 1e-4; GPSO_F32: 1e-3) */
 #define GPSO_OPTF_TOL_MEAN 101 /* max |d mean| at the training inputs, relative to max |y - c|   (default 1e-4; GPSO_F32: 1e-3) */

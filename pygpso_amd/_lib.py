@@ -36,7 +36,7 @@ OPT_SMALL_CALLS = 9
 OPT_CONTRACTION = 10
 OPT_FUSED_PREP = 11
 OPT_FIT_OVERLAP = 12
-OPT_XCD_MAP = 13
+OPT_ROW_LOOP = 13
 CONTRACTION_AUTO, CONTRACTION_F32, CONTRACTION_F16 = 0, 1, 2
 SPLIT_KERNEL_AUTO, SPLIT_KERNEL_TWO_PHASE = 0, 1
 OPTF_TOL_VAR, OPTF_TOL_MEAN = 100, 101

@@ -499,8 +499,8 @@ struct EngineT : Engine {
         if (value < 0 || value > 2) return ctx->fail(GPSO_E_ARG, "fit plane mode must be 0 (f32 MFMA), 1 (bf16 pieces) or 2 (fp16 pieces)");
         fit_planes_mode = value;
         return GPSO_OK;
-      case GPSO_OPT_XCD_MAP:
-        gpso::g_leaf_xcd_map = value != 0;  // (process-wide: a property of the kernels' launch, not of a posterior)
+      case GPSO_OPT_ROW_LOOP:
+        gpso::g_leaf_row_loop = value != 0;  // (process-wide: a property of the kernels' launch, not of a posterior)
         return GPSO_OK;
       case GPSO_OPT_FIT_OVERLAP:
         if (value < 0) return ctx->fail(GPSO_E_ARG, "fit overlap must be >= 0");

@@ -73,8 +73,9 @@ __device__ __forceinline__ void glds4(const void* gsrc_lane, void* lds_wave_base
 #define GPSO_LEAF_STAGGER 0
 #endif
 constexpr bool kLeafStagger = GPSO_LEAF_STAGGER != 0;
-// GPSO_OPT_XCD_MAP (process-wide switch of the split kernels' workgroup assignment; api.hip sets it): predict.hip owns it
-extern int g_leaf_xcd_map;
+// GPSO_OPT_ROW_LOOP (process-wide switch of the split kernels' workgroup shape; api.hip sets it): predict.hip owns both
+extern int g_leaf_row_loop;
+int leaf_cu_count();
 #ifndef GPSO_BSTAMP
 #define GPSO_BSTAMP(q, i)  // tools/micro/leaf_bf16_phases.hip defines this to record s_memtime stamps
 #endif
@@ -629,36 +630,25 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     const TG* __restrict__ lnorm, double* __restrict__ part_var, double* __restrict__ part_mean,
     int npad16, int dp4, int64_t mpad, int nbi, float variance, const int64_t* __restrict__ m_live,
     const float* __restrict__ inv_scale_a, float inv_scale_b, const float* __restrict__ c16_scale, int q_max,
-    int xcd_map /* 1: XCD-aware (leaf tile, row block) assignment (see below); 0: rounds 1-5's */,
     const float* __restrict__ raw /* nullable (C16 only): the caller's UNSCALED float leaves [raw_m][raw_d] -- the prologue
     scales them itself ((float)(x / l), rows beyond raw_m are padding): no prep launch in front of this kernel */,
     const double* __restrict__ raw_ls, int64_t raw_m, int raw_d) {
   constexpr int RT = 16, CT = 2, NW = 8;
   constexpr TG SC = (TG)GenScale<KERNEL>::SC;
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  // ---- which (leaf tile, row block) this workgroup computes ------------------------------------------------------------
-  // Default: leaf tile = blockIdx.x, row block = heaviest first over blockIdx.y.  Consecutive workgroups go to the 8 XCDs
-  // round-robin, so all eight work on the SAME row block at any time and each XCD's L2 pulls its own copy of that block's
-  // planes: 89.8 MB of HBM / fabric traffic per launch at C3 against 12.4 MB algorithmic (7.2x).  Round 6 built the obvious
-  // cure (xcd_map != 0, GPSO_OPT_XCD_MAP = 1; needs an even number of row blocks and whole units per XCD): row blocks PAIRED
-  // (g, nbi - 1 - g) -- every pair weighs the same nbi + 1 units --, the (pair, leaf tile) units dealt to the XCDs in contiguous
-  // runs, two workgroups (heavier member first) per unit, so that a pair's planes are fetched by one or two XCDs.  Same tiles,
-  // same bits (tests/test_gpu_parity.py) -- and 54 % SLOWER (C3 0.720 -> 1.106 ms, C4 share 5.34 -> 8.55, C5 92.9 -> 144.2;
-  // profiles/r06_predict_experiments.txt): workgroups are dispatched IN ORDER across the XCDs, so one XCD busy with 64-step
-  // workgroups holds back the dispatch to the others; balanced totals per XCD do not help, every slot of the order would have
-  // to weigh the same on all eight -- which is exactly "all XCDs on the same row block".  The traffic is 127 GB/s: irrelevant to
-  // time.  Off by default; the cure that keeps the order out of the dispatcher's hands is a persistent grid with one work
-  // queue per XCD -- priced, not built.
-  int bi_sel = nbi - 1 - (int)blockIdx.y;
-  int64_t leaf_tile = blockIdx.x;
-  if (xcd_map) {
-    const int64_t ltiles = gridDim.x, w = (int64_t)blockIdx.y * ltiles + blockIdx.x;
-    const int64_t per_xcd = ltiles * (nbi / 2) / 8;  // units per XCD
-    const int64_t unit = (w & 7) * per_xcd + (w >> 4);
-    const int g = (int)(unit / ltiles);
-    leaf_tile = unit - (int64_t)g * ltiles;
-    bi_sel = ((w >> 3) & 1) ? g : nbi - 1 - g;
-  }
+  // ---- which (leaf tile, row blocks) this workgroup computes ---------------------------------------------------------------
+  // Rounds 1-5: one workgroup = (leaf tile blockIdx.x, ONE row block, heaviest first over blockIdx.y): 2 048 workgroups at C3,
+  // eight per CU one after the other, each paying the leaf prologue (the tile's fragments from global memory, split into fp16
+  // pieces), a cold first DMA and a dispatch.  Round 6: a workgroup keeps its leaf tile and LOOPS over row blocks -- split
+  // blockIdx.y of gridDim.y takes the row blocks of rank j S + (j even ? split : S - 1 - split) in heaviest-first order (a
+  // zig-zag: the splits weigh the same within one row block) -- so the prologue is paid once per leaf tile.  gridDim.y = nbi is
+  // rounds 1-5's kernel; the launcher picks the smallest S that still fills the chip evenly (C3: S = 1, 256 workgroups of 288
+  // k-steps each).  Same tiles, same operations in the same order per (leaf tile, row block): the same bits.
+  // (Also measured this round and not kept -- row blocks paired heaviest + lightest and dealt to the XCDs in runs so that a
+  // block's planes are fetched by one or two L2s instead of all eight: a third of the HBM traffic, same bits, 54 % slower,
+  // because workgroups are dispatched in order ACROSS the XCDs; commit b85fc33, profiles/r06_predict_experiments.txt.)
+  const int S = (int)gridDim.y, split = (int)blockIdx.y;
+  const int64_t leaf_tile = blockIdx.x;
   if (m_live != nullptr && leaf_tile * (NW * CT * 16) >= *m_live) return;  // workgroup-uniform
   // STAG (round 6): waves 4-7 run half a step behind waves 0-3 (leaf_bf16_fused_half); the L^-1 pieces then live in a ring of
   // three buffers -- where that fits the 160 KB (one chunk of the fp16 contraction: D <= 28)
@@ -673,15 +663,14 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   // this wave's leaf fragments: [CT][dp4][64] TG, or (C16) [CT][chunk][piece][64] x 16 bytes
   TG* xb = reinterpret_cast<TG*>(xsl + 3 * xstride + (size_t)wave * xfrag);
 
-  const int bi = bi_sel;
   const int64_t col0 = (leaf_tile * NW + wave) * (CT * 16);
   const int dp = dp4 * 4;
   const int npad32 = npad16 / 2;
-  const int q_diag0 = bi * (RT / 2), q_end = q_diag0 + RT / 2;
+  // the row block in hand (set_row_block): bi, its diagonal k-steps [q_diag0, q_end), and q_lim --
   // q_max = ceil(N / 32): the k-steps from there on hold padding points only -- all-zero columns of L^-1.  The fused
   // loop stops applying there (the last row block of an N that is not a multiple of 256; adding exact zeros or not adding
   // them: the same partial sums).  q_diag0 < q_max always: a row block has at least one training row.
-  const int q_lim = FUSED ? min(q_end, q_max) : q_end;
+  int bi = 0, q_diag0 = 0, q_end = 0, q_lim = 0;
 
   // ---- LDS-DMA duties, dealt EVENLY over the eight waves (round 4) -------------------------------------------
   // A step's DMAs are NS x 16 fragments of the L^-1 pieces (1 KB each), the X fragments of the step (256-byte pieces)
@@ -703,12 +692,22 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   const bool dma_wave = wave < DW;
   const int lane16 = lane * 16, lane4 = lane * 4;
   const unsigned char* pgb[FPW];
+  bool has_next = false;
+  auto rank_of = [&](int j) { return j * S + ((j & 1) ? S - 1 - split : split); };
+  auto set_row_block = [&](int j_mine /* this workgroup's j-th row block */) {
+    const int rank = rank_of(j_mine);  // (ranks in heaviest-first order)
+    has_next = rank_of(j_mine + 1) < nbi;
+    bi = nbi - 1 - rank;
+    q_diag0 = bi * (RT / 2);
+    q_end = q_diag0 + RT / 2;
+    q_lim = FUSED ? min(q_end, q_max) : q_end;
 #pragma unroll
-  for (int j = 0; j < FPW; ++j) {
-    const int f = FPW * (wave % DW) + j, sp = f / RT, rt = f % RT;  // fragment f = piece sp, row tile rt
-    pgb[j] = reinterpret_cast<const unsigned char*>(linv_b + ((size_t)sp * npad16 + (bi * RT + rt)) * npad32 * 64) -
-             (j * 1024 - FPW * 512);
-  }
+    for (int j = 0; j < FPW; ++j) {
+      const int f = FPW * (wave % DW) + j, sp = f / RT, rt = f % RT;  // fragment f = piece sp, row tile rt
+      pgb[j] = reinterpret_cast<const unsigned char*>(linv_b + ((size_t)sp * npad16 + (bi * RT + rt)) * npad32 * 64) -
+               (j * 1024 - FPW * 512);
+    }
+  };
   // (the empty asm keeps a wave-uniform address in scalar registers: left alone, the compiler hoists
   // base + lane offset out of the loop as per-lane 64-bit pointers and spills them)
   auto uniform = [](const unsigned char* p) {
@@ -761,9 +760,15 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     }
   };
 
-  issue_panel(0, 0);
-  issue_x(0);
-  if (1 < q_end) issue_x(1);
+  // the first DMAs of a row block: its L^-1 pieces of step 0 into buffer 0 and the inputs of steps 0 and 1 (every row block has
+  // at least eight steps)
+  auto issue_block_start = [&]() {
+    issue_panel(0, 0);
+    issue_x(0);
+    issue_x(1);
+  };
+  set_row_block(0);
+  issue_block_start();
   TG cm = TG(-2) * SC;
   float nb_c16[CT] = {0, 0};
   if constexpr (C16) {
@@ -827,14 +832,26 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     else nb[t] = lnorm[col0 + t * 16 + (lane & 15)] * SC;
   }
   f32x4 acc[RT][CT];
+  float macc[CT];
+  bf16x8 bfrag[NS][CT];
+  float vc[3];
+  gen_poly_coeffs<KERNEL>(variance, vc);
+  // ---- the row blocks of this workgroup, heaviest first -------------------------------------------------------------------
+  // (every step ends with a workgroup barrier, the last one included: when the DMAs of the next row block's first steps are
+  // issued, no wave still reads the buffers they land in)
+  // (Measured and not kept: the next row block's first DMAs issued during the LAST step of the one in hand -- its buffers are
+  // free there.  The second set of wave-uniform pointers spills 87 scalar registers into vector lanes inside the hot loop: C3
+  // 0.7193 | 0.7221 ms against 0.7464 | 0.7304 without the prefetch, C4 / C5 +2.5 %.  r06_predict_experiments.txt.)
+  for (int rbj = 0;; ++rbj) {
+  if (rbj > 0) {
+    set_row_block(rbj);
+    issue_block_start();
+  }
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int t = 0; t < CT; ++t) acc[rt][t] = f32x4{0, 0, 0, 0};
-  float macc[CT] = {0, 0};
-  bf16x8 bfrag[NS][CT];
-  float vc[3];
-  gen_poly_coeffs<KERNEL>(variance, vc);
+  macc[0] = macc[1] = 0.0f;
   __syncthreads();
 
   auto issue_for = [&](int k) {
@@ -973,6 +990,8 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
       part_mean[(int64_t)bi * mpad + col] = mm;
     }
   }
+  if (!has_next) break;  // (workgroup-uniform)
+  }  // row blocks
 }
 
 // FUSED and KS (kernel families 0-1: Matern-5/2, -3/2 | 2-3: Matern-1/2, squared exponential) are template parameters of
@@ -999,17 +1018,26 @@ static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const T
   const float var_arg = F16 ? (float)ldexp(kp.variance, 14 - eb) : (float)kp.variance;
   const float inv_b = F16 ? (float)ldexp(1.0, eb - 14) : 1.0f;
   const int q_max = n_rows > 0 ? (int)((n_rows + 31) / 32) : (int)(npad / 32);
-  // the XCD-aware assignment where its arithmetic is exact (an even number of row blocks, whole units per XCD)
-  const int xcd_map = (g_leaf_xcd_map && nbi >= 2 && nbi % 2 == 0 && ((mpad / 256) * (nbi / 2)) % 8 == 0) ? 1 : 0;
+  // how many workgroups share a leaf tile's row blocks (gridDim.y): nbi = one row block each (rounds 1-5); with the row-block
+  // loop the smallest power of two that fills the chip evenly -- leaf tiles x S a multiple of the CU count -- or, failing that,
+  // enough workgroups (8 per CU) for the dispatcher to even out what is left
+  int S = nbi;
+  if (g_leaf_row_loop) {
+    const int64_t ltiles = mpad / 256, ncu = leaf_cu_count();
+    S = 1;
+    while (S < nbi && (ltiles * S) % ncu != 0 && ltiles * S < 8 * ncu) S *= 2;
+    S = std::min(S, nbi);
+  }
+  const dim3 grid_s((unsigned)(mpad / 256), (unsigned)S);
   // FUSED (GPSO_SPLIT_KERNEL_AUTO): the fused step; otherwise round 3's two-phase step.  Same bits either way.
 #define GPSO_L(K)                                                                                   \
   do {                                                                                              \
     const int rc = ensure_dyn_lds((const void*)leaf_tiles_bf16_kernel<NS, TG, K, F16, FUSED, C16>, (int)lds); \
     if (rc) return rc;                                                                              \
-    hipLaunchKernelGGL((leaf_tiles_bf16_kernel<NS, TG, K, F16, FUSED, C16>), grid, dim3(512), lds, st, \
+    hipLaunchKernelGGL((leaf_tiles_bf16_kernel<NS, TG, K, F16, FUSED, C16>), grid_s, dim3(512), lds, st, \
                        static_cast<const u32x4*>(linv_b), xs_p, xnorm, alpha, leaves_s, lnorm,      \
                        part_var, part_mean, (int)(npad / 16), dp4, mpad, nbi, var_arg, m_live,      \
-                       inv_scale_a, inv_b, c16_scale, q_max, xcd_map, C16 ? rawl.x : nullptr, rawl.ls, rawl.m, rawl.d); \
+                       inv_scale_a, inv_b, c16_scale, q_max, C16 ? rawl.x : nullptr, rawl.ls, rawl.m, rawl.d); \
   } while (0)
   if constexpr (KS == 0) {
     if (kp.kernel == 0) GPSO_L(0);

@@ -23,7 +23,16 @@
 #include "leaf_split.hpp"  // (LDS-DMA helpers, the fp16 pair split; the split kernels themselves: predict_split_*.hip)
 
 namespace gpso {
-int g_leaf_xcd_map = 0;  // (leaf_split.hpp: the XCD-aware workgroup assignment of the split predict kernels; GPSO_OPT_XCD_MAP -- measured SLOWER, off)
+int g_leaf_row_loop = 1;  // (leaf_split.hpp: a workgroup of the split predict kernels keeps its leaf tile and loops over row blocks; GPSO_OPT_ROW_LOOP)
+int leaf_cu_count() {
+  static int n = 0;  // (one device type per process: MI355X, 256)
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
 
 
 // Completion token (round 5): the LAST kernel of a call, where it is a single workgroup, writes a sequence number behind its

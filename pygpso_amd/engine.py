@@ -127,10 +127,10 @@ class HipGPEngine:
         True / 1: three launches, or one where that measures faster; 2: three only; 3: one wherever it applies; 0: general."""
         self._check(self._lib.gpso_set_option(self._h, L.OPT_SMALL_CALLS, int(on)))
 
-    def set_xcd_map(self, on):
-        """GPSO_OPT_XCD_MAP (process-wide): the split predict kernels' XCD-aware workgroup assignment (default OFF: same bits,
-        a third of the HBM traffic, 54 % slower -- leaf_split.hpp)."""
-        self._check(self._lib.gpso_set_option(self._h, L.OPT_XCD_MAP, int(bool(on))))
+    def set_row_loop(self, on):
+        """GPSO_OPT_ROW_LOOP (process-wide): a workgroup of the split predict kernels keeps its leaf tile and loops over row
+        blocks (default on) | one row block per workgroup (rounds 1-5).  Same bits."""
+        self._check(self._lib.gpso_set_option(self._h, L.OPT_ROW_LOOP, int(bool(on))))
 
     def set_precision_check(self, on):
         self._check(self._lib.gpso_set_option(self._h, L.OPT_PRECISION_CHECK, 1 if on else 0))

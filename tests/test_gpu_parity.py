@@ -1236,13 +1236,16 @@ def test_overlapped_double_fit_gives_the_sequential_schedules_bits(n, d, force_t
     assert f2 == f and eng.get_matrix(L.MAT_LINV).tobytes() == res[3][0][2]
 
 
-# ---- round 6: the split kernels' XCD-aware workgroup assignment (GPSO_OPT_XCD_MAP) -----------------------------------------
-@pytest.mark.parametrize("dtype,math", [("float32", "f16x3"), ("float32", "bf16x6"), ("mixed", "f16x3"), ("float32", "bf16x3")])
-@pytest.mark.parametrize("n,d,m", [(2048, 12, 8192), (512, 6, 2048), (1024, 20, 1024), (2040, 12, 4096), (4096, 6, 2048)])
-def test_xcd_aware_assignment_gives_the_same_bits(dtype, math, n, d, m):
-    """GPSO_OPT_XCD_MAP = 1 (an experiment, off by default: a third of the HBM traffic, 54 % slower): row blocks paired heaviest +
-    lightest and dealt to the XCDs in runs -- every workgroup computes the same (leaf tile, row block) it did before, under
-    another number: means, variances and winners are the bits of the default order, segments included."""
+# ---- round 6: a workgroup of the split kernels loops over row blocks (GPSO_OPT_ROW_LOOP) ---------------------------------------
+@pytest.mark.parametrize("dtype,math", [("float32", "f16x3"), ("float32", "bf16x6"), ("mixed", "f16x3"), ("float32", "bf16x3"),
+                                        ("mixed", "bf16x6")])
+@pytest.mark.parametrize("n,d,m", [(2048, 12, 65536), (2048, 12, 8192), (512, 6, 2048), (1024, 20, 1000), (2040, 12, 4096),
+                                   (4096, 6, 300), (1100, 33, 77000), (300, 5, 4096)])
+def test_row_block_loop_gives_the_one_row_block_kernels_bits(dtype, math, n, d, m):
+    """A workgroup keeps its leaf tile and loops over the row blocks of its split (the leaf prologue once per tile instead of
+    once per row block); the launcher picks 1, 2, 4 ... splits per leaf tile by the batch size.  Every (leaf tile, row block)
+    is computed by the same operations in the same order: means, variances and winners are the bits of rounds 1-5's kernel,
+    with segments, two-phase and fused steps, a last row block of few rows (N = 1100, 2040) and batches of every size class."""
     from pygpso_amd import HipGPEngine
 
     X, y, th = _problem(n, d, variance=1.0)
@@ -1253,9 +1256,12 @@ def test_xcd_aware_assignment_gives_the_same_bits(dtype, math, n, d, m):
     out = {}
     try:
         for on in (1, 0, 1):
-            eng.set_xcd_map(on)
-            mean, var = eng.predict(Xs)
-            out[on] = (mean.tobytes(), var.tobytes(), tuple(a.tobytes() for a in eng.best_ucb(Xs, VS, seg)))
+            eng.set_row_loop(on)
+            for which in ("auto", "two-phase"):
+                eng.set_split_kernel(which)
+                mean, var = eng.predict(Xs)
+                out[(on, which)] = (mean.tobytes(), var.tobytes(), tuple(a.tobytes() for a in eng.best_ucb(Xs, VS, seg)))
     finally:
-        eng.set_xcd_map(0)
-    assert out[1] == out[0]
+        eng.set_row_loop(1)
+        eng.set_split_kernel("auto")
+    assert out[(1, "auto")] == out[(0, "auto")] == out[(0, "two-phase")] == out[(1, "two-phase")]
