@@ -127,8 +127,11 @@ typedef struct gpso_ctx gpso_ctx;
                                    /* whole free CUs and starve behind the update's tiles).  0: round 5's sequential schedule.  The    */
                                    /* same products in the same order on the same tiles: the same bits whatever the value.             */
 #define GPSO_OPT_ROW_LOOP 13       /* 1 (default): a workgroup of the split predict kernels keeps its 256 leaves and loops over row     */
-                                   /* blocks of L^-1 (the leaf prologue once per leaf tile; C3: 256 workgroups of 288 k-steps instead  */
-                                   /* of 2 048 of 8 .. 64); 0: one row block per workgroup (rounds 1-5).  Process-wide.  Same bits.     */
+                                   /* blocks of L^-1, the row blocks of a leaf tile shared by as many workgroups as gives the shortest  */
+                                   /* modelled makespan (C3: one -- 256 workgroups of 288 k-steps instead of 2 048 of 8 .. 64; ragged   */
+                                   /* batches and batches whose live count only the device knows: one row block per workgroup);        */
+                                   /* 0: one row block per workgroup always (rounds 1-5); v >= 2: exactly min(v, row blocks)            */
+                                   /* workgroups per leaf tile (tests).  Process-wide.  Same bits whatever the value.                   */
 /* floating-point options (gpso_set_option_f64): tolerances of the self-test */
 #define GPSO_OPTF_TOL_VAR 100  /* max |d var| at the training inputs, relative to the kernel variance (default 1e-4; GPSO_F32: 1e-3) */
 #define GPSO_OPTF_TOL_MEAN 101 /* max |d mean| at the training inputs, relative to max |y - c|   (default 1e-4; GPSO_F32: 1e-3) */
@@ -413,7 +416,9 @@ double gpso_last_ms(gpso_ctx* ctx, int what);
  * gpso/param_space.py:186-200: (3^depth - 1) / 2 rows per box, 3^(depth-1) distinct).
  * what = 2: the arithmetic the LARGE PRODUCTS of the last gpso_fit_eval ran on (GPSO_FITMATH_*: what a roofline figure of
  * the fit is priced against -- the f32 / f64 matrix instruction, or the two-level float fit's 16-bit pieces: six bf16 or
- * three fp16 MFMAs per f32 product). */
+ * three fp16 MFMAs per f32 product).
+ * what = 3: how many workgroups shared a leaf tile's row blocks in the last launch of a split predict kernel (GPSO_OPT_ROW_LOOP;
+ * process-wide, for tests and tools). */
 #define GPSO_FITMATH_NONE 0
 #define GPSO_FITMATH_SMALL 1   /* N <= 128: one launch, vector arithmetic in double */
 #define GPSO_FITMATH_F32 2     /* v_mfma_f32_16x16x4_f32 (float fits up to N_pad = 3584, or GPSO_OPT_FIT_BF16_SYRK = 0) */

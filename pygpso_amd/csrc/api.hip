@@ -500,7 +500,8 @@ struct EngineT : Engine {
         fit_planes_mode = value;
         return GPSO_OK;
       case GPSO_OPT_ROW_LOOP:
-        gpso::g_leaf_row_loop = value != 0;  // (process-wide: a property of the kernels' launch, not of a posterior)
+        if (value < 0) return ctx->fail(GPSO_E_ARG, "row loop: 0, 1 or a split count >= 2");
+        gpso::g_leaf_row_loop = (int)value;  // (process-wide: a property of the kernels' launch, not of a posterior)
         return GPSO_OK;
       case GPSO_OPT_FIT_OVERLAP:
         if (value < 0) return ctx->fail(GPSO_E_ARG, "fit overlap must be >= 0");
@@ -3181,7 +3182,8 @@ int gpso_comm_abort(gpso_ctx* ctx) {
 }
 
 int64_t gpso_last_count(gpso_ctx* ctx, int what) {
-  if (!ctx || what < 0 || what > 2) return -1;
+  if (!ctx || what < 0 || what > 3) return -1;
+  if (what == 3) return gpso::g_leaf_last_splits;
   return ctx->last_count[what];
 }
 

@@ -47,6 +47,7 @@ void launch_pack_linv_bf16(hipStream_t st, int nsplit, const TF* linv, int64_t n
 // fragments, for a generation type of tg_bytes
 // c16: the contraction runs on the fp16 pipe (float generation only): the X fragments of a k-step and the leaf fragments
 // of a wave are fp16 piece pairs of 32-dimension chunks instead of float groups of four dimensions
+extern int g_leaf_last_splits;  // predict.hip: what the launcher of the split kernels chose last (gpso_last_count(ctx, 3))
 extern int g_leaf_row_loop;  // predict.hip: GPSO_OPT_ROW_LOOP (a workgroup of the split predict kernels loops over row blocks)
 inline int leaf_c16_chunks(int dp4) { return (dp4 + 8) / 8; }  // D_pad inputs + the norm slot, 32 slots per chunk
 inline size_t leaf_bf16_lds_bytes(int nsplit, int dp4, int tg_bytes, bool c16 = false) {

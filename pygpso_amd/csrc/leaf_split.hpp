@@ -75,6 +75,7 @@ __device__ __forceinline__ void glds4(const void* gsrc_lane, void* lds_wave_base
 constexpr bool kLeafStagger = GPSO_LEAF_STAGGER != 0;
 // GPSO_OPT_ROW_LOOP (process-wide switch of the split kernels' workgroup shape; api.hip sets it): predict.hip owns both
 extern int g_leaf_row_loop;
+extern int g_leaf_last_splits;
 int leaf_cu_count();
 #ifndef GPSO_BSTAMP
 #define GPSO_BSTAMP(q, i)  // tools/micro/leaf_bf16_phases.hip defines this to record s_memtime stamps
@@ -994,6 +995,41 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   }  // row blocks
 }
 
+// How many workgroups share a leaf tile's row blocks (gridDim.y of the split kernels).  GPSO_OPT_ROW_LOOP = 0: nbi, one row block
+// each (rounds 1-5); v >= 2: v (tests); 1 (default): the count with the shortest modelled makespan.  In k-steps: row block bi costs
+// 8 (bi + 1), a workgroup kPrologue on top (the leaf prologue + a cold first DMA, from the C3 A/B: 2.7 % of 288 + 8 x that);
+// with S < nbi equal-weight workgroups the chip runs ceil(tiles S / CUs) rounds of the heaviest split; with one row block per
+// workgroup, heaviest first, the dispatcher packs them to within a light block of the mean.  C3 (256 tiles): 1; C4 share
+// (128): 2; C5 share (512): 1; ragged batches (462 or 1 384 tiles): nbi -- a coarser grain there costs a whole round of tail
+// (measured: +4.7 % on bench.py --leaves grow --depth 11 with the first version of this rule, which only looked at the
+// workgroup count).  A batch whose live row count only the device knows (m_live) keeps one row block per workgroup.
+inline int leaf_row_splits(int64_t ltiles, int nbi, int ncu, bool live_known) {
+  const int mode = g_leaf_row_loop;
+  if (mode == 0 || nbi <= 1) return nbi;
+  if (mode >= 2) return std::min(mode, nbi);
+  if (!live_known) return nbi;
+  constexpr double kPrologue = 1.2;
+  const double total = 4.0 * nbi * (nbi + 1);
+  const double per_cu = (double)ltiles * (total + kPrologue * nbi) / ncu + 8.0;
+  double best = std::max(per_cu, 8.0 * nbi + kPrologue);
+  int best_s = nbi;
+  for (int S = nbi / 2; S >= 1; S /= 2) {  // (down, so that ties go to the smaller count)
+    double heaviest = 0.0;
+    for (int split = 0; split < S; ++split) {
+      double w = 0.0;
+      for (int j = 0;; ++j) {
+        const int rank = j * S + ((j & 1) ? S - 1 - split : split);
+        if (rank >= nbi) break;
+        w += 8.0 * (nbi - rank);
+      }
+      heaviest = std::max(heaviest, w);
+    }
+    const double t = (double)((ltiles * S + ncu - 1) / ncu) * (heaviest + kPrologue);
+    if (t <= best) best = t, best_s = S;
+  }
+  return best_s;
+}
+
 // FUSED and KS (kernel families 0-1: Matern-5/2, -3/2 | 2-3: Matern-1/2, squared exponential) are template parameters of
 // the launchers: each (TG, FUSED, KS) slice of the kernels is instantiated in a translation unit of its own
 // (launch_leaf_tiles_bf16_v<TG, FUSED, KS>, predict_split_*.hip), and the slices compile in parallel
@@ -1018,16 +1054,8 @@ static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const T
   const float var_arg = F16 ? (float)ldexp(kp.variance, 14 - eb) : (float)kp.variance;
   const float inv_b = F16 ? (float)ldexp(1.0, eb - 14) : 1.0f;
   const int q_max = n_rows > 0 ? (int)((n_rows + 31) / 32) : (int)(npad / 32);
-  // how many workgroups share a leaf tile's row blocks (gridDim.y): nbi = one row block each (rounds 1-5); with the row-block
-  // loop the smallest power of two that fills the chip evenly -- leaf tiles x S a multiple of the CU count -- or, failing that,
-  // enough workgroups (8 per CU) for the dispatcher to even out what is left
-  int S = nbi;
-  if (g_leaf_row_loop) {
-    const int64_t ltiles = mpad / 256, ncu = leaf_cu_count();
-    S = 1;
-    while (S < nbi && (ltiles * S) % ncu != 0 && ltiles * S < 8 * ncu) S *= 2;
-    S = std::min(S, nbi);
-  }
+  const int S = leaf_row_splits(mpad / 256, nbi, leaf_cu_count(), m_live == nullptr);
+  g_leaf_last_splits = S;
   const dim3 grid_s((unsigned)(mpad / 256), (unsigned)S);
   // FUSED (GPSO_SPLIT_KERNEL_AUTO): the fused step; otherwise round 3's two-phase step.  Same bits either way.
 #define GPSO_L(K)                                                                                   \

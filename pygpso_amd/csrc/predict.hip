@@ -23,6 +23,7 @@
 #include "leaf_split.hpp"  // (LDS-DMA helpers, the fp16 pair split; the split kernels themselves: predict_split_*.hip)
 
 namespace gpso {
+int g_leaf_last_splits = 0;  // workgroups per leaf tile of the last split-kernel launch (gpso_last_count(ctx, 3))
 int g_leaf_row_loop = 1;  // (leaf_split.hpp: a workgroup of the split predict kernels keeps its leaf tile and loops over row blocks; GPSO_OPT_ROW_LOOP)
 int leaf_cu_count() {
   static int n = 0;  // (one device type per process: MI355X, 256)

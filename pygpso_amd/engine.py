@@ -128,9 +128,10 @@ class HipGPEngine:
         self._check(self._lib.gpso_set_option(self._h, L.OPT_SMALL_CALLS, int(on)))
 
     def set_row_loop(self, on):
-        """GPSO_OPT_ROW_LOOP (process-wide): a workgroup of the split predict kernels keeps its leaf tile and loops over row
-        blocks (default on) | one row block per workgroup (rounds 1-5).  Same bits."""
-        self._check(self._lib.gpso_set_option(self._h, L.OPT_ROW_LOOP, int(bool(on))))
+        """GPSO_OPT_ROW_LOOP (process-wide): 1 / True = a workgroup of the split predict kernels keeps its leaf tile and loops
+        over row blocks, the launcher choosing how many workgroups share a tile (default); 0 = one row block per workgroup
+        (rounds 1-5); v >= 2 = exactly min(v, row blocks) workgroups per leaf tile.  Same bits."""
+        self._check(self._lib.gpso_set_option(self._h, L.OPT_ROW_LOOP, int(on)))
 
     def set_precision_check(self, on):
         self._check(self._lib.gpso_set_option(self._h, L.OPT_PRECISION_CHECK, 1 if on else 0))

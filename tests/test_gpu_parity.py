@@ -1243,7 +1243,7 @@ def test_overlapped_double_fit_gives_the_sequential_schedules_bits(n, d, force_t
                                    (4096, 6, 300), (1100, 33, 77000), (300, 5, 4096)])
 def test_row_block_loop_gives_the_one_row_block_kernels_bits(dtype, math, n, d, m):
     """A workgroup keeps its leaf tile and loops over the row blocks of its split (the leaf prologue once per tile instead of
-    once per row block); the launcher picks 1, 2, 4 ... splits per leaf tile by the batch size.  Every (leaf tile, row block)
+    once per row block); the launcher picks how many workgroups share a leaf tile (forced here to 1 ... all of them).  Every (leaf tile, row block)
     is computed by the same operations in the same order: means, variances and winners are the bits of rounds 1-5's kernel,
     with segments, two-phase and fused steps, a last row block of few rows (N = 1100, 2040) and batches of every size class."""
     from pygpso_amd import HipGPEngine
@@ -1255,7 +1255,7 @@ def test_row_block_loop_gives_the_one_row_block_kernels_bits(dtype, math, n, d, 
     seg = np.array([0, m // 3, m // 3, m - 5, m], dtype=np.int64)
     out = {}
     try:
-        for on in (1, 0, 1):
+        for on in (1, 0, 2, 3, 4, 1000):  # (2, 3, 4, 1000: that many workgroups per leaf tile, capped at the row blocks)
             eng.set_row_loop(on)
             for which in ("auto", "two-phase"):
                 eng.set_split_kernel(which)
@@ -1264,4 +1264,30 @@ def test_row_block_loop_gives_the_one_row_block_kernels_bits(dtype, math, n, d, 
     finally:
         eng.set_row_loop(1)
         eng.set_split_kernel("auto")
-    assert out[(1, "auto")] == out[(0, "auto")] == out[(0, "two-phase")] == out[(1, "two-phase")]
+    assert len(set(out.values())) == 1, [k for k, v in out.items() if v != out[(0, "auto")]]
+
+
+@pytest.mark.gpu
+def test_row_block_split_count_follows_the_makespan_model():
+    """gpso_last_count(ctx, 3) = workgroups per leaf tile of the last split launch.  The rule (leaf_row_splits, leaf_split.hpp):
+    C3's 256 leaf tiles = one workgroup each on the 256 CUs -> 1; a batch of 32 tiles -> one row block per workgroup (256
+    workgroups); 462 tiles (bench.py --leaves grow --depth 11: a coarser grain costs a round of tail, measured +4.7 %) -> one row
+    block per workgroup; a grown batch, whose live count only the device knows -> one row block per workgroup."""
+    from pygpso_amd import HipGPEngine
+
+    X, y, th = _problem(2048, 12, variance=1.0)
+    eng = HipGPEngine("float32", predict_math="f16x3", precision_check=False)
+    _fit(eng, X, y, th, grad=False)
+    nbi = 2048 // 256
+    for m, want in ((65536, 1), (8192, nbi), (118098, nbi), (4 * 65536, 1), (128 * 256, 2)):
+        eng.best_ucb(synthetic_leaves(m, 12).astype(np.float32), VS)
+        assert eng.last_count(3) == want, (m, eng.last_count(3))
+    eng.set_row_loop(0)
+    try:
+        eng.best_ucb(synthetic_leaves(65536, 12).astype(np.float32), VS)
+        assert eng.last_count(3) == nbi
+    finally:
+        eng.set_row_loop(1)
+    boxes = np.array([[[0.0, 1.0 / 3]] + [[0.0, 1.0]] * 11, [[2.0 / 3, 1.0]] + [[0.0, 1.0]] * 11])
+    eng.best_ucb_grow(boxes, 9, VS)
+    assert eng.last_count(3) == nbi

@@ -35,6 +35,8 @@ def worker(args):
         leaves = torch.from_numpy(synthetic_leaves(m, d).astype(np.float32)).cuda()
         for math in args.math.split(","):
             eng = HipGPEngine("float32", predict_math=math)
+            if os.environ.get("AB_ROW_LOOP"):  # "<lib>:rl0" on the command line: GPSO_OPT_ROW_LOOP = 0 (one row block per workgroup)
+                eng.set_row_loop(int(os.environ["AB_ROW_LOOP"]))
             eng.set_data(X, y)
             eng.fit_eval(*theta, want_grad=False)
             t_end = time.perf_counter() + 0.3
@@ -107,7 +109,10 @@ def main():
     res = {lib: [] for lib in args.libs}
     for r in range(args.rounds):
         for lib in args.libs:
-            env = dict(os.environ, GPSO_HIP_LIB=os.path.abspath(lib), GPSO_HIP_LIB_OLDER="1")
+            path, _, opt = lib.partition(":rl")
+            env = dict(os.environ, GPSO_HIP_LIB=os.path.abspath(path), GPSO_HIP_LIB_OLDER="1")
+            if opt:
+                env["AB_ROW_LOOP"] = opt
             cmd = [sys.executable, os.path.abspath(__file__), "--worker", "--what", args.what, "--steps", str(args.steps),
                    "--shape", *map(str, args.shape), "--math", args.math, "--dtype", args.dtype]
             p = subprocess.run(cmd, env=env, capture_output=True, text=True)
