@@ -102,6 +102,10 @@ typedef struct gpso_ctx gpso_ctx;
 #define GPSO_SPLIT_KERNEL_AUTO 0   /*   FUSED step of round 4 (every wave applies step q with the generation of step q+1  */
 #define GPSO_SPLIT_KERNEL_TWO_PHASE 1 /* dealt into its MFMA shadows), 1 round 3's two-phase step.  Both give the SAME    */
                                    /*   BITS (tests/test_gpu_parity.py); the option exists for that comparison            */
+#define GPSO_SPLIT_KERNEL_FUSED16 2 /* the fused step by name (= AUTO)                                                     */
+#define GPSO_SPLIT_KERNEL_FUSED32 3 /* the fused step on the 32x32x16 matrix instruction: fewer issue slots, 4.9 % fewer  */
+                                   /*   clocks, an 11 % lower clock -- 7 % slower; only in builds with -DGPSO_STEP32=1,    */
+                                   /*   GPSO_E_ARG otherwise.  Same tolerances, not the same bits.                         */
 #define GPSO_OPT_SMALL_CALLS 9     /* best-UCB calls on small batches (<= 16384 rows) are launch-bound.  1 (default): a   */
                                    /* short sequence -- THREE launches (growth + input scaling with the boxes by value,    */
                                    /* tiles, one-workgroup finalize + arg-max writing pinned host memory), or ONE where   */

@@ -38,7 +38,7 @@ OPT_FUSED_PREP = 11
 OPT_FIT_OVERLAP = 12
 OPT_ROW_LOOP = 13
 CONTRACTION_AUTO, CONTRACTION_F32, CONTRACTION_F16 = 0, 1, 2
-SPLIT_KERNEL_AUTO, SPLIT_KERNEL_TWO_PHASE = 0, 1
+SPLIT_KERNEL_AUTO, SPLIT_KERNEL_TWO_PHASE, SPLIT_KERNEL_FUSED16, SPLIT_KERNEL_FUSED32 = 0, 1, 2, 3
 OPTF_TOL_VAR, OPTF_TOL_MEAN = 100, 101
 GEN_F64, GEN_F32, GEN_AUTO = 0, 1, 2
 FITMATH_NONE, FITMATH_SMALL, FITMATH_F32, FITMATH_F64, FITMATH_BF16X6, FITMATH_F16X3 = 0, 1, 2, 3, 4, 5  # gpso_last_count(ctx, 2)

@@ -537,7 +537,9 @@ struct EngineT : Engine {
         }
         return GPSO_OK;
       case GPSO_OPT_SPLIT_KERNEL:
-        if (value != GPSO_SPLIT_KERNEL_AUTO && value != GPSO_SPLIT_KERNEL_TWO_PHASE) return ctx->fail(GPSO_E_ARG, "unknown split kernel %d", value);
+        if (value < GPSO_SPLIT_KERNEL_AUTO || value > GPSO_SPLIT_KERNEL_FUSED32) return ctx->fail(GPSO_E_ARG, "unknown split kernel %d", value);
+        if (value == GPSO_SPLIT_KERNEL_FUSED32 && !gpso::leaf_step32_built())
+          return ctx->fail(GPSO_E_ARG, "the 32x32x16 step is not in this build (measured slower: leaf_split.hpp, GPSO_STEP32)");
         split_variant = value;
         return GPSO_OK;
       case GPSO_OPT_PRECISION_CHECK:
@@ -1272,6 +1274,7 @@ struct EngineT : Engine {
       // live, the caller's leaves in float.  A NaN coordinate reaches the partial sums by itself on this path (no clamp in
       // float generation), so the finalize stage needs no norms.
       RawLeaves rawl{};
+      rawl.step32 = split_variant == GPSO_SPLIT_KERNEL_FUSED32;
       if constexpr (kFloatPredict && sizeof(TG) == 4) {
         if (fuse_prep && use_bf16 && !prepared && xs_dtype == GPSO_F32 && nchunk == 1 && m_live_c == nullptr && c16_in_use(false)) {
           rawl.x = reinterpret_cast<const float*>(src);

@@ -47,6 +47,7 @@ void launch_pack_linv_bf16(hipStream_t st, int nsplit, const TF* linv, int64_t n
 // fragments, for a generation type of tg_bytes
 // c16: the contraction runs on the fp16 pipe (float generation only): the X fragments of a k-step and the leaf fragments
 // of a wave are fp16 piece pairs of 32-dimension chunks instead of float groups of four dimensions
+bool leaf_step32_built();  // predict_split_f32.hip: was the library built with -DGPSO_STEP32=1 (leaf_split.hpp)
 extern int g_leaf_last_splits;  // predict.hip: what the launcher of the split kernels chose last (gpso_last_count(ctx, 3))
 extern int g_leaf_row_loop;  // predict.hip: GPSO_OPT_ROW_LOOP (a workgroup of the split predict kernels loops over row blocks)
 inline int leaf_c16_chunks(int dp4) { return (dp4 + 8) / 8; }  // D_pad inputs + the norm slot, 32 slots per chunk
@@ -69,6 +70,7 @@ struct RawLeaves {
   const double* ls = nullptr;  // lengthscale per input dimension (device)
   int64_t m = 0;
   int d = 0;
+  bool step32 = false;  // (rides along: GPSO_SPLIT_KERNEL_FUSED32 -- the fused step on the 32x32x16 instruction, where built)
 };
 template <typename TG, bool FUSED, int KS /* kernel families 0-1 | 2-3 */>
 int launch_leaf_tiles_bf16_v(hipStream_t st, int nsplit, const void* linv_b, const TG* xs_p,
@@ -89,7 +91,7 @@ inline int launch_leaf_tiles_bf16(hipStream_t st, int nsplit, const void* linv_b
                                   const float* c16_scale = nullptr, int64_t n_rows = 0, const RawLeaves& rawl = RawLeaves{}) {
 #define GPSO_V(FUSED, KS) launch_leaf_tiles_bf16_v<TG, FUSED, KS>(st, nsplit, linv_b, xs_p, xnorm, alpha, leaves_s, lnorm, part_var, part_mean, npad, dp4, mpad, kp, m_live, f16_inv_scale_a, xs_h16, c16_scale, n_rows, rawl)
   const bool low = kp.kernel == 0 || kp.kernel == 1;
-  const int rc = variant == 0 ? (low ? GPSO_V(true, 0) : GPSO_V(true, 1)) : (low ? GPSO_V(false, 0) : GPSO_V(false, 1));
+  const int rc = variant != 1 ? (low ? GPSO_V(true, 0) : GPSO_V(true, 1)) : (low ? GPSO_V(false, 0) : GPSO_V(false, 1));
 #undef GPSO_V
   return rc;
 }

@@ -73,6 +73,14 @@ __device__ __forceinline__ void glds4(const void* gsrc_lane, void* lds_wave_base
 #define GPSO_LEAF_STAGGER 0
 #endif
 constexpr bool kLeafStagger = GPSO_LEAF_STAGGER != 0;
+// The fused step on the 32x32x16 matrix instruction (leaf_split_m32.hpp; round 6): correct (errors against float64 equal to the
+// 16x16x32 step's), 4.9 % FEWER clocks per launch (GRBM_GUI_ACTIVE 1.056e7 against 1.111e7 at C3) -- and an 11 % LOWER clock
+// under it (1.80 against 2.02 GHz: MI355X_MICROARCH.md, DVFS give-back, item 7), so 6.6-7.1 % SLOWER at C3 / C4 / C5
+// (profiles/r06_step32_*.jsonl, r06_pmc_16_vs_32.txt).  Built only with -DGPSO_STEP32=1 (then GPSO_SPLIT_KERNEL_FUSED32 selects it).
+#ifndef GPSO_STEP32
+#define GPSO_STEP32 0
+#endif
+constexpr bool kLeafStep32 = GPSO_STEP32 != 0;
 // GPSO_OPT_ROW_LOOP (process-wide switch of the split kernels' workgroup shape; api.hip sets it): predict.hip owns both
 extern int g_leaf_row_loop;
 extern int g_leaf_last_splits;
@@ -618,13 +626,16 @@ __device__ __forceinline__ void leaf_bf16_fused_half(int lane, int dp4, const u3
   }
 }
 
+#include "leaf_split_m32.hpp"
+
 // F16: the fp16 split (two pieces, three products); `variance` then arrives multiplied by 2^sb, inv_scale_a[1] is
 // 2^-sa (device, written by pack_linv_f16_kernel) and inv_scale_b = 2^-sb
 // FUSED: every wave runs the fused step (apply of step q with the generation of step q + 1 in its MFMA shadows, one
 // barrier per step); otherwise round 3's two-phase step with the waves of a SIMD in opposite order
 // C16: the contraction on the fp16 pipe -- xs_p then points at the fp16 piece pairs of the scaled inputs
 // (pack_xs_f16_kernel's order) and c16_scale at their scale (device: [1] = 2^sx, [2] = 2^-2sx)
-template <int NS, typename TG, int KERNEL, bool F16 = false, bool FUSED = false, int C16 = 0>
+// M32P: the fused step on the 32x32x16 matrix instruction (leaf_split_m32.hpp; fp16 split with the fp16 contraction only)
+template <int NS, typename TG, int KERNEL, bool F16 = false, bool FUSED = false, int C16 = 0, bool M32P = false>
 __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     const u32x4* __restrict__ linv_b, const TG* __restrict__ xs_p, const TG* __restrict__ xnorm,
     const float* __restrict__ alpha, const TG* __restrict__ leaves_s,
@@ -636,6 +647,8 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     const double* __restrict__ raw_ls, int64_t raw_m, int raw_d) {
   constexpr int RT = 16, CT = 2, NW = 8;
   constexpr TG SC = (TG)GenScale<KERNEL>::SC;
+  constexpr bool M32 = M32P && FUSED && F16 && NS == 2 && C16 != 0 && sizeof(TG) == 4;
+  static_assert(M32 == M32P, "the 32x32x16 step exists for the fp16 split with the fp16 contraction");
   extern __shared__ __align__(16) unsigned char lds_raw[];
   // ---- which (leaf tile, row blocks) this workgroup computes ---------------------------------------------------------------
   // Rounds 1-5: one workgroup = (leaf tile blockIdx.x, ONE row block, heaviest first over blockIdx.y): 2 048 workgroups at C3,
@@ -837,6 +850,13 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   bf16x8 bfrag[NS][CT];
   float vc[3];
   gen_poly_coeffs<KERNEL>(variance, vc);
+  // (M32) the same tile as eight 32 x 32 accumulators; this lane's leaf is col0 + (lane & 31)
+  f32x16 acc32[RT / 2];
+  float macc32 = 0.0f;
+  u32x4 bfrag32[2][2];
+  const M32Lanes ml = m32_lanes<C16 != 0 ? C16 : 1>(lane);
+  const float nb32 = M32 ? (float)(((lane >> 4) & 1) ? nb[1] : nb[0]) : 0.0f;
+  (void)acc32; (void)macc32; (void)bfrag32; (void)ml; (void)nb32;
   // ---- the row blocks of this workgroup, heaviest first -------------------------------------------------------------------
   // (every step ends with a workgroup barrier, the last one included: when the DMAs of the next row block's first steps are
   // issued, no wave still reads the buffers they land in)
@@ -848,11 +868,19 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     set_row_block(rbj);
     issue_block_start();
   }
+  if constexpr (M32) {
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
+    for (int R = 0; R < RT / 2; ++R)
 #pragma unroll
-    for (int t = 0; t < CT; ++t) acc[rt][t] = f32x4{0, 0, 0, 0};
-  macc[0] = macc[1] = 0.0f;
+      for (int i = 0; i < 16; ++i) acc32[R][i] = 0.0f;
+    macc32 = 0.0f;
+  } else {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int t = 0; t < CT; ++t) acc[rt][t] = f32x4{0, 0, 0, 0};
+    macc[0] = macc[1] = 0.0f;
+  }
   __syncthreads();
 
   auto issue_for = [&](int k) {
@@ -868,8 +896,15 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     const bool late = wave >= NW / 2;  // (wave-uniform) the staggered half
     (void)fregs;
     (void)late;
-    if (q_diag0 == 0) leaf_bf16_gen<NS, TG, KERNEL, F16, true, C16>(lane, dp4, xsl, xb, nb, cm, vc, bfrag, macc);
-    else leaf_bf16_gen<NS, TG, KERNEL, F16, false, C16>(lane, dp4, xsl, xb, nb, cm, vc, bfrag, macc);
+    u32x4 bnxt32[2][2];
+    (void)bnxt32;
+    if constexpr (M32) {
+      if (q_diag0 == 0) leaf_gen32<KERNEL, true, C16>(dp4, xsl, xb, ml, nb32, (float)cm, vc, bfrag32, macc32);
+      else leaf_gen32<KERNEL, false, C16>(dp4, xsl, xb, ml, nb32, (float)cm, vc, bfrag32, macc32);
+    } else {
+      if (q_diag0 == 0) leaf_bf16_gen<NS, TG, KERNEL, F16, true, C16>(lane, dp4, xsl, xb, nb, cm, vc, bfrag, macc);
+      else leaf_bf16_gen<NS, TG, KERNEL, F16, false, C16>(lane, dp4, xsl, xb, nb, cm, vc, bfrag, macc);
+    }
     // Measured and NOT kept (tools/ab_time.py, same box, f16x3 at C3: two-phase 0.850 | this 0.7955 ms): the step's DMAs
     // dealt behind the MFMAs of row tiles 1, 2, ... like the map (+2 %); a ring of THREE buffers of L^-1 pieces with the
     // DMAs of step q + 2 issued at the tail of step q behind a raw s_barrier (0.7973); the SIMD's issue priority handed
@@ -895,6 +930,12 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
                                                                       bfrag, bnxt, acc, macc, fregs);                 \
       GPSO_BSTAMP(q, 4);                                                                                              \
       if (!late) __syncthreads();                                                                                     \
+    } else if constexpr (M32) {                                                                                       \
+      leaf_fused_step32<KERNEL, ASKIP, GMODE, C16, RTL>(dp4, panel + (q & 1) * NS * RT * 64,                          \
+                                                        xsl + ((q + 1) % 3) * xstride, xb, ml, nb32, (float)cm, vc,   \
+                                                        bfrag32, bnxt32, acc32, macc32);                              \
+      GPSO_BSTAMP(q, 4);                                                                                              \
+      __syncthreads();                                                                                                \
     } else {                                                                                                          \
       leaf_bf16_fused_step<NS, TG, KERNEL, F16, ASKIP, GMODE, C16, RTL>(q, q_diag0, lane, dp4,                        \
                                                                    panel + (q & 1) * NS * RT * 64,                    \
@@ -905,8 +946,13 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     }                                                                                                                 \
     GPSO_BSTAMP(q, 5);                                                                                                \
     if (GMODE != 0) {                                                                                                 \
-      for (int sp = 0; sp < NS; ++sp)                                                                                 \
-        for (int t = 0; t < CT; ++t) bfrag[sp][t] = bnxt[sp][t];                                                      \
+      if constexpr (M32) {                                                                                            \
+        for (int sp = 0; sp < 2; ++sp)                                                                                \
+          for (int sl = 0; sl < 2; ++sl) bfrag32[sp][sl] = bnxt32[sp][sl];                                            \
+      } else {                                                                                                        \
+        for (int sp = 0; sp < NS; ++sp)                                                                               \
+          for (int t = 0; t < CT; ++t) bfrag[sp][t] = bnxt[sp][t];                                                    \
+      }                                                                                                               \
     }                                                                                                                 \
   }
     auto fused_loops = [&](auto rtl_) {
@@ -969,26 +1015,44 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     unscale2 = (ia * ib) * (ia * ib);
     unscale_m = ib;
   }
-#pragma unroll
-  for (int t = 0; t < CT; ++t) {
+  if constexpr (M32) {
     double sq = 0;
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+    for (int R = 0; R < RT / 2; ++R)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sq = fma((double)acc[rt][t][r], (double)acc[rt][t][r], sq);
-    sq += __shfl_xor(sq, 16);
+      for (int i = 0; i < 16; ++i) sq = fma((double)acc32[R][i], (double)acc32[R][i], sq);
     sq += __shfl_xor(sq, 32);
-    double mm = (double)macc[t];
-    mm += __shfl_xor(mm, 16);
+    double mm = (double)macc32;
     mm += __shfl_xor(mm, 32);
-    if constexpr (F16) {
-      sq *= unscale2;
-      mm *= unscale_m;
-    }
-    if (lane < 16) {
-      const int64_t col = col0 + t * 16 + lane;
+    sq *= unscale2;
+    mm *= unscale_m;
+    if (lane < 32) {
+      const int64_t col = col0 + lane;
       part_var[(int64_t)bi * mpad + col] = sq;
       part_mean[(int64_t)bi * mpad + col] = mm;
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      double sq = 0;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sq = fma((double)acc[rt][t][r], (double)acc[rt][t][r], sq);
+      sq += __shfl_xor(sq, 16);
+      sq += __shfl_xor(sq, 32);
+      double mm = (double)macc[t];
+      mm += __shfl_xor(mm, 16);
+      mm += __shfl_xor(mm, 32);
+      if constexpr (F16) {
+        sq *= unscale2;
+        mm *= unscale_m;
+      }
+      if (lane < 16) {
+        const int64_t col = col0 + t * 16 + lane;
+        part_var[(int64_t)bi * mpad + col] = sq;
+        part_mean[(int64_t)bi * mpad + col] = mm;
+      }
     }
   }
   if (!has_next) break;  // (workgroup-uniform)
@@ -1058,14 +1122,26 @@ static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const T
   g_leaf_last_splits = S;
   const dim3 grid_s((unsigned)(mpad / 256), (unsigned)S);
   // FUSED (GPSO_SPLIT_KERNEL_AUTO): the fused step; otherwise round 3's two-phase step.  Same bits either way.
-#define GPSO_L(K)                                                                                   \
+  // rawl.step32 (GPSO_SPLIT_KERNEL_AUTO): the fused step on the 32x32x16 instruction, where that kernel exists
+  constexpr bool kHasM32 = kLeafStep32 && FUSED && F16 && NS == 2 && C16 != 0 && sizeof(TG) == 4;
+  const bool m32 = kHasM32 && rawl.step32;
+#define GPSO_L1(K, M32)                                                                             \
   do {                                                                                              \
-    const int rc = ensure_dyn_lds((const void*)leaf_tiles_bf16_kernel<NS, TG, K, F16, FUSED, C16>, (int)lds); \
+    const int rc = ensure_dyn_lds((const void*)leaf_tiles_bf16_kernel<NS, TG, K, F16, FUSED, C16, M32>, (int)lds); \
     if (rc) return rc;                                                                              \
-    hipLaunchKernelGGL((leaf_tiles_bf16_kernel<NS, TG, K, F16, FUSED, C16>), grid_s, dim3(512), lds, st, \
+    hipLaunchKernelGGL((leaf_tiles_bf16_kernel<NS, TG, K, F16, FUSED, C16, M32>), grid_s, dim3(512), lds, st, \
                        static_cast<const u32x4*>(linv_b), xs_p, xnorm, alpha, leaves_s, lnorm,      \
                        part_var, part_mean, (int)(npad / 16), dp4, mpad, nbi, var_arg, m_live,      \
                        inv_scale_a, inv_b, c16_scale, q_max, C16 ? rawl.x : nullptr, rawl.ls, rawl.m, rawl.d); \
+  } while (0)
+#define GPSO_L(K)                                   \
+  do {                                              \
+    if constexpr (kHasM32) {                        \
+      if (m32) GPSO_L1(K, true);                    \
+      else GPSO_L1(K, false);                       \
+    } else {                                        \
+      GPSO_L1(K, false);                            \
+    }                                               \
   } while (0)
   if constexpr (KS == 0) {
     if (kp.kernel == 0) GPSO_L(0);
@@ -1075,6 +1151,8 @@ static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const T
     else GPSO_L(3);
   }
 #undef GPSO_L
+#undef GPSO_L1
+  (void)m32;
   return 0;
 }
 

@@ -5,5 +5,6 @@
 #include "leaf_split.hpp"
 
 namespace gpso {
+bool leaf_step32_built() { return kLeafStep32; }
 template int launch_leaf_tiles_bf16_v<float, true, 0>(hipStream_t, int, const void*, const float*, const float*, const float*, const float*, const float*, double*, double*, int64_t, int, int64_t, const KernParams&, const int64_t*, const float*, const void*, const float*, int64_t, const RawLeaves&);
 }  // namespace gpso

@@ -115,7 +115,7 @@ class HipGPEngine:
 
     def set_split_kernel(self, which):
         """GPSO_OPT_SPLIT_KERNEL: "auto" (the fused step) | "two-phase" (round 3's step): same bits, different speed."""
-        self._check(self._lib.gpso_set_option(self._h, L.OPT_SPLIT_KERNEL, {"auto": 0, "two-phase": 1}[which]))
+        self._check(self._lib.gpso_set_option(self._h, L.OPT_SPLIT_KERNEL, {"auto": 0, "two-phase": 1, "fused16": 2, "fused32": 3}[which]))
 
     def set_contraction(self, which):
         """GPSO_OPT_CONTRACTION: "auto" / "f16" (the x.x* contraction of the fp16-split kernel on the fp16 pipe under
