@@ -100,7 +100,11 @@ struct Bf16Lds {
 // the x.x* contraction of one k-step of a wave: s[h][t] += (16 training points of half h) x (16 leaves of column tile t).
 // Float / double: software-pipelined over the groups of four dimensions -- the operands of group c + 1 are on their way
 // from LDS while the MFMAs of group c issue.  C16: three fp16 products per chunk of 32 dimensions, small terms first.
-template <typename TG, int C16, int CT>
+// XP = 1 (round 6): the LAST chunk uses at most 16 of its 32 slots (D_pad + 1 - 32 (chunks - 1) <= 16: C3's D = 12, the second
+// chunk of C5's D = 40) -- its two small products share ONE instruction: A = [h0 (slots 0-15) | h1 (slots 0-15)] against
+// B = [h1' | h0'], then h0 h0' as before (the pieces' slots 16-31 are zeros): 8 contraction MFMAs per chunk instead of 12.  The
+// operands are the same 16-byte words of the same fragments, fetched by other lanes.
+template <typename TG, int C16, int CT, int XP = 0>
 __device__ __forceinline__ void leaf_contract(int lane, int dp4, const unsigned char* xs_b, const TG* xb,
                                               typename Mfma<TG>::vec4 (&s)[2][CT]) {
   if constexpr (C16 != 0) {
@@ -110,6 +114,34 @@ __device__ __forceinline__ void leaf_contract(int lane, int dp4, const unsigned 
     const u32x4* lb = reinterpret_cast<const u32x4*>(xb);    // [t][cc][piece][64]
 #pragma unroll
     for (int cc = 0; cc < nc; ++cc) {
+      if constexpr (XP == 1) {
+        if (cc == nc - 1) {  // (compile-time after unrolling)
+          const int g1 = lane >> 5;                      // lanes 32-63 take the words of the OTHER piece
+          const int w = (lane & 15) + 16 * ((lane >> 4) & 1);  // ... at slots 0-15: lane groups 0, 1 of the fragment
+          u32x4 a1[2], a2[2], b1[CT], b2[CT];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            a1[h] = xa[((h * nc + cc) * 2 + g1) * 64 + w];
+            a2[h] = xa[((h * nc + cc) * 2 + 0) * 64 + lane];
+          }
+#pragma unroll
+          for (int t = 0; t < CT; ++t) {
+            b1[t] = lb[((t * nc + cc) * 2 + 1 - g1) * 64 + w];
+            b2[t] = lb[((t * nc + cc) * 2 + 0) * 64 + lane];
+          }
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int t = 0; t < CT; ++t)
+              s[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a1[h]), __builtin_bit_cast(f16x8, b1[t]), s[h][t], 0, 0, 0);
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int t = 0; t < CT; ++t)
+              s[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a2[h]), __builtin_bit_cast(f16x8, b2[t]), s[h][t], 0, 0, 0);
+          continue;
+        }
+      }
       u32x4 a[2][2], b[CT][2];
 #pragma unroll
       for (int h = 0; h < 2; ++h)
@@ -202,7 +234,7 @@ __device__ __forceinline__ void gen_poly_coeffs(float variance, float (&vc)[3]) 
   vc[1] = variance * kLn2;
   vc[2] = variance * (kLn2 * kLn2 / 3.0f);
 }
-template <int NS, typename TG, int KERNEL, bool F16, bool DIAG, int C16 = 0, int CT = 2>
+template <int NS, typename TG, int KERNEL, bool F16, bool DIAG, int C16 = 0, int CT = 2, int XP = 0>
 __device__ __forceinline__ void leaf_bf16_gen(int lane, int dp4,
                                               const unsigned char* xs_b /* [2][dp4] X fragments | norms | alpha */,
                                               const TG* xb, const TG (&nb)[CT] /* SC |x*|^2 */, const TG cm /* -2 SC (C16: x 2^-2sx) */,
@@ -228,7 +260,7 @@ __device__ __forceinline__ void leaf_bf16_gen(int lane, int dp4,
 #pragma unroll
     for (int h = 0; h < 2; ++h) nav[h] = *reinterpret_cast<const vecG*>(nrm + 16 * h + 4 * (lane >> 4));
   }
-  leaf_contract<TG, C16, CT>(lane, dp4, xs_b, xb, s);
+  leaf_contract<TG, C16, CT, XP>(lane, dp4, xs_b, xb, s);
   float p[CT][8];
   // stage 0: u = SC r^2, GPflow's GEMM form combined in TG, rounded to float
 #pragma unroll
@@ -372,7 +404,7 @@ __device__ __forceinline__ void leaf_bf16_apply(int q, int q_diag0, int lane, co
 // per step (disassembly), in the steps that already have the least matrix work to hide them behind.
 // RTL: row tiles of the block that hold training rows (16, or 8 for a LAST row block with <= 128 of them: the tiles
 // beyond are all zero and are not applied; the map of the next step is then dealt over row tiles 1 .. RTL - 1)
-template <int NS, typename TG, int KERNEL, bool F16, int ASKIP, int GMODE, int C16 = 0, int RTL = 16>
+template <int NS, typename TG, int KERNEL, bool F16, int ASKIP, int GMODE, int C16 = 0, int RTL = 16, int XP = 0>
 __device__ __forceinline__ void leaf_bf16_fused_step(int q, int q_diag0, int lane, int dp4,
                                                      const u32x4* panel_b /* [NS][16][64]: L^-1 pieces of step q */,
                                                      const unsigned char* xs_n /* inputs of step q + 1 */, const TG* xb,
@@ -398,7 +430,7 @@ __device__ __forceinline__ void leaf_bf16_fused_step(int q, int q_diag0, int lan
 #pragma unroll
       for (int h = 0; h < 2; ++h) nav[h] = *reinterpret_cast<const vecG*>(nrm + 16 * h + 4 * (lane >> 4));
     }
-    leaf_contract<TG, C16, CT>(lane, dp4, xs_n, xb, s);
+    leaf_contract<TG, C16, CT, XP>(lane, dp4, xs_n, xb, s);
   }
   // ---- apply of step q, the map of step q + 1 dealt over row tiles 1 .. 15 --------------------------------------------
   // value e = 8 t + j, j = 4 h + r (column tile t, 16-point half h, accumulator register r); ops in stage-major order --
@@ -635,7 +667,8 @@ __device__ __forceinline__ void leaf_bf16_fused_half(int lane, int dp4, const u3
 // C16: the contraction on the fp16 pipe -- xs_p then points at the fp16 piece pairs of the scaled inputs
 // (pack_xs_f16_kernel's order) and c16_scale at their scale (device: [1] = 2^sx, [2] = 2^-2sx)
 // M32P: the fused step on the 32x32x16 matrix instruction (leaf_split_m32.hpp; fp16 split with the fp16 contraction only)
-template <int NS, typename TG, int KERNEL, bool F16 = false, bool FUSED = false, int C16 = 0, bool M32P = false>
+// XP: the last chunk of the fp16 contraction packs its two small products into one instruction (leaf_contract)
+template <int NS, typename TG, int KERNEL, bool F16 = false, bool FUSED = false, int C16 = 0, bool M32P = false, int XP = 0>
 __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     const u32x4* __restrict__ linv_b, const TG* __restrict__ xs_p, const TG* __restrict__ xnorm,
     const float* __restrict__ alpha, const TG* __restrict__ leaves_s,
@@ -902,8 +935,8 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
       if (q_diag0 == 0) leaf_gen32<KERNEL, true, C16>(dp4, xsl, xb, ml, nb32, (float)cm, vc, bfrag32, macc32);
       else leaf_gen32<KERNEL, false, C16>(dp4, xsl, xb, ml, nb32, (float)cm, vc, bfrag32, macc32);
     } else {
-      if (q_diag0 == 0) leaf_bf16_gen<NS, TG, KERNEL, F16, true, C16>(lane, dp4, xsl, xb, nb, cm, vc, bfrag, macc);
-      else leaf_bf16_gen<NS, TG, KERNEL, F16, false, C16>(lane, dp4, xsl, xb, nb, cm, vc, bfrag, macc);
+      if (q_diag0 == 0) leaf_bf16_gen<NS, TG, KERNEL, F16, true, C16, 2, XP>(lane, dp4, xsl, xb, nb, cm, vc, bfrag, macc);
+      else leaf_bf16_gen<NS, TG, KERNEL, F16, false, C16, 2, XP>(lane, dp4, xsl, xb, nb, cm, vc, bfrag, macc);
     }
     // Measured and NOT kept (tools/ab_time.py, same box, f16x3 at C3: two-phase 0.850 | this 0.7955 ms): the step's DMAs
     // dealt behind the MFMAs of row tiles 1, 2, ... like the map (+2 %); a ring of THREE buffers of L^-1 pieces with the
@@ -937,7 +970,7 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
       GPSO_BSTAMP(q, 4);                                                                                              \
       __syncthreads();                                                                                                \
     } else {                                                                                                          \
-      leaf_bf16_fused_step<NS, TG, KERNEL, F16, ASKIP, GMODE, C16, RTL>(q, q_diag0, lane, dp4,                        \
+      leaf_bf16_fused_step<NS, TG, KERNEL, F16, ASKIP, GMODE, C16, RTL, XP>(q, q_diag0, lane, dp4,                    \
                                                                    panel + (q & 1) * NS * RT * 64,                    \
                                                                    xsl + ((q + 1) % 3) * xstride, xb, nb, cm, vc,     \
                                                                    bfrag, bnxt, acc, macc);                           \
@@ -992,7 +1025,7 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     if (!ahead || q == 0) issue_for(q);                                                                               \
     else if (q >= 2) issue_for(q - 1); /* (this wave's iteration q starts in interval q - 1) */                       \
     GPSO_BSTAMP(q, 1);                                                                                                \
-    leaf_bf16_gen<NS, TG, KERNEL, F16, DIAGF, C16>(lane, dp4, xsl + (q % 3) * xstride, xb, nb, cm, vc, bfrag, macc);  \
+    leaf_bf16_gen<NS, TG, KERNEL, F16, DIAGF, C16, 2, XP>(lane, dp4, xsl + (q % 3) * xstride, xb, nb, cm, vc, bfrag, macc); \
     GPSO_BSTAMP(q, 2);                                                                                                \
     if (ahead && q > 0) __syncthreads();                                                                              \
     GPSO_BSTAMP(q, 3);                                                                                                \
@@ -1125,11 +1158,13 @@ static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const T
   // rawl.step32 (GPSO_SPLIT_KERNEL_AUTO): the fused step on the 32x32x16 instruction, where that kernel exists
   constexpr bool kHasM32 = kLeafStep32 && FUSED && F16 && NS == 2 && C16 != 0 && sizeof(TG) == 4;
   const bool m32 = kHasM32 && rawl.step32;
-#define GPSO_L1(K, M32)                                                                             \
+  // xp: the last chunk of the fp16 contraction uses <= 16 slots (the scaled inputs and the norm slot behind them)
+  const bool xp = C16 != 0 && dp4 * 4 + 1 - 32 * (C16 - 1) <= 16;
+#define GPSO_L1(K, M32, XP)                                                                         \
   do {                                                                                              \
-    const int rc = ensure_dyn_lds((const void*)leaf_tiles_bf16_kernel<NS, TG, K, F16, FUSED, C16, M32>, (int)lds); \
+    const int rc = ensure_dyn_lds((const void*)leaf_tiles_bf16_kernel<NS, TG, K, F16, FUSED, C16, M32, XP>, (int)lds); \
     if (rc) return rc;                                                                              \
-    hipLaunchKernelGGL((leaf_tiles_bf16_kernel<NS, TG, K, F16, FUSED, C16, M32>), grid_s, dim3(512), lds, st, \
+    hipLaunchKernelGGL((leaf_tiles_bf16_kernel<NS, TG, K, F16, FUSED, C16, M32, XP>), grid_s, dim3(512), lds, st, \
                        static_cast<const u32x4*>(linv_b), xs_p, xnorm, alpha, leaves_s, lnorm,      \
                        part_var, part_mean, (int)(npad / 16), dp4, mpad, nbi, var_arg, m_live,      \
                        inv_scale_a, inv_b, c16_scale, q_max, C16 ? rawl.x : nullptr, rawl.ls, rawl.m, rawl.d); \
@@ -1137,10 +1172,14 @@ static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const T
 #define GPSO_L(K)                                   \
   do {                                              \
     if constexpr (kHasM32) {                        \
-      if (m32) GPSO_L1(K, true);                    \
-      else GPSO_L1(K, false);                       \
+      if (m32) GPSO_L1(K, true, 0);                 \
+      else if (xp) GPSO_L1(K, false, 1);            \
+      else GPSO_L1(K, false, 0);                    \
+    } else if constexpr (C16 != 0) {                \
+      if (xp) GPSO_L1(K, false, 1);                 \
+      else GPSO_L1(K, false, 0);                    \
     } else {                                        \
-      GPSO_L1(K, false);                            \
+      GPSO_L1(K, false, 0);                         \
     }                                               \
   } while (0)
   if constexpr (KS == 0) {
@@ -1153,6 +1192,7 @@ static int launch_leaf_tiles_bf16_ns(hipStream_t st, const void* linv_b, const T
 #undef GPSO_L
 #undef GPSO_L1
   (void)m32;
+  (void)xp;
   return 0;
 }
 
