@@ -738,7 +738,13 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   static_assert(FPW * DW == NS * RT && FPW * 1024 <= 8192 && RT == 16, "window of a wave's fragments");
   const bool dma_wave = wave < DW;
   const int lane16 = lane * 16, lane4 = lane * 4;
-  const unsigned char* pgb[FPW];
+  // The fragments of a DMA wave: f = FPW (wave % DW) + j, piece f / RT, row tile f % RT.  Where FPW divides RT (two pieces: 8 or 4
+  // fragments per wave) they are consecutive row tiles of ONE piece -- equidistant in memory (a row tile's pieces are N_pad / 32
+  // KB apart): one 64-bit base per wave and a 32-bit stride instead of FPW 64-bit bases (up to 16 of the ~100 scalar registers
+  // the kernel has).  Three pieces (FPW = 6) straddle pieces: those kernels keep the array.
+  constexpr bool kStrided = RT % FPW == 0;
+  const unsigned char* pgb[kStrided ? 1 : FPW];
+  const unsigned pg_step = (unsigned)npad32 * 1024u - 1024u;  // (from fragment j to j + 1, net of the immediate offsets' 1 KB)
   bool has_next = false;
   auto rank_of = [&](int j) { return j * S + ((j & 1) ? S - 1 - split : split); };
   auto set_row_block = [&](int j_mine /* this workgroup's j-th row block */) {
@@ -749,7 +755,7 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     q_end = q_diag0 + RT / 2;
     q_lim = FUSED ? min(q_end, q_max) : q_end;
 #pragma unroll
-    for (int j = 0; j < FPW; ++j) {
+    for (int j = 0; j < (kStrided ? 1 : FPW); ++j) {
       const int f = FPW * (wave % DW) + j, sp = f / RT, rt = f % RT;  // fragment f = piece sp, row tile rt
       pgb[j] = reinterpret_cast<const unsigned char*>(linv_b + ((size_t)sp * npad16 + (bi * RT + rt)) * npad32 * 64) -
                (j * 1024 - FPW * 512);
@@ -766,10 +772,18 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   auto issue_panel = [&](int q, int buf) {
     if (!dma_wave) return;
     unsigned char* centre = reinterpret_cast<unsigned char*>(panel) + buf * (NS * RT * 1024) + wave * (FPW * 1024) + FPW * 512;
-    static_for<0, FPW>([&](auto j_) {
-      constexpr int j = decltype(j_)::value;
-      glds16_off<j * 1024 - FPW * 512>(uniform(pgb[j] + (size_t)q * 1024) + lane16, centre);
-    });
+    if constexpr (kStrided) {
+      const unsigned char* pq = pgb[0] + (size_t)q * 1024;
+      static_for<0, FPW>([&](auto j_) {
+        constexpr int j = decltype(j_)::value;
+        glds16_off<j * 1024 - FPW * 512>(uniform(pq + (size_t)j * pg_step) + lane16, centre);
+      });
+    } else {
+      static_for<0, FPW>([&](auto j_) {
+        constexpr int j = decltype(j_)::value;
+        glds16_off<j * 1024 - FPW * 512>(uniform(pgb[j] + (size_t)q * 1024) + lane16, centre);
+      });
+    }
   };
   // the inputs of a k-step: a ring of three buffers (step q + 1 is generated during step q).  Piece r of
   // the X fragments is bytes [256 r, 256 r + 256) of the step's contiguous source block and of the buffer alike
