@@ -6,7 +6,7 @@
 TAG=${1:-r06}
 PART=${2:-all}   # a = bench lines + kernel stats + PMC, b = fit timelines, loop bench, host overhead, fuzz
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-KPAT="leaf_tiles_bf16_kernel<2, float, 0, true, true, 1>"   # the fp16 split instantiation (first rung of GPSO_MATH_AUTO)
+KPAT="leaf_tiles_bf16_kernel<2, float, 0, true, true, 1, false, 1>"   # the fp16 split instantiation at C3 (first rung of GPSO_MATH_AUTO; fused step, one chunk of the fp16 contraction, 16x16x32, packed contraction)
 if [ $PART = a ] || [ $PART = all ]; then
 python3 $R/bench.py > $O/bench_c3.json 2> $O/bench_c3.err
 for w in c2 c4 c5 c3f64; do python3 $R/bench.py --workload $w --no-cpu-baseline > $O/bench_$w.json 2>/dev/null; done
@@ -23,7 +23,7 @@ rocprofv3 --pmc FETCH_SIZE TCC_HIT GRBM_GUI_ACTIVE --kernel-trace --output-forma
 rocprofv3 --pmc WRITE_SIZE TCC_MISS TCC_REQ --kernel-trace --output-format csv -d $O/pmc2 -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > /dev/null 2>&1; echo "pmc2 rc $?"
 rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pmc3 -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > /dev/null 2>&1; echo "pmc3 rc $?"
 for pat in "$KPAT" "leaf_tiles_bf16_kernel<3" "leaf_tiles_v2_kernel" potrf_step gram_kernel; do echo "## $pat (largest-grid dispatches only)"; for p in pmc1 pmc2 pmc3; do python3 $R/tools/pmc_summary.py $O/$p "$pat"; done; done > $O/pmc_summary.txt 2>&1
-python3 $R/tools/pmc_traffic_json.py $O/pmc_leaf_tiles_f16x3_c3.json c3 "$KPAT" "leaf_tiles_bf16_kernel<2, float, 0, true, true, 1> (fp16 split x3, fused step, fp16 contraction: first rung of GPSO_MATH_AUTO)" $O/pmc1 $O/pmc2 $O/pmc3 > /dev/null
+python3 $R/tools/pmc_traffic_json.py $O/pmc_leaf_tiles_f16x3_c3.json c3 "$KPAT" "leaf_tiles_bf16_kernel<2, float, 0, true, true, 1, false, 1> (fp16 split x3, fused step, fp16 contraction with its small products packed: first rung of GPSO_MATH_AUTO)" $O/pmc1 $O/pmc2 $O/pmc3 > /dev/null
 rm -rf $O/prof $O/pmc1 $O/pmc2 $O/pmc3
 echo "bench profile done"
 rocprofv3 --kernel-trace --output-format csv -d $O/steptrace -- python3 $R/bench.py --steps 60 --warmup 5 --no-cpu-baseline > /dev/null 2>&1

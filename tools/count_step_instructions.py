@@ -6,7 +6,7 @@ DESIGN 4.1's "vector instructions per MFMA" (SQ_INSTS_VALU co
     hipcc --offload-arch=gfx950 -O3 ... --cuda-device-only -S predict_split_f32.hip -o K.s
     python tools/count_step_instructions.py K.s [kernel-name-substring]
 
-The hot loop = the loop (a backward branch) with the most v_mfma instructions inside the kernel."""
+The hot loop = the INNERMOST loop (a backward branch around no other) with the most v_mfma instructions inside the kernel."""
 import re
 import sys
 from collections import Counter
@@ -64,7 +64,10 @@ for i, l in enumerate(body):
         ops = keep[:-1]
         c = Counter(klass(o) for o in ops)
         loops.append((c["mfma"], labels[m.group(1)], i, c, ops))
-loops.sort(reverse=True, key=lambda t: t[0])
+# the hot loop = the INNERMOST loop with the most MFMAs: since round 6 the kernel's outer loop walks the row blocks (its body holds
+# the diagonal block's unrolled steps too); an innermost loop is one that contains no other loop's back edge
+inner = [t for t in loops if not any(o is not t and t[1] <= o[1] and o[2] <= t[2] and (o[1], o[2]) != (t[1], t[2]) for o in loops)]
+loops = sorted(inner, reverse=True, key=lambda t: t[0] / max(1, t[3]['s_barrier']))  # (most MFMAs per k-step: the steps below the diagonal block)
 total = Counter(klass(t.split()[0]) for t in (x.strip() for x in body) if t and not t.startswith((";", ".", "//")) and not t.endswith(":"))
 print(f"kernel: {len(body)} lines; whole-kernel census: {dict(total)}")
 for nm, a, b, c, ops in loops[:3]:

@@ -26,7 +26,7 @@ WHAT = [  # (regex on the family name, what it is / how it is made)
     (r"^fit_(bench|experiments|analysis)", "what was built, measured and kept or not in the fit kernels of that round (fp16 / bf16 planes, persistent chains, 128-wide steps)"),
     (r"^append_(bench|experiments)|^ab_bits_append", "`gpso_append`: times beside the from-scratch fit (`tools/append_bench.py`), the versions measured on the way incl. round 6's fused-epilogue variant (slower, not kept), bit comparison with the round before"),
     (r"^predict_experiments", "the split predict kernel: every variant with same-box A/B numbers, stamps, ablations; round 6: instruction census, issue-port budget, the stagger"),
-    (r"^(ab_|ablation_times)", "raw `tools/ab_time.py` / `tools/ab_bits.py` outputs of single changes"),
+    (r"^(ab_|ablation_times)", "raw `tools/ab_time.py` / `tools/ab_bits.py` / `tools/ab_bench.sh` (round 6: through `bench.py` itself) outputs of single changes: two builds alternating on one box"),
     (r"^(step_timeline|explore_overhead|host_overhead|small_call_modes|graph_probe|loop_profile)", "host / launch overhead of a call: device timeline of bench steps, wall vs device of small calls, launch-sequence modes"),
     (r"^loop_(bench|refit_every|large_n)", "caller-level runs (`tools/loop_bench.py`, `tools/loop_large_n.py`): whole GPSO runs against the CPU oracle loop; `refit_every`; round 6: D = 12 with 2 000 initial points"),
     (r"^(sweep|c16_check|pad_bench|gen_probe|gen_choice|split_math_accuracy|grad_error|precision_)", "accuracy / throughput sweeps over N x D, predict math, generation type (`tools/sweep.py`, `c16_check.py`, `split_math_accuracy.py`, ...)"),
@@ -37,6 +37,8 @@ WHAT = [  # (regex on the family name, what it is / how it is made)
     (r"^vendor_yardstick", "`tools/vendor_yardstick.py`: the same fits / predictions through torch -> rocSOLVER / rocBLAS on the same box (test-only yardstick)"),
     (r"^(linv_tile_census|screen_census)", "CPU censuses that decided NOT to build something: fragments of L^-1 far below the fp16 scale (round 5), survivors of a screened best-UCB call (round 6)"),
     (r"^hyperopt_notpd_probe", "`tools/hyperopt_notpd_probe.py`: where a float32 hyper-parameter search loses positive definiteness, what the escalation to `mixed` costs, the oracle's fit beside it"),
+    (r"^(step32|pmc_16_vs_32)", "round 6: the fused step on the 32x32x16 matrix instruction beside the 16x16x32 one (`tools/step32_ab.py`; PMC: clocks, instruction counts): fewer clocks at a lower clock, 7 % slower, not kept"),
+    (r"^(boundary_fit|step_census)", "round 6: what a row-block boundary of the split kernel costs (kernel ms over N at D = 12, least squares); the instruction census of the final kernel's hot loop (`tools/count_step_instructions.py`)"),
     (r"^asan_cpu", "host-side ASan + UBSan run of the CPU suites (`tools/run_asan_cpu.sh`)"),
     (r"^gputest", "a full `pytest -m gpu` log of that round"),
 ]
