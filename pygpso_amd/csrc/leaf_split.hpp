@@ -911,10 +911,6 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   // free there.  The second set of wave-uniform pointers spills 87 scalar registers into vector lanes inside the hot loop: C3
   // 0.7193 | 0.7221 ms against 0.7464 | 0.7304 without the prefetch, C4 / C5 +2.5 %.  r06_predict_experiments.txt.)
   for (int rbj = 0;; ++rbj) {
-  if (rbj > 0) {
-    set_row_block(rbj);
-    issue_block_start();
-  }
   if constexpr (M32) {
 #pragma unroll
     for (int R = 0; R < RT / 2; ++R)
@@ -1055,6 +1051,16 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
 
   }
 
+  // The next row block's first DMAs fly under this block's epilogue (~1 us of conversions and f64 sums that touch no LDS): every
+  // wave is past the last step's barrier, so the buffers they land in are free.  From here on bi, q_diag0, q_end, q_lim and
+  // has_next are the NEXT block's.
+  const int bi_out = bi;
+  const bool more = has_next;
+  if constexpr (STAG) __syncthreads();  // (waves 4-7 meet their last barrier in the middle of a step)
+  if (more) {  // (workgroup-uniform)
+    set_row_block(rbj + 1);
+    issue_block_start();
+  }
   // (fp16 split: undo the power-of-two scales of the two operands -- exact)
   double unscale2 = 1.0, unscale_m = 1.0;
   if constexpr (F16) {
@@ -1075,8 +1081,8 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     mm *= unscale_m;
     if (lane < 32) {
       const int64_t col = col0 + lane;
-      part_var[(int64_t)bi * mpad + col] = sq;
-      part_mean[(int64_t)bi * mpad + col] = mm;
+      part_var[(int64_t)bi_out * mpad + col] = sq;
+      part_mean[(int64_t)bi_out * mpad + col] = mm;
     }
   } else {
 #pragma unroll
@@ -1097,12 +1103,12 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
       }
       if (lane < 16) {
         const int64_t col = col0 + t * 16 + lane;
-        part_var[(int64_t)bi * mpad + col] = sq;
-        part_mean[(int64_t)bi * mpad + col] = mm;
+        part_var[(int64_t)bi_out * mpad + col] = sq;
+        part_mean[(int64_t)bi_out * mpad + col] = mm;
       }
     }
   }
-  if (!has_next) break;  // (workgroup-uniform)
+  if (!more) break;  // (workgroup-uniform)
   }  // row blocks
 }
 
