@@ -487,14 +487,25 @@ __device__ __forceinline__ void leaf_bf16_fused_step(int q, int q_diag0, int lan
     }
   };
   static_assert(ASKIP >= 0 && ASKIP < RTL && RTL <= RT, "at least one live row tile");
-  u32x4 a[2][NS];
+  // the L^-1 fragments of a row tile are read AD tiles ahead of their MFMAs (GPSO_LEAF_AHEAD, default 1: two register sets; 2:
+  // three sets, a read has two tiles' MFMAs = 192 clocks to land instead of 96)
+#ifndef GPSO_LEAF_AHEAD
+#define GPSO_LEAF_AHEAD 1
+#endif
+  constexpr int AD = (NS == 2) ? GPSO_LEAF_AHEAD : 1, AB = AD + 1;
+  u32x4 a[AB][NS];
+  static_for<0, AD>([&](auto d_) {
+    constexpr int rt0 = ASKIP + decltype(d_)::value;
+    if constexpr (rt0 < RTL) {
 #pragma unroll
-  for (int sp = 0; sp < NS; ++sp) a[ASKIP & 1][sp] = panel_b[(sp * RT + ASKIP) * 64 + lane];
+      for (int sp = 0; sp < NS; ++sp) a[rt0 % AB][sp] = panel_b[(sp * RT + rt0) * 64 + lane];
+    }
+  });
   static_for<0, RTL>([&](auto rt_) {
     constexpr int rt = decltype(rt_)::value;
-    if constexpr (rt + 1 < RTL && rt + 1 > ASKIP) {
+    if constexpr (rt + AD < RTL && rt + AD >= ASKIP + AD && rt >= ASKIP) {
 #pragma unroll
-      for (int sp = 0; sp < NS; ++sp) a[(rt + 1) & 1][sp] = panel_b[(sp * RT + rt + 1) * 64 + lane];
+      for (int sp = 0; sp < NS; ++sp) a[(rt + AD) % AB][sp] = panel_b[(sp * RT + rt + AD) * 64 + lane];
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (rt >= ASKIP) {  // (diagonal block: all-zero tiles above the diagonal)
@@ -502,8 +513,8 @@ __device__ __forceinline__ void leaf_bf16_fused_step(int q, int q_diag0, int lan
       for (int t = 0; t < CT; ++t) {
         f32x4 c = acc[rt][t];
 #define GPSO_BF(SA, SB)                                                                                                   \
-  c = F16 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[rt & 1][SA]), __builtin_bit_cast(f16x8, bcur[SB][t]), c, 0, 0, 0) \
-          : __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[rt & 1][SA]), bcur[SB][t], c, 0, 0, 0)
+  c = F16 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[rt % AB][SA]), __builtin_bit_cast(f16x8, bcur[SB][t]), c, 0, 0, 0) \
+          : __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[rt % AB][SA]), bcur[SB][t], c, 0, 0, 0)
         if constexpr (NS == 3) {
           GPSO_BF(2, 0);
           GPSO_BF(0, 2);
