@@ -922,6 +922,10 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   // free there.  The second set of wave-uniform pointers spills 87 scalar registers into vector lanes inside the hot loop: C3
   // 0.7193 | 0.7221 ms against 0.7464 | 0.7304 without the prefetch, C4 / C5 +2.5 %.  r06_predict_experiments.txt.)
   for (int rbj = 0;; ++rbj) {
+  if (rbj > 0) {
+    set_row_block(rbj);
+    issue_block_start();
+  }
   if constexpr (M32) {
 #pragma unroll
     for (int R = 0; R < RT / 2; ++R)
@@ -1062,16 +1066,13 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
 
   }
 
-  // The next row block's first DMAs fly under this block's epilogue (~1 us of conversions and f64 sums that touch no LDS): every
-  // wave is past the last step's barrier, so the buffers they land in are free.  From here on bi, q_diag0, q_end, q_lim and
-  // has_next are the NEXT block's.
+  // (Measured and NOT kept: the next row block's first DMAs issued HERE, before the epilogue -- every wave is past the last step's
+  // barrier and the epilogue touches no LDS.  -0.2 ... -0.4 % at C3 / C4 / C5, bit-identical on 126 parity cases and 35 hashes --
+  // and the variance of the bf16x6 kernel at C5 (noise 1e-2) came out 0.018 sigma^2 off, every run, with nothing else changed
+  // (tests/test_gpu_parity.py::test_config_C5_one_gpu_share_at_size): an ordering this code relies on without stating it.
+  // Not found in the time left; the order of rounds 1-5 stays.  profiles/r06_predict_experiments.txt, section 10.)
   const int bi_out = bi;
   const bool more = has_next;
-  if constexpr (STAG) __syncthreads();  // (waves 4-7 meet their last barrier in the middle of a step)
-  if (more) {  // (workgroup-uniform)
-    set_row_block(rbj + 1);
-    issue_block_start();
-  }
   // (fp16 split: undo the power-of-two scales of the two operands -- exact)
   double unscale2 = 1.0, unscale_m = 1.0;
   if constexpr (F16) {
