@@ -53,6 +53,16 @@ __device__ __forceinline__ void glds4(const void* gsrc_lane, void* lds_wave_base
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
+// The workgroup barrier of the split kernels: every barrier there publishes LDS-DMA data, so the wave's own DMAs are waited for
+// EXPLICITLY in front of it.  hipcc 7.2 inserts that wait (s_waitcnt vmcnt(0)) itself when the DMA and the barrier share a basic
+// block or an iteration -- and does not when the DMAs were issued before a loop's back edge and the barrier stands at the loop's
+// header (round 6: the next row block's first DMAs issued before the epilogue; the barrier at the top of the block then had
+// lgkmcnt(0) only, and the variances of the bf16 kernels at C5 came out wrong now and then -- found by the full GPU suite, read
+// in the assembly).  The explicit wait costs nothing where the compiler's is already there.
+__device__ __forceinline__ void leaf_sync() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
 
 // ---- fp16 split ("f16x3"): x = h0 + h1 with fp16 pieces (11 significant bits each, round to nearest: |x - h0 - h1| <=
 // 2^-23 |x|), a product = h0 h0' + h0 h1' + h1 h0' on v_mfma_f32_16x16x32_f16 -- THREE matrix instructions instead of
@@ -73,6 +83,10 @@ __device__ __forceinline__ void glds4(const void* gsrc_lane, void* lds_wave_base
 #define GPSO_LEAF_STAGGER 0
 #endif
 constexpr bool kLeafStagger = GPSO_LEAF_STAGGER != 0;
+#ifndef GPSO_EARLY_DMA
+#define GPSO_EARLY_DMA 1
+#endif
+constexpr bool kEarlyDma = GPSO_EARLY_DMA != 0;  // the next row block's first DMAs issued before the epilogue (leaf_tiles_bf16_kernel)
 // The fused step on the 32x32x16 matrix instruction (leaf_split_m32.hpp; round 6): correct (errors against float64 equal to the
 // 16x16x32 step's), 4.9 % FEWER clocks per launch (GRBM_GUI_ACTIVE 1.056e7 against 1.111e7 at C3) -- and an 11 % LOWER clock
 // under it (1.80 against 2.02 GHz: MI355X_MICROARCH.md, DVFS give-back, item 7), so 6.6-7.1 % SLOWER at C3 / C4 / C5
@@ -922,7 +936,7 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
   // free there.  The second set of wave-uniform pointers spills 87 scalar registers into vector lanes inside the hot loop: C3
   // 0.7193 | 0.7221 ms against 0.7464 | 0.7304 without the prefetch, C4 / C5 +2.5 %.  r06_predict_experiments.txt.)
   for (int rbj = 0;; ++rbj) {
-  if (rbj > 0) {
+  if (!kEarlyDma && rbj > 0) {
     set_row_block(rbj);
     issue_block_start();
   }
@@ -939,7 +953,7 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
       for (int t = 0; t < CT; ++t) acc[rt][t] = f32x4{0, 0, 0, 0};
     macc[0] = macc[1] = 0.0f;
   }
-  __syncthreads();
+  leaf_sync();
 
   auto issue_for = [&](int k) {
     if (k + 1 < q_lim) issue_panel(k + 1, STAG ? (k + 1) % 3 : (k + 1) & 1);
@@ -981,26 +995,26 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
                                                                       xsl + ((q + 1) % 3) * xstride, xb, nb, cm, vc,  \
                                                                       bfrag, bnxt, acc, macc, fregs);                 \
       GPSO_BSTAMP(q, 2);                                                                                              \
-      if (late) __syncthreads(); /* waves 4-7 meet the barrier in the middle of their step */                         \
+      if (late) leaf_sync(); /* waves 4-7 meet the barrier in the middle of their step */                         \
       GPSO_BSTAMP(q, 3);                                                                                              \
       leaf_bf16_fused_half<NS, TG, KERNEL, F16, ASKIP, GMODE, C16, RTL, 1>(lane, dp4, panel + (q % 3) * NS * RT * 64, \
                                                                       xsl + ((q + 1) % 3) * xstride, xb, nb, cm, vc,  \
                                                                       bfrag, bnxt, acc, macc, fregs);                 \
       GPSO_BSTAMP(q, 4);                                                                                              \
-      if (!late) __syncthreads();                                                                                     \
+      if (!late) leaf_sync();                                                                                     \
     } else if constexpr (M32) {                                                                                       \
       leaf_fused_step32<KERNEL, ASKIP, GMODE, C16, RTL>(dp4, panel + (q & 1) * NS * RT * 64,                          \
                                                         xsl + ((q + 1) % 3) * xstride, xb, ml, nb32, (float)cm, vc,   \
                                                         bfrag32, bnxt32, acc32, macc32);                              \
       GPSO_BSTAMP(q, 4);                                                                                              \
-      __syncthreads();                                                                                                \
+      leaf_sync();                                                                                                \
     } else {                                                                                                          \
       leaf_bf16_fused_step<NS, TG, KERNEL, F16, ASKIP, GMODE, C16, RTL, XP>(q, q_diag0, lane, dp4,                    \
                                                                    panel + (q & 1) * NS * RT * 64,                    \
                                                                    xsl + ((q + 1) % 3) * xstride, xb, nb, cm, vc,     \
                                                                    bfrag, bnxt, acc, macc);                           \
       GPSO_BSTAMP(q, 4);                                                                                              \
-      __syncthreads();                                                                                                \
+      leaf_sync();                                                                                                \
     }                                                                                                                 \
     GPSO_BSTAMP(q, 5);                                                                                                \
     if (GMODE != 0) {                                                                                                 \
@@ -1052,27 +1066,32 @@ __global__ __launch_bounds__(512, 2) void leaf_tiles_bf16_kernel(
     GPSO_BSTAMP(q, 1);                                                                                                \
     leaf_bf16_gen<NS, TG, KERNEL, F16, DIAGF, C16, 2, XP>(lane, dp4, xsl + (q % 3) * xstride, xb, nb, cm, vc, bfrag, macc); \
     GPSO_BSTAMP(q, 2);                                                                                                \
-    if (ahead && q > 0) __syncthreads();                                                                              \
+    if (ahead && q > 0) leaf_sync();                                                                              \
     GPSO_BSTAMP(q, 3);                                                                                                \
     leaf_bf16_apply<NS, F16, DIAGF>(q, q_diag0, lane, panel + (q & 1) * NS * RT * 64, bfrag, acc);                    \
     GPSO_BSTAMP(q, 4);                                                                                                \
-    if (!ahead) __syncthreads();                                                                                      \
+    if (!ahead) leaf_sync();                                                                                      \
     GPSO_BSTAMP(q, 5);                                                                                                \
   }
   for (int q = 0; q < q_diag0; ++q) GPSO_BF16_STEP(false)
   for (int q = q_diag0; q < q_end; ++q) GPSO_BF16_STEP(true)
 #undef GPSO_BF16_STEP
-  if (ahead) __syncthreads();
+  if (ahead) leaf_sync();
 
   }
 
-  // (Measured and NOT kept: the next row block's first DMAs issued HERE, before the epilogue -- every wave is past the last step's
-  // barrier and the epilogue touches no LDS.  -0.2 ... -0.4 % at C3 / C4 / C5, bit-identical on 126 parity cases and 35 hashes --
-  // and the variance of the bf16x6 kernel at C5 (noise 1e-2) came out 0.018 sigma^2 off, every run, with nothing else changed
-  // (tests/test_gpu_parity.py::test_config_C5_one_gpu_share_at_size): an ordering this code relies on without stating it.
-  // Not found in the time left; the order of rounds 1-5 stays.  profiles/r06_predict_experiments.txt, section 10.)
+  // The next row block's first DMAs fly under this block's epilogue (conversions and f64 sums that touch no LDS): every wave is
+  // past the last step's barrier, so the buffers they land in are free (-0.2 ... -0.4 % at C3 / C4 / C5; GPSO_EARLY_DMA=0: at the
+  // top of the next block as in rounds 1-5).  The barrier that publishes them stands at the loop's header: leaf_sync() waits for
+  // them explicitly -- the compiler does not, across the back edge.  From here on bi, q_diag0, q_end, q_lim and has_next are the
+  // NEXT block's.
   const int bi_out = bi;
   const bool more = has_next;
+  if (kEarlyDma && more) {  // (workgroup-uniform)
+    if constexpr (STAG) leaf_sync();  // (waves 4-7 meet their last barrier in the middle of a step)
+    set_row_block(rbj + 1);
+    issue_block_start();
+  }
   // (fp16 split: undo the power-of-two scales of the two operands -- exact)
   double unscale2 = 1.0, unscale_m = 1.0;
   if constexpr (F16) {
