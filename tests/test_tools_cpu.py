@@ -70,3 +70,47 @@ def test_roofline_fit_prices_a_fit_against_the_arithmetic_that_ran():
     assert f64["peak"] == 78.6 and abs(f64["posterior"]["frac"] - 0.24) < 0.01
     for rec in (c5, c3, f64):
         assert all(rec[k]["frac"] < 1.0 for k in ("posterior", "nlml_grad", "append_k7") if k in rec)
+
+
+def test_dma_barrier_check_flags_a_barrier_behind_a_back_edge(tmp_path):
+    """tools/check_dma_barriers.py (round 6): a wave must not reach an s_barrier with LDS-DMAs of its own possibly in flight.  The
+    shape hipcc 7.2 produced for the split kernels -- DMAs issued at the END of a loop body, the publishing barrier at the loop's
+    HEADER with lgkmcnt(0) only -- is flagged; the same loop with the wait in front of the barrier is clean; a counted wait in
+    front of a raw barrier (a ring deeper than two) is reported with its count and accepted only by name."""
+    bad = """
+_Z3badv:
+\ts_mov_b32 s0, 0
+.LBB0_1:
+\ts_waitcnt lgkmcnt(0)
+\ts_barrier
+\tds_read_b128 v[0:3], v4
+\tglobal_load_lds_dwordx4 v[8:9], off
+\ts_cbranch_scc1 .LBB0_1
+\ts_endpgm
+.Lfunc_end0:
+"""
+    good = bad.replace("_Z3badv", "_Z4goodv").replace("s_waitcnt lgkmcnt(0)", "s_waitcnt vmcnt(0) lgkmcnt(0)").replace("LBB0", "LBB1").replace("end0", "end1")
+    ring = """
+_Z4ringv:
+.LBB2_1:
+\tglobal_load_lds_dwordx4 v[8:9], off
+\tglobal_load_lds_dwordx4 v[8:9], off offset:1024
+\ts_waitcnt vmcnt(2)
+\ts_barrier
+\ts_cbranch_scc1 .LBB2_1
+\ts_endpgm
+.Lfunc_end2:
+"""
+    p = tmp_path / "k.s"
+    p.write_text(bad + good + ring)
+    tool = os.path.join(ROOT, "tools", "check_dma_barriers.py")
+    r = subprocess.run([sys.executable, tool, str(p)], capture_output=True, text=True)
+    out = r.stdout.splitlines()
+    assert r.returncode == 1
+    assert any(l.startswith("PENDING") and "_Z3badv" in l and "1 of 1 barriers" in l for l in out), out
+    assert any(l.startswith("ok") and "_Z4goodv" in l for l in out), out
+    assert any(l.startswith("PENDING") and "_Z4ringv" in l and "up to 2 " in l for l in out), out
+    r = subprocess.run([sys.executable, tool, "--allow=ringv", str(p)], capture_output=True, text=True)
+    assert any(l.startswith("by design") and "_Z4ringv" in l for l in r.stdout.splitlines())
+    p.write_text(good + ring)
+    assert subprocess.run([sys.executable, tool, "--allow=ringv", str(p)], capture_output=True, text=True).returncode == 0
